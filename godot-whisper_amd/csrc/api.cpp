@@ -1,0 +1,392 @@
+// C ABI of libwhisper_mi355.so: the whisper.h subset (include/whisper_mi355.h) and the device-level
+// entry points (include/wmi_device.h).  Nothing throws across the boundary; errors are return codes
+// plus the process-global log callback, as in the reference (W/whisper.cpp:6601-6629).
+
+#include "wmi.h"
+#include "kernels.h"
+
+#include <chrono>
+#include <cmath>
+#include <cstdarg>
+#include <cstring>
+#include <fstream>
+
+namespace wmi {
+
+namespace {
+void default_log(ggml_log_level, const char * text, void *) { fputs(text, stderr); fflush(stderr); }
+ggml_log_callback g_log_cb = default_log;
+void * g_log_ud = nullptr;
+}
+
+void log_msg(ggml_log_level lvl, const char * fmt, ...) {
+    va_list ap, ap2;
+    va_start(ap, fmt);
+    va_copy(ap2, ap);
+    char buf[1024];
+    const int len = vsnprintf(buf, sizeof(buf), fmt, ap);
+    if (len < (int) sizeof(buf)) g_log_cb(lvl, buf, g_log_ud);
+    else { std::vector<char> big(len + 1); vsnprintf(big.data(), big.size(), fmt, ap2); g_log_cb(lvl, big.data(), g_log_ud); }
+    va_end(ap2);
+    va_end(ap);
+}
+
+bool hip_ok(hipError_t e, const char * what, const char * file, int line) {
+    if (e == hipSuccess) return true;
+    log_msg(GGML_LOG_LEVEL_ERROR, "HIP error %d (%s) at %s:%d: %s\n", (int) e, hipGetErrorString(e), file, line, what);
+    return false;
+}
+
+int64_t time_us() {
+    return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+static whisper_context * init_common(const void * buffer, size_t size, int device) {
+    const int64_t t0 = time_us();
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
+        // the product has no CPU path: fail loudly instead of silently degrading
+        WMI_ERR("whisper_mi355: no HIP device available - this backend requires an AMD GPU (gfx950)\n");
+        return nullptr;
+    }
+    if (device < 0 || device >= n_dev) { WMI_ERR("whisper_mi355: invalid device %d (have %d)\n", device, n_dev); return nullptr; }
+    whisper_context * ctx = new whisper_context();
+    ctx->device = device;
+    ctx->t_start_us = t0;
+    WMI_INFO("%s: loading model from buffer\n", __func__);
+    if (!parse_model((const uint8_t *) buffer, size, ctx->model)) { WMI_ERR("%s: failed to load model\n", __func__); delete ctx; return nullptr; }
+    if (!HIP_OK(hipSetDevice(device))) { delete ctx; return nullptr; }
+    if (!init_state(*ctx)) { free_state(*ctx); delete ctx; return nullptr; }
+    if (!upload_weights(ctx->model, (const uint8_t *) buffer, nullptr, ctx->w, ctx->state->dev.stream)) {
+        WMI_ERR("%s: failed to load model\n", __func__);
+        free_state(*ctx); free_weights(ctx->w); delete ctx; return nullptr;
+    }
+    ctx->t_load_us = time_us() - t0;
+    return ctx;
+}
+
+} // namespace wmi
+
+using namespace wmi;
+
+extern "C" {
+
+// ------------------------------------------------------------------ [host] entry points
+struct whisper_context * whisper_init_from_buffer_with_params(void * buffer, size_t buffer_size, struct whisper_context_params params) {
+    // params.use_gpu is honoured trivially: there is only a GPU path (the Godot setting defaults to true)
+    whisper_context * ctx = init_common(buffer, buffer_size, 0);
+    if (ctx) ctx->params = params;
+    return ctx;
+}
+
+void whisper_free(struct whisper_context * ctx) {
+    if (!ctx) return;
+    (void) hipSetDevice(ctx->device);
+    free_state(*ctx);
+    free_weights(ctx->w);
+    delete ctx;
+}
+
+const char * whisper_print_system_info(void) {
+    static std::string s;
+    int n_dev = 0; (void) hipGetDeviceCount(&n_dev);
+    hipDeviceProp_t p{};
+    std::string arch = "none", name = "none"; int cus = 0;
+    if (n_dev > 0 && hipGetDeviceProperties(&p, 0) == hipSuccess) { arch = p.gcnArchName; name = p.name; cus = p.multiProcessorCount; }
+    s = "HIP = 1 | DEVICES = " + std::to_string(n_dev) + " | ARCH = " + arch + " | CU = " + std::to_string(cus) +
+        " | NAME = " + name + " | MFMA_F16 = 1 | CPU_FALLBACK = 0 | ";
+    return s.c_str();
+}
+
+struct whisper_full_params whisper_full_default_params(enum whisper_sampling_strategy strategy) {   // W/whisper.cpp:4311-4410
+    struct whisper_full_params p;
+    memset(&p, 0, sizeof(p));
+    p.strategy = strategy;
+    p.n_threads = 4;  p.n_max_text_ctx = 16384;
+    p.no_context = true;  p.print_progress = true;  p.print_timestamps = true;
+    p.thold_pt = 0.01f;  p.thold_ptsum = 0.01f;
+    p.language = "en";
+    p.suppress_blank = true;
+    p.temperature = 0.0f;  p.max_initial_ts = 1.0f;  p.length_penalty = -1.0f;
+    p.temperature_inc = 0.2f;  p.entropy_thold = 2.4f;  p.logprob_thold = -1.0f;  p.no_speech_thold = 0.6f;
+    p.greedy.best_of = -1;  p.beam_search.beam_size = -1;  p.beam_search.patience = -1.0f;
+    p.grammar_penalty = 100.0f;
+    if (strategy == WHISPER_SAMPLING_GREEDY) p.greedy.best_of = 5;
+    else if (strategy == WHISPER_SAMPLING_BEAM_SEARCH) { p.beam_search.beam_size = 5; p.beam_search.patience = -1.0f; }
+    return p;
+}
+
+int whisper_full(struct whisper_context * ctx, struct whisper_full_params params, const float * samples, int n_samples) {
+    if (!ctx || !ctx->state) return -1;
+    (void) hipSetDevice(ctx->device);
+    return full(*ctx, params, samples, nullptr, n_samples);
+}
+
+int whisper_full_n_segments(struct whisper_context * ctx) { return (int) ctx->state->result_all.size(); }
+int whisper_full_n_tokens(struct whisper_context * ctx, int i) { return (int) ctx->state->result_all[i].tokens.size(); }
+const char * whisper_full_get_segment_text(struct whisper_context * ctx, int i) { return ctx->state->result_all[i].text.c_str(); }
+const char * whisper_full_get_token_text(struct whisper_context * ctx, int i, int j) {
+    return ctx->model.vocab.id_to_token[ctx->state->result_all[i].tokens[j].id].c_str();
+}
+whisper_token_data whisper_full_get_token_data(struct whisper_context * ctx, int i, int j) { return ctx->state->result_all[i].tokens[j]; }
+
+void whisper_log_set(ggml_log_callback cb, void * user_data) { g_log_cb = cb ? cb : default_log; g_log_ud = user_data; }
+
+// ------------------------------------------------------------------ rest of the whisper.h subset
+struct whisper_context_params whisper_context_default_params(void) { struct whisper_context_params p = { true }; return p; }
+
+struct whisper_context * whisper_init_from_file_with_params(const char * path, struct whisper_context_params params) {
+    WMI_INFO("%s: loading model from '%s'\n", __func__, path);
+    std::ifstream f(path, std::ios::binary | std::ios::ate);
+    if (!f) { WMI_ERR("%s: failed to open '%s'\n", __func__, path); return nullptr; }
+    const std::streamsize n = f.tellg();
+    f.seekg(0);
+    std::vector<char> buf((size_t) n);
+    if (!f.read(buf.data(), n)) { WMI_ERR("%s: failed to read '%s'\n", __func__, path); return nullptr; }
+    return whisper_init_from_buffer_with_params(buf.data(), buf.size(), params);
+}
+
+int whisper_pcm_to_mel(struct whisper_context * ctx, const float * samples, int n_samples, int) {
+    (void) hipSetDevice(ctx->device);
+    if (!pcm_to_mel(*ctx, samples, n_samples, false)) { WMI_ERR("%s: failed to compute mel spectrogram\n", __func__); return -1; }
+    return 0;
+}
+int whisper_set_mel(struct whisper_context * ctx, const float * data, int n_len, int n_mel) {
+    if (n_mel != ctx->model.n_filt_mel) { WMI_ERR("%s: invalid number of mel bands: %d (expected %d)\n", __func__, n_mel, ctx->model.n_filt_mel); return -1; }
+    (void) hipSetDevice(ctx->device);
+    return set_mel(*ctx, data, n_len, n_mel) ? 0 : -1;
+}
+int whisper_encode(struct whisper_context * ctx, int offset, int) {
+    (void) hipSetDevice(ctx->device);
+    if (!encode(*ctx, offset)) { WMI_ERR("%s: failed to eval\n", __func__); return -1; }
+    return 0;
+}
+int whisper_decode(struct whisper_context * ctx, const whisper_token * tokens, int n_tokens, int n_past, int) {
+    if (!ctx->state) { WMI_ERR("%s: ERROR state was not loaded.\n", __func__); return -1; }
+    (void) hipSetDevice(ctx->device);
+    State & st = *ctx->state;
+    st.batch.prep_legacy(tokens, n_tokens, n_past, 0);
+    kv_seq_rm(st.kv_self, 0, n_past, -1);
+    if (!decode(*ctx, st.batch)) { WMI_ERR("%s: failed to eval\n", __func__); return 1; }
+    return 0;
+}
+int whisper_tokenize(struct whisper_context * ctx, const char * text, whisper_token * tokens, int n_max_tokens) {
+    const auto res = tokenize(ctx->model.vocab, text);
+    if (n_max_tokens < (int) res.size()) { WMI_ERR("%s: too many resulting tokens: %d (max %d)\n", __func__, (int) res.size(), n_max_tokens); return -1; }
+    for (size_t i = 0; i < res.size(); ++i) tokens[i] = res[i];
+    return (int) res.size();
+}
+float * whisper_get_logits(struct whisper_context * ctx) { return ctx->state->logits.data(); }
+
+int whisper_lang_max_id(void) { return lang_max_id(); }
+int whisper_lang_id(const char * lang) { return lang_id(lang); }
+const char * whisper_lang_str(int id) { return lang_str(id); }
+int whisper_lang_auto_detect(struct whisper_context * ctx, int offset_ms, int, float * lang_probs) {
+    (void) hipSetDevice(ctx->device);
+    return lang_auto_detect(*ctx, offset_ms, lang_probs);
+}
+
+int whisper_n_len(struct whisper_context * ctx) { return ctx->state->mel.n_len_org; }
+int whisper_n_vocab(struct whisper_context * ctx) { return ctx->model.vocab.n_vocab; }
+int whisper_n_text_ctx(struct whisper_context * ctx) { return ctx->model.hp.n_text_ctx; }
+int whisper_n_audio_ctx(struct whisper_context * ctx) { return ctx->model.hp.n_audio_ctx; }
+int whisper_is_multilingual(struct whisper_context * ctx) { return ctx->model.vocab.is_multilingual() ? 1 : 0; }
+int whisper_model_n_vocab(struct whisper_context * ctx) { return ctx->model.hp.n_vocab; }
+int whisper_model_n_audio_ctx(struct whisper_context * ctx) { return ctx->model.hp.n_audio_ctx; }
+int whisper_model_n_audio_state(struct whisper_context * ctx) { return ctx->model.hp.n_audio_state; }
+int whisper_model_n_audio_head(struct whisper_context * ctx) { return ctx->model.hp.n_audio_head; }
+int whisper_model_n_audio_layer(struct whisper_context * ctx) { return ctx->model.hp.n_audio_layer; }
+int whisper_model_n_text_ctx(struct whisper_context * ctx) { return ctx->model.hp.n_text_ctx; }
+int whisper_model_n_text_state(struct whisper_context * ctx) { return ctx->model.hp.n_text_state; }
+int whisper_model_n_text_head(struct whisper_context * ctx) { return ctx->model.hp.n_text_head; }
+int whisper_model_n_text_layer(struct whisper_context * ctx) { return ctx->model.hp.n_text_layer; }
+int whisper_model_n_mels(struct whisper_context * ctx) { return ctx->model.hp.n_mels; }
+int whisper_model_ftype(struct whisper_context * ctx) { return ctx->model.hp.ftype; }
+int whisper_model_type(struct whisper_context * ctx) { return ctx->model.model_type; }
+const char * whisper_model_type_readable(struct whisper_context * ctx) {
+    static const char * names[] = { "unknown", "tiny", "base", "small", "medium", "large" };
+    const int t = ctx->model.model_type;
+    return names[t >= 0 && t <= 5 ? t : 0];
+}
+const char * whisper_token_to_str(struct whisper_context * ctx, whisper_token token) { return ctx->model.vocab.id_to_token.at(token).c_str(); }
+whisper_token whisper_token_eot(struct whisper_context * ctx) { return ctx->model.vocab.eot; }
+whisper_token whisper_token_sot(struct whisper_context * ctx) { return ctx->model.vocab.sot; }
+whisper_token whisper_token_solm(struct whisper_context * ctx) { return ctx->model.vocab.solm; }
+whisper_token whisper_token_prev(struct whisper_context * ctx) { return ctx->model.vocab.prev; }
+whisper_token whisper_token_nosp(struct whisper_context * ctx) { return ctx->model.vocab.nosp; }
+whisper_token whisper_token_not(struct whisper_context * ctx) { return ctx->model.vocab.not_; }
+whisper_token whisper_token_beg(struct whisper_context * ctx) { return ctx->model.vocab.beg; }
+whisper_token whisper_token_lang(struct whisper_context * ctx, int lang_id) { return ctx->model.vocab.sot + 1 + lang_id; }
+whisper_token whisper_token_translate(struct whisper_context * ctx) { return ctx->model.vocab.translate; }
+whisper_token whisper_token_transcribe(struct whisper_context * ctx) { return ctx->model.vocab.transcribe; }
+int whisper_full_lang_id(struct whisper_context * ctx) { return ctx->state->lang_id; }
+int64_t whisper_full_get_segment_t0(struct whisper_context * ctx, int i) { return ctx->state->result_all[i].t0; }
+int64_t whisper_full_get_segment_t1(struct whisper_context * ctx, int i) { return ctx->state->result_all[i].t1; }
+whisper_token whisper_full_get_token_id(struct whisper_context * ctx, int i, int j) { return ctx->state->result_all[i].tokens[j].id; }
+float whisper_full_get_token_p(struct whisper_context * ctx, int i, int j) { return ctx->state->result_all[i].tokens[j].p; }
+
+void whisper_print_timings(struct whisper_context * ctx) {
+    const int64_t t_end = time_us();
+    WMI_INFO("\n");
+    WMI_INFO("%s:     load time = %8.2f ms\n", __func__, ctx->t_load_us / 1000.0f);
+    if (ctx->state) {
+        const State & s = *ctx->state;
+        const int n_sample = std::max(1, s.n_sample), n_encode = std::max(1, s.n_encode), n_decode = std::max(1, s.n_decode),
+                  n_batchd = std::max(1, s.n_batchd), n_prompt = std::max(1, s.n_prompt);
+        WMI_INFO("%s:     fallbacks = %3d p / %3d h\n", __func__, s.n_fail_p, s.n_fail_h);
+        WMI_INFO("%s:      mel time = %8.2f ms\n", __func__, s.t_mel_us / 1000.0f);
+        WMI_INFO("%s:   sample time = %8.2f ms / %5d runs (%8.2f ms per run)\n", __func__, 1e-3f * s.t_sample_us, n_sample, 1e-3f * s.t_sample_us / n_sample);
+        WMI_INFO("%s:   encode time = %8.2f ms / %5d runs (%8.2f ms per run)\n", __func__, 1e-3f * s.t_encode_us, n_encode, 1e-3f * s.t_encode_us / n_encode);
+        WMI_INFO("%s:   decode time = %8.2f ms / %5d runs (%8.2f ms per run)\n", __func__, 1e-3f * s.t_decode_us, n_decode, 1e-3f * s.t_decode_us / n_decode);
+        WMI_INFO("%s:   batchd time = %8.2f ms / %5d runs (%8.2f ms per run)\n", __func__, 1e-3f * s.t_batchd_us, n_batchd, 1e-3f * s.t_batchd_us / n_batchd);
+        WMI_INFO("%s:   prompt time = %8.2f ms / %5d runs (%8.2f ms per run)\n", __func__, 1e-3f * s.t_prompt_us, n_prompt, 1e-3f * s.t_prompt_us / n_prompt);
+    }
+    WMI_INFO("%s:    total time = %8.2f ms\n", __func__, (t_end - ctx->t_start_us) / 1000.0f);
+}
+void whisper_reset_timings(struct whisper_context * ctx) {
+    ctx->t_start_us = time_us();
+    if (!ctx->state) return;
+    State & s = *ctx->state;
+    s.t_mel_us = s.t_sample_us = s.t_encode_us = s.t_decode_us = s.t_batchd_us = s.t_prompt_us = 0;
+    s.n_sample = s.n_encode = s.n_decode = s.n_batchd = s.n_prompt = 0;
+}
+
+// ------------------------------------------------------------------ device-level ABI (include/wmi_device.h)
+int wmi_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess ? n : 0; }
+const char * wmi_version(void) { return "whisper_mi355 0.1 (gfx950, whisper.cpp v1.5.4 ABI)"; }
+
+struct whisper_context * wmi_init_from_buffer_on_device(const void * buffer, size_t buffer_size, int device) {
+    whisper_context * ctx = init_common(buffer, buffer_size, device);
+    if (ctx) ctx->params.use_gpu = true;
+    return ctx;
+}
+
+int wmi_pcm_to_mel_device(struct whisper_context * ctx, const float * d_samples, int n_samples) {
+    (void) hipSetDevice(ctx->device);
+    return pcm_to_mel(*ctx, d_samples, n_samples, true) ? 0 : -1;
+}
+
+int wmi_full_device_pcm(struct whisper_context * ctx, struct whisper_full_params params, const float * d_samples, int n_samples,
+                        const float * h_samples) {
+    if (!ctx || !ctx->state) return -1;
+    (void) hipSetDevice(ctx->device);
+    return full(*ctx, params, h_samples, d_samples, n_samples);
+}
+
+int wmi_mel_dims(struct whisper_context * ctx, int * n_len, int * n_len_org, int * n_mel) {
+    const Mel & m = ctx->state->mel;
+    if (n_len) *n_len = m.n_len; if (n_len_org) *n_len_org = m.n_len_org; if (n_mel) *n_mel = m.n_mel;
+    return m.n_len * m.n_mel;
+}
+
+int wmi_get_tensor(struct whisper_context * ctx, const char * name, float * dst, int n) {
+    (void) hipSetDevice(ctx->device);
+    State & st = *ctx->state; DeviceState & d = st.dev; const HParams & hp = ctx->model.hp;
+    const int S = hp.n_audio_state, T = st.enc_n_ctx > 0 ? st.enc_n_ctx : hp.n_audio_ctx, Lt = hp.n_text_layer;
+    const void * src = nullptr; size_t count = 0; bool is_half = false;
+    const std::string nm(name);
+    if (nm == "mel")            { src = d.mel; count = (size_t) st.mel.n_len * st.mel.n_mel; }
+    else if (nm == "embd_conv") { src = d.embd_conv; count = (size_t) T * S; }
+    else if (nm == "embd_enc")  { src = d.enc_out; count = (size_t) T * S; }
+    else if (nm == "enc_x")     { src = d.x; count = (size_t) T * S; }
+    else if (nm == "cross_k")   { src = d.kvc_k; count = (size_t) Lt * T * S; is_half = true; }
+    else if (nm == "cross_v")   { src = d.kvc_v; count = (size_t) Lt * T * S; is_half = true; }
+    else if (nm == "self_k")    { src = st.kv_self.k; count = (size_t) Lt * st.kv_self.size * S; is_half = true; }
+    else if (nm == "self_v")    { src = st.kv_self.v; count = (size_t) Lt * st.kv_self.size * S; is_half = true; }
+    else return -1;
+    if (!dst) return (int) count;
+    if (!src) return -1;
+    if ((size_t) n > count) n = (int) count;
+    if (!HIP_OK(hipStreamSynchronize(d.stream))) return -1;
+    if (!is_half) { if (!HIP_OK(hipMemcpy(dst, src, (size_t) n * 4, hipMemcpyDeviceToHost))) return -1; }
+    else {
+        std::vector<__half> tmp(n);
+        if (!HIP_OK(hipMemcpy(tmp.data(), src, (size_t) n * 2, hipMemcpyDeviceToHost))) return -1;
+        for (int i = 0; i < n; ++i) dst[i] = __half2float(tmp[i]);
+    }
+    return n;
+}
+
+void wmi_get_timings(struct whisper_context * ctx, int64_t * t6, int32_t * n5) {
+    const State & s = *ctx->state;
+    t6[0] = s.t_mel_us; t6[1] = s.t_encode_us; t6[2] = s.t_decode_us; t6[3] = s.t_batchd_us; t6[4] = s.t_prompt_us; t6[5] = s.t_sample_us;
+    n5[0] = s.n_encode; n5[1] = s.n_decode; n5[2] = s.n_batchd; n5[3] = s.n_prompt; n5[4] = s.n_sample;
+}
+
+void * wmi_stream(struct whisper_context * ctx) { return (void *) ctx->state->dev.stream; }
+
+int wmi_process_logits(struct whisper_context * ctx, struct whisper_full_params params, const float * raw_logits,
+                       const whisper_token * hist, int n_hist, int has_ts, int seek_delta, float temperature,
+                       float * out_logits, float * out_logprobs, float * out_probs) {
+    State & st = *ctx->state;
+    Decoder & d = st.decoders[0];
+    const int nv = ctx->model.vocab.n_vocab;
+    st.logits.assign(raw_logits, raw_logits + nv);
+    d.i_batch = 0;
+    d.sequence.tokens.clear();
+    for (int i = 0; i < n_hist; ++i) d.sequence.tokens.push_back(whisper_token_data{ hist[i], 0, 0.f, 0.f, 0.f, 0.f, -1, -1, 0.f });
+    d.has_ts = has_ts != 0; d.seek_delta = seek_delta;
+    process_logits(*ctx, d, params, temperature);
+    memcpy(out_logits, d.logits.data(), (size_t) nv * 4);
+    memcpy(out_logprobs, d.logprobs.data(), (size_t) nv * 4);
+    memcpy(out_probs, d.probs.data(), (size_t) nv * 4);
+    return nv;
+}
+
+int wmi_sample_draws(struct whisper_context * ctx, const float * probs, const float * logprobs, int n_draw, int reseed,
+                     whisper_token_data * out) {
+    Decoder & d = ctx->state->decoders[0];
+    const int nv = ctx->model.vocab.n_vocab;
+    d.probs.assign(probs, probs + nv); d.logprobs.assign(logprobs, logprobs + nv);
+    if (reseed) d.rng = std::mt19937(0);
+    for (int i = 0; i < n_draw; ++i) out[i] = sample_token(*ctx, d, false);
+    return n_draw;
+}
+
+double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters) {
+    (void) hipSetDevice(ctx->device);
+    State & st = *ctx->state; DeviceState & d = st.dev; const HParams & hp = ctx->model.hp; const Weights & w = ctx->w;
+    const int S = hp.n_audio_state, T = hp.n_audio_ctx, H = hp.n_audio_head;
+    hipStream_t s = d.stream;
+    hipEvent_t e0, e1;
+    if (!HIP_OK(hipEventCreate(&e0)) || !HIP_OK(hipEventCreate(&e1))) return -1.0;
+    auto once = [&]() {
+        switch (which) {
+            case 0: {
+                k::GemmArgs a{};
+                a.A = d.xn; a.lda = S; a.W = w.enc[0].w_fc1; a.ldw = S; a.M = T; a.N = 4 * S; a.K = S; a.bias = w.enc[0].b_fc1;
+                a.C = d.h; a.ldc = 4 * S;
+                k::gemm(k::EPI_F16_BIAS_GELU, a, s);
+            } break;
+            case 1: {
+                k::GemvArgs g{};
+                g.x32 = d.dx; g.ln_g = w.d_ln_g; g.ln_b = w.d_ln_b; g.eps = hp.eps; g.n = 1; g.K = S; g.N = hp.n_vocab; g.W = w.d_te;
+                g.epi = k::EPI_LOGITS; g.C = d.logits; g.ldc = hp.n_vocab; g.rows = nullptr;
+                k::gemv(g, s);
+            } break;
+            case 2: k::attn_encoder(d.q, d.k, d.vt, T, d.Tpad, S, H, 0.125f, d.att, s); break;
+            default: break;
+        }
+    };
+    if (which == 3) {
+        if (d.mel == nullptr) return -1.0;
+        const int saved = st.exp_n_audio_ctx;
+        encode(*ctx, 0);                                            // warm-up (includes a sync)
+        const int64_t t0 = time_us();
+        for (int i = 0; i < iters; ++i) encode(*ctx, 0);
+        st.exp_n_audio_ctx = saved;
+        (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+        return (double) (time_us() - t0) / iters;
+    }
+    once();
+    (void) hipEventRecord(e0, s);
+    for (int i = 0; i < iters; ++i) once();
+    (void) hipEventRecord(e1, s);
+    (void) hipEventSynchronize(e1);
+    float ms = 0.0f;
+    (void) hipEventElapsedTime(&ms, e0, e1);
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    return (double) ms * 1000.0 / iters;
+}
+
+} // extern "C"

@@ -1,0 +1,307 @@
+// Device-side orchestration of the hot path: state arenas, PCM -> mel, encoder, decoder step
+// (reference seam: log_mel_spectrogram W/whisper.cpp:2793,
+// whisper_encode_internal :2086, whisper_decode_internal :2517).
+//
+// HBM layout of one context (base.en figures):
+//   weights arena  148 MB   one allocation, f16 matrices K-contiguous, f32 vectors
+//   self KV        16.5 MB  k,v [L][3*n_text_ctx][S] f16       (same capacity as the reference)
+//   cross KV       18.4 MB  k,v [L][T][S] f16 (V is NOT transposed here; see attn_decoder)
+//   encoder work   ~16 MB   token-major activations, f32 residual + f16 GEMM operands
+// Every buffer is allocated once in init_state and reused; nothing is allocated on the hot path
+// except when a longer PCM / mel than ever seen before arrives (grow-only).
+
+#include "wmi.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace wmi {
+
+namespace {
+
+template <typename T> bool dalloc(T *& p, size_t n_elems) {
+    p = nullptr;
+    return HIP_OK(hipMalloc((void **) &p, std::max<size_t>(n_elems, 1) * sizeof(T)));
+}
+template <typename T> void dfree(T *& p) { if (p) (void) hipFree(p); p = nullptr; }
+
+} // namespace
+
+bool init_state(whisper_context & ctx) {
+    const HParams & hp = ctx.model.hp;
+    State * st = new State();
+    ctx.state = st;
+    DeviceState & d = st->dev;
+    if (!HIP_OK(hipSetDevice(ctx.device))) return false;
+    HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+
+    const size_t S = hp.n_audio_state, T = hp.n_audio_ctx, Lt = hp.n_text_layer, H = hp.n_audio_head;
+    const size_t n_self = 3 * (size_t) hp.n_text_ctx;                         // W/whisper.cpp:3009 (factor 3)
+    st->kv_self.size = (uint32_t) n_self; st->kv_self.cells.assign(n_self, KVCell());
+    bool ok = true;
+    ok = ok && dalloc(st->kv_self.k, Lt * n_self * S) && dalloc(st->kv_self.v, Lt * n_self * S);
+    ok = ok && dalloc(d.kvc_k, Lt * T * S) && dalloc(d.kvc_v, Lt * T * S);
+    d.Tpad = (int) ((T + 63) / 64 * 64);
+    const size_t mel_rows = 2 * T + 8;
+    ok = ok && dalloc(d.mel_t, mel_rows * hp.n_mels + 1024) && dalloc(d.conv1, (2 * T + 4) * S)
+            && dalloc(d.x, T * S) && dalloc(d.embd_conv, T * S) && dalloc(d.xn, T * S)
+            && dalloc(d.q, T * S) && dalloc(d.k, T * S) && dalloc(d.vt, S * d.Tpad) && dalloc(d.att, T * S)
+            && dalloc(d.h, T * 4 * S) && dalloc(d.rowmax, H * T) && dalloc(d.enc_out, T * S) && dalloc(d.enc_out_h, T * S)
+            && dalloc(d.mel_max, 4);
+    const size_t n = hp.n_text_ctx;
+    d.logits_rows_cap = 8;
+    ok = ok && dalloc(d.d_tokens, n) && dalloc(d.d_pos, n) && dalloc(d.d_mask, n * n_self) && dalloc(d.d_rows, n)
+            && dalloc(d.dx, n * S) && dalloc(d.dxn, n * S) && dalloc(d.dq, n * S) && dalloc(d.datt, n * S)
+            && dalloc(d.dh, n * 4 * S) && dalloc(d.logits, (size_t) d.logits_rows_cap * hp.n_vocab);
+    d.pinned_bytes = std::max<size_t>((size_t) d.logits_rows_cap * hp.n_vocab * 4, n * n_self * 4 + 3 * n * 4 + 4096);
+    ok = ok && HIP_OK(hipHostMalloc(&d.pinned, d.pinned_bytes, hipHostMallocDefault));
+    if (!ok) { WMI_ERR("%s: device allocation failed\n", __func__); return false; }
+    // buffers that are read before being fully written must hold finite values
+    k::fill_zero(d.vt, S * d.Tpad * sizeof(__half), d.stream);
+    k::fill_zero(d.conv1, (2 * T + 4) * S * sizeof(__half), d.stream);
+    k::fill_zero(d.mel_t, (mel_rows * hp.n_mels + 1024) * sizeof(__half), d.stream);
+    k::fill_zero(st->kv_self.k, Lt * n_self * S * sizeof(__half), d.stream);
+    k::fill_zero(st->kv_self.v, Lt * n_self * S * sizeof(__half), d.stream);
+    k::fill_zero(d.kvc_k, Lt * T * S * sizeof(__half), d.stream);
+    k::fill_zero(d.kvc_v, Lt * T * S * sizeof(__half), d.stream);
+    HIP_TRY(hipStreamSynchronize(d.stream));
+
+    st->batch.token.resize(n); st->batch.pos.resize(n); st->batch.seq_id.resize(n); st->batch.logits.resize(n);
+    st->logits.reserve((size_t) hp.n_vocab * 8);
+    for (auto & dec : st->decoders) dec.rng = std::mt19937(0);
+    WMI_INFO("%s: kv self size = %.2f MB, kv cross size = %.2f MB\n", __func__,
+             2.0 * Lt * n_self * S * 2 / 1e6, 2.0 * Lt * T * S * 2 / 1e6);
+    return true;
+}
+
+void free_state(whisper_context & ctx) {
+    State * st = ctx.state;
+    if (!st) return;
+    DeviceState & d = st->dev;
+    if (d.stream) (void) hipStreamSynchronize(d.stream);
+    dfree(st->kv_self.k); dfree(st->kv_self.v); dfree(d.kvc_k); dfree(d.kvc_v);
+    dfree(d.pcm); dfree(d.mel); dfree(d.mel_max); dfree(d.mel_t); dfree(d.conv1); dfree(d.x); dfree(d.embd_conv);
+    dfree(d.xn); dfree(d.q); dfree(d.k); dfree(d.vt); dfree(d.att); dfree(d.h); dfree(d.rowmax); dfree(d.enc_out);
+    dfree(d.enc_out_h); dfree(d.d_tokens); dfree(d.d_pos); dfree(d.d_mask); dfree(d.d_rows); dfree(d.dx); dfree(d.dxn);
+    dfree(d.dq); dfree(d.datt); dfree(d.dh); dfree(d.logits);
+    if (d.pinned) (void) hipHostFree(d.pinned);
+    if (d.stream) (void) hipStreamDestroy(d.stream);
+    delete st;
+    ctx.state = nullptr;
+}
+
+// ------------------------------------------------------------------------------------------------ mel
+static bool ensure_mel_capacity(DeviceState & d, size_t n_pad, size_t n_mel_elems) {
+    if (n_pad > d.pcm_cap) { dfree(d.pcm); if (!dalloc(d.pcm, n_pad + 1024)) return false; d.pcm_cap = n_pad + 1024; }
+    if (n_mel_elems > d.mel_cap) { dfree(d.mel); if (!dalloc(d.mel, n_mel_elems)) return false; d.mel_cap = n_mel_elems; }
+    return true;
+}
+
+bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, bool samples_on_device) {
+    State & st = *ctx.state; DeviceState & d = st.dev;
+    const int64_t t0 = time_us();
+    const int n_mel = ctx.model.n_filt_mel;
+    // Appendix G: padded = [200 reflect | n | 480000 + 200 zeros]
+    const int64_t n_pad = (int64_t) n_samples + 480000 + 400;
+    const int n_len = (int) ((n_pad - 400) / 160);
+    const int n_len_org = 1 + (n_samples + 200 - 400) / 160;
+    const int n_valid = n_samples + 200;
+    const int n_fft_frames = std::min(n_valid / 160 + 1, n_len);
+    if (!ensure_mel_capacity(d, (size_t) n_pad + (size_t) n_samples, (size_t) n_mel * n_len)) return false;
+    const float * src = samples;
+    if (!samples_on_device) {                      // stage the borrowed host PCM behind the padded image
+        float * stage = d.pcm + n_pad;
+        HIP_TRY(hipMemcpyAsync(stage, samples, (size_t) n_samples * 4, hipMemcpyHostToDevice, d.stream));
+        src = stage;
+    }
+    k::mel_pad(src, n_samples, d.pcm, (int) n_pad, d.stream);
+    k::mel_frames(d.pcm, n_valid, n_fft_frames, n_len, n_mel, ctx.w.mel_filters, d.mel, (int *) d.mel_max, d.stream);
+    k::mel_normalize(d.mel, n_mel * n_len, (const int *) d.mel_max, d.stream);
+    HIP_TRY(hipStreamSynchronize(d.stream));
+    st.mel.n_len = n_len; st.mel.n_len_org = n_len_org; st.mel.n_mel = n_mel;
+    st.t_mel_us += time_us() - t0;
+    return true;
+}
+
+bool set_mel(whisper_context & ctx, const float * data, int n_len, int n_mel) {
+    State & st = *ctx.state; DeviceState & d = st.dev;
+    if (!ensure_mel_capacity(d, 0, (size_t) n_len * n_mel)) return false;
+    HIP_TRY(hipMemcpyAsync(d.mel, data, (size_t) n_len * n_mel * 4, hipMemcpyHostToDevice, d.stream));
+    HIP_TRY(hipStreamSynchronize(d.stream));
+    st.mel.n_len = n_len; st.mel.n_len_org = n_len; st.mel.n_mel = n_mel;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ encoder
+bool encode(whisper_context & ctx, int mel_offset) {
+    State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
+    const int64_t t0 = time_us();
+    const int T = st.exp_n_audio_ctx > 0 ? st.exp_n_audio_ctx : hp.n_audio_ctx;
+    const int S = hp.n_audio_state, H = hp.n_audio_head, La = hp.n_audio_layer, Lt = hp.n_text_layer, nm = hp.n_mels;
+    hipStream_t s = d.stream;
+    if (st.mel.n_mel != nm || d.mel == nullptr) { WMI_ERR("%s: no mel spectrogram (n_mel %d, expected %d)\n", __func__, st.mel.n_mel, nm); return false; }
+
+    // conv front-end (row a2): two implicit GEMMs over token-major buffers with a zero row on each side
+    const int rows_mel = 2 * T + 6;
+    k::mel_slice(d.mel, st.mel.n_len, nm, mel_offset, 2 * T, d.mel_t, nm, rows_mel, s);
+    {
+        k::GemmArgs a{};
+        a.A = d.mel_t; a.lda = nm; a.W = w.conv1_w; a.ldw = w.conv1_k; a.M = 2 * T; a.N = S; a.K = w.conv1_k;
+        a.bias = w.conv1_b; a.C = d.conv1 + S; a.ldc = S;                       // rows 1..2T ; rows 0 and 2T+1 stay zero
+        k::gemm(k::EPI_F16_BIAS_GELU, a, s);
+    }
+    k::fill_zero(d.conv1 + (size_t) (2 * T + 1) * S, (size_t) S * sizeof(__half), s);   // stale row when audio_ctx shrank
+    {
+        k::GemmArgs a{};
+        a.A = d.conv1; a.lda = 2 * S; a.W = w.conv2_w; a.ldw = w.conv2_k; a.M = T; a.N = S; a.K = w.conv2_k;
+        a.bias = w.conv2_b; a.C = d.x; a.ldc = S; a.resid = w.e_pe; a.ldr = S; a.aux = d.embd_conv; a.ldaux = S;
+        k::gemm(k::EPI_CONV2, a, s);
+    }
+    // encoder blocks (row a3)
+    const float kq_scale = 1.0f / sqrtf((float) S / H);
+    for (int il = 0; il < La; ++il) {
+        const EncLayerW & l = w.enc[il];
+        k::layernorm(d.x, T, S, l.ln1_g, l.ln1_b, hp.eps, d.xn, nullptr, s);
+        {
+            k::GemmArgs a{};
+            a.A = d.xn; a.lda = S; a.W = l.w_qkv; a.ldw = S; a.M = T; a.N = 3 * S; a.K = S; a.bias = l.b_qkv;
+            a.C = d.q; a.ldc = S; a.aux = d.k; a.ldaux = S; a.aux2 = d.vt; a.ldaux2 = d.Tpad; a.S = S;
+            k::gemm(k::EPI_QKV_ENC, a, s);
+        }
+        k::attn_encoder(d.q, d.k, d.vt, T, d.Tpad, S, H, kq_scale, d.att, s);
+        {
+            k::GemmArgs a{};
+            a.A = d.att; a.lda = S; a.W = l.w_o; a.ldw = S; a.M = T; a.N = S; a.K = S; a.bias = l.b_o;
+            a.C = d.x; a.ldc = S; a.resid = d.x; a.ldr = S;
+            k::gemm(k::EPI_F32_BIAS_RESID, a, s);
+        }
+        k::layernorm(d.x, T, S, l.ln2_g, l.ln2_b, hp.eps, d.xn, nullptr, s);
+        {
+            k::GemmArgs a{};
+            a.A = d.xn; a.lda = S; a.W = l.w_fc1; a.ldw = S; a.M = T; a.N = 4 * S; a.K = S; a.bias = l.b_fc1;
+            a.C = d.h; a.ldc = 4 * S;
+            k::gemm(k::EPI_F16_BIAS_GELU, a, s);
+        }
+        {
+            k::GemmArgs a{};
+            a.A = d.h; a.lda = 4 * S; a.W = l.w_fc2; a.ldw = 4 * S; a.M = T; a.N = S; a.K = 4 * S; a.bias = l.b_fc2;
+            a.C = d.x; a.ldc = S; a.resid = d.x; a.ldr = S;
+            k::gemm(k::EPI_F32_BIAS_RESID, a, s);
+        }
+    }
+    k::layernorm(d.x, T, S, w.e_ln_g, w.e_ln_b, hp.eps, d.enc_out_h, d.enc_out, s);
+    // cross-attention K/V of every decoder layer in one GEMM (row a4): N = L * 2S
+    {
+        k::GemmArgs a{};
+        a.A = d.enc_out_h; a.lda = S; a.W = w.w_ckv; a.ldw = S; a.M = T; a.N = Lt * 2 * S; a.K = S; a.bias = w.b_ckv;
+        a.C = d.kvc_k; a.ldc = S; a.aux = d.kvc_v; a.ldaux = S; a.S = S; a.layer_stride = (int64_t) T * S;
+        a.scale = powf((float) S / H, -0.25f);
+        k::gemm(k::EPI_CROSS_KV, a, s);
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    if (!HIP_OK(hipGetLastError())) return false;
+    st.enc_n_ctx = T;
+    st.t_encode_us += time_us() - t0;
+    st.n_encode++;
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------------ decoder
+bool decode(whisper_context & ctx, const Batch & batch) {
+    State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
+    const int64_t t0 = time_us();
+    KVCache & kv = st.kv_self;
+    const int n = batch.n_tokens;
+    if (n <= 0) return false;
+    if (!kv_find_slot(kv, batch)) return false;                   // W/whisper.cpp:2540
+    kv.n = (uint32_t) kv_cell_max(kv);
+    const int n_kv = (int) kv.n, kv_head = (int) kv.head, n_ctx = (int) kv.size;
+    const int S = hp.n_text_state, H = hp.n_text_head, Lt = hp.n_text_layer, NV = hp.n_vocab;
+    const int Tc = st.enc_n_ctx > 0 ? st.enc_n_ctx : (st.exp_n_audio_ctx > 0 ? st.exp_n_audio_ctx : hp.n_audio_ctx);
+    hipStream_t s = d.stream;
+
+    // host -> pinned -> device: tokens, positions, mask (W/whisper.cpp:2186-2226), rows wanting logits
+    int32_t * p_tok = (int32_t *) d.pinned, * p_pos = p_tok + n, * p_rows = p_pos + n;
+    float * p_mask = (float *) (p_rows + n);
+    std::vector<int> rows;
+    for (int i = 0; i < n; ++i) { p_tok[i] = batch.token[i]; p_pos[i] = batch.pos[i]; if (batch.logits[i]) rows.push_back(i); }
+    for (size_t i = 0; i < rows.size(); ++i) p_rows[i] = rows[i];
+    for (int j = 0; j < n; ++j) {
+        const int32_t pos = batch.pos[j], seq = batch.seq_id[j];
+        for (int i = 0; i < n_kv; ++i)
+            p_mask[(size_t) j * n_kv + i] = (!kv.cells[i].has(seq) || kv.cells[i].pos > pos) ? -INFINITY : 0.0f;
+    }
+    HIP_TRY(hipMemcpyAsync(d.d_tokens, p_tok, (size_t) n * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d.d_pos, p_pos, (size_t) n * 4, hipMemcpyHostToDevice, s));
+    if (!rows.empty()) HIP_TRY(hipMemcpyAsync(d.d_rows, p_rows, rows.size() * 4, hipMemcpyHostToDevice, s));
+    HIP_TRY(hipMemcpyAsync(d.d_mask, p_mask, (size_t) n * n_kv * 4, hipMemcpyHostToDevice, s));
+
+    k::dec_embed(d.d_tokens, d.d_pos, n, S, w.d_te, w.d_pe, d.dx, s);
+    const float kq_scale = powf((float) S / H, -0.25f);
+    const bool skinny = n <= 8;
+
+    // generic projection: y = W . LN?(x) with a fused epilogue, through the weight-streaming kernel
+    // (n <= 8) or the MFMA GEMM (prompt / initial_prompt batches)
+    auto proj = [&](int epi, const float * ln_g, const float * ln_b, const __half * a16, int K, int N, const __half * W,
+                    const float * bias, void * C, int ldc, const float * resid, void * aux, int ldaux, void * aux2,
+                    int ldaux2, float scale) {
+        if (skinny) {
+            k::GemvArgs g{};
+            g.x32 = d.dx; g.ln_g = ln_g; g.ln_b = ln_b; g.eps = hp.eps; g.a16 = a16; g.n = n; g.K = K; g.N = N; g.W = W;
+            g.bias = bias; g.epi = epi; g.C = C; g.ldc = ldc; g.resid = resid; g.ldr = S; g.aux = aux; g.ldaux = ldaux;
+            g.aux2 = aux2; g.ldaux2 = ldaux2; g.scale = scale; g.S = S; g.rows = nullptr;
+            k::gemv(g, s);
+        } else {
+            const __half * A = a16;
+            if (ln_g) { k::layernorm(d.dx, n, S, ln_g, ln_b, hp.eps, d.dxn, nullptr, s); A = d.dxn; }
+            k::GemmArgs a{};
+            a.A = A; a.lda = K; a.W = W; a.ldw = K; a.M = n; a.N = N; a.K = K; a.bias = bias; a.C = C; a.ldc = ldc;
+            a.resid = resid; a.ldr = S; a.aux = aux; a.ldaux = ldaux; a.aux2 = aux2; a.ldaux2 = ldaux2; a.scale = scale; a.S = S;
+            k::gemm(epi, a, s);
+        }
+    };
+
+    for (int il = 0; il < Lt; ++il) {
+        const DecLayerW & l = w.dec[il];
+        __half * ck = kv.k + ((size_t) il * n_ctx) * S, * cv = kv.v + ((size_t) il * n_ctx) * S;
+        // self-attention: q | k -> cache | v -> cache  (W/whisper.cpp:2248-2290)
+        proj(k::EPI_QKV_DEC, l.ln1_g, l.ln1_b, nullptr, S, 3 * S, l.w_qkv, l.b_qkv, d.dq, S, nullptr,
+             ck + (size_t) kv_head * S, S, cv + (size_t) kv_head * S, S, kq_scale);
+        k::attn_decoder(d.dq, n, S, H, ck, cv, n_kv, d.d_mask, n_kv, d.datt, s);
+        proj(k::EPI_F32_BIAS_RESID, nullptr, nullptr, d.datt, S, S, l.w_o, l.b_o, d.dx, S, d.dx, nullptr, 0, nullptr, 0, 0.f);
+        // cross-attention against the encoder K/V of this layer, no mask (W/whisper.cpp:2359-2433)
+        proj(k::EPI_Q_SCALED, l.ln2_g, l.ln2_b, nullptr, S, S, l.w_cq, l.b_cq, d.dq, S, nullptr, nullptr, 0, nullptr, 0, kq_scale);
+        k::attn_decoder(d.dq, n, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, nullptr, 0, d.datt, s);
+        proj(k::EPI_F32_BIAS_RESID, nullptr, nullptr, d.datt, S, S, l.w_co, l.b_co, d.dx, S, d.dx, nullptr, 0, nullptr, 0, 0.f);
+        // MLP
+        proj(k::EPI_F16_BIAS_GELU, l.ln3_g, l.ln3_b, nullptr, S, 4 * S, l.w_fc1, l.b_fc1, d.dh, 4 * S, nullptr, nullptr, 0, nullptr, 0, 0.f);
+        proj(k::EPI_F32_BIAS_RESID, nullptr, nullptr, d.dh, 4 * S, S, l.w_fc2, l.b_fc2, d.dx, S, d.dx, nullptr, 0, nullptr, 0, 0.f);
+    }
+
+    // final LN + logits = d_te . x for the rows that asked for them (the reference computes all rows
+    // and copies out the flagged ones, W/whisper.cpp:2498, 2566-2572)
+    st.logits.resize((size_t) n * NV);
+    for (size_t r0 = 0; r0 < rows.size(); r0 += 8) {
+        const int nr = (int) std::min<size_t>(8, rows.size() - r0);
+        k::GemvArgs g{};
+        g.x32 = d.dx; g.ln_g = w.d_ln_g; g.ln_b = w.d_ln_b; g.eps = hp.eps; g.n = nr; g.K = S; g.N = NV; g.W = w.d_te;
+        g.epi = k::EPI_LOGITS; g.C = d.logits; g.ldc = NV; g.rows = d.d_rows + r0;
+        k::gemv(g, s);
+        HIP_TRY(hipMemcpyAsync(d.pinned, d.logits, (size_t) nr * NV * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (int r = 0; r < nr; ++r)
+            memcpy(st.logits.data() + (size_t) rows[r0 + r] * NV, (const float *) d.pinned + (size_t) r * NV, (size_t) NV * 4);
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    if (!HIP_OK(hipGetLastError())) return false;
+
+    const int64_t dt = time_us() - t0;                            // timing buckets, W/whisper.cpp:2583-2592
+    if (n == 1)      { st.t_decode_us += dt; st.n_decode++; }
+    else if (n < 16) { st.t_batchd_us += dt; st.n_batchd += n; }
+    else             { st.t_prompt_us += dt; st.n_prompt += n; }
+    return true;
+}
+
+} // namespace wmi

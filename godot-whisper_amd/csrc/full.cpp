@@ -1,0 +1,507 @@
+// The transcription driver behind whisper_full() (reference
+// W/whisper.cpp:4960-5807) and the token-level timestamp heuristics the Godot host enables
+// (row (f)4; W/whisper.cpp:6315-6599).  Control flow stays on the host CPU; the three hot calls —
+// pcm_to_mel, encode, decode — run on the GPU.  Decisions (seek window, prompt assembly, temperature
+// fallback, beam bookkeeping through the unified KV cache, segment splitting) are reproduced
+// decision-for-decision so that the token stream equals the reference's when the logits agree.
+
+#include "wmi.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace wmi {
+
+namespace {
+
+constexpr int MAX_DECODERS = 8;          // W/whisper.cpp:148
+
+struct BeamCandidate { int decoder_idx; int seek_delta; bool has_ts; Sequence sequence; };
+
+const char * tok_str(whisper_context & ctx, int32_t id) { return ctx.model.vocab.id_to_token.at(id).c_str(); }
+
+void emit_segment(whisper_context & ctx, const whisper_full_params & params, int64_t t0, int64_t t1, const std::string & text,
+                  const std::vector<whisper_token_data> & toks, int i0, int i1_excl, bool speaker_turn_next) {
+    State & st = *ctx.state;
+    const int64_t tt0 = params.speed_up ? 2 * t0 : t0, tt1 = params.speed_up ? 2 * t1 : t1;
+    if (params.print_realtime) {
+        if (params.print_timestamps) printf("[%lld --> %lld]  %s\n", (long long) tt0, (long long) tt1, text.c_str());
+        else { printf("%s", text.c_str()); fflush(stdout); }
+    }
+    Segment seg{tt0, tt1, text, {}, speaker_turn_next};
+    seg.tokens.assign(toks.begin() + i0, toks.begin() + i1_excl);
+    st.result_all.push_back(std::move(seg));
+    int n_new = 1;
+    if (params.token_timestamps) {
+        token_level_timestamps(ctx, (int) st.result_all.size() - 1, params.thold_pt, params.thold_ptsum);
+        if (params.max_len > 0) n_new = wrap_segment(ctx, params.max_len, params.split_on_word);
+    }
+    if (params.new_segment_callback)
+        params.new_segment_callback(&ctx, (whisper_state *) ctx.state, n_new, params.new_segment_callback_user_data);
+}
+
+} // namespace
+
+int full(whisper_context & ctx, whisper_full_params params, const float * samples, const float * d_samples, int n_samples) {
+    State & st = *ctx.state;
+    const Vocab & v = ctx.model.vocab;
+    const HParams & hp = ctx.model.hp;
+    st.result_all.clear();
+
+    if (n_samples > 0) {
+        if (params.speed_up) { WMI_ERR("%s: failed to compute log mel spectrogram\n", __func__); return -1; }
+        const bool ok_mel = d_samples ? pcm_to_mel(ctx, d_samples, n_samples, true) : pcm_to_mel(ctx, samples, n_samples, false);
+        if (!ok_mel) { WMI_ERR("%s: failed to compute log mel spectrogram\n", __func__); return -2; }
+    }
+
+    if (params.language == nullptr || strlen(params.language) == 0 || strcmp(params.language, "auto") == 0 || params.detect_language) {
+        std::vector<float> probs(lang_max_id() + 1, 0.0f);
+        const int lid = lang_auto_detect(ctx, 0, probs.data());
+        if (lid < 0) { WMI_ERR("%s: failed to auto-detect language\n", __func__); return -3; }
+        st.lang_id = lid;
+        params.language = lang_str(lid);
+        WMI_INFO("%s: auto-detected language: %s (p = %f)\n", __func__, params.language, probs[lid]);
+        if (params.detect_language) return 0;
+    }
+
+    if (params.token_timestamps) {
+        st.t_beg = 0; st.t_last = 0; st.tid_last = 0;
+        if (n_samples > 0 && samples) st.energy = signal_energy(samples, n_samples, 32);
+    }
+
+    const int seek_start = params.offset_ms / 10;
+    const int seek_end = params.duration_ms == 0 ? st.mel.n_len_org : seek_start + params.duration_ms / 10;
+    if (seek_end < seek_start + (params.speed_up ? 50 : 100)) return 0;      // < 1 s of audio: nothing to do
+
+    std::vector<float> temperatures;
+    if (params.temperature_inc > 0.0f) for (float t = params.temperature; t < 1.0f + 1e-6f; t += params.temperature_inc) temperatures.push_back(t);
+    else temperatures.push_back(params.temperature);
+
+    int n_decoders = 1;
+    if (params.strategy == WHISPER_SAMPLING_GREEDY) n_decoders = params.greedy.best_of;
+    else if (params.strategy == WHISPER_SAMPLING_BEAM_SEARCH) n_decoders = std::max(params.greedy.best_of, params.beam_search.beam_size);
+    n_decoders = std::max(1, n_decoders);
+    if (n_decoders > MAX_DECODERS) { WMI_ERR("%s: too many decoders requested (%d), max = %d\n", __func__, n_decoders, MAX_DECODERS); return -4; }
+    for (int j = 1; j < n_decoders; ++j) {
+        Decoder & d = st.decoders[j];
+        d.probs.resize(v.n_vocab); d.logits.resize(v.n_vocab); d.logprobs.resize(v.n_vocab);
+        d.rng = std::mt19937(0);
+    }
+
+    auto & prompt_past = st.prompt_past;
+    if (params.no_context) prompt_past.clear();
+    std::vector<int32_t> prompt_tokens_own;
+    if (!params.prompt_tokens && params.initial_prompt) {
+        prompt_tokens_own = tokenize(v, params.initial_prompt);
+        if (prompt_tokens_own.size() > 1024) {             // the reference tokenises into a 1024-slot buffer and gets -1
+            WMI_ERR("%s: too many resulting tokens: %d (max %d)\n", "whisper_tokenize", (int) prompt_tokens_own.size(), 1024);
+            prompt_tokens_own.clear();                     // (resize(-1) there is undefined; we treat it as "no prompt")
+        }
+        params.prompt_tokens = prompt_tokens_own.data();
+        params.prompt_n_tokens = (int) prompt_tokens_own.size();
+    }
+    if (params.prompt_tokens && params.prompt_n_tokens > 0) {
+        for (int i = 0; i < params.prompt_n_tokens; ++i) prompt_past.push_back(params.prompt_tokens[i]);
+        std::rotate(prompt_past.begin(), prompt_past.end() - params.prompt_n_tokens, prompt_past.end());
+    }
+
+    if (params.audio_ctx > hp.n_audio_ctx) {
+        WMI_ERR("%s: audio_ctx is larger than the maximum allowed (%d > %d)\n", __func__, params.audio_ctx, hp.n_audio_ctx);
+        return -5;
+    }
+    st.exp_n_audio_ctx = params.audio_ctx;
+
+    std::vector<int32_t> prompt_init = { v.sot };
+    if (v.is_multilingual()) {
+        const int lid = lang_id(params.language);
+        st.lang_id = lid;
+        prompt_init.push_back(v.sot + 1 + lid);
+        prompt_init.push_back(params.translate ? v.translate : v.transcribe);
+    }
+    if (hp.n_text_layer == 2 && !params.no_timestamps) {   // distilled checkpoints
+        WMI_WARN("%s: using distilled model - forcing no_timestamps\n", __func__);
+        params.no_timestamps = true;
+    }
+    if (params.no_timestamps) prompt_init.push_back(v.not_);
+
+    int seek = seek_start;
+    std::vector<int32_t> prompt;
+    prompt.reserve(hp.n_text_ctx);
+    std::vector<std::vector<BeamCandidate>> bc_per_dec(n_decoders);
+    std::vector<BeamCandidate> beam_candidates;
+    const bool beam = params.strategy == WHISPER_SAMPLING_BEAM_SEARCH;
+
+    while (true) {
+        if (params.progress_callback)
+            params.progress_callback(&ctx, (whisper_state *) ctx.state, (100 * (seek - seek_start)) / (seek_end - seek_start),
+                                     params.progress_callback_user_data);
+        if (seek + 100 >= seek_end) break;
+        if (params.encoder_begin_callback &&
+            !params.encoder_begin_callback(&ctx, (whisper_state *) ctx.state, params.encoder_begin_callback_user_data)) {
+            WMI_ERR("%s: encoder_begin_callback returned false - aborting\n", __func__);
+            break;
+        }
+        if (!encode(ctx, seek) || (params.abort_callback && params.abort_callback(params.abort_callback_user_data))) {
+            WMI_ERR("%s: failed to encode\n", __func__);
+            return -6;
+        }
+        if (seek > seek_start && seek + 500 >= seek_end) prompt_past.clear();
+
+        int best_decoder_id = 0;
+        for (int it = 0; it < (int) temperatures.size(); ++it) {
+            const float t_cur = temperatures[it];
+            int n_cur = 1;
+            if (!beam) { if (t_cur > 0.0f) n_cur = params.greedy.best_of; }
+            else       { n_cur = t_cur > 0.0f ? params.greedy.best_of : params.beam_search.beam_size; }
+            n_cur = std::max(1, n_cur);
+
+            for (int j = 0; j < n_cur; ++j) {
+                Decoder & d = st.decoders[j];
+                d.sequence.tokens.clear();
+                d.sequence.result_len = 0; d.sequence.sum_logprobs_all = 0.0;
+                d.sequence.sum_logprobs = -INFINITY; d.sequence.avg_logprobs = -INFINITY;
+                d.sequence.entropy = 0.0; d.sequence.score = -INFINITY;
+                d.seek_delta = 100 * WHISPER_CHUNK_SIZE;
+                d.failed = false; d.completed = false; d.has_ts = false;
+            }
+
+            // prompt = [prev, tail of past text] (only while t < 0.5) + [sot, (lang, task), (notimestamps)]
+            prompt.clear();
+            if (!prompt_past.empty() && t_cur < 0.5f && params.n_max_text_ctx > 0) {
+                const int n_take = std::min(std::min(params.n_max_text_ctx, hp.n_text_ctx / 2), (int) prompt_past.size());
+                prompt.push_back(v.prev);
+                prompt.insert(prompt.end(), prompt_past.end() - n_take, prompt_past.end());
+            }
+            prompt.insert(prompt.end(), prompt_init.begin(), prompt_init.end());
+
+            kv_clear(st.kv_self);
+            st.batch.prep_legacy(prompt.data(), (int) prompt.size(), 0, 0);
+            if (!decode(ctx, st.batch) || (params.abort_callback && params.abort_callback(params.abort_callback_user_data))) {
+                WMI_ERR("%s: failed to decode\n", __func__);
+                return -7;
+            }
+            {
+                const int64_t ts = time_us();
+                st.decoders[0].i_batch = (int) prompt.size() - 1;
+                process_logits(ctx, st.decoders[0], params, t_cur);
+                for (int j = 1; j < n_cur; ++j) {
+                    Decoder & d = st.decoders[j];
+                    kv_seq_cp(st.kv_self, 0, j, -1, -1);
+                    d.probs = st.decoders[0].probs; d.logits = st.decoders[0].logits; d.logprobs = st.decoders[0].logprobs;
+                }
+                st.t_sample_us += time_us() - ts;
+            }
+
+            const int n_max = hp.n_text_ctx / 2 - 4;
+            for (int i = 0; i < n_max; ++i) {
+                const int64_t ts = time_us();
+                if (beam) for (auto & bc : bc_per_dec) bc.clear();
+
+                // sample (each decoder owns its RNG, so the result does not depend on threading)
+                for (int j = 0; j < n_cur; ++j) {
+                    Decoder & d = st.decoders[j];
+                    if (d.completed || d.failed) continue;
+                    if (!beam) {
+                        d.sequence.tokens.push_back(sample_token(ctx, d, t_cur < 1e-6f));
+                        d.sequence.sum_logprobs_all += d.sequence.tokens.back().plog;
+                    } else {
+                        for (const auto & tok : sample_token_topk(ctx, d, params.beam_search.beam_size)) {
+                            bc_per_dec[j].push_back({ j, d.seek_delta, d.has_ts, d.sequence });
+                            bc_per_dec[j].back().sequence.tokens.push_back(tok);
+                            bc_per_dec[j].back().sequence.sum_logprobs_all += tok.plog;
+                        }
+                    }
+                }
+
+                if (beam) {
+                    beam_candidates.clear();
+                    for (const auto & bc : bc_per_dec) beam_candidates.insert(beam_candidates.end(), bc.begin(), bc.end());
+                    std::sort(beam_candidates.begin(), beam_candidates.end(), [](const BeamCandidate & a, const BeamCandidate & b) {
+                        return a.sequence.sum_logprobs_all > b.sequence.sum_logprobs_all; });
+                    uint32_t cur_c = 0;
+                    for (int j = 0; j < n_cur; ++j) {
+                        Decoder & d = st.decoders[j];
+                        if (d.completed || d.failed) continue;
+                        if (cur_c >= beam_candidates.size()) cur_c = 0;
+                        BeamCandidate & cur = beam_candidates[cur_c++];
+                        while (beam_candidates.size() > cur_c &&
+                               beam_candidates[cur_c].sequence.sum_logprobs_all == cur.sequence.sum_logprobs_all && i > 0) ++cur_c;
+                        d.seek_delta = cur.seek_delta; d.has_ts = cur.has_ts; d.sequence = cur.sequence;
+                        kv_seq_cp(st.kv_self, cur.decoder_idx, MAX_DECODERS + j, -1, -1);
+                    }
+                    for (int j = 0; j < n_cur; ++j) {
+                        Decoder & d = st.decoders[j];
+                        if (d.completed || d.failed) continue;
+                        kv_seq_rm(st.kv_self, j, -1, -1);
+                        kv_seq_cp(st.kv_self, MAX_DECODERS + j, j, -1, -1);
+                        kv_seq_rm(st.kv_self, MAX_DECODERS + j, -1, -1);
+                    }
+                }
+
+                // per-decoder state machine: timestamps move the window, EOT / limits complete the segment
+                for (int j = 0; j < n_cur; ++j) {
+                    Decoder & d = st.decoders[j];
+                    if (d.completed || d.failed) continue;
+                    int & result_len = d.sequence.result_len;
+                    const whisper_token_data & tok = d.sequence.tokens.back();
+                    if (tok.id > v.beg) {
+                        const int sd_new = 2 * (tok.id - v.beg);
+                        if (d.has_ts && d.seek_delta > sd_new && result_len < i) { d.failed = true; continue; }   // going back in time
+                        d.seek_delta = sd_new; result_len = i + 1; d.has_ts = true;
+                    }
+                    if (tok.id == v.eot || (params.max_tokens > 0 && i >= params.max_tokens) ||
+                        (d.has_ts && seek + d.seek_delta + 100 >= seek_end)) {
+                        if (result_len == 0) {
+                            if (seek + d.seek_delta + 100 >= seek_end) result_len = i + 1;
+                            else { d.failed = true; continue; }
+                        }
+                        if (params.single_segment) { result_len = i + 1; d.seek_delta = 100 * WHISPER_CHUNK_SIZE; }
+                        d.completed = true;
+                        continue;
+                    }
+                    if (ctx.model.n_loaded == 0) { d.seek_delta = 100 * WHISPER_CHUNK_SIZE; d.completed = true; continue; }   // empty test model
+                    if (i == n_max - 1 && (result_len == 0 || d.seek_delta < 100 * WHISPER_CHUNK_SIZE / 2)) { d.failed = true; continue; }
+                }
+
+                bool all_done = true;
+                for (int j = 0; j < n_cur; ++j) if (!st.decoders[j].completed && !st.decoders[j].failed) all_done = false;
+                if (all_done) break;
+                st.t_sample_us += time_us() - ts;
+
+                // next step: one token per live decoder, each in its own sequence id
+                Batch & b = st.batch;
+                b.n_tokens = 0;
+                const int n_past = (int) prompt.size() + i;
+                for (int j = 0; j < n_cur; ++j) {
+                    Decoder & d = st.decoders[j];
+                    if (d.failed || d.completed) continue;
+                    d.i_batch = b.n_tokens;
+                    b.token[b.n_tokens] = d.sequence.tokens.back().id; b.pos[b.n_tokens] = n_past;
+                    b.seq_id[b.n_tokens] = j; b.logits[b.n_tokens] = 1;
+                    b.n_tokens++;
+                }
+                if (!decode(ctx, b) || (params.abort_callback && params.abort_callback(params.abort_callback_user_data))) {
+                    WMI_ERR("%s: failed to decode\n", __func__);
+                    return -8;
+                }
+                const int64_t ts2 = time_us();
+                for (int j = 0; j < n_cur; ++j) {
+                    Decoder & d = st.decoders[j];
+                    if (d.failed || d.completed) continue;
+                    process_logits(ctx, d, params, t_cur);
+                }
+                st.t_sample_us += time_us() - ts2;
+            }
+
+            // rank the finished sequences
+            {
+                double best_score = -INFINITY;
+                for (int j = 0; j < n_cur; ++j) {
+                    Decoder & d = st.decoders[j];
+                    if (d.failed) continue;
+                    d.sequence.tokens.resize(d.sequence.result_len);
+                    sequence_score(params, d.sequence);
+                    if (d.sequence.result_len > 32 && d.sequence.entropy < params.entropy_thold) { d.failed = true; st.n_fail_h++; continue; }
+                    if (best_score < d.sequence.score) { best_score = d.sequence.score; best_decoder_id = j; }
+                }
+            }
+            bool success = true;
+            if (it != (int) temperatures.size() - 1) {
+                const Decoder & d = st.decoders[best_decoder_id];
+                if (d.failed || d.sequence.avg_logprobs < params.logprob_thold) { success = false; st.n_fail_p++; }
+            }
+            if (success) break;
+        }
+
+        // results of this window
+        {
+            const Decoder & best = st.decoders[best_decoder_id];
+            const int seek_delta = best.seek_delta, result_len = best.sequence.result_len;
+            const auto & toks = best.sequence.tokens;
+
+            prompt_past.clear();
+            if (prompt.front() == v.prev) prompt_past.insert(prompt_past.end(), prompt.begin() + 1, prompt.end() - prompt_init.size());
+            for (int i = 0; i < result_len; ++i) prompt_past.push_back(toks[i].id);
+
+            if (!toks.empty() && ctx.model.n_loaded > 0) {
+                int i0 = 0;
+                int64_t t0 = seek + 2 * (toks.front().tid - v.beg);
+                std::string text;
+                bool speaker_turn_next = false;
+                for (int i = 0; i < (int) toks.size(); ++i) {
+                    if (params.print_special || toks[i].id < v.eot) text += tok_str(ctx, toks[i].id);
+                    if (params.tdrz_enable && toks[i].id == v.solm) speaker_turn_next = true;
+                    if (toks[i].id > v.beg && !params.single_segment) {
+                        const int64_t t1 = seek + 2 * (toks[i].tid - v.beg);
+                        if (!text.empty()) emit_segment(ctx, params, t0, t1, text, toks, i0, i + 1, speaker_turn_next);
+                        text.clear();
+                        while (i < (int) toks.size() && toks[i].id > v.beg) ++i;
+                        --i;
+                        t0 = t1; i0 = i + 1; speaker_turn_next = false;
+                    }
+                }
+                if (!text.empty()) emit_segment(ctx, params, t0, seek + seek_delta, text, toks, i0, (int) toks.size(), speaker_turn_next);
+            }
+            seek += seek_delta;
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------ token-level timestamps (W/whisper.cpp:6315-6599)
+namespace {
+int ts_to_sample(int64_t t, int n_samples) { return std::max(0, std::min(n_samples - 1, (int) ((t * WHISPER_SAMPLE_RATE) / 100))); }
+int64_t sample_to_ts(int i) { return (100ll * i) / WHISPER_SAMPLE_RATE; }
+float voice_length(const char * s) {
+    float r = 0.0f;
+    for (; *s; ++s) {
+        const char c = *s;
+        if (c == ' ') r += 0.01f; else if (c == ',') r += 2.00f;
+        else if (c == '.' || c == '!' || c == '?') r += 3.00f;
+        else if (c >= '0' && c <= '9') r += 3.00f; else r += 1.00f;
+    }
+    return r;
+}
+} // namespace
+
+std::vector<float> signal_energy(const float * signal, int n_samples, int hw) {
+    // mean |x| over a (2 hw + 1) window; same left-to-right f32 summation as the reference so the
+    // thresholds below see identical values
+    std::vector<float> out(n_samples);
+    for (int i = 0; i < n_samples; ++i) {
+        float sum = 0.0f;
+        const int a = std::max(0, i - hw), b = std::min(n_samples - 1, i + hw);
+        for (int j = a; j <= b; ++j) sum += fabsf(signal[j]);
+        out[i] = sum / (2 * hw + 1);
+    }
+    return out;
+}
+
+void token_level_timestamps(whisper_context & ctx, int i_segment, float thold_pt, float thold_ptsum) {
+    State & st = *ctx.state;
+    const Vocab & v = ctx.model.vocab;
+    Segment & seg = st.result_all[i_segment];
+    auto & tokens = seg.tokens;
+    const int n_samples = (int) st.energy.size();
+    if (n_samples == 0) { WMI_ERR("%s: no signal data available\n", __func__); return; }
+    const int64_t t0 = seg.t0, t1 = seg.t1;
+    const int n = (int) tokens.size();
+    if (n == 0) return;
+    if (n == 1) { tokens[0].t0 = t0; tokens[0].t1 = t1; return; }
+
+    for (int j = 0; j < n; ++j) {
+        whisper_token_data & tok = tokens[j];
+        if (j == 0) {
+            if (tok.id == v.beg) {
+                tokens[0].t0 = t0; tokens[0].t1 = t0; tokens[1].t0 = t0;
+                st.t_beg = t0; st.t_last = t0; st.tid_last = v.beg;
+            } else {
+                tokens[0].t0 = st.t_last;
+            }
+        }
+        const int64_t tt = st.t_beg + 2 * (tok.tid - v.beg);
+        tok.vlen = voice_length(tok_str(ctx, tok.id));
+        if (tok.pt > thold_pt && tok.ptsum > thold_ptsum && tok.tid > st.tid_last && tt <= t1) {
+            if (j > 0) tokens[j - 1].t1 = tt;
+            tok.t0 = tt;
+            st.tid_last = tok.tid;
+        }
+    }
+    tokens[n - 2].t1 = t1; tokens[n - 1].t0 = t1; tokens[n - 1].t1 = t1;
+    st.t_last = t1;
+
+    // spread unknown intervals proportionally to the voice length
+    for (int p0 = 0, p1 = 0;;) {
+        while (p1 < n && tokens[p1].t1 < 0) ++p1;
+        if (p1 >= n) --p1;
+        if (p1 > p0) {
+            double psum = 0.0;
+            for (int j = p0; j <= p1; ++j) psum += tokens[j].vlen;
+            const double dt = (double) (tokens[p1].t1 - tokens[p0].t0);
+            for (int j = p0 + 1; j <= p1; ++j) {
+                const double ct = tokens[j - 1].t0 + dt * tokens[j - 1].vlen / psum;
+                tokens[j - 1].t1 = (int64_t) ct;
+                tokens[j].t0 = (int64_t) ct;
+            }
+        }
+        ++p1; p0 = p1;
+        if (p1 >= n) break;
+    }
+    for (int j = 0; j < n - 1; ++j) {
+        if (tokens[j].t1 < 0) tokens[j + 1].t0 = tokens[j].t1;
+        if (j > 0 && tokens[j - 1].t1 > tokens[j].t0) {
+            tokens[j].t0 = tokens[j - 1].t1;
+            tokens[j].t1 = std::max(tokens[j].t0, tokens[j].t1);
+        }
+    }
+
+    // expand / contract by voice activity
+    const int hw = WHISPER_SAMPLE_RATE / 8;
+    const std::vector<float> & en = st.energy;
+    for (int j = 0; j < n; ++j) {
+        if (tokens[j].id >= v.eot) continue;
+        int s0 = ts_to_sample(tokens[j].t0, n_samples), s1 = ts_to_sample(tokens[j].t1, n_samples);
+        const int ss0 = std::max(s0 - hw, 0), ss1 = std::min(s1 + hw, n_samples);
+        const int ns = ss1 - ss0;
+        float sum = 0.0f;
+        for (int k2 = ss0; k2 < ss1; ++k2) sum += en[k2];
+        const float thold = 0.5 * sum / ns;
+        {
+            int k2 = s0;
+            if (en[k2] > thold && j > 0) {
+                while (k2 > 0 && en[k2] > thold) --k2;
+                tokens[j].t0 = sample_to_ts(k2);
+                if (tokens[j].t0 < tokens[j - 1].t1) tokens[j].t0 = tokens[j - 1].t1; else s0 = k2;
+            } else {
+                while (en[k2] < thold && k2 < s1) ++k2;
+                s0 = k2;
+                tokens[j].t0 = sample_to_ts(k2);
+            }
+        }
+        {
+            int k2 = s1;
+            if (en[k2] > thold) {
+                while (k2 < n_samples - 1 && en[k2] > thold) ++k2;
+                tokens[j].t1 = sample_to_ts(k2);
+                if (j < ns - 1 && tokens[j].t1 > tokens[j + 1].t0) tokens[j].t1 = tokens[j + 1].t0; else s1 = k2;
+            } else {
+                while (en[k2] < thold && k2 > s0) --k2;
+                s1 = k2;
+                tokens[j].t1 = sample_to_ts(k2);
+            }
+        }
+    }
+}
+
+int wrap_segment(whisper_context & ctx, int max_len, bool split_on_word) {          // W/whisper.cpp:4430-4484
+    State & st = *ctx.state;
+    const Vocab & v = ctx.model.vocab;
+    Segment seg = st.result_all.back();
+    int res = 1, acc = 0;
+    std::string text;
+    for (int i = 0; i < (int) seg.tokens.size(); ++i) {
+        const whisper_token_data & tok = seg.tokens[i];
+        if (tok.id >= v.eot) continue;
+        const char * txt = tok_str(ctx, tok.id);
+        const int cur = (int) strlen(txt);
+        const bool may_split = !split_on_word || txt[0] == ' ';
+        if (acc + cur > max_len && i > 0 && may_split) {
+            Segment & last = st.result_all.back();
+            last.text = std::move(text); last.t1 = tok.t0; last.tokens.resize(i); last.speaker_turn_next = false;
+            Segment next{tok.t0, seg.t1, std::string(), {}, seg.speaker_turn_next};
+            next.tokens.assign(seg.tokens.begin() + i, seg.tokens.end());
+            st.result_all.push_back(std::move(next));
+            acc = 0; text.clear();
+            seg = st.result_all.back();
+            i = -1;
+            ++res;
+        } else {
+            acc += cur; text += txt;
+        }
+    }
+    st.result_all.back().text = std::move(text);
+    return res;
+}
+
+} // namespace wmi

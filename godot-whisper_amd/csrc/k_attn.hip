@@ -1,0 +1,234 @@
+// Attention kernels for gfx950.
+//
+// Numerics contract (SURVEY App. B rules 4, 5, 7): scores = f16 Q . f16 K accumulated in f32; row
+// max in f32; e = f16(exp(f16(s - max))) — the reference's exp goes through an f16 table, i.e. the
+// argument AND the result are rounded to f16; probabilities enter the P.V product as f16.
+// To keep that contract without materialising the T x T score matrix (72 MB per layer for base.en)
+// the encoder kernel walks the keys twice: sweep 1 finds the exact row max, sweep 2 recomputes the
+// scores, forms e with the reference's two roundings and accumulates e.V; the 1/sum is applied to the
+// f32 accumulator at the end.  The only departure from the reference is that e is not multiplied by
+// 1/sum and re-rounded to f16 before P.V (one rounding fewer).
+//
+// Encoder kernel layout: workgroup = 4 wavefronts = 64 query rows of one head, 16 rows per
+// wavefront.  K and V^T tiles of 64 keys are staged in LDS (XOR-swizzled 128-byte rows) and shared
+// by the four wavefronts.  QK^T is computed transposed (A = K tile, B = Q) so that each lane ends up
+// holding scores of ONE query row (q = lane & 15): the row reductions are in-register plus two
+// cross-group shuffles, and the e values are already in the A-operand slot order of the P.V MFMA
+// (slot (g, j) <-> key 32*ks + 4*g + j for j < 4, + 16 for j >= 4; V^T fragments are gathered to match).
+
+#include "kernels.h"
+
+namespace wmi { namespace k {
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float    floatx4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float round_f16(float x) { return __half2float(__float2half_rn(x)); }
+// the reference's exp-through-f16-table (W/ggml.c:11176-11186)
+__device__ __forceinline__ float exp16(float d) { return round_f16(expf(round_f16(d))); }
+
+__device__ __forceinline__ uint32_t lds_off(int row, int chunk) { return (uint32_t) (row * 128 + ((chunk ^ (row & 7)) << 4)); }
+
+__global__ __launch_bounds__(256) void k_attn_enc(const __half * __restrict__ q, const __half * __restrict__ k,
+                                                  const __half * __restrict__ vt, int T, int Tpad, int S, float scale,
+                                                  __half * __restrict__ out) {
+    __shared__ __attribute__((aligned(16))) unsigned char sK[64 * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char sV[64 * 128];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int fr = lane & 15, fq = lane >> 4;
+    const int head = blockIdx.y;
+    const int q0 = blockIdx.x * 64 + wave * 16;
+
+    half8 qf[2];
+    {
+        int qr = q0 + fr; if (qr > T - 1) qr = T - 1;
+        const __half * qp = q + (size_t) qr * S + head * 64 + fq * 8;
+        qf[0] = *(const half8 *) (qp);
+        qf[1] = *(const half8 *) (qp + 32);
+    }
+    const int srow = tid >> 2, sch = (tid & 3) * 2;          // staging: 64 rows x 8 chunks, 2 chunks per thread
+
+    auto stage_k = [&](int kt0) {
+        int kr = kt0 + srow; if (kr > T - 1) kr = T - 1;
+        const uint4 * src = (const uint4 *) (k + (size_t) kr * S + head * 64 + sch * 8);
+        const uint4 a = src[0], b = src[1];
+        *(uint4 *) (sK + lds_off(srow, sch)) = a;
+        *(uint4 *) (sK + lds_off(srow, sch + 1)) = b;
+    };
+    auto stage_v = [&](int kt0) {
+        const uint4 * src = (const uint4 *) (vt + (size_t) (head * 64 + srow) * Tpad + kt0 + sch * 8);
+        const uint4 a = src[0], b = src[1];
+        *(uint4 *) (sV + lds_off(srow, sch)) = a;
+        *(uint4 *) (sV + lds_off(srow, sch + 1)) = b;
+    };
+    auto score_tile = [&](int kt) -> floatx4 {                // S^T for keys kt*16..+15 of the staged tile
+        floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            const half8 kf = *(const half8 *) (sK + lds_off(kt * 16 + fr, kk * 4 + fq));
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf[kk], acc, 0, 0, 0);
+        }
+        return acc;                                           // acc[r] = S[q = fr][key = kt*16 + fq*4 + r]
+    };
+
+    // ---- sweep 1: exact row max
+    float m = -INFINITY;
+    for (int kt0 = 0; kt0 < T; kt0 += 64) {
+        stage_k(kt0);
+        __syncthreads();
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const floatx4 acc = score_tile(kt);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = kt0 + kt * 16 + fq * 4 + r;
+                if (key < T) m = fmaxf(m, acc[r] * scale);
+            }
+        }
+        __syncthreads();
+    }
+    m = fmaxf(m, __shfl_xor(m, 16));
+    m = fmaxf(m, __shfl_xor(m, 32));
+
+    // ---- sweep 2: e = exp16(s - max), l = sum e, O += e . V
+    float l = 0.0f;
+    floatx4 o[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) o[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    for (int kt0 = 0; kt0 < T; kt0 += 64) {
+        stage_k(kt0);
+        stage_v(kt0);
+        __syncthreads();
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            half8 pf;
+#pragma unroll
+            for (int hh = 0; hh < 2; ++hh) {
+                const int kt = ks * 2 + hh;
+                const floatx4 acc = score_tile(kt);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kt0 + kt * 16 + fq * 4 + r;
+                    const float e = key < T ? exp16(acc[r] * scale - m) : 0.0f;
+                    l += e;
+                    pf[hh * 4 + r] = (_Float16) e;
+                }
+            }
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const int dv = nt * 16 + fr;
+                const int ch = ks * 4 + (fq >> 1);
+                const half4 v0 = *(const half4 *) (sV + lds_off(dv, ch) + (fq & 1) * 8);
+                const half4 v1 = *(const half4 *) (sV + lds_off(dv, ch + 2) + (fq & 1) * 8);
+                half8 vf;
+                vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
+                vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
+                o[nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pf, vf, o[nt], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    l += __shfl_xor(l, 16);
+    l += __shfl_xor(l, 32);
+    const float inv = (float) (1.0 / (double) l);
+
+    // o[nt][r]: query row fq*4 + r, value column nt*16 + fr
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qrow = fq * 4 + r;
+        const float li = __shfl(inv, qrow);
+        const int qg = q0 + qrow;
+        if (qg < T) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                out[(size_t) qg * S + head * 64 + nt * 16 + fr] = __float2half_rn(o[nt][r] * li);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Decoder attention: one (token, head) per workgroup; keys/values come from an f16 cache laid out
+// [cell][S].  Exactly the reference's three steps (scores + mask, soft-max through exp16, P rounded to
+// f16, P.V) — the score row (<= 1536 floats) lives in LDS.  HBM-bound: reads 2 * n_kv * 128 B.
+__global__ __launch_bounds__(256) void k_attn_dec(const __half * __restrict__ q, int S, const __half * __restrict__ kc,
+                                                  const __half * __restrict__ vc, int n_kv,
+                                                  const float * __restrict__ mask, int ld_mask, __half * __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float * sc  = (float *) smem;                 // [n_kv]
+    float * qs  = sc + ((n_kv + 3) & ~3);         // [64]
+    float * red = qs + 64;                        // [256]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x, head = blockIdx.y;
+
+    if (tid < 64) qs[tid] = __half2float(q[(size_t) i * S + head * 64 + tid]);
+    __syncthreads();
+
+    float lmax = -INFINITY;
+    for (int j = tid; j < n_kv; j += 256) {
+        const uint4 * kp = (const uint4 *) (kc + (size_t) j * S + head * 64);
+        float dot = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const uint4 u = kp[c];
+            const __half2 * h = (const __half2 *) &u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float2 f = __half22float2(h[e]);
+                dot = fmaf(f.x, qs[c * 8 + e * 2], dot);
+                dot = fmaf(f.y, qs[c * 8 + e * 2 + 1], dot);
+            }
+        }
+        const float s = mask ? dot + mask[(size_t) i * ld_mask + j] : dot;
+        sc[j] = s;
+        lmax = fmaxf(lmax, s);
+    }
+    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+    if (lane == 0) red[wave] = lmax;
+    __syncthreads();
+    const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+
+    float lsum = 0.0f;
+    for (int j = tid; j < n_kv; j += 256) {
+        const float s = sc[j];
+        const float e = (s == -INFINITY) ? 0.0f : exp16(s - m);
+        sc[j] = e;
+        lsum += e;
+    }
+    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+    if (lane == 0) red[wave] = lsum;
+    __syncthreads();
+    const float inv = (float) (1.0 / ((double) red[0] + (double) red[1] + (double) red[2] + (double) red[3]));
+    __syncthreads();
+    for (int j = tid; j < n_kv; j += 256) sc[j] = round_f16(sc[j] * inv);   // P enters P.V as f16 (App. B rule 1)
+    __syncthreads();
+
+    // P.V: lane <-> value column, wavefront <-> key residue class
+    float acc = 0.0f;
+    const __half * vp = vc + head * 64 + lane;
+    for (int j = wave; j < n_kv; j += 4) acc = fmaf(sc[j], __half2float(vp[(size_t) j * S]), acc);
+    red[wave * 64 + lane] = acc;
+    __syncthreads();
+    if (tid < 64) {
+        const float r = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+        out[(size_t) i * S + head * 64 + tid] = __float2half_rn(r);
+    }
+}
+
+} // namespace
+
+void attn_encoder(const __half * q, const __half * k, const __half * vt, int T, int Tpad, int S, int H, float scale,
+                  __half * out, hipStream_t st) {
+    hipLaunchKernelGGL(k_attn_enc, dim3((T + 63) / 64, H), dim3(256), 0, st, q, k, vt, T, Tpad, S, scale, out);
+}
+
+void attn_decoder(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int n_kv,
+                  const float * mask, int ld_mask, __half * out, hipStream_t st) {
+    const size_t smem = (((size_t) n_kv + 3) & ~(size_t) 3) * 4 + 64 * 4 + 256 * 4;
+    hipLaunchKernelGGL(k_attn_dec, dim3(n, H), dim3(256), smem, st, q, S, kc, vc, n_kv, mask, ld_mask, out);
+}
+
+}} // namespace wmi::k

@@ -1,0 +1,237 @@
+// f16 x f16 -> f32 MFMA GEMM with fused epilogues for gfx950.
+//
+//   C[M][N] = A[M][K] . W[N][K]^T       A: activations (f16, row stride lda)
+//                                        W: weights     (f16, row stride ldw)  — both K-contiguous
+//
+// Numerics follow the reference's mul_mat contract (SURVEY App. B rule 1): both operands are IEEE
+// f16, products are exact, accumulation is f32 — v_mfma_f32_16x16x32_f16.  Everything the reference
+// does as separate graph nodes after a mul_mat (bias add, GELU through the f16 table, residual add,
+// q/k scaling, f32->f16 copies into K/V layouts) happens in the epilogue on the accumulator registers.
+//
+// Tiling: BM x BN x 64 per workgroup, 256 threads = 4 wavefronts (64 lanes) in a 2 x 2 grid, each
+// wavefront owning a (BM/2) x (BN/2) sub-tile as (BM/32) x (BN/32) MFMA fragments.  Operand tiles are
+// staged global -> VGPR -> LDS (16 B per lane, coalesced 128 B rows) into a double-buffered,
+// XOR-swizzled LDS image so that the ds_read_b128 fragment reads are conflict-free; the next tile's
+// global loads are in flight while the current tile is multiplied (one barrier per K step).
+// The conv front-end reuses this kernel as an implicit GEMM: a token-major activation buffer with
+// lda < K makes consecutive A rows overlap, which is exactly im2col for a k=3 convolution.
+
+#include "kernels.h"
+
+namespace wmi { namespace k {
+
+namespace {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float    floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 64;                 // K extent of one LDS tile (two MFMA k-steps)
+
+__device__ __forceinline__ float round_f16(float x) { return __half2float(__float2half_rn(x)); }
+
+// GELU exactly as the reference evaluates it: input rounded to f16, tanh form in f32, result rounded
+// to f16 (its 65536-entry table is this function tabulated; W/ggml.c:1400-1423, 2229-2231)
+__device__ __forceinline__ float gelu16(float x) {
+    const float xh = round_f16(x);
+    const float g  = 0.5f * xh * (1.0f + tanhf(0.79788456080286535587989211986876f * xh * (1.0f + 0.044715f * xh * xh)));
+    return round_f16(g);
+}
+
+__device__ __forceinline__ uint32_t lds_off(int row, int chunk) {      // byte offset inside a [rows][64] f16 tile
+    return (uint32_t) (row * 128 + ((chunk ^ (row & 7)) << 4));
+}
+
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
+    constexpr int FM = BM / 32, FN = BN / 32;          // fragments per wavefront
+    constexpr int LA = BM / 32, LB = BN / 32;          // 16-byte loads per thread per tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    auto sA = [&](int buf) -> unsigned char * { return smem + buf * ((BM + BN) * 128); };
+    auto sB = [&](int buf) -> unsigned char * { return smem + buf * ((BM + BN) * 128) + BM * 128; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8), so give each
+    // XCD a contiguous run of tiles that share A panels in its private L2.
+    const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN, nwg = ntm * ntn;
+    int wg = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, idx = wg / 8;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = wg / ntn, tn = wg % ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // per-thread staging coordinates: pass p covers rows p*32 + tid/8, chunk tid%8
+    const int srow = tid >> 3, schunk = tid & 7;
+    const __half * gA[LA]; const __half * gB[LB];
+#pragma unroll
+    for (int p = 0; p < LA; ++p) {
+        int r = m0 + p * 32 + srow; if (r > a.M - 1) r = a.M - 1;
+        gA[p] = a.A + (size_t) r * a.lda + schunk * 8;
+    }
+#pragma unroll
+    for (int p = 0; p < LB; ++p) {
+        int r = n0 + p * 32 + srow; if (r > a.N - 1) r = a.N - 1;
+        gB[p] = a.W + (size_t) r * a.ldw + schunk * 8;
+    }
+
+    floatx4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = (a.K + BK - 1) / BK;
+    const int ktail = a.K - (nk - 1) * BK;             // 32 or 64 (K is a multiple of 32)
+    uint4 ra[LA], rb[LB];
+
+    auto load_tile = [&](int kt) {
+        // a tile whose upper 32 columns lie beyond K (K % 64 == 32) must not be read past the weight row
+        const bool half_only = (kt == nk - 1) && (ktail < BK) && (schunk >= 4);
+#pragma unroll
+        for (int p = 0; p < LA; ++p) ra[p] = half_only ? uint4{0, 0, 0, 0} : *(const uint4 *) (gA[p] + kt * BK);
+#pragma unroll
+        for (int p = 0; p < LB; ++p) rb[p] = half_only ? uint4{0, 0, 0, 0} : *(const uint4 *) (gB[p] + kt * BK);
+    };
+    auto store_tile = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < LA; ++p) *(uint4 *) (sA(buf) + lds_off(p * 32 + srow, schunk)) = ra[p];
+#pragma unroll
+        for (int p = 0; p < LB; ++p) *(uint4 *) (sB(buf) + lds_off(p * 32 + srow, schunk)) = rb[p];
+    };
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    const int frow = lane & 15, fq = lane >> 4;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8 fa[FM], fb[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+                fa[i] = *(const half8 *) (sA(buf) + lds_off(wm * (BM / 2) + i * 16 + frow, kk * 4 + fq));
+#pragma unroll
+            for (int j = 0; j < FN; ++j)
+                fb[j] = *(const half8 *) (sB(buf) + lds_off(wn * (BN / 2) + j * 16 + frow, kk * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+        if (kt + 1 < nk) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    // fragment (i, j): rows m = mb + i*16 + fq*4 + r (r = 0..3), column n = nb + j*16 + frow
+    const int mb = m0 + wm * (BM / 2), nb = n0 + wn * (BN / 2);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = nb + j * 16 + frow;
+        if (n >= a.N) continue;
+        const float bias = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int mrow = mb + i * 16 + fq * 4;
+            if constexpr (EPI == EPI_QKV_ENC) {
+                const int seg = n / a.S, c = n - seg * a.S;
+                if (seg == 2) {            // V^T: four consecutive time steps per lane -> one 8-byte store
+                    __half * vt = (__half *) a.aux2 + (size_t) c * a.ldaux2;
+                    if (mrow + 3 < a.M) {
+                        half4 v;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = (_Float16) (acc[i][j][r] + bias);
+                        *(half4 *) (vt + mrow) = v;
+                    } else {
+                        for (int r = 0; r < 4; ++r)
+                            if (mrow + r < a.M) vt[mrow + r] = __float2half_rn(acc[i][j][r] + bias);
+                    }
+                    continue;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int m = mrow + r;
+                    if (m >= a.M) continue;
+                    const float v = acc[i][j][r] + bias;
+                    if (seg == 0) ((__half *) a.C)[(size_t) m * a.ldc + c] = __float2half_rn(v);
+                    else          ((__half *) a.aux)[(size_t) m * a.ldaux + c] = __float2half_rn(v);
+                }
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mrow + r;
+                if (m >= a.M) continue;
+                const float v = acc[i][j][r];
+                if constexpr (EPI == EPI_F16_BIAS) {
+                    ((__half *) a.C)[(size_t) m * a.ldc + n] = __float2half_rn(v + bias);
+                } else if constexpr (EPI == EPI_F16_BIAS_GELU) {
+                    ((__half *) a.C)[(size_t) m * a.ldc + n] = __float2half_rn(gelu16(v + bias));
+                } else if constexpr (EPI == EPI_F32_BIAS_RESID) {
+                    ((float *) a.C)[(size_t) m * a.ldc + n] = (v + bias) + a.resid[(size_t) m * a.ldr + n];
+                } else if constexpr (EPI == EPI_CONV2) {
+                    const float g = gelu16(v + bias);
+                    if (a.aux) ((float *) a.aux)[(size_t) m * a.ldaux + n] = g;
+                    ((float *) a.C)[(size_t) m * a.ldc + n] = a.resid[(size_t) m * a.ldr + n] + g;
+                } else if constexpr (EPI == EPI_QKV_DEC) {
+                    const int seg = n / a.S, c = n - seg * a.S;
+                    if (seg == 0)      ((__half *) a.C)[(size_t) m * a.ldc + c]       = __float2half_rn((v + bias) * a.scale);
+                    else if (seg == 1) ((__half *) a.aux)[(size_t) m * a.ldaux + c]   = __float2half_rn(v * a.scale);
+                    else               ((__half *) a.aux2)[(size_t) m * a.ldaux2 + c] = __float2half_rn(v + bias);
+                } else if constexpr (EPI == EPI_CROSS_KV) {
+                    const int il = n / (2 * a.S), c = n - il * 2 * a.S;
+                    if (c < a.S) ((__half *) a.C)[il * a.layer_stride + (size_t) m * a.ldc + c] = __float2half_rn(v * a.scale);
+                    else         ((__half *) a.aux)[il * a.layer_stride + (size_t) m * a.ldaux + (c - a.S)] = __float2half_rn(v + bias);
+                } else if constexpr (EPI == EPI_Q_SCALED) {
+                    ((__half *) a.C)[(size_t) m * a.ldc + n] = __float2half_rn((v + bias) * a.scale);
+                }
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int EPI>
+void launch(const GemmArgs & a, hipStream_t st) {
+    const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
+    const size_t smem = 2 * (size_t) (BM + BN) * 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void) hipFuncSetAttribute((const void *) k_gemm<BM, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((k_gemm<BM, BN, EPI>), dim3(ntm * ntn), dim3(256), smem, st, a);
+}
+
+template <int EPI>
+void dispatch(const GemmArgs & a, hipStream_t st) {
+    // 256 CUs: prefer the 128x128 tile only when it still yields >= ~1.5 waves of workgroups
+    const long t128 = (long) ((a.M + 127) / 128) * ((a.N + 127) / 128);
+    if (t128 >= 384) launch<128, 128, EPI>(a, st);
+    else             launch<64, 64, EPI>(a, st);
+}
+
+} // namespace
+
+void gemm(int epi, const GemmArgs & a, hipStream_t st) {
+    switch (epi) {
+        case EPI_F16_BIAS:       dispatch<EPI_F16_BIAS>(a, st); break;
+        case EPI_F16_BIAS_GELU:  dispatch<EPI_F16_BIAS_GELU>(a, st); break;
+        case EPI_F32_BIAS_RESID: dispatch<EPI_F32_BIAS_RESID>(a, st); break;
+        case EPI_CONV2:          dispatch<EPI_CONV2>(a, st); break;
+        case EPI_QKV_ENC:        dispatch<EPI_QKV_ENC>(a, st); break;
+        case EPI_QKV_DEC:        dispatch<EPI_QKV_DEC>(a, st); break;
+        case EPI_CROSS_KV:       dispatch<EPI_CROSS_KV>(a, st); break;
+        case EPI_Q_SCALED:       dispatch<EPI_Q_SCALED>(a, st); break;
+        default: break;
+    }
+}
+
+}} // namespace wmi::k

@@ -1,0 +1,213 @@
+// log-mel front end on gfx950 (reference W/whisper.cpp:2614-2887, Appendix G).
+//
+// One workgroup per STFT frame.  The frame transform follows the reference's decomposition
+// exactly — radix-2 even/odd splits 400 -> 200 -> 100 -> 50 -> 25 and a direct 25-point DFT at the
+// leaves, with the same 400-entry sin/cos table — so that the f32 rounding sequence (and therefore
+// log10 of near-silent bins) tracks the CPU path instead of merely approximating it.  The tables
+// (Hann window, sin, cos) are computed on the host with the host libm and uploaded once.
+// HBM traffic is trivial (1.9 MB PCM in, 1.9 MB mel out per 30 s); the kernel is latency/VALU bound
+// and contributes < 1 % of a transcription.
+
+#include "kernels.h"
+#include <climits>
+#include <cmath>
+#include <mutex>
+
+namespace wmi { namespace k {
+
+namespace {
+
+struct MelTables { float hann[400]; float sinv[400]; float cosv[400]; };
+__constant__ MelTables c_mel;
+
+std::once_flag g_tables_once;
+
+void upload_tables() {
+    MelTables t;
+    for (int i = 0; i < 400; ++i) {
+        t.hann[i] = 0.5 * (1.0 - cosf((2.0 * M_PI * i) / 400));       // W/whisper.cpp:2712-2725 (periodic)
+        double theta = (2 * M_PI * i) / 400;                            // W/whisper.cpp:2620-2629
+        t.sinv[i] = sinf(theta);
+        t.cosv[i] = cosf(theta);
+    }
+    (void) hipMemcpyToSymbol(HIP_SYMBOL(c_mel), &t, sizeof(t));
+}
+
+__device__ inline int enc_ordered(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
+__device__ inline float dec_ordered(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+
+__global__ void k_mel_pad(const float * __restrict__ pcm, int n, float * __restrict__ out, int total) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    float v = 0.0f;
+    if (i < 200) {                       // reflect: out[i] = pcm[200 - i]   (W/whisper.cpp:2827)
+        int j = 200 - i; if (j > n - 1) j = n - 1; if (j < 0) j = 0;
+        v = n > 0 ? pcm[j] : 0.0f;
+    } else if (i < 200 + n) {
+        v = pcm[i - 200];
+    }
+    out[i] = v;
+}
+
+// butterfly stage: for g groups, combine E = src[(g)*half ...], O = src[(g + ngroups)*half ...]
+// into dst[g*N + k], dst[g*N + k + half].  Arrays are stored as [leaf][k] complex (re, im interleaved).
+__device__ inline void butterfly_stage(const float * src, float * dst, int ngroups, int N, int tid, int nthreads,
+                                       bool last, int limit_k) {
+    const int half = N / 2;
+    const int step = 400 / N;
+    const int total = ngroups * half;
+    for (int t = tid; t < total; t += nthreads) {
+        const int g = t / half, kk = t % half;
+        const float * E = src + 2 * (g * half);
+        const float * O = src + 2 * ((g + ngroups) * half);
+        const int   idx = kk * step;
+        const float re =  c_mel.cosv[idx];
+        const float im = -c_mel.sinv[idx];
+        const float er = E[2 * kk], ei = E[2 * kk + 1], orr = O[2 * kk], oi = O[2 * kk + 1];
+        float * D = dst + 2 * (g * N);
+        D[2 * kk]     = fmaf(-im, oi, fmaf(re, orr, er));
+        D[2 * kk + 1] = fmaf(im, orr, fmaf(re, oi, ei));
+        if (!last || kk == 0) {          // the last stage only needs bins 0..200
+            D[2 * (kk + half)]     = fmaf(im, oi, fmaf(-re, orr, er));
+            D[2 * (kk + half) + 1] = fmaf(-im, orr, fmaf(-re, oi, ei));
+        }
+    }
+    (void) limit_k;
+}
+
+__global__ __launch_bounds__(128) void k_mel_frames(const float * __restrict__ pad, int n_valid, int n_fft_frames,
+                                                    int n_len, int n_mel, const float * __restrict__ filters,
+                                                    float * __restrict__ mel, int * __restrict__ gmax) {
+    __shared__ float xin[400];
+    __shared__ float bufA[800];
+    __shared__ float bufB[800];
+    __shared__ float pw[204];
+    const int frame = blockIdx.x;
+    const int tid = threadIdx.x;
+
+    if (frame >= n_fft_frames) {         // frames past the audio: log10(1e-10)  (W/whisper.cpp:2784-2789)
+        for (int j = tid; j < n_mel; j += 128) mel[(size_t) j * n_len + frame] = -10.0f;
+        if (tid == 0) atomicMax(gmax, enc_ordered(-10.0f));
+        return;
+    }
+
+    const int offset = frame * 160;
+    int nin = n_valid - offset; if (nin > 400) nin = 400;
+    for (int j = tid; j < 400; j += 128) xin[j] = j < nin ? c_mel.hann[j] * pad[offset + j] : 0.0f;
+    __syncthreads();
+
+    // 16 leaf DFTs of 25 points: leaf r holds x[r + 16 m]  (W/whisper.cpp:2634-2654)
+    // leaves are stored in the order the combine stages want: slot(r) with bit-reversed 4-bit r
+    for (int t = tid; t < 400; t += 128) {
+        const int r = t / 25, kk = t % 25;
+        float re = 0.0f, im = 0.0f;
+        for (int m = 0; m < 25; ++m) {
+            const int idx = (kk * m * 16) % 400;
+            const float v = xin[r + 16 * m];
+            re = fmaf(v, c_mel.cosv[idx], re);
+            im = fmaf(-v, c_mel.sinv[idx], im);
+        }
+        bufA[2 * (r * 25 + kk)]     = re;
+        bufA[2 * (r * 25 + kk) + 1] = im;
+    }
+    __syncthreads();
+    // N=50: pairs (r, r+8) -> 8 arrays of 50 indexed by r<8 ; N=100: (r, r+4) ; N=200: (r, r+2) ; N=400: (0,1)
+    butterfly_stage(bufA, bufB, 8, 50, tid, 128, false, 0);   __syncthreads();
+    butterfly_stage(bufB, bufA, 4, 100, tid, 128, false, 0);  __syncthreads();
+    butterfly_stage(bufA, bufB, 2, 200, tid, 128, false, 0);  __syncthreads();
+    butterfly_stage(bufB, bufA, 1, 400, tid, 128, true, 0);   __syncthreads();
+
+    for (int j = tid; j < 201; j += 128) {
+        const float re = bufA[2 * j], im = bufA[2 * j + 1];
+        pw[j] = fmaf(re, re, im * im);
+    }
+    __syncthreads();
+
+    float vmax = -INFINITY;
+    for (int j = tid; j < n_mel; j += 128) {
+        const float * f = filters + (size_t) j * 201;
+        double sum = 0.0;
+        int kk = 0;
+        for (; kk < 201 - 3; kk += 4) {                          // W/whisper.cpp:2759-2768
+            float g = pw[kk] * f[kk];
+            g = fmaf(pw[kk + 1], f[kk + 1], g);
+            g = fmaf(pw[kk + 2], f[kk + 2], g);
+            g = fmaf(pw[kk + 3], f[kk + 3], g);
+            sum += (double) g;
+        }
+        for (; kk < 201; ++kk) sum += (double) (pw[kk] * f[kk]);
+        sum = log10(sum > 1e-10 ? sum : 1e-10);
+        const float v = (float) sum;
+        mel[(size_t) j * n_len + frame] = v;
+        vmax = fmaxf(vmax, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    if ((tid & 63) == 0 && vmax > -INFINITY) atomicMax(gmax, enc_ordered(vmax));
+}
+
+__global__ void k_mel_normalize(float * __restrict__ mel, int n, const int * __restrict__ gmax) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double mmax = (double) dec_ordered(*gmax) - 8.0;       // W/whisper.cpp:2855-2871
+    float v = mel[i];
+    if ((double) v < mmax) v = (float) mmax;
+    mel[i] = (float) (((double) v + 4.0) / 4.0);
+}
+
+__global__ void k_mel_slice(const float * __restrict__ mel, int n_len, int n_mel, int offset, int n_frames,
+                            __half * __restrict__ out, int ld, int rows_total) {
+    // out row r <-> frame offset + r - 1 ; transposes [n_mel][n_len] -> [frame][n_mel] through LDS
+    __shared__ float tile[32][33];
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 256 threads: 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        const int fr = offset + r - 1;
+        float v = 0.0f;
+        if (c < n_mel && r >= 1 && r <= n_frames && fr < n_len && fr >= 0) v = mel[(size_t) c * n_len + fr];
+        tile[j][tx] = v;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        if (r < rows_total && c < ld) out[(size_t) r * ld + c] = __float2half_rn(c < n_mel ? tile[tx][j] : 0.0f);
+    }
+}
+
+__global__ void k_fill_zero(uint32_t * p, size_t n) {
+    size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t) gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = 0u;
+}
+
+__global__ void k_set_int(int * p, int v) { *p = v; }
+
+} // namespace
+
+void mel_pad(const float * pcm, int n_samples, float * pcm_pad, int n_pad_total, hipStream_t st) {
+    hipLaunchKernelGGL(k_mel_pad, dim3((n_pad_total + 255) / 256), dim3(256), 0, st, pcm, n_samples, pcm_pad, n_pad_total);
+}
+
+void mel_frames(const float * pcm_pad, int n_valid, int n_fft_frames, int n_len, int n_mel, const float * filters,
+                float * mel, int * gmax, hipStream_t st) {
+    std::call_once(g_tables_once, upload_tables);
+    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, gmax, INT_MIN);
+    hipLaunchKernelGGL(k_mel_frames, dim3(n_len), dim3(128), 0, st, pcm_pad, n_valid, n_fft_frames, n_len, n_mel,
+                       filters, mel, gmax);
+}
+
+void mel_normalize(float * mel, int n, const int * gmax, hipStream_t st) {
+    hipLaunchKernelGGL(k_mel_normalize, dim3((n + 255) / 256), dim3(256), 0, st, mel, n, gmax);
+}
+
+void mel_slice(const float * mel, int n_len, int n_mel, int offset, int n_frames, __half * out, int ld, int rows_total,
+               hipStream_t st) {
+    dim3 grid((rows_total + 31) / 32, (ld + 31) / 32);
+    hipLaunchKernelGGL(k_mel_slice, grid, dim3(256), 0, st, mel, n_len, n_mel, offset, n_frames, out, ld, rows_total);
+}
+
+void fill_zero(void * p, size_t bytes, hipStream_t st) {
+    (void) hipMemsetAsync(p, 0, bytes, st);
+}
+
+}} // namespace wmi::k

@@ -1,0 +1,85 @@
+// Launch prototypes of the gfx950 kernels (definitions in k_*.hip).
+// Conventions: activations are token-major ([row][feature], feature contiguous); every matrix
+// operand is K-contiguous; f16 = IEEE half (the reference's rounding points).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <cstdint>
+
+namespace wmi { namespace k {
+
+// ---------------------------------------------------------------- mel (k_mel.hip)
+// pcm_pad: [200 reflect | n_samples | zeros] ; frames [0, n_fft_frames) get an FFT, the rest up to
+// n_len the constant log10(1e-10).  mel: [n_mel][n_len] f32.  gmax: ordered-int encoded running max.
+void mel_pad(const float * pcm, int n_samples, float * pcm_pad, int n_pad_total, hipStream_t st);
+void mel_frames(const float * pcm_pad, int n_valid, int n_fft_frames, int n_len, int n_mel,
+                const float * filters, float * mel, int * gmax, hipStream_t st);
+void mel_normalize(float * mel, int n, const int * gmax, hipStream_t st);
+// token-major f16 slice for the conv front-end: out[r][c], r in [0, rows_total), row r holds frame
+// (offset + r - 1); rows outside [1, n_frames] and frames >= n_len are zero.
+void mel_slice(const float * mel, int n_len, int n_mel, int offset, int n_frames, __half * out, int ld,
+               int rows_total, hipStream_t st);
+
+// ---------------------------------------------------------------- GEMM (k_gemm.hip)
+enum Epi : int {
+    EPI_F16_BIAS = 0,       // C f16 = acc + bias
+    EPI_F16_BIAS_GELU,      // C f16 = gelu16(acc + bias)
+    EPI_F32_BIAS_RESID,     // C f32 = acc + bias + resid
+    EPI_CONV2,              // x f32 = gelu16(acc + bias) + pe ; aux f32 = gelu16(acc + bias)
+    EPI_QKV_ENC,            // q | k | v^T split (encoder)
+    EPI_QKV_DEC,            // q*s | k*s -> cache | v -> cache (decoder self-attention)
+    EPI_CROSS_KV,           // per decoder layer: k*s | v+b into the cross cache
+    EPI_Q_SCALED,           // C f16 = (acc + bias) * scale  (decoder cross-attention query)
+};
+struct GemmArgs {
+    const __half * A;  int lda;     // [M][K]
+    const __half * W;  int ldw;     // [N][K]
+    int M, N, K;                    // K multiple of 32 (weights zero-padded)
+    const float * bias;             // [N] or null
+    void *  C;   int ldc;           // primary output
+    const float * resid; int ldr;   // EPI_F32_BIAS_RESID / EPI_CONV2 (pe)
+    void *  aux; int ldaux;         // second output (EPI_CONV2: embd_conv; QKV: k / cache k)
+    void *  aux2; int ldaux2;       // third output (QKV: v^T / cache v)
+    float   scale;                  // q/k scale
+    int     S;                      // split width for the QKV / cross epilogues
+    int64_t layer_stride;           // EPI_CROSS_KV: elements between layers in the cross cache
+};
+void gemm(int epi, const GemmArgs & a, hipStream_t st);
+
+// ---------------------------------------------------------------- LayerNorm (k_norm.hip)
+// y = (x - mean) / sqrt(var + eps) * g + b ; one wave per row. out16 and/or out32 may be null.
+void layernorm(const float * x, int rows, int S, const float * g, const float * b, float eps,
+               __half * out16, float * out32, hipStream_t st);
+
+// ---------------------------------------------------------------- attention (k_attn.hip)
+// encoder: q,k [T][S] f16 ; vt [S][Tpad] f16 ; out [T][S] f16 ; scale applied to q.k before softmax
+void attn_encoder(const __half * q, const __half * k, const __half * vt, int T, int Tpad, int S, int H,
+                  float scale, __half * out, hipStream_t st);
+// decoder: one (token, head) per workgroup.  kc/vc: [n_kv][S] caches (this layer), mask: [n][ld_mask] or null
+void attn_decoder(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int n_kv,
+                  const float * mask, int ld_mask, __half * out, hipStream_t st);
+
+// ---------------------------------------------------------------- decoder small-batch (k_dec.hip)
+void dec_embed(const int32_t * tokens, const int32_t * pos, int n, int S, const __half * te, const float * pe,
+               float * x, hipStream_t st);
+// rows <= 8 "GEMV" path: out[i][o] = sum_k W[o][k] * a[i][k] with the same epilogues as the GEMM.
+// If ln_g != null the A operand is LayerNorm(x32) computed in the prologue (fused), else a16.
+struct GemvArgs {
+    const float * x32; const float * ln_g; const float * ln_b; float eps;   // fused-LN input [n][K]
+    const __half * a16;                                                     // or plain f16 input [n][K]
+    int n, K, N;
+    const __half * W; const float * bias;
+    int epi;                                  // Epi (F16_BIAS, F16_BIAS_GELU, F32_BIAS_RESID, QKV_DEC, Q_SCALED) or EPI_LOGITS
+    void * C; int ldc;
+    const float * resid; int ldr;
+    void * aux; int ldaux; void * aux2; int ldaux2;
+    float scale; int S;
+    const int32_t * rows;                     // optional row gather for the A operand (logits)
+};
+enum { EPI_LOGITS = 100 };                    // C f32 [n][N] = acc
+void gemv(const GemvArgs & a, hipStream_t st);
+
+// misc
+void fill_zero(void * p, size_t bytes, hipStream_t st);
+
+}} // namespace wmi::k

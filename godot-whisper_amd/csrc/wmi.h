@@ -1,0 +1,238 @@
+// Internal header of libwhisper_mi355.so: host-side model/state structs and the launch
+// prototypes of the gfx950 kernels.  Nothing here is ABI; the ABI is include/*.h.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <map>
+#include <random>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "../../include/whisper_mi355.h"
+#include "../../include/wmi_device.h"
+
+namespace wmi {
+
+// ---------------------------------------------------------------- logging / errors
+void log_msg(ggml_log_level lvl, const char * fmt, ...) __attribute__((format(printf, 2, 3)));
+#define WMI_ERR(...)  ::wmi::log_msg(GGML_LOG_LEVEL_ERROR, __VA_ARGS__)
+#define WMI_WARN(...) ::wmi::log_msg(GGML_LOG_LEVEL_WARN,  __VA_ARGS__)
+#define WMI_INFO(...) ::wmi::log_msg(GGML_LOG_LEVEL_INFO,  __VA_ARGS__)
+
+bool hip_ok(hipError_t e, const char * what, const char * file, int line);
+#define HIP_OK(expr) ::wmi::hip_ok((expr), #expr, __FILE__, __LINE__)
+// use inside functions returning bool
+#define HIP_TRY(expr) do { if (!HIP_OK(expr)) return false; } while (0)
+
+int64_t time_us();
+
+// ---------------------------------------------------------------- model (host view)
+struct HParams {            // W/whisper.cpp:537-550
+    int32_t n_vocab = 51864, n_audio_ctx = 1500, n_audio_state = 384, n_audio_head = 6, n_audio_layer = 4;
+    int32_t n_text_ctx = 448, n_text_state = 384, n_text_head = 6, n_text_layer = 4, n_mels = 80, ftype = 1;
+    float   eps = 1e-5f;
+};
+
+struct Vocab {              // W/whisper.cpp:365-394
+    int n_vocab = 51864;
+    std::map<std::string, int32_t> token_to_id;
+    std::vector<std::string>       id_to_token;   // dense: ids are 0..n_vocab-1
+    int32_t eot = 50256, sot = 50257, translate = 50357, transcribe = 50358, solm = 50359,
+            prev = 50360, nosp = 50361, not_ = 50362, beg = 50363;
+    bool is_multilingual() const { return n_vocab >= 51865; }
+    int  num_languages()   const { return n_vocab - 51765 - (is_multilingual() ? 1 : 0); }
+};
+
+// a tensor record of the ggml file: where its payload sits in the caller's buffer
+struct FileTensor {
+    std::string name;
+    int32_t     ttype = 0;          // ggml_type
+    int32_t     n_dims = 0;
+    int64_t     ne[4] = {1, 1, 1, 1};
+    size_t      offset = 0, nbytes = 0;
+};
+
+struct ModelFile {
+    HParams hp;
+    int     model_type = 0;         // e_model: 0 unknown, 1 tiny, 2 base, 3 small, 4 medium, 5 large
+    int     n_filt_mel = 0, n_filt_fft = 0;
+    std::vector<float> filters;     // [n_mel][n_fft]
+    Vocab   vocab;
+    std::map<std::string, FileTensor> tensors;
+    int     n_loaded = 0;
+};
+
+// parse header + vocab + tensor directory out of an in-memory ggml file (W/whisper.cpp:1102-1640)
+bool parse_model(const uint8_t * buf, size_t n, ModelFile & mf);
+
+// ---------------------------------------------------------------- weights (device view)
+// All matrices are f16, row-major [out][in] with `in` contiguous (the ggml ne0 order), which is
+// the K-contiguous "B^T" operand layout of the MFMA GEMM.  Vectors are f32.
+struct EncLayerW {
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
+    const __half *w_qkv;  const float *b_qkv;    // [3S][S]; rows q | k | v; k-bias = 0
+    const __half *w_o;    const float *b_o;      // [S][S]
+    const __half *w_fc1;  const float *b_fc1;    // [4S][S]
+    const __half *w_fc2;  const float *b_fc2;    // [S][4S]
+};
+struct DecLayerW {
+    const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *ln3_g, *ln3_b;
+    const __half *w_qkv;  const float *b_qkv;    // self-attn [3S][S]
+    const __half *w_o;    const float *b_o;
+    const __half *w_cq;   const float *b_cq;     // cross-attn query [S][S]
+    const __half *w_co;   const float *b_co;
+    const __half *w_fc1;  const float *b_fc1;
+    const __half *w_fc2;  const float *b_fc2;
+};
+struct Weights {
+    void *  arena = nullptr;  size_t arena_bytes = 0;
+    // conv front-end, weights re-laid as [oc][k][ic] (+ zero pad to a multiple of 32) for the
+    // overlapped-row implicit GEMM
+    const __half *conv1_w; const float *conv1_b; int conv1_k = 0;     // K (padded)
+    const __half *conv2_w; const float *conv2_b; int conv2_k = 0;
+    const float  *e_pe;                                               // [n_audio_ctx][S]
+    std::vector<EncLayerW> enc;
+    const float  *e_ln_g, *e_ln_b;
+    // cross-attention K/V projections of all decoder layers stacked: [L][2S][S] (k rows, v rows)
+    const __half *w_ckv;   const float *b_ckv;                        // bias [L][2S] (k part 0)
+    const float  *d_pe;                                               // [n_text_ctx][S]
+    const __half *d_te;                                               // [n_vocab][S]
+    std::vector<DecLayerW> dec;
+    const float  *d_ln_g, *d_ln_b;
+    const float  *mel_filters;                                        // [n_mel][201]
+};
+
+// src selects where tensor payloads are read from: a host pointer (H2D copies) or a device image
+// of the same ggml file (D2D, used after an RCCL broadcast of the file image).
+bool upload_weights(const ModelFile & mf, const uint8_t * host_buf, const void * dev_image, Weights & w, hipStream_t st);
+void free_weights(Weights & w);
+
+// ---------------------------------------------------------------- KV cache bookkeeping (host)
+struct KVCell { int32_t pos = -1; std::set<int32_t> seq; bool has(int32_t s) const { return seq.count(s) != 0; } };
+struct KVCache {                                     // W/whisper.cpp:639-664
+    uint32_t head = 0, size = 0, n = 0;
+    std::vector<KVCell> cells;
+    __half * k = nullptr;  __half * v = nullptr;     // device: [L][size][S] each
+};
+struct Batch {                                       // W/whisper.cpp:407-415
+    std::vector<int32_t> token, pos, seq_id; std::vector<int8_t> logits;
+    int n_tokens = 0;
+    void prep_legacy(const int32_t * tokens, int n, int n_past, int seq);
+};
+bool  kv_find_slot(KVCache & c, const Batch & b);
+int   kv_cell_max(const KVCache & c);
+void  kv_clear(KVCache & c);
+void  kv_seq_rm(KVCache & c, int32_t seq, int32_t p0, int32_t p1);
+void  kv_seq_cp(KVCache & c, int32_t src, int32_t dst, int32_t p0, int32_t p1);
+
+// ---------------------------------------------------------------- decode-time structs
+struct Sequence {
+    std::vector<whisper_token_data> tokens;
+    int    result_len = 0;
+    double sum_logprobs_all = 0, sum_logprobs = 0, avg_logprobs = 0, entropy = 0, score = 0;
+};
+struct Decoder {
+    Sequence sequence;
+    int  i_batch = 0, seek_delta = 0;
+    bool failed = false, completed = false, has_ts = false;
+    std::vector<float> probs, logits, logprobs;
+    std::mt19937 rng{0};
+};
+struct Segment { int64_t t0, t1; std::string text; std::vector<whisper_token_data> tokens; bool speaker_turn_next; };
+
+struct Mel { int n_len = 0, n_len_org = 0, n_mel = 0; };
+
+// device scratch for one in-flight chunk; sized at init for the model's maxima
+struct DeviceState {
+    hipStream_t stream = nullptr;
+    // mel
+    float * pcm = nullptr;      size_t pcm_cap = 0;          // padded PCM
+    float * mel = nullptr;      size_t mel_cap = 0;          // [n_mel][n_len] f32 (reference layout)
+    float * mel_max = nullptr;                                // 1 float (ordered-int encoded)
+    // encoder activations, token-major
+    __half * mel_t = nullptr;                                 // [2T+2+pad][n_mel_pad] f16, rows -1 and 2T are zero
+    __half * conv1 = nullptr;                                 // [2T+2][S] f16 (row 0 and 2T+1 zero)
+    float  * x     = nullptr;                                 // [T][S] f32 residual stream
+    float  * embd_conv = nullptr;                             // [T][S] f32 (kept for inspection)
+    __half * xn    = nullptr;                                 // [T][S] f16 LN output
+    __half * q     = nullptr, * k = nullptr;                  // [T][S] f16
+    __half * vt    = nullptr;                                 // [S][Tpad] f16 (V transposed, per head rows)
+    __half * att   = nullptr;                                 // [T][S] f16
+    __half * h     = nullptr;                                 // [T][4S] f16
+    float  * rowmax = nullptr;                                // [H][T] f32 (attention pass A)
+    float  * enc_out = nullptr;                               // [T][S] f32  (embd_enc)
+    __half * enc_out_h = nullptr;                             // [T][S] f16
+    __half * kvc_k = nullptr, * kvc_v = nullptr;              // cross cache [L][T][S] each
+    int      Tpad = 0;
+    // decoder activations (n <= n_text_ctx)
+    int32_t * d_tokens = nullptr, * d_pos = nullptr;          // [n]
+    float   * d_mask = nullptr;                               // [n][n_kv_max]
+    int32_t * d_rows = nullptr;                               // rows flagged for logits
+    float  * dx = nullptr;  __half * dxn = nullptr, * dq = nullptr, * datt = nullptr, * dh = nullptr;
+    float  * logits = nullptr;  int logits_rows_cap = 0;      // [rows][n_vocab]
+    void   * pinned = nullptr;  size_t pinned_bytes = 0;      // host staging (tokens/pos/mask/logits)
+};
+
+struct State {
+    int64_t t_sample_us = 0, t_encode_us = 0, t_decode_us = 0, t_batchd_us = 0, t_prompt_us = 0, t_mel_us = 0;
+    int32_t n_sample = 0, n_encode = 0, n_decode = 0, n_batchd = 0, n_prompt = 0, n_fail_p = 0, n_fail_h = 0;
+    KVCache kv_self;
+    Mel     mel;
+    Batch   batch;
+    Decoder decoders[8];
+    std::vector<float> logits;                    // [n_tokens][n_vocab] host copy (flagged rows only)
+    std::vector<Segment> result_all;
+    std::vector<int32_t> prompt_past;
+    int     lang_id = 0;
+    int64_t t_beg = 0, t_last = 0; int32_t tid_last = 0;
+    std::vector<float> energy;
+    int32_t exp_n_audio_ctx = 0;
+    int     enc_n_ctx = 0;                        // n_ctx of the last encode (cross cache extent)
+    DeviceState dev;
+};
+
+} // namespace wmi
+
+struct whisper_context {
+    int64_t t_load_us = 0, t_start_us = 0;
+    whisper_context_params params{};
+    wmi::ModelFile model;
+    wmi::Weights   w;
+    wmi::State *   state = nullptr;
+    int            device = 0;
+};
+
+namespace wmi {
+
+bool init_state(whisper_context & ctx);
+void free_state(whisper_context & ctx);
+
+// hot path (device)
+bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, bool samples_on_device);
+bool set_mel(whisper_context & ctx, const float * data, int n_len, int n_mel);
+bool encode(whisper_context & ctx, int mel_offset);
+bool decode(whisper_context & ctx, const Batch & batch);
+
+// host logic (logits filters, sampling, driver)
+void process_logits(whisper_context & ctx, Decoder & dec, const whisper_full_params & params, float temperature);
+whisper_token_data sample_token(whisper_context & ctx, Decoder & dec, bool best);
+std::vector<whisper_token_data> sample_token_topk(whisper_context & ctx, Decoder & dec, int k);
+void sequence_score(const whisper_full_params & params, Sequence & seq);
+std::vector<int32_t> tokenize(const Vocab & vocab, const std::string & text);
+int  lang_auto_detect(whisper_context & ctx, int offset_ms, float * lang_probs);
+int  full(whisper_context & ctx, whisper_full_params params, const float * samples, const float * d_samples, int n_samples);
+std::vector<float> signal_energy(const float * signal, int n_samples, int hw);
+void token_level_timestamps(whisper_context & ctx, int i_segment, float thold_pt, float thold_ptsum);
+int  wrap_segment(whisper_context & ctx, int max_len, bool split_on_word);
+
+int         lang_id(const char * lang);
+const char *lang_str(int id);
+int         lang_max_id();
+int         lang_count();
+
+} // namespace wmi

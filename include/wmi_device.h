@@ -1,0 +1,81 @@
+/*
+ * wmi_device.h — the thin device-level C ABI of libwhisper_mi355.so (new in this repository).
+ *
+ * whisper.h hands the library HOST buffers (the Godot host owns PackedFloat32Array /
+ * PackedByteArray).  The entry points below are what a batching front end, the bench and the
+ * parity tests bind: PCM that is already resident in HBM, access to the tensors the reference
+ * keeps in its `whisper_state` (W/whisper.cpp:769-844), and the per-stage timers.
+ * Shape follows the reference's encoder-plugin precedent
+ * (W/openvino/whisper-openvino-encoder.h:12-27, W/coreml/whisper-encoder.h:14-22):
+ * init / encode / free with plain pointers and sizes.  No torch types, no C++ types.
+ */
+#ifndef WMI_DEVICE_H
+#define WMI_DEVICE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "whisper_mi355.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Library / device identification; aborts nothing, returns 0 on a box without a usable GPU. */
+WHISPER_API int          wmi_device_count(void);
+WHISPER_API const char * wmi_version(void);
+
+/* Like whisper_init_from_buffer_with_params but pins the context to HIP device `device`
+ * (one process per GPU: pass LOCAL_RANK).  replaces: W/whisper.h:151 for multi-GPU hosts. */
+WHISPER_API struct whisper_context * wmi_init_from_buffer_on_device(const void * buffer, size_t buffer_size, int device);
+
+/* PCM already in HBM (f32 mono 16 kHz, device pointer on the context's device) -> log-mel in the
+ * context.  replaces: whisper_pcm_to_mel (W/whisper.h:240) when the samples never touch the host. */
+WHISPER_API int wmi_pcm_to_mel_device(struct whisper_context * ctx, const float * d_samples, int n_samples);
+
+/* whisper_full over device-resident PCM: identical control flow and results, minus the H2D copy.
+ * `h_samples_for_timestamps` may be NULL unless params.token_timestamps is set (the timestamp
+ * heuristics read the waveform on the host, W/whisper.cpp:5003-5010). */
+WHISPER_API int wmi_full_device_pcm(struct whisper_context * ctx, struct whisper_full_params params,
+                                    const float * d_samples, int n_samples, const float * h_samples_for_timestamps);
+
+/* Copy an internal tensor out as f32 (f16 tensors are widened).  Returns the element count, or -1 for
+ * an unknown name; with dst == NULL only reports the count.  Names and layouts (row-major):
+ *   "mel"        [n_mel][n_len]                 log-mel (W/whisper.cpp:2779)
+ *   "embd_conv"  [n_ctx][n_state]               conv front-end output (reference holds the transpose)
+ *   "embd_enc"   [n_ctx][n_state]               encoder output
+ *   "cross_k"    [n_text_layer][n_ctx][n_state] cross-attention keys (pre-scaled by d^-1/4)
+ *   "cross_v"    [n_text_layer][n_ctx][n_state] cross-attention values (reference holds [state][ctx])
+ *   "self_k" / "self_v"  [n_text_layer][3*n_text_ctx][n_state]
+ *   "enc_x"      [n_ctx][n_state]               residual stream after the last encoder block
+ */
+WHISPER_API int wmi_get_tensor(struct whisper_context * ctx, const char * name, float * dst, int n);
+WHISPER_API int wmi_mel_dims(struct whisper_context * ctx, int * n_len, int * n_len_org, int * n_mel);
+
+/* Stage timers in microseconds, the reference's counters (W/whisper.cpp:770-783):
+ * t[0..5] = mel, encode, decode, batchd, prompt, sample ; n[0..4] = n_encode, n_decode, n_batchd, n_prompt, n_sample */
+WHISPER_API void wmi_get_timings(struct whisper_context * ctx, int64_t * t6, int32_t * n5);
+
+/* The context's HIP stream (as void*), so a caller can order its own work / events against the hot path. */
+WHISPER_API void * wmi_stream(struct whisper_context * ctx);
+
+/* Host-logic probes used by the parity tests (same decisions as the reference given the same logits). */
+WHISPER_API int wmi_process_logits(struct whisper_context * ctx, struct whisper_full_params params, const float * raw_logits,
+                                   const whisper_token * hist, int n_hist, int has_ts, int seek_delta, float temperature,
+                                   float * out_logits, float * out_logprobs, float * out_probs);
+WHISPER_API int wmi_sample_draws(struct whisper_context * ctx, const float * probs, const float * logprobs, int n_draw,
+                                 int reseed, whisper_token_data * out);
+
+/* Kernel micro-benchmarks on synthetic operands (used by bench.py for the roofline line):
+ * runs `iters` launches on the context stream between two HIP events, returns average microseconds.
+ *   which = 0  encoder MLP-0 GEMM  [T x 4S x S] f16 MFMA   (flops = 2*T*4S*S)
+ *   which = 1  logits GEMV         [n_vocab x S] weight stream (bytes = n_vocab*S*2)
+ *   which = 2  encoder attention   one layer
+ *   which = 3  full encode (conv + L blocks + cross) — same as whisper_encode without the host sync per call
+ */
+WHISPER_API double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* WMI_DEVICE_H */

@@ -1,0 +1,38 @@
+import pathlib
+import sys
+
+import pytest
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+import __graft_entry__ as entry  # noqa: E402
+
+entry.load_package()
+entry.load_oracle()
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def product_lib():
+    from godot_whisper_amd import runtime
+    lib = runtime.require_gpu()
+    runtime.silence_logs(lib)
+    return lib
+
+
+@pytest.fixture(scope="session")
+def ref_lib():
+    from oracle import reflib
+    if not reflib.available():
+        pytest.skip("oracle/_ref/libwhisper_ref.so not built (make -C oracle ref needs /root/reference)")
+    lib = reflib.lib()
+    import ctypes as C
+    from godot_whisper_amd import abi
+    cb = abi.ggml_log_callback(lambda lvl, txt, ud: None)
+    lib.whisper_log_set(C.cast(cb, C.c_void_p), None)
+    lib._cb = cb
+    return lib

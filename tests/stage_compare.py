@@ -1,0 +1,191 @@
+"""Stage-by-stage comparison of the HIP path against a checker (compiled reference or the port).
+Importable helper + CLI:  python tests/stage_compare.py [shape] [seconds] [audio_ctx]"""
+from __future__ import annotations
+
+import ctypes as C
+import sys
+import time
+
+import numpy as np
+
+
+def _fptr(a):
+    return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def err_stats(a: np.ndarray, b: np.ndarray) -> dict:
+    a = a.astype(np.float64).ravel(); b = b.astype(np.float64).ravel()
+    d = np.abs(a - b)
+    scale = max(float(np.sqrt(np.mean(b * b))), 1e-30)
+    return {"max_abs": float(d.max()), "rms_rel": float(np.sqrt(np.mean(d * d)) / scale),
+            "ref_rms": scale, "argmax": int(d.argmax())}
+
+
+class RefSide:
+    """Drives oracle/_ref/libwhisper_ref.so and returns tensors in the PRODUCT's layouts."""
+
+    def __init__(self, lib, model_bytes: bytes):
+        from godot_whisper_amd import abi
+        self.lib = lib
+        buf = C.create_string_buffer(model_bytes, len(model_bytes))
+        self.ctx = lib.whisper_init_from_buffer_with_params(C.cast(buf, C.c_void_p), len(model_bytes),
+                                                            abi.whisper_context_params(False))
+        assert self.ctx
+        self.S = lib.whisper_model_n_audio_state(self.ctx)
+        self.L = lib.whisper_model_n_text_layer(self.ctx)
+        self.NV = lib.whisper_n_vocab(self.ctx)
+        self.n_audio_ctx = lib.whisper_n_audio_ctx(self.ctx)
+
+    def close(self):
+        self.lib.whisper_free(self.ctx); self.ctx = None
+
+    def mel(self, pcm):
+        assert self.lib.whisper_pcm_to_mel(self.ctx, _fptr(pcm), pcm.size, 4) == 0
+        n_len, n_org, n_mel = C.c_int(), C.c_int(), C.c_int()
+        n = self.lib.ref_mel_dims(self.ctx, C.byref(n_len), C.byref(n_org), C.byref(n_mel))
+        out = np.empty(n, np.float32)
+        self.lib.ref_mel_copy(self.ctx, _fptr(out), n)
+        return out.reshape(n_mel.value, n_len.value), n_org.value
+
+    def encode(self, offset=0, audio_ctx=0):
+        self.lib.ref_set_audio_ctx(self.ctx, audio_ctx)
+        assert self.lib.whisper_encode(self.ctx, offset, 4) == 0
+        T = audio_ctx if audio_ctx > 0 else self.n_audio_ctx
+        S, L = self.S, self.L
+        conv = np.empty(T * S, np.float32); self.lib.ref_embd_conv(self.ctx, _fptr(conv), conv.size)
+        enc = np.empty(T * S, np.float32); self.lib.ref_embd_enc(self.ctx, _fptr(enc), enc.size)
+        nk = self.lib.ref_kv_copy(self.ctx, 0, None, 0)
+        k16 = np.empty(nk, np.uint16); v16 = np.empty(nk, np.uint16)
+        self.lib.ref_kv_copy(self.ctx, 0, k16.ctypes.data_as(C.POINTER(C.c_uint16)), nk)
+        self.lib.ref_kv_copy(self.ctx, 1, v16.ctypes.data_as(C.POINTER(C.c_uint16)), nk)
+        k = k16.view(np.float16)[: L * T * S].astype(np.float32).reshape(L, T, S)
+        v = v16.view(np.float16)[: L * T * S].astype(np.float32).reshape(L, S, T).transpose(0, 2, 1)
+        return {"embd_conv": conv.reshape(S, T).T.copy(), "embd_enc": enc.reshape(T, S),
+                "cross_k": k, "cross_v": np.ascontiguousarray(v)}
+
+    def decode(self, tokens, n_past):
+        t = np.asarray(tokens, np.int32)
+        assert self.lib.whisper_decode(self.ctx, t.ctypes.data_as(C.POINTER(C.c_int32)), t.size, n_past, 4) == 0
+        lp = self.lib.whisper_get_logits(self.ctx)
+        full = np.ctypeslib.as_array(lp, shape=(t.size * self.NV,)).reshape(t.size, self.NV)
+        return full[-1].copy()
+
+
+class ProductSide:
+    def __init__(self, lib, model_bytes: bytes):
+        from godot_whisper_amd import abi
+        self.lib = lib
+        buf = C.create_string_buffer(model_bytes, len(model_bytes))
+        self.ctx = lib.whisper_init_from_buffer_with_params(C.cast(buf, C.c_void_p), len(model_bytes),
+                                                            abi.whisper_context_params(True))
+        assert self.ctx, "product init failed"
+        self.S = lib.whisper_model_n_audio_state(self.ctx)
+        self.L = lib.whisper_model_n_text_layer(self.ctx)
+        self.NV = lib.whisper_n_vocab(self.ctx)
+        self.n_audio_ctx = lib.whisper_n_audio_ctx(self.ctx)
+
+    def close(self):
+        self.lib.whisper_free(self.ctx); self.ctx = None
+
+    def tensor(self, name):
+        from godot_whisper_amd import runtime
+        return runtime.get_tensor(self.lib, self.ctx, name)
+
+    def mel(self, pcm):
+        assert self.lib.whisper_pcm_to_mel(self.ctx, _fptr(pcm), pcm.size, 4) == 0
+        n_len, n_org, n_mel = C.c_int(), C.c_int(), C.c_int()
+        self.lib.wmi_mel_dims(self.ctx, C.byref(n_len), C.byref(n_org), C.byref(n_mel))
+        return self.tensor("mel").reshape(n_mel.value, n_len.value), n_org.value
+
+    def set_mel(self, mel):
+        m = np.ascontiguousarray(mel, np.float32)
+        assert self.lib.whisper_set_mel(self.ctx, _fptr(m), m.shape[1], m.shape[0]) == 0
+
+    def encode(self, offset=0, audio_ctx=0):
+        # whisper_full sets exp_n_audio_ctx; for the bare encode call use a 1-sample-free path:
+        if audio_ctx:
+            from godot_whisper_amd import abi
+            p = self.lib.whisper_full_default_params(0)
+            p.audio_ctx = audio_ctx; p.duration_ms = 10  # < 1 s: returns right after storing audio_ctx
+            self.lib.whisper_full(self.ctx, p, None, 0)
+        assert self.lib.whisper_encode(self.ctx, offset, 4) == 0
+        T = audio_ctx if audio_ctx > 0 else self.n_audio_ctx
+        S, L = self.S, self.L
+        return {"embd_conv": self.tensor("embd_conv").reshape(T, S), "embd_enc": self.tensor("embd_enc").reshape(T, S),
+                "cross_k": self.tensor("cross_k").reshape(L, T, S), "cross_v": self.tensor("cross_v").reshape(L, T, S)}
+
+    def decode(self, tokens, n_past):
+        t = np.asarray(tokens, np.int32)
+        assert self.lib.whisper_decode(self.ctx, t.ctypes.data_as(C.POINTER(C.c_int32)), t.size, n_past, 4) == 0
+        lp = self.lib.whisper_get_logits(self.ctx)
+        full = np.ctypeslib.as_array(lp, shape=(t.size * self.NV,)).reshape(t.size, self.NV)
+        return full[-1].copy()
+
+
+def compare_stages(prod: ProductSide, ref: RefSide, pcm, audio_ctx=0, n_steps=6, feed_ref_mel=False, log=print):
+    """Returns {stage: err_stats}.  Stages isolate kernels: the encoder can be fed the checker's mel."""
+    out = {}
+    mel_r, org_r = ref.mel(pcm)
+    mel_p, org_p = prod.mel(pcm)
+    assert mel_r.shape == mel_p.shape and org_r == org_p, (mel_r.shape, mel_p.shape, org_r, org_p)
+    out["mel"] = err_stats(mel_p, mel_r)
+    if feed_ref_mel:
+        prod.set_mel(mel_r)
+    er = ref.encode(0, audio_ctx)
+    ep = prod.encode(0, audio_ctx)
+    for k in ("embd_conv", "embd_enc", "cross_k", "cross_v"):
+        out[k] = err_stats(ep[k], er[k])
+    sot = ref.lib.whisper_token_sot(ref.ctx)
+    toks = [sot]
+    lr = ref.decode(toks, 0); lpd = prod.decode(toks, 0)
+    out["logits_prompt"] = err_stats(lpd, lr)
+    agree = 0
+    for i in range(n_steps):
+        nxt = int(np.argmax(lr[:50256]))
+        lr = ref.decode([nxt], len(toks) + i); lpd = prod.decode([nxt], len(toks) + i)
+        st = err_stats(lpd, lr)
+        out[f"logits_step{i}"] = st
+        agree += int(np.argmax(lr) == np.argmax(lpd))
+    out["argmax_agree"] = {"steps": n_steps, "agree": agree}
+    # a multi-token batch (prompt path, MFMA GEMM when > 8 rows)
+    many = [sot] + [int(x) for x in (np.arange(11) * 997 + 1000)]
+    lr = ref.decode(many, 0); lpd = prod.decode(many, 0)
+    out["logits_batch12"] = err_stats(lpd, lr)
+    if log:
+        for k, v in out.items():
+            log(f"{k:16s} {v}")
+    return out
+
+
+def main():
+    import pathlib
+    sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent.parent))
+    import __graft_entry__ as entry
+    entry.load_package(); entry.load_oracle()
+    from godot_whisper_amd import runtime, synth, host
+    from oracle import reflib
+    shape = sys.argv[1] if len(sys.argv) > 1 else "micro.en"
+    secs = float(sys.argv[2]) if len(sys.argv) > 2 else 30.0
+    actx = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    lib = runtime.require_gpu()
+    print(lib.whisper_print_system_info().decode())
+    rl = reflib.lib()
+    mb = synth.make_model(shape, seed=1234)
+    pcm = synth.make_pcm(secs, seed=1234)
+    t0 = time.time(); prod = ProductSide(lib, mb); print("product init", round(time.time() - t0, 3), "s")
+    ref = RefSide(rl, mb)
+    compare_stages(prod, ref, pcm, audio_ctx=actx)
+    print("--- encoder fed with the checker's mel")
+    compare_stages(prod, ref, pcm, audio_ctx=actx, feed_ref_mel=True, n_steps=2)
+    # end-to-end through the host mirror
+    for name, L in (("ref", rl), ("product", lib)):
+        node = host.SpeechToText(L); node.set_language_model(mb)
+        t0 = time.time(); r = node.transcribe(pcm, "", actx); dt = time.time() - t0
+        print(name, "transcribe %.1f ms" % (dt * 1e3), r[0][:80] if r else None)
+        print("   ", [(d["id"], round(d["p"], 4), d["t0"], d["t1"]) for d in r[1:]])
+        node.close()
+    prod.close(); ref.close()
+
+
+if __name__ == "__main__":
+    main()
