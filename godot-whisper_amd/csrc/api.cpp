@@ -273,6 +273,12 @@ int wmi_full_device_pcm(struct whisper_context * ctx, struct whisper_full_params
     return full(*ctx, params, h_samples, d_samples, n_samples);
 }
 
+int wmi_set_audio_ctx(struct whisper_context * ctx, int n_audio_ctx) {
+    if (n_audio_ctx < 0 || n_audio_ctx > ctx->model.hp.n_audio_ctx) return -5;
+    ctx->state->exp_n_audio_ctx = n_audio_ctx;
+    return 0;
+}
+
 int wmi_mel_dims(struct whisper_context * ctx, int * n_len, int * n_len_org, int * n_mel) {
     const Mel & m = ctx->state->mel;
     if (n_len) *n_len = m.n_len; if (n_len_org) *n_len_org = m.n_len_org; if (n_mel) *n_mel = m.n_mel;
@@ -341,6 +347,75 @@ int wmi_sample_draws(struct whisper_context * ctx, const float * probs, const fl
     if (reseed) d.rng = std::mt19937(0);
     for (int i = 0; i < n_draw; ++i) out[i] = sample_token(*ctx, d, false);
     return n_draw;
+}
+
+// Kernel-level cross-check: run one decoder projection of layer `layer` through BOTH implementations
+// (weight-streaming GEMV and MFMA GEMM) on the same n <= 8 random activation rows and report the
+// largest absolute difference over every output (q, cache k, cache v / f16 / f32 results).
+double wmi_selftest_proj(struct whisper_context * ctx, int op, int n, int layer) {
+    (void) hipSetDevice(ctx->device);
+    State & st = *ctx->state; DeviceState & d = st.dev; const HParams & hp = ctx->model.hp;
+    const DecLayerW & l = ctx->w.dec[layer];
+    const int S = hp.n_text_state;
+    hipStream_t s = d.stream;
+    if (n < 1 || n > 8) return -1.0;
+    // inputs: x (f32 residual) and a16 (f16 activations, also used as the 4S-wide MLP input)
+    std::vector<float> hx((size_t) n * S); std::vector<__half> ha((size_t) n * 4 * S);
+    std::mt19937 rng(1234 + op); std::normal_distribution<float> nd(0.f, 1.f);
+    for (auto & v : hx) v = nd(rng);
+    for (auto & v : ha) v = __float2half_rn(nd(rng));
+    float * x0 = nullptr; __half * a16 = nullptr; __half * o16[2][3] = {}; float * o32[2] = {};
+    bool ok = HIP_OK(hipMalloc((void **) &x0, hx.size() * 4)) && HIP_OK(hipMalloc((void **) &a16, ha.size() * 2));
+    for (int v = 0; v < 2 && ok; ++v) {
+        for (int t = 0; t < 3 && ok; ++t) ok = HIP_OK(hipMalloc((void **) &o16[v][t], (size_t) n * 4 * S * 2)) && HIP_OK(hipMemset(o16[v][t], 0, (size_t) n * 4 * S * 2));
+        ok = ok && HIP_OK(hipMalloc((void **) &o32[v], (size_t) n * S * 4));
+    }
+    if (!ok) return -1.0;
+    (void) hipMemcpy(a16, ha.data(), ha.size() * 2, hipMemcpyHostToDevice);
+    const float kq = powf((float) S / hp.n_text_head, -0.25f);
+    for (int v = 0; v < 2; ++v) {
+        (void) hipMemcpy(x0, hx.data(), hx.size() * 4, hipMemcpyHostToDevice);
+        (void) hipMemcpy(o32[v], hx.data(), hx.size() * 4, hipMemcpyHostToDevice);      // residual input = x
+        int epi = 0, K = S, N = S; const float * lg = nullptr, * lb = nullptr; const __half * W = nullptr; const float * bias = nullptr;
+        void * C = nullptr; int ldc = S; const float * resid = nullptr; void * aux = nullptr, * aux2 = nullptr; float scale = 0.f;
+        switch (op) {
+            case 0: epi = k::EPI_QKV_DEC; lg = l.ln1_g; lb = l.ln1_b; N = 3 * S; W = l.w_qkv; bias = l.b_qkv; C = o16[v][0]; aux = o16[v][1]; aux2 = o16[v][2]; scale = kq; break;
+            case 1: epi = k::EPI_F32_BIAS_RESID; W = l.w_o; bias = l.b_o; C = o32[v]; resid = o32[v]; break;
+            case 2: epi = k::EPI_Q_SCALED; lg = l.ln2_g; lb = l.ln2_b; W = l.w_cq; bias = l.b_cq; C = o16[v][0]; scale = kq; break;
+            case 4: epi = k::EPI_F16_BIAS_GELU; lg = l.ln3_g; lb = l.ln3_b; N = 4 * S; W = l.w_fc1; bias = l.b_fc1; C = o16[v][0]; ldc = 4 * S; break;
+            case 5: epi = k::EPI_F32_BIAS_RESID; K = 4 * S; W = l.w_fc2; bias = l.b_fc2; C = o32[v]; resid = o32[v]; break;
+            default: return -1.0;
+        }
+        if (v == 0) {
+            k::GemvArgs g{};
+            g.x32 = x0; g.ln_g = lg; g.ln_b = lb; g.eps = hp.eps; g.a16 = a16; g.n = n; g.K = K; g.N = N; g.W = W; g.bias = bias;
+            g.epi = epi; g.C = C; g.ldc = ldc; g.resid = resid; g.ldr = S; g.aux = aux; g.ldaux = S; g.aux2 = aux2; g.ldaux2 = S;
+            g.scale = scale; g.S = S;
+            k::gemv(g, s);
+        } else {
+            const __half * A = a16;
+            if (lg) { k::layernorm(x0, n, S, lg, lb, hp.eps, d.dxn, nullptr, s); A = d.dxn; }
+            k::GemmArgs a{};
+            a.A = A; a.lda = K; a.W = W; a.ldw = K; a.M = n; a.N = N; a.K = K; a.bias = bias; a.C = C; a.ldc = ldc;
+            a.resid = resid; a.ldr = S; a.aux = aux; a.ldaux = S; a.aux2 = aux2; a.ldaux2 = S; a.scale = scale; a.S = S;
+            k::gemm(epi, a, s);
+        }
+        (void) hipStreamSynchronize(s);
+    }
+    double worst = 0.0;
+    std::vector<__half> h0((size_t) n * 4 * S), h1((size_t) n * 4 * S);
+    for (int t = 0; t < 3; ++t) {
+        (void) hipMemcpy(h0.data(), o16[0][t], h0.size() * 2, hipMemcpyDeviceToHost);
+        (void) hipMemcpy(h1.data(), o16[1][t], h1.size() * 2, hipMemcpyDeviceToHost);
+        for (size_t i = 0; i < h0.size(); ++i) worst = std::max(worst, (double) fabsf(__half2float(h0[i]) - __half2float(h1[i])));
+    }
+    std::vector<float> f0((size_t) n * S), f1((size_t) n * S);
+    (void) hipMemcpy(f0.data(), o32[0], f0.size() * 4, hipMemcpyDeviceToHost);
+    (void) hipMemcpy(f1.data(), o32[1], f1.size() * 4, hipMemcpyDeviceToHost);
+    for (size_t i = 0; i < f0.size(); ++i) worst = std::max(worst, (double) fabsf(f0[i] - f1[i]));
+    (void) hipFree(x0); (void) hipFree(a16);
+    for (int v = 0; v < 2; ++v) { for (int t = 0; t < 3; ++t) (void) hipFree(o16[v][t]); (void) hipFree(o32[v]); }
+    return worst;
 }
 
 double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters) {

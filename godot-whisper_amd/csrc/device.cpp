@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace wmi {
@@ -240,13 +241,17 @@ bool decode(whisper_context & ctx, const Batch & batch) {
 
     k::dec_embed(d.d_tokens, d.d_pos, n, S, w.d_te, w.d_pe, d.dx, s);
     const float kq_scale = powf((float) S / H, -0.25f);
-    const bool skinny = n <= 8;
+    // WMI_DECODE_PATH=gemm|gemv forces one projection path (debug / A-B measurements); default: by batch size
+    static const char * force_path = getenv("WMI_DECODE_PATH");
+    static const int gemm_mask = getenv("WMI_GEMM_MASK") ? atoi(getenv("WMI_GEMM_MASK")) : 0;   // per-op override (debug)
+    const bool skinny_default = (force_path && !strcmp(force_path, "gemm")) ? false : n <= 8;
 
     // generic projection: y = W . LN?(x) with a fused epilogue, through the weight-streaming kernel
     // (n <= 8) or the MFMA GEMM (prompt / initial_prompt batches)
-    auto proj = [&](int epi, const float * ln_g, const float * ln_b, const __half * a16, int K, int N, const __half * W,
+    auto proj = [&](int op, int epi, const float * ln_g, const float * ln_b, const __half * a16, int K, int N, const __half * W,
                     const float * bias, void * C, int ldc, const float * resid, void * aux, int ldaux, void * aux2,
                     int ldaux2, float scale) {
+        const bool skinny = n <= 8 && (skinny_default ? !((gemm_mask >> op) & 1) : false);
         if (skinny) {
             k::GemvArgs g{};
             g.x32 = d.dx; g.ln_g = ln_g; g.ln_b = ln_b; g.eps = hp.eps; g.a16 = a16; g.n = n; g.K = K; g.N = N; g.W = W;
@@ -267,17 +272,17 @@ bool decode(whisper_context & ctx, const Batch & batch) {
         const DecLayerW & l = w.dec[il];
         __half * ck = kv.k + ((size_t) il * n_ctx) * S, * cv = kv.v + ((size_t) il * n_ctx) * S;
         // self-attention: q | k -> cache | v -> cache  (W/whisper.cpp:2248-2290)
-        proj(k::EPI_QKV_DEC, l.ln1_g, l.ln1_b, nullptr, S, 3 * S, l.w_qkv, l.b_qkv, d.dq, S, nullptr,
+        proj(0, k::EPI_QKV_DEC, l.ln1_g, l.ln1_b, nullptr, S, 3 * S, l.w_qkv, l.b_qkv, d.dq, S, nullptr,
              ck + (size_t) kv_head * S, S, cv + (size_t) kv_head * S, S, kq_scale);
         k::attn_decoder(d.dq, n, S, H, ck, cv, n_kv, d.d_mask, n_kv, d.datt, s);
-        proj(k::EPI_F32_BIAS_RESID, nullptr, nullptr, d.datt, S, S, l.w_o, l.b_o, d.dx, S, d.dx, nullptr, 0, nullptr, 0, 0.f);
+        proj(1, k::EPI_F32_BIAS_RESID, nullptr, nullptr, d.datt, S, S, l.w_o, l.b_o, d.dx, S, d.dx, nullptr, 0, nullptr, 0, 0.f);
         // cross-attention against the encoder K/V of this layer, no mask (W/whisper.cpp:2359-2433)
-        proj(k::EPI_Q_SCALED, l.ln2_g, l.ln2_b, nullptr, S, S, l.w_cq, l.b_cq, d.dq, S, nullptr, nullptr, 0, nullptr, 0, kq_scale);
+        proj(2, k::EPI_Q_SCALED, l.ln2_g, l.ln2_b, nullptr, S, S, l.w_cq, l.b_cq, d.dq, S, nullptr, nullptr, 0, nullptr, 0, kq_scale);
         k::attn_decoder(d.dq, n, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, nullptr, 0, d.datt, s);
-        proj(k::EPI_F32_BIAS_RESID, nullptr, nullptr, d.datt, S, S, l.w_co, l.b_co, d.dx, S, d.dx, nullptr, 0, nullptr, 0, 0.f);
+        proj(3, k::EPI_F32_BIAS_RESID, nullptr, nullptr, d.datt, S, S, l.w_co, l.b_co, d.dx, S, d.dx, nullptr, 0, nullptr, 0, 0.f);
         // MLP
-        proj(k::EPI_F16_BIAS_GELU, l.ln3_g, l.ln3_b, nullptr, S, 4 * S, l.w_fc1, l.b_fc1, d.dh, 4 * S, nullptr, nullptr, 0, nullptr, 0, 0.f);
-        proj(k::EPI_F32_BIAS_RESID, nullptr, nullptr, d.dh, 4 * S, S, l.w_fc2, l.b_fc2, d.dx, S, d.dx, nullptr, 0, nullptr, 0, 0.f);
+        proj(4, k::EPI_F16_BIAS_GELU, l.ln3_g, l.ln3_b, nullptr, S, 4 * S, l.w_fc1, l.b_fc1, d.dh, 4 * S, nullptr, nullptr, 0, nullptr, 0, 0.f);
+        proj(5, k::EPI_F32_BIAS_RESID, nullptr, nullptr, d.dh, 4 * S, S, l.w_fc2, l.b_fc2, d.dx, S, d.dx, nullptr, 0, nullptr, 0, 0.f);
     }
 
     // final LN + logits = d_te . x for the rows that asked for them (the reference computes all rows

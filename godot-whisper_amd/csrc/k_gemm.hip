@@ -182,10 +182,18 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
                     if (a.aux) ((float *) a.aux)[(size_t) m * a.ldaux + n] = g;
                     ((float *) a.C)[(size_t) m * a.ldc + n] = a.resid[(size_t) m * a.ldr + n] + g;
                 } else if constexpr (EPI == EPI_QKV_DEC) {
-                    const int seg = n / a.S, c = n - seg * a.S;
-                    if (seg == 0)      ((__half *) a.C)[(size_t) m * a.ldc + c]       = __float2half_rn((v + bias) * a.scale);
-                    else if (seg == 1) ((__half *) a.aux)[(size_t) m * a.ldaux + c]   = __float2half_rn(v * a.scale);
-                    else               ((__half *) a.aux2)[(size_t) m * a.ldaux2 + c] = __float2half_rn(v + bias);
+                    // The q | k | v segment is decided per 16-column fragment on a WAVE-UNIFORM value
+                    // (S is a multiple of 16, so a fragment never straddles a segment).  A per-lane
+                    // three-way `if` here is miscompiled by hipcc 7.2 for gfx950 (the third arm's
+                    // pointer select is dropped by the control-flow structurizer: v lands in the k
+                    // cache) — see DESIGN.md "toolchain hazards"; tests/test_gpu_kernels.py pins it.
+                    const int seg = __builtin_amdgcn_readfirstlane((nb + j * 16) / a.S);
+                    const int c = n - seg * a.S;
+                    __half * dst; float val;
+                    if (seg == 0)      { dst = (__half *) a.C    + (size_t) m * a.ldc;    val = (v + bias) * a.scale; }
+                    else if (seg == 1) { dst = (__half *) a.aux  + (size_t) m * a.ldaux;  val = v * a.scale; }
+                    else               { dst = (__half *) a.aux2 + (size_t) m * a.ldaux2; val = v + bias; }
+                    dst[c] = __float2half_rn(val);
                 } else if constexpr (EPI == EPI_CROSS_KV) {
                     const int il = n / (2 * a.S), c = n - il * 2 * a.S;
                     if (c < a.S) ((__half *) a.C)[il * a.layer_stride + (size_t) m * a.ldc + c] = __float2half_rn(v * a.scale);

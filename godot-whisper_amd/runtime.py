@@ -18,6 +18,7 @@ DEVICE_API = [
     ("wmi_init_from_buffer_on_device", C.c_void_p, [C.c_void_p, C.c_size_t, C.c_int]),
     ("wmi_pcm_to_mel_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     ("wmi_full_device_pcm", C.c_int, [C.c_void_p, abi.whisper_full_params, C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
+    ("wmi_set_audio_ctx", C.c_int, [C.c_void_p, C.c_int]),
     ("wmi_get_tensor", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int]),
     ("wmi_mel_dims", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("wmi_get_timings", None, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
@@ -27,6 +28,7 @@ DEVICE_API = [
                                       C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("wmi_sample_draws", C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int,
                                     C.POINTER(abi.whisper_token_data)]),
+    ("wmi_selftest_proj", C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     ("wmi_bench_kernel", C.c_double, [C.c_void_p, C.c_int, C.c_int]),
 ]
 

@@ -39,6 +39,10 @@ WHISPER_API int wmi_pcm_to_mel_device(struct whisper_context * ctx, const float 
 WHISPER_API int wmi_full_device_pcm(struct whisper_context * ctx, struct whisper_full_params params,
                                     const float * d_samples, int n_samples, const float * h_samples_for_timestamps);
 
+/* Encoder length override for the bare whisper_encode / whisper_decode calls, i.e. what whisper_full
+ * does with params.audio_ctx (W/whisper.cpp:5098-5102); 0 = model default.  Returns -5 if too large. */
+WHISPER_API int wmi_set_audio_ctx(struct whisper_context * ctx, int n_audio_ctx);
+
 /* Copy an internal tensor out as f32 (f16 tensors are widened).  Returns the element count, or -1 for
  * an unknown name; with dst == NULL only reports the count.  Names and layouts (row-major):
  *   "mel"        [n_mel][n_len]                 log-mel (W/whisper.cpp:2779)
@@ -65,6 +69,11 @@ WHISPER_API int wmi_process_logits(struct whisper_context * ctx, struct whisper_
                                    float * out_logits, float * out_logprobs, float * out_probs);
 WHISPER_API int wmi_sample_draws(struct whisper_context * ctx, const float * probs, const float * logprobs, int n_draw,
                                  int reseed, whisper_token_data * out);
+
+/* Kernel-level cross-check of the two decoder projection implementations (weight-streaming GEMV vs
+ * MFMA GEMM) on identical random inputs; op: 0 self q|k|v, 1 self out, 2 cross q, 4 mlp.0, 5 mlp.2.
+ * Returns the largest absolute difference over all outputs (negative on error). */
+WHISPER_API double wmi_selftest_proj(struct whisper_context * ctx, int op, int n, int layer);
 
 /* Kernel micro-benchmarks on synthetic operands (used by bench.py for the roofline line):
  * runs `iters` launches on the context stream between two HIP events, returns average microseconds.

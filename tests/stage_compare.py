@@ -103,11 +103,7 @@ class ProductSide:
 
     def encode(self, offset=0, audio_ctx=0):
         # whisper_full sets exp_n_audio_ctx; for the bare encode call use a 1-sample-free path:
-        if audio_ctx:
-            from godot_whisper_amd import abi
-            p = self.lib.whisper_full_default_params(0)
-            p.audio_ctx = audio_ctx; p.duration_ms = 10  # < 1 s: returns right after storing audio_ctx
-            self.lib.whisper_full(self.ctx, p, None, 0)
+        assert self.lib.wmi_set_audio_ctx(self.ctx, audio_ctx) == 0
         assert self.lib.whisper_encode(self.ctx, offset, 4) == 0
         T = audio_ctx if audio_ctx > 0 else self.n_audio_ctx
         S, L = self.S, self.L
