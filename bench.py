@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Headline benchmark: realtime factor of PCM -> tokens for base.en on 30 s chunks (BASELINE.json).
+
+  python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+
+A step = one complete transcription of one 30 s chunk of synthetic 16 kHz PCM that is already
+resident in HBM, with the Godot host's parameter set (src/speech_to_text.cpp:403-413: greedy,
+max_tokens 16, single_segment, token timestamps): log-mel -> conv -> 6 encoder blocks -> cross K/V ->
+prompt + <=17 KV-cached decoder steps with the reference's logit filters and sampling.
+Rank r transcribes its own chunks (independent units, no collective in the hot loop: SURVEY §8(e));
+the only collective is the RCCL broadcast of the ggml model image before timing starts.
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+import __graft_entry__ as entry
+
+SHAPE = "base.en"
+CHUNK_S = 30.0
+# algorithmic work per 30 s chunk: encoder FLOP and decoder bytes per token
+ENC_GFLOP = 96.80
+DEC_MB_PER_TOKEN = 115.6
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--shape", default=SHAPE)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    entry.load_package()
+    from godot_whisper_amd import abi, host, runtime, synth
+
+    lib = runtime.require_gpu()
+    runtime.silence_logs(lib)
+
+    # ---- model: rank 0 makes the ggml image; everyone else gets it by ONE RCCL broadcast over xGMI
+    if rank == 0:
+        model = np.frombuffer(synth.make_model(args.shape, seed=1234), dtype=np.uint8)
+        n_bytes = torch.tensor([model.size], dtype=torch.int64, device=dev)
+    else:
+        n_bytes = torch.zeros(1, dtype=torch.int64, device=dev)
+    t_bcast = 0.0
+    if world > 1:
+        dist.broadcast(n_bytes, src=0)
+        image = torch.empty(int(n_bytes.item()), dtype=torch.uint8, device=dev)
+        if rank == 0:
+            image.copy_(torch.from_numpy(model.copy()))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        dist.broadcast(image, src=0)
+        torch.cuda.synchronize()
+        t_bcast = time.perf_counter() - t0
+        model_bytes = image.cpu().numpy().tobytes()
+        del image
+    else:
+        model_bytes = model.tobytes()
+    buf = C.create_string_buffer(model_bytes, len(model_bytes))
+    ctx = lib.wmi_init_from_buffer_on_device(C.cast(buf, C.c_void_p), len(model_bytes), local_rank)
+    assert ctx, "model load failed"
+    del buf
+
+    # ---- inputs: a few distinct seeded chunks per rank, already in HBM
+    n_distinct = 4
+    pcm_host = [synth.make_pcm(CHUNK_S, seed=1234 + 1000 * rank + i) for i in range(n_distinct)]
+    pcm_dev = [torch.from_numpy(p).to(dev) for p in pcm_host]
+    torch.cuda.synchronize()
+
+    node = host.SpeechToText(lib)
+    node.ctx = ctx
+    params = node.full_params("", 0)
+
+    def step(i):
+        t = pcm_dev[i % n_distinct]
+        ret = lib.wmi_full_device_pcm(ctx, params, C.c_void_p(t.data_ptr()), t.numel(), None)
+        assert ret == 0, ret
+
+    for i in range(args.warmup):
+        step(i)
+    t6 = (C.c_int64 * 6)(); n5 = (C.c_int32 * 5)()
+    lib.whisper_reset_timings(ctx)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    lib.wmi_get_timings(ctx, t6, n5)
+    n_tokens = sum(lib.whisper_full_n_tokens(ctx, s) for s in range(lib.whisper_full_n_segments(ctx)))
+
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt_max = float(tmax.item())
+
+    if rank == 0:
+        audio_s = CHUNK_S * args.steps * world
+        rtf = audio_s / dt_max
+        enc_ms = (t6[1] / 1e3) / max(n5[0], 1)
+        dec_calls = max(n5[1], 1)
+        out = {
+            "metric": "realtime-factor (audio-sec/wall-sec), base.en 30 s chunk, PCM->tokens",
+            "value": round(rtf, 2), "unit": "x realtime",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt_max / args.steps, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "base.en, single 30 s chunk per step on 1x MI355X, greedy decode, host params "
+                                   "(max_tokens=16, single_segment, token_timestamps)",
+                       "chunks_per_gpu_per_step": 1, "tokens_per_chunk": int(n_tokens),
+                       "weights": "synthetic seed 1234 (f16 ggml, base.en shape)"},
+            "encode_ms": round(enc_ms, 4),
+            "decode_ms_per_token": round((t6[2] / 1e3) / dec_calls, 4),
+            "mel_ms": round((t6[0] / 1e3) / args.steps, 4),
+            "sample_ms_per_step": round((t6[5] / 1e3) / args.steps, 4),
+            "weight_bcast_ms": round(1e3 * t_bcast, 3),
+        }
+        # ---- roofline of the dominant kernels, measured live with HIP events on the context stream
+        try:
+            hp_S = lib.whisper_model_n_audio_state(ctx); T = lib.whisper_model_n_audio_ctx(ctx); NV = lib.whisper_n_vocab(ctx)
+            us_gemm = lib.wmi_bench_kernel(ctx, 0, 200)
+            us_gemv = lib.wmi_bench_kernel(ctx, 1, 200)
+            us_attn = lib.wmi_bench_kernel(ctx, 2, 50)
+            flops = 2.0 * T * 4 * hp_S * hp_S
+            tf = flops / (us_gemm * 1e-6) / 1e12
+            gbs = NV * hp_S * 2 / (us_gemv * 1e-6) / 1e9
+            out["roofline"] = {"kernel": "k_gemm<EPI_F16_BIAS_GELU> encoder mlp.0 [1500x2048x512] f16 MFMA", "bound": "mfma",
+                               "achieved": round(tf, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
+                               "traffic": None, "avg_us": round(us_gemm, 3)}
+            out["roofline_decode"] = {"kernel": "k_gemv<1> logits [51864x512] f16 weight stream", "bound": "hbm",
+                                      "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
+                                      "traffic": None, "avg_us": round(us_gemv, 3)}
+            out["attn_layer_us"] = round(us_attn, 2)
+            out["encoder_tflops_end_to_end"] = round(ENC_GFLOP / enc_ms, 2)
+        except Exception as e:  # pragma: no cover
+            out["roofline_error"] = repr(e)
+        # ---- CPU baseline on this box's host cores (bounded sample), rank 0 / N=1 only
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(model_bytes, pcm_host[0])
+        print(json.dumps(out), flush=True)
+
+    lib.whisper_free(ctx)
+    node.ctx = None
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(model_bytes: bytes, pcm: np.ndarray) -> dict:
+    """The reference's own CPU path (oracle/_ref, kind "reference") when its prebuilt library travelled
+    with the snapshot, else this repository's CPU restatement (kind "port").  Sample: the same
+    transcription (same model, same 30 s chunk, same host params), run a few times, ~10-30 s of CPU work."""
+    entry.load_oracle()
+    from godot_whisper_amd import host
+    from oracle import reflib
+    kind, lib, threads = None, None, None
+    if reflib.available():
+        import ctypes as C
+        from godot_whisper_amd import abi
+        lib = reflib.lib()
+        cb = abi.ggml_log_callback(lambda lvl, txt, ud: None)
+        lib.whisper_log_set(C.cast(cb, C.c_void_p), None)
+        lib._cb = cb
+        kind = "reference"
+    else:
+        try:
+            from oracle import port
+            lib = port.lib()
+            kind = "port"
+        except Exception as e:
+            return {"value": None, "error": repr(e)}
+    node = host.SpeechToText(lib)
+    node.set_language_model(model_bytes)
+    p = node.full_params("", 0)
+    threads = int(p.n_threads)
+    node.transcribe(pcm, params=p)                      # warm
+    t0 = time.perf_counter(); n = 0
+    while True:
+        node.transcribe(pcm, params=p); n += 1
+        if time.perf_counter() - t0 > 10.0 or n >= 12:
+            break
+    dt = (time.perf_counter() - t0) / n
+    node.close()
+    return {"value": round(CHUNK_S / dt, 2), "unit": "x realtime", "cores": threads, "host_cores": os.cpu_count(),
+            "kind": kind, "ms_per_chunk": round(dt * 1e3, 1),
+            "sample": f"{n} transcriptions of the same 30 s chunk, whisper.cpp default n_threads=min(4,hw)"}
+
+
+if __name__ == "__main__":
+    main()
