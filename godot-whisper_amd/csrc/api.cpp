@@ -81,6 +81,7 @@ struct whisper_context * whisper_init_from_buffer_with_params(void * buffer, siz
 
 void whisper_free(struct whisper_context * ctx) {
     if (!ctx) return;
+    if (ctx->host_only) { delete ctx->state; delete ctx; return; }
     (void) hipSetDevice(ctx->device);
     free_state(*ctx);
     free_weights(ctx->w);
@@ -258,6 +259,16 @@ const char * wmi_version(void) { return "whisper_mi355 0.1 (gfx950, whisper.cpp 
 struct whisper_context * wmi_init_from_buffer_on_device(const void * buffer, size_t buffer_size, int device) {
     whisper_context * ctx = init_common(buffer, buffer_size, device);
     if (ctx) ctx->params.use_gpu = true;
+    return ctx;
+}
+
+struct whisper_context * wmi_init_host_only(const void * buffer, size_t buffer_size) {
+    whisper_context * ctx = new whisper_context();
+    ctx->host_only = true;
+    ctx->t_start_us = time_us();
+    if (!parse_model((const uint8_t *) buffer, buffer_size, ctx->model)) { WMI_ERR("%s: failed to load model\n", __func__); delete ctx; return nullptr; }
+    ctx->state = new State();
+    for (auto & dec : ctx->state->decoders) dec.rng = std::mt19937(0);
     return ctx;
 }
 

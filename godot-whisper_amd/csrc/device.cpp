@@ -101,6 +101,7 @@ static bool ensure_mel_capacity(DeviceState & d, size_t n_pad, size_t n_mel_elem
 }
 
 bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, bool samples_on_device) {
+    if (ctx.host_only) { WMI_ERR("%s: host-only context has no compute path (this backend has no CPU fallback)\n", __func__); return false; }
     State & st = *ctx.state; DeviceState & d = st.dev;
     const int64_t t0 = time_us();
     const int n_mel = ctx.model.n_filt_mel;
@@ -127,6 +128,7 @@ bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, boo
 }
 
 bool set_mel(whisper_context & ctx, const float * data, int n_len, int n_mel) {
+    if (ctx.host_only) { WMI_ERR("%s: host-only context has no compute path (this backend has no CPU fallback)\n", __func__); return false; }
     State & st = *ctx.state; DeviceState & d = st.dev;
     if (!ensure_mel_capacity(d, 0, (size_t) n_len * n_mel)) return false;
     HIP_TRY(hipMemcpyAsync(d.mel, data, (size_t) n_len * n_mel * 4, hipMemcpyHostToDevice, d.stream));
@@ -137,6 +139,7 @@ bool set_mel(whisper_context & ctx, const float * data, int n_len, int n_mel) {
 
 // ------------------------------------------------------------------------------------------------ encoder
 bool encode(whisper_context & ctx, int mel_offset) {
+    if (ctx.host_only) { WMI_ERR("%s: host-only context has no compute path (this backend has no CPU fallback)\n", __func__); return false; }
     State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
     const int64_t t0 = time_us();
     const int T = st.exp_n_audio_ctx > 0 ? st.exp_n_audio_ctx : hp.n_audio_ctx;
@@ -211,6 +214,7 @@ bool encode(whisper_context & ctx, int mel_offset) {
 
 // ------------------------------------------------------------------------------------------------ decoder
 bool decode(whisper_context & ctx, const Batch & batch) {
+    if (ctx.host_only) { WMI_ERR("%s: host-only context has no compute path (this backend has no CPU fallback)\n", __func__); return false; }
     State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
     const int64_t t0 = time_us();
     KVCache & kv = st.kv_self;

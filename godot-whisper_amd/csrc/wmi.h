@@ -205,6 +205,7 @@ struct whisper_context {
     wmi::Weights   w;
     wmi::State *   state = nullptr;
     int            device = 0;
+    bool           host_only = false;   // vocabulary + host logic only (tests); every compute call fails loudly
 };
 
 namespace wmi {

@@ -16,6 +16,7 @@ DEVICE_API = [
     ("wmi_device_count", C.c_int, []),
     ("wmi_version", C.c_char_p, []),
     ("wmi_init_from_buffer_on_device", C.c_void_p, [C.c_void_p, C.c_size_t, C.c_int]),
+    ("wmi_init_host_only", C.c_void_p, [C.c_void_p, C.c_size_t]),
     ("wmi_pcm_to_mel_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     ("wmi_full_device_pcm", C.c_int, [C.c_void_p, abi.whisper_full_params, C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     ("wmi_set_audio_ctx", C.c_int, [C.c_void_p, C.c_int]),

@@ -29,6 +29,11 @@ WHISPER_API const char * wmi_version(void);
  * (one process per GPU: pass LOCAL_RANK).  replaces: W/whisper.h:151 for multi-GPU hosts. */
 WHISPER_API struct whisper_context * wmi_init_from_buffer_on_device(const void * buffer, size_t buffer_size, int device);
 
+/* Vocabulary + host-side decision logic only (tokenizer, logit filters, sampling): no device is touched
+ * and every compute entry point (mel / encode / decode / whisper_full with audio) fails with an error.
+ * Exists so the host logic can be unit-tested on machines without a GPU; it is NOT a CPU fallback. */
+WHISPER_API struct whisper_context * wmi_init_host_only(const void * buffer, size_t buffer_size);
+
 /* PCM already in HBM (f32 mono 16 kHz, device pointer on the context's device) -> log-mel in the
  * context.  replaces: whisper_pcm_to_mel (W/whisper.h:240) when the samples never touch the host. */
 WHISPER_API int wmi_pcm_to_mel_device(struct whisper_context * ctx, const float * d_samples, int n_samples);

@@ -128,6 +128,22 @@ int ref_sample_draws(struct whisper_context * ctx, const float * probs, const fl
 
 // tokenizer of the reference (W/whisper.cpp:2899-2947) is already public as whisper_tokenize.
 
+// the reference's GELU evaluated on every f16 bit pattern (= its ggml_table_gelu_f16, W/ggml.c:2229-2231)
+int ref_gelu_table(uint16_t * out) {
+    struct ggml_init_params ip = { (size_t) 16*1024*1024, nullptr, false };
+    struct ggml_context * g = ggml_init(ip);
+    if (!g) return -1;
+    struct ggml_tensor * x = ggml_new_tensor_1d(g, GGML_TYPE_F32, 65536);
+    for (int i = 0; i < 65536; ++i) ((float *) x->data)[i] = ggml_fp16_to_fp32((ggml_fp16_t) i);
+    struct ggml_tensor * y = ggml_gelu(g, x);
+    struct ggml_cgraph * gf = ggml_new_graph(g);
+    ggml_build_forward_expand(gf, y);
+    ggml_graph_compute_with_ctx(g, gf, 1);
+    for (int i = 0; i < 65536; ++i) out[i] = ggml_fp32_to_fp16(((float *) y->data)[i]);
+    ggml_free(g);
+    return 65536;
+}
+
 size_t ref_sizeof_full_params(void) { return sizeof(struct whisper_full_params); }
 size_t ref_sizeof_token_data(void)  { return sizeof(struct whisper_token_data); }
 

@@ -29,6 +29,7 @@ _SHIM = [
                                       C.POINTER(C.c_float), C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("ref_sample_draws", C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int, C.c_int,
                                     C.POINTER(abi.whisper_token_data)]),
+    ("ref_gelu_table", C.c_int, [C.POINTER(C.c_uint16)]),
     ("ref_sizeof_full_params", C.c_size_t, []),
     ("ref_sizeof_token_data", C.c_size_t, []),
 ]
