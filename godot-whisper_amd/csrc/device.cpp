@@ -83,6 +83,7 @@ void free_state(whisper_context & ctx) {
     DeviceState & d = st->dev;
     if (d.stream) (void) hipStreamSynchronize(d.stream);
     dfree(st->kv_self.k); dfree(st->kv_self.v); dfree(d.kvc_k); dfree(d.kvc_v);
+    dfree(d.energy); if (d.energy_host) (void) hipHostFree(d.energy_host);
     dfree(d.pcm); dfree(d.mel); dfree(d.mel_max); dfree(d.mel_t); dfree(d.conv1); dfree(d.x); dfree(d.embd_conv);
     dfree(d.xn); dfree(d.q); dfree(d.k); dfree(d.vt); dfree(d.att); dfree(d.h); dfree(d.rowmax); dfree(d.enc_out);
     dfree(d.enc_out_h); dfree(d.d_tokens); dfree(d.d_pos); dfree(d.d_mask); dfree(d.d_rows); dfree(d.dx); dfree(d.dxn);
@@ -118,12 +119,30 @@ bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, boo
         HIP_TRY(hipMemcpyAsync(stage, samples, (size_t) n_samples * 4, hipMemcpyHostToDevice, d.stream));
         src = stage;
     }
+    d.last_pcm = src; d.last_pcm_n = n_samples;
     k::mel_pad(src, n_samples, d.pcm, (int) n_pad, d.stream);
     k::mel_frames(d.pcm, n_valid, n_fft_frames, n_len, n_mel, ctx.w.mel_filters, d.mel, (int *) d.mel_max, d.stream);
     k::mel_normalize(d.mel, n_mel * n_len, (const int *) d.mel_max, d.stream);
     HIP_TRY(hipStreamSynchronize(d.stream));
     st.mel.n_len = n_len; st.mel.n_len_org = n_len_org; st.mel.n_mel = n_mel;
     st.t_mel_us += time_us() - t0;
+    return true;
+}
+
+bool signal_energy_device(whisper_context & ctx, int hw) {
+    State & st = *ctx.state; DeviceState & d = st.dev;
+    const int n = d.last_pcm_n;
+    if (!d.last_pcm || n <= 0) return false;
+    if ((size_t) n > d.energy_cap) {
+        dfree(d.energy); if (d.energy_host) (void) hipHostFree(d.energy_host);
+        d.energy_host = nullptr; d.energy_cap = 0;
+        if (!dalloc(d.energy, (size_t) n) || !HIP_OK(hipHostMalloc((void **) &d.energy_host, (size_t) n * 4, hipHostMallocDefault))) return false;
+        d.energy_cap = (size_t) n;
+    }
+    k::signal_energy(d.last_pcm, n, hw, d.energy, d.stream);
+    HIP_TRY(hipMemcpyAsync(d.energy_host, d.energy, (size_t) n * 4, hipMemcpyDeviceToHost, d.stream));
+    HIP_TRY(hipStreamSynchronize(d.stream));
+    st.energy.assign(d.energy_host, d.energy_host + n);
     return true;
 }
 

@@ -67,7 +67,9 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
 
     if (params.token_timestamps) {
         st.t_beg = 0; st.t_last = 0; st.tid_last = 0;
-        if (n_samples > 0 && samples) st.energy = signal_energy(samples, n_samples, 32);
+        // the |x| envelope is computed on the GPU from the samples pcm_to_mel just staged (bit-identical to the
+        // CPU loop, k_signal_energy); the host loop remains only as the definition it is tested against
+        if (n_samples > 0 && !signal_energy_device(ctx, 32)) { WMI_ERR("%s: failed to compute the signal envelope\n", __func__); return -2; }
     }
 
     const int seek_start = params.offset_ms / 10;

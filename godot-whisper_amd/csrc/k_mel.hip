@@ -174,6 +174,20 @@ __global__ void k_mel_slice(const float * __restrict__ mel, int n_len, int n_mel
     }
 }
 
+// mean |x| over a (2 hw + 1)-sample window, summed left to right with the reference's exact arithmetic
+// (float accumulator, each step rounded through a double add: `sum += fabs(x)`, W/whisper.cpp:6352-6366),
+// so the host-side timestamp heuristics see bit-identical thresholds.
+__global__ void k_signal_energy(const float * __restrict__ x, int n, int hw, float * __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float sum = 0.0f;
+    for (int j = -hw; j <= hw; ++j) {
+        const int k = i + j;
+        if (k >= 0 && k < n) sum = (float) ((double) sum + fabs((double) x[k]));
+    }
+    out[i] = sum / (float) (2 * hw + 1);
+}
+
 __global__ void k_fill_zero(uint32_t * p, size_t n) {
     size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t) gridDim.x * blockDim.x;
@@ -204,6 +218,10 @@ void mel_slice(const float * mel, int n_len, int n_mel, int offset, int n_frames
                hipStream_t st) {
     dim3 grid((rows_total + 31) / 32, (ld + 31) / 32);
     hipLaunchKernelGGL(k_mel_slice, grid, dim3(256), 0, st, mel, n_len, n_mel, offset, n_frames, out, ld, rows_total);
+}
+
+void signal_energy(const float * pcm, int n, int hw, float * out, hipStream_t st) {
+    hipLaunchKernelGGL(k_signal_energy, dim3((n + 255) / 256), dim3(256), 0, st, pcm, n, hw, out);
 }
 
 void fill_zero(void * p, size_t bytes, hipStream_t st) {

@@ -20,6 +20,9 @@ void mel_normalize(float * mel, int n, const int * gmax, hipStream_t st);
 void mel_slice(const float * mel, int n_len, int n_mel, int offset, int n_frames, __half * out, int ld,
                int rows_total, hipStream_t st);
 
+// |x| envelope for the token-level timestamp heuristics (W/whisper.cpp:6352-6366), bit-identical to the CPU loop
+void signal_energy(const float * pcm, int n, int hw, float * out, hipStream_t st);
+
 // ---------------------------------------------------------------- GEMM (k_gemm.hip)
 enum Epi : int {
     EPI_F16_BIAS = 0,       // C f16 = acc + bias

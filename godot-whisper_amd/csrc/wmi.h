@@ -154,6 +154,9 @@ struct DeviceState {
     float * pcm = nullptr;      size_t pcm_cap = 0;          // padded PCM
     float * mel = nullptr;      size_t mel_cap = 0;          // [n_mel][n_len] f32 (reference layout)
     float * mel_max = nullptr;                                // 1 float (ordered-int encoded)
+    const float * last_pcm = nullptr; int last_pcm_n = 0;     // device copy of the samples of the last pcm_to_mel
+    float * energy = nullptr;   size_t energy_cap = 0;        // |x| envelope (device)
+    float * energy_host = nullptr;                            // pinned mirror
     // encoder activations, token-major
     __half * mel_t = nullptr;                                 // [2T+2+pad][n_mel_pad] f16, rows -1 and 2T are zero
     __half * conv1 = nullptr;                                 // [2T+2][S] f16 (row 0 and 2T+1 zero)
@@ -218,6 +221,7 @@ bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, boo
 bool set_mel(whisper_context & ctx, const float * data, int n_len, int n_mel);
 bool encode(whisper_context & ctx, int mel_offset);
 bool decode(whisper_context & ctx, const Batch & batch);
+bool signal_energy_device(whisper_context & ctx, int hw);   // fills state.energy from the last PCM
 
 // host logic (logits filters, sampling, driver)
 void process_logits(whisper_context & ctx, Decoder & dec, const whisper_full_params & params, float temperature);

@@ -1,0 +1,139 @@
+"""Host-side decision logic of the product (tokenizer, logit filters, sampling)
+on a host-only context — no GPU needed — against the reference's goldens and, where present, live against
+the compiled reference fed identical logits."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import golden_util as gu
+import stage_compare as sc
+from godot_whisper_amd import abi, host, runtime
+from oracle import reflib
+
+G = np.load(gu.GOLDEN / "hotpath.npz")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    lib = runtime.load_library()
+    runtime.silence_logs(lib)
+    return lib
+
+
+def host_ctx(lib, name):
+    model, _, _ = gu.case_inputs(name)
+    buf = C.create_string_buffer(model, len(model))
+    ctx = lib.wmi_init_host_only(C.cast(buf, C.c_void_p), len(model))
+    assert ctx
+    return ctx
+
+
+HIST = [([], 0, 3000), ([100, 200], 0, 3000), (["beg+10"], 1, 20), ([300, "beg+10"], 1, 20), (["beg+5", "beg+5"], 1, 10), ([400] * 3, 0, 3000)]
+
+
+@pytest.mark.parametrize("name", ["en30", "ml11"])
+def test_logit_filters_and_sampling_match_reference(lib, name):
+    ctx = host_ctx(lib, name)
+    node = host.SpeechToText(lib); node.ctx = ctx
+    try:
+        nv = lib.whisper_n_vocab(ctx); beg = lib.whisper_token_beg(ctx)
+        rng = np.random.default_rng(5)
+        for ci, (hist, has_ts, sd) in enumerate(HIST):
+            hist = [beg + int(h.split("+")[1]) if isinstance(h, str) else h for h in hist]
+            raw = (rng.standard_normal(nv) * 6.0).astype(np.float32)
+            if ci == 2:
+                raw[beg:] += 9.0
+            for temp in (0.0, 0.6):
+                p = node.full_params("", 0)
+                lo, lp, pr = (np.empty(nv, np.float32) for _ in range(3))
+                h = np.asarray(hist, np.int32)
+                lib.wmi_process_logits(ctx, p, sc._fptr(raw), h.ctypes.data_as(C.POINTER(C.c_int32)), h.size, has_ts, sd,
+                                       C.c_float(temp), sc._fptr(lo), sc._fptr(lp), sc._fptr(pr))
+                key = f"{name}/filters/{ci}_t{temp}"
+                assert int(np.isneginf(lo).sum()) == int(G[key + "/n_neg_inf"])
+                assert int(np.flatnonzero(np.isneginf(lo)).astype(np.int64).sum()) == int(G[key + "/neg_inf_hash"])
+                fin = np.isfinite(lp)
+                np.testing.assert_allclose(lp[fin].astype(np.float64).sum(), G[key + "/logprob_sum"], rtol=1e-6)
+                np.testing.assert_allclose(pr.astype(np.float64).sum(), G[key + "/prob_sum"], rtol=1e-6)
+                top = np.argsort(-pr, kind="stable")[:8]
+                assert list(top) == list(G[key + "/top_ids"])
+                np.testing.assert_allclose(pr[top], G[key + "/top_probs"], rtol=1e-6)
+                np.testing.assert_allclose(lp[top], G[key + "/top_logprobs"], rtol=1e-6, atol=1e-6)
+                if temp > 0:
+                    draws = (abi.whisper_token_data * 12)()
+                    lib.wmi_sample_draws(ctx, sc._fptr(pr), sc._fptr(lp), 12, 1, draws)
+                    assert [[d.id, d.tid] for d in draws] == G[key + "/draws"].tolist()
+                    np.testing.assert_allclose([[d.p, d.plog, d.pt, d.ptsum] for d in draws], G[key + "/draw_stats"], rtol=1e-6)
+    finally:
+        node.ctx = None
+        lib.whisper_free(ctx)
+
+
+def test_tokenizer_matches_reference(lib):
+    ctx = host_ctx(lib, "en30")
+    try:
+        buf = (C.c_int32 * 1024)()
+        for i, text in enumerate(gu.PROMPTS):
+            n = lib.whisper_tokenize(ctx, text.encode("utf-8"), buf, 1024)
+            assert list(buf[:max(n, 0)]) == G[f"tokenize/{i}"].tolist(), text
+        assert lib.whisper_tokenize(ctx, b"one two three four", buf, 2) == -1     # too many tokens -> -1 (W/whisper.cpp:3513)
+    finally:
+        lib.whisper_free(ctx)
+
+
+def test_special_tokens_and_languages(lib):
+    en = host_ctx(lib, "en30"); ml = host_ctx(lib, "ml11")
+    try:
+        assert [lib.whisper_token_eot(en), lib.whisper_token_sot(en), lib.whisper_token_beg(en)] == [50256, 50257, 50363]
+        assert [lib.whisper_token_eot(ml), lib.whisper_token_sot(ml), lib.whisper_token_translate(ml),
+                lib.whisper_token_transcribe(ml), lib.whisper_token_beg(ml)] == [50257, 50258, 50358, 50359, 50364]
+        assert lib.whisper_is_multilingual(en) == 0 and lib.whisper_is_multilingual(ml) == 1
+        assert lib.whisper_lang_id(b"en") == 0 and lib.whisper_lang_id(b"german") == 2 and lib.whisper_lang_id(b"yue") == 99
+        assert lib.whisper_lang_id(b"xx") == -1 and lib.whisper_lang_max_id() == 99
+        assert lib.whisper_lang_str(7) == b"ja"
+        assert lib.whisper_token_to_str(en, 50257) == b"[_SOT_]" and lib.whisper_token_to_str(en, 50364) == b"[_TT_1]"
+        assert lib.whisper_token_to_str(ml, 50259) == b"[_LANG_en]"
+    finally:
+        lib.whisper_free(en); lib.whisper_free(ml)
+
+
+def test_host_only_context_has_no_compute_path(lib):
+    """The product must fail loudly, never fall back to a CPU computation."""
+    ctx = host_ctx(lib, "en30")
+    try:
+        pcm = np.zeros(16000 * 2, np.float32)
+        assert lib.whisper_pcm_to_mel(ctx, sc._fptr(pcm), pcm.size, 1) == -1
+        assert lib.whisper_encode(ctx, 0, 1) == -1
+        tok = (C.c_int32 * 1)(50257)
+        assert lib.whisper_decode(ctx, tok, 1, 0, 1) != 0
+        p = lib.whisper_full_default_params(0)
+        assert lib.whisper_full(ctx, p, sc._fptr(pcm), pcm.size) == -2
+    finally:
+        lib.whisper_free(ctx)
+
+
+@pytest.mark.skipif(not reflib.available(), reason="compiled reference absent")
+def test_filters_live_against_reference(lib, ref_lib):
+    model, _, _ = gu.case_inputs("en30")
+    ctx = host_ctx(lib, "en30")
+    rnode = host.SpeechToText(ref_lib); rnode.set_language_model(model)
+    node = host.SpeechToText(lib); node.ctx = ctx
+    try:
+        nv = lib.whisper_n_vocab(ctx)
+        rng = np.random.default_rng(11)
+        for trial in range(6):
+            raw = (rng.standard_normal(nv) * 5.0).astype(np.float32)
+            hist = rng.integers(0, 50000, size=trial).astype(np.int32)
+            outs = []
+            for L, c, fn in ((lib, ctx, lib.wmi_process_logits), (ref_lib, rnode.ctx, ref_lib.ref_process_logits)):
+                nd = node if L is lib else rnode
+                p = nd.full_params("", 0); p.suppress_non_speech_tokens = bool(trial % 2)
+                lo, lp, pr = (np.empty(nv, np.float32) for _ in range(3))
+                fn(c, p, sc._fptr(raw), hist.ctypes.data_as(C.POINTER(C.c_int32)), hist.size, 0, 3000, C.c_float(0.2 * trial),
+                   sc._fptr(lo), sc._fptr(lp), sc._fptr(pr))
+                outs.append((lo.copy(), lp.copy(), pr.copy()))
+            for a, b in zip(outs[0], outs[1]):
+                assert np.array_equal(a, b)
+    finally:
+        node.ctx = None; lib.whisper_free(ctx); rnode.close()
