@@ -466,7 +466,11 @@ void token_level_timestamps(whisper_context & ctx, int i_segment, float thold_pt
             if (en[k2] > thold) {
                 while (k2 < n_samples - 1 && en[k2] > thold) ++k2;
                 tokens[j].t1 = sample_to_ts(k2);
-                if (j < ns - 1 && tokens[j].t1 > tokens[j + 1].t0) tokens[j].t1 = tokens[j + 1].t0; else s1 = k2;
+                // The reference tests `j < ns - 1` (window length, not token count) and so reads tokens[n] — one past
+                // the end — for the last token (W/whisper.cpp:6561); what it finds there is heap garbage (usually 0,
+                // which zeroes the last token's t1).  That read is undefined behaviour and is NOT reproduced: the last
+                // token keeps its own end.  tests/test_gpu_parity.py exempts exactly this field.
+                if (j < ns - 1 && j + 1 < n && tokens[j].t1 > tokens[j + 1].t0) tokens[j].t1 = tokens[j + 1].t0; else s1 = k2;
             } else {
                 while (en[k2] < thold && k2 > s0) --k2;
                 s1 = k2;
