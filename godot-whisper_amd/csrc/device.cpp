@@ -55,7 +55,8 @@ bool init_state(whisper_context & ctx) {
     d.logits_rows_cap = 8;
     ok = ok && dalloc(d.d_tokens, n) && dalloc(d.d_pos, n) && dalloc(d.d_mask, n * n_self) && dalloc(d.d_rows, n)
             && dalloc(d.dx, n * S) && dalloc(d.dxn, n * S) && dalloc(d.dq, n * S) && dalloc(d.datt, n * S)
-            && dalloc(d.dh, n * 4 * S) && dalloc(d.logits, (size_t) d.logits_rows_cap * hp.n_vocab);
+            && dalloc(d.dh, n * 4 * S) && dalloc(d.logits, (size_t) d.logits_rows_cap * hp.n_vocab)
+            && dalloc(d.xattn, k::attn_cross_scratch_floats((int) n, (int) H, (int) T));
     d.pinned_bytes = std::max<size_t>((size_t) d.logits_rows_cap * hp.n_vocab * 4, n * n_self * 4 + 3 * n * 4 + 4096);
     ok = ok && HIP_OK(hipHostMalloc(&d.pinned, d.pinned_bytes, hipHostMallocDefault));
     if (!ok) { WMI_ERR("%s: device allocation failed\n", __func__); return false; }
@@ -87,7 +88,7 @@ void free_state(whisper_context & ctx) {
     dfree(d.pcm); dfree(d.mel); dfree(d.mel_max); dfree(d.mel_t); dfree(d.conv1); dfree(d.x); dfree(d.embd_conv);
     dfree(d.xn); dfree(d.q); dfree(d.k); dfree(d.vt); dfree(d.att); dfree(d.h); dfree(d.rowmax); dfree(d.enc_out);
     dfree(d.enc_out_h); dfree(d.d_tokens); dfree(d.d_pos); dfree(d.d_mask); dfree(d.d_rows); dfree(d.dx); dfree(d.dxn);
-    dfree(d.dq); dfree(d.datt); dfree(d.dh); dfree(d.logits);
+    dfree(d.dq); dfree(d.datt); dfree(d.dh); dfree(d.logits); dfree(d.xattn);
     if (d.pinned) (void) hipHostFree(d.pinned);
     if (d.stream) (void) hipStreamDestroy(d.stream);
     delete st;
@@ -301,7 +302,9 @@ bool decode(whisper_context & ctx, const Batch & batch) {
         proj(1, k::EPI_F32_BIAS_RESID, nullptr, nullptr, d.datt, S, S, l.w_o, l.b_o, d.dx, S, d.dx, nullptr, 0, nullptr, 0, 0.f);
         // cross-attention against the encoder K/V of this layer, no mask (W/whisper.cpp:2359-2433)
         proj(2, k::EPI_Q_SCALED, l.ln2_g, l.ln2_b, nullptr, S, S, l.w_cq, l.b_cq, d.dq, S, nullptr, nullptr, 0, nullptr, 0, kq_scale);
-        k::attn_decoder(d.dq, n, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, nullptr, 0, d.datt, s);
+        static const bool xattn_single = getenv("WMI_XATTN_SINGLE") != nullptr;     // debug: one workgroup per (token, head)
+        if (xattn_single) k::attn_decoder(d.dq, n, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, nullptr, 0, d.datt, s);
+        else k::attn_cross_split(d.dq, n, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, d.datt, s);
         proj(3, k::EPI_F32_BIAS_RESID, nullptr, nullptr, d.datt, S, S, l.w_co, l.b_co, d.dx, S, d.dx, nullptr, 0, nullptr, 0, 0.f);
         // MLP
         proj(4, k::EPI_F16_BIAS_GELU, l.ln3_g, l.ln3_b, nullptr, S, 4 * S, l.w_fc1, l.b_fc1, d.dh, 4 * S, nullptr, nullptr, 0, nullptr, 0, 0.f);

@@ -218,7 +218,137 @@ __global__ __launch_bounds__(256) void k_attn_dec(const __half * __restrict__ q,
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Decoder CROSS-attention, split over the key axis.  A decode step at batch 1 has only n_tokens x H = 8
+// (token, head) pairs, far too few workgroups for 256 CUs, while each pair has to stream 2 x T x 128 B of
+// K/V (384 KB at T = 1500).  The keys are therefore cut into NS slices handled by separate workgroups:
+//   pass 1  scores s = q.k for the slice (one key per lane: 8 independent 16-byte loads), slice max
+//   pass 2  m = max over slice maxima (exact global max), e = exp16(s - m), partial sum and partial e.V
+//   pass 3  combine the NS partial sums / outputs, normalise, round to f16
+// i.e. the reference's soft-max with its two f16 roundings, evaluated without a serial pass over T.
+constexpr int XS_MAX_SLICES = 16;
+
+__global__ __launch_bounds__(256) void k_xattn_scores(const __half * __restrict__ q, int S, const __half * __restrict__ kc,
+                                                      int T, int ks, int ns, float * __restrict__ sc, int ld_sc,
+                                                      float * __restrict__ pmax) {
+    __shared__ float qs[64];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slice = blockIdx.x, head = blockIdx.y, i = blockIdx.z, H = gridDim.y;
+    if (tid < 64) qs[tid] = __half2float(q[(size_t) i * S + head * 64 + tid]);
+    __syncthreads();
+    float lmax = -INFINITY;
+    for (int t = tid; t < ks; t += 256) {
+        const int j = slice * ks + t;
+        if (j >= T) break;
+        const uint4 * kp = (const uint4 *) (kc + (size_t) j * S + head * 64);
+        uint4 u[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) u[c] = kp[c];
+        float dot = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const __half2 * h = (const __half2 *) &u[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float2 f = __half22float2(h[e]);
+                dot = fmaf(f.x, qs[c * 8 + e * 2], dot);
+                dot = fmaf(f.y, qs[c * 8 + e * 2 + 1], dot);
+            }
+        }
+        sc[((size_t) i * H + head) * ld_sc + j] = dot;
+        lmax = fmaxf(lmax, dot);
+    }
+    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+    if (lane == 0) red[wave] = lmax;
+    __syncthreads();
+    if (tid == 0) pmax[((size_t) i * H + head) * ns + slice] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(256) void k_xattn_pv(const __half * __restrict__ vc, int S, int T, int ks, int ns,
+                                                  const float * __restrict__ sc, int ld_sc, const float * __restrict__ pmax,
+                                                  float * __restrict__ part_o, float * __restrict__ part_l) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float * e   = (float *) smem;                 // [ks]
+    float * red = e + ((ks + 3) & ~3);            // [4][64] partial outputs, then [4] sums
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slice = blockIdx.x, head = blockIdx.y, i = blockIdx.z, H = gridDim.y;
+    const size_t row = (size_t) i * H + head;
+    float m = -INFINITY;
+    for (int s2 = 0; s2 < ns; ++s2) m = fmaxf(m, pmax[row * ns + s2]);
+    const int j0 = slice * ks;
+    const int cnt = max(0, min(ks, T - j0));
+    float lsum = 0.0f;
+    for (int t = tid; t < cnt; t += 256) {
+        const float v = exp16(sc[row * ld_sc + j0 + t] - m);
+        e[t] = v; lsum += v;
+    }
+    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+    __syncthreads();
+    // e.V: lane = (key sub-index, 16-byte chunk of the 64-wide head slice); 8 keys per wave instruction
+    const int kg = lane >> 3, ch = lane & 7;
+    float acc[8];
+#pragma unroll
+    for (int d = 0; d < 8; ++d) acc[d] = 0.0f;
+    for (int t = wave * 8 + kg; t < cnt; t += 32) {
+        const uint4 u = *(const uint4 *) (vc + (size_t) (j0 + t) * S + head * 64 + ch * 8);
+        const __half2 * h = (const __half2 *) &u;
+        const float w = e[t];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const float2 f = __half22float2(h[p]);
+            acc[2 * p]     = fmaf(w, f.x, acc[2 * p]);
+            acc[2 * p + 1] = fmaf(w, f.y, acc[2 * p + 1]);
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        float v = acc[d];
+        v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        acc[d] = v;
+    }
+    if (kg == 0) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) red[wave * 64 + ch * 8 + d] = acc[d];
+    }
+    __shared__ float lred[4];
+    if (lane == 0) lred[wave] = lsum;
+    __syncthreads();
+    if (tid < 64) part_o[(row * ns + slice) * 64 + tid] = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
+    if (tid == 0) part_l[row * ns + slice] = (lred[0] + lred[1]) + (lred[2] + lred[3]);
+}
+
+__global__ __launch_bounds__(64) void k_xattn_combine(const float * __restrict__ part_o, const float * __restrict__ part_l,
+                                                      int ns, int S, __half * __restrict__ out) {
+    const int head = blockIdx.x, i = blockIdx.y, H = gridDim.x, d = threadIdx.x;
+    const size_t row = (size_t) i * H + head;
+    float o = 0.0f; double l = 0.0;
+    for (int s2 = 0; s2 < ns; ++s2) { o += part_o[(row * ns + s2) * 64 + d]; l += (double) part_l[row * ns + s2]; }
+    out[(size_t) i * S + head * 64 + d] = __float2half_rn(o * (float) (1.0 / l));
+}
+
 } // namespace
+
+void attn_cross_split(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int T,
+                      float * scratch, __half * out, hipStream_t st) {
+    // scratch layout: scores [n][H][Tpad] | pmax [n][H][NS] | part_l [n][H][NS] | part_o [n][H][NS][64]
+    int ns = (T + 191) / 192; if (ns < 1) ns = 1; if (ns > XS_MAX_SLICES) ns = XS_MAX_SLICES;
+    const int ks = (T + ns - 1) / ns;
+    const int ld_sc = (T + 63) & ~63;
+    float * sc = scratch;
+    float * pmax = sc + (size_t) n * H * ld_sc;
+    float * part_l = pmax + (size_t) n * H * ns;
+    float * part_o = part_l + (size_t) n * H * ns;
+    hipLaunchKernelGGL(k_xattn_scores, dim3(ns, H, n), dim3(256), 0, st, q, S, kc, T, ks, ns, sc, ld_sc, pmax);
+    const size_t smem = (((size_t) ks + 3) & ~(size_t) 3) * 4 + 4 * 64 * 4;
+    hipLaunchKernelGGL(k_xattn_pv, dim3(ns, H, n), dim3(256), smem, st, vc, S, T, ks, ns, sc, ld_sc, pmax, part_o, part_l);
+    hipLaunchKernelGGL(k_xattn_combine, dim3(H, n), dim3(64), 0, st, part_o, part_l, ns, S, out);
+}
+
+size_t attn_cross_scratch_floats(int n, int H, int T) {
+    const int ld_sc = (T + 63) & ~63;
+    return (size_t) n * H * ((size_t) ld_sc + 2 * XS_MAX_SLICES + (size_t) XS_MAX_SLICES * 64);
+}
 
 void attn_encoder(const __half * q, const __half * k, const __half * vt, int T, int Tpad, int S, int H, float scale,
                   __half * out, hipStream_t st) {

@@ -62,6 +62,11 @@ void attn_encoder(const __half * q, const __half * k, const __half * vt, int T, 
 void attn_decoder(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int n_kv,
                   const float * mask, int ld_mask, __half * out, hipStream_t st);
 
+// decoder cross-attention split over the key axis (3 small launches, NS x H x n workgroups); same numerics
+void attn_cross_split(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int T,
+                      float * scratch, __half * out, hipStream_t st);
+size_t attn_cross_scratch_floats(int n, int H, int T);
+
 // ---------------------------------------------------------------- decoder small-batch (k_dec.hip)
 void dec_embed(const int32_t * tokens, const int32_t * pos, int n, int S, const __half * te, const float * pe,
                float * x, hipStream_t st);

@@ -177,6 +177,7 @@ struct DeviceState {
     float   * d_mask = nullptr;                               // [n][n_kv_max]
     int32_t * d_rows = nullptr;                               // rows flagged for logits
     float  * dx = nullptr;  __half * dxn = nullptr, * dq = nullptr, * datt = nullptr, * dh = nullptr;
+    float  * xattn = nullptr;                                 // cross-attention split scratch
     float  * logits = nullptr;  int logits_rows_cap = 0;      // [rows][n_vocab]
     void   * pinned = nullptr;  size_t pinned_bytes = 0;      // host staging (tokens/pos/mask/logits)
 };

@@ -61,8 +61,12 @@ def param_variants(node):
     from godot_whisper_amd import abi
     out = {}
     out["host"] = node.full_params("", 0)
-    p = node.lib.whisper_full_default_params(abi.WHISPER_SAMPLING_GREEDY)      # library defaults: multi-segment, no token ts
-    p.language = b"en"; out["default_greedy"] = p
+    # library defaults (multi-window, multi-segment, no token timestamps) with the temperature fallback switched off:
+    # the fallback decision compares avg_logprob with a threshold and is discontinuous in the logits
+    p = node.lib.whisper_full_default_params(abi.WHISPER_SAMPLING_GREEDY)
+    p.language = b"en"; p.temperature_inc = 0.0; out["default_greedy"] = p
+    p = node.lib.whisper_full_default_params(abi.WHISPER_SAMPLING_GREEDY)      # ... and with it on (compared up to the first split)
+    p.language = b"en"; out["default_fallback"] = p
     p = node.lib.whisper_full_default_params(abi.WHISPER_SAMPLING_BEAM_SEARCH)
     p.language = b"en"; p.max_tokens = 12; p.single_segment = True; out["beam5"] = p
     p = node.full_params("", 0)
