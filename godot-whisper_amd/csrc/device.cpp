@@ -88,7 +88,13 @@ void free_state(whisper_context & ctx) {
     dfree(d.pcm); dfree(d.mel); dfree(d.mel_max); dfree(d.mel_t); dfree(d.conv1); dfree(d.x); dfree(d.embd_conv);
     dfree(d.xn); dfree(d.q); dfree(d.k); dfree(d.vt); dfree(d.att); dfree(d.h); dfree(d.rowmax); dfree(d.enc_out);
     dfree(d.enc_out_h); dfree(d.d_tokens); dfree(d.d_pos); dfree(d.d_mask); dfree(d.d_rows); dfree(d.dx); dfree(d.dxn);
-    dfree(d.dq); dfree(d.datt); dfree(d.dh); dfree(d.logits); dfree(d.xattn);
+    dfree(d.dq); dfree(d.datt); dfree(d.dh); dfree(d.logits); dfree(d.xattn); dfree(d.ban_dev);
+    if (d.step_exec) (void) hipGraphExecDestroy(d.step_exec);
+    if (d.step_graph) (void) hipGraphDestroy(d.step_graph);
+    if (d.step_dev) (void) hipFree(d.step_dev);
+    if (d.sample_dev) (void) hipFree(d.sample_dev);
+    if (d.step_host) (void) hipHostFree(d.step_host);
+    if (d.sample_host) (void) hipHostFree(d.sample_host);
     if (d.pinned) (void) hipHostFree(d.pinned);
     if (d.stream) (void) hipStreamDestroy(d.stream);
     delete st;
@@ -332,6 +338,156 @@ bool decode(whisper_context & ctx, const Batch & batch) {
     if (n == 1)      { st.t_decode_us += dt; st.n_decode++; }
     else if (n < 16) { st.t_batchd_us += dt; st.n_batchd += n; }
     else             { st.t_prompt_us += dt; st.n_prompt += n; }
+    return true;
+}
+
+} // namespace wmi
+
+// ------------------------------------------------------------------------------------------------ greedy fast path
+namespace wmi {
+
+bool fast_path_enabled() {
+    static const bool off = getenv("WMI_HOST_SAMPLING") != nullptr;      // debug / A-B: force the host filter + sampling path
+    return !off;
+}
+
+// static part of the logit filters (W/whisper.cpp:4541-4593): one byte per vocabulary entry, rebuilt only when
+// the parameters that feed it change
+bool upload_static_ban(whisper_context & ctx, const whisper_full_params & params) {
+    State & st = *ctx.state; DeviceState & d = st.dev; const Vocab & v = ctx.model.vocab;
+    const uint64_t sig = (params.suppress_non_speech_tokens ? 1u : 0u) | (params.no_timestamps ? 2u : 0u) | (params.tdrz_enable ? 4u : 0u) | 8u;
+    if (d.ban_dev && d.ban_sig == sig) return true;
+    const int n = v.n_vocab;
+    std::vector<uint8_t> ban(n, 0);
+    auto B = [&](int id) { if (id >= 0 && id < n) ban[id] = 1; };
+    B(v.not_); B(v.sot); B(v.nosp); if (!params.tdrz_enable) B(v.solm);
+    B(v.translate); B(v.transcribe); B(v.prev);
+    for (int i = 0; i < lang_count(); ++i) B(v.sot + 1 + i);
+    if (params.no_timestamps) for (int i = v.beg; i < n; ++i) ban[i] = 1;
+    if (params.suppress_non_speech_tokens) {
+        Decoder tmp; tmp.i_batch = 0;                         // reuse the host filter on an all-zero logit row to harvest the list
+        std::vector<float> saved; saved.swap(st.logits);
+        st.logits.assign(n, 0.0f);
+        for (int i = v.beg; i < n; ++i) st.logits[i] = -1e30f;   // keep the "timestamp mass beats text" rule from firing
+        whisper_full_params p2 = params; p2.suppress_blank = false; p2.max_initial_ts = 0.0f; p2.logits_filter_callback = nullptr;
+        tmp.sequence.tokens.push_back(whisper_token_data{0, 0, 0.f, 0.f, 0.f, 0.f, -1, -1, 0.f});   // not "initial"
+        process_logits(ctx, tmp, p2, 0.0f);
+        for (int i = 0; i < v.beg; ++i) if (tmp.logits[i] == -INFINITY) ban[i] = 1;
+        st.logits.swap(saved);
+    }
+    if (!d.ban_dev && !dalloc(d.ban_dev, (size_t) n)) return false;
+    HIP_TRY(hipMemcpyAsync(d.ban_dev, ban.data(), (size_t) n, hipMemcpyHostToDevice, d.stream));
+    HIP_TRY(hipStreamSynchronize(d.stream));
+    d.ban_sig = sig;
+    return true;
+}
+
+// the kernels of one greedy step; every per-step quantity is read from DecStep on the device, so the same launch
+// sequence can be replayed as a graph
+static void enqueue_greedy_step(whisper_context & ctx, int Tc) {
+    State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
+    KVCache & kv = st.kv_self;
+    const int S = hp.n_text_state, H = hp.n_text_head, Lt = hp.n_text_layer, NV = hp.n_vocab, n_ctx = (int) kv.size;
+    hipStream_t s = d.stream;
+    const k::DecStep * stp = (const k::DecStep *) d.step_dev;
+    const float kq_scale = powf((float) S / H, -0.25f);
+    static const bool dbg = getenv("WMI_DEBUG_SYNC") != nullptr;
+    auto chk = [&](const char * what, int il) {
+        if (!dbg) return;
+        const hipError_t e = hipStreamSynchronize(s);
+        fprintf(stderr, "[wmi] greedy step: %s layer %d -> %s\n", what, il, hipGetErrorString(e));
+    };
+    k::dec_embed(&stp->token, &stp->pos, 1, S, w.d_te, w.d_pe, d.dx, s); chk("embed", -1);
+    auto gv = [&](int epi, const float * lg, const float * lb, const __half * a16, int K, int N, const __half * W, const float * bias,
+                  void * C, int ldc, const float * resid, void * aux, void * aux2, float scale, const int32_t * row_off) {
+        k::GemvArgs g{};
+        g.x32 = d.dx; g.ln_g = lg; g.ln_b = lb; g.eps = hp.eps; g.a16 = a16; g.n = 1; g.K = K; g.N = N; g.W = W; g.bias = bias;
+        g.epi = epi; g.C = C; g.ldc = ldc; g.resid = resid; g.ldr = S; g.aux = aux; g.ldaux = S; g.aux2 = aux2; g.ldaux2 = S;
+        g.scale = scale; g.S = S; g.rows = nullptr; g.row_off = row_off;
+        k::gemv(g, s);
+    };
+    for (int il = 0; il < Lt; ++il) {
+        const DecLayerW & l = w.dec[il];
+        __half * ck = kv.k + ((size_t) il * n_ctx) * S, * cv = kv.v + ((size_t) il * n_ctx) * S;
+        gv(k::EPI_QKV_DEC, l.ln1_g, l.ln1_b, nullptr, S, 3 * S, l.w_qkv, l.b_qkv, d.dq, S, nullptr, ck, cv, kq_scale, &stp->kv_head); chk("qkv", il);
+        k::attn_decoder(d.dq, 1, S, H, ck, cv, 0, nullptr, 0, d.datt, s, &stp->n_kv, n_ctx); chk("self-attn", il);
+        gv(k::EPI_F32_BIAS_RESID, nullptr, nullptr, d.datt, S, S, l.w_o, l.b_o, d.dx, S, d.dx, nullptr, nullptr, 0.f, nullptr);
+        gv(k::EPI_Q_SCALED, l.ln2_g, l.ln2_b, nullptr, S, S, l.w_cq, l.b_cq, d.dq, S, nullptr, nullptr, nullptr, kq_scale, nullptr);
+        chk("cross-q", il);
+        k::attn_cross_split(d.dq, 1, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, d.datt, s); chk("cross-attn", il);
+        gv(k::EPI_F32_BIAS_RESID, nullptr, nullptr, d.datt, S, S, l.w_co, l.b_co, d.dx, S, d.dx, nullptr, nullptr, 0.f, nullptr);
+        gv(k::EPI_F16_BIAS_GELU, l.ln3_g, l.ln3_b, nullptr, S, 4 * S, l.w_fc1, l.b_fc1, d.dh, 4 * S, nullptr, nullptr, nullptr, 0.f, nullptr);
+        gv(k::EPI_F32_BIAS_RESID, nullptr, nullptr, d.dh, 4 * S, S, l.w_fc2, l.b_fc2, d.dx, S, d.dx, nullptr, nullptr, 0.f, nullptr);
+    }
+    chk("layers", Lt);
+    gv(k::EPI_LOGITS, w.d_ln_g, w.d_ln_b, nullptr, S, NV, w.d_te, nullptr, d.logits, NV, nullptr, nullptr, nullptr, 0.f, nullptr); chk("logits", Lt);
+    k::filter_argmax(d.logits, d.ban_dev, stp, (k::SampleOut *) d.sample_dev, s); chk("filter", Lt);
+}
+
+bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const StepFilter & f, whisper_token_data & out) {
+    if (ctx.host_only) { WMI_ERR("%s: host-only context has no compute path\n", __func__); return false; }
+    State & st = *ctx.state; DeviceState & d = st.dev; const HParams & hp = ctx.model.hp; const Vocab & v = ctx.model.vocab;
+    const int64_t t0 = time_us();
+    KVCache & kv = st.kv_self;
+    // same slot bookkeeping as the general path (W/whisper.cpp:2540-2544) so that both paths can be mixed
+    Batch & b = st.batch;
+    b.n_tokens = 1; b.token[0] = token; b.pos[0] = pos; b.seq_id[0] = 0; b.logits[0] = 1;
+    if (!kv_find_slot(kv, b)) return false;
+    kv.n = (uint32_t) kv_cell_max(kv);
+    // the fast path assumes the plain causal layout of a single greedy sequence: cells [0, head] all visible
+    if ((int) kv.n != (int) kv.head + 1) { WMI_ERR("%s: unexpected KV layout (n=%u head=%u)\n", __func__, kv.n, kv.head); return false; }
+    const int Tc = st.enc_n_ctx > 0 ? st.enc_n_ctx : hp.n_audio_ctx;
+
+    if (!d.step_dev) {
+        if (!HIP_OK(hipMalloc(&d.step_dev, sizeof(k::DecStep))) || !HIP_OK(hipMalloc(&d.sample_dev, sizeof(k::SampleOut))) ||
+            !HIP_OK(hipHostMalloc(&d.step_host, sizeof(k::DecStep), hipHostMallocDefault)) ||
+            !HIP_OK(hipHostMalloc(&d.sample_host, sizeof(k::SampleOut), hipHostMallocDefault))) return false;
+    }
+    k::DecStep * hs = (k::DecStep *) d.step_host;
+    memset(hs, 0, sizeof(*hs));
+    hs->token = token; hs->pos = pos; hs->n_kv = (int) kv.n; hs->kv_head = (int) kv.head;
+    hs->flags = (f.ban_blank ? 1 : 0) | (f.last_ts ? 2 : 0) | (f.penult_ts ? 4 : 0);
+    { auto sp = v.token_to_id.find(" "); hs->space_id = sp != v.token_to_id.end() ? sp->second : -1; }
+    hs->eot = v.eot; hs->beg = v.beg; hs->n_vocab = v.n_vocab;
+    hs->ts_floor_end = f.ts_floor_end; hs->ts_initial_start = f.ts_initial_start;
+
+    hipStream_t s = d.stream;
+    static const bool use_graph = getenv("WMI_NO_GRAPH") == nullptr;
+    if (use_graph && d.step_exec && d.step_graph_T != Tc) {             // encoder length changed: re-capture
+        (void) hipGraphExecDestroy(d.step_exec); (void) hipGraphDestroy(d.step_graph);
+        d.step_exec = nullptr; d.step_graph = nullptr;
+    }
+    if (use_graph && !d.step_exec) {
+        // first use: run once eagerly (lets the launchers set their function attributes), then capture
+        HIP_TRY(hipMemcpyAsync(d.step_dev, d.step_host, sizeof(k::DecStep), hipMemcpyHostToDevice, s));
+        enqueue_greedy_step(ctx, Tc);
+        HIP_TRY(hipStreamSynchronize(s));
+        if (HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal))) {
+            (void) hipMemcpyAsync(d.step_dev, d.step_host, sizeof(k::DecStep), hipMemcpyHostToDevice, s);
+            enqueue_greedy_step(ctx, Tc);
+            (void) hipMemcpyAsync(d.sample_host, d.sample_dev, sizeof(k::SampleOut), hipMemcpyDeviceToHost, s);
+            hipGraph_t g = nullptr;
+            if (HIP_OK(hipStreamEndCapture(s, &g)) && g && HIP_OK(hipGraphInstantiate(&d.step_exec, g, nullptr, nullptr, 0))) {
+                d.step_graph = g; d.step_graph_T = Tc;
+            } else {
+                WMI_WARN("%s: graph capture failed - staying on eager launches\n", __func__);
+                d.step_exec = nullptr;
+            }
+        }
+    }
+    if (use_graph && d.step_exec) {
+        HIP_TRY(hipGraphLaunch(d.step_exec, s));
+    } else {
+        HIP_TRY(hipMemcpyAsync(d.step_dev, d.step_host, sizeof(k::DecStep), hipMemcpyHostToDevice, s));
+        enqueue_greedy_step(ctx, Tc);
+        HIP_TRY(hipMemcpyAsync(d.sample_host, d.sample_dev, sizeof(k::SampleOut), hipMemcpyDeviceToHost, s));
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    const k::SampleOut * r = (const k::SampleOut *) d.sample_host;
+    if (getenv("WMI_DEBUG_SYNC")) fprintf(stderr, "[wmi] step token=%d pos=%d n_kv=%d head=%d flags=%d floor=%d init=%d -> id=%d tid=%d p=%g plog=%g pt=%g ptsum=%g forced=%d\n",
+        token, pos, hs->n_kv, hs->kv_head, hs->flags, hs->ts_floor_end, hs->ts_initial_start, r->id, r->tid, r->p, r->plog, r->pt, r->ptsum, r->forced_ts);
+    out = whisper_token_data{ r->id, r->tid, r->p, r->plog, r->pt, r->ptsum, -1, -1, 0.0f };
+    st.t_decode_us += time_us() - t0; st.n_decode++; st.n_sample++;
     return true;
 }
 

@@ -178,6 +178,39 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
             prompt.insert(prompt.end(), prompt_init.begin(), prompt_init.end());
 
             kv_clear(st.kv_self);
+            // Greedy, temperature 0, one decoder, no user logit callback: filters + arg-max run on the GPU and each
+            // step is one graph replay (device.cpp: decode_greedy_step).  Everything else takes the general path.
+            const bool fast = fast_path_enabled() && !beam && t_cur < 1e-6f && n_cur == 1 && !params.logits_filter_callback &&
+                              ctx.model.n_loaded > 0 && upload_static_ban(ctx, params);
+            whisper_token_data fast_next{};      // token picked on the device for the upcoming sampling step
+            auto step_filter = [&](const Decoder & d) {
+                const auto & h = d.sequence.tokens;
+                StepFilter f{};
+                const bool initial = h.empty();
+                f.ban_blank = params.suppress_blank && initial;
+                f.last_ts = !h.empty() && h.back().id >= v.beg;
+                f.penult_ts = h.size() < 2 || h[h.size() - 2].id >= v.beg;
+                f.ts_floor_end = d.has_ts ? v.beg + d.seek_delta / 2 : v.beg;
+                f.ts_initial_start = v.n_vocab;
+                if (initial && params.max_initial_ts > 0.0f) {
+                    const float precision = float(WHISPER_CHUNK_SIZE) / hp.n_audio_ctx;
+                    f.ts_initial_start = v.beg + (int) std::round(params.max_initial_ts / precision) + 1;
+                }
+                return f;
+            };
+            if (fast) {
+                bool ok = true;
+                if (prompt.size() > 1) {            // all but the last prompt token: plain batch decode, no logits wanted
+                    st.batch.prep_legacy(prompt.data(), (int) prompt.size() - 1, 0, 0);
+                    st.batch.logits[prompt.size() - 2] = 0;
+                    ok = decode(ctx, st.batch);
+                }
+                ok = ok && decode_greedy_step(ctx, prompt.back(), (int) prompt.size() - 1, step_filter(st.decoders[0]), fast_next);
+                if (!ok || (params.abort_callback && params.abort_callback(params.abort_callback_user_data))) {
+                    WMI_ERR("%s: failed to decode\n", __func__);
+                    return -7;
+                }
+            } else {
             st.batch.prep_legacy(prompt.data(), (int) prompt.size(), 0, 0);
             if (!decode(ctx, st.batch) || (params.abort_callback && params.abort_callback(params.abort_callback_user_data))) {
                 WMI_ERR("%s: failed to decode\n", __func__);
@@ -194,6 +227,7 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
                 }
                 st.t_sample_us += time_us() - ts;
             }
+            }
 
             const int n_max = hp.n_text_ctx / 2 - 4;
             for (int i = 0; i < n_max; ++i) {
@@ -204,7 +238,10 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
                 for (int j = 0; j < n_cur; ++j) {
                     Decoder & d = st.decoders[j];
                     if (d.completed || d.failed) continue;
-                    if (!beam) {
+                    if (fast) {
+                        d.sequence.tokens.push_back(fast_next);
+                        d.sequence.sum_logprobs_all += fast_next.plog;
+                    } else if (!beam) {
                         d.sequence.tokens.push_back(sample_token(ctx, d, t_cur < 1e-6f));
                         d.sequence.sum_logprobs_all += d.sequence.tokens.back().plog;
                     } else {
@@ -271,6 +308,15 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
                 if (all_done) break;
                 st.t_sample_us += time_us() - ts;
 
+                if (fast) {
+                    Decoder & d0 = st.decoders[0];
+                    if (!decode_greedy_step(ctx, d0.sequence.tokens.back().id, (int) prompt.size() + i, step_filter(d0), fast_next) ||
+                        (params.abort_callback && params.abort_callback(params.abort_callback_user_data))) {
+                        WMI_ERR("%s: failed to decode\n", __func__);
+                        return -8;
+                    }
+                    continue;
+                }
                 // next step: one token per live decoder, each in its own sequence id
                 Batch & b = st.batch;
                 b.n_tokens = 0;

@@ -154,11 +154,13 @@ __global__ __launch_bounds__(256) void k_attn_enc(const __half * __restrict__ q,
 // [cell][S].  Exactly the reference's three steps (scores + mask, soft-max through exp16, P rounded to
 // f16, P.V) — the score row (<= 1536 floats) lives in LDS.  HBM-bound: reads 2 * n_kv * 128 B.
 __global__ __launch_bounds__(256) void k_attn_dec(const __half * __restrict__ q, int S, const __half * __restrict__ kc,
-                                                  const __half * __restrict__ vc, int n_kv,
-                                                  const float * __restrict__ mask, int ld_mask, __half * __restrict__ out) {
+                                                  const __half * __restrict__ vc, int n_kv_arg,
+                                                  const float * __restrict__ mask, int ld_mask, __half * __restrict__ out,
+                                                  const int32_t * __restrict__ n_kv_dev, int n_kv_cap) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float * sc  = (float *) smem;                 // [n_kv]
-    float * qs  = sc + ((n_kv + 3) & ~3);         // [64]
+    const int n_kv = n_kv_dev ? *n_kv_dev : n_kv_arg;
+    float * sc  = (float *) smem;                 // [n_kv]  (sized for n_kv_cap under graph replay)
+    float * qs  = sc + (((n_kv_dev ? n_kv_cap : n_kv) + 3) & ~3);   // [64]
     float * red = qs + 64;                        // [256]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = blockIdx.x, head = blockIdx.y;
@@ -356,9 +358,10 @@ void attn_encoder(const __half * q, const __half * k, const __half * vt, int T, 
 }
 
 void attn_decoder(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int n_kv,
-                  const float * mask, int ld_mask, __half * out, hipStream_t st) {
-    const size_t smem = (((size_t) n_kv + 3) & ~(size_t) 3) * 4 + 64 * 4 + 256 * 4;
-    hipLaunchKernelGGL(k_attn_dec, dim3(n, H), dim3(256), smem, st, q, S, kc, vc, n_kv, mask, ld_mask, out);
+                  const float * mask, int ld_mask, __half * out, hipStream_t st, const int32_t * n_kv_dev, int n_kv_max) {
+    const int cap = n_kv_dev ? n_kv_max : n_kv;
+    const size_t smem = (((size_t) cap + 3) & ~(size_t) 3) * 4 + 64 * 4 + 256 * 4;
+    hipLaunchKernelGGL(k_attn_dec, dim3(n, H), dim3(256), smem, st, q, S, kc, vc, n_kv, mask, ld_mask, out, n_kv_dev, cap);
 }
 
 }} // namespace wmi::k

@@ -131,10 +131,16 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
                     case EPI_F32_BIAS_RESID: ((float *) a.C)[(size_t) r * a.ldc + n] = (v + bias) + a.resid[(size_t) r * a.ldr + n]; break;
                     case EPI_Q_SCALED:       ((__half *) a.C)[(size_t) r * a.ldc + n] = __float2half_rn((v + bias) * a.scale); break;
                     case EPI_QKV_DEC: {
-                        const int seg = n / a.S, c = n - seg * a.S;
-                        if (seg == 0)      ((__half *) a.C)[(size_t) r * a.ldc + c]       = __float2half_rn((v + bias) * a.scale);
-                        else if (seg == 1) ((__half *) a.aux)[(size_t) r * a.ldaux + c]   = __float2half_rn(v * a.scale);
-                        else               ((__half *) a.aux2)[(size_t) r * a.ldaux2 + c] = __float2half_rn(v + bias);
+                        // segment decided on a wave-uniform value (the 4 rows of this wave iteration never straddle a
+                        // q|k|v boundary: S % 4 == 0) — same precaution as in k_gemm.hip, see DESIGN.md §7
+                        const int seg = __builtin_amdgcn_readfirstlane(o0 / a.S);
+                        const int c = n - seg * a.S;
+                        const int ro = a.row_off ? *a.row_off : 0;          // KV-cache head (device scalar under graph replay)
+                        __half * dst; float val;
+                        if (seg == 0)      { dst = (__half *) a.C    + (size_t) r * a.ldc;           val = (v + bias) * a.scale; }
+                        else if (seg == 1) { dst = (__half *) a.aux  + (size_t) (r + ro) * a.ldaux;  val = v * a.scale; }
+                        else               { dst = (__half *) a.aux2 + (size_t) (r + ro) * a.ldaux2; val = v + bias; }
+                        dst[c] = __float2half_rn(val);
                     } break;
                     case EPI_LOGITS:         ((float *) a.C)[(size_t) r * a.ldc + n] = v; break;
                     default: break;

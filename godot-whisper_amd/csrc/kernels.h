@@ -60,7 +60,8 @@ void attn_encoder(const __half * q, const __half * k, const __half * vt, int T, 
                   float scale, __half * out, hipStream_t st);
 // decoder: one (token, head) per workgroup.  kc/vc: [n_kv][S] caches (this layer), mask: [n][ld_mask] or null
 void attn_decoder(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int n_kv,
-                  const float * mask, int ld_mask, __half * out, hipStream_t st);
+                  const float * mask, int ld_mask, __half * out, hipStream_t st,
+                  const int32_t * n_kv_dev = nullptr, int n_kv_max = 0);   // n_kv_dev: read n_kv on the device (graph replay)
 
 // decoder cross-attention split over the key axis (3 small launches, NS x H x n workgroups); same numerics
 void attn_cross_split(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int T,
@@ -83,9 +84,25 @@ struct GemvArgs {
     void * aux; int ldaux; void * aux2; int ldaux2;
     float scale; int S;
     const int32_t * rows;                     // optional row gather for the A operand (logits)
+    const int32_t * row_off;                  // optional device scalar: aux/aux2 row offset (KV cache head), graph replay
 };
 enum { EPI_LOGITS = 100 };                    // C f32 [n][N] = acc
 void gemv(const GemvArgs & a, hipStream_t st);
+
+// ---------------------------------------------------------------- device-side logit filters + greedy pick (k_sample.hip)
+// One decode step's dynamic inputs; lives in device memory, refreshed by a 64-byte H2D copy per step so that
+// the captured HIP graph of the step stays static.
+struct DecStep {
+    int32_t token, pos, n_kv, kv_head;
+    int32_t flags;                 // bit0 ban eot + " " (initial & suppress_blank) ; bit1 last token was a timestamp ; bit2 penultimate too
+    int32_t space_id, eot, beg, n_vocab;
+    int32_t ts_floor_end;          // timestamps in [beg, ts_floor_end) are banned (monotonic rule) ; = beg when inactive
+    int32_t ts_initial_start;      // timestamps in [ts_initial_start, n_vocab) are banned (max_initial_ts) ; = n_vocab when inactive
+    int32_t pad[5];
+};
+struct SampleOut { int32_t id, tid; float p, plog, pt, ptsum; int32_t forced_ts; int32_t pad; };
+// logits [n_vocab] -> filtered soft-max statistics and the arg-max token (W/whisper.cpp:4493-4830 at temperature 0)
+void filter_argmax(const float * logits, const uint8_t * static_ban, const DecStep * step, SampleOut * out, hipStream_t st);
 
 // misc
 void fill_zero(void * p, size_t bytes, hipStream_t st);

@@ -180,6 +180,11 @@ struct DeviceState {
     float  * xattn = nullptr;                                 // cross-attention split scratch
     float  * logits = nullptr;  int logits_rows_cap = 0;      // [rows][n_vocab]
     void   * pinned = nullptr;  size_t pinned_bytes = 0;      // host staging (tokens/pos/mask/logits)
+    // greedy fast path: one decode step = one captured HIP graph (SURVEY (f)1 + launch-bound inner loop)
+    void   * step_dev = nullptr;   void * step_host = nullptr;       // k::DecStep (device / pinned)
+    void   * sample_dev = nullptr; void * sample_host = nullptr;     // k::SampleOut (device / pinned)
+    uint8_t * ban_dev = nullptr;   uint64_t ban_sig = ~0ull;          // static suppress mask + its parameter signature
+    hipGraph_t step_graph = nullptr; hipGraphExec_t step_exec = nullptr; int step_graph_T = -1;
 };
 
 struct State {
@@ -222,6 +227,11 @@ bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, boo
 bool set_mel(whisper_context & ctx, const float * data, int n_len, int n_mel);
 bool encode(whisper_context & ctx, int mel_offset);
 bool decode(whisper_context & ctx, const Batch & batch);
+// greedy fast path: decode ONE token of sequence 0 at position `pos` and pick the next token on the device
+struct StepFilter { bool ban_blank, last_ts, penult_ts; int ts_floor_end, ts_initial_start; };
+bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const StepFilter & f, whisper_token_data & out);
+bool upload_static_ban(whisper_context & ctx, const whisper_full_params & params);
+bool fast_path_enabled();
 bool signal_energy_device(whisper_context & ctx, int hw);   // fills state.energy from the last PCM
 
 // host logic (logits filters, sampling, driver)
