@@ -93,6 +93,7 @@ void free_state(whisper_context & ctx) {
     if (d.step_graph) (void) hipGraphDestroy(d.step_graph);
     if (d.step_dev) (void) hipFree(d.step_dev);
     if (d.sample_dev) (void) hipFree(d.sample_dev);
+    if (d.filter_scratch) (void) hipFree(d.filter_scratch);
     if (d.step_host) (void) hipHostFree(d.step_host);
     if (d.sample_host) (void) hipHostFree(d.sample_host);
     if (d.pinned) (void) hipHostFree(d.pinned);
@@ -414,14 +415,21 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc) {
         gv(k::EPI_F32_BIAS_RESID, nullptr, nullptr, d.datt, S, S, l.w_o, l.b_o, d.dx, S, d.dx, nullptr, nullptr, 0.f, nullptr);
         gv(k::EPI_Q_SCALED, l.ln2_g, l.ln2_b, nullptr, S, S, l.w_cq, l.b_cq, d.dq, S, nullptr, nullptr, nullptr, kq_scale, nullptr);
         chk("cross-q", il);
-        k::attn_cross_split(d.dq, 1, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, d.datt, s); chk("cross-attn", il);
-        gv(k::EPI_F32_BIAS_RESID, nullptr, nullptr, d.datt, S, S, l.w_co, l.b_co, d.dx, S, d.dx, nullptr, nullptr, 0.f, nullptr);
+        {   // cross-attention partials, combined inside the out-projection's prologue
+            const float * po = nullptr, * pl = nullptr; int ns = 0;
+            k::attn_cross_split_partials(d.dq, 1, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, &po, &pl, &ns, s);
+            chk("cross-attn", il);
+            k::GemvArgs g{};
+            g.comb_o = po; g.comb_l = pl; g.comb_ns = ns; g.n = 1; g.K = S; g.N = S; g.W = l.w_co; g.bias = l.b_co; g.epi = k::EPI_F32_BIAS_RESID;
+            g.C = d.dx; g.ldc = S; g.resid = d.dx; g.ldr = S; g.S = S;
+            k::gemv(g, s);
+        }
         gv(k::EPI_F16_BIAS_GELU, l.ln3_g, l.ln3_b, nullptr, S, 4 * S, l.w_fc1, l.b_fc1, d.dh, 4 * S, nullptr, nullptr, nullptr, 0.f, nullptr);
         gv(k::EPI_F32_BIAS_RESID, nullptr, nullptr, d.dh, 4 * S, S, l.w_fc2, l.b_fc2, d.dx, S, d.dx, nullptr, nullptr, 0.f, nullptr);
     }
     chk("layers", Lt);
     gv(k::EPI_LOGITS, w.d_ln_g, w.d_ln_b, nullptr, S, NV, w.d_te, nullptr, d.logits, NV, nullptr, nullptr, nullptr, 0.f, nullptr); chk("logits", Lt);
-    k::filter_argmax(d.logits, d.ban_dev, stp, (k::SampleOut *) d.sample_dev, s); chk("filter", Lt);
+    k::filter_argmax(d.logits, d.ban_dev, stp, (k::SampleOut *) d.sample_dev, d.filter_scratch, s); chk("filter", Lt);
 }
 
 bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const StepFilter & f, whisper_token_data & out) {
@@ -439,7 +447,7 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
     const int Tc = st.enc_n_ctx > 0 ? st.enc_n_ctx : hp.n_audio_ctx;
 
     if (!d.step_dev) {
-        if (!HIP_OK(hipMalloc(&d.step_dev, sizeof(k::DecStep))) || !HIP_OK(hipMalloc(&d.sample_dev, sizeof(k::SampleOut))) ||
+        if (!HIP_OK(hipMalloc(&d.step_dev, sizeof(k::DecStep))) || !HIP_OK(hipMalloc(&d.filter_scratch, k::filter_scratch_bytes())) || !HIP_OK(hipMalloc(&d.sample_dev, sizeof(k::SampleOut))) ||
             !HIP_OK(hipHostMalloc(&d.step_host, sizeof(k::DecStep), hipHostMallocDefault)) ||
             !HIP_OK(hipHostMalloc(&d.sample_host, sizeof(k::SampleOut), hipHostMallocDefault))) return false;
     }

@@ -9,7 +9,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace wmi {
 
@@ -45,6 +47,13 @@ void emit_segment(whisper_context & ctx, const whisper_full_params & params, int
 
 int full(whisper_context & ctx, whisper_full_params params, const float * samples, const float * d_samples, int n_samples) {
     State & st = *ctx.state;
+    static const bool dbg_t = getenv("WMI_DEBUG_TIMING") != nullptr;
+    const int64_t T0 = time_us(); int64_t T_mel = 0, T_energy = 0, T_emit = 0;
+    struct Report { bool on; int64_t t0; int64_t * mel, * en, * emit; State * st; ~Report() { if (on) fprintf(stderr,
+        "[wmi] full: total %.3f ms | mel %.3f | envelope %.3f | encode %.3f | decode %.3f (+prompt/batch %.3f) | segments+timestamps %.3f\n",
+        (time_us() - t0) / 1e3, *mel / 1e3, *en / 1e3, st->t_encode_us / 1e3, st->t_decode_us / 1e3, (st->t_prompt_us + st->t_batchd_us) / 1e3, *emit / 1e3); } }
+        report{dbg_t, T0, &T_mel, &T_energy, &T_emit, &st};
+    if (dbg_t) { st.t_encode_us = st.t_decode_us = st.t_prompt_us = st.t_batchd_us = 0; }
     const Vocab & v = ctx.model.vocab;
     const HParams & hp = ctx.model.hp;
     st.result_all.clear();
@@ -53,6 +62,7 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
         if (params.speed_up) { WMI_ERR("%s: failed to compute log mel spectrogram\n", __func__); return -1; }
         const bool ok_mel = d_samples ? pcm_to_mel(ctx, d_samples, n_samples, true) : pcm_to_mel(ctx, samples, n_samples, false);
         if (!ok_mel) { WMI_ERR("%s: failed to compute log mel spectrogram\n", __func__); return -2; }
+        T_mel = time_us() - T0;
     }
 
     if (params.language == nullptr || strlen(params.language) == 0 || strcmp(params.language, "auto") == 0 || params.detect_language) {
@@ -69,6 +79,8 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
         st.t_beg = 0; st.t_last = 0; st.tid_last = 0;
         // the |x| envelope is computed on the GPU from the samples pcm_to_mel just staged (bit-identical to the
         // CPU loop, k_signal_energy); the host loop remains only as the definition it is tested against
+        const int64_t te0 = time_us();
+        struct En { int64_t & acc; int64_t t0; ~En() { acc += time_us() - t0; } } en_timer{T_energy, te0};
         if (n_samples > 0 && !signal_energy_device(ctx, 32)) { WMI_ERR("%s: failed to compute the signal envelope\n", __func__); return -2; }
     }
 
@@ -364,6 +376,8 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
 
         // results of this window
         {
+            const int64_t tem0 = time_us();
+            struct Em { int64_t & acc; int64_t t0; ~Em() { acc += time_us() - t0; } } em_timer{T_emit, tem0};
             const Decoder & best = st.decoders[best_decoder_id];
             const int seek_delta = best.seek_delta, result_len = best.sequence.result_len;
             const auto & toks = best.sequence.tokens;
@@ -487,6 +501,50 @@ void token_level_timestamps(whisper_context & ctx, int i_segment, float thold_pt
     // expand / contract by voice activity
     const int hw = WHISPER_SAMPLE_RATE / 8;
     const std::vector<float> & en = st.energy;
+    // The walks below ("move left/right while the envelope stays above/below the threshold") run to the end of
+    // the signal on stationary audio — millions of scalar steps per call in the reference.  They are pure
+    // searches, so they are done 16 samples at a time with a branch-free block test the compiler vectorises;
+    // the element they stop on is the same.
+    auto walk_down_while_above = [&](int k, float th) {      // while (k > 0 && en[k] > th) --k;
+        while (k >= 16) {
+            bool all = true;
+            for (int i = 0; i < 16; ++i) all &= en[k - i] > th;
+            if (!all) break;
+            k -= 16;
+        }
+        while (k > 0 && en[k] > th) --k;
+        return k;
+    };
+    auto walk_up_while_above = [&](int k, float th, int last) {   // while (k < last && en[k] > th) ++k;
+        while (k + 16 <= last) {
+            bool all = true;
+            for (int i = 0; i < 16; ++i) all &= en[k + i] > th;
+            if (!all) break;
+            k += 16;
+        }
+        while (k < last && en[k] > th) ++k;
+        return k;
+    };
+    auto walk_up_while_below = [&](int k, float th, int last) {   // while (en[k] < th && k < last) ++k;
+        while (k + 16 <= last) {
+            bool all = true;
+            for (int i = 0; i < 16; ++i) all &= en[k + i] < th;
+            if (!all) break;
+            k += 16;
+        }
+        while (en[k] < th && k < last) ++k;
+        return k;
+    };
+    auto walk_down_while_below = [&](int k, float th, int first) { // while (en[k] < th && k > first) --k;
+        while (k - 16 >= first) {
+            bool all = true;
+            for (int i = 0; i < 16; ++i) all &= en[k - i] < th;
+            if (!all) break;
+            k -= 16;
+        }
+        while (en[k] < th && k > first) --k;
+        return k;
+    };
     for (int j = 0; j < n; ++j) {
         if (tokens[j].id >= v.eot) continue;
         int s0 = ts_to_sample(tokens[j].t0, n_samples), s1 = ts_to_sample(tokens[j].t1, n_samples);
@@ -498,11 +556,11 @@ void token_level_timestamps(whisper_context & ctx, int i_segment, float thold_pt
         {
             int k2 = s0;
             if (en[k2] > thold && j > 0) {
-                while (k2 > 0 && en[k2] > thold) --k2;
+                k2 = walk_down_while_above(k2, thold);
                 tokens[j].t0 = sample_to_ts(k2);
                 if (tokens[j].t0 < tokens[j - 1].t1) tokens[j].t0 = tokens[j - 1].t1; else s0 = k2;
             } else {
-                while (en[k2] < thold && k2 < s1) ++k2;
+                k2 = walk_up_while_below(k2, thold, s1);
                 s0 = k2;
                 tokens[j].t0 = sample_to_ts(k2);
             }
@@ -510,7 +568,7 @@ void token_level_timestamps(whisper_context & ctx, int i_segment, float thold_pt
         {
             int k2 = s1;
             if (en[k2] > thold) {
-                while (k2 < n_samples - 1 && en[k2] > thold) ++k2;
+                k2 = walk_up_while_above(k2, thold, n_samples - 1);
                 tokens[j].t1 = sample_to_ts(k2);
                 // The reference tests `j < ns - 1` (window length, not token count) and so reads tokens[n] — one past
                 // the end — for the last token (W/whisper.cpp:6561); what it finds there is heap garbage (usually 0,
@@ -518,7 +576,7 @@ void token_level_timestamps(whisper_context & ctx, int i_segment, float thold_pt
                 // token keeps its own end.  tests/test_gpu_parity.py exempts exactly this field.
                 if (j < ns - 1 && j + 1 < n && tokens[j].t1 > tokens[j + 1].t0) tokens[j].t1 = tokens[j + 1].t0; else s1 = k2;
             } else {
-                while (en[k2] < thold && k2 > s0) --k2;
+                k2 = walk_down_while_below(k2, thold, s0);
                 s1 = k2;
                 tokens[j].t1 = sample_to_ts(k2);
             }

@@ -347,6 +347,21 @@ void attn_cross_split(const __half * q, int n, int S, int H, const __half * kc, 
     hipLaunchKernelGGL(k_xattn_combine, dim3(H, n), dim3(64), 0, st, part_o, part_l, ns, S, out);
 }
 
+void attn_cross_split_partials(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int T,
+                               float * scratch, const float ** po, const float ** pl, int * pns, hipStream_t st) {
+    int ns = (T + 191) / 192; if (ns < 1) ns = 1; if (ns > XS_MAX_SLICES) ns = XS_MAX_SLICES;
+    const int ks = (T + ns - 1) / ns;
+    const int ld_sc = (T + 63) & ~63;
+    float * sc = scratch;
+    float * pmax = sc + (size_t) n * H * ld_sc;
+    float * part_l = pmax + (size_t) n * H * ns;
+    float * part_o = part_l + (size_t) n * H * ns;
+    hipLaunchKernelGGL(k_xattn_scores, dim3(ns, H, n), dim3(256), 0, st, q, S, kc, T, ks, ns, sc, ld_sc, pmax);
+    const size_t smem = (((size_t) ks + 3) & ~(size_t) 3) * 4 + 4 * 64 * 4;
+    hipLaunchKernelGGL(k_xattn_pv, dim3(ns, H, n), dim3(256), smem, st, vc, S, T, ks, ns, sc, ld_sc, pmax, part_o, part_l);
+    *po = part_o; *pl = part_l; *pns = ns;
+}
+
 size_t attn_cross_scratch_floats(int n, int H, int T) {
     const int ld_sc = (T + 63) & ~63;
     return (size_t) n * H * ((size_t) ld_sc + 2 * XS_MAX_SLICES + (size_t) XS_MAX_SLICES * 64);

@@ -41,24 +41,51 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
     __half * act = (__half *) smem;                         // [R][K]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K;
+    const int nwaves = gridDim.x * 4;
+    const int gw = blockIdx.x * 4 + wave;
 
-    // ---- prologue: stage the activation rows (optionally LayerNorm'ed) as f16
-    if (a.ln_g) {
+    // ---- weight prefetch: the first 16 bytes of this wavefront's first rows do not depend on the activations,
+    // so their HBM/MALL latency is overlapped with the prologue below
+    uint4 wpre[ROWS_IN_FLIGHT];
+    const bool have_pre = gw * ROWS_IN_FLIGHT < a.N && lane * 8 < K;
+    if (have_pre) {
+#pragma unroll
+        for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
+            int o = gw * ROWS_IN_FLIGHT + u; if (o > a.N - 1) o = a.N - 1;
+            wpre[u] = *(const uint4 *) (a.W + (size_t) o * K + lane * 8);
+        }
+    }
+
+    // ---- prologue: stage the activation rows as f16
+    if (a.ln_g) {                                           // fused LayerNorm of the f32 residual stream
+        constexpr int XV = 20;                              // row kept in registers: K <= 64 * 20 = 1280 (every Whisper size)
         for (int r = wave; r < R; r += 4) {
             const int src = a.rows ? a.rows[r] : r;
             const float * xr = a.x32 + (size_t) src * K;
-            float sum = 0.0f;
-            for (int c = lane; c < K; c += 64) sum += xr[c];
+            float xv[XV]; float sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < XV; ++j) { const int c = lane + 64 * j; xv[j] = c < K ? xr[c] : 0.0f; sum += xv[j]; }
             for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
             const float mean = sum / (float) K;
             float sq = 0.0f;
-            for (int c = lane; c < K; c += 64) { const float d = xr[c] - mean; sq += d * d; }
+#pragma unroll
+            for (int j = 0; j < XV; ++j) { const int c = lane + 64 * j; if (c < K) { xv[j] -= mean; sq += xv[j] * xv[j]; } }
             for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
             const float sc = 1.0f / sqrtf(sq / (float) K + a.eps);
-            for (int c = lane; c < K; c += 64) {
-                const float y = __fadd_rn(__fmul_rn((xr[c] - mean) * sc, a.ln_g[c]), a.ln_b[c]);
-                act[r * K + c] = __float2half_rn(y);
+#pragma unroll
+            for (int j = 0; j < XV; ++j) {
+                const int c = lane + 64 * j;
+                if (c < K) act[r * K + c] = __float2half_rn(__fadd_rn(__fmul_rn(xv[j] * sc, a.ln_g[c]), a.ln_b[c]));
             }
+        }
+    } else if (a.comb_o) {                                  // fused combine of the split cross-attention partials
+        const int H = K / 64, ns = a.comb_ns;
+        for (int e = tid; e < R * K; e += 256) {
+            const int r = e / K, c = e - r * K, h = c >> 6, dd = c & 63;
+            const size_t row = (size_t) r * H + h;
+            float o = 0.0f; double l = 0.0;
+            for (int s2 = 0; s2 < ns; ++s2) { o += a.comb_o[(row * ns + s2) * 64 + dd]; l += (double) a.comb_l[row * ns + s2]; }
+            act[e] = __float2half_rn(o * (float) (1.0 / l));
         }
     } else {
         for (int r = 0; r < R; ++r) {
@@ -70,8 +97,7 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
     }
     __syncthreads();
 
-    const int nwaves = gridDim.x * 4;
-    const int gw = blockIdx.x * 4 + wave;
+    bool first = have_pre;
     for (int o0 = gw * ROWS_IN_FLIGHT; o0 < a.N; o0 += nwaves * ROWS_IN_FLIGHT) {
         float acc[ROWS_IN_FLIGHT][R];
 #pragma unroll
@@ -81,10 +107,16 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
 
         for (int c = lane * 8; c < K; c += 512) {
             uint4 w[ROWS_IN_FLIGHT];
+            if (first) {
 #pragma unroll
-            for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
-                int o = o0 + u; if (o > a.N - 1) o = a.N - 1;
-                w[u] = *(const uint4 *) (a.W + (size_t) o * K + c);
+                for (int u = 0; u < ROWS_IN_FLIGHT; ++u) w[u] = wpre[u];
+                first = false;
+            } else {
+#pragma unroll
+                for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
+                    int o = o0 + u; if (o > a.N - 1) o = a.N - 1;
+                    w[u] = *(const uint4 *) (a.W + (size_t) o * K + c);
+                }
             }
             float av[R][8];
 #pragma unroll

@@ -66,6 +66,9 @@ void attn_decoder(const __half * q, int n, int S, int H, const __half * kc, cons
 // decoder cross-attention split over the key axis (3 small launches, NS x H x n workgroups); same numerics
 void attn_cross_split(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int T,
                       float * scratch, __half * out, hipStream_t st);
+// same without the combine launch: the consumer GEMV combines the partials in its prologue (GemvArgs::comb_*)
+void attn_cross_split_partials(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int T,
+                               float * scratch, const float ** part_o, const float ** part_l, int * ns, hipStream_t st);
 size_t attn_cross_scratch_floats(int n, int H, int T);
 
 // ---------------------------------------------------------------- decoder small-batch (k_dec.hip)
@@ -85,6 +88,7 @@ struct GemvArgs {
     float scale; int S;
     const int32_t * rows;                     // optional row gather for the A operand (logits)
     const int32_t * row_off;                  // optional device scalar: aux/aux2 row offset (KV cache head), graph replay
+    const float * comb_o; const float * comb_l; int comb_ns;   // optional: A operand = combined split cross-attention partials
 };
 enum { EPI_LOGITS = 100 };                    // C f32 [n][N] = acc
 void gemv(const GemvArgs & a, hipStream_t st);
@@ -102,7 +106,8 @@ struct DecStep {
 };
 struct SampleOut { int32_t id, tid; float p, plog, pt, ptsum; int32_t forced_ts; int32_t pad; };
 // logits [n_vocab] -> filtered soft-max statistics and the arg-max token (W/whisper.cpp:4493-4830 at temperature 0)
-void filter_argmax(const float * logits, const uint8_t * static_ban, const DecStep * step, SampleOut * out, hipStream_t st);
+void filter_argmax(const float * logits, const uint8_t * static_ban, const DecStep * step, SampleOut * out, void * scratch, hipStream_t st);
+size_t filter_scratch_bytes();
 
 // misc
 void fill_zero(void * p, size_t bytes, hipStream_t st);

@@ -183,6 +183,7 @@ struct DeviceState {
     // greedy fast path: one decode step = one captured HIP graph (SURVEY (f)1 + launch-bound inner loop)
     void   * step_dev = nullptr;   void * step_host = nullptr;       // k::DecStep (device / pinned)
     void   * sample_dev = nullptr; void * sample_host = nullptr;     // k::SampleOut (device / pinned)
+    void   * filter_scratch = nullptr;
     uint8_t * ban_dev = nullptr;   uint64_t ban_sig = ~0ull;          // static suppress mask + its parameter signature
     hipGraph_t step_graph = nullptr; hipGraphExec_t step_exec = nullptr; int step_graph_T = -1;
 };
