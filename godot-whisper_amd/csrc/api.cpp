@@ -454,6 +454,19 @@ double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters) {
             default: break;
         }
     };
+    if (which >= 10 && which <= 12) {                                   // launch-floor probes: chains of trivial dependent kernels
+        const int blocks = which == 10 ? 1 : which == 11 ? 32 : 256;
+        int * p = (int *) d.mel_max;
+        for (int i = 0; i < 8; ++i) k::touch(p, blocks, s);
+        (void) hipStreamSynchronize(s);
+        (void) hipEventRecord(e0, s);
+        for (int i = 0; i < iters; ++i) k::touch(p, blocks, s);
+        (void) hipEventRecord(e1, s);
+        (void) hipEventSynchronize(e1);
+        float ms = 0.0f; (void) hipEventElapsedTime(&ms, e0, e1);
+        (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+        return (double) ms * 1000.0 / iters;
+    }
     if (which == 3) {
         if (d.mel == nullptr) return -1.0;
         const int saved = st.exp_n_audio_ctx;

@@ -398,7 +398,9 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc) {
         const hipError_t e = hipStreamSynchronize(s);
         fprintf(stderr, "[wmi] greedy step: %s layer %d -> %s\n", what, il, hipGetErrorString(e));
     };
-    k::dec_embed(&stp->token, &stp->pos, 1, S, w.d_te, w.d_pe, d.dx, s); chk("embed", -1);
+    // step parameters come from pinned host memory, the result goes back into pinned host memory: the replayed
+    // graph contains kernels only (memcpy nodes cost tens of microseconds each on this stack)
+    k::dec_embed_step((const k::DecStep *) d.step_host, (k::DecStep *) d.step_dev, S, w.d_te, w.d_pe, d.dx, s); chk("embed", -1);
     auto gv = [&](int epi, const float * lg, const float * lb, const __half * a16, int K, int N, const __half * W, const float * bias,
                   void * C, int ldc, const float * resid, void * aux, void * aux2, float scale, const int32_t * row_off) {
         k::GemvArgs g{};
@@ -411,8 +413,13 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc) {
         const DecLayerW & l = w.dec[il];
         __half * ck = kv.k + ((size_t) il * n_ctx) * S, * cv = kv.v + ((size_t) il * n_ctx) * S;
         gv(k::EPI_QKV_DEC, l.ln1_g, l.ln1_b, nullptr, S, 3 * S, l.w_qkv, l.b_qkv, d.dq, S, nullptr, ck, cv, kq_scale, &stp->kv_head); chk("qkv", il);
-        k::attn_decoder(d.dq, 1, S, H, ck, cv, 0, nullptr, 0, d.datt, s, &stp->n_kv, n_ctx); chk("self-attn", il);
-        gv(k::EPI_F32_BIAS_RESID, nullptr, nullptr, d.datt, S, S, l.w_o, l.b_o, d.dx, S, d.dx, nullptr, nullptr, 0.f, nullptr);
+        {   // self-attention over the cache, recomputed in the out-projection's prologue (one launch fewer)
+            k::GemvArgs g{};
+            g.sa_q = d.dq; g.sa_k = ck; g.sa_v = cv; g.sa_nkv = &stp->n_kv; g.sa_cap = hp.n_text_ctx;
+            g.n = 1; g.K = S; g.N = S; g.W = l.w_o; g.bias = l.b_o; g.epi = k::EPI_F32_BIAS_RESID;
+            g.C = d.dx; g.ldc = S; g.resid = d.dx; g.ldr = S; g.S = S;
+            k::gemv(g, s); chk("self-attn+out", il);
+        }
         gv(k::EPI_Q_SCALED, l.ln2_g, l.ln2_b, nullptr, S, S, l.w_cq, l.b_cq, d.dq, S, nullptr, nullptr, nullptr, kq_scale, nullptr);
         chk("cross-q", il);
         {   // cross-attention partials, combined inside the out-projection's prologue
@@ -429,7 +436,7 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc) {
     }
     chk("layers", Lt);
     gv(k::EPI_LOGITS, w.d_ln_g, w.d_ln_b, nullptr, S, NV, w.d_te, nullptr, d.logits, NV, nullptr, nullptr, nullptr, 0.f, nullptr); chk("logits", Lt);
-    k::filter_argmax(d.logits, d.ban_dev, stp, (k::SampleOut *) d.sample_dev, d.filter_scratch, s); chk("filter", Lt);
+    k::filter_argmax(d.logits, d.ban_dev, stp, (k::SampleOut *) d.sample_dev, d.filter_scratch, s, (k::SampleOut *) d.sample_host); chk("filter", Lt);
 }
 
 bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const StepFilter & f, whisper_token_data & out) {
@@ -467,13 +474,10 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
     }
     if (use_graph && !d.step_exec) {
         // first use: run once eagerly (lets the launchers set their function attributes), then capture
-        HIP_TRY(hipMemcpyAsync(d.step_dev, d.step_host, sizeof(k::DecStep), hipMemcpyHostToDevice, s));
         enqueue_greedy_step(ctx, Tc);
         HIP_TRY(hipStreamSynchronize(s));
         if (HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal))) {
-            (void) hipMemcpyAsync(d.step_dev, d.step_host, sizeof(k::DecStep), hipMemcpyHostToDevice, s);
             enqueue_greedy_step(ctx, Tc);
-            (void) hipMemcpyAsync(d.sample_host, d.sample_dev, sizeof(k::SampleOut), hipMemcpyDeviceToHost, s);
             hipGraph_t g = nullptr;
             if (HIP_OK(hipStreamEndCapture(s, &g)) && g && HIP_OK(hipGraphInstantiate(&d.step_exec, g, nullptr, nullptr, 0))) {
                 d.step_graph = g; d.step_graph_T = Tc;
@@ -486,9 +490,7 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
     if (use_graph && d.step_exec) {
         HIP_TRY(hipGraphLaunch(d.step_exec, s));
     } else {
-        HIP_TRY(hipMemcpyAsync(d.step_dev, d.step_host, sizeof(k::DecStep), hipMemcpyHostToDevice, s));
         enqueue_greedy_step(ctx, Tc);
-        HIP_TRY(hipMemcpyAsync(d.sample_host, d.sample_dev, sizeof(k::SampleOut), hipMemcpyDeviceToHost, s));
     }
     HIP_TRY(hipStreamSynchronize(s));
     const k::SampleOut * r = (const k::SampleOut *) d.sample_host;

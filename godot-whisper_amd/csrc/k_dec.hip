@@ -33,9 +33,21 @@ __global__ void k_dec_embed(const int32_t * __restrict__ tokens, const int32_t *
     for (int c = threadIdx.x; c < S; c += blockDim.x) x[(size_t) i * S + c] = __half2float(t[c]) + p[c];
 }
 
-constexpr int ROWS_IN_FLIGHT = 4;
+// Graph-replay variant: the step parameters are read straight from pinned HOST memory (one PCIe read, no memcpy
+// node in the graph) and mirrored into device memory for the kernels that follow.
+__global__ void k_dec_embed_step(const DecStep * __restrict__ host_step, DecStep * __restrict__ dev_step, int S,
+                                 const __half * __restrict__ te, const float * __restrict__ pe, float * __restrict__ x) {
+    __shared__ DecStep st;
+    if (threadIdx.x < sizeof(DecStep) / 4) ((int32_t *) &st)[threadIdx.x] = ((const volatile int32_t *) host_step)[threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < sizeof(DecStep) / 4) ((int32_t *) dev_step)[threadIdx.x] = ((const int32_t *) &st)[threadIdx.x];
+    const __half * t = te + (size_t) st.token * S;
+    const float *  p = pe + (size_t) st.pos * S;
+    for (int c = threadIdx.x; c < S; c += blockDim.x) x[c] = __half2float(t[c]) + p[c];
+}
 
-template <int R>
+
+template <int R, int ROWS_IN_FLIGHT>
 __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __half * act = (__half *) smem;                         // [R][K]
@@ -56,15 +68,32 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
         }
     }
 
+    // epilogue operands of the first tile (bias, residual, KV-cache head): independent of everything, fetched now so
+    // that the epilogue does not add a dependent memory round trip (~1.5 us each on freshly written lines)
+    float bias_pre = 0.0f, resid_pre = 0.0f; int ro_pre = 0;
+    {
+        const int u = lane / R, r = lane - u * R, n = gw * ROWS_IN_FLIGHT + u;
+        if (lane < ROWS_IN_FLIGHT * R && n < a.N) {
+            if (a.bias) bias_pre = a.bias[n];
+            if (a.resid) resid_pre = a.resid[(size_t) r * a.ldr + n];
+        }
+        if (a.row_off) ro_pre = *a.row_off;
+    }
+
     // ---- prologue: stage the activation rows as f16
     if (a.ln_g) {                                           // fused LayerNorm of the f32 residual stream
         constexpr int XV = 20;                              // row kept in registers: K <= 64 * 20 = 1280 (every Whisper size)
         for (int r = wave; r < R; r += 4) {
             const int src = a.rows ? a.rows[r] : r;
             const float * xr = a.x32 + (size_t) src * K;
-            float xv[XV]; float sum = 0.0f;
+            float xv[XV], gv[XV], bv[XV]; float sum = 0.0f;
 #pragma unroll
-            for (int j = 0; j < XV; ++j) { const int c = lane + 64 * j; xv[j] = c < K ? xr[c] : 0.0f; sum += xv[j]; }
+            for (int j = 0; j < XV; ++j) {
+                const int c = lane + 64 * j;
+                xv[j] = c < K ? xr[c] : 0.0f; gv[j] = c < K ? a.ln_g[c] : 0.0f; bv[j] = c < K ? a.ln_b[c] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < XV; ++j) sum += xv[j];
             for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
             const float mean = sum / (float) K;
             float sq = 0.0f;
@@ -75,8 +104,72 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
 #pragma unroll
             for (int j = 0; j < XV; ++j) {
                 const int c = lane + 64 * j;
-                if (c < K) act[r * K + c] = __float2half_rn(__fadd_rn(__fmul_rn(xv[j] * sc, a.ln_g[c]), a.ln_b[c]));
+                if (c < K) act[r * K + c] = __float2half_rn(__fadd_rn(__fmul_rn(xv[j] * sc, gv[j]), bv[j]));
             }
+        }
+    } else if (a.sa_q) {                                    // fused single-token self-attention over the KV cache
+        // Every workgroup recomputes the (tiny) attention of all heads: n_kv x H dot products of 64 — cheaper than
+        // a separate launch on the critical path of a decode step.  Numerics as k_attn_dec: scores f16.f16 -> f32,
+        // exp through f16, probabilities rounded to f16 before P.V (SURVEY App. B rules 1, 4, 5).
+        const int H = K / 64;
+        float * sc = (float *) (smem + (((size_t) R * K * sizeof(__half) + 15) & ~(size_t) 15));   // [H][sa_cap]
+        float * qf = sc + (size_t) H * a.sa_cap;                                                   // [K]
+        // pair p <-> (key p / H, head p % H): independent of n_kv, so the first K row of every thread is requested
+        // before n_kv and q have arrived (rows past n_kv are finite cache garbage and never used)
+        uint4 kpre[8];
+        {
+            const int j = tid / H, h = tid - j * H;
+            const uint4 * kp = (const uint4 *) (a.sa_k + (size_t) (j < a.sa_cap ? j : 0) * K + h * 64);
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) kpre[c8] = kp[c8];
+        }
+        const int n_kv = *a.sa_nkv;
+        for (int c = tid; c < K; c += 256) qf[c] = __half2float(a.sa_q[c]);
+        __syncthreads();
+        for (int p = tid; p < H * n_kv; p += 256) {
+            const int j = p / H, h = p - j * H;
+            const uint4 * kp = (const uint4 *) (a.sa_k + (size_t) j * K + h * 64);
+            float dot = 0.0f;
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+                const uint4 u = p == tid ? kpre[c8] : kp[c8];
+                const __half2 * hh = (const __half2 *) &u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float2 f = __half22float2(hh[e]);
+                    dot = fmaf(f.x, qf[h * 64 + c8 * 8 + e * 2], dot);
+                    dot = fmaf(f.y, qf[h * 64 + c8 * 8 + e * 2 + 1], dot);
+                }
+            }
+            sc[(size_t) h * a.sa_cap + j] = dot;
+        }
+        __syncthreads();
+        for (int h = wave; h < H; h += 4) {                 // soft-max of one head per wavefront
+            float * row = sc + (size_t) h * a.sa_cap;
+            float m = -INFINITY;
+            for (int j = lane; j < n_kv; j += 64) m = fmaxf(m, row[j]);
+            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+            float l = 0.0f;
+            for (int j = lane; j < n_kv; j += 64) { const float e = round_f16(expf(round_f16(row[j] - m))); row[j] = e; l += e; }
+            for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
+            const float inv = (float) (1.0 / (double) l);
+            for (int j = lane; j < n_kv; j += 64) row[j] = round_f16(row[j] * inv);
+        }
+        __syncthreads();
+        for (int c = tid; c < K; c += 256) {
+            const float * row = sc + (size_t) (c >> 6) * a.sa_cap;
+            const __half * vp = a.sa_v + c;
+            float acc = 0.0f;
+            int j = 0;
+            for (; j + 8 <= n_kv; j += 8) {             // loads issued 8 at a time, accumulated in key order
+                __half vv[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) vv[t] = vp[(size_t) (j + t) * K];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) acc = fmaf(row[j + t], __half2float(vv[t]), acc);
+            }
+            for (; j < n_kv; ++j) acc = fmaf(row[j], __half2float(vp[(size_t) j * K]), acc);
+            act[c] = __float2half_rn(acc);
         }
     } else if (a.comb_o) {                                  // fused combine of the split cross-attention partials
         const int H = K / 64, ns = a.comb_ns;
@@ -107,10 +200,21 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
 
         for (int c = lane * 8; c < K; c += 512) {
             uint4 w[ROWS_IN_FLIGHT];
-            if (first) {
+            if (first && c == lane * 8) {
 #pragma unroll
                 for (int u = 0; u < ROWS_IN_FLIGHT; ++u) w[u] = wpre[u];
                 first = false;
+                // software pipeline over the row tiles: the first chunk of the NEXT tile is requested before this
+                // tile is multiplied and reduced (the logits matrix is 51 864 rows: ~6 tiles per wavefront)
+                const int on = o0 + nwaves * ROWS_IN_FLIGHT;
+                if (on < a.N && lane * 8 < K) {
+#pragma unroll
+                    for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
+                        int o = on + u; if (o > a.N - 1) o = a.N - 1;
+                        wpre[u] = *(const uint4 *) (a.W + (size_t) o * K + lane * 8);
+                    }
+                    first = true;                       // consumed by the next o0 iteration's first chunk
+                }
             } else {
 #pragma unroll
                 for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
@@ -156,18 +260,20 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
 #pragma unroll
                 for (int rr = 0; rr < R; ++rr) if (uu == u && rr == r) v = acc[uu][rr];
             if (n < a.N) {
-                const float bias = a.bias ? a.bias[n] : 0.0f;
+                const bool pre = o0 == gw * ROWS_IN_FLIGHT;
+                const float bias = pre ? bias_pre : (a.bias ? a.bias[n] : 0.0f);
+                const float resid = a.resid ? (pre ? resid_pre : a.resid[(size_t) r * a.ldr + n]) : 0.0f;
                 switch (a.epi) {
                     case EPI_F16_BIAS:       ((__half *) a.C)[(size_t) r * a.ldc + n] = __float2half_rn(v + bias); break;
                     case EPI_F16_BIAS_GELU:  ((__half *) a.C)[(size_t) r * a.ldc + n] = __float2half_rn(gelu16(v + bias)); break;
-                    case EPI_F32_BIAS_RESID: ((float *) a.C)[(size_t) r * a.ldc + n] = (v + bias) + a.resid[(size_t) r * a.ldr + n]; break;
+                    case EPI_F32_BIAS_RESID: ((float *) a.C)[(size_t) r * a.ldc + n] = (v + bias) + resid; break;
                     case EPI_Q_SCALED:       ((__half *) a.C)[(size_t) r * a.ldc + n] = __float2half_rn((v + bias) * a.scale); break;
                     case EPI_QKV_DEC: {
                         // segment decided on a wave-uniform value (the 4 rows of this wave iteration never straddle a
                         // q|k|v boundary: S % 4 == 0) — same precaution as in k_gemm.hip, see DESIGN.md §7
                         const int seg = __builtin_amdgcn_readfirstlane(o0 / a.S);
                         const int c = n - seg * a.S;
-                        const int ro = a.row_off ? *a.row_off : 0;          // KV-cache head (device scalar under graph replay)
+                        const int ro = ro_pre;                              // KV-cache head (device scalar under graph replay)
                         __half * dst; float val;
                         if (seg == 0)      { dst = (__half *) a.C    + (size_t) r * a.ldc;           val = (v + bias) * a.scale; }
                         else if (seg == 1) { dst = (__half *) a.aux  + (size_t) (r + ro) * a.ldaux;  val = v * a.scale; }
@@ -182,17 +288,25 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
     }
 }
 
-template <int R>
-void launch_gemv(const GemvArgs & a, hipStream_t st) {
-    const size_t smem = (size_t) R * a.K * sizeof(__half);
-    int blocks = (a.N + 4 * ROWS_IN_FLIGHT - 1) / (4 * ROWS_IN_FLIGHT);
-    if (blocks > 2048) blocks = 2048;
+template <int R, int RIF>
+void launch_gemv_t(const GemvArgs & a, hipStream_t st) {
+    size_t smem = (size_t) R * a.K * sizeof(__half);
+    if (a.sa_q) smem = ((smem + 15) & ~(size_t) 15) + ((size_t) (a.K / 64) * a.sa_cap + a.K) * sizeof(float);
+    int blocks = (a.N + 4 * RIF - 1) / (4 * RIF);
+    if (blocks > 512) blocks = 512;                     // 2 workgroups per CU; longer rows-per-wave loops are software-pipelined
     static size_t attr_bytes = 0;
     if (smem > 48 * 1024 && smem > attr_bytes) {
-        (void) hipFuncSetAttribute((const void *) k_gemv<R>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+        (void) hipFuncSetAttribute((const void *) k_gemv<R, RIF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
         attr_bytes = smem;
     }
-    hipLaunchKernelGGL((k_gemv<R>), dim3(blocks), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((k_gemv<R, RIF>), dim3(blocks), dim3(256), smem, st, a);
+}
+
+template <int R>
+void launch_gemv(const GemvArgs & a, hipStream_t st) {
+    // the vocabulary projection streams 53 MB: keep 8 rows (8 KB) per wavefront in flight; small matrices use 4
+    if (R == 1 && a.N >= 16384) launch_gemv_t<1, 8>(a, st);
+    else launch_gemv_t<R, 4>(a, st);
 }
 
 } // namespace
@@ -200,6 +314,11 @@ void launch_gemv(const GemvArgs & a, hipStream_t st) {
 void dec_embed(const int32_t * tokens, const int32_t * pos, int n, int S, const __half * te, const float * pe,
                float * x, hipStream_t st) {
     hipLaunchKernelGGL(k_dec_embed, dim3(n), dim3(256), 0, st, tokens, pos, S, te, pe, x);
+}
+
+void dec_embed_step(const DecStep * host_step, DecStep * dev_step, int S, const __half * te, const float * pe, float * x,
+                    hipStream_t st) {
+    hipLaunchKernelGGL(k_dec_embed_step, dim3(1), dim3(256), 0, st, host_step, dev_step, S, te, pe, x);
 }
 
 void gemv(const GemvArgs & a, hipStream_t st) {

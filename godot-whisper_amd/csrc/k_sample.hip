@@ -100,7 +100,7 @@ __global__ __launch_bounds__(NT) void k_filter_stats(const float * __restrict__ 
 }
 
 __global__ __launch_bounds__(64) void k_filter_pick(const Partial * __restrict__ part, const DecStep * __restrict__ stp,
-                                                    SampleOut * __restrict__ out) {
+                                                    SampleOut * __restrict__ out, SampleOut * __restrict__ out_host) {
     const int lane = threadIdx.x;
     const Partial p = part[lane];                       // NB == 64: one partial per lane
     const MaxIdx a = wave_max(p.all), t = wave_max(p.txt), z = wave_max(p.ts);
@@ -125,16 +125,17 @@ __global__ __launch_bounds__(64) void k_filter_pick(const Partial * __restrict__
         r.ptsum = (float) sum_ts_p;
         if (r.id >= beg) { r.tid = r.id; r.pt = r.p; }
         *out = r;
+        if (out_host) { *out_host = r; __threadfence_system(); }     // result straight into pinned host memory
     }
 }
 
 } // namespace
 
 void filter_argmax(const float * logits, const uint8_t * static_ban, const DecStep * step, SampleOut * out, void * scratch,
-                   hipStream_t st) {
+                   hipStream_t st, SampleOut * out_host) {
     Partial * part = (Partial *) scratch;
     hipLaunchKernelGGL(k_filter_stats, dim3(NB), dim3(NT), 0, st, logits, static_ban, step, part);
-    hipLaunchKernelGGL(k_filter_pick, dim3(1), dim3(64), 0, st, part, step, out);
+    hipLaunchKernelGGL(k_filter_pick, dim3(1), dim3(64), 0, st, part, step, out, out_host);
 }
 size_t filter_scratch_bytes() { return NB * sizeof(Partial); }
 

@@ -89,6 +89,8 @@ struct GemvArgs {
     const int32_t * rows;                     // optional row gather for the A operand (logits)
     const int32_t * row_off;                  // optional device scalar: aux/aux2 row offset (KV cache head), graph replay
     const float * comb_o; const float * comb_l; int comb_ns;   // optional: A operand = combined split cross-attention partials
+    // optional (n == 1): A operand = self-attention output computed in the prologue from q and this layer's KV cache
+    const __half * sa_q; const __half * sa_k; const __half * sa_v; const int32_t * sa_nkv; int sa_cap;
 };
 enum { EPI_LOGITS = 100 };                    // C f32 [n][N] = acc
 void gemv(const GemvArgs & a, hipStream_t st);
@@ -106,10 +108,14 @@ struct DecStep {
 };
 struct SampleOut { int32_t id, tid; float p, plog, pt, ptsum; int32_t forced_ts; int32_t pad; };
 // logits [n_vocab] -> filtered soft-max statistics and the arg-max token (W/whisper.cpp:4493-4830 at temperature 0)
-void filter_argmax(const float * logits, const uint8_t * static_ban, const DecStep * step, SampleOut * out, void * scratch, hipStream_t st);
+void filter_argmax(const float * logits, const uint8_t * static_ban, const DecStep * step, SampleOut * out, void * scratch, hipStream_t st,
+                   SampleOut * out_host = nullptr);
 size_t filter_scratch_bytes();
+// first kernel of a replayed step: fetch DecStep from pinned host memory, mirror it on the device, embed the token
+void dec_embed_step(const DecStep * host_step, DecStep * dev_step, int S, const __half * te, const float * pe, float * x, hipStream_t st);
 
 // misc
+void touch(int * p, int blocks, hipStream_t st);     // trivial dependent kernel (launch-floor probe)
 void fill_zero(void * p, size_t bytes, hipStream_t st);
 
 }} // namespace wmi::k
