@@ -17,6 +17,7 @@
 // (slot (g, j) <-> key 32*ks + 4*g + j for j < 4, + 16 for j >= 4; V^T fragments are gathered to match).
 
 #include "kernels.h"
+#include <cstdlib>
 
 namespace wmi { namespace k {
 
@@ -29,10 +30,14 @@ typedef float    floatx4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ float round_f16(float x) { return __half2float(__float2half_rn(x)); }
 // the reference's exp-through-f16-table (W/ggml.c:11176-11186)
 __device__ __forceinline__ float exp16(float d) { return round_f16(expf(round_f16(d))); }
+// encoder variant: hardware exp2 path (v_exp_f32, ~2 ulp) — 18 M evaluations per layer make the libm expf the
+// longest VALU chain of the kernel; after the f16 rounding the two agree except on ~0.2 % of (tiny) entries
+__device__ __forceinline__ float exp16_fast(float d) { return round_f16(__expf(round_f16(d))); }
 
 __device__ __forceinline__ uint32_t lds_off(int row, int chunk) { return (uint32_t) (row * 128 + ((chunk ^ (row & 7)) << 4)); }
 
-__global__ __launch_bounds__(256) void k_attn_enc(const __half * __restrict__ q, const __half * __restrict__ k,
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void k_attn_enc(const __half * __restrict__ q, const __half * __restrict__ k,
                                                   const __half * __restrict__ vt, int T, int Tpad, int S, float scale,
                                                   __half * __restrict__ out) {
     __shared__ __attribute__((aligned(16))) unsigned char sK[64 * 128];
@@ -40,7 +45,7 @@ __global__ __launch_bounds__(256) void k_attn_enc(const __half * __restrict__ q,
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int head = blockIdx.y;
-    const int q0 = blockIdx.x * 64 + wave * 16;
+    const int q0 = blockIdx.x * (NW * 16) + wave * 16;
 
     half8 qf[2];
     {
@@ -49,21 +54,25 @@ __global__ __launch_bounds__(256) void k_attn_enc(const __half * __restrict__ q,
         qf[0] = *(const half8 *) (qp);
         qf[1] = *(const half8 *) (qp + 32);
     }
-    const int srow = tid >> 2, sch = (tid & 3) * 2;          // staging: 64 rows x 8 chunks, 2 chunks per thread
+    // staging: 64 rows x 8 chunks of 16 B = 512 chunks, (512 / threads) consecutive chunks per thread
+    constexpr int CPT = 512 / (NW * 64);
+    const int srow = (tid * CPT) >> 3, sch = (tid * CPT) & 7;
 
-    auto stage_k = [&](int kt0) {
-        int kr = kt0 + srow; if (kr > T - 1) kr = T - 1;
-        const uint4 * src = (const uint4 *) (k + (size_t) kr * S + head * 64 + sch * 8);
-        const uint4 a = src[0], b = src[1];
-        *(uint4 *) (sK + lds_off(srow, sch)) = a;
-        *(uint4 *) (sK + lds_off(srow, sch + 1)) = b;
-    };
-    auto stage_v = [&](int kt0) {
-        const uint4 * src = (const uint4 *) (vt + (size_t) (head * 64 + srow) * Tpad + kt0 + sch * 8);
-        const uint4 a = src[0], b = src[1];
-        *(uint4 *) (sV + lds_off(srow, sch)) = a;
-        *(uint4 *) (sV + lds_off(srow, sch + 1)) = b;
-    };
+    // global -> registers -> LDS staging, split so that the NEXT tile's loads are in flight while the current tile
+    // is multiplied (the tiles live in L2 — K and V^T of one head are 2 x 192 KB — but an unhidden L2 round trip
+    // per 64 keys was ~60 % of this kernel)
+    // Staging registers are individually named on purpose: an indexed uint4[CPT] here ended up in scratch memory
+    // (80-144 B/lane, 50 -> 76 us per layer) even with fully unrolled constant indices.
+    uint4 rk0, rk1, rk2, rk3, rv0, rv1, rv2, rv3;
+#define LOAD_K(kt0_) do { int kr_ = (kt0_) + srow; if (kr_ > T - 1) kr_ = T - 1;                                   \
+        const uint4 * src_ = (const uint4 *) (k + (size_t) kr_ * S + head * 64 + sch * 8);                          \
+        rk0 = src_[0]; rk1 = src_[1]; if constexpr (CPT == 4) { rk2 = src_[2]; rk3 = src_[3]; } } while (0)
+#define LOAD_V(kt0_) do { const uint4 * src_ = (const uint4 *) (vt + (size_t) (head * 64 + srow) * Tpad + (kt0_) + sch * 8); \
+        rv0 = src_[0]; rv1 = src_[1]; if constexpr (CPT == 4) { rv2 = src_[2]; rv3 = src_[3]; } } while (0)
+#define STORE_K() do { *(uint4 *) (sK + lds_off(srow, sch)) = rk0; *(uint4 *) (sK + lds_off(srow, sch + 1)) = rk1;   \
+        if constexpr (CPT == 4) { *(uint4 *) (sK + lds_off(srow, sch + 2)) = rk2; *(uint4 *) (sK + lds_off(srow, sch + 3)) = rk3; } } while (0)
+#define STORE_V() do { *(uint4 *) (sV + lds_off(srow, sch)) = rv0; *(uint4 *) (sV + lds_off(srow, sch + 1)) = rv1;   \
+        if constexpr (CPT == 4) { *(uint4 *) (sV + lds_off(srow, sch + 2)) = rv2; *(uint4 *) (sV + lds_off(srow, sch + 3)) = rv3; } } while (0)
     auto score_tile = [&](int kt) -> floatx4 {                // S^T for keys kt*16..+15 of the staged tile
         floatx4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -76,9 +85,11 @@ __global__ __launch_bounds__(256) void k_attn_enc(const __half * __restrict__ q,
 
     // ---- sweep 1: exact row max
     float m = -INFINITY;
+    LOAD_K(0);
     for (int kt0 = 0; kt0 < T; kt0 += 64) {
-        stage_k(kt0);
+        STORE_K();
         __syncthreads();
+        if (kt0 + 64 < T) LOAD_K(kt0 + 64);
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             const floatx4 acc = score_tile(kt);
@@ -98,10 +109,11 @@ __global__ __launch_bounds__(256) void k_attn_enc(const __half * __restrict__ q,
     floatx4 o[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) o[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    LOAD_K(0); LOAD_V(0);
     for (int kt0 = 0; kt0 < T; kt0 += 64) {
-        stage_k(kt0);
-        stage_v(kt0);
+        STORE_K(); STORE_V();
         __syncthreads();
+        if (kt0 + 64 < T) { LOAD_K(kt0 + 64); LOAD_V(kt0 + 64); }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             half8 pf;
@@ -112,7 +124,7 @@ __global__ __launch_bounds__(256) void k_attn_enc(const __half * __restrict__ q,
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = kt0 + kt * 16 + fq * 4 + r;
-                    const float e = key < T ? exp16(acc[r] * scale - m) : 0.0f;
+                    const float e = key < T ? exp16_fast(acc[r] * scale - m) : 0.0f;
                     l += e;
                     pf[hh * 4 + r] = (_Float16) e;
                 }
@@ -369,7 +381,9 @@ size_t attn_cross_scratch_floats(int n, int H, int T) {
 
 void attn_encoder(const __half * q, const __half * k, const __half * vt, int T, int Tpad, int S, int H, float scale,
                   __half * out, hipStream_t st) {
-    hipLaunchKernelGGL(k_attn_enc, dim3((T + 63) / 64, H), dim3(256), 0, st, q, k, vt, T, Tpad, S, scale, out);
+    static const int nw = getenv("WMI_ATTN_NW") ? atoi(getenv("WMI_ATTN_NW")) : 4;      // wavefronts per workgroup (A/B knob)
+    if (nw == 4) hipLaunchKernelGGL((k_attn_enc<4>), dim3((T + 63) / 64, H), dim3(256), 0, st, q, k, vt, T, Tpad, S, scale, out);
+    else         hipLaunchKernelGGL((k_attn_enc<2>), dim3((T + 31) / 32, H), dim3(128), 0, st, q, k, vt, T, Tpad, S, scale, out);
 }
 
 void attn_decoder(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int n_kv,
