@@ -189,7 +189,7 @@ class CaptureStreamToText(SpeechToText):
         self.punct = punctuation_characters
 
     def stream(self, pcm16k: np.ndarray, max_calls: int | None = None):
-        """Yield (is_final, text, n_samples_used) per transcribe call."""
+        """Yield (is_final, text, n_samples_used, audio_ctx, token dicts) per transcribe call."""
         sr = abi.WHISPER_SAMPLE_RATE
         step = int(round(self.interval * sr))
         start, pos, calls = 0, 0, 0
@@ -208,6 +208,7 @@ class CaptureStreamToText(SpeechToText):
                 continue
             text = remove_special_characters(tokens.pop(0).decode("utf-8", errors="replace"))
             n_tok = len(tokens)
+            call_tokens = list(tokens)
             finish = False
             total_ms = total_s * 1000
             if total_ms > self.min_ms:
@@ -217,7 +218,7 @@ class CaptureStreamToText(SpeechToText):
                 if total_ms > self.max_ms:
                     finish = True
             last_tokens = n_tok
-            yield finish, text, acc.size
+            yield finish, text, acc.size, audio_ctx, call_tokens
             if finish:
                 start = max(pos - int(0.2 * sr), 0)  # keep only the last 0.2 s (:111)
                 last_tokens = -1

@@ -214,3 +214,92 @@ def read_wav_mono16(path) -> np.ndarray:
     if fmt[1] > 1:
         x = x.reshape(-1, fmt[1]).mean(axis=1)
     return x
+
+
+# ------------------------------------------------------------------------------------------------
+# ggml block quantisation (W/ggml-quants.c quantize_row_q*_reference, block layouts W/ggml-quants.h:10-47),
+# applied the way the reference's `quantize` tool does (W/examples/common-ggml.cpp:38-215): every 2-D tensor
+# except the conv biases and the two positional embeddings; header ftype = 2000 + ftype.
+# tests/test_synth_and_shard.py checks the output byte for byte against the reference tool in the build container.
+QTYPES = {"q4_0": (2, 2), "q4_1": (3, 3), "q5_0": (6, 8), "q5_1": (7, 9), "q8_0": (8, 7)}   # name: (ggml_type, ftype)
+_SKIP = ("encoder.conv1.bias", "encoder.conv2.bias", "encoder.positional_embedding", "decoder.positional_embedding")
+
+
+def _f16_bytes(x32: np.ndarray) -> np.ndarray:
+    return x32.astype(np.float16).view(np.uint8).reshape(-1, 2)
+
+
+def quantize_blocks(x: np.ndarray, qtype: str) -> bytes:
+    x = np.ascontiguousarray(x, np.float32).reshape(-1, 32)
+    nb = x.shape[0]
+    one = np.float32(1.0)
+    if qtype == "q8_0":
+        amax = np.abs(x).max(axis=1)
+        d = (amax / np.float32(127.0)).astype(np.float32)
+        idv = np.where(d != 0, one / np.where(d != 0, d, one), np.float32(0)).astype(np.float32)
+        q = np.round((x * idv[:, None]).astype(np.float32)).astype(np.int8)       # roundf: half away from zero
+        x0 = (x * idv[:, None]).astype(np.float32)
+        q = np.where(x0 >= 0, np.floor(x0 + np.float32(0.5)), np.ceil(x0 - np.float32(0.5))).astype(np.int8)
+        out = np.empty((nb, 34), np.uint8)
+        out[:, 0:2] = _f16_bytes(d); out[:, 2:] = q.view(np.uint8)
+        return out.tobytes()
+    if qtype in ("q4_0", "q5_0"):
+        idx = np.abs(x).argmax(axis=1)
+        mx = x[np.arange(nb), idx]
+        div = np.float32(-8.0) if qtype == "q4_0" else np.float32(-16.0)
+        d = (mx / div).astype(np.float32)
+        idv = np.where(d != 0, one / np.where(d != 0, d, one), np.float32(0)).astype(np.float32)
+        off = np.float32(8.5) if qtype == "q4_0" else np.float32(16.5)
+        lim = 15 if qtype == "q4_0" else 31
+        xi = np.minimum(lim, ((x * idv[:, None]).astype(np.float32) + off).astype(np.float32).astype(np.int8).astype(np.int32)).astype(np.uint8)
+        dh, mh = _f16_bytes(d), None
+    else:  # q4_1, q5_1
+        mn = x.min(axis=1); mx = x.max(axis=1)
+        lv = np.float32(15.0) if qtype == "q4_1" else np.float32(31.0)
+        d = ((mx - mn) / lv).astype(np.float32)
+        idv = np.where(d != 0, one / np.where(d != 0, d, one), np.float32(0)).astype(np.float32)
+        x0 = (((x - mn[:, None]).astype(np.float32) * idv[:, None]).astype(np.float32) + np.float32(0.5)).astype(np.float32)
+        if qtype == "q4_1":
+            xi = np.minimum(15, x0.astype(np.int8).astype(np.int32)).astype(np.uint8)
+        else:
+            xi = x0.astype(np.uint8)
+        dh, mh = _f16_bytes(d), _f16_bytes(mn)
+    lo, hi = xi[:, :16], xi[:, 16:]
+    qs = ((lo & 0x0F) | ((hi & 0x0F) << 4)).astype(np.uint8)
+    parts = [dh] + ([mh] if mh is not None else [])
+    if qtype in ("q5_0", "q5_1"):
+        j = np.arange(16, dtype=np.uint32)
+        qh = (((lo.astype(np.uint32) & 0x10) >> 4) << j).sum(axis=1, dtype=np.uint32) | \
+             (((hi.astype(np.uint32) & 0x10) >> 4) << (j + 16)).sum(axis=1, dtype=np.uint32)
+        parts.append(qh.astype("<u4").view(np.uint8).reshape(-1, 4))
+    parts.append(qs)
+    return np.concatenate(parts, axis=1).tobytes()
+
+
+def quantize_model(model: bytes, qtype: str = "q5_1") -> bytes:
+    gtype, ftype = QTYPES[qtype]
+    b = model
+    hp = list(struct.unpack_from("<11i", b, 4))
+    off = 4 + 44
+    n_mel, n_fft = struct.unpack_from("<2i", b, off)
+    off += 8 + 4 * n_mel * n_fft
+    (nv,) = struct.unpack_from("<i", b, off)
+    off += 4
+    for _ in range(nv):
+        (ln,) = struct.unpack_from("<I", b, off)
+        off += 4 + ln
+    hp[10] = 2 * 1000 + ftype                       # GGML_QNT_VERSION = 2
+    out = [b[:4], struct.pack("<11i", *hp), b[48:off]]
+    while off < len(b):
+        nd, nl, tt = struct.unpack_from("<3i", b, off); off += 12
+        ne = struct.unpack_from(f"<{nd}i", b, off); off += 4 * nd
+        name = b[off:off + nl]; off += nl
+        n = int(np.prod(ne))
+        nbytes = n * (2 if tt == 1 else 4)
+        raw = b[off:off + nbytes]; off += nbytes
+        if nd == 2 and name.decode() not in _SKIP:
+            x = np.frombuffer(raw, np.float16 if tt == 1 else np.float32).astype(np.float32)
+            out += [struct.pack("<3i", nd, nl, gtype), struct.pack(f"<{nd}i", *ne), name, quantize_blocks(x, qtype)]
+        else:
+            out += [struct.pack("<3i", nd, nl, tt), struct.pack(f"<{nd}i", *ne), name, raw]
+    return b"".join(out)

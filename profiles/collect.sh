@@ -1,0 +1,16 @@
+#!/bin/bash
+# Profile collection recipe (run on the GPU box through gpurun from the repo root):
+#   bash profiles/collect.sh r01c
+# 1. kernel trace + stats of the default bench  2-4. PMC passes (one counter group per pass, never combined
+# with the sys/hip/hsa trace domains), each on a short bench run.  Outputs land in gpurun_out/prof_<tag>/;
+# the summaries worth keeping are copied to profiles/ by profiles/summarise.py.
+set -u
+TAG=${1:-r01}
+cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+OUT=gpurun_out/prof_$TAG
+mkdir -p $OUT
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trace -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_trace.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o pmc_fetch -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o pmc_write -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $OUT -o pmc_mfma -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_pmc_mfma.log 2>&1
+ls -la $OUT

@@ -99,6 +99,15 @@ def main():
                         out[key + "/draws"] = np.asarray([[d.id, d.tid] for d in draws], np.int32)
                         out[key + "/draw_stats"] = np.asarray([[d.p, d.plog, d.pt, d.ptsum] for d in draws], np.float64)
         node.close()
+    # streaming node (BASELINE config 3 call pattern): growing buffer re-transcribed on a cadence with
+    # audio_ctx = total_s*50 + 128 (addon/capture_stream_to_text.gd:84) — ragged encoder lengths on every call
+    model, pcm = gu.stream_inputs()
+    node = host.CaptureStreamToText(lib, transcribe_interval=gu.STREAM_INTERVAL); node.set_language_model(model)
+    for ci, (fin, text, n_used, actx, toks) in enumerate(node.stream(pcm)):
+        out[f"stream/{ci}/meta"] = np.asarray([int(fin), n_used, actx], np.int64)
+        out[f"stream/{ci}/tokens"] = gu.tokens_array([b""] + toks)
+    out["stream/n_calls"] = np.int64(ci + 1)
+    node.close()
     path = gu.GOLDEN / "hotpath.npz"
     np.savez_compressed(path, **out)
     print("wrote", path, path.stat().st_size, "bytes,", len(out), "arrays")

@@ -75,4 +75,12 @@ def param_variants(node):
     return out
 
 
+STREAM_INTERVAL = 0.7
+
+
+def stream_inputs():
+    from godot_whisper_amd import synth
+    return synth.make_model("micro", seed=77), synth.make_pcm(9.0, seed=21, gate=True)
+
+
 PROMPTS = ["Hello, world!", " It's 42 degrees; don't panic.", "multi   space\ttab\nnewline", "naïve café — ünïcode ♪", ""]

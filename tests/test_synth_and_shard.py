@@ -83,3 +83,18 @@ def test_two_process_broadcast_and_gather_over_gloo(tmp_path):
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"RANK_OK {r}" in o, o
+
+
+@pytest.mark.parametrize("qtype", ["q5_1", "q4_0", "q8_0"])
+def test_quantiser_is_byte_identical_to_the_reference_tool(qtype, tmp_path):
+    """synth.quantize_model regenerates quantised models on the GPU box; here (build container) it is pinned against
+    the reference's own `quantize` tool (W/examples/quantize), compiled by oracle/Makefile."""
+    import pathlib
+    tool = pathlib.Path(__file__).resolve().parent.parent / "oracle" / "_ref" / "quantize"
+    if not tool.exists():
+        pytest.skip("reference quantize tool not built")
+    mb = synth.make_model("micro.en", seed=5)
+    (tmp_path / "m.bin").write_bytes(mb)
+    r = subprocess.run([str(tool), str(tmp_path / "m.bin"), str(tmp_path / "o.bin"), qtype], capture_output=True)
+    assert r.returncode == 0
+    assert (tmp_path / "o.bin").read_bytes() == synth.quantize_model(mb, qtype)
