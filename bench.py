@@ -55,32 +55,18 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     entry.load_package()
-    from godot_whisper_amd import abi, host, runtime, synth
+    from godot_whisper_amd import abi, host, runtime, shard, synth
 
     lib = runtime.require_gpu()
     runtime.silence_logs(lib)
 
     # ---- model: rank 0 makes the ggml image; everyone else gets it by ONE RCCL broadcast over xGMI
-    if rank == 0:
-        model = np.frombuffer(synth.make_model(args.shape, seed=1234), dtype=np.uint8)
-        n_bytes = torch.tensor([model.size], dtype=torch.int64, device=dev)
-    else:
-        n_bytes = torch.zeros(1, dtype=torch.int64, device=dev)
-    t_bcast = 0.0
-    if world > 1:
-        dist.broadcast(n_bytes, src=0)
-        image = torch.empty(int(n_bytes.item()), dtype=torch.uint8, device=dev)
-        if rank == 0:
-            image.copy_(torch.from_numpy(model.copy()))
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        dist.broadcast(image, src=0)
-        torch.cuda.synchronize()
-        t_bcast = time.perf_counter() - t0
-        model_bytes = image.cpu().numpy().tobytes()
-        del image
-    else:
-        model_bytes = model.tobytes()
+    model = synth.make_model(args.shape, seed=1234) if rank == 0 else None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    model_bytes = shard.broadcast_model(model, rank, world, dist, dev)
+    torch.cuda.synchronize()
+    t_bcast = (time.perf_counter() - t0) if world > 1 else 0.0
     buf = C.create_string_buffer(model_bytes, len(model_bytes))
     ctx = lib.wmi_init_from_buffer_on_device(C.cast(buf, C.c_void_p), len(model_bytes), local_rank)
     assert ctx, "model load failed"
@@ -145,22 +131,29 @@ def main():
             "sample_ms_per_step": round((t6[5] / 1e3) / args.steps, 4),
             "weight_bcast_ms": round(1e3 * t_bcast, 3),
         }
-        # ---- roofline of the dominant kernels, measured live with HIP events on the context stream
+        # ---- roofline of the dominant kernel, measured live with HIP events on the context's stream.
+        # Dominant by GPU time (profiles/*_kernel_stats.csv) is the decoder's weight-streaming k_gemv; its largest
+        # instance — the vocabulary projection, 53.1 MB of f16 weights per launch — is the one reported: HBM bound.
+        # The encoder's MFMA GEMM is reported next to it.
         try:
             hp_S = lib.whisper_model_n_audio_state(ctx); T = lib.whisper_model_n_audio_ctx(ctx); NV = lib.whisper_n_vocab(ctx)
-            us_gemm = lib.wmi_bench_kernel(ctx, 0, 200)
-            us_gemv = lib.wmi_bench_kernel(ctx, 1, 200)
-            us_attn = lib.wmi_bench_kernel(ctx, 2, 50)
+            us_gemv = lib.wmi_bench_kernel(ctx, 1, 300)
+            us_gemm = lib.wmi_bench_kernel(ctx, 0, 300)
+            us_attn = lib.wmi_bench_kernel(ctx, 2, 60)
+            alg_bytes = NV * hp_S * 2                       # V*S*2 bytes of d_te per token
+            gbs = alg_bytes / (us_gemv * 1e-6) / 1e9
+            out["roofline"] = {"kernel": "k_gemv<1,8> logits = d_te[51864x512] . LN(x)  (f16 weight stream, fused LN prologue)",
+                               "bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
+                               "frac": round(gbs / 8000.0, 4), "traffic": pmc_traffic("k_gemv<1, 8>"),
+                               "algorithmic_bytes": alg_bytes, "avg_us": round(us_gemv, 3)}
             flops = 2.0 * T * 4 * hp_S * hp_S
             tf = flops / (us_gemm * 1e-6) / 1e12
-            gbs = NV * hp_S * 2 / (us_gemv * 1e-6) / 1e9
-            out["roofline"] = {"kernel": "k_gemm<EPI_F16_BIAS_GELU> encoder mlp.0 [1500x2048x512] f16 MFMA", "bound": "mfma",
-                               "achieved": round(tf, 2), "peak": 2500.0, "unit": "TFLOP/s", "frac": round(tf / 2500.0, 4),
-                               "traffic": None, "avg_us": round(us_gemm, 3)}
-            out["roofline_decode"] = {"kernel": "k_gemv<1> logits [51864x512] f16 weight stream", "bound": "hbm",
-                                      "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(gbs / 8000.0, 4),
-                                      "traffic": None, "avg_us": round(us_gemv, 3)}
+            out["roofline_encoder_gemm"] = {"kernel": "k_gemm<64,64,EPI_F16_BIAS_GELU> encoder mlp.0 [1500x2048x512] f16 MFMA",
+                                            "bound": "mfma", "achieved": round(tf, 2), "peak": 2500.0, "unit": "TFLOP/s",
+                                            "frac": round(tf / 2500.0, 4), "traffic": pmc_traffic("k_gemm<64, 64, 1> grid=196608"),
+                                            "avg_us": round(us_gemm, 3)}
             out["attn_layer_us"] = round(us_attn, 2)
+            out["attn_layer_tflops"] = round(3 * 2.0 * T * T * hp_S / (us_attn * 1e-6) / 1e12, 1)
             out["encoder_tflops_end_to_end"] = round(ENC_GFLOP / enc_ms, 2)
         except Exception as e:  # pragma: no cover
             out["roofline_error"] = repr(e)
@@ -173,6 +166,23 @@ def main():
     node.ctx = None
     if world > 1:
         dist.destroy_process_group()
+
+
+def pmc_traffic(kernel_key: str):
+    """HBM bytes per launch from the committed rocprofv3 PMC summary (profiles/*_pmc_summary.json, produced by
+    profiles/collect.sh + summarise.py): FETCH_SIZE x 2 (gfx950 correction, MI355X_MICROARCH.md §HBM) + WRITE_SIZE.
+    None when no summary has been committed for this kernel."""
+    import glob
+    best = None
+    for path in sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_summary.json"))):
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        for k, e in d.items():
+            if k.startswith(kernel_key) and "fetch_bytes_x2_corrected" in e:
+                best = int(e["fetch_bytes_x2_corrected"] + e.get("write_bytes_raw", 0))
+    return best
 
 
 def cpu_baseline(model_bytes: bytes, pcm: np.ndarray) -> dict:

@@ -65,9 +65,8 @@ def main():
         if k in write:
             e["write_bytes_raw"] = write[k]["WRITE_SIZE"] * 1024
         if k in mfma and mfma[k].get("GRBM_GUI_ACTIVE"):
-            # SQ_VALU_MFMA_BUSY_CYCLES is summed over SIMDs; 256 CUs x 4 SIMDs
-            e["mfma_busy_frac"] = mfma[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / (mfma[k]["GRBM_GUI_ACTIVE"] / 8 * 1024) if False else \
-                mfma[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / (mfma[k]["GRBM_GUI_ACTIVE"] * 1024 / max(1, round(mfma[k]["GRBM_GUI_ACTIVE"] / max(mfma[k]["GRBM_GUI_ACTIVE"], 1))))
+            # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
+            e["mfma_busy_frac"] = mfma[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / (mfma[k]["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
             e["mfma_busy_cycles"] = mfma[k]["SQ_VALU_MFMA_BUSY_CYCLES"]
             e["gui_active_cycles_sum"] = mfma[k]["GRBM_GUI_ACTIVE"]
         summary[k] = e
