@@ -83,6 +83,7 @@ void whisper_free(struct whisper_context * ctx) {
     if (!ctx) return;
     if (ctx->host_only) { delete ctx->state; delete ctx; return; }
     (void) hipSetDevice(ctx->device);
+    free_batch(*ctx);
     free_state(*ctx);
     free_weights(ctx->w);
     delete ctx;
@@ -328,6 +329,25 @@ void wmi_get_timings(struct whisper_context * ctx, int64_t * t6, int32_t * n5) {
     const State & s = *ctx->state;
     t6[0] = s.t_mel_us; t6[1] = s.t_encode_us; t6[2] = s.t_decode_us; t6[3] = s.t_batchd_us; t6[4] = s.t_prompt_us; t6[5] = s.t_sample_us;
     n5[0] = s.n_encode; n5[1] = s.n_decode; n5[2] = s.n_batchd; n5[3] = s.n_prompt; n5[4] = s.n_sample;
+}
+
+int wmi_full_batch(struct whisper_context * ctx, struct whisper_full_params params, const float * const * pcm, const int * n_samples,
+                   int n_chunks, int pcm_on_device) {
+    if (!ctx || !ctx->state || !pcm || !n_samples || n_chunks < 0) return -1;
+    (void) hipSetDevice(ctx->device);
+    params.no_context = true;                 // chunks are independent transcriptions
+    return full_batch(*ctx, params, pcm, n_samples, n_chunks, pcm_on_device != 0);
+}
+
+int wmi_batch_select(struct whisper_context * ctx, int chunk) {
+    if (!ctx || !ctx->state || !ctx->batch || chunk < 0 || chunk >= (int) ctx->batch->results.size()) return -1;
+    ctx->state->result_all = ctx->batch->results[chunk];
+    return (int) ctx->state->result_all.size();
+}
+
+int wmi_batch_chunk_mode(struct whisper_context * ctx, int chunk) {
+    if (!ctx || !ctx->batch || chunk < 0 || chunk >= (int) ctx->batch->redo.size()) return -1;
+    return ctx->batch->redo[chunk];
 }
 
 void * wmi_stream(struct whisper_context * ctx) { return (void *) ctx->state->dev.stream; }

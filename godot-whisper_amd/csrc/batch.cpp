@@ -1,0 +1,515 @@
+// Lock-step transcription of several independent 30 s chunks on ONE GPU (BASELINE config 4:
+// 8 chunks per GPU).  Precedent in the reference: whisper_full_parallel (W/whisper.cpp:5809-5935) — shared
+// read-only weights, one whisper_state per worker.  Here the workers are not threads but rows of the same
+// kernels:
+//   * encoder: the chunks are stacked along M, so every projection / MLP GEMM runs once with M = B*T rows
+//     (the weights are read once per batch instead of once per chunk, the MFMA tiles fill the chip); attention
+//     gets a chunk dimension in grid.z; the conv front-end stays per chunk (overlapping-row implicit GEMM);
+//   * decoder: one greedy step advances every chunk by one token: the weight-streaming GEMV carries one
+//     activation row per chunk (R = B <= 8), each row with its own self-attention cache, cross cache slice and
+//     step record (token, position, filter flags); filters + arg-max run per row on the device.
+// The control flow per chunk is the one of full() (seek windows, prompt, state machine, segment emission);
+// chunks whose window would need the temperature fallback are re-run alone through full() afterwards, so the
+// result of every chunk equals what a separate whisper_full() call returns for it.
+
+#include "wmi.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+
+namespace wmi {
+
+namespace {
+
+constexpr int MAX_LANES = 8;               // rows of k_gemv
+
+template <typename T> bool dalloc(T *& p, size_t n_elems) {
+    p = nullptr;
+    return HIP_OK(hipMalloc((void **) &p, std::max<size_t>(n_elems, 1) * sizeof(T)));
+}
+template <typename T> void dfree(T *& p) { if (p) (void) hipFree(p); p = nullptr; }
+
+struct StateSwap {                          // run per-chunk host logic (mel, envelope, emission) against a lane's state
+    whisper_context & ctx; State * saved;
+    StateSwap(whisper_context & c, State * lane) : ctx(c), saved(c.state) { c.state = lane; }
+    ~StateSwap() { ctx.state = saved; }
+};
+
+State * new_lane_state(whisper_context & ctx) {
+    State * st = new State();
+    st->dev.stream = ctx.state->dev.stream;                 // one stream: the lanes are rows of the same launches
+    if (!dalloc(st->dev.mel_max, 4)) { delete st; return nullptr; }
+    for (auto & dec : st->decoders) dec.rng = std::mt19937(0);
+    return st;
+}
+
+void free_lane_state(State * st) {
+    DeviceState & d = st->dev;
+    dfree(d.pcm); dfree(d.mel); dfree(d.mel_max); dfree(d.energy);
+    if (d.energy_host) (void) hipHostFree(d.energy_host);
+    delete st;
+}
+
+bool ensure_batch(whisper_context & ctx, int B) {
+    if (!ctx.batch) ctx.batch = new BatchWork();
+    BatchWork & w = *ctx.batch;
+    if (w.B >= B) return true;
+    // grow: drop the old arenas (never on the hot path: the first call decides the size)
+    hipStream_t s = ctx.state->dev.stream;
+    (void) hipStreamSynchronize(s);
+    dfree(w.mel_t); dfree(w.conv1); dfree(w.x); dfree(w.xn); dfree(w.q); dfree(w.k); dfree(w.att); dfree(w.vt); dfree(w.h);
+    dfree(w.enc_out_h); dfree(w.kvc_k); dfree(w.kvc_v); dfree(w.self_k); dfree(w.self_v); dfree(w.dx); dfree(w.dq); dfree(w.dh);
+    dfree(w.logits); dfree(w.xattn);
+    if (w.step_dev) (void) hipFree(w.step_dev);
+    if (w.sample_dev) (void) hipFree(w.sample_dev);
+    if (w.filter_scratch) (void) hipFree(w.filter_scratch);
+    if (w.step_host) (void) hipHostFree(w.step_host);
+    if (w.sample_host) (void) hipHostFree(w.sample_host);
+    w.step_dev = w.sample_dev = w.filter_scratch = w.step_host = w.sample_host = nullptr;
+
+    const HParams & hp = ctx.model.hp;
+    const size_t S = hp.n_audio_state, T = hp.n_audio_ctx, Lt = hp.n_text_layer, H = hp.n_audio_head, n_ctx = hp.n_text_ctx;
+    w.Tpad = (int) ((T + 63) / 64 * 64);
+    w.mel_rows = 2 * T + 8;
+    const size_t nb = (size_t) B;
+    bool ok = dalloc(w.mel_t, nb * w.mel_rows * hp.n_mels + 1024) && dalloc(w.conv1, nb * (2 * T + 4) * S)
+           && dalloc(w.x, nb * T * S) && dalloc(w.xn, nb * T * S) && dalloc(w.q, nb * T * S) && dalloc(w.k, nb * T * S)
+           && dalloc(w.att, nb * T * S) && dalloc(w.vt, nb * S * w.Tpad) && dalloc(w.h, nb * T * 4 * S) && dalloc(w.enc_out_h, nb * T * S)
+           && dalloc(w.kvc_k, Lt * nb * T * S) && dalloc(w.kvc_v, Lt * nb * T * S)
+           && dalloc(w.self_k, nb * Lt * n_ctx * S) && dalloc(w.self_v, nb * Lt * n_ctx * S)
+           && dalloc(w.dx, nb * S) && dalloc(w.dq, nb * S) && dalloc(w.dh, nb * 4 * S) && dalloc(w.logits, nb * hp.n_vocab)
+           && dalloc(w.xattn, k::attn_cross_scratch_floats(B, (int) H, (int) T));
+    ok = ok && HIP_OK(hipMalloc(&w.step_dev, nb * sizeof(k::DecStep))) && HIP_OK(hipMalloc(&w.sample_dev, nb * sizeof(k::SampleOut)))
+            && HIP_OK(hipMalloc(&w.filter_scratch, k::filter_scratch_bytes(B)))
+            && HIP_OK(hipHostMalloc(&w.step_host, nb * sizeof(k::DecStep), hipHostMallocDefault))
+            && HIP_OK(hipHostMalloc(&w.sample_host, nb * sizeof(k::SampleOut), hipHostMallocDefault));
+    if (!ok) { WMI_ERR("%s: device allocation failed (B = %d)\n", __func__, B); w.B = 0; return false; }
+    k::fill_zero(w.vt, nb * S * w.Tpad * sizeof(__half), s);
+    k::fill_zero(w.conv1, nb * (2 * T + 4) * S * sizeof(__half), s);
+    k::fill_zero(w.mel_t, (nb * w.mel_rows * hp.n_mels + 1024) * sizeof(__half), s);
+    k::fill_zero(w.self_k, nb * Lt * n_ctx * S * sizeof(__half), s);
+    k::fill_zero(w.self_v, nb * Lt * n_ctx * S * sizeof(__half), s);
+    k::fill_zero(w.kvc_k, Lt * nb * T * S * sizeof(__half), s);
+    k::fill_zero(w.kvc_v, Lt * nb * T * S * sizeof(__half), s);
+    HIP_TRY(hipStreamSynchronize(s));
+    if (w.lanes.empty()) w.lanes.push_back(ctx.state);
+    while ((int) w.lanes.size() < B) {
+        State * st = new_lane_state(ctx);
+        if (!st) return false;
+        w.lanes.push_back(st);
+    }
+    w.B = B;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------- batched encoder
+// rows[r] = lane whose mel feeds chunk row r; seek[r] = its mel frame offset
+bool encode_rows(whisper_context & ctx, const std::vector<int> & rows, const std::vector<int> & seek, int audio_ctx) {
+    BatchWork & b = *ctx.batch; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
+    const int64_t t0 = time_us();
+    const int nb = (int) rows.size();
+    const int T = audio_ctx > 0 ? audio_ctx : hp.n_audio_ctx;
+    const int S = hp.n_audio_state, H = hp.n_audio_head, La = hp.n_audio_layer, Lt = hp.n_text_layer, nm = hp.n_mels;
+    hipStream_t s = ctx.state->dev.stream;
+    const int M = nb * T;
+
+    // conv front-end, per chunk (the overlapping-row implicit GEMM needs each chunk's zero guard rows)
+    const int rows_mel = 2 * T + 6;
+    for (int r = 0; r < nb; ++r) {
+        State & ls = *b.lanes[rows[r]];
+        if (ls.mel.n_mel != nm || ls.dev.mel == nullptr) { WMI_ERR("%s: chunk row %d has no mel spectrogram\n", __func__, r); return false; }
+        __half * mel_t = b.mel_t + (size_t) r * b.mel_rows * nm;
+        __half * conv1 = b.conv1 + (size_t) r * (2 * hp.n_audio_ctx + 4) * S;
+        k::mel_slice(ls.dev.mel, ls.mel.n_len, nm, seek[r], 2 * T, mel_t, nm, rows_mel, s);
+        {
+            k::GemmArgs a{};
+            a.A = mel_t; a.lda = nm; a.W = w.conv1_w; a.ldw = w.conv1_k; a.M = 2 * T; a.N = S; a.K = w.conv1_k;
+            a.bias = w.conv1_b; a.C = conv1 + S; a.ldc = S;
+            k::gemm(k::EPI_F16_BIAS_GELU, a, s);
+        }
+        k::fill_zero(conv1 + (size_t) (2 * T + 1) * S, (size_t) S * sizeof(__half), s);
+        {
+            k::GemmArgs a{};
+            a.A = conv1; a.lda = 2 * S; a.W = w.conv2_w; a.ldw = w.conv2_k; a.M = T; a.N = S; a.K = w.conv2_k;
+            a.bias = w.conv2_b; a.C = b.x + (size_t) r * T * S; a.ldc = S; a.resid = w.e_pe; a.ldr = S;
+            k::gemm(k::EPI_CONV2, a, s);
+        }
+    }
+    const float kq_scale = 1.0f / sqrtf((float) S / H);
+    for (int il = 0; il < La; ++il) {
+        const EncLayerW & l = w.enc[il];
+        k::layernorm(b.x, M, S, l.ln1_g, l.ln1_b, hp.eps, b.xn, nullptr, s);
+        {
+            k::GemmArgs a{};
+            a.A = b.xn; a.lda = S; a.W = l.w_qkv; a.ldw = S; a.M = M; a.N = 3 * S; a.K = S; a.bias = l.b_qkv;
+            a.C = b.q; a.ldc = S; a.aux = b.k; a.ldaux = S; a.aux2 = b.vt; a.ldaux2 = b.Tpad; a.S = S;
+            a.rows_per_chunk = T; a.chunk_stride_aux2 = (int64_t) S * b.Tpad;
+            k::gemm(k::EPI_QKV_ENC, a, s);
+        }
+        k::attn_encoder(b.q, b.k, b.vt, T, b.Tpad, S, H, kq_scale, b.att, s, nb);
+        {
+            k::GemmArgs a{};
+            a.A = b.att; a.lda = S; a.W = l.w_o; a.ldw = S; a.M = M; a.N = S; a.K = S; a.bias = l.b_o;
+            a.C = b.x; a.ldc = S; a.resid = b.x; a.ldr = S;
+            k::gemm(k::EPI_F32_BIAS_RESID, a, s);
+        }
+        k::layernorm(b.x, M, S, l.ln2_g, l.ln2_b, hp.eps, b.xn, nullptr, s);
+        {
+            k::GemmArgs a{};
+            a.A = b.xn; a.lda = S; a.W = l.w_fc1; a.ldw = S; a.M = M; a.N = 4 * S; a.K = S; a.bias = l.b_fc1;
+            a.C = b.h; a.ldc = 4 * S;
+            k::gemm(k::EPI_F16_BIAS_GELU, a, s);
+        }
+        {
+            k::GemmArgs a{};
+            a.A = b.h; a.lda = 4 * S; a.W = l.w_fc2; a.ldw = 4 * S; a.M = M; a.N = S; a.K = 4 * S; a.bias = l.b_fc2;
+            a.C = b.x; a.ldc = S; a.resid = b.x; a.ldr = S;
+            k::gemm(k::EPI_F32_BIAS_RESID, a, s);
+        }
+    }
+    k::layernorm(b.x, M, S, w.e_ln_g, w.e_ln_b, hp.eps, b.enc_out_h, nullptr, s);
+    {   // cross K/V of every decoder layer and every chunk: [L][nb*T][S] — chunk r of layer il starts at (il*nb + r)*T*S
+        k::GemmArgs a{};
+        a.A = b.enc_out_h; a.lda = S; a.W = w.w_ckv; a.ldw = S; a.M = M; a.N = Lt * 2 * S; a.K = S; a.bias = w.b_ckv;
+        a.C = b.kvc_k; a.ldc = S; a.aux = b.kvc_v; a.ldaux = S; a.S = S; a.layer_stride = (int64_t) M * S;
+        a.scale = powf((float) S / H, -0.25f);
+        k::gemm(k::EPI_CROSS_KV, a, s);
+    }
+    HIP_TRY(hipStreamSynchronize(s));
+    if (!HIP_OK(hipGetLastError())) return false;
+    b.enc_rows = nb; b.enc_T = T;
+    b.t_encode_us += time_us() - t0;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------- batched greedy step
+// step records are already in b.step_host[0..nb); results land in b.sample_host[0..nb)
+bool decode_rows_step(whisper_context & ctx, int nb) {
+    BatchWork & b = *ctx.batch; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
+    const int64_t t0 = time_us();
+    const int S = hp.n_text_state, H = hp.n_text_head, Lt = hp.n_text_layer, NV = hp.n_vocab, n_ctx = hp.n_text_ctx;
+    const int Tc = b.enc_T;
+    hipStream_t s = ctx.state->dev.stream;
+    const k::DecStep * stp = (const k::DecStep *) b.step_dev;
+    const float kq_scale = powf((float) S / H, -0.25f);
+    const int step_stride = (int) (sizeof(k::DecStep) / sizeof(int32_t));
+    const int64_t cache_stride = (int64_t) Lt * n_ctx * S;             // between the chunks' self caches
+    const int64_t cross_layer = (int64_t) b.enc_rows * Tc * S;
+
+    k::dec_embed_step((const k::DecStep *) b.step_host, (k::DecStep *) b.step_dev, S, w.d_te, w.d_pe, b.dx, s, nb);
+    auto base = [&](int K, int N, const __half * W, const float * bias, int epi, void * C, int ldc) {
+        k::GemvArgs g{};
+        g.n = nb; g.K = K; g.N = N; g.W = W; g.bias = bias; g.epi = epi; g.C = C; g.ldc = ldc; g.ldr = S; g.S = S; g.eps = hp.eps;
+        g.lanes = 1; g.step_stride = step_stride; g.cache_row_stride = cache_stride;
+        return g;
+    };
+    for (int il = 0; il < Lt; ++il) {
+        const DecLayerW & l = w.dec[il];
+        __half * ck = b.self_k + (size_t) il * n_ctx * S, * cv = b.self_v + (size_t) il * n_ctx * S;     // chunk 0; + r * cache_stride
+        {   // LN1 + q | k -> cache | v -> cache
+            k::GemvArgs g = base(S, 3 * S, l.w_qkv, l.b_qkv, k::EPI_QKV_DEC, b.dq, S);
+            g.x32 = b.dx; g.ln_g = l.ln1_g; g.ln_b = l.ln1_b; g.aux = ck; g.ldaux = S; g.aux2 = cv; g.ldaux2 = S; g.scale = kq_scale;
+            g.row_off = &stp->kv_head;
+            k::gemv(g, s);
+        }
+        {   // self-attention (prologue) + out projection + residual
+            k::GemvArgs g = base(S, S, l.w_o, l.b_o, k::EPI_F32_BIAS_RESID, b.dx, S);
+            g.sa_q = b.dq; g.sa_k = ck; g.sa_v = cv; g.sa_nkv = &stp->n_kv; g.sa_cap = n_ctx; g.resid = b.dx;
+            k::gemv(g, s);
+        }
+        {   // LN2 + cross query
+            k::GemvArgs g = base(S, S, l.w_cq, l.b_cq, k::EPI_Q_SCALED, b.dq, S);
+            g.x32 = b.dx; g.ln_g = l.ln2_g; g.ln_b = l.ln2_b; g.scale = kq_scale;
+            k::gemv(g, s);
+        }
+        {   // cross-attention partials over each row's own chunk, combined in the out projection's prologue
+            const float * po = nullptr, * pl = nullptr; int ns = 0;
+            k::attn_cross_split_partials(b.dq, nb, S, H, b.kvc_k + (size_t) il * cross_layer, b.kvc_v + (size_t) il * cross_layer, Tc,
+                                         b.xattn, &po, &pl, &ns, s, (int64_t) Tc * S);
+            k::GemvArgs g = base(S, S, l.w_co, l.b_co, k::EPI_F32_BIAS_RESID, b.dx, S);
+            g.comb_o = po; g.comb_l = pl; g.comb_ns = ns; g.resid = b.dx;
+            k::gemv(g, s);
+        }
+        {
+            k::GemvArgs g = base(S, 4 * S, l.w_fc1, l.b_fc1, k::EPI_F16_BIAS_GELU, b.dh, 4 * S);
+            g.x32 = b.dx; g.ln_g = l.ln3_g; g.ln_b = l.ln3_b;
+            k::gemv(g, s);
+        }
+        {
+            k::GemvArgs g = base(4 * S, S, l.w_fc2, l.b_fc2, k::EPI_F32_BIAS_RESID, b.dx, S);
+            g.a16 = b.dh; g.resid = b.dx;
+            k::gemv(g, s);
+        }
+    }
+    {
+        k::GemvArgs g = base(S, NV, w.d_te, nullptr, k::EPI_LOGITS, b.logits, NV);
+        g.x32 = b.dx; g.ln_g = w.d_ln_g; g.ln_b = w.d_ln_b;
+        k::gemv(g, s);
+    }
+    k::filter_argmax(b.logits, ctx.state->dev.ban_dev, stp, (k::SampleOut *) b.sample_dev, b.filter_scratch, s,
+                     (k::SampleOut *) b.sample_host, nb);
+    HIP_TRY(hipStreamSynchronize(s));
+    if (!HIP_OK(hipGetLastError())) return false;
+    b.t_decode_us += time_us() - t0; b.n_steps++;
+    return true;
+}
+
+// per-chunk bookkeeping of one lock-step group
+struct Row {
+    int chunk = 0, lane = 0;
+    int seek = 0, seek_start = 0, seek_end = 0;
+    bool live = false;                       // still has windows to decode in lock-step
+    bool redo = false;                       // needs the temperature fallback: re-run alone
+    std::vector<int32_t> prompt;
+    int n_fed = 0;                           // prompt tokens already through the decoder
+    int i = 0;                               // sampled tokens accepted in this window
+    bool done = false;                       // window finished (completed, failed or length limit)
+};
+
+} // namespace
+
+void free_batch(whisper_context & ctx) {
+    if (!ctx.batch) return;
+    BatchWork & w = *ctx.batch;
+    dfree(w.mel_t); dfree(w.conv1); dfree(w.x); dfree(w.xn); dfree(w.q); dfree(w.k); dfree(w.att); dfree(w.vt); dfree(w.h);
+    dfree(w.enc_out_h); dfree(w.kvc_k); dfree(w.kvc_v); dfree(w.self_k); dfree(w.self_v); dfree(w.dx); dfree(w.dq); dfree(w.dh);
+    dfree(w.logits); dfree(w.xattn);
+    if (w.step_dev) (void) hipFree(w.step_dev);
+    if (w.sample_dev) (void) hipFree(w.sample_dev);
+    if (w.filter_scratch) (void) hipFree(w.filter_scratch);
+    if (w.step_host) (void) hipHostFree(w.step_host);
+    if (w.sample_host) (void) hipHostFree(w.sample_host);
+    for (size_t i = 1; i < w.lanes.size(); ++i) free_lane_state(w.lanes[i]);
+    delete ctx.batch;
+    ctx.batch = nullptr;
+}
+
+int full_batch(whisper_context & ctx, whisper_full_params params, const float * const * pcm, const int * n_samples, int n_chunks,
+               bool on_device) {
+    if (ctx.host_only) { WMI_ERR("%s: host-only context has no compute path (this backend has no CPU fallback)\n", __func__); return -2; }
+    if (n_chunks <= 0) return 0;
+    const Vocab & v = ctx.model.vocab;
+    const HParams & hp = ctx.model.hp;
+    State * primary = ctx.state;
+    if (!ctx.batch) ctx.batch = new BatchWork();
+    ctx.batch->results.assign(n_chunks, {});
+    ctx.batch->redo.assign(n_chunks, 0);
+    ctx.batch->t_mel_us = ctx.batch->t_encode_us = ctx.batch->t_decode_us = ctx.batch->t_emit_us = 0; ctx.batch->n_steps = 0;
+
+    auto run_alone = [&](int c) -> int {                          // the general driver, one chunk at a time
+        // as on a fresh whisper_state (what every whisper_full_parallel worker gets, W/whisper.cpp:5837-5843): the
+        // decoders' generators start from their initial seed (W/whisper.cpp:3077), so a chunk's result does not
+        // depend on which chunks were transcribed before it
+        for (auto & dec : primary->decoders) dec.rng = std::mt19937(0);
+        const int rc = full(ctx, params, on_device ? nullptr : pcm[c], on_device ? pcm[c] : nullptr, n_samples[c]);
+        if (rc == 0) ctx.batch->results[c] = std::move(primary->result_all);
+        primary->result_all.clear();
+        return rc;
+    };
+
+    static const bool force_seq = getenv("WMI_BATCH_SEQUENTIAL") != nullptr;     // debug / A-B
+    const bool lang_known = params.language && strlen(params.language) > 0 && strcmp(params.language, "auto") != 0 && !params.detect_language;
+    const bool distilled = hp.n_text_layer == 2 && !params.no_timestamps;
+    const bool lockstep = !force_seq && fast_path_enabled() && params.strategy == WHISPER_SAMPLING_GREEDY && params.temperature < 1e-6f &&
+                          lang_known && !distilled && !params.speed_up && !params.logits_filter_callback && !params.new_segment_callback &&
+                          !params.progress_callback && !params.encoder_begin_callback && !params.abort_callback &&
+                          ctx.model.n_loaded > 0 && n_chunks > 1;
+    if (!lockstep) {
+        for (int c = 0; c < n_chunks; ++c) { const int rc = run_alone(c); if (rc != 0) return rc; ctx.batch->redo[c] = 1; }
+        return 0;
+    }
+    if (params.audio_ctx > hp.n_audio_ctx) {
+        WMI_ERR("%s: audio_ctx is larger than the maximum allowed (%d > %d)\n", __func__, params.audio_ctx, hp.n_audio_ctx);
+        return -5;
+    }
+    if (!ensure_batch(ctx, std::min(n_chunks, MAX_LANES))) return -2;
+    BatchWork & b = *ctx.batch;
+    if (!upload_static_ban(ctx, params)) return -7;
+
+    const bool has_fallback = params.temperature_inc > 0.0f && params.temperature + params.temperature_inc < 1.0f + 1e-6f;
+    std::vector<int32_t> prompt_user;
+    if (!params.prompt_tokens && params.initial_prompt) {
+        prompt_user = tokenize(v, params.initial_prompt);
+        if (prompt_user.size() > 1024) {
+            WMI_ERR("%s: too many resulting tokens: %d (max %d)\n", "whisper_tokenize", (int) prompt_user.size(), 1024);
+            prompt_user.clear();
+        }
+    } else if (params.prompt_tokens && params.prompt_n_tokens > 0) {
+        prompt_user.assign(params.prompt_tokens, params.prompt_tokens + params.prompt_n_tokens);
+    }
+    std::vector<int32_t> prompt_init = { v.sot };
+    if (v.is_multilingual()) {
+        const int lid = lang_id(params.language);
+        prompt_init.push_back(v.sot + 1 + lid);
+        prompt_init.push_back(params.translate ? v.translate : v.transcribe);
+    }
+    if (params.no_timestamps) prompt_init.push_back(v.not_);
+    int space_id = -1;
+    { auto sp = v.token_to_id.find(" "); if (sp != v.token_to_id.end()) space_id = sp->second; }
+    const int n_max = hp.n_text_ctx / 2 - 4;
+
+    for (int g0 = 0; g0 < n_chunks; g0 += b.B) {
+        const int ng = std::min(b.B, n_chunks - g0);
+        std::vector<Row> rows(ng);
+        // ---- per chunk: PCM -> mel, envelope, window bounds (the head of full())
+        for (int r = 0; r < ng; ++r) {
+            Row & row = rows[r]; row.chunk = g0 + r; row.lane = r;
+            State & ls = *b.lanes[r];
+            StateSwap sw(ctx, &ls);
+            ls.result_all.clear();
+            ls.prompt_past = prompt_user;                     // every chunk is an independent transcription (no_context semantics)
+            ls.exp_n_audio_ctx = params.audio_ctx;
+            if (v.is_multilingual()) ls.lang_id = lang_id(params.language);
+            const int64_t tm0 = time_us();
+            if (n_samples[row.chunk] > 0) {
+                if (!pcm_to_mel(ctx, pcm[row.chunk], n_samples[row.chunk], on_device)) { WMI_ERR("%s: failed to compute log mel spectrogram\n", __func__); return -2; }
+            }
+            if (params.token_timestamps) {
+                ls.t_beg = 0; ls.t_last = 0; ls.tid_last = 0;
+                if (n_samples[row.chunk] > 0 && !signal_energy_device(ctx, 32)) { WMI_ERR("%s: failed to compute the signal envelope\n", __func__); return -2; }
+            }
+            b.t_mel_us += time_us() - tm0;
+            row.seek_start = params.offset_ms / 10;
+            row.seek_end = params.duration_ms == 0 ? ls.mel.n_len_org : row.seek_start + params.duration_ms / 10;
+            row.seek = row.seek_start;
+            row.live = row.seek_end >= row.seek_start + 100;   // < 1 s of audio: nothing to do
+        }
+
+        // ---- windows in lock-step
+        while (true) {
+            std::vector<int> act;                              // row r of the kernels <-> rows[act[r]]
+            for (int r = 0; r < ng; ++r) if (rows[r].live && !rows[r].redo && rows[r].seek + 100 < rows[r].seek_end) act.push_back(r);
+            if (act.empty()) break;
+            const int nb = (int) act.size();
+            {
+                std::vector<int> lanes(nb), seeks(nb);
+                for (int r = 0; r < nb; ++r) { lanes[r] = rows[act[r]].lane; seeks[r] = rows[act[r]].seek; }
+                if (!encode_rows(ctx, lanes, seeks, params.audio_ctx)) { WMI_ERR("%s: failed to encode\n", __func__); return -6; }
+            }
+            for (int r = 0; r < nb; ++r) {
+                Row & row = rows[act[r]]; State & ls = *b.lanes[row.lane];
+                if (row.seek > row.seek_start && row.seek + 500 >= row.seek_end) ls.prompt_past.clear();
+                Decoder & d = ls.decoders[0];
+                d.sequence.tokens.clear();
+                d.sequence.result_len = 0; d.sequence.sum_logprobs_all = 0.0;
+                d.sequence.sum_logprobs = -INFINITY; d.sequence.avg_logprobs = -INFINITY;
+                d.sequence.entropy = 0.0; d.sequence.score = -INFINITY;
+                d.seek_delta = 100 * WHISPER_CHUNK_SIZE;
+                d.failed = false; d.completed = false; d.has_ts = false;
+                row.prompt.clear();
+                if (!ls.prompt_past.empty() && params.n_max_text_ctx > 0) {      // t = 0 < 0.5
+                    const int n_take = std::min(std::min(params.n_max_text_ctx, hp.n_text_ctx / 2), (int) ls.prompt_past.size());
+                    row.prompt.push_back(v.prev);
+                    row.prompt.insert(row.prompt.end(), ls.prompt_past.end() - n_take, ls.prompt_past.end());
+                }
+                row.prompt.insert(row.prompt.end(), prompt_init.begin(), prompt_init.end());
+                row.n_fed = 0; row.i = 0; row.done = false;
+            }
+
+            // ---- decode steps: every row feeds one token (prompt tokens first, one per step, then its own samples)
+            while (true) {
+                bool any = false;
+                k::DecStep * hs = (k::DecStep *) b.step_host;
+                for (int r = 0; r < nb; ++r) {
+                    Row & row = rows[act[r]]; const Decoder & d = b.lanes[row.lane]->decoders[0];
+                    k::DecStep & st = hs[r];
+                    memset(&st, 0, sizeof(st));
+                    st.space_id = space_id; st.eot = v.eot; st.beg = v.beg; st.n_vocab = v.n_vocab;
+                    st.ts_floor_end = v.beg; st.ts_initial_start = v.n_vocab;
+                    if (row.done) { st.token = v.eot; st.pos = 0; st.n_kv = 1; st.kv_head = 0; continue; }   // idle row
+                    any = true;
+                    const int np = (int) row.prompt.size();
+                    if (row.n_fed < np) { st.token = row.prompt[row.n_fed]; st.pos = row.n_fed; }
+                    else                { st.token = d.sequence.tokens.back().id; st.pos = np + row.i - 1; }
+                    st.n_kv = st.pos + 1; st.kv_head = st.pos;
+                    // filter state of the token this step will sample (W/whisper.cpp:4541-4657); see full()'s step_filter
+                    const auto & h = d.sequence.tokens;
+                    const bool initial = h.empty();
+                    const bool last_ts = !h.empty() && h.back().id >= v.beg;
+                    const bool penult_ts = h.size() < 2 || h[h.size() - 2].id >= v.beg;
+                    st.flags = ((params.suppress_blank && initial) ? 1 : 0) | (last_ts ? 2 : 0) | (penult_ts ? 4 : 0);
+                    if (d.has_ts) st.ts_floor_end = v.beg + d.seek_delta / 2;
+                    if (initial && params.max_initial_ts > 0.0f) {
+                        const float precision = float(WHISPER_CHUNK_SIZE) / hp.n_audio_ctx;
+                        st.ts_initial_start = v.beg + (int) std::round(params.max_initial_ts / precision) + 1;
+                    }
+                }
+                if (!any) break;
+                if (!decode_rows_step(ctx, nb)) { WMI_ERR("%s: failed to decode\n", __func__); return -8; }
+                const k::SampleOut * so = (const k::SampleOut *) b.sample_host;
+                for (int r = 0; r < nb; ++r) {
+                    Row & row = rows[act[r]];
+                    if (row.done) continue;
+                    const int np = (int) row.prompt.size();
+                    if (row.n_fed < np) { row.n_fed++; if (row.n_fed < np) continue; }     // still inside the prompt: discard
+                    Decoder & d = b.lanes[row.lane]->decoders[0];
+                    const int i = row.i;
+                    const whisper_token_data tok{ so[r].id, so[r].tid, so[r].p, so[r].plog, so[r].pt, so[r].ptsum, -1, -1, 0.0f };
+                    d.sequence.tokens.push_back(tok);
+                    d.sequence.sum_logprobs_all += tok.plog;
+                    row.i++;
+                    // state machine of one decoder (W/whisper.cpp:5450-5519)
+                    int & result_len = d.sequence.result_len;
+                    if (tok.id > v.beg) {
+                        const int sd_new = 2 * (tok.id - v.beg);
+                        if (d.has_ts && d.seek_delta > sd_new && result_len < i) { d.failed = true; row.done = true; continue; }
+                        d.seek_delta = sd_new; result_len = i + 1; d.has_ts = true;
+                    }
+                    if (tok.id == v.eot || (params.max_tokens > 0 && i >= params.max_tokens) ||
+                        (d.has_ts && row.seek + d.seek_delta + 100 >= row.seek_end)) {
+                        if (result_len == 0) {
+                            if (row.seek + d.seek_delta + 100 >= row.seek_end) result_len = i + 1;
+                            else { d.failed = true; row.done = true; continue; }
+                        }
+                        if (params.single_segment) { result_len = i + 1; d.seek_delta = 100 * WHISPER_CHUNK_SIZE; }
+                        d.completed = true; row.done = true;
+                        continue;
+                    }
+                    if (i == n_max - 1) {
+                        if (result_len == 0 || d.seek_delta < 100 * WHISPER_CHUNK_SIZE / 2) d.failed = true;
+                        row.done = true;
+                    }
+                }
+            }
+
+            // ---- rank / fallback decision / emission per row
+            for (int r = 0; r < nb; ++r) {
+                Row & row = rows[act[r]]; State & ls = *b.lanes[row.lane];
+                Decoder & d = ls.decoders[0];
+                if (!d.failed) {
+                    d.sequence.tokens.resize(d.sequence.result_len);
+                    sequence_score(params, d.sequence);
+                    if (d.sequence.result_len > 32 && d.sequence.entropy < params.entropy_thold) { d.failed = true; primary->n_fail_h++; }
+                }
+                if (has_fallback && (d.failed || d.sequence.avg_logprobs < params.logprob_thold)) { row.redo = true; primary->n_fail_p++; continue; }
+                const int64_t te0 = time_us();
+                StateSwap sw(ctx, &ls);
+                emit_window(ctx, params, row.seek, row.prompt, prompt_init.size(), d);
+                row.seek += d.seek_delta;
+                b.t_emit_us += time_us() - te0;
+            }
+        }
+
+        // ---- collect; chunks that asked for the temperature fallback go through the general driver alone
+        for (int r = 0; r < ng; ++r) {
+            Row & row = rows[r];
+            if (row.redo) {
+                b.redo[row.chunk] = 1;
+                const int rc = run_alone(row.chunk);
+                if (rc != 0) return rc;
+            } else {
+                b.results[row.chunk] = std::move(b.lanes[row.lane]->result_all);
+                b.lanes[row.lane]->result_all.clear();
+            }
+        }
+    }
+    static const bool dbg_t = getenv("WMI_DEBUG_TIMING") != nullptr;
+    if (dbg_t) fprintf(stderr, "[wmi] full_batch: %d chunks | mel+envelope %.3f ms | encode %.3f | decode %.3f (%d steps) | segments+timestamps %.3f\n",
+                       n_chunks, b.t_mel_us / 1e3, b.t_encode_us / 1e3, b.t_decode_us / 1e3, b.n_steps, b.t_emit_us / 1e3);
+    return 0;
+}
+
+} // namespace wmi

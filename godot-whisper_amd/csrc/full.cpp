@@ -212,6 +212,11 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
             };
             if (fast) {
                 bool ok = true;
+                static const bool stepwise = getenv("WMI_PROMPT_STEPWISE") != nullptr;   // debug / A-B: prompt token by token
+                if (stepwise) {
+                    for (size_t t = 0; ok && t + 1 < prompt.size(); ++t)
+                        ok = decode_greedy_step(ctx, prompt[t], (int) t, step_filter(st.decoders[0]), fast_next);
+                } else
                 if (prompt.size() > 1) {            // all but the last prompt token: plain batch decode, no logits wanted
                     st.batch.prep_legacy(prompt.data(), (int) prompt.size() - 1, 0, 0);
                     st.batch.logits[prompt.size() - 2] = 0;
@@ -379,37 +384,46 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
             const int64_t tem0 = time_us();
             struct Em { int64_t & acc; int64_t t0; ~Em() { acc += time_us() - t0; } } em_timer{T_emit, tem0};
             const Decoder & best = st.decoders[best_decoder_id];
-            const int seek_delta = best.seek_delta, result_len = best.sequence.result_len;
-            const auto & toks = best.sequence.tokens;
-
-            prompt_past.clear();
-            if (prompt.front() == v.prev) prompt_past.insert(prompt_past.end(), prompt.begin() + 1, prompt.end() - prompt_init.size());
-            for (int i = 0; i < result_len; ++i) prompt_past.push_back(toks[i].id);
-
-            if (!toks.empty() && ctx.model.n_loaded > 0) {
-                int i0 = 0;
-                int64_t t0 = seek + 2 * (toks.front().tid - v.beg);
-                std::string text;
-                bool speaker_turn_next = false;
-                for (int i = 0; i < (int) toks.size(); ++i) {
-                    if (params.print_special || toks[i].id < v.eot) text += tok_str(ctx, toks[i].id);
-                    if (params.tdrz_enable && toks[i].id == v.solm) speaker_turn_next = true;
-                    if (toks[i].id > v.beg && !params.single_segment) {
-                        const int64_t t1 = seek + 2 * (toks[i].tid - v.beg);
-                        if (!text.empty()) emit_segment(ctx, params, t0, t1, text, toks, i0, i + 1, speaker_turn_next);
-                        text.clear();
-                        while (i < (int) toks.size() && toks[i].id > v.beg) ++i;
-                        --i;
-                        t0 = t1; i0 = i + 1; speaker_turn_next = false;
-                    }
-                }
-                if (!text.empty()) emit_segment(ctx, params, t0, seek + seek_delta, text, toks, i0, (int) toks.size(), speaker_turn_next);
-            }
-            seek += seek_delta;
+            emit_window(ctx, params, seek, prompt, prompt_init.size(), best);
+            seek += best.seek_delta;
         }
     }
     return 0;
 }
+
+void emit_window(whisper_context & ctx, const whisper_full_params & params, int seek, const std::vector<int32_t> & prompt,
+                 size_t n_prompt_init, const Decoder & best) {
+    State & st = *ctx.state;
+    const Vocab & v = ctx.model.vocab;
+    auto & prompt_past = st.prompt_past;
+    const int seek_delta = best.seek_delta, result_len = best.sequence.result_len;
+    const auto & toks = best.sequence.tokens;
+
+    prompt_past.clear();
+    if (prompt.front() == v.prev) prompt_past.insert(prompt_past.end(), prompt.begin() + 1, prompt.end() - n_prompt_init);
+    for (int i = 0; i < result_len; ++i) prompt_past.push_back(toks[i].id);
+
+    if (!toks.empty() && ctx.model.n_loaded > 0) {
+        int i0 = 0;
+        int64_t t0 = seek + 2 * (toks.front().tid - v.beg);
+        std::string text;
+        bool speaker_turn_next = false;
+        for (int i = 0; i < (int) toks.size(); ++i) {
+            if (params.print_special || toks[i].id < v.eot) text += tok_str(ctx, toks[i].id);
+            if (params.tdrz_enable && toks[i].id == v.solm) speaker_turn_next = true;
+            if (toks[i].id > v.beg && !params.single_segment) {
+                const int64_t t1 = seek + 2 * (toks[i].tid - v.beg);
+                if (!text.empty()) emit_segment(ctx, params, t0, t1, text, toks, i0, i + 1, speaker_turn_next);
+                text.clear();
+                while (i < (int) toks.size() && toks[i].id > v.beg) ++i;
+                --i;
+                t0 = t1; i0 = i + 1; speaker_turn_next = false;
+            }
+        }
+        if (!text.empty()) emit_segment(ctx, params, t0, seek + seek_delta, text, toks, i0, (int) toks.size(), speaker_turn_next);
+    }
+}
+
 
 // ------------------------------------------------------------------ token-level timestamps (W/whisper.cpp:6315-6599)
 namespace {

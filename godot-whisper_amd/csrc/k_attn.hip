@@ -46,6 +46,10 @@ __global__ __launch_bounds__(NW * 64) void k_attn_enc(const __half * __restrict_
     const int fr = lane & 15, fq = lane >> 4;
     const int head = blockIdx.y;
     const int q0 = blockIdx.x * (NW * 16) + wave * 16;
+    {   // chunk (lane of a batched encode): activations are [B][T][S], V^T is [B][S][Tpad]
+        const size_t zb = blockIdx.z;
+        q += zb * (size_t) T * S; k += zb * (size_t) T * S; out += zb * (size_t) T * S; vt += zb * (size_t) S * Tpad;
+    }
 
     half8 qf[2];
     {
@@ -244,12 +248,13 @@ constexpr int XS_MAX_SLICES = 16;
 
 __global__ __launch_bounds__(256) void k_xattn_scores(const __half * __restrict__ q, int S, const __half * __restrict__ kc,
                                                       int T, int ks, int ns, float * __restrict__ sc, int ld_sc,
-                                                      float * __restrict__ pmax) {
+                                                      float * __restrict__ pmax, int64_t kv_row_stride) {
     __shared__ float qs[64];
     __shared__ float red[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slice = blockIdx.x, head = blockIdx.y, i = blockIdx.z, H = gridDim.y;
     if (tid < 64) qs[tid] = __half2float(q[(size_t) i * S + head * 64 + tid]);
+    kc += (int64_t) i * kv_row_stride;                      // lock-step chunks: row i attends to its own chunk's cross cache
     __syncthreads();
     float lmax = -INFINITY;
     for (int t = tid; t < ks; t += 256) {
@@ -281,13 +286,14 @@ __global__ __launch_bounds__(256) void k_xattn_scores(const __half * __restrict_
 
 __global__ __launch_bounds__(256) void k_xattn_pv(const __half * __restrict__ vc, int S, int T, int ks, int ns,
                                                   const float * __restrict__ sc, int ld_sc, const float * __restrict__ pmax,
-                                                  float * __restrict__ part_o, float * __restrict__ part_l) {
+                                                  float * __restrict__ part_o, float * __restrict__ part_l, int64_t kv_row_stride) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float * e   = (float *) smem;                 // [ks]
     float * red = e + ((ks + 3) & ~3);            // [4][64] partial outputs, then [4] sums
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slice = blockIdx.x, head = blockIdx.y, i = blockIdx.z, H = gridDim.y;
     const size_t row = (size_t) i * H + head;
+    vc += (int64_t) i * kv_row_stride;
     float m = -INFINITY;
     for (int s2 = 0; s2 < ns; ++s2) m = fmaxf(m, pmax[row * ns + s2]);
     const int j0 = slice * ks;
@@ -344,7 +350,7 @@ __global__ __launch_bounds__(64) void k_xattn_combine(const float * __restrict__
 } // namespace
 
 void attn_cross_split(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int T,
-                      float * scratch, __half * out, hipStream_t st) {
+                      float * scratch, __half * out, hipStream_t st, int64_t kv_row_stride) {
     // scratch layout: scores [n][H][Tpad] | pmax [n][H][NS] | part_l [n][H][NS] | part_o [n][H][NS][64]
     int ns = (T + 191) / 192; if (ns < 1) ns = 1; if (ns > XS_MAX_SLICES) ns = XS_MAX_SLICES;
     const int ks = (T + ns - 1) / ns;
@@ -353,14 +359,15 @@ void attn_cross_split(const __half * q, int n, int S, int H, const __half * kc, 
     float * pmax = sc + (size_t) n * H * ld_sc;
     float * part_l = pmax + (size_t) n * H * ns;
     float * part_o = part_l + (size_t) n * H * ns;
-    hipLaunchKernelGGL(k_xattn_scores, dim3(ns, H, n), dim3(256), 0, st, q, S, kc, T, ks, ns, sc, ld_sc, pmax);
+    hipLaunchKernelGGL(k_xattn_scores, dim3(ns, H, n), dim3(256), 0, st, q, S, kc, T, ks, ns, sc, ld_sc, pmax, kv_row_stride);
     const size_t smem = (((size_t) ks + 3) & ~(size_t) 3) * 4 + 4 * 64 * 4;
-    hipLaunchKernelGGL(k_xattn_pv, dim3(ns, H, n), dim3(256), smem, st, vc, S, T, ks, ns, sc, ld_sc, pmax, part_o, part_l);
+    hipLaunchKernelGGL(k_xattn_pv, dim3(ns, H, n), dim3(256), smem, st, vc, S, T, ks, ns, sc, ld_sc, pmax, part_o, part_l, kv_row_stride);
     hipLaunchKernelGGL(k_xattn_combine, dim3(H, n), dim3(64), 0, st, part_o, part_l, ns, S, out);
 }
 
 void attn_cross_split_partials(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int T,
-                               float * scratch, const float ** po, const float ** pl, int * pns, hipStream_t st) {
+                               float * scratch, const float ** po, const float ** pl, int * pns, hipStream_t st,
+                               int64_t kv_row_stride) {
     int ns = (T + 191) / 192; if (ns < 1) ns = 1; if (ns > XS_MAX_SLICES) ns = XS_MAX_SLICES;
     const int ks = (T + ns - 1) / ns;
     const int ld_sc = (T + 63) & ~63;
@@ -368,9 +375,9 @@ void attn_cross_split_partials(const __half * q, int n, int S, int H, const __ha
     float * pmax = sc + (size_t) n * H * ld_sc;
     float * part_l = pmax + (size_t) n * H * ns;
     float * part_o = part_l + (size_t) n * H * ns;
-    hipLaunchKernelGGL(k_xattn_scores, dim3(ns, H, n), dim3(256), 0, st, q, S, kc, T, ks, ns, sc, ld_sc, pmax);
+    hipLaunchKernelGGL(k_xattn_scores, dim3(ns, H, n), dim3(256), 0, st, q, S, kc, T, ks, ns, sc, ld_sc, pmax, kv_row_stride);
     const size_t smem = (((size_t) ks + 3) & ~(size_t) 3) * 4 + 4 * 64 * 4;
-    hipLaunchKernelGGL(k_xattn_pv, dim3(ns, H, n), dim3(256), smem, st, vc, S, T, ks, ns, sc, ld_sc, pmax, part_o, part_l);
+    hipLaunchKernelGGL(k_xattn_pv, dim3(ns, H, n), dim3(256), smem, st, vc, S, T, ks, ns, sc, ld_sc, pmax, part_o, part_l, kv_row_stride);
     *po = part_o; *pl = part_l; *pns = ns;
 }
 
@@ -380,10 +387,10 @@ size_t attn_cross_scratch_floats(int n, int H, int T) {
 }
 
 void attn_encoder(const __half * q, const __half * k, const __half * vt, int T, int Tpad, int S, int H, float scale,
-                  __half * out, hipStream_t st) {
+                  __half * out, hipStream_t st, int B) {
     static const int nw = getenv("WMI_ATTN_NW") ? atoi(getenv("WMI_ATTN_NW")) : 4;      // wavefronts per workgroup (A/B knob)
-    if (nw == 4) hipLaunchKernelGGL((k_attn_enc<4>), dim3((T + 63) / 64, H), dim3(256), 0, st, q, k, vt, T, Tpad, S, scale, out);
-    else         hipLaunchKernelGGL((k_attn_enc<2>), dim3((T + 31) / 32, H), dim3(128), 0, st, q, k, vt, T, Tpad, S, scale, out);
+    if (nw == 4) hipLaunchKernelGGL((k_attn_enc<4>), dim3((T + 63) / 64, H, B), dim3(256), 0, st, q, k, vt, T, Tpad, S, scale, out);
+    else         hipLaunchKernelGGL((k_attn_enc<2>), dim3((T + 31) / 32, H, B), dim3(128), 0, st, q, k, vt, T, Tpad, S, scale, out);
 }
 
 void attn_decoder(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int n_kv,

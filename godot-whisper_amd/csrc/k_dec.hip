@@ -38,6 +38,7 @@ __global__ void k_dec_embed(const int32_t * __restrict__ tokens, const int32_t *
 __global__ void k_dec_embed_step(const DecStep * __restrict__ host_step, DecStep * __restrict__ dev_step, int S,
                                  const __half * __restrict__ te, const float * __restrict__ pe, float * __restrict__ x) {
     __shared__ DecStep st;
+    host_step += blockIdx.x; dev_step += blockIdx.x; x += (size_t) blockIdx.x * S;      // one workgroup per lock-step chunk
     if (threadIdx.x < sizeof(DecStep) / 4) ((int32_t *) &st)[threadIdx.x] = ((const volatile int32_t *) host_step)[threadIdx.x];
     __syncthreads();
     if (threadIdx.x < sizeof(DecStep) / 4) ((int32_t *) dev_step)[threadIdx.x] = ((const int32_t *) &st)[threadIdx.x];
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
             if (a.bias) bias_pre = a.bias[n];
             if (a.resid) resid_pre = a.resid[(size_t) r * a.ldr + n];
         }
-        if (a.row_off) ro_pre = *a.row_off;
+        if (a.row_off) ro_pre = a.lanes ? a.row_off[(lane < ROWS_IN_FLIGHT * R ? r : 0) * a.step_stride] : *a.row_off;
     }
 
     // ---- prologue: stage the activation rows as f16
@@ -111,6 +112,7 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
         // Every workgroup recomputes the (tiny) attention of all heads: n_kv x H dot products of 64 — cheaper than
         // a separate launch on the critical path of a decode step.  Numerics as k_attn_dec: scores f16.f16 -> f32,
         // exp through f16, probabilities rounded to f16 before P.V (SURVEY App. B rules 1, 4, 5).
+        // R > 1 (lock-step chunks): one pass per row, each against its own chunk's cache.
         const int H = K / 64;
         float * sc = (float *) (smem + (((size_t) R * K * sizeof(__half) + 15) & ~(size_t) 15));   // [H][sa_cap]
         float * qf = sc + (size_t) H * a.sa_cap;                                                   // [K]
@@ -123,53 +125,59 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
 #pragma unroll
             for (int c8 = 0; c8 < 8; ++c8) kpre[c8] = kp[c8];
         }
-        const int n_kv = *a.sa_nkv;
-        for (int c = tid; c < K; c += 256) qf[c] = __half2float(a.sa_q[c]);
-        __syncthreads();
-        for (int p = tid; p < H * n_kv; p += 256) {
-            const int j = p / H, h = p - j * H;
-            const uint4 * kp = (const uint4 *) (a.sa_k + (size_t) j * K + h * 64);
-            float dot = 0.0f;
+#pragma unroll 1
+        for (int r = 0; r < R; ++r) {
+            const __half * sk = a.sa_k + (int64_t) r * a.cache_row_stride, * sv = a.sa_v + (int64_t) r * a.cache_row_stride;
+            const __half * sq = a.sa_q + (size_t) r * K;
+            const int n_kv = a.sa_nkv[r * a.step_stride];
+            for (int c = tid; c < K; c += 256) qf[c] = __half2float(sq[c]);
+            __syncthreads();
+            for (int p = tid; p < H * n_kv; p += 256) {
+                const int j = p / H, h = p - j * H;
+                const uint4 * kp = (const uint4 *) (sk + (size_t) j * K + h * 64);
+                float dot = 0.0f;
 #pragma unroll
-            for (int c8 = 0; c8 < 8; ++c8) {
-                const uint4 u = p == tid ? kpre[c8] : kp[c8];
-                const __half2 * hh = (const __half2 *) &u;
+                for (int c8 = 0; c8 < 8; ++c8) {
+                    const uint4 u = (p == tid && r == 0) ? kpre[c8] : kp[c8];
+                    const __half2 * hh = (const __half2 *) &u;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float2 f = __half22float2(hh[e]);
-                    dot = fmaf(f.x, qf[h * 64 + c8 * 8 + e * 2], dot);
-                    dot = fmaf(f.y, qf[h * 64 + c8 * 8 + e * 2 + 1], dot);
+                    for (int e = 0; e < 4; ++e) {
+                        const float2 f = __half22float2(hh[e]);
+                        dot = fmaf(f.x, qf[h * 64 + c8 * 8 + e * 2], dot);
+                        dot = fmaf(f.y, qf[h * 64 + c8 * 8 + e * 2 + 1], dot);
+                    }
                 }
+                sc[(size_t) h * a.sa_cap + j] = dot;
             }
-            sc[(size_t) h * a.sa_cap + j] = dot;
-        }
-        __syncthreads();
-        for (int h = wave; h < H; h += 4) {                 // soft-max of one head per wavefront
-            float * row = sc + (size_t) h * a.sa_cap;
-            float m = -INFINITY;
-            for (int j = lane; j < n_kv; j += 64) m = fmaxf(m, row[j]);
-            for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-            float l = 0.0f;
-            for (int j = lane; j < n_kv; j += 64) { const float e = round_f16(expf(round_f16(row[j] - m))); row[j] = e; l += e; }
-            for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
-            const float inv = (float) (1.0 / (double) l);
-            for (int j = lane; j < n_kv; j += 64) row[j] = round_f16(row[j] * inv);
-        }
-        __syncthreads();
-        for (int c = tid; c < K; c += 256) {
-            const float * row = sc + (size_t) (c >> 6) * a.sa_cap;
-            const __half * vp = a.sa_v + c;
-            float acc = 0.0f;
-            int j = 0;
-            for (; j + 8 <= n_kv; j += 8) {             // loads issued 8 at a time, accumulated in key order
-                __half vv[8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) vv[t] = vp[(size_t) (j + t) * K];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) acc = fmaf(row[j + t], __half2float(vv[t]), acc);
+            __syncthreads();
+            for (int h = wave; h < H; h += 4) {                 // soft-max of one head per wavefront
+                float * row = sc + (size_t) h * a.sa_cap;
+                float m = -INFINITY;
+                for (int j = lane; j < n_kv; j += 64) m = fmaxf(m, row[j]);
+                for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+                float l = 0.0f;
+                for (int j = lane; j < n_kv; j += 64) { const float e = round_f16(expf(round_f16(row[j] - m))); row[j] = e; l += e; }
+                for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
+                const float inv = (float) (1.0 / (double) l);
+                for (int j = lane; j < n_kv; j += 64) row[j] = round_f16(row[j] * inv);
             }
-            for (; j < n_kv; ++j) acc = fmaf(row[j], __half2float(vp[(size_t) j * K]), acc);
-            act[c] = __float2half_rn(acc);
+            __syncthreads();
+            for (int c = tid; c < K; c += 256) {
+                const float * row = sc + (size_t) (c >> 6) * a.sa_cap;
+                const __half * vp = sv + c;
+                float acc = 0.0f;
+                int j = 0;
+                for (; j + 8 <= n_kv; j += 8) {             // loads issued 8 at a time, accumulated in key order
+                    __half vv[8];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) vv[t] = vp[(size_t) (j + t) * K];
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) acc = fmaf(row[j + t], __half2float(vv[t]), acc);
+                }
+                for (; j < n_kv; ++j) acc = fmaf(row[j], __half2float(vp[(size_t) j * K]), acc);
+                act[(size_t) r * K + c] = __float2half_rn(acc);
+            }
+            if (R > 1) __syncthreads();                         // sc / qf are reused by the next row
         }
     } else if (a.comb_o) {                                  // fused combine of the split cross-attention partials
         const int H = K / 64, ns = a.comb_ns;
@@ -275,9 +283,12 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
                         const int c = n - seg * a.S;
                         const int ro = ro_pre;                              // KV-cache head (device scalar under graph replay)
                         __half * dst; float val;
-                        if (seg == 0)      { dst = (__half *) a.C    + (size_t) r * a.ldc;           val = (v + bias) * a.scale; }
-                        else if (seg == 1) { dst = (__half *) a.aux  + (size_t) (r + ro) * a.ldaux;  val = v * a.scale; }
-                        else               { dst = (__half *) a.aux2 + (size_t) (r + ro) * a.ldaux2; val = v + bias; }
+                        // cache row: consecutive slots of one sequence batch, or (lock-step chunks) slot ro of chunk r's own cache
+                        const int64_t crow = a.lanes ? (int64_t) r * a.cache_row_stride : 0;
+                        const int slot = a.lanes ? ro : r + ro;
+                        if (seg == 0)      { dst = (__half *) a.C    + (size_t) r * a.ldc;                  val = (v + bias) * a.scale; }
+                        else if (seg == 1) { dst = (__half *) a.aux  + crow + (size_t) slot * a.ldaux;      val = v * a.scale; }
+                        else               { dst = (__half *) a.aux2 + crow + (size_t) slot * a.ldaux2;     val = v + bias; }
                         dst[c] = __float2half_rn(val);
                     } break;
                     case EPI_LOGITS:         ((float *) a.C)[(size_t) r * a.ldc + n] = v; break;
@@ -317,8 +328,8 @@ void dec_embed(const int32_t * tokens, const int32_t * pos, int n, int S, const 
 }
 
 void dec_embed_step(const DecStep * host_step, DecStep * dev_step, int S, const __half * te, const float * pe, float * x,
-                    hipStream_t st) {
-    hipLaunchKernelGGL(k_dec_embed_step, dim3(1), dim3(256), 0, st, host_step, dev_step, S, te, pe, x);
+                    hipStream_t st, int n_rows) {
+    hipLaunchKernelGGL(k_dec_embed_step, dim3(n_rows), dim3(256), 0, st, host_step, dev_step, S, te, pe, x);
 }
 
 void gemv(const GemvArgs & a, hipStream_t st) {

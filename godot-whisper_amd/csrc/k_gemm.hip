@@ -144,15 +144,22 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
             if constexpr (EPI == EPI_QKV_ENC) {
                 const int seg = n / a.S, c = n - seg * a.S;
                 if (seg == 2) {            // V^T: four consecutive time steps per lane -> one 8-byte store
-                    __half * vt = (__half *) a.aux2 + (size_t) c * a.ldaux2;
-                    if (mrow + 3 < a.M) {
+                    // batched encode: row m = chunk * rows_per_chunk + t, V^T is [chunk][S][Tpad]
+                    const int rpc = a.rows_per_chunk > 0 ? a.rows_per_chunk : a.M;
+                    const int cb = mrow / rpc, t0 = mrow - cb * rpc;
+                    __half * vt = (__half *) a.aux2 + (size_t) cb * a.chunk_stride_aux2 + (size_t) c * a.ldaux2;
+                    if (mrow + 3 < a.M && t0 + 3 < rpc && ((t0 & 3) == 0)) {
                         half4 v;
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = (_Float16) (acc[i][j][r] + bias);
-                        *(half4 *) (vt + mrow) = v;
+                        *(half4 *) (vt + t0) = v;
                     } else {
-                        for (int r = 0; r < 4; ++r)
-                            if (mrow + r < a.M) vt[mrow + r] = __float2half_rn(acc[i][j][r] + bias);
+                        for (int r = 0; r < 4; ++r) {
+                            const int m = mrow + r;
+                            if (m >= a.M) continue;
+                            const int cb2 = m / rpc, t = m - cb2 * rpc;
+                            ((__half *) a.aux2)[(size_t) cb2 * a.chunk_stride_aux2 + (size_t) c * a.ldaux2 + t] = __float2half_rn(acc[i][j][r] + bias);
+                        }
                     }
                     continue;
                 }

@@ -41,9 +41,10 @@ __global__ __launch_bounds__(NT) void k_filter_stats(const float * __restrict__ 
     __shared__ MaxIdx s_all[4], s_txt[4], s_ts[4];
     __shared__ float s_sum[4], s_sum_ts[4];
     __shared__ float b_M;
-    const DecStep st = *stp;
+    const DecStep st = stp[blockIdx.y];                  // grid.y: lock-step chunk (row of the logits matrix)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int NV = st.n_vocab, beg = st.beg;
+    logits += (size_t) blockIdx.y * NV; part += (size_t) blockIdx.y * NB;
     const bool ban_blank = st.flags & 1, last_ts = st.flags & 2, pen_ts = st.flags & 4;
     const int per = (NV + NB - 1) / NB, i0 = blockIdx.x * per, i1 = min(NV, i0 + per);
 
@@ -102,6 +103,7 @@ __global__ __launch_bounds__(NT) void k_filter_stats(const float * __restrict__ 
 __global__ __launch_bounds__(64) void k_filter_pick(const Partial * __restrict__ part, const DecStep * __restrict__ stp,
                                                     SampleOut * __restrict__ out, SampleOut * __restrict__ out_host) {
     const int lane = threadIdx.x;
+    part += (size_t) blockIdx.x * NB; stp += blockIdx.x; out += blockIdx.x; if (out_host) out_host += blockIdx.x;
     const Partial p = part[lane];                       // NB == 64: one partial per lane
     const MaxIdx a = wave_max(p.all), t = wave_max(p.txt), z = wave_max(p.ts);
     const float M = a.v;
@@ -132,11 +134,11 @@ __global__ __launch_bounds__(64) void k_filter_pick(const Partial * __restrict__
 } // namespace
 
 void filter_argmax(const float * logits, const uint8_t * static_ban, const DecStep * step, SampleOut * out, void * scratch,
-                   hipStream_t st, SampleOut * out_host) {
+                   hipStream_t st, SampleOut * out_host, int n_rows) {
     Partial * part = (Partial *) scratch;
-    hipLaunchKernelGGL(k_filter_stats, dim3(NB), dim3(NT), 0, st, logits, static_ban, step, part);
-    hipLaunchKernelGGL(k_filter_pick, dim3(1), dim3(64), 0, st, part, step, out, out_host);
+    hipLaunchKernelGGL(k_filter_stats, dim3(NB, n_rows), dim3(NT), 0, st, logits, static_ban, step, part);
+    hipLaunchKernelGGL(k_filter_pick, dim3(n_rows), dim3(64), 0, st, part, step, out, out_host);
 }
-size_t filter_scratch_bytes() { return NB * sizeof(Partial); }
+size_t filter_scratch_bytes(int n_rows) { return (size_t) n_rows * NB * sizeof(Partial); }
 
 }} // namespace wmi::k

@@ -46,6 +46,8 @@ struct GemmArgs {
     float   scale;                  // q/k scale
     int     S;                      // split width for the QKV / cross epilogues
     int64_t layer_stride;           // EPI_CROSS_KV: elements between layers in the cross cache
+    int     rows_per_chunk;         // EPI_QKV_ENC, batched encode: M = chunks * rows_per_chunk (0: one chunk)
+    int64_t chunk_stride_aux2;      //   elements between the chunks' V^T images
 };
 void gemm(int epi, const GemmArgs & a, hipStream_t st);
 
@@ -56,8 +58,9 @@ void layernorm(const float * x, int rows, int S, const float * g, const float * 
 
 // ---------------------------------------------------------------- attention (k_attn.hip)
 // encoder: q,k [T][S] f16 ; vt [S][Tpad] f16 ; out [T][S] f16 ; scale applied to q.k before softmax
+// B > 1: B chunks back to back (q,k,out [B][T][S]; vt [B][S][Tpad]), one grid.z slice each
 void attn_encoder(const __half * q, const __half * k, const __half * vt, int T, int Tpad, int S, int H,
-                  float scale, __half * out, hipStream_t st);
+                  float scale, __half * out, hipStream_t st, int B = 1);
 // decoder: one (token, head) per workgroup.  kc/vc: [n_kv][S] caches (this layer), mask: [n][ld_mask] or null
 void attn_decoder(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int n_kv,
                   const float * mask, int ld_mask, __half * out, hipStream_t st,
@@ -65,10 +68,11 @@ void attn_decoder(const __half * q, int n, int S, int H, const __half * kc, cons
 
 // decoder cross-attention split over the key axis (3 small launches, NS x H x n workgroups); same numerics
 void attn_cross_split(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int T,
-                      float * scratch, __half * out, hipStream_t st);
+                      float * scratch, __half * out, hipStream_t st, int64_t kv_row_stride = 0);
 // same without the combine launch: the consumer GEMV combines the partials in its prologue (GemvArgs::comb_*)
 void attn_cross_split_partials(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int T,
-                               float * scratch, const float ** part_o, const float ** part_l, int * ns, hipStream_t st);
+                               float * scratch, const float ** part_o, const float ** part_l, int * ns, hipStream_t st,
+                               int64_t kv_row_stride = 0);   // row i reads kc/vc + i * kv_row_stride (lock-step chunks)
 size_t attn_cross_scratch_floats(int n, int H, int T);
 
 // ---------------------------------------------------------------- decoder small-batch (k_dec.hip)
@@ -91,6 +95,10 @@ struct GemvArgs {
     const float * comb_o; const float * comb_l; int comb_ns;   // optional: A operand = combined split cross-attention partials
     // optional (n == 1): A operand = self-attention output computed in the prologue from q and this layer's KV cache
     const __half * sa_q; const __half * sa_k; const __half * sa_v; const int32_t * sa_nkv; int sa_cap;
+    // lock-step chunks (lanes != 0): row r belongs to chunk r with its own KV cache and step record.
+    //   aux/aux2 row = row_off[r * step_stride] (no "+ r"), cache base + r * cache_row_stride ; sa_nkv[r * step_stride] ;
+    //   sa_k / sa_v + r * cache_row_stride
+    int lanes; int step_stride; int64_t cache_row_stride;
 };
 enum { EPI_LOGITS = 100 };                    // C f32 [n][N] = acc
 void gemv(const GemvArgs & a, hipStream_t st);
@@ -108,11 +116,13 @@ struct DecStep {
 };
 struct SampleOut { int32_t id, tid; float p, plog, pt, ptsum; int32_t forced_ts; int32_t pad; };
 // logits [n_vocab] -> filtered soft-max statistics and the arg-max token (W/whisper.cpp:4493-4830 at temperature 0)
+// n_rows > 1: lock-step chunks — logits [n_rows][n_vocab], step[n_rows], out[n_rows]
 void filter_argmax(const float * logits, const uint8_t * static_ban, const DecStep * step, SampleOut * out, void * scratch, hipStream_t st,
-                   SampleOut * out_host = nullptr);
-size_t filter_scratch_bytes();
+                   SampleOut * out_host = nullptr, int n_rows = 1);
+size_t filter_scratch_bytes(int n_rows = 1);
 // first kernel of a replayed step: fetch DecStep from pinned host memory, mirror it on the device, embed the token
-void dec_embed_step(const DecStep * host_step, DecStep * dev_step, int S, const __half * te, const float * pe, float * x, hipStream_t st);
+void dec_embed_step(const DecStep * host_step, DecStep * dev_step, int S, const __half * te, const float * pe, float * x, hipStream_t st,
+                    int n_rows = 1);
 
 // misc
 void touch(int * p, int blocks, hipStream_t st);     // trivial dependent kernel (launch-floor probe)

@@ -206,6 +206,27 @@ struct State {
     DeviceState dev;
 };
 
+// Lock-step transcription of several independent chunks on one GPU (8 chunks per GPU; same ownership
+// split as whisper_full_parallel, W/whisper.cpp:5837-5858: shared read-only weights, one state per worker).
+// Activations carry a chunk dimension (encoder GEMMs see M = B * T rows), every chunk has its own self / cross cache.
+struct BatchWork {
+    int B = 0;                                               // chunk slots allocated (<= 8: rows of the decode GEMV)
+    int Tpad = 0;
+    size_t mel_rows = 0;                                      // rows of one chunk's token-major mel image
+    __half * mel_t = nullptr, * conv1 = nullptr;              // [B][mel_rows][n_mel], [B][2T+4][S]
+    float  * x = nullptr;                                     // [B*T][S] f32 residual stream
+    __half * xn = nullptr, * q = nullptr, * k = nullptr, * att = nullptr, * vt = nullptr, * h = nullptr, * enc_out_h = nullptr;
+    __half * kvc_k = nullptr, * kvc_v = nullptr;              // cross cache [L][B*T][S]
+    __half * self_k = nullptr, * self_v = nullptr;            // self cache  [B][L][n_ctx][S]
+    float  * dx = nullptr; __half * dq = nullptr, * dh = nullptr; float * logits = nullptr, * xattn = nullptr;
+    void   * step_dev = nullptr, * step_host = nullptr, * sample_dev = nullptr, * sample_host = nullptr, * filter_scratch = nullptr;
+    int      enc_rows = 0, enc_T = 0;                         // chunk rows / encoder length of the last batched encode
+    std::vector<State *> lanes;                               // lanes[0] is the context's own state (not owned)
+    std::vector<std::vector<Segment>> results;                // per chunk of the last wmi_full_batch call
+    std::vector<int> redo;                                    // per chunk: 1 if it was re-run alone (temperature fallback)
+    int64_t t_mel_us = 0, t_encode_us = 0, t_decode_us = 0, t_emit_us = 0; int n_steps = 0;
+};
+
 } // namespace wmi
 
 struct whisper_context {
@@ -216,6 +237,7 @@ struct whisper_context {
     wmi::State *   state = nullptr;
     int            device = 0;
     bool           host_only = false;   // vocabulary + host logic only (tests); every compute call fails loudly
+    wmi::BatchWork * batch = nullptr;   // lazily created by wmi_full_batch
 };
 
 namespace wmi {
@@ -243,6 +265,12 @@ void sequence_score(const whisper_full_params & params, Sequence & seq);
 std::vector<int32_t> tokenize(const Vocab & vocab, const std::string & text);
 int  lang_auto_detect(whisper_context & ctx, int offset_ms, float * lang_probs);
 int  full(whisper_context & ctx, whisper_full_params params, const float * samples, const float * d_samples, int n_samples);
+// several independent chunks in lock-step (batch.cpp); results per chunk in ctx.batch->results
+int  full_batch(whisper_context & ctx, whisper_full_params params, const float * const * pcm, const int * n_samples, int n_chunks, bool on_device);
+void free_batch(whisper_context & ctx);
+// segment emission of one decoded window: updates prompt_past and appends to state.result_all (W/whisper.cpp:5682-5796)
+void emit_window(whisper_context & ctx, const whisper_full_params & params, int seek, const std::vector<int32_t> & prompt,
+                 size_t n_prompt_init, const Decoder & best);
 std::vector<float> signal_energy(const float * signal, int n_samples, int hw);
 void token_level_timestamps(whisper_context & ctx, int i_segment, float thold_pt, float thold_ptsum);
 int  wrap_segment(whisper_context & ctx, int max_len, bool split_on_word);

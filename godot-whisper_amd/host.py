@@ -110,6 +110,35 @@ class SpeechToText:
         out.insert(0, full_text)
         return out
 
+    # -- several independent buffers at once (product library only: include/wmi_device.h wmi_full_batch).  The
+    #    reference host has no such call; the semantics are "transcribe() of each buffer, on a fresh context".
+    def transcribe_batch(self, buffers: list, initial_prompt: str = "", audio_ctx: int = 0, params=None,
+                         device_ptrs: list | None = None) -> list:
+        if not self.ctx:
+            return []
+        p = params if params is not None else self.full_params(initial_prompt, audio_ctx)
+        n = len(buffers)
+        if device_ptrs is None:
+            bufs = [np.ascontiguousarray(b, dtype=np.float32) for b in buffers]
+            ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+            lens = (C.c_int * n)(*[int(b.size) for b in bufs])
+            on_dev = 0
+        else:
+            ptrs = (C.c_void_p * n)(*device_ptrs)
+            lens = (C.c_int * n)(*[int(b) for b in buffers])          # sample counts
+            on_dev = 1
+        ret = self.lib.wmi_full_batch(self.ctx, p, ptrs, lens, n, on_dev)
+        self.last_ret = ret
+        if ret != 0:
+            return []
+        out = []
+        self.last_modes = []
+        for c in range(n):
+            assert self.lib.wmi_batch_select(self.ctx, c) >= 0
+            self.last_modes.append(self.lib.wmi_batch_chunk_mode(self.ctx, c))
+            out.append(self.collect())
+        return out
+
     # -- voice_activity_detection (src/speech_to_text.cpp:53-104, 378-399)
     def voice_activity_detection(self, buffer: np.ndarray) -> bool:
         n_win = abi.WHISPER_SAMPLE_RATE * 3

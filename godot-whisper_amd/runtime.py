@@ -19,6 +19,9 @@ DEVICE_API = [
     ("wmi_init_host_only", C.c_void_p, [C.c_void_p, C.c_size_t]),
     ("wmi_pcm_to_mel_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     ("wmi_full_device_pcm", C.c_int, [C.c_void_p, abi.whisper_full_params, C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
+    ("wmi_full_batch", C.c_int, [C.c_void_p, abi.whisper_full_params, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int]),
+    ("wmi_batch_select", C.c_int, [C.c_void_p, C.c_int]),
+    ("wmi_batch_chunk_mode", C.c_int, [C.c_void_p, C.c_int]),
     ("wmi_set_audio_ctx", C.c_int, [C.c_void_p, C.c_int]),
     ("wmi_get_tensor", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int]),
     ("wmi_mel_dims", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -44,6 +44,24 @@ WHISPER_API int wmi_pcm_to_mel_device(struct whisper_context * ctx, const float 
 WHISPER_API int wmi_full_device_pcm(struct whisper_context * ctx, struct whisper_full_params params,
                                     const float * d_samples, int n_samples, const float * h_samples_for_timestamps);
 
+/* Several independent chunks on one GPU in lock-step (BASELINE config 4: 8 chunks per GPU).  Every chunk is
+ * transcribed as by whisper_full(ctx, params, pcm[c], n_samples[c]) on a freshly initialised context
+ * (params.no_context = true, decoder RNGs at their initial seed);
+ * the chunks share the weights and advance together: encoder GEMMs over all chunks at once (M = chunks * n_ctx),
+ * one decode step = one token for every chunk.  More than 8 chunks are processed in groups of 8.
+ * replaces: the per-worker loop of whisper_full_parallel (W/whisper.cpp:5809-5935: shared model, one
+ * whisper_state per worker) — workers are rows of the same kernels instead of threads.
+ * Lock-step needs greedy sampling at temperature 0 without callbacks and a known language; otherwise, and for
+ * any chunk that triggers the temperature fallback, the chunk is run alone through the whisper_full driver.
+ * pcm[c] are host pointers, or device pointers when pcm_on_device != 0.  Returns whisper_full's codes. */
+WHISPER_API int wmi_full_batch(struct whisper_context * ctx, struct whisper_full_params params, const float * const * pcm,
+                               const int * n_samples, int n_chunks, int pcm_on_device);
+/* Make the whisper_full_n_segments / whisper_full_get_* accessors (W/whisper.h:541-575) read chunk `chunk` of the
+ * last wmi_full_batch call.  Returns its segment count, -1 for a bad index. */
+WHISPER_API int wmi_batch_select(struct whisper_context * ctx, int chunk);
+/* 0: chunk `chunk` was decoded in lock-step; 1: it was run alone (fallback, see above); -1: bad index. */
+WHISPER_API int wmi_batch_chunk_mode(struct whisper_context * ctx, int chunk);
+
 /* Encoder length override for the bare whisper_encode / whisper_decode calls, i.e. what whisper_full
  * does with params.audio_ctx (W/whisper.cpp:5098-5102); 0 = model default.  Returns -5 if too large. */
 WHISPER_API int wmi_set_audio_ctx(struct whisper_context * ctx, int n_audio_ctx);

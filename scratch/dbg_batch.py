@@ -1,21 +1,23 @@
-import sys, os, numpy as np
+import sys, os
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
-import __graft_entry__ as e
-e.load_package(); e.load_oracle()
-from godot_whisper_amd import runtime, synth
-from oracle import reflib
-import stage_compare as sc
+import numpy as np
+import __graft_entry__ as ge
+ge.load_package()
+from godot_whisper_amd import host, runtime, synth
+import golden_util as gu
 lib = runtime.require_gpu(); runtime.silence_logs(lib)
-rl = reflib.lib()
-mb = synth.make_model("micro.en", seed=1234); pcm = synth.make_pcm(30.0, seed=1234)
-prod = sc.ProductSide(lib, mb); ref = sc.RefSide(rl, mb)
-ref.mel(pcm); prod.mel(pcm); ref.encode(); prod.encode()
-sot = rl.whisper_token_sot(ref.ctx)
-for n in (1, 2, 3, 8, 9, 12, 40):
-    toks = [sot] + [int(x) for x in (np.arange(n - 1) * 997 + 1000)]
-    a = ref.decode(toks, 0); b = prod.decode(toks, 0)
-    print(os.environ.get("WMI_DECODE_PATH"), n, sc.err_stats(b, a))
-# incremental: 3 tokens then 2 more at n_past=3
-toks = [sot, 1000, 2000]; ref.decode(toks, 0); prod.decode(toks, 0)
-a = ref.decode([3000, 4000], 3); b = prod.decode([3000, 4000], 3)
-print("incremental", sc.err_stats(b, a))
+model = synth.make_model("micro", seed=2024)
+secs = [30.0, 11.0, 4.0, 47.0, 30.0, 0.5, 22.5, 30.0, 8.0, 30.0, 15.0]
+pcms = [synth.make_pcm(s, seed=100 + i, gate=(i % 3 == 1)) for i, s in enumerate(secs)]
+def P(node): return gu.param_variants(node)["host_prompt"]
+node = host.SpeechToText(lib); node.set_language_model(model)
+def show(tag, r):
+    a = gu.tokens_array(r)
+    print(tag, [(int(x[0]), round(x[2], 4)) for x in a[:6]])
+w = node.transcribe(pcms[10], params=P(node)); show("alone     ", w)
+for combo in ([10, 10], [8, 9, 10], [10, 8], [0, 10]):
+    g = node.transcribe_batch([pcms[i] for i in combo], params=P(node))
+    for i, c in enumerate(combo):
+        show(f"batch{combo}[{c}] mode={node.last_modes[i]}", g[i])
+w0 = node.transcribe(pcms[0], params=P(node)); show("alone c0  ", w0)
+w8 = node.transcribe(pcms[8], params=P(node)); show("alone c8  ", w8)

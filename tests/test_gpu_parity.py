@@ -299,3 +299,116 @@ def test_streaming_node_call_pattern_matches_reference_goldens(product_lib):
         assert n_calls >= 4
     finally:
         node.close()
+
+
+# ------------------------------------------------------------------------------------------------ lock-step chunks
+def _assert_same_transcription(got, want, what, strict):
+    g, w = gu.tokens_array(got), gu.tokens_array(want)
+    if strict:
+        # same kernels row for row, bit-identical sums: everything equal, probabilities to f32 noise
+        assert g.shape == w.shape, (what, g.shape, w.shape)
+        assert np.array_equal(g[:, [0, 1, 6, 7, 8]], w[:, [0, 1, 6, 7, 8]]), (what, g[:, [0, 1, 6, 7]], w[:, [0, 1, 6, 7]])
+        if len(g):
+            assert np.abs(g[:, 2:6] - w[:, 2:6]).max() <= 1e-6, what
+        assert bytes(got[0]) == bytes(want[0]), what
+        return
+    # different f32 summation order somewhere upstream (see the callers): identical up to the first near-tie
+    n = min(len(g), len(w))
+    same = g[:n, 0] == w[:n, 0]
+    first = n if same.all() else int(np.argmin(same))
+    if first < n:
+        assert abs(g[first, 2] - w[first, 2]) <= 2e-2, (what, first, g[first], w[first])
+    else:
+        assert g.shape == w.shape, (what, g.shape, w.shape)
+    if first:
+        assert np.abs(g[:first, [2, 4, 5]] - w[:first, [2, 4, 5]]).max() <= 1e-2, what
+    if first == n and n:
+        assert np.array_equal(g[:, [6, 7, 8]], w[:, [6, 7, 8]]), what
+        assert bytes(got[0]) == bytes(want[0]), what
+
+
+@pytest.mark.parametrize("shape,variant", [("micro.en", "host"), ("micro", "host"), ("micro.en", "default_greedy"),
+                                           ("micro.en", "default_fallback"), ("micro", "host_prompt")])
+def test_lockstep_chunks_equal_one_at_a_time(product_lib, shape, variant):
+    """wmi_full_batch (several chunks as rows of the same kernels) == whisper_full per chunk on a fresh context:
+    ragged lengths (4 s ... 47 s: one and two seek windows, < 1 s: no output), more chunks than rows (11 > 8)."""
+    model = synth.make_model(shape, seed=2024)
+    secs = [30.0, 11.0, 4.0, 47.0, 30.0, 0.5, 22.5, 30.0, 8.0, 30.0, 15.0]
+    pcms = [synth.make_pcm(s, seed=100 + i, gate=(i % 3 == 1)) for i, s in enumerate(secs)]
+
+    def params(node):
+        p = gu.param_variants(node)[variant]
+        if shape == "micro" and variant == "host":
+            node.language = "de"; p = node.full_params("", 0)
+        if shape == "micro":
+            # multi-token prompts are not bit-identical between the two paths (see below), and the temperature
+            # fallback is a threshold on avg_logprob — discontinuous in the logits (SURVEY §7; one of these chunks
+            # sits at avg_logprob = -1.00 +- 1e-3).  Token parity is checked with the fallback off, as in the goldens.
+            p.temperature_inc = 0.0
+        return p
+
+    want = []
+    for b in pcms:                                               # fresh context per chunk: decoder RNGs at their seed
+        node = host.SpeechToText(product_lib); node.set_language_model(model)
+        want.append(node.transcribe(b, params=params(node)))
+        assert node.last_ret == 0
+        node.close()
+    node = host.SpeechToText(product_lib); node.set_language_model(model)
+    try:
+        got = node.transcribe_batch(pcms, params=params(node))
+        assert node.last_ret == 0 and len(got) == len(pcms)
+        modes = list(node.last_modes)
+        # a chunk leaves the lock-step path when a window asks for the temperature fallback (logprob / entropy
+        # thresholds, W/whisper.cpp:5643-5670) and is then run alone; with the fallback switched off none may
+        if variant == "default_greedy":
+            assert modes == [0] * len(pcms), modes
+        assert modes.count(0) >= 2, modes
+        for c, (g, w) in enumerate(zip(got, want)):
+            # Lock-step rows with a single-token prompt and one window use the same kernels as the one-at-a-time path
+            # (bit-identical); chunks run alone are the one-at-a-time path.  Longer prompts (multilingual, initial
+            # prompt, second window with context) go through the MFMA GEMM when alone and token by token through the
+            # GEMV here, which changes the f32 summation order.
+            strict = modes[c] == 1 or (shape == "micro.en" and variant == "host")
+            if variant == "default_fallback" and not strict:
+                continue        # context prompts after the first window + live fallback thresholds: covered by default_greedy
+            _assert_same_transcription(g, w, (shape, variant, c, modes[c]), strict)
+    finally:
+        node.close()
+
+
+def test_lockstep_chunks_with_audio_ctx_and_device_pcm(product_lib):
+    model = synth.make_model("micro.en", seed=5)
+    pcms = [synth.make_pcm(6.0, seed=40 + i) for i in range(3)]
+    node = host.SpeechToText(product_lib); node.set_language_model(model)
+    try:
+        want = [node.transcribe(b, "", 428) for b in pcms]
+        hip = _hip(); dev = []
+        for b in pcms:
+            dptr = C.c_void_p()
+            assert hip.hipMalloc(C.byref(dptr), C.c_size_t(b.nbytes)) == 0
+            assert hip.hipMemcpy(dptr, b.ctypes.data_as(C.c_void_p), C.c_size_t(b.nbytes), 1) == 0
+            dev.append(dptr)
+        got = node.transcribe_batch([b.size for b in pcms], "", 428, device_ptrs=[d.value for d in dev])
+        for d in dev:
+            hip.hipFree(d)
+        assert node.last_ret == 0
+        for c, (g, w) in enumerate(zip(got, want)):
+            if node.last_modes[c] == 0:
+                _assert_same_transcription(g, w, c, True)
+    finally:
+        node.close()
+
+
+def test_lockstep_base_en_eight_chunks(product_lib):
+    """BASELINE config 4's per-GPU share: 8 chunks of 30 s on base.en, batch == one at a time."""
+    model = synth.make_model("base.en", seed=1234)
+    pcms = [synth.make_pcm(30.0, seed=1234 + i) for i in range(8)]
+    node = host.SpeechToText(product_lib); node.set_language_model(model)
+    try:
+        want = [node.transcribe(b, "", 0) for b in pcms]
+        got = node.transcribe_batch(pcms, "", 0)
+        assert node.last_ret == 0 and node.last_modes == [0] * 8
+        for c, (g, w) in enumerate(zip(got, want)):
+            _assert_same_transcription(g, w, c, True)
+    finally:
+        node.close()
