@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--shape", default=SHAPE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chunks", type=int, default=1,
+                    help="chunks per GPU per step: 1 = BASELINE configs[1] (headline); 8 = configs[3]'s per-GPU share, lock-step")
     args = ap.parse_args()
 
     import torch
@@ -73,7 +75,7 @@ def main():
     del buf
 
     # ---- inputs: a few distinct seeded chunks per rank, already in HBM
-    n_distinct = 4
+    n_distinct = 8
     pcm_host = [synth.make_pcm(CHUNK_S, seed=1234 + 1000 * rank + i) for i in range(n_distinct)]
     pcm_dev = [torch.from_numpy(p).to(dev) for p in pcm_host]
     torch.cuda.synchronize()
@@ -82,9 +84,17 @@ def main():
     node.ctx = ctx
     params = node.full_params("", 0)
 
+    def batch_args(i, nb):
+        ts = [pcm_dev[(i * nb + j) % n_distinct] for j in range(nb)]
+        return (C.c_void_p * nb)(*[t.data_ptr() for t in ts]), (C.c_int * nb)(*[t.numel() for t in ts])
+
     def step(i):
-        t = pcm_dev[i % n_distinct]
-        ret = lib.wmi_full_device_pcm(ctx, params, C.c_void_p(t.data_ptr()), t.numel(), None)
+        if args.chunks > 1:                      # lock-step chunks (include/wmi_device.h: wmi_full_batch)
+            ptrs, lens = batch_args(i, args.chunks)
+            ret = lib.wmi_full_batch(ctx, params, ptrs, lens, args.chunks, 1)
+        else:
+            t = pcm_dev[i % n_distinct]
+            ret = lib.wmi_full_device_pcm(ctx, params, C.c_void_p(t.data_ptr()), t.numel(), None)
         assert ret == 0, ret
 
     for i in range(args.warmup):
@@ -102,7 +112,34 @@ def main():
         dist.barrier()
     dt = time.perf_counter() - t0
     lib.wmi_get_timings(ctx, t6, n5)
+    if args.chunks > 1:
+        lib.wmi_batch_select(ctx, 0)
     n_tokens = sum(lib.whisper_full_n_tokens(ctx, s) for s in range(lib.whisper_full_n_segments(ctx)))
+
+    # ---- secondary figure in the same run (N = 1, headline configuration only): 8 chunks in lock-step
+    batch8 = None
+    if args.chunks == 1 and world == 1:
+        nb, reps = 8, max(3, args.steps // 8)
+        ptrs, lens = batch_args(0, nb)
+        for _ in range(2):
+            assert lib.wmi_full_batch(ctx, params, ptrs, lens, nb, 1) == 0
+        torch.cuda.synchronize()
+        tb0 = time.perf_counter()
+        acc = np.zeros(4); nsteps = 0
+        t4 = (C.c_int64 * 4)(); ns = C.c_int32()
+        for _ in range(reps):
+            assert lib.wmi_full_batch(ctx, params, ptrs, lens, nb, 1) == 0
+            lib.wmi_get_batch_timings(ctx, t4, C.byref(ns))
+            acc += np.array(list(t4), dtype=np.float64); nsteps += ns.value
+        torch.cuda.synchronize()
+        tb = (time.perf_counter() - tb0) / reps
+        modes = [lib.wmi_batch_chunk_mode(ctx, c) for c in range(nb)]
+        batch8 = {"workload": "8 x 30 s chunks per call in lock-step (BASELINE configs[3] per-GPU share), same params",
+                  "value": round(nb * CHUNK_S / tb, 1), "unit": "x realtime", "ms_per_call": round(tb * 1e3, 3),
+                  "mel_envelope_ms": round(acc[0] / reps / 1e3, 3), "encode_ms": round(acc[1] / reps / 1e3, 3),
+                  "decode_ms": round(acc[2] / reps / 1e3, 3), "decode_steps": nsteps // reps,
+                  "segments_timestamps_ms": round(acc[3] / reps / 1e3, 3), "chunks_run_alone": int(sum(modes)),
+                  "encoder_tflops": round(nb * ENC_GFLOP / (acc[1] / reps / 1e3), 1)}
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -110,7 +147,7 @@ def main():
     dt_max = float(tmax.item())
 
     if rank == 0:
-        audio_s = CHUNK_S * args.steps * world
+        audio_s = CHUNK_S * args.steps * world * args.chunks
         rtf = audio_s / dt_max
         enc_ms = (t6[1] / 1e3) / max(n5[0], 1)
         dec_calls = max(n5[1], 1)
@@ -121,9 +158,10 @@ def main():
             "ms_per_step": round(1e3 * dt_max / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "base.en, single 30 s chunk per step on 1x MI355X, greedy decode, host params "
-                                   "(max_tokens=16, single_segment, token_timestamps)",
-                       "chunks_per_gpu_per_step": 1, "tokens_per_chunk": int(n_tokens),
+            "config": {"workload": ("base.en, single 30 s chunk per step on 1x MI355X, greedy decode, host params "
+                                    "(max_tokens=16, single_segment, token_timestamps)") if args.chunks == 1 else
+                                   (f"base.en, {args.chunks} x 30 s chunks per GPU per step in lock-step, greedy decode, host params"),
+                       "chunks_per_gpu_per_step": args.chunks, "tokens_per_chunk": int(n_tokens),
                        "weights": "synthetic seed 1234 (f16 ggml, base.en shape)"},
             "encode_ms": round(enc_ms, 4),
             "decode_ms_per_token": round((t6[2] / 1e3) / dec_calls, 4),
@@ -131,6 +169,8 @@ def main():
             "sample_ms_per_step": round((t6[5] / 1e3) / args.steps, 4),
             "weight_bcast_ms": round(1e3 * t_bcast, 3),
         }
+        if batch8:
+            out["batch8"] = batch8
         # ---- roofline of the dominant kernel, measured live with HIP events on the context's stream.
         # Dominant by GPU time (profiles/*_kernel_stats.csv) is the decoder's weight-streaming k_gemv; its largest
         # instance — the vocabulary projection, 53.1 MB of f16 weights per launch — is the one reported: HBM bound.

@@ -345,6 +345,13 @@ int wmi_batch_select(struct whisper_context * ctx, int chunk) {
     return (int) ctx->state->result_all.size();
 }
 
+void wmi_get_batch_timings(struct whisper_context * ctx, int64_t * t4, int32_t * n_steps) {
+    t4[0] = t4[1] = t4[2] = t4[3] = 0; *n_steps = 0;
+    if (!ctx || !ctx->batch) return;
+    const BatchWork & b = *ctx->batch;
+    t4[0] = b.t_mel_us; t4[1] = b.t_encode_us; t4[2] = b.t_decode_us; t4[3] = b.t_emit_us; *n_steps = b.n_steps;
+}
+
 int wmi_batch_chunk_mode(struct whisper_context * ctx, int chunk) {
     if (!ctx || !ctx->batch || chunk < 0 || chunk >= (int) ctx->batch->redo.size()) return -1;
     return ctx->batch->redo[chunk];

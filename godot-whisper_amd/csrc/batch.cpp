@@ -61,7 +61,7 @@ bool ensure_batch(whisper_context & ctx, int B) {
     hipStream_t s = ctx.state->dev.stream;
     (void) hipStreamSynchronize(s);
     dfree(w.mel_t); dfree(w.conv1); dfree(w.x); dfree(w.xn); dfree(w.q); dfree(w.k); dfree(w.att); dfree(w.vt); dfree(w.h);
-    dfree(w.enc_out_h); dfree(w.kvc_k); dfree(w.kvc_v); dfree(w.self_k); dfree(w.self_v); dfree(w.dx); dfree(w.dq); dfree(w.dh);
+    dfree(w.enc_out_h); dfree(w.kvc_k); dfree(w.kvc_v); dfree(w.self_k); dfree(w.self_v); dfree(w.dx); dfree(w.dq); dfree(w.datt); dfree(w.dh);
     dfree(w.logits); dfree(w.xattn);
     if (w.step_dev) (void) hipFree(w.step_dev);
     if (w.sample_dev) (void) hipFree(w.sample_dev);
@@ -80,7 +80,7 @@ bool ensure_batch(whisper_context & ctx, int B) {
            && dalloc(w.att, nb * T * S) && dalloc(w.vt, nb * S * w.Tpad) && dalloc(w.h, nb * T * 4 * S) && dalloc(w.enc_out_h, nb * T * S)
            && dalloc(w.kvc_k, Lt * nb * T * S) && dalloc(w.kvc_v, Lt * nb * T * S)
            && dalloc(w.self_k, nb * Lt * n_ctx * S) && dalloc(w.self_v, nb * Lt * n_ctx * S)
-           && dalloc(w.dx, nb * S) && dalloc(w.dq, nb * S) && dalloc(w.dh, nb * 4 * S) && dalloc(w.logits, nb * hp.n_vocab)
+           && dalloc(w.dx, nb * S) && dalloc(w.dq, nb * S) && dalloc(w.datt, nb * S) && dalloc(w.dh, nb * 4 * S) && dalloc(w.logits, nb * hp.n_vocab)
            && dalloc(w.xattn, k::attn_cross_scratch_floats(B, (int) H, (int) T));
     ok = ok && HIP_OK(hipMalloc(&w.step_dev, nb * sizeof(k::DecStep))) && HIP_OK(hipMalloc(&w.sample_dev, nb * sizeof(k::SampleOut)))
             && HIP_OK(hipMalloc(&w.filter_scratch, k::filter_scratch_bytes(B)))
@@ -215,9 +215,11 @@ bool decode_rows_step(whisper_context & ctx, int nb) {
             g.row_off = &stp->kv_head;
             k::gemv(g, s);
         }
-        {   // self-attention (prologue) + out projection + residual
+        {   // self-attention, one workgroup per chunk row (same arithmetic as the single-row fused prologue), then
+            // out projection + residual
+            k::self_attn_rows(b.dq, nb, S, ck, cv, cache_stride, &stp->n_kv, step_stride, n_ctx, b.datt, s);
             k::GemvArgs g = base(S, S, l.w_o, l.b_o, k::EPI_F32_BIAS_RESID, b.dx, S);
-            g.sa_q = b.dq; g.sa_k = ck; g.sa_v = cv; g.sa_nkv = &stp->n_kv; g.sa_cap = n_ctx; g.resid = b.dx;
+            g.a16 = b.datt; g.resid = b.dx;
             k::gemv(g, s);
         }
         {   // LN2 + cross query
@@ -229,8 +231,9 @@ bool decode_rows_step(whisper_context & ctx, int nb) {
             const float * po = nullptr, * pl = nullptr; int ns = 0;
             k::attn_cross_split_partials(b.dq, nb, S, H, b.kvc_k + (size_t) il * cross_layer, b.kvc_v + (size_t) il * cross_layer, Tc,
                                          b.xattn, &po, &pl, &ns, s, (int64_t) Tc * S);
+            k::attn_cross_combine(po, pl, ns, nb, S, H, b.datt, s);
             k::GemvArgs g = base(S, S, l.w_co, l.b_co, k::EPI_F32_BIAS_RESID, b.dx, S);
-            g.comb_o = po; g.comb_l = pl; g.comb_ns = ns; g.resid = b.dx;
+            g.a16 = b.datt; g.resid = b.dx;
             k::gemv(g, s);
         }
         {
@@ -275,7 +278,7 @@ void free_batch(whisper_context & ctx) {
     if (!ctx.batch) return;
     BatchWork & w = *ctx.batch;
     dfree(w.mel_t); dfree(w.conv1); dfree(w.x); dfree(w.xn); dfree(w.q); dfree(w.k); dfree(w.att); dfree(w.vt); dfree(w.h);
-    dfree(w.enc_out_h); dfree(w.kvc_k); dfree(w.kvc_v); dfree(w.self_k); dfree(w.self_v); dfree(w.dx); dfree(w.dq); dfree(w.dh);
+    dfree(w.enc_out_h); dfree(w.kvc_k); dfree(w.kvc_v); dfree(w.self_k); dfree(w.self_v); dfree(w.dx); dfree(w.dq); dfree(w.datt); dfree(w.dh);
     dfree(w.logits); dfree(w.xattn);
     if (w.step_dev) (void) hipFree(w.step_dev);
     if (w.sample_dev) (void) hipFree(w.sample_dev);

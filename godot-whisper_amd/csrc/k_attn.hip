@@ -381,6 +381,10 @@ void attn_cross_split_partials(const __half * q, int n, int S, int H, const __ha
     *po = part_o; *pl = part_l; *pns = ns;
 }
 
+void attn_cross_combine(const float * part_o, const float * part_l, int ns, int n, int S, int H, __half * out, hipStream_t st) {
+    hipLaunchKernelGGL(k_xattn_combine, dim3(H, n), dim3(64), 0, st, part_o, part_l, ns, S, out);
+}
+
 size_t attn_cross_scratch_floats(int n, int H, int T) {
     const int ld_sc = (T + 63) & ~63;
     return (size_t) n * H * ((size_t) ld_sc + 2 * XS_MAX_SLICES + (size_t) XS_MAX_SLICES * 64);

@@ -48,6 +48,78 @@ __global__ void k_dec_embed_step(const DecStep * __restrict__ host_step, DecStep
 }
 
 
+// Single-token self-attention of one row over its KV cache, all heads, by one 256-thread workgroup.
+// Numerics as k_attn_dec: scores f16.f16 -> f32, exp through f16, probabilities rounded to f16 before P.V, P.V
+// accumulated in key order (SURVEY App. B rules 1, 4, 5).  sc: [H][cap] floats, qf: [K] floats (LDS); out: [K] f16
+// (LDS or global).  kpre: this thread's first K row if it was requested early (use_pre).
+__device__ __forceinline__ void self_attn_row(const __half * __restrict__ sq, const __half * __restrict__ sk,
+                                              const __half * __restrict__ sv, int n_kv, int K, int cap,
+                                              float * sc, float * qf, __half * out, const uint4 (&kpre)[8], bool use_pre) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = K / 64;
+    for (int c = tid; c < K; c += 256) qf[c] = __half2float(sq[c]);
+    __syncthreads();
+    for (int p = tid; p < H * n_kv; p += 256) {
+        const int j = p / H, h = p - j * H;
+        const uint4 * kp = (const uint4 *) (sk + (size_t) j * K + h * 64);
+        float dot = 0.0f;
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) {
+            const uint4 u = (p == tid && use_pre) ? kpre[c8] : kp[c8];
+            const __half2 * hh = (const __half2 *) &u;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float2 f = __half22float2(hh[e]);
+                dot = fmaf(f.x, qf[h * 64 + c8 * 8 + e * 2], dot);
+                dot = fmaf(f.y, qf[h * 64 + c8 * 8 + e * 2 + 1], dot);
+            }
+        }
+        sc[(size_t) h * cap + j] = dot;
+    }
+    __syncthreads();
+    for (int h = wave; h < H; h += 4) {                 // soft-max of one head per wavefront
+        float * row = sc + (size_t) h * cap;
+        float m = -INFINITY;
+        for (int j = lane; j < n_kv; j += 64) m = fmaxf(m, row[j]);
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float l = 0.0f;
+        for (int j = lane; j < n_kv; j += 64) { const float e = round_f16(expf(round_f16(row[j] - m))); row[j] = e; l += e; }
+        for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
+        const float inv = (float) (1.0 / (double) l);
+        for (int j = lane; j < n_kv; j += 64) row[j] = round_f16(row[j] * inv);
+    }
+    __syncthreads();
+    for (int c = tid; c < K; c += 256) {
+        const float * row = sc + (size_t) (c >> 6) * cap;
+        const __half * vp = sv + c;
+        float acc = 0.0f;
+        int j = 0;
+        for (; j + 8 <= n_kv; j += 8) {             // loads issued 8 at a time, accumulated in key order
+            __half vv[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) vv[t] = vp[(size_t) (j + t) * K];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc = fmaf(row[j + t], __half2float(vv[t]), acc);
+        }
+        for (; j < n_kv; ++j) acc = fmaf(row[j], __half2float(vp[(size_t) j * K]), acc);
+        out[c] = __float2half_rn(acc);
+    }
+}
+
+// lock-step chunks: one workgroup per row, each against its own chunk's cache; out [R][K] f16 (global)
+__global__ __launch_bounds__(256) void k_self_attn_rows(const __half * __restrict__ q, const __half * __restrict__ kc,
+                                                        const __half * __restrict__ vc, int64_t cache_row_stride,
+                                                        const int32_t * __restrict__ n_kv, int step_stride, int K, int cap,
+                                                        __half * __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float * sc = (float *) smem;                        // [H][cap]
+    float * qf = sc + (size_t) (K / 64) * cap;          // [K]
+    const int r = blockIdx.x;
+    uint4 kpre[8] = {};
+    self_attn_row(q + (size_t) r * K, kc + (int64_t) r * cache_row_stride, vc + (int64_t) r * cache_row_stride,
+                  n_kv[r * step_stride], K, cap, sc, qf, out + (size_t) r * K, kpre, false);
+}
+
 template <int R, int ROWS_IN_FLIGHT>
 __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -110,9 +182,8 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
         }
     } else if (a.sa_q) {                                    // fused single-token self-attention over the KV cache
         // Every workgroup recomputes the (tiny) attention of all heads: n_kv x H dot products of 64 — cheaper than
-        // a separate launch on the critical path of a decode step.  Numerics as k_attn_dec: scores f16.f16 -> f32,
-        // exp through f16, probabilities rounded to f16 before P.V (SURVEY App. B rules 1, 4, 5).
-        // R > 1 (lock-step chunks): one pass per row, each against its own chunk's cache.
+        // a separate launch on the critical path of a decode step at one row.  (Lock-step chunks use the separate
+        // k_self_attn_rows launch below: R rows recomputed by every workgroup would cost more than the launch.)
         const int H = K / 64;
         float * sc = (float *) (smem + (((size_t) R * K * sizeof(__half) + 15) & ~(size_t) 15));   // [H][sa_cap]
         float * qf = sc + (size_t) H * a.sa_cap;                                                   // [K]
@@ -127,56 +198,8 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
         }
 #pragma unroll 1
         for (int r = 0; r < R; ++r) {
-            const __half * sk = a.sa_k + (int64_t) r * a.cache_row_stride, * sv = a.sa_v + (int64_t) r * a.cache_row_stride;
-            const __half * sq = a.sa_q + (size_t) r * K;
-            const int n_kv = a.sa_nkv[r * a.step_stride];
-            for (int c = tid; c < K; c += 256) qf[c] = __half2float(sq[c]);
-            __syncthreads();
-            for (int p = tid; p < H * n_kv; p += 256) {
-                const int j = p / H, h = p - j * H;
-                const uint4 * kp = (const uint4 *) (sk + (size_t) j * K + h * 64);
-                float dot = 0.0f;
-#pragma unroll
-                for (int c8 = 0; c8 < 8; ++c8) {
-                    const uint4 u = (p == tid && r == 0) ? kpre[c8] : kp[c8];
-                    const __half2 * hh = (const __half2 *) &u;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float2 f = __half22float2(hh[e]);
-                        dot = fmaf(f.x, qf[h * 64 + c8 * 8 + e * 2], dot);
-                        dot = fmaf(f.y, qf[h * 64 + c8 * 8 + e * 2 + 1], dot);
-                    }
-                }
-                sc[(size_t) h * a.sa_cap + j] = dot;
-            }
-            __syncthreads();
-            for (int h = wave; h < H; h += 4) {                 // soft-max of one head per wavefront
-                float * row = sc + (size_t) h * a.sa_cap;
-                float m = -INFINITY;
-                for (int j = lane; j < n_kv; j += 64) m = fmaxf(m, row[j]);
-                for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-                float l = 0.0f;
-                for (int j = lane; j < n_kv; j += 64) { const float e = round_f16(expf(round_f16(row[j] - m))); row[j] = e; l += e; }
-                for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
-                const float inv = (float) (1.0 / (double) l);
-                for (int j = lane; j < n_kv; j += 64) row[j] = round_f16(row[j] * inv);
-            }
-            __syncthreads();
-            for (int c = tid; c < K; c += 256) {
-                const float * row = sc + (size_t) (c >> 6) * a.sa_cap;
-                const __half * vp = sv + c;
-                float acc = 0.0f;
-                int j = 0;
-                for (; j + 8 <= n_kv; j += 8) {             // loads issued 8 at a time, accumulated in key order
-                    __half vv[8];
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) vv[t] = vp[(size_t) (j + t) * K];
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) acc = fmaf(row[j + t], __half2float(vv[t]), acc);
-                }
-                for (; j < n_kv; ++j) acc = fmaf(row[j], __half2float(vp[(size_t) j * K]), acc);
-                act[(size_t) r * K + c] = __float2half_rn(acc);
-            }
+            self_attn_row(a.sa_q + (size_t) r * K, a.sa_k + (int64_t) r * a.cache_row_stride, a.sa_v + (int64_t) r * a.cache_row_stride,
+                          a.sa_nkv[r * a.step_stride], K, a.sa_cap, sc, qf, act + (size_t) r * K, kpre, r == 0);
             if (R > 1) __syncthreads();                         // sc / qf are reused by the next row
         }
     } else if (a.comb_o) {                                  // fused combine of the split cross-attention partials
@@ -330,6 +353,12 @@ void dec_embed(const int32_t * tokens, const int32_t * pos, int n, int S, const 
 void dec_embed_step(const DecStep * host_step, DecStep * dev_step, int S, const __half * te, const float * pe, float * x,
                     hipStream_t st, int n_rows) {
     hipLaunchKernelGGL(k_dec_embed_step, dim3(n_rows), dim3(256), 0, st, host_step, dev_step, S, te, pe, x);
+}
+
+void self_attn_rows(const __half * q, int n, int K, const __half * kc, const __half * vc, int64_t cache_row_stride,
+                    const int32_t * n_kv, int step_stride, int cap, __half * out, hipStream_t st) {
+    const size_t smem = ((size_t) (K / 64) * cap + K) * sizeof(float);
+    hipLaunchKernelGGL(k_self_attn_rows, dim3(n), dim3(256), smem, st, q, kc, vc, cache_row_stride, n_kv, step_stride, K, cap, out);
 }
 
 void gemv(const GemvArgs & a, hipStream_t st) {

@@ -100,6 +100,12 @@ struct GemvArgs {
     //   sa_k / sa_v + r * cache_row_stride
     int lanes; int step_stride; int64_t cache_row_stride;
 };
+// lock-step chunks: single-token self-attention of n rows, row r against the cache at kc/vc + r * cache_row_stride with
+// n_kv[r * step_stride] cells; same arithmetic as the fused prologue of gemv (GemvArgs::sa_*).  out [n][K] f16
+void self_attn_rows(const __half * q, int n, int K, const __half * kc, const __half * vc, int64_t cache_row_stride,
+                    const int32_t * n_kv, int step_stride, int cap, __half * out, hipStream_t st);
+// split cross-attention partials -> out [n][S] f16 (the separate form of GemvArgs::comb_*)
+void attn_cross_combine(const float * part_o, const float * part_l, int ns, int n, int S, int H, __half * out, hipStream_t st);
 enum { EPI_LOGITS = 100 };                    // C f32 [n][N] = acc
 void gemv(const GemvArgs & a, hipStream_t st);
 

@@ -218,7 +218,7 @@ struct BatchWork {
     __half * xn = nullptr, * q = nullptr, * k = nullptr, * att = nullptr, * vt = nullptr, * h = nullptr, * enc_out_h = nullptr;
     __half * kvc_k = nullptr, * kvc_v = nullptr;              // cross cache [L][B*T][S]
     __half * self_k = nullptr, * self_v = nullptr;            // self cache  [B][L][n_ctx][S]
-    float  * dx = nullptr; __half * dq = nullptr, * dh = nullptr; float * logits = nullptr, * xattn = nullptr;
+    float  * dx = nullptr; __half * dq = nullptr, * datt = nullptr, * dh = nullptr; float * logits = nullptr, * xattn = nullptr;
     void   * step_dev = nullptr, * step_host = nullptr, * sample_dev = nullptr, * sample_host = nullptr, * filter_scratch = nullptr;
     int      enc_rows = 0, enc_T = 0;                         // chunk rows / encoder length of the last batched encode
     std::vector<State *> lanes;                               // lanes[0] is the context's own state (not owned)

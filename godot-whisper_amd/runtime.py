@@ -22,6 +22,7 @@ DEVICE_API = [
     ("wmi_full_batch", C.c_int, [C.c_void_p, abi.whisper_full_params, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int]),
     ("wmi_batch_select", C.c_int, [C.c_void_p, C.c_int]),
     ("wmi_batch_chunk_mode", C.c_int, [C.c_void_p, C.c_int]),
+    ("wmi_get_batch_timings", None, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     ("wmi_set_audio_ctx", C.c_int, [C.c_void_p, C.c_int]),
     ("wmi_get_tensor", C.c_int, [C.c_void_p, C.c_char_p, C.POINTER(C.c_float), C.c_int]),
     ("wmi_mel_dims", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -62,6 +62,10 @@ WHISPER_API int wmi_batch_select(struct whisper_context * ctx, int chunk);
 /* 0: chunk `chunk` was decoded in lock-step; 1: it was run alone (fallback, see above); -1: bad index. */
 WHISPER_API int wmi_batch_chunk_mode(struct whisper_context * ctx, int chunk);
 
+/* Wall-clock buckets of the last wmi_full_batch call, microseconds: mel + envelope, encoder, decoder steps,
+ * segment emission + token timestamps; n_steps = lock-step decode steps.  (cf. whisper_timings, W/whisper.cpp:3672) */
+WHISPER_API void wmi_get_batch_timings(struct whisper_context * ctx, int64_t * t4, int32_t * n_steps);
+
 /* Encoder length override for the bare whisper_encode / whisper_decode calls, i.e. what whisper_full
  * does with params.audio_ctx (W/whisper.cpp:5098-5102); 0 = model default.  Returns -5 if too large. */
 WHISPER_API int wmi_set_audio_ctx(struct whisper_context * ctx, int n_audio_ctx);
