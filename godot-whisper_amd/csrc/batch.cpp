@@ -19,6 +19,7 @@
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 namespace wmi {
 
@@ -48,6 +49,8 @@ State * new_lane_state(whisper_context & ctx) {
 
 void free_lane_state(State * st) {
     DeviceState & d = st->dev;
+    if (d.copy_stream) { (void) hipStreamSynchronize(d.copy_stream); (void) hipStreamDestroy(d.copy_stream); }
+    if (d.energy_ev) (void) hipEventDestroy(d.energy_ev);
     dfree(d.pcm); dfree(d.mel); dfree(d.mel_max); dfree(d.energy);
     if (d.energy_host) (void) hipHostFree(d.energy_host);
     delete st;
@@ -331,6 +334,8 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
     if (!ensure_batch(ctx, std::min(n_chunks, MAX_LANES))) return -2;
     BatchWork & b = *ctx.batch;
     if (!upload_static_ban(ctx, params)) return -7;
+    // the envelope kernels read the caller's samples on side streams: never return while one is in flight
+    struct EnvelopeGuard { BatchWork & b; ~EnvelopeGuard() { for (State * l : b.lanes) (void) signal_energy_wait(*l); } } envelope_guard{b};
 
     const bool has_fallback = params.temperature_inc > 0.0f && params.temperature + params.temperature_inc < 1.0f + 1e-6f;
     std::vector<int32_t> prompt_user;
@@ -367,14 +372,25 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
             ls.exp_n_audio_ctx = params.audio_ctx;
             if (v.is_multilingual()) ls.lang_id = lang_id(params.language);
             const int64_t tm0 = time_us();
+            // kernels of all chunks are queued back to back; one synchronisation after the loop
             if (n_samples[row.chunk] > 0) {
-                if (!pcm_to_mel(ctx, pcm[row.chunk], n_samples[row.chunk], on_device)) { WMI_ERR("%s: failed to compute log mel spectrogram\n", __func__); return -2; }
+                if (!pcm_to_mel(ctx, pcm[row.chunk], n_samples[row.chunk], on_device, false)) { WMI_ERR("%s: failed to compute log mel spectrogram\n", __func__); return -2; }
             }
             if (params.token_timestamps) {
                 ls.t_beg = 0; ls.t_last = 0; ls.tid_last = 0;
-                if (n_samples[row.chunk] > 0 && !signal_energy_device(ctx, 32)) { WMI_ERR("%s: failed to compute the signal envelope\n", __func__); return -2; }
+                if (n_samples[row.chunk] > 0 && !signal_energy_device(ctx, 32, false)) { WMI_ERR("%s: failed to compute the signal envelope\n", __func__); return -2; }
             }
             b.t_mel_us += time_us() - tm0;
+        }
+        // one synchronisation for the mel kernels of all chunks (keeps the mel / encoder time buckets separate); the
+        // envelopes are written to the host by the chunks' side streams and are awaited at emission time
+        {
+            const int64_t tm0 = time_us();
+            if (!HIP_OK(hipStreamSynchronize(primary->dev.stream))) return -2;
+            b.t_mel_us += time_us() - tm0;
+        }
+        for (int r = 0; r < ng; ++r) {
+            Row & row = rows[r]; State & ls = *b.lanes[r];
             row.seek_start = params.offset_ms / 10;
             row.seek_end = params.duration_ms == 0 ? ls.mel.n_len_org : row.seek_start + params.duration_ms / 10;
             row.seek = row.seek_start;
@@ -478,7 +494,9 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
                 }
             }
 
-            // ---- rank / fallback decision / emission per row
+            // ---- rank / fallback decision per row, then segment emission (token timestamps: host CPU work, one
+            //      thread per chunk — every chunk owns its State)
+            std::vector<int> emit;
             for (int r = 0; r < nb; ++r) {
                 Row & row = rows[act[r]]; State & ls = *b.lanes[row.lane];
                 Decoder & d = ls.decoders[0];
@@ -488,10 +506,23 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
                     if (d.sequence.result_len > 32 && d.sequence.entropy < params.entropy_thold) { d.failed = true; primary->n_fail_h++; }
                 }
                 if (has_fallback && (d.failed || d.sequence.avg_logprobs < params.logprob_thold)) { row.redo = true; primary->n_fail_p++; continue; }
+                emit.push_back(act[r]);
+            }
+            {
                 const int64_t te0 = time_us();
-                StateSwap sw(ctx, &ls);
-                emit_window(ctx, params, row.seek, row.prompt, prompt_init.size(), d);
-                row.seek += d.seek_delta;
+                auto emit_row = [&](int ri) {
+                    Row & row = rows[ri]; State & ls = *b.lanes[row.lane];
+                    emit_window(ctx, ls, params, row.seek, row.prompt, prompt_init.size(), ls.decoders[0]);
+                    row.seek += ls.decoders[0].seek_delta;
+                };
+                if (params.token_timestamps && !params.print_realtime && emit.size() > 1) {
+                    std::vector<std::thread> pool;
+                    for (size_t e = 1; e < emit.size(); ++e) pool.emplace_back(emit_row, emit[e]);
+                    emit_row(emit[0]);
+                    for (auto & t : pool) t.join();
+                } else {
+                    for (int ri : emit) emit_row(ri);
+                }
                 b.t_emit_us += time_us() - te0;
             }
         }

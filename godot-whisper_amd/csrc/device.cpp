@@ -84,6 +84,8 @@ void free_state(whisper_context & ctx) {
     DeviceState & d = st->dev;
     if (d.stream) (void) hipStreamSynchronize(d.stream);
     dfree(st->kv_self.k); dfree(st->kv_self.v); dfree(d.kvc_k); dfree(d.kvc_v);
+    if (d.copy_stream) { (void) hipStreamSynchronize(d.copy_stream); (void) hipStreamDestroy(d.copy_stream); }
+    if (d.energy_ev) (void) hipEventDestroy(d.energy_ev);
     dfree(d.energy); if (d.energy_host) (void) hipHostFree(d.energy_host);
     dfree(d.pcm); dfree(d.mel); dfree(d.mel_max); dfree(d.mel_t); dfree(d.conv1); dfree(d.x); dfree(d.embd_conv);
     dfree(d.xn); dfree(d.q); dfree(d.k); dfree(d.vt); dfree(d.att); dfree(d.h); dfree(d.rowmax); dfree(d.enc_out);
@@ -109,7 +111,7 @@ static bool ensure_mel_capacity(DeviceState & d, size_t n_pad, size_t n_mel_elem
     return true;
 }
 
-bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, bool samples_on_device) {
+bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, bool samples_on_device, bool sync) {
     if (ctx.host_only) { WMI_ERR("%s: host-only context has no compute path (this backend has no CPU fallback)\n", __func__); return false; }
     State & st = *ctx.state; DeviceState & d = st.dev;
     const int64_t t0 = time_us();
@@ -129,28 +131,44 @@ bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, boo
     }
     d.last_pcm = src; d.last_pcm_n = n_samples;
     k::mel_pad(src, n_samples, d.pcm, (int) n_pad, d.stream);
-    k::mel_frames(d.pcm, n_valid, n_fft_frames, n_len, n_mel, ctx.w.mel_filters, d.mel, (int *) d.mel_max, d.stream);
+    k::mel_frames(d.pcm, n_valid, n_fft_frames, n_len, n_mel, ctx.w.mel_filters, ctx.w.mel_ranges, d.mel, (int *) d.mel_max, d.stream);
     k::mel_normalize(d.mel, n_mel * n_len, (const int *) d.mel_max, d.stream);
-    HIP_TRY(hipStreamSynchronize(d.stream));
+    if (sync) HIP_TRY(hipStreamSynchronize(d.stream));          // lock-step chunks: one sync for all chunks (batch.cpp)
     st.mel.n_len = n_len; st.mel.n_len_org = n_len_org; st.mel.n_mel = n_mel;
     st.t_mel_us += time_us() - t0;
     return true;
 }
 
-bool signal_energy_device(whisper_context & ctx, int hw) {
+bool signal_energy_device(whisper_context & ctx, int hw, bool sync) {
     State & st = *ctx.state; DeviceState & d = st.dev;
     const int n = d.last_pcm_n;
     if (!d.last_pcm || n <= 0) return false;
+    if (!d.copy_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&d.copy_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&d.energy_ev, hipEventDisableTiming));
+    }
+    if (d.energy_pending) { HIP_TRY(hipStreamSynchronize(d.copy_stream)); d.energy_pending = false; }   // previous envelope still being written
     if ((size_t) n > d.energy_cap) {
-        dfree(d.energy); if (d.energy_host) (void) hipHostFree(d.energy_host);
+        if (d.energy_host) (void) hipHostFree(d.energy_host);
         d.energy_host = nullptr; d.energy_cap = 0;
-        if (!dalloc(d.energy, (size_t) n) || !HIP_OK(hipHostMalloc((void **) &d.energy_host, (size_t) n * 4, hipHostMallocDefault))) return false;
+        if (!HIP_OK(hipHostMalloc((void **) &d.energy_host, (size_t) n * 4, hipHostMallocDefault))) return false;
         d.energy_cap = (size_t) n;
     }
-    k::signal_energy(d.last_pcm, n, hw, d.energy, d.stream);
-    HIP_TRY(hipMemcpyAsync(d.energy_host, d.energy, (size_t) n * 4, hipMemcpyDeviceToHost, d.stream));
-    HIP_TRY(hipStreamSynchronize(d.stream));
-    st.energy.assign(d.energy_host, d.energy_host + n);
+    // The kernel runs on the side stream, behind the staging of the samples, and stores straight into pinned host
+    // memory: no memcpy call, and the 1.9 MB of PCIe writes overlap the encoder on the main stream.
+    HIP_TRY(hipEventRecord(d.energy_ev, d.stream));
+    HIP_TRY(hipStreamWaitEvent(d.copy_stream, d.energy_ev, 0));
+    k::signal_energy(d.last_pcm, n, hw, d.energy_host, d.copy_stream);
+    d.energy_pending = true;
+    return sync ? signal_energy_wait(st) : true;
+}
+
+bool signal_energy_wait(State & st) {
+    DeviceState & d = st.dev;
+    if (!d.energy_pending) return true;
+    HIP_TRY(hipStreamSynchronize(d.copy_stream));
+    st.energy.assign(d.energy_host, d.energy_host + d.last_pcm_n);
+    d.energy_pending = false;
     return true;
 }
 

@@ -23,9 +23,8 @@ struct BeamCandidate { int decoder_idx; int seek_delta; bool has_ts; Sequence se
 
 const char * tok_str(whisper_context & ctx, int32_t id) { return ctx.model.vocab.id_to_token.at(id).c_str(); }
 
-void emit_segment(whisper_context & ctx, const whisper_full_params & params, int64_t t0, int64_t t1, const std::string & text,
+void emit_segment(whisper_context & ctx, State & st, const whisper_full_params & params, int64_t t0, int64_t t1, const std::string & text,
                   const std::vector<whisper_token_data> & toks, int i0, int i1_excl, bool speaker_turn_next) {
-    State & st = *ctx.state;
     const int64_t tt0 = params.speed_up ? 2 * t0 : t0, tt1 = params.speed_up ? 2 * t1 : t1;
     if (params.print_realtime) {
         if (params.print_timestamps) printf("[%lld --> %lld]  %s\n", (long long) tt0, (long long) tt1, text.c_str());
@@ -36,11 +35,12 @@ void emit_segment(whisper_context & ctx, const whisper_full_params & params, int
     st.result_all.push_back(std::move(seg));
     int n_new = 1;
     if (params.token_timestamps) {
-        token_level_timestamps(ctx, (int) st.result_all.size() - 1, params.thold_pt, params.thold_ptsum);
-        if (params.max_len > 0) n_new = wrap_segment(ctx, params.max_len, params.split_on_word);
+        (void) signal_energy_wait(st);             // the envelope's D2H copy ran behind the encoder / decoder
+        token_level_timestamps(ctx, st, (int) st.result_all.size() - 1, params.thold_pt, params.thold_ptsum);
+        if (params.max_len > 0) n_new = wrap_segment(ctx, st, params.max_len, params.split_on_word);
     }
     if (params.new_segment_callback)
-        params.new_segment_callback(&ctx, (whisper_state *) ctx.state, n_new, params.new_segment_callback_user_data);
+        params.new_segment_callback(&ctx, (whisper_state *) &st, n_new, params.new_segment_callback_user_data);
 }
 
 } // namespace
@@ -57,6 +57,8 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
     const Vocab & v = ctx.model.vocab;
     const HParams & hp = ctx.model.hp;
     st.result_all.clear();
+    // the envelope kernel reads the caller's samples on a side stream: never return while it is in flight
+    struct EnvelopeGuard { State & st; ~EnvelopeGuard() { (void) signal_energy_wait(st); } } envelope_guard{st};
 
     if (n_samples > 0) {
         if (params.speed_up) { WMI_ERR("%s: failed to compute log mel spectrogram\n", __func__); return -1; }
@@ -81,7 +83,7 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
         // CPU loop, k_signal_energy); the host loop remains only as the definition it is tested against
         const int64_t te0 = time_us();
         struct En { int64_t & acc; int64_t t0; ~En() { acc += time_us() - t0; } } en_timer{T_energy, te0};
-        if (n_samples > 0 && !signal_energy_device(ctx, 32)) { WMI_ERR("%s: failed to compute the signal envelope\n", __func__); return -2; }
+        if (n_samples > 0 && !signal_energy_device(ctx, 32, false)) { WMI_ERR("%s: failed to compute the signal envelope\n", __func__); return -2; }
     }
 
     const int seek_start = params.offset_ms / 10;
@@ -384,16 +386,15 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
             const int64_t tem0 = time_us();
             struct Em { int64_t & acc; int64_t t0; ~Em() { acc += time_us() - t0; } } em_timer{T_emit, tem0};
             const Decoder & best = st.decoders[best_decoder_id];
-            emit_window(ctx, params, seek, prompt, prompt_init.size(), best);
+            emit_window(ctx, st, params, seek, prompt, prompt_init.size(), best);
             seek += best.seek_delta;
         }
     }
     return 0;
 }
 
-void emit_window(whisper_context & ctx, const whisper_full_params & params, int seek, const std::vector<int32_t> & prompt,
+void emit_window(whisper_context & ctx, State & st, const whisper_full_params & params, int seek, const std::vector<int32_t> & prompt,
                  size_t n_prompt_init, const Decoder & best) {
-    State & st = *ctx.state;
     const Vocab & v = ctx.model.vocab;
     auto & prompt_past = st.prompt_past;
     const int seek_delta = best.seek_delta, result_len = best.sequence.result_len;
@@ -413,14 +414,14 @@ void emit_window(whisper_context & ctx, const whisper_full_params & params, int 
             if (params.tdrz_enable && toks[i].id == v.solm) speaker_turn_next = true;
             if (toks[i].id > v.beg && !params.single_segment) {
                 const int64_t t1 = seek + 2 * (toks[i].tid - v.beg);
-                if (!text.empty()) emit_segment(ctx, params, t0, t1, text, toks, i0, i + 1, speaker_turn_next);
+                if (!text.empty()) emit_segment(ctx, st, params, t0, t1, text, toks, i0, i + 1, speaker_turn_next);
                 text.clear();
                 while (i < (int) toks.size() && toks[i].id > v.beg) ++i;
                 --i;
                 t0 = t1; i0 = i + 1; speaker_turn_next = false;
             }
         }
-        if (!text.empty()) emit_segment(ctx, params, t0, seek + seek_delta, text, toks, i0, (int) toks.size(), speaker_turn_next);
+        if (!text.empty()) emit_segment(ctx, st, params, t0, seek + seek_delta, text, toks, i0, (int) toks.size(), speaker_turn_next);
     }
 }
 
@@ -454,8 +455,7 @@ std::vector<float> signal_energy(const float * signal, int n_samples, int hw) {
     return out;
 }
 
-void token_level_timestamps(whisper_context & ctx, int i_segment, float thold_pt, float thold_ptsum) {
-    State & st = *ctx.state;
+void token_level_timestamps(whisper_context & ctx, State & st, int i_segment, float thold_pt, float thold_ptsum) {
     const Vocab & v = ctx.model.vocab;
     Segment & seg = st.result_all[i_segment];
     auto & tokens = seg.tokens;
@@ -598,8 +598,7 @@ void token_level_timestamps(whisper_context & ctx, int i_segment, float thold_pt
     }
 }
 
-int wrap_segment(whisper_context & ctx, int max_len, bool split_on_word) {          // W/whisper.cpp:4430-4484
-    State & st = *ctx.state;
+int wrap_segment(whisper_context & ctx, State & st, int max_len, bool split_on_word) {          // W/whisper.cpp:4430-4484
     const Vocab & v = ctx.model.vocab;
     Segment seg = st.result_all.back();
     int res = 1, acc = 0;

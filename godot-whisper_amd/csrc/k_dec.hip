@@ -14,6 +14,8 @@
 
 #include "kernels.h"
 
+#include <cstdlib>
+
 namespace wmi { namespace k {
 
 namespace {
@@ -322,6 +324,163 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Lock-step chunk rows (2..16 activation rows, one per chunk) on the matrix cores.  With R rows the VALU
+// kernel above spends R x the multiply-adds plus a 64-lane butterfly per (weight row, activation row) pair and
+// stops being a pure weight stream (profiles/: 42 us for the vocabulary projection at R = 8 against 15 us at
+// R = 1).  Here a wavefront owns a tile of 16 weight rows: A = W[16][32] straight from HBM (16 B per lane, the
+// rows are still read front to back exactly once), B = the activation rows from LDS as the 16 MFMA columns
+// (columns >= n are zero), C[feature][chunk] accumulates in the MFMA f32 registers — no cross-lane reduction.
+//   KSPLIT = false: every wavefront streams whole tiles (grid-stride over tiles) — the vocabulary projection;
+//   KSPLIT = true : one tile per workgroup, the four wavefronts take a quarter of K each and are summed through
+//                   LDS in a fixed order — the N = S .. 4S projections, where tiles are few and latency matters.
+// Same prologues (fused LayerNorm / plain f16 rows) and epilogues as k_gemv.
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float    floatx4 __attribute__((ext_vector_type(4)));
+
+template <bool KSPLIT>
+__global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.K, n = a.n;
+    const int lda = K + 8;                                  // LDS row stride in halves: +16 B skews the banks
+    __half * act = (__half *) smem;                         // [n][lda]
+    const int col = lane & 15, kq = lane >> 4;
+    const int ntiles = (a.N + 15) >> 4;
+    constexpr int MAXF = 16;                                // A fragments (32 k each) held in registers per pass
+
+    const int kbeg = KSPLIT ? wave * (K >> 2) : 0;
+    const int kend = KSPLIT ? kbeg + (K >> 2) : K;
+    int tile = KSPLIT ? (int) blockIdx.x : (int) (blockIdx.x * 4 + wave);
+    const int tstride = KSPLIT ? (int) gridDim.x : (int) (gridDim.x * 4);
+
+    // ---- weight prefetch of the first pass (independent of the activations)
+    uint4 wf[MAXF];
+    const int nf0 = min(MAXF, (kend - kbeg) >> 5);
+    if (tile < ntiles) {
+        int row = tile * 16 + col; if (row > a.N - 1) row = a.N - 1;
+        const __half * wp = a.W + (size_t) row * K + kbeg + kq * 8;
+#pragma unroll
+        for (int f = 0; f < MAXF; ++f) if (f < nf0) wf[f] = *(const uint4 *) (wp + f * 32);
+    }
+    int ro_pre = 0;
+    if (a.row_off && col < n) ro_pre = a.lanes ? a.row_off[col * a.step_stride] : *a.row_off;
+
+    // ---- prologue: activation rows as f16 in LDS
+    if (a.ln_g) {
+        constexpr int XV = 20;
+        for (int r = wave; r < n; r += 4) {
+            const int src = a.rows ? a.rows[r] : r;
+            const float * xr = a.x32 + (size_t) src * K;
+            float xv[XV], gv[XV], bv[XV]; float sum = 0.0f;
+#pragma unroll
+            for (int j = 0; j < XV; ++j) {
+                const int c = lane + 64 * j;
+                xv[j] = c < K ? xr[c] : 0.0f; gv[j] = c < K ? a.ln_g[c] : 0.0f; bv[j] = c < K ? a.ln_b[c] : 0.0f;
+            }
+#pragma unroll
+            for (int j = 0; j < XV; ++j) sum += xv[j];
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            const float mean = sum / (float) K;
+            float sq = 0.0f;
+#pragma unroll
+            for (int j = 0; j < XV; ++j) { const int c = lane + 64 * j; if (c < K) { xv[j] -= mean; sq += xv[j] * xv[j]; } }
+            for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+            const float sc = 1.0f / sqrtf(sq / (float) K + a.eps);
+#pragma unroll
+            for (int j = 0; j < XV; ++j) {
+                const int c = lane + 64 * j;
+                if (c < K) act[r * lda + c] = __float2half_rn(__fadd_rn(__fmul_rn(xv[j] * sc, gv[j]), bv[j]));
+            }
+        }
+    } else {
+        for (int r = 0; r < n; ++r) {
+            const int src = a.rows ? a.rows[r] : r;
+            const uint4 * s4 = (const uint4 *) (a.a16 + (size_t) src * K);
+            uint4 * d4 = (uint4 *) (act + r * lda);
+            for (int c = tid; c < K / 8; c += 256) d4[c] = s4[c];
+        }
+    }
+    __syncthreads();
+
+    float * red = (float *) (smem + (((size_t) n * lda * sizeof(__half) + 15) & ~(size_t) 15));   // KSPLIT: [4][64][4]
+    bool first = true;
+    for (; tile < ntiles; tile += tstride) {
+        floatx4 acc = {0.0f, 0.0f, 0.0f, 0.0f};
+        int row = tile * 16 + col; if (row > a.N - 1) row = a.N - 1;
+        const __half * wrow = a.W + (size_t) row * K + kq * 8;
+        for (int k0 = kbeg; k0 < kend; k0 += MAXF * 32) {
+            const int nf = min(MAXF, (kend - k0) >> 5);
+            if (!(first && k0 == kbeg)) {
+#pragma unroll
+                for (int f = 0; f < MAXF; ++f) if (f < nf) wf[f] = *(const uint4 *) (wrow + k0 + f * 32);
+            }
+#pragma unroll
+            for (int f = 0; f < MAXF; ++f) {
+                if (f < nf) {
+                    uint4 bu = make_uint4(0u, 0u, 0u, 0u);
+                    if (col < n) bu = *(const uint4 *) (act + col * lda + k0 + f * 32 + kq * 8);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const half8 *) &wf[f], *(const half8 *) &bu, acc, 0, 0, 0);
+                }
+            }
+        }
+        first = false;
+        if (KSPLIT) {
+            if (tile != (int) blockIdx.x) __syncthreads();          // red reused across tiles (grid-stride)
+            *(floatx4 *) (red + ((size_t) wave * 64 + lane) * 4) = acc;
+            __syncthreads();
+            if (wave != 0) continue;
+            const floatx4 p1 = *(const floatx4 *) (red + ((size_t) 64 + lane) * 4);
+            const floatx4 p2 = *(const floatx4 *) (red + ((size_t) 128 + lane) * 4);
+            const floatx4 p3 = *(const floatx4 *) (red + ((size_t) 192 + lane) * 4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] = (acc[r] + p1[r]) + (p2[r] + p3[r]);
+        }
+        if (col >= n) continue;
+        // epilogue: this lane holds C[feature = tile*16 + kq*4 + r][chunk row = col]
+        const int seg = __builtin_amdgcn_readfirstlane((tile * 16) / (a.S > 0 ? a.S : 1));   // wave-uniform (16 | S), see DESIGN.md §7
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int nf_ = tile * 16 + kq * 4 + r;
+            if (nf_ >= a.N) continue;
+            const float v = acc[r];
+            const float bias = a.bias ? a.bias[nf_] : 0.0f;
+            switch (a.epi) {
+                case EPI_F16_BIAS:       ((__half *) a.C)[(size_t) col * a.ldc + nf_] = __float2half_rn(v + bias); break;
+                case EPI_F16_BIAS_GELU:  ((__half *) a.C)[(size_t) col * a.ldc + nf_] = __float2half_rn(gelu16(v + bias)); break;
+                case EPI_F32_BIAS_RESID: ((float *) a.C)[(size_t) col * a.ldc + nf_] = (v + bias) + a.resid[(size_t) col * a.ldr + nf_]; break;
+                case EPI_Q_SCALED:       ((__half *) a.C)[(size_t) col * a.ldc + nf_] = __float2half_rn((v + bias) * a.scale); break;
+                case EPI_QKV_DEC: {
+                    const int c = nf_ - seg * a.S;
+                    const int64_t crow = a.lanes ? (int64_t) col * a.cache_row_stride : 0;
+                    const int slot = a.lanes ? ro_pre : col + ro_pre;
+                    __half * dst; float val;
+                    if (seg == 0)      { dst = (__half *) a.C    + (size_t) col * a.ldc;              val = (v + bias) * a.scale; }
+                    else if (seg == 1) { dst = (__half *) a.aux  + crow + (size_t) slot * a.ldaux;    val = v * a.scale; }
+                    else               { dst = (__half *) a.aux2 + crow + (size_t) slot * a.ldaux2;   val = v + bias; }
+                    dst[c] = __float2half_rn(val);
+                } break;
+                case EPI_LOGITS:         ((float *) a.C)[(size_t) col * a.ldc + nf_] = v; break;
+                default: break;
+            }
+        }
+    }
+}
+
+template <bool KSPLIT>
+void launch_rows_mfma(const GemvArgs & a, hipStream_t st) {
+    size_t smem = (((size_t) a.n * (a.K + 8) * sizeof(__half) + 15) & ~(size_t) 15) + (KSPLIT ? 4 * 64 * 4 * sizeof(float) : 0);
+    const int ntiles = (a.N + 15) / 16;
+    int blocks = KSPLIT ? ntiles : (ntiles + 3) / 4;
+    if (blocks > 1024) blocks = 1024;
+    static size_t attr_bytes = 0;
+    if (smem > 48 * 1024 && smem > attr_bytes) {
+        (void) hipFuncSetAttribute((const void *) k_rows_mfma<KSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+        attr_bytes = smem;
+    }
+    hipLaunchKernelGGL((k_rows_mfma<KSPLIT>), dim3(blocks), dim3(256), smem, st, a);
+}
+
 template <int R, int RIF>
 void launch_gemv_t(const GemvArgs & a, hipStream_t st) {
     size_t smem = (size_t) R * a.K * sizeof(__half);
@@ -361,7 +520,20 @@ void self_attn_rows(const __half * q, int n, int K, const __half * kc, const __h
     hipLaunchKernelGGL(k_self_attn_rows, dim3(n), dim3(256), smem, st, q, kc, vc, cache_row_stride, n_kv, step_stride, K, cap, out);
 }
 
+static bool g_rows_valu = false;
+void set_rows_valu(bool on) { g_rows_valu = on; }
+
 void gemv(const GemvArgs & a, hipStream_t st) {
+    // lock-step chunk rows go to the matrix cores (WMI_ROWS_VALU=1 keeps them on the VALU kernel, whose per-row
+    // arithmetic is bit-identical to the single-row path: used by the parity tests to pin the control flow)
+    static const bool rows_valu_env = getenv("WMI_ROWS_VALU") != nullptr;
+    const bool rows_valu = rows_valu_env || g_rows_valu;
+    const bool mfma_ok = a.lanes && a.n >= 2 && a.n <= 16 && !a.sa_q && !a.comb_o && (a.K % 128) == 0 &&
+                         (a.epi != EPI_QKV_DEC || (a.S % 16) == 0) && (!rows_valu || a.n > 8);
+    if (mfma_ok) {
+        if (a.N >= 8192) launch_rows_mfma<false>(a, st); else launch_rows_mfma<true>(a, st);
+        return;
+    }
     switch (a.n) {
         case 1: launch_gemv<1>(a, st); break;
         case 2: launch_gemv<2>(a, st); break;

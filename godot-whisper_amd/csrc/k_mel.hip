@@ -52,7 +52,7 @@ __global__ void k_mel_pad(const float * __restrict__ pcm, int n, float * __restr
 // butterfly stage: for g groups, combine E = src[(g)*half ...], O = src[(g + ngroups)*half ...]
 // into dst[g*N + k], dst[g*N + k + half].  Arrays are stored as [leaf][k] complex (re, im interleaved).
 __device__ inline void butterfly_stage(const float * src, float * dst, int ngroups, int N, int tid, int nthreads,
-                                       bool last, int limit_k) {
+                                       bool last, const float * t_cos, const float * t_sin) {
     const int half = N / 2;
     const int step = 400 / N;
     const int total = ngroups * half;
@@ -61,8 +61,8 @@ __device__ inline void butterfly_stage(const float * src, float * dst, int ngrou
         const float * E = src + 2 * (g * half);
         const float * O = src + 2 * ((g + ngroups) * half);
         const int   idx = kk * step;
-        const float re =  c_mel.cosv[idx];
-        const float im = -c_mel.sinv[idx];
+        const float re =  t_cos[idx];
+        const float im = -t_sin[idx];
         const float er = E[2 * kk], ei = E[2 * kk + 1], orr = O[2 * kk], oi = O[2 * kk + 1];
         float * D = dst + 2 * (g * N);
         D[2 * kk]     = fmaf(-im, oi, fmaf(re, orr, er));
@@ -72,28 +72,38 @@ __device__ inline void butterfly_stage(const float * src, float * dst, int ngrou
             D[2 * (kk + half) + 1] = fmaf(-im, orr, fmaf(-re, oi, ei));
         }
     }
-    (void) limit_k;
+}
+
+// frames past the audio: log10(1e-10)  (W/whisper.cpp:2784-2789) — one thread per element, no FFT workgroups
+__global__ void k_mel_tail(float * __restrict__ mel, int n_len, int n_mel, int n_fft_frames, int * __restrict__ gmax) {
+    const int w = n_len - n_fft_frames;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < w * n_mel) { const int j = i / w, f = n_fft_frames + (i - j * w); mel[(size_t) j * n_len + f] = -10.0f; }
+    if (i == 0 && w > 0) atomicMax(gmax, enc_ordered(-10.0f));
 }
 
 __global__ __launch_bounds__(128) void k_mel_frames(const float * __restrict__ pad, int n_valid, int n_fft_frames,
                                                     int n_len, int n_mel, const float * __restrict__ filters,
+                                                    const int32_t * __restrict__ ranges,
                                                     float * __restrict__ mel, int * __restrict__ gmax) {
     __shared__ float xin[400];
     __shared__ float bufA[800];
     __shared__ float bufB[800];
     __shared__ float pw[204];
+    __shared__ float t_cos[400], t_sin[400];       // twiddles in LDS: per-lane indices make constant-memory reads vector loads
     const int frame = blockIdx.x;
     const int tid = threadIdx.x;
-
-    if (frame >= n_fft_frames) {         // frames past the audio: log10(1e-10)  (W/whisper.cpp:2784-2789)
-        for (int j = tid; j < n_mel; j += 128) mel[(size_t) j * n_len + frame] = -10.0f;
-        if (tid == 0) atomicMax(gmax, enc_ordered(-10.0f));
-        return;
-    }
+    if (frame >= n_fft_frames) return;
 
     const int offset = frame * 160;
     int nin = n_valid - offset; if (nin > 400) nin = 400;
-    for (int j = tid; j < 400; j += 128) xin[j] = j < nin ? c_mel.hann[j] * pad[offset + j] : 0.0f;
+    for (int j = tid; j < 400; j += 128) {
+        xin[j] = j < nin ? c_mel.hann[j] * pad[offset + j] : 0.0f;
+        t_cos[j] = c_mel.cosv[j]; t_sin[j] = c_mel.sinv[j];
+    }
+    // filter rows of this thread's mel bin(s): independent of the transform, requested up front
+    int fr0 = 0, fr1 = 0;
+    if (tid < n_mel) { fr0 = ranges[2 * tid]; fr1 = ranges[2 * tid + 1]; }
     __syncthreads();
 
     // 16 leaf DFTs of 25 points: leaf r holds x[r + 16 m]  (W/whisper.cpp:2634-2654)
@@ -101,21 +111,24 @@ __global__ __launch_bounds__(128) void k_mel_frames(const float * __restrict__ p
     for (int t = tid; t < 400; t += 128) {
         const int r = t / 25, kk = t % 25;
         float re = 0.0f, im = 0.0f;
+        int idx = 0;                                 // (kk * m * 16) % 400, advanced incrementally
+        const int inc = kk * 16;                     // < 400
+#pragma unroll 5
         for (int m = 0; m < 25; ++m) {
-            const int idx = (kk * m * 16) % 400;
             const float v = xin[r + 16 * m];
-            re = fmaf(v, c_mel.cosv[idx], re);
-            im = fmaf(-v, c_mel.sinv[idx], im);
+            re = fmaf(v, t_cos[idx], re);
+            im = fmaf(-v, t_sin[idx], im);
+            idx += inc; if (idx >= 400) idx -= 400;
         }
         bufA[2 * (r * 25 + kk)]     = re;
         bufA[2 * (r * 25 + kk) + 1] = im;
     }
     __syncthreads();
     // N=50: pairs (r, r+8) -> 8 arrays of 50 indexed by r<8 ; N=100: (r, r+4) ; N=200: (r, r+2) ; N=400: (0,1)
-    butterfly_stage(bufA, bufB, 8, 50, tid, 128, false, 0);   __syncthreads();
-    butterfly_stage(bufB, bufA, 4, 100, tid, 128, false, 0);  __syncthreads();
-    butterfly_stage(bufA, bufB, 2, 200, tid, 128, false, 0);  __syncthreads();
-    butterfly_stage(bufB, bufA, 1, 400, tid, 128, true, 0);   __syncthreads();
+    butterfly_stage(bufA, bufB, 8, 50, tid, 128, false, t_cos, t_sin);   __syncthreads();
+    butterfly_stage(bufB, bufA, 4, 100, tid, 128, false, t_cos, t_sin);  __syncthreads();
+    butterfly_stage(bufA, bufB, 2, 200, tid, 128, false, t_cos, t_sin);  __syncthreads();
+    butterfly_stage(bufB, bufA, 1, 400, tid, 128, true, t_cos, t_sin);   __syncthreads();
 
     for (int j = tid; j < 201; j += 128) {
         const float re = bufA[2 * j], im = bufA[2 * j + 1];
@@ -125,17 +138,20 @@ __global__ __launch_bounds__(128) void k_mel_frames(const float * __restrict__ p
 
     float vmax = -INFINITY;
     for (int j = tid; j < n_mel; j += 128) {
+        if (j != tid) { fr0 = ranges[2 * j]; fr1 = ranges[2 * j + 1]; }
         const float * f = filters + (size_t) j * 201;
         double sum = 0.0;
-        int kk = 0;
-        for (; kk < 201 - 3; kk += 4) {                          // W/whisper.cpp:2759-2768
+        // W/whisper.cpp:2759-2768 sums 50 groups of 4 taps + the last tap; groups outside [fr0, fr1) are all-zero
+        // weights and contribute exactly +0.0 (model.cpp: mel_ranges), so they are skipped
+        for (int g4 = fr0; g4 < fr1; ++g4) {
+            const int kk = 4 * g4;
             float g = pw[kk] * f[kk];
             g = fmaf(pw[kk + 1], f[kk + 1], g);
             g = fmaf(pw[kk + 2], f[kk + 2], g);
             g = fmaf(pw[kk + 3], f[kk + 3], g);
             sum += (double) g;
         }
-        for (; kk < 201; ++kk) sum += (double) (pw[kk] * f[kk]);
+        sum += (double) (pw[200] * f[200]);
         sum = log10(sum > 1e-10 ? sum : 1e-10);
         const float v = (float) sum;
         mel[(size_t) j * n_len + frame] = v;
@@ -203,11 +219,14 @@ void mel_pad(const float * pcm, int n_samples, float * pcm_pad, int n_pad_total,
 }
 
 void mel_frames(const float * pcm_pad, int n_valid, int n_fft_frames, int n_len, int n_mel, const float * filters,
-                float * mel, int * gmax, hipStream_t st) {
+                const int32_t * ranges, float * mel, int * gmax, hipStream_t st) {
     std::call_once(g_tables_once, upload_tables);
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, gmax, INT_MIN);
-    hipLaunchKernelGGL(k_mel_frames, dim3(n_len), dim3(128), 0, st, pcm_pad, n_valid, n_fft_frames, n_len, n_mel,
-                       filters, mel, gmax);
+    if (n_fft_frames > 0)
+        hipLaunchKernelGGL(k_mel_frames, dim3(n_fft_frames), dim3(128), 0, st, pcm_pad, n_valid, n_fft_frames, n_len, n_mel,
+                           filters, ranges, mel, gmax);
+    const int tail = (n_len - n_fft_frames) * n_mel;
+    if (tail > 0) hipLaunchKernelGGL(k_mel_tail, dim3((tail + 255) / 256), dim3(256), 0, st, mel, n_len, n_mel, n_fft_frames, gmax);
 }
 
 void mel_normalize(float * mel, int n, const int * gmax, hipStream_t st) {

@@ -13,7 +13,7 @@ namespace wmi { namespace k {
 // n_len the constant log10(1e-10).  mel: [n_mel][n_len] f32.  gmax: ordered-int encoded running max.
 void mel_pad(const float * pcm, int n_samples, float * pcm_pad, int n_pad_total, hipStream_t st);
 void mel_frames(const float * pcm_pad, int n_valid, int n_fft_frames, int n_len, int n_mel,
-                const float * filters, float * mel, int * gmax, hipStream_t st);
+                const float * filters, const int32_t * ranges, float * mel, int * gmax, hipStream_t st);
 void mel_normalize(float * mel, int n, const int * gmax, hipStream_t st);
 // token-major f16 slice for the conv front-end: out[r][c], r in [0, rows_total), row r holds frame
 // (offset + r - 1); rows outside [1, n_frames] and frames >= n_len are zero.
@@ -108,6 +108,7 @@ void self_attn_rows(const __half * q, int n, int K, const __half * kc, const __h
 void attn_cross_combine(const float * part_o, const float * part_l, int ns, int n, int S, int H, __half * out, hipStream_t st);
 enum { EPI_LOGITS = 100 };                    // C f32 [n][N] = acc
 void gemv(const GemvArgs & a, hipStream_t st);
+void set_rows_valu(bool on);                  // lock-step rows: true = VALU kernel (bit-identical to the one-row path), false = MFMA
 
 // ---------------------------------------------------------------- device-side logit filters + greedy pick (k_sample.hip)
 // One decode step's dynamic inputs; lives in device memory, refreshed by a 64-byte H2D copy per step so that

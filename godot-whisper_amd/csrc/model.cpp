@@ -355,6 +355,26 @@ bool upload_weights(const ModelFile & mf, const uint8_t * host_buf, const void *
     const size_t o_dlng = b.vec("decoder.ln.weight", S), o_dlnb = b.vec("decoder.ln.bias", S);
     const size_t o_filt = ar.reserve(mf.filters.size() * 4);
     memcpy(ar.host.data() + o_filt, mf.filters.data(), mf.filters.size() * 4);
+    // per mel filter: the range of 4-tap groups that hold a non-zero weight.  The reference sums all 201 taps
+    // (W/whisper.cpp:2759-2768); groups of zeros add exactly +0.0 to its double accumulator, so skipping them is
+    // bit-identical and cuts the filterbank work ~8x (triangular filters are narrow).
+    const int n_filt = mf.n_filt_mel, n_fft = mf.n_filt_fft;
+    const size_t o_rng = ar.reserve((size_t) std::max(n_filt, 1) * 2 * 4);
+    {
+        int32_t * rng = (int32_t *) (ar.host.data() + o_rng);
+        const int n_groups = (n_fft - 1) / 4 + ((n_fft - 1) % 4 ? 1 : 0);     // 201 taps: groups 0..49 cover taps 0..199
+        for (int j = 0; j < n_filt; ++j) {
+            const float * f = mf.filters.data() + (size_t) j * n_fft;
+            int g0 = n_groups, g1 = 0;
+            for (int g = 0; g < n_groups; ++g) {
+                bool nz = false;
+                for (int t = 4 * g; t < std::min(4 * g + 4, n_fft); ++t) nz = nz || f[t] != 0.0f;
+                if (nz) { g0 = std::min(g0, g); g1 = g + 1; }
+            }
+            if (g0 > g1) g0 = g1 = 0;
+            rng[2 * j] = g0; rng[2 * j + 1] = g1;
+        }
+    }
     ar.reserve(4096);                                  // tail slack: GEMM tiles may over-read clamped rows
 
     if (!b.ok) return false;
@@ -387,6 +407,7 @@ bool upload_weights(const ModelFile & mf, const uint8_t * host_buf, const void *
     }
     w.d_ln_g = F(o_dlng); w.d_ln_b = F(o_dlnb);
     w.mel_filters = F(o_filt);
+    w.mel_ranges = (const int32_t *) (base + o_rng);
     WMI_INFO("%s: device weight arena = %.2f MB\n", __func__, w.arena_bytes / 1e6);
     return true;
 }

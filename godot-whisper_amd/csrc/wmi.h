@@ -105,6 +105,7 @@ struct Weights {
     std::vector<DecLayerW> dec;
     const float  *d_ln_g, *d_ln_b;
     const float  *mel_filters;                                        // [n_mel][201]
+    const int32_t *mel_ranges;                                        // [n_mel][2]: non-zero 4-tap groups [g0, g1) of each filter
 };
 
 // src selects where tensor payloads are read from: a host pointer (H2D copies) or a device image
@@ -157,6 +158,8 @@ struct DeviceState {
     const float * last_pcm = nullptr; int last_pcm_n = 0;     // device copy of the samples of the last pcm_to_mel
     float * energy = nullptr;   size_t energy_cap = 0;        // |x| envelope (device)
     float * energy_host = nullptr;                            // pinned mirror
+    hipStream_t copy_stream = nullptr; hipEvent_t energy_ev = nullptr;   // envelope D2H overlaps the encoder
+    bool    energy_pending = false;                            // copy in flight: signal_energy_wait() before reading state.energy
     // encoder activations, token-major
     __half * mel_t = nullptr;                                 // [2T+2+pad][n_mel_pad] f16, rows -1 and 2T are zero
     __half * conv1 = nullptr;                                 // [2T+2][S] f16 (row 0 and 2T+1 zero)
@@ -246,7 +249,7 @@ bool init_state(whisper_context & ctx);
 void free_state(whisper_context & ctx);
 
 // hot path (device)
-bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, bool samples_on_device);
+bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, bool samples_on_device, bool sync = true);
 bool set_mel(whisper_context & ctx, const float * data, int n_len, int n_mel);
 bool encode(whisper_context & ctx, int mel_offset);
 bool decode(whisper_context & ctx, const Batch & batch);
@@ -255,7 +258,10 @@ struct StepFilter { bool ban_blank, last_ts, penult_ts; int ts_floor_end, ts_ini
 bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const StepFilter & f, whisper_token_data & out);
 bool upload_static_ban(whisper_context & ctx, const whisper_full_params & params);
 bool fast_path_enabled();
-bool signal_energy_device(whisper_context & ctx, int hw);   // fills state.energy from the last PCM
+// |x| envelope of the last PCM on the GPU; the D2H copy runs on a side stream while the encoder works.
+// sync = false: state.energy is valid only after signal_energy_wait()
+bool signal_energy_device(whisper_context & ctx, int hw, bool sync = true);
+bool signal_energy_wait(State & st);
 
 // host logic (logits filters, sampling, driver)
 void process_logits(whisper_context & ctx, Decoder & dec, const whisper_full_params & params, float temperature);
@@ -269,11 +275,11 @@ int  full(whisper_context & ctx, whisper_full_params params, const float * sampl
 int  full_batch(whisper_context & ctx, whisper_full_params params, const float * const * pcm, const int * n_samples, int n_chunks, bool on_device);
 void free_batch(whisper_context & ctx);
 // segment emission of one decoded window: updates prompt_past and appends to state.result_all (W/whisper.cpp:5682-5796)
-void emit_window(whisper_context & ctx, const whisper_full_params & params, int seek, const std::vector<int32_t> & prompt,
+void emit_window(whisper_context & ctx, State & st, const whisper_full_params & params, int seek, const std::vector<int32_t> & prompt,
                  size_t n_prompt_init, const Decoder & best);
 std::vector<float> signal_energy(const float * signal, int n_samples, int hw);
-void token_level_timestamps(whisper_context & ctx, int i_segment, float thold_pt, float thold_ptsum);
-int  wrap_segment(whisper_context & ctx, int max_len, bool split_on_word);
+void token_level_timestamps(whisper_context & ctx, State & st, int i_segment, float thold_pt, float thold_ptsum);
+int  wrap_segment(whisper_context & ctx, State & st, int max_len, bool split_on_word);
 
 int         lang_id(const char * lang);
 const char *lang_str(int id);

@@ -20,6 +20,7 @@ DEVICE_API = [
     ("wmi_pcm_to_mel_device", C.c_int, [C.c_void_p, C.c_void_p, C.c_int]),
     ("wmi_full_device_pcm", C.c_int, [C.c_void_p, abi.whisper_full_params, C.c_void_p, C.c_int, C.POINTER(C.c_float)]),
     ("wmi_full_batch", C.c_int, [C.c_void_p, abi.whisper_full_params, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int, C.c_int]),
+    ("wmi_set_lockstep_exact", None, [C.c_int]),
     ("wmi_batch_select", C.c_int, [C.c_void_p, C.c_int]),
     ("wmi_batch_chunk_mode", C.c_int, [C.c_void_p, C.c_int]),
     ("wmi_get_batch_timings", None, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),

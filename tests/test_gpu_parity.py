@@ -327,9 +327,17 @@ def _assert_same_transcription(got, want, what, strict):
         assert bytes(got[0]) == bytes(want[0]), what
 
 
+@pytest.fixture(params=["mfma", "exact"])
+def lockstep_mode(request, product_lib):
+    """Lock-step projections: MFMA rows kernel (default) or the VALU kernel that is bit-identical to the one-chunk path."""
+    product_lib.wmi_set_lockstep_exact(1 if request.param == "exact" else 0)
+    yield request.param
+    product_lib.wmi_set_lockstep_exact(0)
+
+
 @pytest.mark.parametrize("shape,variant", [("micro.en", "host"), ("micro", "host"), ("micro.en", "default_greedy"),
                                            ("micro.en", "default_fallback"), ("micro", "host_prompt")])
-def test_lockstep_chunks_equal_one_at_a_time(product_lib, shape, variant):
+def test_lockstep_chunks_equal_one_at_a_time(product_lib, lockstep_mode, shape, variant):
     """wmi_full_batch (several chunks as rows of the same kernels) == whisper_full per chunk on a fresh context:
     ragged lengths (4 s ... 47 s: one and two seek windows, < 1 s: no output), more chunks than rows (11 > 8)."""
     model = synth.make_model(shape, seed=2024)
@@ -340,7 +348,7 @@ def test_lockstep_chunks_equal_one_at_a_time(product_lib, shape, variant):
         p = gu.param_variants(node)[variant]
         if shape == "micro" and variant == "host":
             node.language = "de"; p = node.full_params("", 0)
-        if shape == "micro":
+        if shape == "micro" or (lockstep_mode == "mfma" and variant == "host"):
             # multi-token prompts are not bit-identical between the two paths (see below), and the temperature
             # fallback is a threshold on avg_logprob — discontinuous in the logits (one of these chunks
             # sits at avg_logprob = -1.00 +- 1e-3).  Token parity is checked with the fallback off, as in the goldens.
@@ -368,7 +376,7 @@ def test_lockstep_chunks_equal_one_at_a_time(product_lib, shape, variant):
             # (bit-identical); chunks run alone are the one-at-a-time path.  Longer prompts (multilingual, initial
             # prompt, second window with context) go through the MFMA GEMM when alone and token by token through the
             # GEMV here, which changes the f32 summation order.
-            strict = modes[c] == 1 or (shape == "micro.en" and variant == "host")
+            strict = modes[c] == 1 or (shape == "micro.en" and variant == "host" and lockstep_mode == "exact")
             if variant == "default_fallback" and not strict:
                 continue        # context prompts after the first window + live fallback thresholds: covered by default_greedy
             _assert_same_transcription(g, w, (shape, variant, c, modes[c]), strict)
@@ -376,7 +384,7 @@ def test_lockstep_chunks_equal_one_at_a_time(product_lib, shape, variant):
         node.close()
 
 
-def test_lockstep_chunks_with_audio_ctx_and_device_pcm(product_lib):
+def test_lockstep_chunks_with_audio_ctx_and_device_pcm(product_lib, lockstep_mode):
     model = synth.make_model("micro.en", seed=5)
     pcms = [synth.make_pcm(6.0, seed=40 + i) for i in range(3)]
     node = host.SpeechToText(product_lib); node.set_language_model(model)
@@ -394,12 +402,12 @@ def test_lockstep_chunks_with_audio_ctx_and_device_pcm(product_lib):
         assert node.last_ret == 0
         for c, (g, w) in enumerate(zip(got, want)):
             if node.last_modes[c] == 0:
-                _assert_same_transcription(g, w, c, True)
+                _assert_same_transcription(g, w, c, lockstep_mode == "exact")
     finally:
         node.close()
 
 
-def test_lockstep_base_en_eight_chunks(product_lib):
+def test_lockstep_base_en_eight_chunks(product_lib, lockstep_mode):
     """BASELINE config 4's per-GPU share: 8 chunks of 30 s on base.en, batch == one at a time."""
     model = synth.make_model("base.en", seed=1234)
     pcms = [synth.make_pcm(30.0, seed=1234 + i) for i in range(8)]
@@ -407,8 +415,11 @@ def test_lockstep_base_en_eight_chunks(product_lib):
     try:
         want = [node.transcribe(b, "", 0) for b in pcms]
         got = node.transcribe_batch(pcms, "", 0)
-        assert node.last_ret == 0 and node.last_modes == [0] * 8
+        assert node.last_ret == 0
+        if lockstep_mode == "exact":
+            assert node.last_modes == [0] * 8
         for c, (g, w) in enumerate(zip(got, want)):
-            _assert_same_transcription(g, w, c, True)
+            if node.last_modes[c] == 0:
+                _assert_same_transcription(g, w, c, lockstep_mode == "exact")
     finally:
         node.close()
