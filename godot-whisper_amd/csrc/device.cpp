@@ -149,6 +149,7 @@ bool signal_energy_device(whisper_context & ctx, int hw, bool sync) {
     }
     if (d.energy_pending) { HIP_TRY(hipStreamSynchronize(d.copy_stream)); d.energy_pending = false; }   // previous envelope still being written
     if ((size_t) n > d.energy_cap) {
+        st.energy = nullptr; st.energy_n = 0;
         if (d.energy_host) (void) hipHostFree(d.energy_host);
         d.energy_host = nullptr; d.energy_cap = 0;
         if (!HIP_OK(hipHostMalloc((void **) &d.energy_host, (size_t) n * 4, hipHostMallocDefault))) return false;
@@ -167,7 +168,7 @@ bool signal_energy_wait(State & st) {
     DeviceState & d = st.dev;
     if (!d.energy_pending) return true;
     HIP_TRY(hipStreamSynchronize(d.copy_stream));
-    st.energy.assign(d.energy_host, d.energy_host + d.last_pcm_n);
+    st.energy = d.energy_host; st.energy_n = d.last_pcm_n;
     d.energy_pending = false;
     return true;
 }

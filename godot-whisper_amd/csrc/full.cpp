@@ -8,7 +8,9 @@
 #include "wmi.h"
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -459,7 +461,7 @@ void token_level_timestamps(whisper_context & ctx, State & st, int i_segment, fl
     const Vocab & v = ctx.model.vocab;
     Segment & seg = st.result_all[i_segment];
     auto & tokens = seg.tokens;
-    const int n_samples = (int) st.energy.size();
+    const int n_samples = st.energy_n;
     if (n_samples == 0) { WMI_ERR("%s: no signal data available\n", __func__); return; }
     const int64_t t0 = seg.t0, t1 = seg.t1;
     const int n = (int) tokens.size();
@@ -514,7 +516,7 @@ void token_level_timestamps(whisper_context & ctx, State & st, int i_segment, fl
 
     // expand / contract by voice activity
     const int hw = WHISPER_SAMPLE_RATE / 8;
-    const std::vector<float> & en = st.energy;
+    const float * en = st.energy;                    // pinned host memory the GPU wrote (device.cpp: signal_energy_device)
     // The walks below ("move left/right while the envelope stays above/below the threshold") run to the end of
     // the signal on stationary audio — millions of scalar steps per call in the reference.  They are pure
     // searches, so they are done 16 samples at a time with a branch-free block test the compiler vectorises;
@@ -559,13 +561,42 @@ void token_level_timestamps(whisper_context & ctx, State & st, int i_segment, fl
         while (en[k] < th && k > first) --k;
         return k;
     };
+    // Window sums of the envelope (the threshold of each token).  A token's window depends only on its t0 / t1 as
+    // they stand before this loop (iteration j rewrites tokens[j] only, after its own sum), so all sums are taken
+    // first.  Each one must stay a sequential left-to-right f32 sum (the reference's rounding), i.e. a 4-cycle
+    // dependency chain per add — eight tokens are therefore summed side by side, eight independent chains.
+    std::vector<float> win_sum(n, 0.0f);
+    {
+        std::vector<int> idx;
+        for (int j = 0; j < n; ++j) if (tokens[j].id < v.eot) idx.push_back(j);
+        for (size_t g0 = 0; g0 < idx.size(); g0 += 8) {
+            const int ng = (int) std::min<size_t>(8, idx.size() - g0);
+            const float * base[8]; int len[8]; float acc[8];
+            int common = INT32_MAX;
+            for (int t = 0; t < 8; ++t) {
+                const int j = idx[g0 + std::min(t, ng - 1)];                 // pad the group with its last token
+                const int a0 = std::max(ts_to_sample(tokens[j].t0, n_samples) - hw, 0);
+                const int a1 = std::min(ts_to_sample(tokens[j].t1, n_samples) + hw, n_samples);
+                base[t] = en + a0; len[t] = std::max(a1 - a0, 0); acc[t] = 0.0f;
+                common = std::min(common, len[t]);
+            }
+            for (int i = 0; i < common; ++i) {
+                acc[0] += base[0][i]; acc[1] += base[1][i]; acc[2] += base[2][i]; acc[3] += base[3][i];
+                acc[4] += base[4][i]; acc[5] += base[5][i]; acc[6] += base[6][i]; acc[7] += base[7][i];
+            }
+            for (int t = 0; t < ng; ++t) {
+                float sum = acc[t];
+                for (int i = common; i < len[t]; ++i) sum += base[t][i];
+                win_sum[idx[g0 + t]] = sum;
+            }
+        }
+    }
     for (int j = 0; j < n; ++j) {
         if (tokens[j].id >= v.eot) continue;
         int s0 = ts_to_sample(tokens[j].t0, n_samples), s1 = ts_to_sample(tokens[j].t1, n_samples);
         const int ss0 = std::max(s0 - hw, 0), ss1 = std::min(s1 + hw, n_samples);
         const int ns = ss1 - ss0;
-        float sum = 0.0f;
-        for (int k2 = ss0; k2 < ss1; ++k2) sum += en[k2];
+        const float sum = win_sum[j];
         const float thold = 0.5 * sum / ns;
         {
             int k2 = s0;

@@ -203,7 +203,7 @@ struct State {
     std::vector<int32_t> prompt_past;
     int     lang_id = 0;
     int64_t t_beg = 0, t_last = 0; int32_t tid_last = 0;
-    std::vector<float> energy;
+    const float * energy = nullptr; int energy_n = 0;   // |x| envelope of the last PCM (view of dev.energy_host)
     int32_t exp_n_audio_ctx = 0;
     int     enc_n_ctx = 0;                        // n_ctx of the last encode (cross cache extent)
     DeviceState dev;

@@ -40,6 +40,9 @@ SHAPES = {
     # (3 text layers: n_text_layer == 2 would trip the "distilled" rule, W/whisper.cpp:5119-5125)
     "micro.en": (51864, 1500, 128, 2, 2, 448, 128, 2, 3, 80),
     "micro": (51865, 1500, 128, 2, 2, 448, 128, 2, 3, 80),
+    # large-v3's widths (1280 state, 20 heads, 128 mel bins, 51866 tokens / 100 languages) on 2 + 3 layers: exercises
+    # every kernel at the widest shape of BASELINE configs[4] at a size the CPU checker finishes in seconds
+    "v3-slice": (51866, 1500, 1280, 20, 2, 448, 1280, 20, 3, 128),
 }
 
 

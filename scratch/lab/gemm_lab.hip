@@ -1,0 +1,167 @@
+// GEMM lab: candidate encoder GEMM kernels for gfx950, timed and checked against the shipping k_gemm.
+// build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -I../../godot-whisper_amd/csrc gemm_lab.hip -o gemm_lab
+#include "../../godot-whisper_amd/csrc/k_gemm.hip"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+
+using namespace wmi::k;
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float    f4 __attribute__((ext_vector_type(4)));
+
+// ---------------------------------------------------------------------------------------------------------------
+// V1/V2: 128x128x64 tile, 4 waves (2x2, 64x64 each), operands staged with global_load_lds (16 B per lane, 1 KiB per
+// wave instruction) into the XOR-swizzled image (position p = row*8 + (chunk ^ (row & 7))): the swizzle is applied
+// to the GLOBAL address of each lane, LDS is written linearly.
+// NBUF = 1: load -> barrier -> compute -> barrier (latency hidden by other workgroups on the CU: 32 KiB LDS)
+// NBUF = 2: next tile's loads are issued before the current tile is multiplied
+template <int NBUF>
+__global__ __launch_bounds__(256) void k_gemm_glds(const GemmArgs a) {
+    constexpr int BM = 128, BN = 128;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN, nwg = ntm * ntn;
+    int wg = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, idx = wg / 8;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = wg / ntn, tn = wg % ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    // staging: the A tile is 16 pieces of 8 rows (1 KiB); wave w issues pieces w*4 .. w*4+3; same for B
+    const int prow = lane >> 3, pch = (lane & 7) ^ (prow & 7);        // row inside the piece, global chunk of this lane
+    const __half * gA[4]; const __half * gB[4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        int r = m0 + (wave * 4 + p) * 8 + prow; if (r > a.M - 1) r = a.M - 1;
+        gA[p] = a.A + (size_t) r * a.lda + pch * 8;
+        r = n0 + (wave * 4 + p) * 8 + prow; if (r > a.N - 1) r = a.N - 1;
+        gB[p] = a.W + (size_t) r * a.ldw + pch * 8;
+    }
+    f4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+
+    const int nk = a.K / 64;
+    auto sA = [&](int buf) -> unsigned char * { return smem + buf * 32768; };
+    auto sB = [&](int buf) -> unsigned char * { return smem + buf * 32768 + 16384; };
+    auto issue = [&](int kt, int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            __builtin_amdgcn_global_load_lds((const void *) (gA[p] + kt * 64), (__attribute__((address_space(3))) void *) (sA(buf) + (wave * 4 + p) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void *) (gB[p] + kt * 64), (__attribute__((address_space(3))) void *) (sB(buf) + (wave * 4 + p) * 1024), 16, 0, 0);
+        }
+    };
+    const int frow = lane & 15, fq = lane >> 4;
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            h8 fa[4], fb[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fa[i] = *(const h8 *) (sA(buf) + lds_off(wm * 64 + i * 16 + frow, kk * 4 + fq));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) fb[j] = *(const h8 *) (sB(buf) + lds_off(wn * 64 + j * 16 + frow, kk * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    if (NBUF == 1) {
+        for (int kt = 0; kt < nk; ++kt) {
+            issue(kt, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(0);
+            __syncthreads();
+        }
+    } else {
+        issue(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                  // tile kt landed for everyone; buffer (kt+1)&1 is free
+            if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+            compute(kt & 1);
+        }
+    }
+    // epilogue: C f16 = acc + bias
+    const int mb = m0 + wm * 64, nb = n0 + wn * 64;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = nb + j * 16 + frow;
+        if (n >= a.N) continue;
+        const float bias = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mb + i * 16 + fq * 4 + r;
+                if (m < a.M) ((__half *) a.C)[(size_t) m * a.ldc + n] = __float2half_rn(acc[i][j][r] + bias);
+            }
+    }
+}
+
+template <int NBUF> void launch_glds(const GemmArgs & a, hipStream_t st) {
+    const int ntm = (a.M + 127) / 128, ntn = (a.N + 127) / 128;
+    const size_t smem = (size_t) NBUF * 32768;
+    (void) hipFuncSetAttribute((const void *) k_gemm_glds<NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    hipLaunchKernelGGL((k_gemm_glds<NBUF>), dim3(ntm * ntn), dim3(256), smem, st, a);
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+int main(int argc, char ** argv) {
+    struct Shape { int M, N, K; const char * what; };
+    const Shape shapes[] = { {12000, 2048, 512, "fc1 x8"}, {12000, 1536, 512, "qkv x8"}, {12000, 512, 2048, "fc2 x8"}, {12000, 512, 512, "o x8"},
+                             {12000, 6144, 512, "crosskv x8"}, {1500, 2048, 512, "fc1 x1"}, {1500, 512, 2048, "fc2 x1"} };
+    hipStream_t st; CK(hipStreamCreate(&st));
+    for (const Shape & s : shapes) {
+        const size_t nA = (size_t) s.M * s.K, nW = (size_t) s.N * s.K, nC = (size_t) s.M * s.N;
+        std::vector<__half> hA(nA), hW(nW); std::vector<float> hb(s.N);
+        uint32_t seed = 12345u;
+        auto rnd = [&]() { seed = seed * 1664525u + 1013904223u; return ((seed >> 8) & 0xffff) / 65536.0f - 0.5f; };
+        for (auto & v : hA) v = __float2half(rnd());
+        for (auto & v : hW) v = __float2half(rnd() * 0.1f);
+        for (auto & v : hb) v = rnd();
+        __half * dA, * dW, * dC0, * dC1; float * db;
+        CK(hipMalloc(&dA, nA * 2 + 4096)); CK(hipMalloc(&dW, nW * 2 + 4096)); CK(hipMalloc(&dC0, nC * 2)); CK(hipMalloc(&dC1, nC * 2)); CK(hipMalloc(&db, s.N * 4));
+        CK(hipMemcpy(dA, hA.data(), nA * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(dW, hW.data(), nW * 2, hipMemcpyHostToDevice));
+        CK(hipMemcpy(db, hb.data(), s.N * 4, hipMemcpyHostToDevice));
+        GemmArgs a{}; a.A = dA; a.lda = s.K; a.W = dW; a.ldw = s.K; a.M = s.M; a.N = s.N; a.K = s.K; a.bias = db; a.C = dC0; a.ldc = s.N;
+        auto time_it = [&](auto && fn, int iters) {
+            hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            for (int i = 0; i < 3; ++i) fn();
+            CK(hipEventRecord(e0, st));
+            for (int i = 0; i < iters; ++i) fn();
+            CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            return ms * 1000.0 / iters;
+        };
+        const double flop = 2.0 * s.M * s.N * s.K;
+        a.C = dC0;
+        const double t0 = time_it([&]() { gemm(EPI_F16_BIAS, a, st); }, 50);
+        GemmArgs a1 = a; a1.C = dC1;
+        auto check = [&](const char * name) {
+            std::vector<__half> c0(nC), c1(nC);
+            CK(hipMemcpy(c0.data(), dC0, nC * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(c1.data(), dC1, nC * 2, hipMemcpyDeviceToHost));
+            double md = 0; size_t bad = 0;
+            for (size_t i = 0; i < nC; ++i) { const double d = fabs((double) __half2float(c0[i]) - (double) __half2float(c1[i])); if (d > md) md = d; if (d > 1e-2) ++bad; }
+            printf("    %-10s max|d| vs shipping = %.3g  (%zu > 1e-2)\n", name, md, bad);
+        };
+        printf("%-11s M=%5d N=%5d K=%5d | shipping %8.2f us %7.1f TF/s\n", s.what, s.M, s.N, s.K, t0, flop / t0 / 1e6);
+        CK(hipMemset(dC1, 0, nC * 2));
+        const double t1 = time_it([&]() { launch_glds<1>(a1, st); }, 50);
+        printf("    glds 1-buf  %8.2f us %7.1f TF/s\n", t1, flop / t1 / 1e6); check("glds1");
+        CK(hipMemset(dC1, 0, nC * 2));
+        const double t2 = time_it([&]() { launch_glds<2>(a1, st); }, 50);
+        printf("    glds 2-buf  %8.2f us %7.1f TF/s\n", t2, flop / t2 / 1e6); check("glds2");
+        hipFree(dA); hipFree(dW); hipFree(dC0); hipFree(dC1); hipFree(db);
+    }
+    return 0;
+}
