@@ -284,6 +284,123 @@ __global__ __launch_bounds__(256) void k_xattn_scores(const __half * __restrict_
     if (tid == 0) pmax[((size_t) i * H + head) * ns + slice] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// k_xattn_scores with the cross-attention query projection folded in (S <= 512: tiny / base): every (slice, head)
+// workgroup recomputes LN2(x) and its head's 64 rows of W_cq — 64 KB of weights out of L2 — instead of waiting for a
+// separate projection launch.  No LDS round trip in the projection: every wavefront normalises the row in registers
+// (lane holds x[8 lane .. 8 lane + 8), the slice its dot products need), loads its 16 weight rows in one go before
+// the LayerNorm, and reduces the 16 partial dot products with a halving exchange (17 shuffles instead of 96).
+// Roundings as in k_gemv + EPI_Q_SCALED (LN output f16, f32 accumulation, (dot + b) * scale -> f16); the f32
+// summation order differs from that kernel's.
+__global__ __launch_bounds__(256) void k_xattn_qscores(const float * __restrict__ x32, const float * __restrict__ ln_g,
+                                                       const float * __restrict__ ln_b, float eps,
+                                                       const __half * __restrict__ wq, const float * __restrict__ bq, float qscale,
+                                                       int S, const __half * __restrict__ kc, int T, int ks, int ns,
+                                                       float * __restrict__ sc, int ld_sc, float * __restrict__ pmax,
+                                                       int64_t kv_row_stride) {
+    __shared__ float qs[64];
+    __shared__ float red[4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slice = blockIdx.x, head = blockIdx.y, i = blockIdx.z, H = gridDim.y;
+    kc += (int64_t) i * kv_row_stride;
+    const bool on = lane * 8 < S;                                  // S <= 512, multiple of 8
+
+    // 16 weight rows of this wavefront (independent of x: requested first), then x, gain, bias
+    uint4 w[16];
+    const __half * wrow0 = wq + (size_t) (head * 64 + wave * 16) * S + lane * 8;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) w[u] = on ? *(const uint4 *) (wrow0 + (size_t) u * S) : make_uint4(0u, 0u, 0u, 0u);
+    float xv[8], gv[8], bv[8];
+    {
+        const float * xr = x32 + (size_t) i * S + lane * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xv[e] = on ? xr[e] : 0.0f; gv[e] = on ? ln_g[lane * 8 + e] : 0.0f; bv[e] = on ? ln_b[lane * 8 + e] : 0.0f; }
+    }
+    const float bias = bq ? bq[head * 64 + wave * 16 + ((lane >> 2) & 15)] : 0.0f;
+    __builtin_amdgcn_sched_barrier(0);          // keep all 16 + 3 loads in flight together (the scheduler would sink them to their uses)
+    float sum = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += xv[e];
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float) S;
+    float sq = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { if (on) { xv[e] -= mean; sq += xv[e] * xv[e]; } }
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float scl = 1.0f / sqrtf(sq / (float) S + eps);
+    float av[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) av[e] = round_f16(__fadd_rn(__fmul_rn(xv[e] * scl, gv[e]), bv[e]));
+    float acc[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const __half2 * wh = (const __half2 *) &w[u];
+        float a = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float2 f = __half22float2(wh[e]);
+            a = fmaf(f.x, av[2 * e], a);
+            a = fmaf(f.y, av[2 * e + 1], a);
+        }
+        acc[u] = a;
+    }
+    // halving exchange: after the steps with masks 32, 16, 8, 4 lane L holds the partial sum of row (L >> 2) & 15 over
+    // 4 lanes' worth of columns; masks 2 and 1 finish it
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const bool hi = lane & 32;
+        const float keep = hi ? acc[u + 8] : acc[u], send = hi ? acc[u] : acc[u + 8];
+        acc[u] = keep + __shfl_xor(send, 32);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const bool hi = lane & 16;
+        const float keep = hi ? acc[u + 4] : acc[u], send = hi ? acc[u] : acc[u + 4];
+        acc[u] = keep + __shfl_xor(send, 16);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const bool hi = lane & 8;
+        const float keep = hi ? acc[u + 2] : acc[u], send = hi ? acc[u] : acc[u + 2];
+        acc[u] = keep + __shfl_xor(send, 8);
+    }
+    {
+        const bool hi = lane & 4;
+        const float keep = hi ? acc[1] : acc[0], send = hi ? acc[0] : acc[1];
+        acc[0] = keep + __shfl_xor(send, 4);
+    }
+    acc[0] += __shfl_xor(acc[0], 2);
+    acc[0] += __shfl_xor(acc[0], 1);
+    if ((lane & 3) == 0) qs[wave * 16 + ((lane >> 2) & 15)] = round_f16((acc[0] + bias) * qscale);
+    __syncthreads();
+
+    float lmax = -INFINITY;
+    for (int t = tid; t < ks; t += 256) {
+        const int j = slice * ks + t;
+        if (j >= T) break;
+        const uint4 * kp = (const uint4 *) (kc + (size_t) j * S + head * 64);
+        uint4 u[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) u[c] = kp[c];
+        float dot = 0.0f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const __half2 * h = (const __half2 *) &u[c];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float2 f = __half22float2(h[e]);
+                dot = fmaf(f.x, qs[c * 8 + e * 2], dot);
+                dot = fmaf(f.y, qs[c * 8 + e * 2 + 1], dot);
+            }
+        }
+        sc[((size_t) i * H + head) * ld_sc + j] = dot;
+        lmax = fmaxf(lmax, dot);
+    }
+    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+    if (lane == 0) red[wave] = lmax;
+    __syncthreads();
+    if (tid == 0) pmax[((size_t) i * H + head) * ns + slice] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
 __global__ __launch_bounds__(256) void k_xattn_pv(const __half * __restrict__ vc, int S, int T, int ks, int ns,
                                                   const float * __restrict__ sc, int ld_sc, const float * __restrict__ pmax,
                                                   float * __restrict__ part_o, float * __restrict__ part_l, int64_t kv_row_stride) {
@@ -383,6 +500,24 @@ void attn_cross_split_partials(const __half * q, int n, int S, int H, const __ha
 
 void attn_cross_combine(const float * part_o, const float * part_l, int ns, int n, int S, int H, __half * out, hipStream_t st) {
     hipLaunchKernelGGL(k_xattn_combine, dim3(H, n), dim3(64), 0, st, part_o, part_l, ns, S, out);
+}
+
+void attn_cross_qsplit_partials(const float * x32, const float * ln_g, const float * ln_b, float eps, const __half * wq,
+                                const float * bq, float qscale, int n, int S, int H, const __half * kc, const __half * vc, int T,
+                                float * scratch, const float ** po, const float ** pl, int * pns, hipStream_t st,
+                                int64_t kv_row_stride) {
+    int ns = (T + 191) / 192; if (ns < 1) ns = 1; if (ns > XS_MAX_SLICES) ns = XS_MAX_SLICES;
+    const int ks = (T + ns - 1) / ns;
+    const int ld_sc = (T + 63) & ~63;
+    float * sc = scratch;
+    float * pmax = sc + (size_t) n * H * ld_sc;
+    float * part_l = pmax + (size_t) n * H * ns;
+    float * part_o = part_l + (size_t) n * H * ns;
+    hipLaunchKernelGGL(k_xattn_qscores, dim3(ns, H, n), dim3(256), 0, st, x32, ln_g, ln_b, eps, wq, bq, qscale, S, kc, T, ks, ns,
+                       sc, ld_sc, pmax, kv_row_stride);
+    const size_t smem = (((size_t) ks + 3) & ~(size_t) 3) * 4 + 4 * 64 * 4;
+    hipLaunchKernelGGL(k_xattn_pv, dim3(ns, H, n), dim3(256), smem, st, vc, S, T, ks, ns, sc, ld_sc, pmax, part_o, part_l, kv_row_stride);
+    *po = part_o; *pl = part_l; *pns = ns;
 }
 
 size_t attn_cross_scratch_floats(int n, int H, int T) {

@@ -73,6 +73,12 @@ void attn_cross_split(const __half * q, int n, int S, int H, const __half * kc, 
 void attn_cross_split_partials(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int T,
                                float * scratch, const float ** part_o, const float ** part_l, int * ns, hipStream_t st,
                                int64_t kv_row_stride = 0);   // row i reads kc/vc + i * kv_row_stride (lock-step chunks)
+// the same with the query projection folded into the score kernel: q = (W_cq . LN(x32) + b_cq) * qscale is recomputed per
+// (slice, head) workgroup (bit-identical to gemv + EPI_Q_SCALED); saves one launch per decoder layer
+void attn_cross_qsplit_partials(const float * x32, const float * ln_g, const float * ln_b, float eps, const __half * wq,
+                                const float * bq, float qscale, int n, int S, int H, const __half * kc, const __half * vc, int T,
+                                float * scratch, const float ** part_o, const float ** part_l, int * ns, hipStream_t st,
+                                int64_t kv_row_stride = 0);
 size_t attn_cross_scratch_floats(int n, int H, int T);
 
 // ---------------------------------------------------------------- decoder small-batch (k_dec.hip)

@@ -17,7 +17,11 @@ typedef float    f4 __attribute__((ext_vector_type(4)));
 // to the GLOBAL address of each lane, LDS is written linearly.
 // NBUF = 1: load -> barrier -> compute -> barrier (latency hidden by other workgroups on the CU: 32 KiB LDS)
 // NBUF = 2: next tile's loads are issued before the current tile is multiplied
-template <int NBUF>
+template <int SW> __device__ __forceinline__ int swz(int row) { return SW == 0 ? (row & 7) : ((row >> 1) & 7); }
+template <int SW> __device__ __forceinline__ uint32_t lds_off2(int row, int chunk) { return (uint32_t) (row * 128 + ((chunk ^ swz<SW>(row)) << 4)); }
+
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+template <int NBUF, int SW, int EPV, int SKIP = 0>
 __global__ __launch_bounds__(256) void k_gemm_glds(const GemmArgs a) {
     constexpr int BM = 128, BN = 128;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -33,13 +37,15 @@ __global__ __launch_bounds__(256) void k_gemm_glds(const GemmArgs a) {
     const int m0 = tm * BM, n0 = tn * BN;
 
     // staging: the A tile is 16 pieces of 8 rows (1 KiB); wave w issues pieces w*4 .. w*4+3; same for B
-    const int prow = lane >> 3, pch = (lane & 7) ^ (prow & 7);        // row inside the piece, global chunk of this lane
+    const int prow = lane >> 3;                                       // row inside the piece
     const __half * gA[4]; const __half * gB[4];
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
-        int r = m0 + (wave * 4 + p) * 8 + prow; if (r > a.M - 1) r = a.M - 1;
+        const int lrow = (wave * 4 + p) * 8 + prow;                   // row inside the tile
+        const int pch = (lane & 7) ^ swz<SW>(lrow);                   // global chunk this lane fetches
+        int r = m0 + lrow; if (r > a.M - 1) r = a.M - 1;
         gA[p] = a.A + (size_t) r * a.lda + pch * 8;
-        r = n0 + (wave * 4 + p) * 8 + prow; if (r > a.N - 1) r = a.N - 1;
+        r = n0 + lrow; if (r > a.N - 1) r = a.N - 1;
         gB[p] = a.W + (size_t) r * a.ldw + pch * 8;
     }
     f4 acc[4][4];
@@ -52,6 +58,7 @@ __global__ __launch_bounds__(256) void k_gemm_glds(const GemmArgs a) {
     auto sA = [&](int buf) -> unsigned char * { return smem + buf * 32768; };
     auto sB = [&](int buf) -> unsigned char * { return smem + buf * 32768 + 16384; };
     auto issue = [&](int kt, int buf) {
+        if (SKIP >= 2) return;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             __builtin_amdgcn_global_load_lds((const void *) (gA[p] + kt * 64), (__attribute__((address_space(3))) void *) (sA(buf) + (wave * 4 + p) * 1024), 16, 0, 0);
@@ -60,17 +67,19 @@ __global__ __launch_bounds__(256) void k_gemm_glds(const GemmArgs a) {
     };
     const int frow = lane & 15, fq = lane >> 4;
     auto compute = [&](int buf) {
+        if (SKIP == 1) return;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             h8 fa[4], fb[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fa[i] = *(const h8 *) (sA(buf) + lds_off(wm * 64 + i * 16 + frow, kk * 4 + fq));
+            for (int i = 0; i < 4; ++i) fa[i] = *(const h8 *) (sA(buf) + lds_off2<SW>(wm * 64 + i * 16 + frow, kk * 4 + fq));
 #pragma unroll
-            for (int j = 0; j < 4; ++j) fb[j] = *(const h8 *) (sB(buf) + lds_off(wn * 64 + j * 16 + frow, kk * 4 + fq));
+            for (int j = 0; j < 4; ++j) fb[j] = *(const h8 *) (sB(buf) + lds_off2<SW>(wn * 64 + j * 16 + frow, kk * 4 + fq));
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 4; ++j) acc[i][j] = EPV == 2 ? __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0)
+                                                                 : __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
     };
     if (NBUF == 1) {
@@ -91,7 +100,62 @@ __global__ __launch_bounds__(256) void k_gemm_glds(const GemmArgs a) {
         }
     }
     // epilogue: C f16 = acc + bias
+    if (SKIP == 3) {                                   // no stores: keep the accumulators alive with an impossible condition
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t += acc[i][j][0] + acc[i][j][1] + acc[i][j][2] + acc[i][j][3];
+        if (t == 123456.789f) ((__half *) a.C)[tid] = __float2half(t);
+        return;
+    }
     const int mb = m0 + wm * 64, nb = n0 + wn * 64;
+    const bool full = (m0 + BM <= a.M) && (n0 + BN <= a.N);
+    if (EPV == 2) {
+        // swapped operands: acc[i][j][r] = C[mb + i*16 + frow][nb + j*16 + fq*4 + r] -> one 8-byte store per fragment
+        if (full) {
+            float4 bias[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bias[j] = a.bias ? *(const float4 *) (a.bias + nb + j * 16 + fq * 4) : float4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __half * crow = (__half *) a.C + (size_t) (mb + i * 16 + frow) * a.ldc + nb + fq * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    h4 v;
+                    v[0] = (_Float16) (acc[i][j][0] + bias[j].x); v[1] = (_Float16) (acc[i][j][1] + bias[j].y);
+                    v[2] = (_Float16) (acc[i][j][2] + bias[j].z); v[3] = (_Float16) (acc[i][j][3] + bias[j].w);
+                    *(h4 *) (crow + j * 16) = v;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = mb + i * 16 + frow;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = nb + j * 16 + fq * 4 + r;
+                        if (m < a.M && n < a.N) ((__half *) a.C)[(size_t) m * a.ldc + n] = __float2half_rn(acc[i][j][r] + (a.bias ? a.bias[n] : 0.0f));
+                    }
+            }
+        }
+        return;
+    }
+    if (EPV == 1 && full) {
+        float bias[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bias[j] = a.bias ? a.bias[nb + j * 16 + frow] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    ((__half *) a.C)[(size_t) (mb + i * 16 + fq * 4 + r) * a.ldc + nb + j * 16 + frow] = __float2half_rn(acc[i][j][r] + bias[j]);
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int n = nb + j * 16 + frow;
@@ -107,11 +171,114 @@ __global__ __launch_bounds__(256) void k_gemm_glds(const GemmArgs a) {
     }
 }
 
-template <int NBUF> void launch_glds(const GemmArgs & a, hipStream_t st) {
+template <int NBUF, int SW = 0, int EPV = 0, int SKIP = 0> void launch_glds(const GemmArgs & a, hipStream_t st) {
     const int ntm = (a.M + 127) / 128, ntn = (a.N + 127) / 128;
     const size_t smem = (size_t) NBUF * 32768;
-    (void) hipFuncSetAttribute((const void *) k_gemm_glds<NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
-    hipLaunchKernelGGL((k_gemm_glds<NBUF>), dim3(ntm * ntn), dim3(256), smem, st, a);
+    (void) hipFuncSetAttribute((const void *) k_gemm_glds<NBUF, SW, EPV, SKIP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    hipLaunchKernelGGL((k_gemm_glds<NBUF, SW, EPV, SKIP>), dim3(ntm * ntn), dim3(256), smem, st, a);
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// V3: BM x 128 x 64 block tile (BM = 256: 4 waves 2x2, each 128 x 64 = 8 x 4 fragments; BM = 128 falls back to 64 x 64)
+// LDS reads per MFMA: (FM + FN) / (FM * FN) KiB = 0.375 (8x4) vs 0.5 (4x4)
+template <int FM, int FN, int NBUF>
+__global__ __launch_bounds__(256) void k_gemm_glds_w(const GemmArgs a) {
+    constexpr int BM = FM * 32, BN = FN * 32;                 // 2 x 2 waves
+    constexpr int PA = BM / 32, PB = BN / 32;                 // 1 KiB pieces per wave per operand
+    constexpr int STAGE = (BM + BN) * 128;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN, nwg = ntm * ntn;
+    int wg = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, idx = wg / 8;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = wg / ntn, tn = wg % ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int prow = lane >> 3, pch = (lane & 7) ^ (prow & 7);
+    const __half * gA[PA]; const __half * gB[PB];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        int r = m0 + (wave * PA + p) * 8 + prow; if (r > a.M - 1) r = a.M - 1;
+        gA[p] = a.A + (size_t) r * a.lda + pch * 8;
+    }
+#pragma unroll
+    for (int p = 0; p < PB; ++p) {
+        int r = n0 + (wave * PB + p) * 8 + prow; if (r > a.N - 1) r = a.N - 1;
+        gB[p] = a.W + (size_t) r * a.ldw + pch * 8;
+    }
+    f4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    const int nk = a.K / 64;
+    auto sA = [&](int buf) -> unsigned char * { return smem + buf * STAGE; };
+    auto sB = [&](int buf) -> unsigned char * { return smem + buf * STAGE + BM * 128; };
+    auto issue = [&](int kt, int buf) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p)
+            __builtin_amdgcn_global_load_lds((const void *) (gA[p] + kt * 64), (__attribute__((address_space(3))) void *) (sA(buf) + (wave * PA + p) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int p = 0; p < PB; ++p)
+            __builtin_amdgcn_global_load_lds((const void *) (gB[p] + kt * 64), (__attribute__((address_space(3))) void *) (sB(buf) + (wave * PB + p) * 1024), 16, 0, 0);
+    };
+    const int frow = lane & 15, fq = lane >> 4;
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            h8 fa[FM], fb[FN];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) fb[j] = *(const h8 *) (sB(buf) + lds_off(wn * (BN / 2) + j * 16 + frow, kk * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < FM; ++i) fa[i] = *(const h8 *) (sA(buf) + lds_off(wm * (BM / 2) + i * 16 + frow, kk * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    };
+    if (NBUF == 1) {
+        for (int kt = 0; kt < nk; ++kt) {
+            issue(kt, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            compute(0);
+            __syncthreads();
+        }
+    } else {
+        issue(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+            compute(kt & 1);
+        }
+    }
+    const int mb = m0 + wm * (BM / 2), nb = n0 + wn * (BN / 2);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = nb + j * 16 + frow;
+        if (n >= a.N) continue;
+        const float bias = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mb + i * 16 + fq * 4 + r;
+                if (m < a.M) ((__half *) a.C)[(size_t) m * a.ldc + n] = __float2half_rn(acc[i][j][r] + bias);
+            }
+    }
+}
+template <int FM, int FN, int NBUF> void launch_glds_w(const GemmArgs & a, hipStream_t st) {
+    constexpr int BM = FM * 32, BN = FN * 32;
+    const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
+    const size_t smem = (size_t) NBUF * (BM + BN) * 128;
+    (void) hipFuncSetAttribute((const void *) k_gemm_glds_w<FM, FN, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+    hipLaunchKernelGGL((k_gemm_glds_w<FM, FN, NBUF>), dim3(ntm * ntn), dim3(256), smem, st, a);
 }
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
@@ -121,7 +288,9 @@ int main(int argc, char ** argv) {
     const Shape shapes[] = { {12000, 2048, 512, "fc1 x8"}, {12000, 1536, 512, "qkv x8"}, {12000, 512, 2048, "fc2 x8"}, {12000, 512, 512, "o x8"},
                              {12000, 6144, 512, "crosskv x8"}, {1500, 2048, 512, "fc1 x1"}, {1500, 512, 2048, "fc2 x1"} };
     hipStream_t st; CK(hipStreamCreate(&st));
+    const int max_shapes = getenv("LAB_SHAPES") ? atoi(getenv("LAB_SHAPES")) : 100; int si = 0;
     for (const Shape & s : shapes) {
+        if (si++ >= max_shapes) break;
         const size_t nA = (size_t) s.M * s.K, nW = (size_t) s.N * s.K, nC = (size_t) s.M * s.N;
         std::vector<__half> hA(nA), hW(nW); std::vector<float> hb(s.N);
         uint32_t seed = 12345u;
@@ -136,6 +305,7 @@ int main(int argc, char ** argv) {
         GemmArgs a{}; a.A = dA; a.lda = s.K; a.W = dW; a.ldw = s.K; a.M = s.M; a.N = s.N; a.K = s.K; a.bias = db; a.C = dC0; a.ldc = s.N;
         auto time_it = [&](auto && fn, int iters) {
             hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+            if (getenv("LAB_ITERS")) iters = atoi(getenv("LAB_ITERS"));
             for (int i = 0; i < 3; ++i) fn();
             CK(hipEventRecord(e0, st));
             for (int i = 0; i < iters; ++i) fn();
@@ -161,6 +331,19 @@ int main(int argc, char ** argv) {
         CK(hipMemset(dC1, 0, nC * 2));
         const double t2 = time_it([&]() { launch_glds<2>(a1, st); }, 50);
         printf("    glds 2-buf  %8.2f us %7.1f TF/s\n", t2, flop / t2 / 1e6); check("glds2");
+        auto run = [&](const char * name, auto && fn) {
+            CK(hipMemset(dC1, 0, nC * 2));
+            const double t = time_it(fn, 50);
+            printf("    %-14s %8.2f us %7.1f TF/s\n", name, t, flop / t / 1e6); check(name);
+        };
+        run("glds1 ep1", [&]() { launch_glds<1, 0, 1>(a1, st); });
+        run("glds2 ep1", [&]() { launch_glds<2, 0, 1>(a1, st); });
+        run("g1 loadonly", [&]() { launch_glds<1, 0, 1, 1>(a1, st); });
+        run("g2 loadonly", [&]() { launch_glds<2, 0, 1, 1>(a1, st); });
+        run("g1 mathnost", [&]() { launch_glds<1, 0, 1, 3>(a1, st); });
+        run("g2 mathnost", [&]() { launch_glds<2, 0, 1, 3>(a1, st); });
+        run("g1 mathonly", [&]() { launch_glds<1, 0, 1, 2>(a1, st); });
+        run("g2 mathonly", [&]() { launch_glds<2, 0, 1, 2>(a1, st); });
         hipFree(dA); hipFree(dW); hipFree(dC0); hipFree(dC1); hipFree(db);
     }
     return 0;
