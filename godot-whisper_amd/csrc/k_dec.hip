@@ -122,7 +122,62 @@ __global__ __launch_bounds__(256) void k_self_attn_rows(const __half * __restric
                   n_kv[r * step_stride], K, cap, sc, qf, out + (size_t) r * K, kpre, false);
 }
 
-template <int R, int ROWS_IN_FLIGHT>
+// LayerNorm of one row by one wavefront, lane L holding the slices x[512 t + 8 L .. + 8) (the slices its dot products
+// need).  y = f16((x - mean) * rstd * g + b) as separate mul / add (SURVEY App. B rule 6); sums in f32: per lane over
+// (t, e) in order, then the 64-lane butterfly.  MAXCH chunks of 512 columns; av[t][e] = 0 outside the row.
+template <int MAXCH>
+__device__ __forceinline__ void ln_row_regs(const float * __restrict__ xr, const float * __restrict__ g, const float * __restrict__ b,
+                                            int K, float eps, int lane, float (&av)[MAXCH][8]) {
+    float xv[MAXCH][8], gv[MAXCH][8], bv[MAXCH][8];
+#pragma unroll
+    for (int t = 0; t < MAXCH; ++t) {
+        const int c = lane * 8 + 512 * t;
+        if (c < K) {
+            const float4 x0 = *(const float4 *) (xr + c), x1 = *(const float4 *) (xr + c + 4);
+            const float4 g0 = *(const float4 *) (g + c),  g1 = *(const float4 *) (g + c + 4);
+            const float4 b0 = *(const float4 *) (b + c),  b1 = *(const float4 *) (b + c + 4);
+            xv[t][0] = x0.x; xv[t][1] = x0.y; xv[t][2] = x0.z; xv[t][3] = x0.w; xv[t][4] = x1.x; xv[t][5] = x1.y; xv[t][6] = x1.z; xv[t][7] = x1.w;
+            gv[t][0] = g0.x; gv[t][1] = g0.y; gv[t][2] = g0.z; gv[t][3] = g0.w; gv[t][4] = g1.x; gv[t][5] = g1.y; gv[t][6] = g1.z; gv[t][7] = g1.w;
+            bv[t][0] = b0.x; bv[t][1] = b0.y; bv[t][2] = b0.z; bv[t][3] = b0.w; bv[t][4] = b1.x; bv[t][5] = b1.y; bv[t][6] = b1.z; bv[t][7] = b1.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xv[t][e] = 0.0f; gv[t][e] = 0.0f; bv[t][e] = 0.0f; }
+        }
+    }
+    float sum = 0.0f;
+#pragma unroll
+    for (int t = 0; t < MAXCH; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += xv[t][e];
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float) K;
+    float sq = 0.0f;
+#pragma unroll
+    for (int t = 0; t < MAXCH; ++t) {
+        const bool on = lane * 8 + 512 * t < K;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) if (on) { xv[t][e] -= mean; sq += xv[t][e] * xv[t][e]; }
+    }
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float sc = 1.0f / sqrtf(sq / (float) K + eps);
+#pragma unroll
+    for (int t = 0; t < MAXCH; ++t) {
+        const bool on = lane * 8 + 512 * t < K;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) av[t][e] = on ? round_f16(__fadd_rn(__fmul_rn(xv[t][e] * sc, gv[t][e]), bv[t][e])) : 0.0f;
+    }
+}
+
+template <bool NT> __device__ __forceinline__ uint4 ldw(const __half * p) {
+    if (NT) {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        const u4 v = __builtin_nontemporal_load((const u4 *) p);
+        return make_uint4(v[0], v[1], v[2], v[3]);
+    }
+    return *(const uint4 *) p;
+}
+
+template <int R, int ROWS_IN_FLIGHT, bool NT = false>
 __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __half * act = (__half *) smem;                         // [R][K]
@@ -139,7 +194,7 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
 #pragma unroll
         for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
             int o = gw * ROWS_IN_FLIGHT + u; if (o > a.N - 1) o = a.N - 1;
-            wpre[u] = *(const uint4 *) (a.W + (size_t) o * K + lane * 8);
+            wpre[u] = ldw<NT>(a.W + (size_t) o * K + lane * 8);
         }
     }
 
@@ -156,30 +211,20 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
     }
 
     // ---- prologue: stage the activation rows as f16
-    if (a.ln_g) {                                           // fused LayerNorm of the f32 residual stream
-        constexpr int XV = 20;                              // row kept in registers: K <= 64 * 20 = 1280 (every Whisper size)
+    if (a.ln_g) {                                           // fused LayerNorm of the f32 residual stream (K <= 1536)
         for (int r = wave; r < R; r += 4) {
             const int src = a.rows ? a.rows[r] : r;
-            const float * xr = a.x32 + (size_t) src * K;
-            float xv[XV], gv[XV], bv[XV]; float sum = 0.0f;
+            float av[3][8];
+            ln_row_regs<3>(a.x32 + (size_t) src * K, a.ln_g, a.ln_b, K, a.eps, lane, av);
 #pragma unroll
-            for (int j = 0; j < XV; ++j) {
-                const int c = lane + 64 * j;
-                xv[j] = c < K ? xr[c] : 0.0f; gv[j] = c < K ? a.ln_g[c] : 0.0f; bv[j] = c < K ? a.ln_b[c] : 0.0f;
-            }
+            for (int t = 0; t < 3; ++t) {
+                const int c = lane * 8 + 512 * t;
+                if (c < K) {
+                    __half2 h[4];
 #pragma unroll
-            for (int j = 0; j < XV; ++j) sum += xv[j];
-            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-            const float mean = sum / (float) K;
-            float sq = 0.0f;
-#pragma unroll
-            for (int j = 0; j < XV; ++j) { const int c = lane + 64 * j; if (c < K) { xv[j] -= mean; sq += xv[j] * xv[j]; } }
-            for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-            const float sc = 1.0f / sqrtf(sq / (float) K + a.eps);
-#pragma unroll
-            for (int j = 0; j < XV; ++j) {
-                const int c = lane + 64 * j;
-                if (c < K) act[r * K + c] = __float2half_rn(__fadd_rn(__fmul_rn(xv[j] * sc, gv[j]), bv[j]));
+                    for (int e = 0; e < 4; ++e) h[e] = __floats2half2_rn(av[t][2 * e], av[t][2 * e + 1]);
+                    *(uint4 *) (act + r * K + c) = *(const uint4 *) h;
+                }
             }
         }
     } else if (a.sa_q) {                                    // fused single-token self-attention over the KV cache
@@ -244,7 +289,7 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
 #pragma unroll
                     for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
                         int o = on + u; if (o > a.N - 1) o = a.N - 1;
-                        wpre[u] = *(const uint4 *) (a.W + (size_t) o * K + lane * 8);
+                        wpre[u] = ldw<NT>(a.W + (size_t) o * K + lane * 8);
                     }
                     first = true;                       // consumed by the next o0 iteration's first chunk
                 }
@@ -252,7 +297,7 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
 #pragma unroll
                 for (int u = 0; u < ROWS_IN_FLIGHT; ++u) {
                     int o = o0 + u; if (o > a.N - 1) o = a.N - 1;
-                    w[u] = *(const uint4 *) (a.W + (size_t) o * K + c);
+                    w[u] = ldw<NT>(a.W + (size_t) o * K + c);
                 }
             }
             float av[R][8];
@@ -322,6 +367,182 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// One activation row (the greedy decode step): the activations never go through LDS.  Every wavefront keeps the row
+// in registers — lane L holds columns 512 t + 8 L .. + 8, exactly the columns its 16-byte weight loads multiply —
+// and, for the fused-LN variant, normalises it itself (four redundant 64-lane LayerNorms cost less than one LDS
+// round trip + barrier on the critical path of a ~5 us kernel).  All NCH x RIF weight loads of a row tile are issued
+// together (K = 2048: 16 loads in flight per lane instead of four dependent rounds of four).  The fused attention
+// prologues (sa_*, comb_*) still stage through LDS, once.  K <= 512 NCH.
+template <int RIF, int NCH, bool NT>
+__global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __half * act = (__half *) smem;                         // [K], attention prologues only
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.K;
+    const int nwaves = gridDim.x * 4;
+    const int gw = blockIdx.x * 4 + wave;
+
+    uint4 wpre[RIF];
+    const bool have_pre = gw * RIF < a.N && lane * 8 < K;
+    if (have_pre) {
+#pragma unroll
+        for (int u = 0; u < RIF; ++u) {
+            int o = gw * RIF + u; if (o > a.N - 1) o = a.N - 1;
+            wpre[u] = ldw<NT>(a.W + (size_t) o * K + lane * 8);
+        }
+    }
+    float bias_pre = 0.0f, resid_pre = 0.0f; int ro_pre = 0;
+    {
+        const int n = gw * RIF + lane;
+        if (lane < RIF && n < a.N) {
+            if (a.bias) bias_pre = a.bias[n];
+            if (a.resid) resid_pre = a.resid[n];
+        }
+        if (a.row_off) ro_pre = *a.row_off;
+    }
+
+    float av[NCH][8];
+    const int src = a.rows ? a.rows[0] : 0;
+    if (a.ln_g) {
+        // same instantiation as k_gemv<R>'s prologue: the lock-step VALU path must stay bit-identical to this kernel
+        float av3[3][8];
+        ln_row_regs<3>(a.x32 + (size_t) src * K, a.ln_g, a.ln_b, K, a.eps, lane, av3);
+#pragma unroll
+        for (int t = 0; t < NCH; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) av[t][e] = t < 3 ? av3[t < 3 ? t : 0][e] : 0.0f;
+    } else {
+        const __half * arow = a.a16 + (size_t) src * K;
+        if (a.sa_q) {
+            const int H = K / 64;
+            float * sc = (float *) (smem + (((size_t) K * sizeof(__half) + 15) & ~(size_t) 15));   // [H][sa_cap]
+            float * qf = sc + (size_t) H * a.sa_cap;                                             // [K]
+            uint4 kpre[8];
+            {
+                const int j = tid / H, h = tid - j * H;
+                const uint4 * kp = (const uint4 *) (a.sa_k + (size_t) (j < a.sa_cap ? j : 0) * K + h * 64);
+#pragma unroll
+                for (int c8 = 0; c8 < 8; ++c8) kpre[c8] = kp[c8];
+            }
+            self_attn_row(a.sa_q, a.sa_k, a.sa_v, a.sa_nkv[0], K, a.sa_cap, sc, qf, act, kpre, true);
+            __syncthreads();
+            arow = act;
+        } else if (a.comb_o) {
+            const int H = K / 64, ns = a.comb_ns;
+            for (int e = tid; e < K; e += 256) {
+                const int h = e >> 6, dd = e & 63;
+                float o = 0.0f; double l = 0.0;
+                for (int s2 = 0; s2 < ns; ++s2) { o += a.comb_o[((size_t) h * ns + s2) * 64 + dd]; l += (double) a.comb_l[(size_t) h * ns + s2]; }
+                act[e] = __float2half_rn(o * (float) (1.0 / l));
+            }
+            (void) H;
+            __syncthreads();
+            arow = act;
+        }
+#pragma unroll
+        for (int t = 0; t < NCH; ++t) {
+            const int c = lane * 8 + 512 * t;
+            uint4 u4 = make_uint4(0u, 0u, 0u, 0u);
+            if (c < K) u4 = *(const uint4 *) (arow + c);
+            const __half2 * h = (const __half2 *) &u4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float2 f = __half22float2(h[e]); av[t][2 * e] = f.x; av[t][2 * e + 1] = f.y; }
+        }
+    }
+
+    bool first = have_pre;
+    for (int o0 = gw * RIF; o0 < a.N; o0 += nwaves * RIF) {
+        uint4 w[NCH][RIF];
+#pragma unroll
+        for (int t = 0; t < NCH; ++t) {
+            const int c = lane * 8 + 512 * t;
+#pragma unroll
+            for (int u = 0; u < RIF; ++u) {
+                int o = o0 + u; if (o > a.N - 1) o = a.N - 1;
+                if (t == 0 && first) w[t][u] = wpre[u];
+                else w[t][u] = c < K ? ldw<NT>(a.W + (size_t) o * K + c) : make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
+        {   // software pipeline over the row tiles: first chunk of the NEXT tile is requested before this one is reduced
+            const int on = o0 + nwaves * RIF;
+            first = false;
+            if (on < a.N && lane * 8 < K) {
+#pragma unroll
+                for (int u = 0; u < RIF; ++u) {
+                    int o = on + u; if (o > a.N - 1) o = a.N - 1;
+                    wpre[u] = ldw<NT>(a.W + (size_t) o * K + lane * 8);
+                }
+                first = true;
+            }
+        }
+        float acc[RIF];
+#pragma unroll
+        for (int u = 0; u < RIF; ++u) acc[u] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NCH; ++t)
+#pragma unroll
+            for (int u = 0; u < RIF; ++u) {
+                const __half2 * h = (const __half2 *) &w[t][u];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float2 f = __half22float2(h[e]);
+                    acc[u] = fmaf(f.x, av[t][2 * e], acc[u]);
+                    acc[u] = fmaf(f.y, av[t][2 * e + 1], acc[u]);
+                }
+            }
+#pragma unroll
+        for (int u = 0; u < RIF; ++u) {
+            float v = acc[u];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            acc[u] = v;
+        }
+        if (lane < RIF) {
+            const int n = o0 + lane;
+            float v = 0.0f;
+#pragma unroll
+            for (int uu = 0; uu < RIF; ++uu) if (uu == lane) v = acc[uu];
+            if (n < a.N) {
+                const bool pre = o0 == gw * RIF;
+                const float bias = pre ? bias_pre : (a.bias ? a.bias[n] : 0.0f);
+                const float resid = a.resid ? (pre ? resid_pre : a.resid[n]) : 0.0f;
+                switch (a.epi) {
+                    case EPI_F16_BIAS:       ((__half *) a.C)[n] = __float2half_rn(v + bias); break;
+                    case EPI_F16_BIAS_GELU:  ((__half *) a.C)[n] = __float2half_rn(gelu16(v + bias)); break;
+                    case EPI_F32_BIAS_RESID: ((float *) a.C)[n] = (v + bias) + resid; break;
+                    case EPI_Q_SCALED:       ((__half *) a.C)[n] = __float2half_rn((v + bias) * a.scale); break;
+                    case EPI_QKV_DEC: {
+                        const int seg = __builtin_amdgcn_readfirstlane(o0 / a.S);      // wave-uniform, see DESIGN.md §7
+                        const int c = n - seg * a.S;
+                        __half * dst; float val;
+                        if (seg == 0)      { dst = (__half *) a.C;                                val = (v + bias) * a.scale; }
+                        else if (seg == 1) { dst = (__half *) a.aux  + (size_t) ro_pre * a.ldaux;  val = v * a.scale; }
+                        else               { dst = (__half *) a.aux2 + (size_t) ro_pre * a.ldaux2; val = v + bias; }
+                        dst[c] = __float2half_rn(val);
+                    } break;
+                    case EPI_LOGITS:         ((float *) a.C)[n] = v; break;
+                    default: break;
+                }
+            }
+        }
+    }
+}
+
+template <int RIF, int NCH, bool NT = false>
+void launch_gemv1(const GemvArgs & a, hipStream_t st, int max_blocks = 512) {
+    size_t smem = 0;
+    if (a.sa_q)        smem = ((((size_t) a.K * sizeof(__half)) + 15) & ~(size_t) 15) + ((size_t) (a.K / 64) * a.sa_cap + a.K) * sizeof(float);
+    else if (a.comb_o) smem = (size_t) a.K * sizeof(__half);
+    int blocks = (a.N + 4 * RIF - 1) / (4 * RIF);
+    if (blocks > max_blocks) blocks = max_blocks;
+    static size_t attr_bytes = 0;
+    if (smem > 48 * 1024 && smem > attr_bytes) {
+        (void) hipFuncSetAttribute((const void *) k_gemv1<RIF, NCH, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+        attr_bytes = smem;
+    }
+    hipLaunchKernelGGL((k_gemv1<RIF, NCH, NT>), dim3(blocks), dim3(256), smem, st, a);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -481,24 +702,31 @@ void launch_rows_mfma(const GemvArgs & a, hipStream_t st) {
     hipLaunchKernelGGL((k_rows_mfma<KSPLIT>), dim3(blocks), dim3(256), smem, st, a);
 }
 
-template <int R, int RIF>
-void launch_gemv_t(const GemvArgs & a, hipStream_t st) {
+template <int R, int RIF, bool NT = false>
+void launch_gemv_t(const GemvArgs & a, hipStream_t st, int max_blocks = 512) {
     size_t smem = (size_t) R * a.K * sizeof(__half);
     if (a.sa_q) smem = ((smem + 15) & ~(size_t) 15) + ((size_t) (a.K / 64) * a.sa_cap + a.K) * sizeof(float);
     int blocks = (a.N + 4 * RIF - 1) / (4 * RIF);
-    if (blocks > 512) blocks = 512;                     // 2 workgroups per CU; longer rows-per-wave loops are software-pipelined
+    if (blocks > max_blocks) blocks = max_blocks;       // 2 workgroups per CU; longer rows-per-wave loops are software-pipelined
     static size_t attr_bytes = 0;
     if (smem > 48 * 1024 && smem > attr_bytes) {
-        (void) hipFuncSetAttribute((const void *) k_gemv<R, RIF>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+        (void) hipFuncSetAttribute((const void *) k_gemv<R, RIF, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
         attr_bytes = smem;
     }
-    hipLaunchKernelGGL((k_gemv<R, RIF>), dim3(blocks), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((k_gemv<R, RIF, NT>), dim3(blocks), dim3(256), smem, st, a);
 }
 
 template <int R>
 void launch_gemv(const GemvArgs & a, hipStream_t st) {
     // the vocabulary projection streams 53 MB: keep 8 rows (8 KB) per wavefront in flight; small matrices use 4
-    if (R == 1 && a.N >= 16384) launch_gemv_t<1, 8>(a, st);
+    if (R == 1 && a.N >= 16384) {
+        static const int rif = getenv("WMI_LOGITS_RIF") ? atoi(getenv("WMI_LOGITS_RIF")) : 8;          // A/B knobs
+        static const int mb = getenv("WMI_LOGITS_BLOCKS") ? atoi(getenv("WMI_LOGITS_BLOCKS")) : 512;
+        static const bool nt = getenv("WMI_LOGITS_NT") != nullptr;
+        if (rif == 16)     { if (nt) launch_gemv_t<1, 16, true>(a, st, mb); else launch_gemv_t<1, 16>(a, st, mb); }
+        else if (rif == 4) { if (nt) launch_gemv_t<1, 4, true>(a, st, mb);  else launch_gemv_t<1, 4>(a, st, mb); }
+        else               { if (nt) launch_gemv_t<1, 8, true>(a, st, mb);  else launch_gemv_t<1, 8>(a, st, mb); }
+    }
     else launch_gemv_t<R, 4>(a, st);
 }
 
@@ -532,6 +760,18 @@ void gemv(const GemvArgs & a, hipStream_t st) {
                          (a.epi != EPI_QKV_DEC || (a.S % 16) == 0) && (!rows_valu || a.n > 8);
     if (mfma_ok) {
         if (a.N >= 8192) launch_rows_mfma<false>(a, st); else launch_rows_mfma<true>(a, st);
+        return;
+    }
+    static const bool gemv1_off = getenv("WMI_GEMV1_OFF") != nullptr;       // debug / A-B: LDS-staged one-row path
+    static const int gemv1_mask = getenv("WMI_GEMV1_MASK") ? atoi(getenv("WMI_GEMV1_MASK")) : 0;   // debug: per-prologue opt-out
+    const int kind = a.ln_g ? 1 : a.sa_q ? 2 : a.comb_o ? 4 : 8;
+    if (a.n == 1 && !a.lanes && a.K <= 2048 && (a.K % 8) == 0 && !gemv1_off && !(gemv1_mask & kind) && (!a.ln_g || a.K <= 1536)) {
+        const int nch = (a.K + 511) / 512;
+        if (a.N >= 16384) {                       // vocabulary projection: 8 rows (8 KB) per wavefront in flight
+            if (nch == 1) launch_gemv1<8, 1>(a, st); else if (nch == 2) launch_gemv1<8, 2>(a, st); else if (nch == 3) launch_gemv1<8, 3>(a, st); else launch_gemv1<4, 4>(a, st);
+        } else {
+            if (nch == 1) launch_gemv1<4, 1>(a, st); else if (nch == 2) launch_gemv1<4, 2>(a, st); else if (nch == 3) launch_gemv1<4, 3>(a, st); else launch_gemv1<4, 4>(a, st);
+        }
         return;
     }
     switch (a.n) {
