@@ -394,10 +394,14 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
             wpre[u] = ldw<NT>(a.W + (size_t) o * K + lane * 8);
         }
     }
+    // after the halving reduction below, row u of a tile ends up on the lanes with (lane / LPR) % RIF == u; lane u * LPR writes it
+    constexpr int LPR = 64 / RIF;                           // 16 (RIF 4) or 8 (RIF 8)
+    const int wrow = lane / LPR;                            // row this lane would write
+    const bool writer = (lane % LPR) == 0;
     float bias_pre = 0.0f, resid_pre = 0.0f; int ro_pre = 0;
     {
-        const int n = gw * RIF + lane;
-        if (lane < RIF && n < a.N) {
+        const int n = gw * RIF + wrow;
+        if (writer && n < a.N) {
             if (a.bias) bias_pre = a.bias[n];
             if (a.resid) resid_pre = a.resid[n];
         }
@@ -493,17 +497,25 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
                     acc[u] = fmaf(f.y, av[t][2 * e + 1], acc[u]);
                 }
             }
+        // 64-lane sums of RIF values by halving exchange: at mask m a lane keeps the half of the rows selected by its
+        // bit m and receives the partner's partial for those rows — the same pairs in the same order as RIF separate
+        // butterflies (bit-identical totals), with RIF - 1 + log2(64 / RIF) shuffles instead of 6 RIF
+        float v;
+        if (RIF == 8) {
 #pragma unroll
-        for (int u = 0; u < RIF; ++u) {
-            float v = acc[u];
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-            acc[u] = v;
+            for (int u = 0; u < 4; ++u) { const bool hi = lane & 32; const float keep = hi ? acc[u + 4] : acc[u], send = hi ? acc[u] : acc[u + 4]; acc[u] = keep + __shfl_xor(send, 32); }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const bool hi = lane & 16; const float keep = hi ? acc[u + 2] : acc[u], send = hi ? acc[u] : acc[u + 2]; acc[u] = keep + __shfl_xor(send, 16); }
+            { const bool hi = lane & 8; const float keep = hi ? acc[1] : acc[0], send = hi ? acc[0] : acc[1]; v = keep + __shfl_xor(send, 8); }
+            v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const bool hi = lane & 32; const float keep = hi ? acc[u + 2] : acc[u], send = hi ? acc[u] : acc[u + 2]; acc[u] = keep + __shfl_xor(send, 32); }
+            { const bool hi = lane & 16; const float keep = hi ? acc[1] : acc[0], send = hi ? acc[0] : acc[1]; v = keep + __shfl_xor(send, 16); }
+            v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
         }
-        if (lane < RIF) {
-            const int n = o0 + lane;
-            float v = 0.0f;
-#pragma unroll
-            for (int uu = 0; uu < RIF; ++uu) if (uu == lane) v = acc[uu];
+        if (writer) {
+            const int n = o0 + wrow;
             if (n < a.N) {
                 const bool pre = o0 == gw * RIF;
                 const float bias = pre ? bias_pre : (a.bias ? a.bias[n] : 0.0f);
