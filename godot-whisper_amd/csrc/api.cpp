@@ -311,6 +311,10 @@ int wmi_get_tensor(struct whisper_context * ctx, const char * name, float * dst,
     else if (nm == "cross_v")   { src = d.kvc_v; count = (size_t) Lt * T * S; is_half = true; }
     else if (nm == "self_k")    { src = st.kv_self.k; count = (size_t) Lt * st.kv_self.size * S; is_half = true; }
     else if (nm == "self_v")    { src = st.kv_self.v; count = (size_t) Lt * st.kv_self.size * S; is_half = true; }
+    // lock-step work buffers of the last wmi_full_batch group (debug / tests): [L][rows*T][S] and [rows*T][S]
+    else if (nm == "batch_cross_k" && ctx->batch) { src = ctx->batch->kvc_k; count = (size_t) Lt * ctx->batch->enc_rows * ctx->batch->enc_T * S; is_half = true; }
+    else if (nm == "batch_cross_v" && ctx->batch) { src = ctx->batch->kvc_v; count = (size_t) Lt * ctx->batch->enc_rows * ctx->batch->enc_T * S; is_half = true; }
+    else if (nm == "batch_enc_x" && ctx->batch)   { src = ctx->batch->x; count = (size_t) ctx->batch->enc_rows * ctx->batch->enc_T * S; }
     else return -1;
     if (!dst) return (int) count;
     if (!src) return -1;

@@ -27,7 +27,7 @@ typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float    floatx4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ float round_f16(float x) { return __half2float(__float2half_rn(x)); }
+__device__ __forceinline__ float round_f16(float x) { return __half2float(f2h(x)); }
 // the reference's exp-through-f16-table (W/ggml.c:11176-11186)
 __device__ __forceinline__ float exp16(float d) { return round_f16(expf(round_f16(d))); }
 // encoder variant: hardware exp2 path (v_exp_f32, ~2 ulp) — 18 M evaluations per layer make the libm expf the
@@ -160,7 +160,7 @@ __global__ __launch_bounds__(NW * 64) void k_attn_enc(const __half * __restrict_
         if (qg < T) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
-                out[(size_t) qg * S + head * 64 + nt * 16 + fr] = __float2half_rn(o[nt][r] * li);
+                out[(size_t) qg * S + head * 64 + nt * 16 + fr] = f2h(o[nt][r] * li);
         }
     }
 }
@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256) void k_attn_dec(const __half * __restrict__ q,
     __syncthreads();
     if (tid < 64) {
         const float r = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
-        out[(size_t) i * S + head * 64 + tid] = __float2half_rn(r);
+        out[(size_t) i * S + head * 64 + tid] = f2h(r);
     }
 }
 
@@ -461,7 +461,7 @@ __global__ __launch_bounds__(64) void k_xattn_combine(const float * __restrict__
     const size_t row = (size_t) i * H + head;
     float o = 0.0f; double l = 0.0;
     for (int s2 = 0; s2 < ns; ++s2) { o += part_o[(row * ns + s2) * 64 + d]; l += (double) part_l[row * ns + s2]; }
-    out[(size_t) i * S + head * 64 + d] = __float2half_rn(o * (float) (1.0 / l));
+    out[(size_t) i * S + head * 64 + d] = f2h(o * (float) (1.0 / l));
 }
 
 } // namespace

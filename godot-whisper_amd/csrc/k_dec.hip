@@ -20,7 +20,7 @@ namespace wmi { namespace k {
 
 namespace {
 
-__device__ __forceinline__ float round_f16(float x) { return __half2float(__float2half_rn(x)); }
+__device__ __forceinline__ float round_f16(float x) { return __half2float(f2h(x)); }
 __device__ __forceinline__ float gelu16(float x) {
     const float xh = round_f16(x);
     const float g  = 0.5f * xh * (1.0f + tanhf(0.79788456080286535587989211986876f * xh * (1.0f + 0.044715f * xh * xh)));
@@ -104,7 +104,7 @@ __device__ __forceinline__ void self_attn_row(const __half * __restrict__ sq, co
             for (int t = 0; t < 8; ++t) acc = fmaf(row[j + t], __half2float(vv[t]), acc);
         }
         for (; j < n_kv; ++j) acc = fmaf(row[j], __half2float(vp[(size_t) j * K]), acc);
-        out[c] = __float2half_rn(acc);
+        out[c] = f2h(acc);
     }
 }
 
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
             const size_t row = (size_t) r * H + h;
             float o = 0.0f; double l = 0.0;
             for (int s2 = 0; s2 < ns; ++s2) { o += a.comb_o[(row * ns + s2) * 64 + dd]; l += (double) a.comb_l[row * ns + s2]; }
-            act[e] = __float2half_rn(o * (float) (1.0 / l));
+            act[e] = f2h(o * (float) (1.0 / l));
         }
     } else {
         for (int r = 0; r < R; ++r) {
@@ -342,10 +342,10 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
                 const float bias = pre ? bias_pre : (a.bias ? a.bias[n] : 0.0f);
                 const float resid = a.resid ? (pre ? resid_pre : a.resid[(size_t) r * a.ldr + n]) : 0.0f;
                 switch (a.epi) {
-                    case EPI_F16_BIAS:       ((__half *) a.C)[(size_t) r * a.ldc + n] = __float2half_rn(v + bias); break;
-                    case EPI_F16_BIAS_GELU:  ((__half *) a.C)[(size_t) r * a.ldc + n] = __float2half_rn(gelu16(v + bias)); break;
+                    case EPI_F16_BIAS:       ((__half *) a.C)[(size_t) r * a.ldc + n] = f2h(v + bias); break;
+                    case EPI_F16_BIAS_GELU:  ((__half *) a.C)[(size_t) r * a.ldc + n] = f2h(gelu16(v + bias)); break;
                     case EPI_F32_BIAS_RESID: ((float *) a.C)[(size_t) r * a.ldc + n] = (v + bias) + resid; break;
-                    case EPI_Q_SCALED:       ((__half *) a.C)[(size_t) r * a.ldc + n] = __float2half_rn((v + bias) * a.scale); break;
+                    case EPI_Q_SCALED:       ((__half *) a.C)[(size_t) r * a.ldc + n] = f2h((v + bias) * a.scale); break;
                     case EPI_QKV_DEC: {
                         // segment decided on a wave-uniform value (the 4 rows of this wave iteration never straddle a
                         // q|k|v boundary: S % 4 == 0) — same precaution as in k_gemm.hip, see DESIGN.md §7
@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
                         if (seg == 0)      { dst = (__half *) a.C    + (size_t) r * a.ldc;                  val = (v + bias) * a.scale; }
                         else if (seg == 1) { dst = (__half *) a.aux  + crow + (size_t) slot * a.ldaux;      val = v * a.scale; }
                         else               { dst = (__half *) a.aux2 + crow + (size_t) slot * a.ldaux2;     val = v + bias; }
-                        dst[c] = __float2half_rn(val);
+                        dst[c] = f2h(val);
                     } break;
                     case EPI_LOGITS:         ((float *) a.C)[(size_t) r * a.ldc + n] = v; break;
                     default: break;
@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
                 const int h = e >> 6, dd = e & 63;
                 float o = 0.0f; double l = 0.0;
                 for (int s2 = 0; s2 < ns; ++s2) { o += a.comb_o[((size_t) h * ns + s2) * 64 + dd]; l += (double) a.comb_l[(size_t) h * ns + s2]; }
-                act[e] = __float2half_rn(o * (float) (1.0 / l));
+                act[e] = f2h(o * (float) (1.0 / l));
             }
             (void) H;
             __syncthreads();
@@ -521,10 +521,10 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
                 const float bias = pre ? bias_pre : (a.bias ? a.bias[n] : 0.0f);
                 const float resid = a.resid ? (pre ? resid_pre : a.resid[n]) : 0.0f;
                 switch (a.epi) {
-                    case EPI_F16_BIAS:       ((__half *) a.C)[n] = __float2half_rn(v + bias); break;
-                    case EPI_F16_BIAS_GELU:  ((__half *) a.C)[n] = __float2half_rn(gelu16(v + bias)); break;
+                    case EPI_F16_BIAS:       ((__half *) a.C)[n] = f2h(v + bias); break;
+                    case EPI_F16_BIAS_GELU:  ((__half *) a.C)[n] = f2h(gelu16(v + bias)); break;
                     case EPI_F32_BIAS_RESID: ((float *) a.C)[n] = (v + bias) + resid; break;
-                    case EPI_Q_SCALED:       ((__half *) a.C)[n] = __float2half_rn((v + bias) * a.scale); break;
+                    case EPI_Q_SCALED:       ((__half *) a.C)[n] = f2h((v + bias) * a.scale); break;
                     case EPI_QKV_DEC: {
                         const int seg = __builtin_amdgcn_readfirstlane(o0 / a.S);      // wave-uniform, see DESIGN.md §7
                         const int c = n - seg * a.S;
@@ -532,7 +532,7 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
                         if (seg == 0)      { dst = (__half *) a.C;                                val = (v + bias) * a.scale; }
                         else if (seg == 1) { dst = (__half *) a.aux  + (size_t) ro_pre * a.ldaux;  val = v * a.scale; }
                         else               { dst = (__half *) a.aux2 + (size_t) ro_pre * a.ldaux2; val = v + bias; }
-                        dst[c] = __float2half_rn(val);
+                        dst[c] = f2h(val);
                     } break;
                     case EPI_LOGITS:         ((float *) a.C)[n] = v; break;
                     default: break;
@@ -623,7 +623,7 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
 #pragma unroll
             for (int j = 0; j < XV; ++j) {
                 const int c = lane + 64 * j;
-                if (c < K) act[r * lda + c] = __float2half_rn(__fadd_rn(__fmul_rn(xv[j] * sc, gv[j]), bv[j]));
+                if (c < K) act[r * lda + c] = f2h(__fadd_rn(__fmul_rn(xv[j] * sc, gv[j]), bv[j]));
             }
         }
     } else {
@@ -679,10 +679,10 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
             const float v = acc[r];
             const float bias = a.bias ? a.bias[nf_] : 0.0f;
             switch (a.epi) {
-                case EPI_F16_BIAS:       ((__half *) a.C)[(size_t) col * a.ldc + nf_] = __float2half_rn(v + bias); break;
-                case EPI_F16_BIAS_GELU:  ((__half *) a.C)[(size_t) col * a.ldc + nf_] = __float2half_rn(gelu16(v + bias)); break;
+                case EPI_F16_BIAS:       ((__half *) a.C)[(size_t) col * a.ldc + nf_] = f2h(v + bias); break;
+                case EPI_F16_BIAS_GELU:  ((__half *) a.C)[(size_t) col * a.ldc + nf_] = f2h(gelu16(v + bias)); break;
                 case EPI_F32_BIAS_RESID: ((float *) a.C)[(size_t) col * a.ldc + nf_] = (v + bias) + a.resid[(size_t) col * a.ldr + nf_]; break;
-                case EPI_Q_SCALED:       ((__half *) a.C)[(size_t) col * a.ldc + nf_] = __float2half_rn((v + bias) * a.scale); break;
+                case EPI_Q_SCALED:       ((__half *) a.C)[(size_t) col * a.ldc + nf_] = f2h((v + bias) * a.scale); break;
                 case EPI_QKV_DEC: {
                     const int c = nf_ - seg * a.S;
                     const int64_t crow = a.lanes ? (int64_t) col * a.cache_row_stride : 0;
@@ -691,7 +691,7 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
                     if (seg == 0)      { dst = (__half *) a.C    + (size_t) col * a.ldc;              val = (v + bias) * a.scale; }
                     else if (seg == 1) { dst = (__half *) a.aux  + crow + (size_t) slot * a.ldaux;    val = v * a.scale; }
                     else               { dst = (__half *) a.aux2 + crow + (size_t) slot * a.ldaux2;   val = v + bias; }
-                    dst[c] = __float2half_rn(val);
+                    dst[c] = f2h(val);
                 } break;
                 case EPI_LOGITS:         ((float *) a.C)[(size_t) col * a.ldc + nf_] = v; break;
                 default: break;

@@ -18,6 +18,9 @@
 
 #include "kernels.h"
 
+#include <cstdlib>
+#include <type_traits>
+
 namespace wmi { namespace k {
 
 namespace {
@@ -28,7 +31,7 @@ typedef float    floatx4 __attribute__((ext_vector_type(4)));
 
 constexpr int BK = 64;                 // K extent of one LDS tile (two MFMA k-steps)
 
-__device__ __forceinline__ float round_f16(float x) { return __half2float(__float2half_rn(x)); }
+__device__ __forceinline__ float round_f16(float x) { return __half2float(f2h(x)); }
 
 // GELU exactly as the reference evaluates it: input rounded to f16, tanh form in f32, result rounded
 // to f16 (its 65536-entry table is this function tabulated; W/ggml.c:1400-1423, 2229-2231)
@@ -103,14 +106,8 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
         for (int p = 0; p < LB; ++p) *(uint4 *) (sB(buf) + lds_off(p * 32 + srow, schunk)) = rb[p];
     };
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
     const int frow = lane & 15, fq = lane >> 4;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);
+    auto compute = [&](int buf) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             half8 fa[FM], fb[FN];
@@ -126,91 +123,152 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
                 for (int j = 0; j < FN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
         }
-        if (kt + 1 < nk) store_tile(buf ^ 1);
+    };
+
+    if (BM == 128 && BN == 128 && (a.K % BK) == 0 && !(a.no_glds & 1)) {
+        // Large tiles (batched encoder, cross K/V): operands go global -> LDS directly (global_load_lds, 16 B per lane,
+        // 1 KiB per wave instruction, no staging VGPRs or ds_write pass).  LDS is written lane-linearly, so the XOR
+        // swizzle is applied to each lane's GLOBAL address instead: position p = row*8 + (chunk ^ (row & 7)) of a
+        // piece of 8 rows is fetched by lane p.  One barrier per K step: tile kt+1 is in flight while kt is multiplied.
+        // (profiles/: +38 % on the M = 12 000 encoder GEMMs over the register-staged loop)
+        constexpr int PA = BM / 32, PB = BN / 32;             // 1 KiB pieces per wavefront per operand
+        const int prow = lane >> 3;
+        const __half * qA[PA]; const __half * qB[PB];
+#pragma unroll
+        for (int p = 0; p < PA; ++p) {
+            const int lrow = (wave * PA + p) * 8 + prow, pch = (lane & 7) ^ (lrow & 7);
+            int r = m0 + lrow; if (r > a.M - 1) r = a.M - 1;
+            qA[p] = a.A + (size_t) r * a.lda + pch * 8;
+        }
+#pragma unroll
+        for (int p = 0; p < PB; ++p) {
+            const int lrow = (wave * PB + p) * 8 + prow, pch = (lane & 7) ^ (lrow & 7);
+            int r = n0 + lrow; if (r > a.N - 1) r = a.N - 1;
+            qB[p] = a.W + (size_t) r * a.ldw + pch * 8;
+        }
+        auto issue = [&](int kt, int buf) {
+#pragma unroll
+            for (int p = 0; p < PA; ++p)
+                __builtin_amdgcn_global_load_lds((const void *) (qA[p] + kt * BK), (__attribute__((address_space(3))) void *) (sA(buf) + (wave * PA + p) * 1024), 16, 0, 0);
+#pragma unroll
+            for (int p = 0; p < PB; ++p)
+                __builtin_amdgcn_global_load_lds((const void *) (qB[p] + kt * BK), (__attribute__((address_space(3))) void *) (sB(buf) + (wave * PB + p) * 1024), 16, 0, 0);
+        };
+        issue(0, 0);
+        for (int kt = 0; kt < nk; ++kt) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                  // tile kt landed for everyone; buffer (kt + 1) & 1 is free again
+            if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
+            compute(kt & 1);
+        }
+    } else {
+        load_tile(0);
+        store_tile(0);
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) load_tile(kt + 1);
+            compute(buf);
+            if (kt + 1 < nk) store_tile(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     // ------------------------------------------------------------------ epilogue
-    // fragment (i, j): rows m = mb + i*16 + fq*4 + r (r = 0..3), column n = nb + j*16 + frow
+    // fragment (i, j): rows m = mb + i*16 + fq*4 + r (r = 0..3), column n = nb + j*16 + frow.
+    // Interior tiles take an instantiation without bounds checks: a per-element `if (m < M)` makes every store its own
+    // basic block, and hipcc then waits vmcnt(0) before each one (vmcnt also counts stores on gfx9-family parts), i.e.
+    // the 64 stores of a lane complete one after the other (profiles/: -10..30 % kernel time on the M = 12 000 GEMMs).
     const int mb = m0 + wm * (BM / 2), nb = n0 + wn * (BN / 2);
+    auto epilogue = [&](auto guard_tag) {
+        constexpr bool GUARD = decltype(guard_tag)::value;
+        float biasv[FN];
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-        const int n = nb + j * 16 + frow;
-        if (n >= a.N) continue;
-        const float bias = a.bias ? a.bias[n] : 0.0f;
+        for (int j = 0; j < FN; ++j) {
+            const int n = nb + j * 16 + frow;
+            biasv[j] = (a.bias && (!GUARD || n < a.N)) ? a.bias[n] : 0.0f;
+        }
 #pragma unroll
-        for (int i = 0; i < FM; ++i) {
-            const int mrow = mb + i * 16 + fq * 4;
-            if constexpr (EPI == EPI_QKV_ENC) {
-                const int seg = n / a.S, c = n - seg * a.S;
-                if (seg == 2) {            // V^T: four consecutive time steps per lane -> one 8-byte store
-                    // batched encode: row m = chunk * rows_per_chunk + t, V^T is [chunk][S][Tpad]
-                    const int rpc = a.rows_per_chunk > 0 ? a.rows_per_chunk : a.M;
-                    const int cb = mrow / rpc, t0 = mrow - cb * rpc;
-                    __half * vt = (__half *) a.aux2 + (size_t) cb * a.chunk_stride_aux2 + (size_t) c * a.ldaux2;
-                    if (mrow + 3 < a.M && t0 + 3 < rpc && ((t0 & 3) == 0)) {
-                        half4 v;
+        for (int j = 0; j < FN; ++j) {
+            const int n = nb + j * 16 + frow;
+            if (GUARD && n >= a.N) continue;
+            const float bias = biasv[j];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = (_Float16) (acc[i][j][r] + bias);
-                        *(half4 *) (vt + t0) = v;
-                    } else {
-                        for (int r = 0; r < 4; ++r) {
-                            const int m = mrow + r;
-                            if (m >= a.M) continue;
-                            const int cb2 = m / rpc, t = m - cb2 * rpc;
-                            ((__half *) a.aux2)[(size_t) cb2 * a.chunk_stride_aux2 + (size_t) c * a.ldaux2 + t] = __float2half_rn(acc[i][j][r] + bias);
+            for (int i = 0; i < FM; ++i) {
+                const int mrow = mb + i * 16 + fq * 4;
+                if constexpr (EPI == EPI_QKV_ENC) {
+                    const int seg = n / a.S, c = n - seg * a.S;
+                    if (seg == 2) {            // V^T: four consecutive time steps per lane -> one 8-byte store
+                        // batched encode: row m = chunk * rows_per_chunk + t, V^T is [chunk][S][Tpad]
+                        const int rpc = a.rows_per_chunk > 0 ? a.rows_per_chunk : a.M;
+                        const int cb = mrow / rpc, t0 = mrow - cb * rpc;
+                        __half * vt = (__half *) a.aux2 + (size_t) cb * a.chunk_stride_aux2 + (size_t) c * a.ldaux2;
+                        if ((!GUARD || mrow + 3 < a.M) && t0 + 3 < rpc && ((t0 & 3) == 0)) {
+                            half4 v;
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) v[r] = (_Float16) pin_f32(acc[i][j][r] + bias);
+                            *(half4 *) (vt + t0) = v;
+                        } else {
+                            for (int r = 0; r < 4; ++r) {
+                                const int m = mrow + r;
+                                if (m >= a.M) continue;
+                                const int cb2 = m / rpc, t = m - cb2 * rpc;
+                                ((__half *) a.aux2)[(size_t) cb2 * a.chunk_stride_aux2 + (size_t) c * a.ldaux2 + t] = f2h(acc[i][j][r] + bias);
+                            }
                         }
+                        continue;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = mrow + r;
+                        if (GUARD && m >= a.M) continue;
+                        const float v = acc[i][j][r] + bias;
+                        if (seg == 0) ((__half *) a.C)[(size_t) m * a.ldc + c] = f2h(v);
+                        else          ((__half *) a.aux)[(size_t) m * a.ldaux + c] = f2h(v);
                     }
                     continue;
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = mrow + r;
-                    if (m >= a.M) continue;
-                    const float v = acc[i][j][r] + bias;
-                    if (seg == 0) ((__half *) a.C)[(size_t) m * a.ldc + c] = __float2half_rn(v);
-                    else          ((__half *) a.aux)[(size_t) m * a.ldaux + c] = __float2half_rn(v);
-                }
-                continue;
-            }
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = mrow + r;
-                if (m >= a.M) continue;
-                const float v = acc[i][j][r];
-                if constexpr (EPI == EPI_F16_BIAS) {
-                    ((__half *) a.C)[(size_t) m * a.ldc + n] = __float2half_rn(v + bias);
-                } else if constexpr (EPI == EPI_F16_BIAS_GELU) {
-                    ((__half *) a.C)[(size_t) m * a.ldc + n] = __float2half_rn(gelu16(v + bias));
-                } else if constexpr (EPI == EPI_F32_BIAS_RESID) {
-                    ((float *) a.C)[(size_t) m * a.ldc + n] = (v + bias) + a.resid[(size_t) m * a.ldr + n];
-                } else if constexpr (EPI == EPI_CONV2) {
-                    const float g = gelu16(v + bias);
-                    if (a.aux) ((float *) a.aux)[(size_t) m * a.ldaux + n] = g;
-                    ((float *) a.C)[(size_t) m * a.ldc + n] = a.resid[(size_t) m * a.ldr + n] + g;
-                } else if constexpr (EPI == EPI_QKV_DEC) {
-                    // The q | k | v segment is decided per 16-column fragment on a WAVE-UNIFORM value
-                    // (S is a multiple of 16, so a fragment never straddles a segment).  A per-lane
-                    // three-way `if` here is miscompiled by hipcc 7.2 for gfx950 (the third arm's
-                    // pointer select is dropped by the control-flow structurizer: v lands in the k
-                    // cache) — see DESIGN.md "toolchain hazards"; tests/test_gpu_kernels.py pins it.
-                    const int seg = __builtin_amdgcn_readfirstlane((nb + j * 16) / a.S);
-                    const int c = n - seg * a.S;
-                    __half * dst; float val;
-                    if (seg == 0)      { dst = (__half *) a.C    + (size_t) m * a.ldc;    val = (v + bias) * a.scale; }
-                    else if (seg == 1) { dst = (__half *) a.aux  + (size_t) m * a.ldaux;  val = v * a.scale; }
-                    else               { dst = (__half *) a.aux2 + (size_t) m * a.ldaux2; val = v + bias; }
-                    dst[c] = __float2half_rn(val);
-                } else if constexpr (EPI == EPI_CROSS_KV) {
-                    const int il = n / (2 * a.S), c = n - il * 2 * a.S;
-                    if (c < a.S) ((__half *) a.C)[il * a.layer_stride + (size_t) m * a.ldc + c] = __float2half_rn(v * a.scale);
-                    else         ((__half *) a.aux)[il * a.layer_stride + (size_t) m * a.ldaux + (c - a.S)] = __float2half_rn(v + bias);
-                } else if constexpr (EPI == EPI_Q_SCALED) {
-                    ((__half *) a.C)[(size_t) m * a.ldc + n] = __float2half_rn((v + bias) * a.scale);
+                    if (GUARD && m >= a.M) continue;
+                    const float v = acc[i][j][r];
+                    if constexpr (EPI == EPI_F16_BIAS) {
+                        ((__half *) a.C)[(size_t) m * a.ldc + n] = f2h(v + bias);
+                    } else if constexpr (EPI == EPI_F16_BIAS_GELU) {
+                        ((__half *) a.C)[(size_t) m * a.ldc + n] = f2h(gelu16(v + bias));
+                    } else if constexpr (EPI == EPI_F32_BIAS_RESID) {
+                        ((float *) a.C)[(size_t) m * a.ldc + n] = (v + bias) + a.resid[(size_t) m * a.ldr + n];
+                    } else if constexpr (EPI == EPI_CONV2) {
+                        const float g = gelu16(v + bias);
+                        if (a.aux) ((float *) a.aux)[(size_t) m * a.ldaux + n] = g;
+                        ((float *) a.C)[(size_t) m * a.ldc + n] = a.resid[(size_t) m * a.ldr + n] + g;
+                    } else if constexpr (EPI == EPI_QKV_DEC) {
+                        // The q | k | v segment is decided per 16-column fragment on a WAVE-UNIFORM value
+                        // (S is a multiple of 16, so a fragment never straddles a segment).  A per-lane
+                        // three-way `if` here is miscompiled by hipcc 7.2 for gfx950 (the third arm's
+                        // pointer select is dropped by the control-flow structurizer: v lands in the k
+                        // cache) — see DESIGN.md "toolchain hazards"; tests/test_gpu_kernels.py pins it.
+                        const int seg = __builtin_amdgcn_readfirstlane((nb + j * 16) / a.S);
+                        const int c = n - seg * a.S;
+                        __half * dst; float val;
+                        if (seg == 0)      { dst = (__half *) a.C    + (size_t) m * a.ldc;    val = (v + bias) * a.scale; }
+                        else if (seg == 1) { dst = (__half *) a.aux  + (size_t) m * a.ldaux;  val = v * a.scale; }
+                        else               { dst = (__half *) a.aux2 + (size_t) m * a.ldaux2; val = v + bias; }
+                        dst[c] = f2h(val);
+                    } else if constexpr (EPI == EPI_CROSS_KV) {
+                        const int il = n / (2 * a.S), c = n - il * 2 * a.S;
+                        if (c < a.S) ((__half *) a.C)[il * a.layer_stride + (size_t) m * a.ldc + c] = f2h(v * a.scale);
+                        else         ((__half *) a.aux)[il * a.layer_stride + (size_t) m * a.ldaux + (c - a.S)] = f2h(v + bias);
+                    } else if constexpr (EPI == EPI_Q_SCALED) {
+                        ((__half *) a.C)[(size_t) m * a.ldc + n] = f2h((v + bias) * a.scale);
+                    }
                 }
             }
         }
-    }
+    };
+    if (m0 + BM <= a.M && n0 + BN <= a.N && !(a.no_glds & 2)) epilogue(std::false_type{});
+    else                                  epilogue(std::true_type{});
 }
 
 template <int BM, int BN, int EPI>
@@ -229,13 +287,16 @@ template <int EPI>
 void dispatch(const GemmArgs & a, hipStream_t st) {
     // 256 CUs: prefer the 128x128 tile only when it still yields >= ~1.5 waves of workgroups
     const long t128 = (long) ((a.M + 127) / 128) * ((a.N + 127) / 128);
-    if (t128 >= 384) launch<128, 128, EPI>(a, st);
+    if (t128 >= 384 || (t128 >= 256 && a.K >= 1024)) launch<128, 128, EPI>(a, st);
     else             launch<64, 64, EPI>(a, st);
 }
 
 } // namespace
 
-void gemm(int epi, const GemmArgs & a, hipStream_t st) {
+void gemm(int epi, const GemmArgs & a_in, hipStream_t st) {
+    static const bool no_glds = getenv("WMI_GEMM_NO_GLDS") != nullptr;       // debug / A-B: register-staged loop for every tile size
+    static const bool guard_all = getenv("WMI_GEMM_GUARD_ALL") != nullptr;   // debug / A-B: bounds-checked epilogue for every tile
+    GemmArgs a = a_in; a.no_glds = (no_glds ? 1 : 0) | (guard_all ? 2 : 0);
     switch (epi) {
         case EPI_F16_BIAS:       dispatch<EPI_F16_BIAS>(a, st); break;
         case EPI_F16_BIAS_GELU:  dispatch<EPI_F16_BIAS_GELU>(a, st); break;

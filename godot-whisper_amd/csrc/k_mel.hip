@@ -186,7 +186,7 @@ __global__ void k_mel_slice(const float * __restrict__ mel, int n_len, int n_mel
     __syncthreads();
     for (int j = ty; j < 32; j += 8) {
         const int r = r0 + j, c = c0 + tx;
-        if (r < rows_total && c < ld) out[(size_t) r * ld + c] = __float2half_rn(c < n_mel ? tile[tx][j] : 0.0f);
+        if (r < rows_total && c < ld) out[(size_t) r * ld + c] = f2h(c < n_mel ? tile[tx][j] : 0.0f);
     }
 }
 

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float * __restrict__ x,
             y.w = __fadd_rn(__fmul_rn(v[i].w * scale, gg.w), bb.w);
             if (out32) *(float4 *) (out32 + (size_t) row * S + c) = y;
             if (out16) {
-                __half2 h01 = __floats2half2_rn(y.x, y.y), h23 = __floats2half2_rn(y.z, y.w);
+                __half2 h01 = __floats2half2_rn(pin_f32(y.x), pin_f32(y.y)), h23 = __floats2half2_rn(pin_f32(y.z), pin_f32(y.w));
                 uint2 pk; pk.x = *(uint32_t *) &h01; pk.y = *(uint32_t *) &h23;
                 *(uint2 *) (out16 + (size_t) row * S + c) = pk;
             }

@@ -8,6 +8,16 @@
 
 namespace wmi { namespace k {
 
+// f32 -> f16 with the value pinned in a register first.  Without the empty asm the AMDGPU back end folds SOME of the
+// `cvt(mul)` / `cvt(add)` pairs of an unrolled epilogue into v_fma_mixlo_f16 — one rounding instead of the reference's
+// two (f32 op, then f16 store) — and which elements get the fused form depends on their slot in the tile, so identical
+// inputs gave results that differed in the last f16 bit with the position of a row in M (found by the lock-step
+// bit-exactness test; scratch/lab/pos_test.hip reproduces it).  -ffp-contract=off does not stop this fold.
+#if defined(__HIPCC__)
+__device__ __forceinline__ float pin_f32(float x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ __half f2h(float x) { return __float2half_rn(pin_f32(x)); }
+#endif
+
 // ---------------------------------------------------------------- mel (k_mel.hip)
 // pcm_pad: [200 reflect | n_samples | zeros] ; frames [0, n_fft_frames) get an FFT, the rest up to
 // n_len the constant log10(1e-10).  mel: [n_mel][n_len] f32.  gmax: ordered-int encoded running max.
@@ -48,6 +58,7 @@ struct GemmArgs {
     int64_t layer_stride;           // EPI_CROSS_KV: elements between layers in the cross cache
     int     rows_per_chunk;         // EPI_QKV_ENC, batched encode: M = chunks * rows_per_chunk (0: one chunk)
     int64_t chunk_stride_aux2;      //   elements between the chunks' V^T images
+    int     no_glds;                // debug: keep 128x128 tiles on the register-staged loop
 };
 void gemm(int epi, const GemmArgs & a, hipStream_t st);
 

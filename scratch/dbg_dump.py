@@ -4,12 +4,14 @@ import numpy as np
 import __graft_entry__ as ge
 ge.load_package()
 from godot_whisper_amd import host, runtime, synth
-import golden_util as gu
 lib = runtime.require_gpu(); runtime.silence_logs(lib)
+tag = sys.argv[1]
 model = synth.make_model("micro.en", seed=2024)
-pcm = synth.make_pcm(11.0, seed=101, gate=True)
+pcms = [synth.make_pcm(12.0, seed=100 + i, gate=(i % 3 == 1)) for i in range(3)]
 node = host.SpeechToText(lib); node.set_language_model(model)
-w = gu.tokens_array(node.transcribe(pcm, "", 0))
-lib.wmi_set_lockstep_exact(1)
-g = gu.tokens_array(node.transcribe_batch([pcm, pcm], "", 0)[1])
-print("max |dp| per token:", np.abs(g[:, 2] - w[:, 2]).round(7))
+node.transcribe(pcms[2], "", 0)
+out = {}
+for nm in ("embd_conv", "enc_x", "embd_enc", "cross_k", "cross_v"):
+    out[nm] = runtime.get_tensor(lib, node.ctx, nm)
+np.savez(f"gpurun_out/dump_{tag}.npz", **out)
+print("saved", tag)
