@@ -484,9 +484,21 @@ double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters) {
                 k::gemv(g, s);
             } break;
             case 2: k::attn_encoder(d.q, d.k, d.vt, T, d.Tpad, S, H, 0.125f, d.att, s); break;
+            case 4: {                                  // mlp.0 over the lock-step work buffers: M = chunks * T
+                const BatchWork & b = *ctx->batch;
+                k::GemmArgs a{};
+                a.A = b.xn; a.lda = S; a.W = w.enc[0].w_fc1; a.ldw = S; a.M = b.B * T; a.N = 4 * S; a.K = S; a.bias = w.enc[0].b_fc1;
+                a.C = b.h; a.ldc = 4 * S;
+                k::gemm(k::EPI_F16_BIAS_GELU, a, s);
+            } break;
+            case 5: {                                  // encoder attention of all lock-step chunks
+                const BatchWork & b = *ctx->batch;
+                k::attn_encoder(b.q, b.k, b.vt, T, b.Tpad, S, H, 0.125f, b.att, s, b.B);
+            } break;
             default: break;
         }
     };
+    if ((which == 4 || which == 5) && (!ctx->batch || ctx->batch->B < 1)) { (void) hipEventDestroy(e0); (void) hipEventDestroy(e1); return -1.0; }
     if (which >= 10 && which <= 12) {                                   // launch-floor probes: chains of trivial dependent kernels
         const int blocks = which == 10 ? 1 : which == 11 ? 32 : 256;
         int * p = (int *) d.mel_max;

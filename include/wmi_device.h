@@ -112,6 +112,9 @@ WHISPER_API double wmi_selftest_proj(struct whisper_context * ctx, int op, int n
  *   which = 1  logits GEMV         [n_vocab x S] weight stream (bytes = n_vocab*S*2)
  *   which = 2  encoder attention   one layer
  *   which = 3  full encode (conv + L blocks + cross) — same as whisper_encode without the host sync per call
+ *   which = 4  encoder MLP-0 GEMM over the lock-step work buffers [chunks*T x 4S x S] (after a wmi_full_batch call)
+ *   which = 5  encoder attention, all lock-step chunks, one layer
+ *   which = 10..12  chains of trivial dependent kernels on 1 / 32 / 256 workgroups (launch floor)
  */
 WHISPER_API double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters);
 

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Profile collection recipe (run on the GPU box through gpurun from the repo root):
-#   bash profiles/collect.sh r01c
+#   bash profiles/collect.sh r01e
 # 1. kernel trace + stats of the default bench  2-4. PMC passes (one counter group per pass, never combined
 # with the sys/hip/hsa trace domains), each on a short bench run.  Outputs land in gpurun_out/prof_<tag>/;
 # the summaries worth keeping are copied to profiles/ by profiles/summarise.py.

@@ -315,7 +315,7 @@ int main(int argc, char ** argv) {
         };
         const double flop = 2.0 * s.M * s.N * s.K;
         a.C = dC0;
-        const double t0 = time_it([&]() { gemm(EPI_F16_BIAS, a, st); }, 50);
+        const double t0 = time_it([&]() { gemm(EPI_F16_BIAS, a, st); }, 50); { GemmArgs ag = a; ag.C = dC1; const double tg = time_it([&]() { gemm(EPI_F16_BIAS_GELU, ag, st); }, 50); printf("    shipping +GELU %8.2f us\n", tg); }
         GemmArgs a1 = a; a1.C = dC1;
         auto check = [&](const char * name) {
             std::vector<__half> c0(nC), c1(nC);
