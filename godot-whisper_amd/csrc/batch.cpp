@@ -90,6 +90,8 @@ bool ensure_batch(whisper_context & ctx, int B) {
             && HIP_OK(hipHostMalloc(&w.step_host, nb * sizeof(k::DecStep), hipHostMallocDefault))
             && HIP_OK(hipHostMalloc(&w.sample_host, nb * sizeof(k::SampleOut), hipHostMallocDefault));
     if (!ok) { WMI_ERR("%s: device allocation failed (B = %d)\n", __func__, B); w.B = 0; return false; }
+    memset(w.sample_host, 0, nb * sizeof(k::SampleOut));
+    w.step_seq = 0;
     k::fill_zero(w.vt, nb * S * w.Tpad * sizeof(__half), s);
     k::fill_zero(w.conv1, nb * (2 * T + 4) * S * sizeof(__half), s);
     k::fill_zero(w.mel_t, (nb * w.mel_rows * hp.n_mels + 1024) * sizeof(__half), s);
@@ -260,8 +262,11 @@ bool decode_rows_step(whisper_context & ctx, int nb) {
     }
     k::filter_argmax(b.logits, ctx.state->dev.ban_dev, stp, (k::SampleOut *) b.sample_dev, b.filter_scratch, s,
                      (k::SampleOut *) b.sample_host, nb);
-    HIP_TRY(hipStreamSynchronize(s));
-    if (!HIP_OK(hipGetLastError())) return false;
+    {   // every row's result carries the step's sequence number (set by the caller in the step records)
+        const k::DecStep * hs = (const k::DecStep *) b.step_host;
+        const k::SampleOut * so = (const k::SampleOut *) b.sample_host;
+        for (int r = 0; r < nb; ++r) if (!wait_for_seq(&so[r].seq, hs[r].seq, s)) return false;
+    }
     b.t_decode_us += time_us() - t0; b.n_steps++;
     return true;
 }
@@ -439,6 +444,7 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
                     Row & row = rows[act[r]]; const Decoder & d = b.lanes[row.lane]->decoders[0];
                     k::DecStep & st = hs[r];
                     memset(&st, 0, sizeof(st));
+                    st.seq = b.step_seq + 1;
                     st.space_id = space_id; st.eot = v.eot; st.beg = v.beg; st.n_vocab = v.n_vocab;
                     st.ts_floor_end = v.beg; st.ts_initial_start = v.n_vocab;
                     if (row.done) { st.token = v.eot; st.pos = 0; st.n_kv = 1; st.kv_head = 0; continue; }   // idle row
@@ -460,6 +466,7 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
                     }
                 }
                 if (!any) break;
+                ++b.step_seq;
                 if (!decode_rows_step(ctx, nb)) { WMI_ERR("%s: failed to decode\n", __func__); return -8; }
                 const k::SampleOut * so = (const k::SampleOut *) b.sample_host;
                 for (int r = 0; r < nb; ++r) {

@@ -402,6 +402,24 @@ bool upload_static_ban(whisper_context & ctx, const whisper_full_params & params
     return true;
 }
 
+// Completion of a step without a stream synchronisation: the last kernel of the step writes the step's sequence number
+// into pinned host memory behind its result (k_filter_pick); the host spins on it (~1 us instead of the 10-20 us of an
+// interrupt-driven hipStreamSynchronize, paid once per token).  Bounded: after ~2 s it falls back to a real
+// synchronisation and reports what the stream says.
+bool wait_for_seq(const volatile int32_t * seq, int32_t want, hipStream_t s) {
+    static const bool no_spin = getenv("WMI_NO_SPIN") != nullptr;          // debug / A-B
+    if (!no_spin) {
+        const int64_t t0 = time_us();
+        for (uint32_t it = 1;; ++it) {
+            if (*seq == want) return true;
+            __builtin_ia32_pause();
+            if ((it & 0xFFFF) == 0 && time_us() - t0 > 2000000) break;
+        }
+    }
+    if (!HIP_OK(hipStreamSynchronize(s))) return false;
+    return *seq == want;
+}
+
 // the kernels of one greedy step; every per-step quantity is read from DecStep on the device, so the same launch
 // sequence can be replayed as a graph
 static void enqueue_greedy_step(whisper_context & ctx, int Tc) {
@@ -480,6 +498,7 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
         if (!HIP_OK(hipMalloc(&d.step_dev, sizeof(k::DecStep))) || !HIP_OK(hipMalloc(&d.filter_scratch, k::filter_scratch_bytes())) || !HIP_OK(hipMalloc(&d.sample_dev, sizeof(k::SampleOut))) ||
             !HIP_OK(hipHostMalloc(&d.step_host, sizeof(k::DecStep), hipHostMallocDefault)) ||
             !HIP_OK(hipHostMalloc(&d.sample_host, sizeof(k::SampleOut), hipHostMallocDefault))) return false;
+        memset(d.sample_host, 0, sizeof(k::SampleOut));
     }
     k::DecStep * hs = (k::DecStep *) d.step_host;
     memset(hs, 0, sizeof(*hs));
@@ -510,13 +529,14 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
             }
         }
     }
+    hs->seq = ++d.step_seq;
     if (use_graph && d.step_exec) {
         HIP_TRY(hipGraphLaunch(d.step_exec, s));
     } else {
         enqueue_greedy_step(ctx, Tc);
     }
-    HIP_TRY(hipStreamSynchronize(s));
     const k::SampleOut * r = (const k::SampleOut *) d.sample_host;
+    if (!wait_for_seq(&r->seq, d.step_seq, s)) return false;
     if (getenv("WMI_DEBUG_SYNC")) fprintf(stderr, "[wmi] step token=%d pos=%d n_kv=%d head=%d flags=%d floor=%d init=%d -> id=%d tid=%d p=%g plog=%g pt=%g ptsum=%g forced=%d\n",
         token, pos, hs->n_kv, hs->kv_head, hs->flags, hs->ts_floor_end, hs->ts_initial_start, r->id, r->tid, r->p, r->plog, r->pt, r->ptsum, r->forced_ts);
     out = whisper_token_data{ r->id, r->tid, r->p, r->plog, r->pt, r->ptsum, -1, -1, 0.0f };

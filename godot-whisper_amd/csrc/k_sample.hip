@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64) void k_filter_pick(const Partial * __restrict__
         const bool force_ts = ts_logprob > max_text;
         const MaxIdx pick = force_ts ? z : a;
         SampleOut r;
-        r.id = pick.i; r.plog = pick.v - lse; r.p = expf(r.plog); r.forced_ts = force_ts ? 1 : 0; r.pad = 0;
+        r.id = pick.i; r.plog = pick.v - lse; r.p = expf(r.plog); r.forced_ts = force_ts ? 1 : 0; r.seq = stp->seq;
         // timestamp statistics over the post-filter probabilities (W/whisper.cpp:4793-4809)
         const float p_ts_max = z.v > -INFINITY ? expf(z.v - lse) : 0.0f;
         const double sum_ts_p = (double) sum_ts * (double) expf(M - lse);
@@ -127,7 +127,15 @@ __global__ __launch_bounds__(64) void k_filter_pick(const Partial * __restrict__
         r.ptsum = (float) sum_ts_p;
         if (r.id >= beg) { r.tid = r.id; r.pt = r.p; }
         *out = r;
-        if (out_host) { *out_host = r; __threadfence_system(); }     // result straight into pinned host memory
+        if (out_host) {
+            // result straight into pinned host memory; the sequence number goes last, behind a system-scope fence: the host
+            // spins on it instead of paying a stream synchronisation per token
+            SampleOut body = r; body.seq = out_host->seq;
+            *out_host = body;
+            __threadfence_system();
+            *(volatile int32_t *) &out_host->seq = r.seq;
+            __threadfence_system();
+        }
     }
 }
 

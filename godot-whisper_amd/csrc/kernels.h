@@ -136,9 +136,10 @@ struct DecStep {
     int32_t space_id, eot, beg, n_vocab;
     int32_t ts_floor_end;          // timestamps in [beg, ts_floor_end) are banned (monotonic rule) ; = beg when inactive
     int32_t ts_initial_start;      // timestamps in [ts_initial_start, n_vocab) are banned (max_initial_ts) ; = n_vocab when inactive
-    int32_t pad[5];
+    int32_t seq;                   // step sequence number, echoed in SampleOut::seq (the host polls pinned memory for it)
+    int32_t pad[4];
 };
-struct SampleOut { int32_t id, tid; float p, plog, pt, ptsum; int32_t forced_ts; int32_t pad; };
+struct SampleOut { int32_t id, tid; float p, plog, pt, ptsum; int32_t forced_ts; int32_t seq; };
 // logits [n_vocab] -> filtered soft-max statistics and the arg-max token (W/whisper.cpp:4493-4830 at temperature 0)
 // n_rows > 1: lock-step chunks — logits [n_rows][n_vocab], step[n_rows], out[n_rows]
 void filter_argmax(const float * logits, const uint8_t * static_ban, const DecStep * step, SampleOut * out, void * scratch, hipStream_t st,

@@ -189,6 +189,7 @@ struct DeviceState {
     void   * filter_scratch = nullptr;
     uint8_t * ban_dev = nullptr;   uint64_t ban_sig = ~0ull;          // static suppress mask + its parameter signature
     hipGraph_t step_graph = nullptr; hipGraphExec_t step_exec = nullptr; int step_graph_T = -1;
+    int32_t step_seq = 0;                                             // sequence number of the last greedy step launched
 };
 
 struct State {
@@ -224,6 +225,7 @@ struct BatchWork {
     float  * dx = nullptr; __half * dq = nullptr, * datt = nullptr, * dh = nullptr; float * logits = nullptr, * xattn = nullptr;
     void   * step_dev = nullptr, * step_host = nullptr, * sample_dev = nullptr, * sample_host = nullptr, * filter_scratch = nullptr;
     int      enc_rows = 0, enc_T = 0;                         // chunk rows / encoder length of the last batched encode
+    int32_t  step_seq = 0;                                    // sequence number of the last lock-step decode step
     std::vector<State *> lanes;                               // lanes[0] is the context's own state (not owned)
     std::vector<std::vector<Segment>> results;                // per chunk of the last wmi_full_batch call
     std::vector<int> redo;                                    // per chunk: 1 if it was re-run alone (temperature fallback)
@@ -257,6 +259,7 @@ bool decode(whisper_context & ctx, const Batch & batch);
 struct StepFilter { bool ban_blank, last_ts, penult_ts; int ts_floor_end, ts_initial_start; };
 bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const StepFilter & f, whisper_token_data & out);
 bool upload_static_ban(whisper_context & ctx, const whisper_full_params & params);
+bool wait_for_seq(const volatile int32_t * seq, int32_t want, hipStream_t s);   // spin on a pinned sequence number (device.cpp)
 bool fast_path_enabled();
 // |x| envelope of the last PCM on the GPU; the D2H copy runs on a side stream while the encoder works.
 // sync = false: state.energy is valid only after signal_energy_wait()
