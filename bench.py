@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--shape", default=SHAPE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stream-seconds", type=float, default=0.0,
+                    help="secondary figure: BASELINE configs[2] — CaptureStreamToText over this many seconds of synthetic microphone "
+                         "audio with the `small` multilingual shape (every 0.3 s the grown buffer is transcribed again, ragged audio_ctx)")
     ap.add_argument("--chunks", type=int, default=1,
                     help="chunks per GPU per step: 1 = BASELINE configs[1] (headline); 8 = configs[3]'s per-GPU share, lock-step")
     args = ap.parse_args()
@@ -141,6 +144,10 @@ def main():
                   "segments_timestamps_ms": round(acc[3] / reps / 1e3, 3), "chunks_run_alone": int(sum(modes)),
                   "encoder_tflops": round(nb * ENC_GFLOP / (acc[1] / reps / 1e3), 1)}
 
+    stream = None
+    if args.stream_seconds > 0 and world == 1:
+        stream = stream_config(lib, args.stream_seconds)
+
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -171,6 +178,8 @@ def main():
         }
         if batch8:
             out["batch8"] = batch8
+        if stream:
+            out["stream_small"] = stream
         # ---- roofline of the dominant kernel, measured live with HIP events on the context's stream.
         # Dominant by GPU time (profiles/*_kernel_stats.csv) is the decoder's weight-streaming k_gemv; its largest
         # instance — the vocabulary projection, 53.1 MB of f16 weights per launch — is the one reported: HBM bound.
@@ -217,6 +226,42 @@ def main():
     node.ctx = None
     if world > 1:
         dist.destroy_process_group()
+
+
+def stream_config(lib, seconds: float) -> dict:
+    """BASELINE configs[2]: the streaming node's call pattern (addon/capture_stream_to_text.gd:65-120) on the `small`
+    multilingual shape: every 0.3 s of simulated time the whole accumulated buffer is transcribed again with
+    audio_ctx = total_s * 50 + 128; a sentence ends on punctuation / VAD / 15 s.  Reported: calls, wall per call and how
+    many seconds of audio one second of wall sustains (the microphone delivers 1)."""
+    from godot_whisper_amd import host, synth
+    model = synth.make_model("small", seed=77)
+    pcm = synth.make_pcm(seconds, seed=21, gate=True)
+    node = host.CaptureStreamToText(lib, transcribe_interval=0.3)
+    node.language = "de"
+    node.set_language_model(model)
+    del model
+    list(node.stream(pcm[: 16000 * 3]))                  # warm-up (first-touch)
+    # only the library calls are timed: the Python mirror's sample-by-sample VAD loop is host-language overhead
+    t_lib = [0.0]; per_call = []
+    inner = node.transcribe
+    def timed(buffer, initial_prompt="", audio_ctx=0, params=None):
+        t = time.perf_counter(); r = inner(buffer, initial_prompt, audio_ctx, params); e = time.perf_counter() - t
+        t_lib[0] += e; per_call.append(e)
+        return r
+    node.transcribe = timed
+    calls = 0; finals = 0; samples = 0; ctxs = []
+    for fin, text, n, actx, toks in node.stream(pcm):
+        calls += 1; finals += int(fin); samples += n; ctxs.append(actx)
+    dt = t_lib[0]
+    node.close()
+    return {"workload": f"small multilingual, {seconds:.0f} s synthetic microphone, transcribe every 0.3 s (grown buffer, ragged audio_ctx)",
+            "calls": calls, "sentences": finals, "ms_per_call": round(1e3 * dt / max(calls, 1), 3),
+            # calls whose first pass fails the reference's logprob / entropy thresholds go through the temperature fallback
+            # (best_of sampling on the general path, W/whisper.cpp:5643-5670): the mean carries them, the median does not
+            "ms_per_call_median": round(1e3 * sorted(per_call)[len(per_call) // 2], 3) if per_call else None,
+            "audio_ctx_min_max": [int(min(ctxs)), int(max(ctxs))] if ctxs else None,
+            "stream_realtime_factor": round(seconds / dt, 1),
+            "retranscribed_audio_s_per_wall_s": round(samples / 16000 / dt, 1)}
 
 
 def pmc_traffic(kernel_key: str):

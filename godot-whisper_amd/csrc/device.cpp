@@ -510,11 +510,16 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
 
     hipStream_t s = d.stream;
     static const bool use_graph = getenv("WMI_NO_GRAPH") == nullptr;
-    if (use_graph && d.step_exec && d.step_graph_T != Tc) {             // encoder length changed: re-capture
+    if (use_graph && d.step_exec && d.step_graph_T != Tc) {             // encoder length changed: the captured step is stale
         (void) hipGraphExecDestroy(d.step_exec); (void) hipGraphDestroy(d.step_graph);
         d.step_exec = nullptr; d.step_graph = nullptr;
     }
-    if (use_graph && !d.step_exec) {
+    // Capture + instantiate costs tens of milliseconds; the streaming node changes audio_ctx on every call (it grows with
+    // the buffer), so a step is only captured once the same encoder length has been decoded for a while — until then the
+    // launches go out eagerly (measured equal to replay within 1 %: the step is bound by dependent-kernel latency on the GPU)
+    if (d.step_seen_T != Tc) { d.step_seen_T = Tc; d.step_seen_n = 0; }
+    const bool capture_now = use_graph && !d.step_exec && ++d.step_seen_n > 64;
+    if (capture_now) {
         // first use: run once eagerly (lets the launchers set their function attributes), then capture
         enqueue_greedy_step(ctx, Tc);
         HIP_TRY(hipStreamSynchronize(s));
