@@ -37,8 +37,12 @@ void emit_segment(whisper_context & ctx, State & st, const whisper_full_params &
     st.result_all.push_back(std::move(seg));
     int n_new = 1;
     if (params.token_timestamps) {
+        static const bool dbg_e = getenv("WMI_DEBUG_EMIT") != nullptr;
+        const int64_t e0 = time_us();
         (void) signal_energy_wait(st);             // the envelope's D2H copy ran behind the encoder / decoder
+        const int64_t e1 = time_us();
         token_level_timestamps(ctx, st, (int) st.result_all.size() - 1, params.thold_pt, params.thold_ptsum);
+        if (dbg_e) fprintf(stderr, "[wmi] emit: envelope wait %lld us, token timestamps %lld us\n", (long long) (e1 - e0), (long long) (time_us() - e1));
         if (params.max_len > 0) n_new = wrap_segment(ctx, st, params.max_len, params.split_on_word);
     }
     if (params.new_segment_callback)

@@ -281,6 +281,115 @@ template <int FM, int FN, int NBUF> void launch_glds_w(const GemmArgs & a, hipSt
     hipLaunchKernelGGL((k_gemm_glds_w<FM, FN, NBUF>), dim3(ntm * ntn), dim3(256), smem, st, a);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Persistent 128x128 tiles: a workgroup walks tiles t = b, b + G, ...; the global_load_lds pipeline runs across tile
+// boundaries (stage 0 of the next tile is in flight during the last K-step and the epilogue of the current one).
+__global__ __launch_bounds__(256) void k_gemm_persist(const GemmArgs a) {
+    constexpr int BM = 128, BN = 128;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN, nwg = ntm * ntn;
+    const int nk = a.K / 64;
+    const int prow = lane >> 3;
+    const int frow = lane & 15, fq = lane >> 4;
+    auto sA = [&](int buf) -> unsigned char * { return smem + buf * 32768; };
+    auto sB = [&](int buf) -> unsigned char * { return smem + buf * 32768 + 16384; };
+    auto tile_of = [&](int t, int & m0, int & n0) {
+        const int q = nwg / 8, r = nwg % 8, xcd = t % 8, idx = t / 8;
+        const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        m0 = (wg / ntn) * BM; n0 = (wg % ntn) * BN;
+    };
+    const __half * gA[4]; const __half * gB[4];
+    auto set_rows = [&](int m0, int n0) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int lrow = (wave * 4 + p) * 8 + prow, pch = (lane & 7) ^ (lrow & 7);
+            int r = m0 + lrow; if (r > a.M - 1) r = a.M - 1;
+            gA[p] = a.A + (size_t) r * a.lda + pch * 8;
+            r = n0 + lrow; if (r > a.N - 1) r = a.N - 1;
+            gB[p] = a.W + (size_t) r * a.ldw + pch * 8;
+        }
+    };
+    auto issue = [&](int kt, int buf) {
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            __builtin_amdgcn_global_load_lds((const void *) (gA[p] + kt * 64), (__attribute__((address_space(3))) void *) (sA(buf) + (wave * 4 + p) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void *) (gB[p] + kt * 64), (__attribute__((address_space(3))) void *) (sB(buf) + (wave * 4 + p) * 1024), 16, 0, 0);
+        }
+    };
+    int t = blockIdx.x;
+    if (t >= nwg) return;
+    int m0, n0; tile_of(t, m0, n0);
+    set_rows(m0, n0);
+    issue(0, 0);
+    int stage = 0;
+    for (; t < nwg; t += gridDim.x) {
+        f4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+        const int cm0 = m0, cn0 = n0;
+        const int tn_next = t + gridDim.x;
+        for (int kt = 0; kt < nk; ++kt, ++stage) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            const int buf = stage & 1;
+            if (kt + 1 < nk) issue(kt + 1, buf ^ 1);
+            else if (tn_next < nwg) { tile_of(tn_next, m0, n0); set_rows(m0, n0); issue(0, buf ^ 1); }
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                h8 fa[4], fb[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) fa[i] = *(const h8 *) (sA(buf) + lds_off(wm * 64 + i * 16 + frow, kk * 4 + fq));
+#pragma unroll
+                for (int j = 0; j < 4; ++j) fb[j] = *(const h8 *) (sB(buf) + lds_off(wn * 64 + j * 16 + frow, kk * 4 + fq));
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        const int mb = cm0 + wm * 64, nb = cn0 + wn * 64;
+        const bool full = (cm0 + BM <= a.M) && (cn0 + BN <= a.N);
+        if (full) {
+            float bias[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) bias[j] = a.bias ? a.bias[nb + j * 16 + frow] : 0.0f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        ((__half *) a.C)[(size_t) (mb + i * 16 + fq * 4 + r) * a.ldc + nb + j * 16 + frow] = f2h(acc[i][j][r] + bias[j]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = nb + j * 16 + frow;
+                if (n >= a.N) continue;
+                const float bias = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = mb + i * 16 + fq * 4 + r;
+                        if (m < a.M) ((__half *) a.C)[(size_t) m * a.ldc + n] = f2h(acc[i][j][r] + bias);
+                    }
+            }
+        }
+    }
+}
+void launch_persist(const GemmArgs & a, hipStream_t st, int blocks_per_cu) {
+    const int ntiles = ((a.M + 127) / 128) * ((a.N + 127) / 128);
+    int grid = 256 * blocks_per_cu; if (grid > ntiles) grid = ntiles;
+    grid = grid / 8 * 8; if (grid < 8) grid = 8;
+    (void) hipFuncSetAttribute((const void *) k_gemm_persist, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+    hipLaunchKernelGGL(k_gemm_persist, dim3(grid), dim3(256), 65536, st, a);
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
 int main(int argc, char ** argv) {
@@ -338,6 +447,8 @@ int main(int argc, char ** argv) {
         };
         run("glds1 ep1", [&]() { launch_glds<1, 0, 1>(a1, st); });
         run("glds2 ep1", [&]() { launch_glds<2, 0, 1>(a1, st); });
+        run("persist 2/CU", [&]() { launch_persist(a1, st, 2); });
+        run("persist 1/CU", [&]() { launch_persist(a1, st, 1); });
         run("g1 loadonly", [&]() { launch_glds<1, 0, 1, 1>(a1, st); });
         run("g2 loadonly", [&]() { launch_glds<2, 0, 1, 1>(a1, st); });
         run("g1 mathnost", [&]() { launch_glds<1, 0, 1, 3>(a1, st); });
