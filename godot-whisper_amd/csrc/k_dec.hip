@@ -599,31 +599,35 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
     int ro_pre = 0;
     if (a.row_off && col < n) ro_pre = a.lanes ? a.row_off[col * a.step_stride] : *a.row_off;
 
+    // epilogue operands of the first tile (bias, residual): independent of the prologue, requested now
+    float bias_pre[4] = {0.f, 0.f, 0.f, 0.f}, resid_pre[4] = {0.f, 0.f, 0.f, 0.f};
+    const int tile0 = tile;
+    if (tile < ntiles && col < n && (!KSPLIT || wave == 0)) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int nf_ = tile * 16 + kq * 4 + r;
+            if (nf_ < a.N) {
+                if (a.bias) bias_pre[r] = a.bias[nf_];
+                if (a.resid) resid_pre[r] = a.resid[(size_t) col * a.ldr + nf_];
+            }
+        }
+    }
+
     // ---- prologue: activation rows as f16 in LDS
-    if (a.ln_g) {
-        constexpr int XV = 20;
+    if (a.ln_g) {                                           // K <= 1536; same arithmetic as k_gemv / k_gemv1 (ln_row_regs)
         for (int r = wave; r < n; r += 4) {
             const int src = a.rows ? a.rows[r] : r;
-            const float * xr = a.x32 + (size_t) src * K;
-            float xv[XV], gv[XV], bv[XV]; float sum = 0.0f;
+            float av[3][8];
+            ln_row_regs<3>(a.x32 + (size_t) src * K, a.ln_g, a.ln_b, K, a.eps, lane, av);
 #pragma unroll
-            for (int j = 0; j < XV; ++j) {
-                const int c = lane + 64 * j;
-                xv[j] = c < K ? xr[c] : 0.0f; gv[j] = c < K ? a.ln_g[c] : 0.0f; bv[j] = c < K ? a.ln_b[c] : 0.0f;
-            }
+            for (int t = 0; t < 3; ++t) {
+                const int c = lane * 8 + 512 * t;
+                if (c < K) {
+                    __half2 h[4];
 #pragma unroll
-            for (int j = 0; j < XV; ++j) sum += xv[j];
-            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
-            const float mean = sum / (float) K;
-            float sq = 0.0f;
-#pragma unroll
-            for (int j = 0; j < XV; ++j) { const int c = lane + 64 * j; if (c < K) { xv[j] -= mean; sq += xv[j] * xv[j]; } }
-            for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
-            const float sc = 1.0f / sqrtf(sq / (float) K + a.eps);
-#pragma unroll
-            for (int j = 0; j < XV; ++j) {
-                const int c = lane + 64 * j;
-                if (c < K) act[r * lda + c] = f2h(__fadd_rn(__fmul_rn(xv[j] * sc, gv[j]), bv[j]));
+                    for (int e = 0; e < 4; ++e) h[e] = __floats2half2_rn(av[t][2 * e], av[t][2 * e + 1]);
+                    *(uint4 *) (act + r * lda + c) = *(const uint4 *) h;
+                }
             }
         }
     } else {
@@ -677,11 +681,12 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
             const int nf_ = tile * 16 + kq * 4 + r;
             if (nf_ >= a.N) continue;
             const float v = acc[r];
-            const float bias = a.bias ? a.bias[nf_] : 0.0f;
+            const bool pre = tile == tile0;
+            const float bias = pre ? bias_pre[r] : (a.bias ? a.bias[nf_] : 0.0f);
             switch (a.epi) {
                 case EPI_F16_BIAS:       ((__half *) a.C)[(size_t) col * a.ldc + nf_] = f2h(v + bias); break;
                 case EPI_F16_BIAS_GELU:  ((__half *) a.C)[(size_t) col * a.ldc + nf_] = f2h(gelu16(v + bias)); break;
-                case EPI_F32_BIAS_RESID: ((float *) a.C)[(size_t) col * a.ldc + nf_] = (v + bias) + a.resid[(size_t) col * a.ldr + nf_]; break;
+                case EPI_F32_BIAS_RESID: ((float *) a.C)[(size_t) col * a.ldc + nf_] = (v + bias) + (pre ? resid_pre[r] : a.resid[(size_t) col * a.ldr + nf_]); break;
                 case EPI_Q_SCALED:       ((__half *) a.C)[(size_t) col * a.ldc + nf_] = f2h((v + bias) * a.scale); break;
                 case EPI_QKV_DEC: {
                     const int c = nf_ - seg * a.S;
