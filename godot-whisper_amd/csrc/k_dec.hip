@@ -108,18 +108,66 @@ __device__ __forceinline__ void self_attn_row(const __half * __restrict__ sq, co
     }
 }
 
-// lock-step chunks: one workgroup per row, each against its own chunk's cache; out [R][K] f16 (global)
-__global__ __launch_bounds__(256) void k_self_attn_rows(const __half * __restrict__ q, const __half * __restrict__ kc,
-                                                        const __half * __restrict__ vc, int64_t cache_row_stride,
-                                                        const int32_t * __restrict__ n_kv, int step_stride, int K, int cap,
-                                                        __half * __restrict__ out) {
+// lock-step chunks: one wavefront per (row, head), each row against its own chunk's cache; out [R][K] f16 (global).
+// Per (key, head) dot product, per-head soft-max and per-column P.V are evaluated exactly as in self_attn_row (same
+// operand order), so the result is bit-identical to the one-row fused prologue; 8 x H workgroups instead of 8.
+__global__ __launch_bounds__(64) void k_self_attn_rows(const __half * __restrict__ q, const __half * __restrict__ kc,
+                                                       const __half * __restrict__ vc, int64_t cache_row_stride,
+                                                       const int32_t * __restrict__ n_kv_p, int step_stride, int K, int cap,
+                                                       __half * __restrict__ out) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    float * sc = (float *) smem;                        // [H][cap]
-    float * qf = sc + (size_t) (K / 64) * cap;          // [K]
-    const int r = blockIdx.x;
-    uint4 kpre[8] = {};
-    self_attn_row(q + (size_t) r * K, kc + (int64_t) r * cache_row_stride, vc + (int64_t) r * cache_row_stride,
-                  n_kv[r * step_stride], K, cap, sc, qf, out + (size_t) r * K, kpre, false);
+    float * row = (float *) smem;                       // [cap] scores -> probabilities of this head
+    float * qf  = row + cap;                            // [64]
+    const int r = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+    const __half * sk = kc + (int64_t) r * cache_row_stride, * sv = vc + (int64_t) r * cache_row_stride;
+    const int n_kv = n_kv_p[r * step_stride];
+    qf[lane] = __half2float(q[(size_t) r * K + h * 64 + lane]);
+    __syncthreads();
+    for (int j = lane; j < n_kv; j += 64) {
+        const uint4 * kp = (const uint4 *) (sk + (size_t) j * K + h * 64);
+        uint4 u[8];
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) u[c8] = kp[c8];
+        float dot = 0.0f;
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) {
+            const __half2 * hh = (const __half2 *) &u[c8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float2 f = __half22float2(hh[e]);
+                dot = fmaf(f.x, qf[c8 * 8 + e * 2], dot);
+                dot = fmaf(f.y, qf[c8 * 8 + e * 2 + 1], dot);
+            }
+        }
+        row[j] = dot;
+    }
+    __syncthreads();
+    {
+        float m = -INFINITY;
+        for (int j = lane; j < n_kv; j += 64) m = fmaxf(m, row[j]);
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float l = 0.0f;
+        for (int j = lane; j < n_kv; j += 64) { const float e = round_f16(expf(round_f16(row[j] - m))); row[j] = e; l += e; }
+        for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
+        const float inv = (float) (1.0 / (double) l);
+        for (int j = lane; j < n_kv; j += 64) row[j] = round_f16(row[j] * inv);
+    }
+    __syncthreads();
+    {
+        const int c = h * 64 + lane;
+        const __half * vp = sv + c;
+        float acc = 0.0f;
+        int j = 0;
+        for (; j + 8 <= n_kv; j += 8) {
+            __half vv[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) vv[t] = vp[(size_t) (j + t) * K];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) acc = fmaf(row[j + t], __half2float(vv[t]), acc);
+        }
+        for (; j < n_kv; ++j) acc = fmaf(row[j], __half2float(vp[(size_t) j * K]), acc);
+        out[(size_t) r * K + c] = f2h(acc);
+    }
 }
 
 // LayerNorm of one row by one wavefront, lane L holding the slices x[512 t + 8 L .. + 8) (the slices its dot products
@@ -761,8 +809,8 @@ void dec_embed_step(const DecStep * host_step, DecStep * dev_step, int S, const 
 
 void self_attn_rows(const __half * q, int n, int K, const __half * kc, const __half * vc, int64_t cache_row_stride,
                     const int32_t * n_kv, int step_stride, int cap, __half * out, hipStream_t st) {
-    const size_t smem = ((size_t) (K / 64) * cap + K) * sizeof(float);
-    hipLaunchKernelGGL(k_self_attn_rows, dim3(n), dim3(256), smem, st, q, kc, vc, cache_row_stride, n_kv, step_stride, K, cap, out);
+    const size_t smem = ((size_t) cap + 64) * sizeof(float);
+    hipLaunchKernelGGL(k_self_attn_rows, dim3(n, K / 64), dim3(64), smem, st, q, kc, vc, cache_row_stride, n_kv, step_stride, K, cap, out);
 }
 
 static bool g_rows_valu = false;
