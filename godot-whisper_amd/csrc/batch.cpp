@@ -43,6 +43,9 @@ State * new_lane_state(whisper_context & ctx) {
     State * st = new State();
     st->dev.stream = ctx.state->dev.stream;                 // one stream: the lanes are rows of the same launches
     if (!dalloc(st->dev.mel_max, 4)) { delete st; return nullptr; }
+    // the chunks' log-mel kernels are latency-bound chains (one workgroup per frame): on their own streams they overlap
+    if (!HIP_OK(hipStreamCreateWithFlags(&st->dev.mel_stream, hipStreamNonBlocking)) ||
+        !HIP_OK(hipEventCreateWithFlags(&st->dev.mel_ev, hipEventDisableTiming))) { delete st; return nullptr; }
     for (auto & dec : st->decoders) dec.rng = std::mt19937(0);
     return st;
 }
@@ -51,6 +54,8 @@ void free_lane_state(State * st) {
     DeviceState & d = st->dev;
     if (d.copy_stream) { (void) hipStreamSynchronize(d.copy_stream); (void) hipStreamDestroy(d.copy_stream); }
     if (d.energy_ev) (void) hipEventDestroy(d.energy_ev);
+    if (d.mel_stream) { (void) hipStreamSynchronize(d.mel_stream); (void) hipStreamDestroy(d.mel_stream); }
+    if (d.mel_ev) (void) hipEventDestroy(d.mel_ev);
     dfree(d.pcm); dfree(d.mel); dfree(d.mel_max); dfree(d.energy);
     if (d.energy_host) (void) hipHostFree(d.energy_host);
     delete st;
@@ -394,6 +399,11 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
         // envelopes are written to the host by the chunks' side streams and are awaited at emission time
         {
             const int64_t tm0 = time_us();
+            for (int r = 0; r < ng; ++r) {                        // the encoder (main stream) waits for every chunk's mel
+                DeviceState & ld = b.lanes[r]->dev;
+                if (!ld.mel_stream || n_samples[g0 + r] <= 0) continue;
+                if (!HIP_OK(hipEventRecord(ld.mel_ev, ld.mel_stream)) || !HIP_OK(hipStreamWaitEvent(primary->dev.stream, ld.mel_ev, 0))) return -2;
+            }
             if (!HIP_OK(hipStreamSynchronize(primary->dev.stream))) return -2;
             b.t_mel_us += time_us() - tm0;
         }

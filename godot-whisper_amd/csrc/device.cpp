@@ -116,6 +116,7 @@ bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, boo
     State & st = *ctx.state; DeviceState & d = st.dev;
     const int64_t t0 = time_us();
     const int n_mel = ctx.model.n_filt_mel;
+    hipStream_t ms = d.mel_stream ? d.mel_stream : d.stream;
     // Appendix G: padded = [200 reflect | n | 480000 + 200 zeros]
     const int64_t n_pad = (int64_t) n_samples + 480000 + 400;
     const int n_len = (int) ((n_pad - 400) / 160);
@@ -126,14 +127,14 @@ bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, boo
     const float * src = samples;
     if (!samples_on_device) {                      // stage the borrowed host PCM behind the padded image
         float * stage = d.pcm + n_pad;
-        HIP_TRY(hipMemcpyAsync(stage, samples, (size_t) n_samples * 4, hipMemcpyHostToDevice, d.stream));
+        HIP_TRY(hipMemcpyAsync(stage, samples, (size_t) n_samples * 4, hipMemcpyHostToDevice, ms));
         src = stage;
     }
     d.last_pcm = src; d.last_pcm_n = n_samples;
-    k::mel_pad(src, n_samples, d.pcm, (int) n_pad, d.stream);
-    k::mel_frames(d.pcm, n_valid, n_fft_frames, n_len, n_mel, ctx.w.mel_filters, ctx.w.mel_ranges, d.mel, (int *) d.mel_max, d.stream);
-    k::mel_normalize(d.mel, n_mel * n_len, (const int *) d.mel_max, d.stream);
-    if (sync) HIP_TRY(hipStreamSynchronize(d.stream));          // lock-step chunks: one sync for all chunks (batch.cpp)
+    k::mel_pad(src, n_samples, d.pcm, (int) n_pad, ms);
+    k::mel_frames(d.pcm, n_valid, n_fft_frames, n_len, n_mel, ctx.w.mel_filters, ctx.w.mel_ranges, d.mel, (int *) d.mel_max, ms);
+    k::mel_normalize(d.mel, n_mel * n_len, (const int *) d.mel_max, ms);
+    if (sync) HIP_TRY(hipStreamSynchronize(ms));          // lock-step chunks: one sync for all chunks (batch.cpp)
     st.mel.n_len = n_len; st.mel.n_len_org = n_len_org; st.mel.n_mel = n_mel;
     st.t_mel_us += time_us() - t0;
     return true;
@@ -157,7 +158,7 @@ bool signal_energy_device(whisper_context & ctx, int hw, bool sync) {
     }
     // The kernel runs on the side stream, behind the staging of the samples, and stores straight into pinned host
     // memory: no memcpy call, and the 1.9 MB of PCIe writes overlap the encoder on the main stream.
-    HIP_TRY(hipEventRecord(d.energy_ev, d.stream));
+    HIP_TRY(hipEventRecord(d.energy_ev, d.mel_stream ? d.mel_stream : d.stream));
     HIP_TRY(hipStreamWaitEvent(d.copy_stream, d.energy_ev, 0));
     k::signal_energy(d.last_pcm, n, hw, d.energy_host, d.copy_stream);
     d.energy_pending = true;

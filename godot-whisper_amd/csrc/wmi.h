@@ -159,6 +159,7 @@ struct DeviceState {
     float * energy = nullptr;   size_t energy_cap = 0;        // |x| envelope (device)
     float * energy_host = nullptr;                            // pinned mirror
     hipStream_t copy_stream = nullptr; hipEvent_t energy_ev = nullptr;   // envelope D2H overlaps the encoder
+    hipStream_t mel_stream = nullptr;  hipEvent_t mel_ev = nullptr;      // lock-step chunks: the mel kernels of the chunks overlap
     bool    energy_pending = false;                            // copy in flight: signal_energy_wait() before reading state.energy
     // encoder activations, token-major
     __half * mel_t = nullptr;                                 // [2T+2+pad][n_mel_pad] f16, rows -1 and 2T are zero
