@@ -50,27 +50,26 @@ __global__ void k_mel_pad(const float * __restrict__ pcm, int n, float * __restr
 }
 
 // butterfly stage: for g groups, combine E = src[(g)*half ...], O = src[(g + ngroups)*half ...]
-// into dst[g*N + k], dst[g*N + k + half].  Arrays are stored as [leaf][k] complex (re, im interleaved).
+// into dst[g*N + k], dst[g*N + k + half].  Arrays are stored as [leaf][k] complex (re, im interleaved, read and
+// written as one 8-byte LDS access).  tw = this stage's twiddles, compact: tw[k] = (cos, sin)(2 pi k / N), k < N/2 —
+// consecutive lanes read consecutive 8-byte slots (the shared 400-entry table read at stride 400/N put 64 lanes on
+// 64/stride banks).
 __device__ inline void butterfly_stage(const float * src, float * dst, int ngroups, int N, int tid, int nthreads,
-                                       bool last, const float * t_cos, const float * t_sin) {
+                                       bool last, const float2 * tw) {
     const int half = N / 2;
-    const int step = 400 / N;
     const int total = ngroups * half;
     for (int t = tid; t < total; t += nthreads) {
         const int g = t / half, kk = t % half;
-        const float * E = src + 2 * (g * half);
-        const float * O = src + 2 * ((g + ngroups) * half);
-        const int   idx = kk * step;
-        const float re =  t_cos[idx];
-        const float im = -t_sin[idx];
-        const float er = E[2 * kk], ei = E[2 * kk + 1], orr = O[2 * kk], oi = O[2 * kk + 1];
-        float * D = dst + 2 * (g * N);
-        D[2 * kk]     = fmaf(-im, oi, fmaf(re, orr, er));
-        D[2 * kk + 1] = fmaf(im, orr, fmaf(re, oi, ei));
-        if (!last || kk == 0) {          // the last stage only needs bins 0..200
-            D[2 * (kk + half)]     = fmaf(im, oi, fmaf(-re, orr, er));
-            D[2 * (kk + half) + 1] = fmaf(-im, orr, fmaf(-re, oi, ei));
-        }
+        const float2 * E = (const float2 *) src + (g * half);
+        const float2 * O = (const float2 *) src + ((g + ngroups) * half);
+        const float2 w = tw[kk];
+        const float re =  w.x;
+        const float im = -w.y;
+        const float2 e = E[kk], o = O[kk];
+        float2 * D = (float2 *) dst + (g * N);
+        D[kk] = make_float2(fmaf(-im, o.y, fmaf(re, o.x, e.x)), fmaf(im, o.x, fmaf(re, o.y, e.y)));
+        if (!last || kk == 0)            // the last stage only needs bins 0..200
+            D[kk + half] = make_float2(fmaf(im, o.y, fmaf(-re, o.x, e.x)), fmaf(-im, o.x, fmaf(-re, o.y, e.y)));
     }
 }
 
@@ -87,19 +86,25 @@ __global__ __launch_bounds__(128) void k_mel_frames(const float * __restrict__ p
                                                     const int32_t * __restrict__ ranges,
                                                     float * __restrict__ mel, int * __restrict__ gmax) {
     __shared__ float xin[400];
-    __shared__ float bufA[800];
-    __shared__ float bufB[800];
+    __shared__ __attribute__((aligned(8))) float bufA[800];
+    __shared__ __attribute__((aligned(8))) float bufB[800];
     __shared__ float pw[204];
-    __shared__ float t_cos[400], t_sin[400];       // twiddles in LDS: per-lane indices make constant-memory reads vector loads
+    // twiddles in LDS, one compact (cos, sin) table per stage: leaf DFT 25 entries (index (kk m) mod 25 <-> the shared
+    // table's 16 (kk m) mod 400), then N = 50, 100, 200, 400 with N/2 entries each.  Same values as the reference's
+    // 400-entry table, laid out so that neighbouring lanes hit neighbouring banks.
+    __shared__ __attribute__((aligned(8))) float2 tw25[25], tw50[25], tw100[50], tw200[100], tw400[200];
     const int frame = blockIdx.x;
     const int tid = threadIdx.x;
     if (frame >= n_fft_frames) return;
 
     const int offset = frame * 160;
     int nin = n_valid - offset; if (nin > 400) nin = 400;
+    for (int j = tid; j < 400; j += 128) xin[j] = j < nin ? c_mel.hann[j] * pad[offset + j] : 0.0f;
     for (int j = tid; j < 400; j += 128) {
-        xin[j] = j < nin ? c_mel.hann[j] * pad[offset + j] : 0.0f;
-        t_cos[j] = c_mel.cosv[j]; t_sin[j] = c_mel.sinv[j];
+        if (j < 25)       { tw25[j] = make_float2(c_mel.cosv[16 * j], c_mel.sinv[16 * j]); tw50[j] = make_float2(c_mel.cosv[8 * j], c_mel.sinv[8 * j]); }
+        if (j < 50)       tw100[j] = make_float2(c_mel.cosv[4 * j], c_mel.sinv[4 * j]);
+        if (j < 100)      tw200[j] = make_float2(c_mel.cosv[2 * j], c_mel.sinv[2 * j]);
+        if (j < 200)      tw400[j] = make_float2(c_mel.cosv[j], c_mel.sinv[j]);
     }
     // filter rows of this thread's mel bin(s): independent of the transform, requested up front
     int fr0 = 0, fr1 = 0;
@@ -111,24 +116,24 @@ __global__ __launch_bounds__(128) void k_mel_frames(const float * __restrict__ p
     for (int t = tid; t < 400; t += 128) {
         const int r = t / 25, kk = t % 25;
         float re = 0.0f, im = 0.0f;
-        int idx = 0;                                 // (kk * m * 16) % 400, advanced incrementally
-        const int inc = kk * 16;                     // < 400
+        int idx = 0;                                 // (kk * m) % 25, advanced incrementally
 #pragma unroll 5
         for (int m = 0; m < 25; ++m) {
             const float v = xin[r + 16 * m];
-            re = fmaf(v, t_cos[idx], re);
-            im = fmaf(-v, t_sin[idx], im);
-            idx += inc; if (idx >= 400) idx -= 400;
+            const float2 w = tw25[idx];
+            re = fmaf(v, w.x, re);
+            im = fmaf(-v, w.y, im);
+            idx += kk; if (idx >= 25) idx -= 25;
         }
         bufA[2 * (r * 25 + kk)]     = re;
         bufA[2 * (r * 25 + kk) + 1] = im;
     }
     __syncthreads();
     // N=50: pairs (r, r+8) -> 8 arrays of 50 indexed by r<8 ; N=100: (r, r+4) ; N=200: (r, r+2) ; N=400: (0,1)
-    butterfly_stage(bufA, bufB, 8, 50, tid, 128, false, t_cos, t_sin);   __syncthreads();
-    butterfly_stage(bufB, bufA, 4, 100, tid, 128, false, t_cos, t_sin);  __syncthreads();
-    butterfly_stage(bufA, bufB, 2, 200, tid, 128, false, t_cos, t_sin);  __syncthreads();
-    butterfly_stage(bufB, bufA, 1, 400, tid, 128, true, t_cos, t_sin);   __syncthreads();
+    butterfly_stage(bufA, bufB, 8, 50, tid, 128, false, tw50);   __syncthreads();
+    butterfly_stage(bufB, bufA, 4, 100, tid, 128, false, tw100); __syncthreads();
+    butterfly_stage(bufA, bufB, 2, 200, tid, 128, false, tw200); __syncthreads();
+    butterfly_stage(bufB, bufA, 1, 400, tid, 128, true, tw400);  __syncthreads();
 
     for (int j = tid; j < 201; j += 128) {
         const float re = bufA[2 * j], im = bufA[2 * j + 1];
