@@ -316,7 +316,15 @@ __global__ __launch_bounds__(256) void k_xattn_qscores(const float * __restrict_
         for (int e = 0; e < 8; ++e) { xv[e] = on ? xr[e] : 0.0f; gv[e] = on ? ln_g[lane * 8 + e] : 0.0f; bv[e] = on ? ln_b[lane * 8 + e] : 0.0f; }
     }
     const float bias = bq ? bq[head * 64 + wave * 16 + ((lane >> 2) & 15)] : 0.0f;
-    __builtin_amdgcn_sched_barrier(0);          // keep all 16 + 3 loads in flight together (the scheduler would sink them to their uses)
+    // this thread's first key row (128 B of the cross cache): independent of q, requested with everything else
+    uint4 kfirst[8];
+    {
+        const int j0 = slice * ks + tid;
+        const uint4 * kp0 = (const uint4 *) (kc + (size_t) (j0 < T ? j0 : 0) * S + head * 64);
+#pragma unroll
+        for (int c = 0; c < 8; ++c) kfirst[c] = kp0[c];
+    }
+    __builtin_amdgcn_sched_barrier(0);          // keep all loads in flight together (the scheduler would sink them to their uses)
     float sum = 0.0f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) sum += xv[e];
@@ -380,7 +388,7 @@ __global__ __launch_bounds__(256) void k_xattn_qscores(const float * __restrict_
         const uint4 * kp = (const uint4 *) (kc + (size_t) j * S + head * 64);
         uint4 u[8];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) u[c] = kp[c];
+        for (int c = 0; c < 8; ++c) u[c] = t == tid ? kfirst[c] : kp[c];
         float dot = 0.0f;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
@@ -412,7 +420,15 @@ __global__ __launch_bounds__(256) void k_xattn_pv(const __half * __restrict__ vc
     const size_t row = (size_t) i * H + head;
     vc += (int64_t) i * kv_row_stride;
     float m = -INFINITY;
-    for (int s2 = 0; s2 < ns; ++s2) m = fmaxf(m, pmax[row * ns + s2]);
+    if (ns == 8) {                                  // all loads first (a loop makes them eight dependent round trips)
+        float pm[8];
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) pm[s2] = pmax[row * 8 + s2];
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) m = fmaxf(m, pm[s2]);
+    } else {
+        for (int s2 = 0; s2 < ns; ++s2) m = fmaxf(m, pmax[row * ns + s2]);
+    }
     const int j0 = slice * ks;
     const int cnt = max(0, min(ks, T - j0));
     float lsum = 0.0f;
@@ -427,6 +443,29 @@ __global__ __launch_bounds__(256) void k_xattn_pv(const __half * __restrict__ vc
     float acc[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) acc[d] = 0.0f;
+    // value rows of this lane (every 32nd key of the slice), requested together: at most 8 for slices of <= 256 keys
+    if (cnt <= 256) {
+        uint4 vu[8];
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int t = wave * 8 + kg + 32 * it;
+            vu[it] = t < cnt ? *(const uint4 *) (vc + (size_t) (j0 + t) * S + head * 64 + ch * 8) : make_uint4(0u, 0u, 0u, 0u);
+        }
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int t = wave * 8 + kg + 32 * it;
+            if (t < cnt) {
+                const __half2 * h = (const __half2 *) &vu[it];
+                const float w = e[t];
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const float2 f = __half22float2(h[p]);
+                    acc[2 * p]     = fmaf(w, f.x, acc[2 * p]);
+                    acc[2 * p + 1] = fmaf(w, f.y, acc[2 * p + 1]);
+                }
+            }
+        }
+    } else
     for (int t = wave * 8 + kg; t < cnt; t += 32) {
         const uint4 u = *(const uint4 *) (vc + (size_t) (j0 + t) * S + head * 64 + ch * 8);
         const __half2 * h = (const __half2 *) &u;
@@ -460,7 +499,15 @@ __global__ __launch_bounds__(64) void k_xattn_combine(const float * __restrict__
     const int head = blockIdx.x, i = blockIdx.y, H = gridDim.x, d = threadIdx.x;
     const size_t row = (size_t) i * H + head;
     float o = 0.0f; double l = 0.0;
-    for (int s2 = 0; s2 < ns; ++s2) { o += part_o[(row * ns + s2) * 64 + d]; l += (double) part_l[row * ns + s2]; }
+    if (ns == 8) {
+        float po[8], pl[8];
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) { po[s2] = part_o[(row * 8 + s2) * 64 + d]; pl[s2] = part_l[row * 8 + s2]; }
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) { o += po[s2]; l += (double) pl[s2]; }
+    } else {
+        for (int s2 = 0; s2 < ns; ++s2) { o += part_o[(row * ns + s2) * 64 + d]; l += (double) part_l[row * ns + s2]; }
+    }
     out[(size_t) i * S + head * 64 + d] = f2h(o * (float) (1.0 / l));
 }
 

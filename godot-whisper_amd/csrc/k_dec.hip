@@ -487,7 +487,15 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
             for (int e = tid; e < K; e += 256) {
                 const int h = e >> 6, dd = e & 63;
                 float o = 0.0f; double l = 0.0;
-                for (int s2 = 0; s2 < ns; ++s2) { o += a.comb_o[((size_t) h * ns + s2) * 64 + dd]; l += (double) a.comb_l[(size_t) h * ns + s2]; }
+                if (ns == 8) {                           // T = 1500: all 16 loads of an element go out before the first add
+                    float po[8], pl[8];
+#pragma unroll
+                    for (int s2 = 0; s2 < 8; ++s2) { po[s2] = a.comb_o[((size_t) h * 8 + s2) * 64 + dd]; pl[s2] = a.comb_l[(size_t) h * 8 + s2]; }
+#pragma unroll
+                    for (int s2 = 0; s2 < 8; ++s2) { o += po[s2]; l += (double) pl[s2]; }
+                } else {
+                    for (int s2 = 0; s2 < ns; ++s2) { o += a.comb_o[((size_t) h * ns + s2) * 64 + dd]; l += (double) a.comb_l[(size_t) h * ns + s2]; }
+                }
                 act[e] = f2h(o * (float) (1.0 / l));
             }
             (void) H;
