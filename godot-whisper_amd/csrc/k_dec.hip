@@ -95,15 +95,13 @@ __device__ __forceinline__ void self_attn_row(const __half * __restrict__ sq, co
         const float * row = sc + (size_t) (c >> 6) * cap;
         const __half * vp = sv + c;
         float acc = 0.0f;
-        int j = 0;
-        for (; j + 8 <= n_kv; j += 8) {             // loads issued 8 at a time, accumulated in key order
-            __half vv[8];
+        for (int j = 0; j < n_kv; j += 8) {         // loads issued 8 at a time (the last group predicated: a scalar tail
+            __half vv[8];                           // loop would be up to 7 dependent round trips), accumulated in key order
 #pragma unroll
-            for (int t = 0; t < 8; ++t) vv[t] = vp[(size_t) (j + t) * K];
+            for (int t = 0; t < 8; ++t) vv[t] = vp[(size_t) (j + t < n_kv ? j + t : n_kv - 1) * K];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) acc = fmaf(row[j + t], __half2float(vv[t]), acc);
+            for (int t = 0; t < 8; ++t) if (j + t < n_kv) acc = fmaf(row[j + t], __half2float(vv[t]), acc);
         }
-        for (; j < n_kv; ++j) acc = fmaf(row[j], __half2float(vp[(size_t) j * K]), acc);
         out[c] = f2h(acc);
     }
 }
@@ -157,15 +155,13 @@ __global__ __launch_bounds__(64) void k_self_attn_rows(const __half * __restrict
         const int c = h * 64 + lane;
         const __half * vp = sv + c;
         float acc = 0.0f;
-        int j = 0;
-        for (; j + 8 <= n_kv; j += 8) {
+        for (int j = 0; j < n_kv; j += 8) {
             __half vv[8];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) vv[t] = vp[(size_t) (j + t) * K];
+            for (int t = 0; t < 8; ++t) vv[t] = vp[(size_t) (j + t < n_kv ? j + t : n_kv - 1) * K];
 #pragma unroll
-            for (int t = 0; t < 8; ++t) acc = fmaf(row[j + t], __half2float(vv[t]), acc);
+            for (int t = 0; t < 8; ++t) if (j + t < n_kv) acc = fmaf(row[j + t], __half2float(vv[t]), acc);
         }
-        for (; j < n_kv; ++j) acc = fmaf(row[j], __half2float(vp[(size_t) j * K]), acc);
         out[(size_t) r * K + c] = f2h(acc);
     }
 }
