@@ -137,7 +137,9 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
         }
     };
 
-    if (BM == 128 && BN == 128 && (a.K % BK) == 0 && !(a.no_glds & 1)) {
+    // 64x64 tiles take the same path while the grid is small (one chunk: latency-bound, -11..15 % per GEMM); with
+    // thousands of small tiles the register-staged loop is the faster one (measured, scratch/lab/gemm_lab.hip)
+    if ((BM == 128 || nwg <= 1024) && (a.K % BK) == 0 && !(a.no_glds & 1)) {
         // Large tiles (batched encoder, cross K/V): operands go global -> LDS directly (global_load_lds, 16 B per lane,
         // 1 KiB per wave instruction, no staging VGPRs or ds_write pass).  LDS is written lane-linearly, so the XOR
         // swizzle is applied to each lane's GLOBAL address instead: position p = row*8 + (chunk ^ (row & 7)) of a

@@ -390,6 +390,90 @@ void launch_persist(const GemmArgs & a, hipStream_t st, int blocks_per_cu) {
     hipLaunchKernelGGL(k_gemm_persist, dim3(grid), dim3(256), 65536, st, a);
 }
 
+
+// 64x64 tiles with global_load_lds staging (2 x 2 waves of 32 x 32), NBUF stages of 16 KiB
+template <int NBUF>
+__global__ __launch_bounds__(256) void k_gemm_glds64(const GemmArgs a) {
+    constexpr int BM = 64, BN = 64;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN, nwg = ntm * ntn;
+    int wg = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, idx = wg / 8;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = wg / ntn, tn = wg % ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int prow = lane >> 3;
+    const __half * gA[2]; const __half * gB[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int lrow = (wave * 2 + p) * 8 + prow, pch = (lane & 7) ^ (lrow & 7);
+        int r = m0 + lrow; if (r > a.M - 1) r = a.M - 1;
+        gA[p] = a.A + (size_t) r * a.lda + pch * 8;
+        r = n0 + lrow; if (r > a.N - 1) r = a.N - 1;
+        gB[p] = a.W + (size_t) r * a.ldw + pch * 8;
+    }
+    f4 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f4{0.f, 0.f, 0.f, 0.f};
+    const int nk = a.K / 64;
+    auto sA = [&](int buf) -> unsigned char * { return smem + buf * 16384; };
+    auto sB = [&](int buf) -> unsigned char * { return smem + buf * 16384 + 8192; };
+    auto issue = [&](int kt, int buf) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            __builtin_amdgcn_global_load_lds((const void *) (gA[p] + kt * 64), (__attribute__((address_space(3))) void *) (sA(buf) + (wave * 2 + p) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void *) (gB[p] + kt * 64), (__attribute__((address_space(3))) void *) (sB(buf) + (wave * 2 + p) * 1024), 16, 0, 0);
+        }
+    };
+    const int frow = lane & 15, fq = lane >> 4;
+    issue(0, 0);
+    if (NBUF > 2 && nk > 1) issue(1, 1);
+    for (int kt = 0; kt < nk; ++kt) {
+        if (NBUF > 2 && kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        const int ahead = NBUF > 2 ? 2 : 1;
+        if (kt + ahead < nk) issue(kt + ahead, (kt + ahead) % NBUF);
+        const int buf = kt % NBUF;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            h8 fa[2], fb[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) fa[i] = *(const h8 *) (sA(buf) + lds_off(wm * 32 + i * 16 + frow, kk * 4 + fq));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[j] = *(const h8 *) (sB(buf) + lds_off(wn * 32 + j * 16 + frow, kk * 4 + fq));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    const int mb = m0 + wm * 32, nb = n0 + wn * 32;
+    const bool full = (m0 + BM <= a.M) && (n0 + BN <= a.N);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int n = nb + j * 16 + frow;
+        if (!full && n >= a.N) continue;
+        const float bias = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = mb + i * 16 + fq * 4 + r;
+                if (full || m < a.M) ((__half *) a.C)[(size_t) m * a.ldc + n] = f2h(acc[i][j][r] + bias);
+            }
+    }
+}
+template <int NBUF> void launch_glds64(const GemmArgs & a, hipStream_t st) {
+    const int ntm = (a.M + 63) / 64, ntn = (a.N + 63) / 64;
+    hipLaunchKernelGGL((k_gemm_glds64<NBUF>), dim3(ntm * ntn), dim3(256), NBUF * 16384, st, a);
+}
+
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
 
 int main(int argc, char ** argv) {
@@ -447,6 +531,8 @@ int main(int argc, char ** argv) {
         };
         run("glds1 ep1", [&]() { launch_glds<1, 0, 1>(a1, st); });
         run("glds2 ep1", [&]() { launch_glds<2, 0, 1>(a1, st); });
+        run("glds64 2buf", [&]() { launch_glds64<2>(a1, st); });
+        run("glds64 3buf", [&]() { launch_glds64<3>(a1, st); });
         run("persist 2/CU", [&]() { launch_persist(a1, st, 2); });
         run("persist 1/CU", [&]() { launch_persist(a1, st, 1); });
         run("g1 loadonly", [&]() { launch_glds<1, 0, 1, 1>(a1, st); });
