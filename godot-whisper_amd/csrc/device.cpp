@@ -150,17 +150,21 @@ bool signal_energy_device(whisper_context & ctx, int hw, bool sync) {
     }
     if (d.energy_pending) { HIP_TRY(hipStreamSynchronize(d.copy_stream)); d.energy_pending = false; }   // previous envelope still being written
     if ((size_t) n > d.energy_cap) {
-        st.energy = nullptr; st.energy_n = 0;
+        st.energy = nullptr; st.energy_n = 0; st.energy_bmin = st.energy_bmax = nullptr;
         if (d.energy_host) (void) hipHostFree(d.energy_host);
         d.energy_host = nullptr; d.energy_cap = 0;
-        if (!HIP_OK(hipHostMalloc((void **) &d.energy_host, (size_t) n * 4, hipHostMallocDefault))) return false;
+        // envelope [n] | block minima [n/256] | block maxima [n/256]
+        if (!HIP_OK(hipHostMalloc((void **) &d.energy_host, ((size_t) n + 2 * ((size_t) n / 256 + 2)) * 4, hipHostMallocDefault))) return false;
         d.energy_cap = (size_t) n;
     }
     // The kernel runs on the side stream, behind the staging of the samples, and stores straight into pinned host
     // memory: no memcpy call, and the 1.9 MB of PCIe writes overlap the encoder on the main stream.
     HIP_TRY(hipEventRecord(d.energy_ev, d.mel_stream ? d.mel_stream : d.stream));
     HIP_TRY(hipStreamWaitEvent(d.copy_stream, d.energy_ev, 0));
-    k::signal_energy(d.last_pcm, n, hw, d.energy_host, d.copy_stream);
+    {
+        const size_t nb = (size_t) n / 256 + 2;
+        k::signal_energy(d.last_pcm, n, hw, d.energy_host, d.energy_host + d.energy_cap, d.energy_host + d.energy_cap + nb, d.copy_stream);
+    }
     d.energy_pending = true;
     return sync ? signal_energy_wait(st) : true;
 }
@@ -170,6 +174,7 @@ bool signal_energy_wait(State & st) {
     if (!d.energy_pending) return true;
     HIP_TRY(hipStreamSynchronize(d.copy_stream));
     st.energy = d.energy_host; st.energy_n = d.last_pcm_n;
+    st.energy_bmin = d.energy_host + d.energy_cap; st.energy_bmax = st.energy_bmin + ((size_t) d.last_pcm_n / 256 + 2);
     d.energy_pending = false;
     return true;
 }

@@ -8,6 +8,7 @@
 #include "wmi.h"
 
 #include <algorithm>
+#include <immintrin.h>
 #include <climits>
 #include <cmath>
 #include <cstdint>
@@ -525,50 +526,44 @@ void token_level_timestamps(whisper_context & ctx, State & st, int i_segment, fl
     // the signal on stationary audio — millions of scalar steps per call in the reference.  They are pure
     // searches, so they are done 16 samples at a time with a branch-free block test the compiler vectorises;
     // the element they stop on is the same.
+    // The walks are pure searches.  With the per-256-sample block minima / maxima the GPU wrote next to the envelope a
+    // whole block is decided by one comparison (all above th <=> block min > th, all below <=> block max < th); the
+    // sample the walk stops on is the same as for the reference's one-by-one loop.
+    const float * bmin = st.energy_bmin, * bmax = st.energy_bmax;
     auto walk_down_while_above = [&](int k, float th) {      // while (k > 0 && en[k] > th) --k;
-        while (k >= 16) {
-            bool all = true;
-            for (int i = 0; i < 16; ++i) all &= en[k - i] > th;
-            if (!all) break;
-            k -= 16;
+        while (k > 0 && en[k] > th) {
+            if ((k & 255) == 255 && bmin && bmin[k >> 8] > th) { if (k < 256) return 0; k -= 256; continue; }
+            --k;
         }
-        while (k > 0 && en[k] > th) --k;
         return k;
     };
     auto walk_up_while_above = [&](int k, float th, int last) {   // while (k < last && en[k] > th) ++k;
-        while (k + 16 <= last) {
-            bool all = true;
-            for (int i = 0; i < 16; ++i) all &= en[k + i] > th;
-            if (!all) break;
-            k += 16;
+        while (k < last && en[k] > th) {
+            if ((k & 255) == 0 && k + 256 <= last && bmin && bmin[k >> 8] > th) { k += 256; continue; }
+            ++k;
         }
-        while (k < last && en[k] > th) ++k;
         return k;
     };
     auto walk_up_while_below = [&](int k, float th, int last) {   // while (en[k] < th && k < last) ++k;
-        while (k + 16 <= last) {
-            bool all = true;
-            for (int i = 0; i < 16; ++i) all &= en[k + i] < th;
-            if (!all) break;
-            k += 16;
+        while (en[k] < th && k < last) {
+            if ((k & 255) == 0 && k + 256 <= last && bmax && bmax[k >> 8] < th) { k += 256; continue; }
+            ++k;
         }
-        while (en[k] < th && k < last) ++k;
         return k;
     };
     auto walk_down_while_below = [&](int k, float th, int first) { // while (en[k] < th && k > first) --k;
-        while (k - 16 >= first) {
-            bool all = true;
-            for (int i = 0; i < 16; ++i) all &= en[k - i] < th;
-            if (!all) break;
-            k -= 16;
+        while (en[k] < th && k > first) {
+            if ((k & 255) == 255 && k - 256 >= first && bmax && bmax[k >> 8] < th) { k -= 256; continue; }
+            --k;
         }
-        while (en[k] < th && k > first) --k;
         return k;
     };
     // Window sums of the envelope (the threshold of each token).  A token's window depends only on its t0 / t1 as
     // they stand before this loop (iteration j rewrites tokens[j] only, after its own sum), so all sums are taken
     // first.  Each one must stay a sequential left-to-right f32 sum (the reference's rounding), i.e. a 4-cycle
     // dependency chain per add — eight tokens are therefore summed side by side, eight independent chains.
+    static const bool dbg_ts = getenv("WMI_DEBUG_EMIT") != nullptr;
+    const int64_t ts0 = time_us();
     std::vector<float> win_sum(n, 0.0f);
     {
         std::vector<int> idx;
@@ -588,13 +583,19 @@ void token_level_timestamps(whisper_context & ctx, State & st, int i_segment, fl
                 acc[0] += base[0][i]; acc[1] += base[1][i]; acc[2] += base[2][i]; acc[3] += base[3][i];
                 acc[4] += base[4][i]; acc[5] += base[5][i]; acc[6] += base[6][i]; acc[7] += base[7][i];
             }
-            for (int t = 0; t < ng; ++t) {
-                float sum = acc[t];
-                for (int i = common; i < len[t]; ++i) sum += base[t][i];
-                win_sum[idx[g0 + t]] = sum;
+            // the rest in lock-step too, windows that have ended add +0.0f (the envelope is non-negative, so the
+            // accumulators are never -0.0 and x + 0.0f == x exactly): eight chains stay in flight to the longest window
+            int longest = 0;
+            for (int t = 0; t < 8; ++t) longest = std::max(longest, len[t]);
+            for (int i = common; i < longest; ++i) {
+#pragma GCC unroll 8
+                for (int t = 0; t < 8; ++t) acc[t] += i < len[t] ? base[t][i] : 0.0f;
             }
+            for (int t = 0; t < ng; ++t) win_sum[idx[g0 + t]] = acc[t];
         }
     }
+    const int64_t ts1 = time_us();
+    struct TsReport { bool on; int64_t a, b; ~TsReport() { if (on) fprintf(stderr, "[wmi] token timestamps: window sums %lld us, walks %lld us\n", (long long) (b - a), (long long) (time_us() - b)); } } ts_report{dbg_ts, ts0, ts1};
     for (int j = 0; j < n; ++j) {
         if (tokens[j].id >= v.eot) continue;
         int s0 = ts_to_sample(tokens[j].t0, n_samples), s1 = ts_to_sample(tokens[j].t1, n_samples);

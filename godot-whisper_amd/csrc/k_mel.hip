@@ -198,15 +198,32 @@ __global__ void k_mel_slice(const float * __restrict__ mel, int n_len, int n_mel
 // mean |x| over a (2 hw + 1)-sample window, summed left to right with the reference's exact arithmetic
 // (float accumulator, each step rounded through a double add: `sum += fabs(x)`, W/whisper.cpp:6352-6366),
 // so the host-side timestamp heuristics see bit-identical thresholds.
-__global__ void k_signal_energy(const float * __restrict__ x, int n, int hw, float * __restrict__ out) {
+// Also written: the minimum and maximum of every 256-sample block of the envelope (bmin / bmax) — the token-timestamp
+// heuristics walk outwards from a token "while the envelope stays above / below a threshold" (W/whisper.cpp:6500-6590),
+// on stationary audio across the whole signal for every token; with the block extrema the host skips 256 samples per
+// comparison and stops on exactly the same sample.
+__global__ __launch_bounds__(256) void k_signal_energy(const float * __restrict__ x, int n, int hw, float * __restrict__ out,
+                                                       float * __restrict__ bmin, float * __restrict__ bmax) {
+    __shared__ float s_min[4], s_max[4];
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    float sum = 0.0f;
-    for (int j = -hw; j <= hw; ++j) {
-        const int k = i + j;
-        if (k >= 0 && k < n) sum = (float) ((double) sum + fabs((double) x[k]));
+    float v = 0.0f;
+    if (i < n) {
+        float sum = 0.0f;
+        for (int j = -hw; j <= hw; ++j) {
+            const int k = i + j;
+            if (k >= 0 && k < n) sum = (float) ((double) sum + fabs((double) x[k]));
+        }
+        v = sum / (float) (2 * hw + 1);
+        out[i] = v;
     }
-    out[i] = sum / (float) (2 * hw + 1);
+    float lo = i < n ? v : INFINITY, hi = i < n ? v : -INFINITY;
+    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+    if ((threadIdx.x & 63) == 0) { s_min[threadIdx.x >> 6] = lo; s_max[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bmin[blockIdx.x] = fminf(fminf(s_min[0], s_min[1]), fminf(s_min[2], s_min[3]));
+        bmax[blockIdx.x] = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    }
 }
 
 __global__ void k_fill_zero(uint32_t * p, size_t n) {
@@ -244,8 +261,8 @@ void mel_slice(const float * mel, int n_len, int n_mel, int offset, int n_frames
     hipLaunchKernelGGL(k_mel_slice, grid, dim3(256), 0, st, mel, n_len, n_mel, offset, n_frames, out, ld, rows_total);
 }
 
-void signal_energy(const float * pcm, int n, int hw, float * out, hipStream_t st) {
-    hipLaunchKernelGGL(k_signal_energy, dim3((n + 255) / 256), dim3(256), 0, st, pcm, n, hw, out);
+void signal_energy(const float * pcm, int n, int hw, float * out, float * bmin, float * bmax, hipStream_t st) {
+    hipLaunchKernelGGL(k_signal_energy, dim3((n + 255) / 256), dim3(256), 0, st, pcm, n, hw, out, bmin, bmax);
 }
 
 __global__ void k_touch(int * p, int nblk) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] += 1; }

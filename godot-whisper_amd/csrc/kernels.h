@@ -31,7 +31,8 @@ void mel_slice(const float * mel, int n_len, int n_mel, int offset, int n_frames
                int rows_total, hipStream_t st);
 
 // |x| envelope for the token-level timestamp heuristics (W/whisper.cpp:6352-6366), bit-identical to the CPU loop
-void signal_energy(const float * pcm, int n, int hw, float * out, hipStream_t st);
+// out[n] plus the minimum / maximum of each 256-sample block of out (bmin, bmax: ceil(n / 256) entries)
+void signal_energy(const float * pcm, int n, int hw, float * out, float * bmin, float * bmax, hipStream_t st);
 
 // ---------------------------------------------------------------- GEMM (k_gemm.hip)
 enum Epi : int {

@@ -207,6 +207,7 @@ struct State {
     int     lang_id = 0;
     int64_t t_beg = 0, t_last = 0; int32_t tid_last = 0;
     const float * energy = nullptr; int energy_n = 0;   // |x| envelope of the last PCM (view of dev.energy_host)
+    const float * energy_bmin = nullptr, * energy_bmax = nullptr;   // its per-256-sample block extrema
     int32_t exp_n_audio_ctx = 0;
     int     enc_n_ctx = 0;                        // n_ctx of the last encode (cross cache extent)
     DeviceState dev;
