@@ -544,3 +544,26 @@ def test_parameter_variants_equal_the_compiled_reference(product_lib, checker_li
         assert np.abs(tp[:, 2] - tr[:, 2]).max() <= 1e-2
         if variant in ("max_len_wrap", "max_len_chars", "thold"):            # token-level timestamps (last t1: reference UB, see above)
             assert np.array_equal(tp[:, 6], tr[:, 6]) and np.array_equal(tp[:-1, 7], tr[:-1, 7]), variant
+
+
+# ------------------------------------------------------------------------------------------------ lifecycle
+def test_context_lifecycle_releases_device_memory(product_lib):
+    """whisper_init / whisper_full / wmi_full_batch / whisper_free in a loop: device memory returns to its level
+    (weights arena, state arenas, lock-step work set, per-chunk streams and pinned buffers are all released)."""
+    hip = _hip()
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        assert hip.hipMemGetInfo(C.byref(f), C.byref(t)) == 0
+        return f.value
+    model = synth.make_model("micro.en", seed=3)
+    pcms = [synth.make_pcm(5.0, seed=70 + i) for i in range(3)]
+    def cycle():
+        node = host.SpeechToText(product_lib); node.set_language_model(model)
+        assert node.transcribe(pcms[0], "", 0)
+        assert len(node.transcribe_batch(pcms, "", 0)) == 3
+        node.close()
+    cycle()                                   # first use: module load, lazy runtime allocations
+    level = free_bytes()
+    for _ in range(8):
+        cycle()
+    assert level - free_bytes() <= 8 << 20, (level, free_bytes())      # allocator granularity, no per-cycle growth
