@@ -343,7 +343,7 @@ int wmi_full_batch(struct whisper_context * ctx, struct whisper_full_params para
     return full_batch(*ctx, params, pcm, n_samples, n_chunks, pcm_on_device != 0);
 }
 
-void wmi_set_lockstep_exact(int on) { k::set_rows_valu(on != 0); }
+void wmi_set_lockstep_exact(int on) { k::set_rows_valu(on != 0); k::set_attn_one_group(on != 0); }
 
 int wmi_batch_select(struct whisper_context * ctx, int chunk) {
     if (!ctx || !ctx->state || !ctx->batch || chunk < 0 || chunk >= (int) ctx->batch->results.size()) return -1;

@@ -36,13 +36,19 @@ __device__ __forceinline__ float exp16_fast(float d) { return round_f16(__expf(r
 
 __device__ __forceinline__ uint32_t lds_off(int row, int chunk) { return (uint32_t) (row * 128 + ((chunk ^ (row & 7)) << 4)); }
 
-template <int NW>
-__global__ __launch_bounds__(NW * 64) void k_attn_enc(const __half * __restrict__ q, const __half * __restrict__ k,
+// KS = 2: two groups of NW wavefronts share the 64 query rows and take one half of the keys each (own K / V^T tiles,
+// common barriers); the halves exchange the row maxima after sweep 1 (the soft-max stays exact) and add their partial
+// sums and outputs at the end.  Used when the grid is small (one or two chunks: 192 workgroups on 256 CUs at one wave per
+// SIMD): twice the wavefronts per CU let the MFMA and the exp / packing VALU work of different waves overlap.
+template <int NW, int KS>
+__global__ __launch_bounds__(NW * 64 * KS) void k_attn_enc(const __half * __restrict__ q, const __half * __restrict__ k,
                                                   const __half * __restrict__ vt, int T, int Tpad, int S, float scale,
                                                   __half * __restrict__ out) {
-    __shared__ __attribute__((aligned(16))) unsigned char sK[64 * 128];
-    __shared__ __attribute__((aligned(16))) unsigned char sV[64 * 128];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ __attribute__((aligned(16))) unsigned char sK_[KS][64 * 128];
+    __shared__ __attribute__((aligned(16))) unsigned char sV_[KS][64 * 128];
+    const int half = KS == 1 ? 0 : (int) (threadIdx.x / (NW * 64));       // key half of this wavefront group
+    unsigned char * sK = sK_[half], * sV = sV_[half];
+    const int tid = threadIdx.x - half * (NW * 64), lane = tid & 63, wave = tid >> 6;
     const int fr = lane & 15, fq = lane >> 4;
     const int head = blockIdx.y;
     const int q0 = blockIdx.x * (NW * 16) + wave * 16;
@@ -71,7 +77,8 @@ __global__ __launch_bounds__(NW * 64) void k_attn_enc(const __half * __restrict_
 #define LOAD_K(kt0_) do { int kr_ = (kt0_) + srow; if (kr_ > T - 1) kr_ = T - 1;                                   \
         const uint4 * src_ = (const uint4 *) (k + (size_t) kr_ * S + head * 64 + sch * 8);                          \
         rk0 = src_[0]; rk1 = src_[1]; if constexpr (CPT == 4) { rk2 = src_[2]; rk3 = src_[3]; } } while (0)
-#define LOAD_V(kt0_) do { const uint4 * src_ = (const uint4 *) (vt + (size_t) (head * 64 + srow) * Tpad + (kt0_) + sch * 8); \
+#define LOAD_V(kt0_) do { int kv_ = (kt0_); if (kv_ > Tpad - 64) kv_ = Tpad - 64;                                     \
+        const uint4 * src_ = (const uint4 *) (vt + (size_t) (head * 64 + srow) * Tpad + kv_ + sch * 8);              \
         rv0 = src_[0]; rv1 = src_[1]; if constexpr (CPT == 4) { rv2 = src_[2]; rv3 = src_[3]; } } while (0)
 #define STORE_K() do { *(uint4 *) (sK + lds_off(srow, sch)) = rk0; *(uint4 *) (sK + lds_off(srow, sch + 1)) = rk1;   \
         if constexpr (CPT == 4) { *(uint4 *) (sK + lds_off(srow, sch + 2)) = rk2; *(uint4 *) (sK + lds_off(srow, sch + 3)) = rk3; } } while (0)
@@ -87,13 +94,17 @@ __global__ __launch_bounds__(NW * 64) void k_attn_enc(const __half * __restrict_
         return acc;                                           // acc[r] = S[q = fr][key = kt*16 + fq*4 + r]
     };
 
+    // keys of this group: [kbeg, kend), tile-aligned split; both groups run the same number of tiles (common barriers)
+    const int ntile_all = (T + 63) / 64, ntile_h = (ntile_all + KS - 1) / KS;
+    const int kbeg = half * ntile_h * 64, kend_loop = kbeg + ntile_h * 64;
+
     // ---- sweep 1: exact row max
     float m = -INFINITY;
-    LOAD_K(0);
-    for (int kt0 = 0; kt0 < T; kt0 += 64) {
+    LOAD_K(kbeg);
+    for (int kt0 = kbeg; kt0 < kend_loop; kt0 += 64) {
         STORE_K();
         __syncthreads();
-        if (kt0 + 64 < T) LOAD_K(kt0 + 64);
+        if (kt0 + 64 < kend_loop) LOAD_K(kt0 + 64);
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt) {
             const floatx4 acc = score_tile(kt);
@@ -107,17 +118,23 @@ __global__ __launch_bounds__(NW * 64) void k_attn_enc(const __half * __restrict_
     }
     m = fmaxf(m, __shfl_xor(m, 16));
     m = fmaxf(m, __shfl_xor(m, 32));
+    if (KS == 2) {                                           // exact row max over both key halves
+        __shared__ float s_m[2][NW][16];
+        if (lane < 16) s_m[half][wave][lane] = m;
+        __syncthreads();
+        m = fmaxf(s_m[0][wave][fr], s_m[1][wave][fr]);
+    }
 
     // ---- sweep 2: e = exp16(s - max), l = sum e, O += e . V
     float l = 0.0f;
     floatx4 o[4];
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) o[nt] = floatx4{0.f, 0.f, 0.f, 0.f};
-    LOAD_K(0); LOAD_V(0);
-    for (int kt0 = 0; kt0 < T; kt0 += 64) {
+    LOAD_K(kbeg); LOAD_V(kbeg);
+    for (int kt0 = kbeg; kt0 < kend_loop; kt0 += 64) {
         STORE_K(); STORE_V();
         __syncthreads();
-        if (kt0 + 64 < T) { LOAD_K(kt0 + 64); LOAD_V(kt0 + 64); }
+        if (kt0 + 64 < kend_loop) { LOAD_K(kt0 + 64); LOAD_V(kt0 + 64); }
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             half8 pf;
@@ -149,6 +166,23 @@ __global__ __launch_bounds__(NW * 64) void k_attn_enc(const __half * __restrict_
     }
     l += __shfl_xor(l, 16);
     l += __shfl_xor(l, 32);
+    if (KS == 2) {                                           // second half hands its partial sums and outputs to the first
+        __shared__ float s_o[NW][64][17];
+        if (half == 1) {
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) s_o[wave][lane][nt * 4 + r] = o[nt][r];
+            s_o[wave][lane][16] = l;
+        }
+        __syncthreads();
+        if (half == 1) return;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[nt][r] += s_o[wave][lane][nt * 4 + r];
+        l += s_o[wave][lane][16];
+    }
     const float inv = (float) (1.0 / (double) l);
 
     // o[nt][r]: query row fq*4 + r, value column nt*16 + fr
@@ -572,11 +606,18 @@ size_t attn_cross_scratch_floats(int n, int H, int T) {
     return (size_t) n * H * ((size_t) ld_sc + 2 * XS_MAX_SLICES + (size_t) XS_MAX_SLICES * 64);
 }
 
+static bool g_attn_one_group = false;
+void set_attn_one_group(bool on) { g_attn_one_group = on; }
+
 void attn_encoder(const __half * q, const __half * k, const __half * vt, int T, int Tpad, int S, int H, float scale,
                   __half * out, hipStream_t st, int B) {
     static const int nw = getenv("WMI_ATTN_NW") ? atoi(getenv("WMI_ATTN_NW")) : 4;      // wavefronts per workgroup (A/B knob)
-    if (nw == 4) hipLaunchKernelGGL((k_attn_enc<4>), dim3((T + 63) / 64, H, B), dim3(256), 0, st, q, k, vt, T, Tpad, S, scale, out);
-    else         hipLaunchKernelGGL((k_attn_enc<2>), dim3((T + 31) / 32, H, B), dim3(128), 0, st, q, k, vt, T, Tpad, S, scale, out);
+    static const int ksplit = getenv("WMI_ATTN_KSPLIT") ? atoi(getenv("WMI_ATTN_KSPLIT")) : -1;      // A/B knob; default: by grid size
+    const int nblk = ((T + 63) / 64) * H * B;
+    const bool ks2 = ksplit >= 0 ? ksplit == 2 : (nblk <= 512 && T >= 256 && !g_attn_one_group);
+    if (nw == 4 && ks2) hipLaunchKernelGGL((k_attn_enc<4, 2>), dim3((T + 63) / 64, H, B), dim3(512), 0, st, q, k, vt, T, Tpad, S, scale, out);
+    else if (nw == 4)   hipLaunchKernelGGL((k_attn_enc<4, 1>), dim3((T + 63) / 64, H, B), dim3(256), 0, st, q, k, vt, T, Tpad, S, scale, out);
+    else                hipLaunchKernelGGL((k_attn_enc<2, 1>), dim3((T + 31) / 32, H, B), dim3(128), 0, st, q, k, vt, T, Tpad, S, scale, out);
 }
 
 void attn_decoder(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int n_kv,

@@ -56,9 +56,10 @@ WHISPER_API int wmi_full_device_pcm(struct whisper_context * ctx, struct whisper
  * pcm[c] are host pointers, or device pointers when pcm_on_device != 0.  Returns whisper_full's codes. */
 WHISPER_API int wmi_full_batch(struct whisper_context * ctx, struct whisper_full_params params, const float * const * pcm,
                                const int * n_samples, int n_chunks, int pcm_on_device);
-/* Lock-step projections run on the matrix cores by default (f32 sums in MFMA order).  on != 0 keeps them on the
- * weight-streaming VALU kernel, whose per-row arithmetic is bit-identical to the one-chunk path: the results of
- * wmi_full_batch then equal whisper_full's bit for bit (used by the parity tests; process-wide debug switch). */
+/* Lock-step projections run on the matrix cores by default (f32 sums in MFMA order), and a one-chunk encoder splits
+ * the attention keys over two wavefront groups (partial sums added at the end).  on != 0 keeps the projections on the
+ * weight-streaming VALU kernel and the attention on one group for every batch size: wmi_full_batch and whisper_full
+ * then agree bit for bit (used by the parity tests; process-wide debug switch, set it before both calls). */
 WHISPER_API void wmi_set_lockstep_exact(int on);
 /* Make the whisper_full_n_segments / whisper_full_get_* accessors (W/whisper.h:541-575) read chunk `chunk` of the
  * last wmi_full_batch call.  Returns its segment count, -1 for a bad index. */
