@@ -109,6 +109,9 @@ def test_host_only_context_has_no_compute_path(lib):
         assert lib.whisper_decode(ctx, tok, 1, 0, 1) != 0
         p = lib.whisper_full_default_params(0)
         assert lib.whisper_full(ctx, p, sc._fptr(pcm), pcm.size) == -2
+        ptrs = (C.c_void_p * 2)(pcm.ctypes.data, pcm.ctypes.data); lens = (C.c_int * 2)(pcm.size, pcm.size)
+        assert lib.wmi_full_batch(ctx, p, ptrs, lens, 2, 0) == -2          # lock-step entry point: same loud failure
+        assert lib.wmi_batch_select(ctx, 0) == -1 or lib.whisper_full_n_segments(ctx) == 0
     finally:
         lib.whisper_free(ctx)
 
