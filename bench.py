@@ -178,6 +178,7 @@ def main():
         }
         if batch8:
             out["batch8"] = batch8
+
         if stream:
             out["stream_small"] = stream
         # ---- roofline of the dominant kernel, measured live with HIP events on the context's stream.
@@ -217,6 +218,21 @@ def main():
             out["encoder_tflops_end_to_end"] = round(ENC_GFLOP / enc_ms, 2)
         except Exception as e:  # pragma: no cover
             out["roofline_error"] = repr(e)
+        # ---- 16 chunks in lock-step (after the kernel micro-benchmarks above, which use the 8-chunk work set)
+        if batch8 is not None:
+            nb16 = 16
+            ptrs16, lens16 = batch_args(0, nb16)
+            for _ in range(2):
+                assert lib.wmi_full_batch(ctx, params, ptrs16, lens16, nb16, 1) == 0
+            torch.cuda.synchronize()
+            tb0 = time.perf_counter()
+            reps16 = 3
+            for _ in range(reps16):
+                assert lib.wmi_full_batch(ctx, params, ptrs16, lens16, nb16, 1) == 0
+            torch.cuda.synchronize()
+            tb16 = (time.perf_counter() - tb0) / reps16
+            out["batch16"] = {"workload": "16 x 30 s chunks per call in lock-step, same params", "value": round(nb16 * CHUNK_S / tb16, 1),
+                              "unit": "x realtime", "ms_per_call": round(tb16 * 1e3, 3)}
         # ---- CPU baseline on this box's host cores (bounded sample), rank 0 / N=1 only
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model_bytes, pcm_host[0])

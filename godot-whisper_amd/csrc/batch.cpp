@@ -25,7 +25,7 @@ namespace wmi {
 
 namespace {
 
-constexpr int MAX_LANES = 8;               // rows of k_gemv
+constexpr int MAX_LANES = 16;              // columns of k_rows_mfma (the exact mode stays within k_gemv's 8 rows)
 
 template <typename T> bool dalloc(T *& p, size_t n_elems) {
     p = nullptr;
@@ -344,7 +344,8 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
         WMI_ERR("%s: audio_ctx is larger than the maximum allowed (%d > %d)\n", __func__, params.audio_ctx, hp.n_audio_ctx);
         return -5;
     }
-    if (!ensure_batch(ctx, std::min(n_chunks, MAX_LANES))) return -2;
+    const int max_lanes = k::rows_valu_enabled() ? 8 : MAX_LANES;
+    if (!ensure_batch(ctx, std::min(n_chunks, max_lanes))) return -2;
     BatchWork & b = *ctx.batch;
     if (!upload_static_ban(ctx, params)) return -7;
     // the envelope kernels read the caller's samples on side streams: never return while one is in flight
@@ -372,8 +373,9 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
     { auto sp = v.token_to_id.find(" "); if (sp != v.token_to_id.end()) space_id = sp->second; }
     const int n_max = hp.n_text_ctx / 2 - 4;
 
-    for (int g0 = 0; g0 < n_chunks; g0 += b.B) {
-        const int ng = std::min(b.B, n_chunks - g0);
+    const int group = std::min(b.B, max_lanes);
+    for (int g0 = 0; g0 < n_chunks; g0 += group) {
+        const int ng = std::min(group, n_chunks - g0);
         std::vector<Row> rows(ng);
         // ---- per chunk: PCM -> mel, envelope, window bounds (the head of full())
         for (int r = 0; r < ng; ++r) {

@@ -819,6 +819,7 @@ void self_attn_rows(const __half * q, int n, int K, const __half * kc, const __h
 
 static bool g_rows_valu = false;
 void set_rows_valu(bool on) { g_rows_valu = on; }
+bool rows_valu_enabled() { static const bool env = getenv("WMI_ROWS_VALU") != nullptr; return env || g_rows_valu; }
 
 void gemv(const GemvArgs & a, hipStream_t st) {
     // lock-step chunk rows go to the matrix cores (WMI_ROWS_VALU=1 keeps them on the VALU kernel, whose per-row

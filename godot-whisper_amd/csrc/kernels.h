@@ -127,6 +127,7 @@ void attn_cross_combine(const float * part_o, const float * part_l, int ns, int 
 enum { EPI_LOGITS = 100 };                    // C f32 [n][N] = acc
 void gemv(const GemvArgs & a, hipStream_t st);
 void set_attn_one_group(bool on);              // encoder attention: never split the keys over two wave groups (bit-identical for any batch)
+bool rows_valu_enabled();
 void set_rows_valu(bool on);                  // lock-step rows: true = VALU kernel (bit-identical to the one-row path), false = MFMA
 
 // ---------------------------------------------------------------- device-side logit filters + greedy pick (k_sample.hip)

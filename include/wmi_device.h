@@ -48,7 +48,7 @@ WHISPER_API int wmi_full_device_pcm(struct whisper_context * ctx, struct whisper
  * transcribed as by whisper_full(ctx, params, pcm[c], n_samples[c]) on a freshly initialised context
  * (params.no_context = true, decoder RNGs at their initial seed);
  * the chunks share the weights and advance together: encoder GEMMs over all chunks at once (M = chunks * n_ctx),
- * one decode step = one token for every chunk.  More than 8 chunks are processed in groups of 8.
+ * one decode step = one token for every chunk.  Up to 16 chunks advance together; more are processed in groups of 16.
  * replaces: the per-worker loop of whisper_full_parallel (W/whisper.cpp:5809-5935: shared model, one
  * whisper_state per worker) — workers are rows of the same kernels instead of threads.
  * Lock-step needs greedy sampling at temperature 0 without callbacks and a known language; otherwise, and for
