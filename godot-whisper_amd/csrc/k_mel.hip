@@ -81,7 +81,8 @@ __global__ void k_mel_tail(float * __restrict__ mel, int n_len, int n_mel, int n
     if (i == 0 && w > 0) atomicMax(gmax, enc_ordered(-10.0f));
 }
 
-__global__ __launch_bounds__(128) void k_mel_frames(const float * __restrict__ pad, int n_valid, int n_fft_frames,
+constexpr int MEL_NT = 256;            // threads per frame (4 wavefronts: 1.6 leaf-DFT outputs per thread)
+__global__ __launch_bounds__(MEL_NT) void k_mel_frames(const float * __restrict__ pad, int n_valid, int n_fft_frames,
                                                     int n_len, int n_mel, const float * __restrict__ filters,
                                                     const int32_t * __restrict__ ranges,
                                                     float * __restrict__ mel, int * __restrict__ gmax) {
@@ -99,8 +100,8 @@ __global__ __launch_bounds__(128) void k_mel_frames(const float * __restrict__ p
 
     const int offset = frame * 160;
     int nin = n_valid - offset; if (nin > 400) nin = 400;
-    for (int j = tid; j < 400; j += 128) xin[j] = j < nin ? c_mel.hann[j] * pad[offset + j] : 0.0f;
-    for (int j = tid; j < 400; j += 128) {
+    for (int j = tid; j < 400; j += MEL_NT) xin[j] = j < nin ? c_mel.hann[j] * pad[offset + j] : 0.0f;
+    for (int j = tid; j < 400; j += MEL_NT) {
         if (j < 25)       { tw25[j] = make_float2(c_mel.cosv[16 * j], c_mel.sinv[16 * j]); tw50[j] = make_float2(c_mel.cosv[8 * j], c_mel.sinv[8 * j]); }
         if (j < 50)       tw100[j] = make_float2(c_mel.cosv[4 * j], c_mel.sinv[4 * j]);
         if (j < 100)      tw200[j] = make_float2(c_mel.cosv[2 * j], c_mel.sinv[2 * j]);
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(128) void k_mel_frames(const float * __restrict__ p
 
     // 16 leaf DFTs of 25 points: leaf r holds x[r + 16 m]  (W/whisper.cpp:2634-2654)
     // leaves are stored in the order the combine stages want: slot(r) with bit-reversed 4-bit r
-    for (int t = tid; t < 400; t += 128) {
+    for (int t = tid; t < 400; t += MEL_NT) {
         const int r = t / 25, kk = t % 25;
         float re = 0.0f, im = 0.0f;
         int idx = 0;                                 // (kk * m) % 25, advanced incrementally
@@ -130,19 +131,19 @@ __global__ __launch_bounds__(128) void k_mel_frames(const float * __restrict__ p
     }
     __syncthreads();
     // N=50: pairs (r, r+8) -> 8 arrays of 50 indexed by r<8 ; N=100: (r, r+4) ; N=200: (r, r+2) ; N=400: (0,1)
-    butterfly_stage(bufA, bufB, 8, 50, tid, 128, false, tw50);   __syncthreads();
-    butterfly_stage(bufB, bufA, 4, 100, tid, 128, false, tw100); __syncthreads();
-    butterfly_stage(bufA, bufB, 2, 200, tid, 128, false, tw200); __syncthreads();
-    butterfly_stage(bufB, bufA, 1, 400, tid, 128, true, tw400);  __syncthreads();
+    butterfly_stage(bufA, bufB, 8, 50, tid, MEL_NT, false, tw50);   __syncthreads();
+    butterfly_stage(bufB, bufA, 4, 100, tid, MEL_NT, false, tw100); __syncthreads();
+    butterfly_stage(bufA, bufB, 2, 200, tid, MEL_NT, false, tw200); __syncthreads();
+    butterfly_stage(bufB, bufA, 1, 400, tid, MEL_NT, true, tw400);  __syncthreads();
 
-    for (int j = tid; j < 201; j += 128) {
+    for (int j = tid; j < 201; j += MEL_NT) {
         const float re = bufA[2 * j], im = bufA[2 * j + 1];
         pw[j] = fmaf(re, re, im * im);
     }
     __syncthreads();
 
     float vmax = -INFINITY;
-    for (int j = tid; j < n_mel; j += 128) {
+    for (int j = tid; j < n_mel; j += MEL_NT) {
         if (j != tid) { fr0 = ranges[2 * j]; fr1 = ranges[2 * j + 1]; }
         const float * f = filters + (size_t) j * 201;
         double sum = 0.0;
@@ -245,7 +246,7 @@ void mel_frames(const float * pcm_pad, int n_valid, int n_fft_frames, int n_len,
     std::call_once(g_tables_once, upload_tables);
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, gmax, INT_MIN);
     if (n_fft_frames > 0)
-        hipLaunchKernelGGL(k_mel_frames, dim3(n_fft_frames), dim3(128), 0, st, pcm_pad, n_valid, n_fft_frames, n_len, n_mel,
+        hipLaunchKernelGGL(k_mel_frames, dim3(n_fft_frames), dim3(MEL_NT), 0, st, pcm_pad, n_valid, n_fft_frames, n_len, n_mel,
                            filters, ranges, mel, gmax);
     const int tail = (n_len - n_fft_frames) * n_mel;
     if (tail > 0) hipLaunchKernelGGL(k_mel_tail, dim3((tail + 255) / 256), dim3(256), 0, st, mel, n_len, n_mel, n_fft_frames, gmax);
