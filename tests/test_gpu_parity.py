@@ -640,3 +640,34 @@ def test_randomised_cases_equal_the_compiled_reference(product_lib, checker_lib,
             assert np.array_equal(tp[:, 6], tr[:, 6]) and np.array_equal(tp[keep, 7], tr[keep, 7]), case
     if first:
         assert np.abs(tp[:first, [2, 4, 5]] - tr[:first, [2, 4, 5]]).max() <= 1e-2, case
+
+
+def test_small_multilingual_shape_against_checker(product_lib, checker_lib):
+    """BASELINE.json configs[2]'s model shape (small multilingual: 12 + 12 layers, 768 wide, 12 heads) at full size: encoder
+    at a ragged audio_ctx as the streaming node uses it, prompt and greedy steps (K = 768: two 512-column chunks per lane
+    in k_gemv1, the unfused cross-query path), then a transcription against the reference."""
+    model = synth.make_model("small", seed=77); pcm = synth.make_pcm(9.0, seed=21, gate=True)
+    prod = sc.ProductSide(product_lib, model); chk = make_checker(model, checker_lib)
+    try:
+        mel_r, _ = chk.mel(pcm); mel_p, _ = prod.mel(pcm)
+        assert np.abs(mel_p - mel_r).max() <= TOL["mel"][0]
+        er = chk.encode(0, 578); ep = prod.encode(0, 578)
+        for k in er:
+            st = sc.err_stats(ep[k], er[k])
+            assert st["max_abs"] <= 2 * TOL[k][0] and st["rms_rel"] <= TOL[k][1], (k, st)     # 12 layers deep: abs bound doubled
+        prompt = sot_prompt(chk, prod)
+        lr = chk.decode(prompt, 0); lp = prod.decode(prompt, 0)
+        assert_logits(lp, lr, "prompt")
+        for i in range(4):
+            tok = int(np.argmax(lr[:50256]))
+            lr = chk.decode([tok], len(prompt) + i); lp = prod.decode([tok], len(prompt) + i)
+            assert_logits(lp, lr, f"step{i}")
+    finally:
+        prod.close(); chk.close()
+    if checker_lib is not None:
+        outs = []
+        for L in (product_lib, checker_lib):
+            node = host.SpeechToText(L); node.set_language_model(model); node.language = "de"
+            p = node.full_params("", 578); p.temperature_inc = 0.0
+            outs.append(node.transcribe(pcm, params=p)); node.close()
+        _assert_same_transcription(outs[0], outs[1], "small", False, ref_last_t1=True)
