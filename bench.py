@@ -52,12 +52,20 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    # rehearsal of the N > 1 flow on a box with fewer GPUs than ranks (ranks share devices, gloo instead of RCCL):
+    # WMI_BENCH_REHEARSAL=1 — never set by the driver, the JSON line says so in "data"
+    rehearsal = world > 1 and os.environ.get("WMI_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     entry.load_package()
     from godot_whisper_amd import abi, host, runtime, shard, synth
@@ -164,8 +172,8 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt_max / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16", "data": "synthetic",
-            "config": {"workload": ("base.en, single 30 s chunk per step on 1x MI355X, greedy decode, host params "
+            "dtype": "f16", "data": "synthetic" + (" (REHEARSAL: ranks share GPUs, gloo)" if rehearsal else ""),
+            "config": {"workload": (f"base.en, single 30 s chunk per step per GPU ({world}x MI355X), greedy decode, host params "
                                     "(max_tokens=16, single_segment, token_timestamps)") if args.chunks == 1 else
                                    (f"base.en, {args.chunks} x 30 s chunks per GPU per step in lock-step, greedy decode, host params"),
                        "chunks_per_gpu_per_step": args.chunks, "tokens_per_chunk": int(n_tokens),
