@@ -74,7 +74,7 @@ class whisper_full_params(C.Structure):  # W/whisper.h:433-526
     ]
 
 
-# (name, restype, argtypes) — the whisper.h subset exported by libwhisper_mi355.so.
+# (name, restype, argtypes) — whisper.h (all 104 functions of v1.5.4) as exported by libwhisper_mi355.so.
 # The first block is exactly what the GDExtension host calls.
 WHISPER_API = [
     ("whisper_init_from_buffer_with_params", C.c_void_p, [C.c_void_p, C.c_size_t, whisper_context_params]),
@@ -137,7 +137,60 @@ WHISPER_API = [
     ("whisper_full_get_token_p", C.c_float, [C.c_void_p, C.c_int, C.c_int]),
     ("whisper_print_timings", None, [C.c_void_p]),
     ("whisper_reset_timings", None, [C.c_void_p]),
+    # --- the remaining constructors, caller-owned states, whisper_full_parallel, bench (W/whisper.h:150-207, 234-367, 529-611)
+    ("whisper_init_with_params", C.c_void_p, [C.c_void_p, whisper_context_params]),
+    ("whisper_init_from_file_with_params_no_state", C.c_void_p, [C.c_char_p, whisper_context_params]),
+    ("whisper_init_from_buffer_with_params_no_state", C.c_void_p, [C.c_void_p, C.c_size_t, whisper_context_params]),
+    ("whisper_init_with_params_no_state", C.c_void_p, [C.c_void_p, whisper_context_params]),
+    ("whisper_init_from_file", C.c_void_p, [C.c_char_p]),
+    ("whisper_init_from_buffer", C.c_void_p, [C.c_void_p, C.c_size_t]),
+    ("whisper_init", C.c_void_p, [C.c_void_p]),
+    ("whisper_init_from_file_no_state", C.c_void_p, [C.c_char_p]),
+    ("whisper_init_from_buffer_no_state", C.c_void_p, [C.c_void_p, C.c_size_t]),
+    ("whisper_init_no_state", C.c_void_p, [C.c_void_p]),
+    ("whisper_context_default_params_by_ref", C.POINTER(whisper_context_params), []),
+    ("whisper_full_default_params_by_ref", C.POINTER(whisper_full_params), [C.c_int]),
+    ("whisper_free_params", None, [C.POINTER(whisper_full_params)]),
+    ("whisper_free_context_params", None, [C.POINTER(whisper_context_params)]),
+    ("whisper_ctx_init_openvino_encoder", C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p]),
+    ("whisper_init_state", C.c_void_p, [C.c_void_p]),
+    ("whisper_free_state", None, [C.c_void_p]),
+    ("whisper_pcm_to_mel_with_state", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int]),
+    ("whisper_set_mel_with_state", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int]),
+    ("whisper_encode_with_state", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    ("whisper_decode_with_state", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int]),
+    ("whisper_lang_auto_detect_with_state", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)]),
+    ("whisper_full_with_state", C.c_int, [C.c_void_p, C.c_void_p, whisper_full_params, C.POINTER(C.c_float), C.c_int]),
+    ("whisper_pcm_to_mel_phase_vocoder", C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int]),
+    ("whisper_pcm_to_mel_phase_vocoder_with_state", C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int]),
+    ("whisper_full_parallel", C.c_int, [C.c_void_p, whisper_full_params, C.POINTER(C.c_float), C.c_int, C.c_int]),
+    ("whisper_n_len_from_state", C.c_int, [C.c_void_p]),
+    ("whisper_get_logits_from_state", C.POINTER(C.c_float), [C.c_void_p]),
+    ("whisper_full_n_segments_from_state", C.c_int, [C.c_void_p]),
+    ("whisper_full_lang_id_from_state", C.c_int, [C.c_void_p]),
+    ("whisper_full_get_segment_t0_from_state", C.c_int64, [C.c_void_p, C.c_int]),
+    ("whisper_full_get_segment_t1_from_state", C.c_int64, [C.c_void_p, C.c_int]),
+    ("whisper_full_get_segment_speaker_turn_next", C.c_bool, [C.c_void_p, C.c_int]),
+    ("whisper_full_get_segment_speaker_turn_next_from_state", C.c_bool, [C.c_void_p, C.c_int]),
+    ("whisper_full_get_segment_text_from_state", C.c_char_p, [C.c_void_p, C.c_int]),
+    ("whisper_full_n_tokens_from_state", C.c_int, [C.c_void_p, C.c_int]),
+    ("whisper_full_get_token_text_from_state", C.c_char_p, [C.c_void_p, C.c_void_p, C.c_int, C.c_int]),
+    ("whisper_full_get_token_id_from_state", C.c_int32, [C.c_void_p, C.c_int, C.c_int]),
+    ("whisper_full_get_token_data_from_state", whisper_token_data, [C.c_void_p, C.c_int, C.c_int]),
+    ("whisper_full_get_token_p_from_state", C.c_float, [C.c_void_p, C.c_int, C.c_int]),
+    ("whisper_lang_str_full", C.c_char_p, [C.c_int]),
+    ("whisper_bench_memcpy", C.c_int, [C.c_int]),
+    ("whisper_bench_memcpy_str", C.c_char_p, [C.c_int]),
+    ("whisper_bench_ggml_mul_mat", C.c_int, [C.c_int]),
+    ("whisper_bench_ggml_mul_mat_str", C.c_char_p, [C.c_int]),
 ]
+
+
+class whisper_model_loader(C.Structure):  # W/whisper.h:108-114
+    _fields_ = [("context", C.c_void_p),
+                ("read", C.CFUNCTYPE(C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t)),
+                ("eof", C.CFUNCTYPE(C.c_bool, C.c_void_p)),
+                ("close", C.CFUNCTYPE(None, C.c_void_p))]
 
 HOST_SYMBOLS = [n for n, _, _ in WHISPER_API[:11]]
 

@@ -41,7 +41,7 @@ int64_t time_us() {
     return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-static whisper_context * init_common(const void * buffer, size_t size, int device) {
+whisper_context * init_context(const void * buffer, size_t size, int device, bool with_state) {
     const int64_t t0 = time_us();
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
@@ -56,8 +56,8 @@ static whisper_context * init_common(const void * buffer, size_t size, int devic
     WMI_INFO("%s: loading model from buffer\n", __func__);
     if (!parse_model((const uint8_t *) buffer, size, ctx->model)) { WMI_ERR("%s: failed to load model\n", __func__); delete ctx; return nullptr; }
     if (!HIP_OK(hipSetDevice(device))) { delete ctx; return nullptr; }
-    if (!init_state(*ctx)) { free_state(*ctx); delete ctx; return nullptr; }
-    if (!upload_weights(ctx->model, (const uint8_t *) buffer, nullptr, ctx->w, ctx->state->dev.stream)) {
+    if (with_state && !init_state(*ctx)) { free_state(*ctx); delete ctx; return nullptr; }
+    if (!upload_weights(ctx->model, (const uint8_t *) buffer, nullptr, ctx->w, ctx->state ? ctx->state->dev.stream : nullptr)) {
         WMI_ERR("%s: failed to load model\n", __func__);
         free_state(*ctx); free_weights(ctx->w); delete ctx; return nullptr;
     }
@@ -74,7 +74,7 @@ extern "C" {
 // ------------------------------------------------------------------ [host] entry points
 struct whisper_context * whisper_init_from_buffer_with_params(void * buffer, size_t buffer_size, struct whisper_context_params params) {
     // params.use_gpu is honoured trivially: there is only a GPU path (the Godot setting defaults to true)
-    whisper_context * ctx = init_common(buffer, buffer_size, 0);
+    whisper_context * ctx = init_context(buffer, buffer_size, 0, true);
     if (ctx) ctx->params = params;
     return ctx;
 }
@@ -118,10 +118,11 @@ struct whisper_full_params whisper_full_default_params(enum whisper_sampling_str
     return p;
 }
 
+// the context's own state is one more whisper_state (api_state.cpp), as in the reference (W/whisper.cpp:5809-5815)
+static inline struct whisper_state * own_state(struct whisper_context * ctx) { return ctx ? reinterpret_cast<struct whisper_state *>(ctx->state) : nullptr; }
+
 int whisper_full(struct whisper_context * ctx, struct whisper_full_params params, const float * samples, int n_samples) {
-    if (!ctx || !ctx->state) return -1;
-    (void) hipSetDevice(ctx->device);
-    return full(*ctx, params, samples, nullptr, n_samples);
+    return whisper_full_with_state(ctx, own_state(ctx), params, samples, n_samples);
 }
 
 int whisper_full_n_segments(struct whisper_context * ctx) { return (int) ctx->state->result_all.size(); }
@@ -148,29 +149,17 @@ struct whisper_context * whisper_init_from_file_with_params(const char * path, s
     return whisper_init_from_buffer_with_params(buf.data(), buf.size(), params);
 }
 
-int whisper_pcm_to_mel(struct whisper_context * ctx, const float * samples, int n_samples, int) {
-    (void) hipSetDevice(ctx->device);
-    if (!pcm_to_mel(*ctx, samples, n_samples, false)) { WMI_ERR("%s: failed to compute mel spectrogram\n", __func__); return -1; }
-    return 0;
+int whisper_pcm_to_mel(struct whisper_context * ctx, const float * samples, int n_samples, int n_threads) {
+    return whisper_pcm_to_mel_with_state(ctx, own_state(ctx), samples, n_samples, n_threads);
 }
 int whisper_set_mel(struct whisper_context * ctx, const float * data, int n_len, int n_mel) {
-    if (n_mel != ctx->model.n_filt_mel) { WMI_ERR("%s: invalid number of mel bands: %d (expected %d)\n", __func__, n_mel, ctx->model.n_filt_mel); return -1; }
-    (void) hipSetDevice(ctx->device);
-    return set_mel(*ctx, data, n_len, n_mel) ? 0 : -1;
+    return whisper_set_mel_with_state(ctx, own_state(ctx), data, n_len, n_mel);
 }
-int whisper_encode(struct whisper_context * ctx, int offset, int) {
-    (void) hipSetDevice(ctx->device);
-    if (!encode(*ctx, offset)) { WMI_ERR("%s: failed to eval\n", __func__); return -1; }
-    return 0;
+int whisper_encode(struct whisper_context * ctx, int offset, int n_threads) {
+    return whisper_encode_with_state(ctx, own_state(ctx), offset, n_threads);
 }
-int whisper_decode(struct whisper_context * ctx, const whisper_token * tokens, int n_tokens, int n_past, int) {
-    if (!ctx->state) { WMI_ERR("%s: ERROR state was not loaded.\n", __func__); return -1; }
-    (void) hipSetDevice(ctx->device);
-    State & st = *ctx->state;
-    st.batch.prep_legacy(tokens, n_tokens, n_past, 0);
-    kv_seq_rm(st.kv_self, 0, n_past, -1);
-    if (!decode(*ctx, st.batch)) { WMI_ERR("%s: failed to eval\n", __func__); return 1; }
-    return 0;
+int whisper_decode(struct whisper_context * ctx, const whisper_token * tokens, int n_tokens, int n_past, int n_threads) {
+    return whisper_decode_with_state(ctx, own_state(ctx), tokens, n_tokens, n_past, n_threads);
 }
 int whisper_tokenize(struct whisper_context * ctx, const char * text, whisper_token * tokens, int n_max_tokens) {
     const auto res = tokenize(ctx->model.vocab, text);
@@ -183,9 +172,8 @@ float * whisper_get_logits(struct whisper_context * ctx) { return ctx->state->lo
 int whisper_lang_max_id(void) { return lang_max_id(); }
 int whisper_lang_id(const char * lang) { return lang_id(lang); }
 const char * whisper_lang_str(int id) { return lang_str(id); }
-int whisper_lang_auto_detect(struct whisper_context * ctx, int offset_ms, int, float * lang_probs) {
-    (void) hipSetDevice(ctx->device);
-    return lang_auto_detect(*ctx, offset_ms, lang_probs);
+int whisper_lang_auto_detect(struct whisper_context * ctx, int offset_ms, int n_threads, float * lang_probs) {
+    return whisper_lang_auto_detect_with_state(ctx, own_state(ctx), offset_ms, n_threads, lang_probs);
 }
 
 int whisper_n_len(struct whisper_context * ctx) { return ctx->state->mel.n_len_org; }
@@ -258,7 +246,7 @@ int wmi_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSucce
 const char * wmi_version(void) { return "whisper_mi355 0.1 (gfx950, whisper.cpp v1.5.4 ABI)"; }
 
 struct whisper_context * wmi_init_from_buffer_on_device(const void * buffer, size_t buffer_size, int device) {
-    whisper_context * ctx = init_common(buffer, buffer_size, device);
+    whisper_context * ctx = init_context(buffer, buffer_size, device, true);
     if (ctx) ctx->params.use_gpu = true;
     return ctx;
 }
@@ -274,6 +262,7 @@ struct whisper_context * wmi_init_host_only(const void * buffer, size_t buffer_s
 }
 
 int wmi_pcm_to_mel_device(struct whisper_context * ctx, const float * d_samples, int n_samples) {
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void) hipSetDevice(ctx->device);
     return pcm_to_mel(*ctx, d_samples, n_samples, true) ? 0 : -1;
 }
@@ -281,6 +270,7 @@ int wmi_pcm_to_mel_device(struct whisper_context * ctx, const float * d_samples,
 int wmi_full_device_pcm(struct whisper_context * ctx, struct whisper_full_params params, const float * d_samples, int n_samples,
                         const float * h_samples) {
     if (!ctx || !ctx->state) return -1;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void) hipSetDevice(ctx->device);
     return full(*ctx, params, h_samples, d_samples, n_samples);
 }

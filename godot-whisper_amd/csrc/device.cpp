@@ -34,6 +34,7 @@ bool init_state(whisper_context & ctx) {
     const HParams & hp = ctx.model.hp;
     State * st = new State();
     ctx.state = st;
+    st->device = ctx.device;
     DeviceState & d = st->dev;
     if (!HIP_OK(hipSetDevice(ctx.device))) return false;
     HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
@@ -78,9 +79,23 @@ bool init_state(whisper_context & ctx) {
     return true;
 }
 
+State * create_state(whisper_context & ctx) {
+    State * saved = ctx.state;
+    ctx.state = nullptr;
+    State * st = nullptr;
+    if (init_state(ctx)) st = ctx.state; else free_state(ctx);
+    ctx.state = saved;
+    return st;
+}
+
 void free_state(whisper_context & ctx) {
-    State * st = ctx.state;
+    destroy_state(ctx.state);
+    ctx.state = nullptr;
+}
+
+void destroy_state(State * st) {
     if (!st) return;
+    (void) hipSetDevice(st->device);
     DeviceState & d = st->dev;
     if (d.stream) (void) hipStreamSynchronize(d.stream);
     dfree(st->kv_self.k); dfree(st->kv_self.v); dfree(d.kvc_k); dfree(d.kvc_v);
@@ -101,7 +116,6 @@ void free_state(whisper_context & ctx) {
     if (d.pinned) (void) hipHostFree(d.pinned);
     if (d.stream) (void) hipStreamDestroy(d.stream);
     delete st;
-    ctx.state = nullptr;
 }
 
 // ------------------------------------------------------------------------------------------------ mel

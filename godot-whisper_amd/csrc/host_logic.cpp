@@ -115,6 +115,12 @@ const char * lang_str(int id) {
     return nullptr;
 }
 
+const char * lang_str_full(int id) {             // W/whisper.cpp:3558-3567
+    if (id >= 0 && id < k_n_langs) return k_langs[id].name;
+    WMI_ERR("%s: unknown language id %d\n", __func__, id);
+    return nullptr;
+}
+
 // ------------------------------------------------------------------ tokenizer (W/whisper.cpp:2899-2947)
 std::vector<int32_t> tokenize(const Vocab & vocab, const std::string & text) {
     std::vector<std::string> words;

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <mutex>
 #include <random>
 #include <set>
 #include <string>
@@ -195,6 +196,7 @@ struct DeviceState {
 };
 
 struct State {
+    int     device = 0;                           // HIP device of the arenas below
     int64_t t_sample_us = 0, t_encode_us = 0, t_decode_us = 0, t_batchd_us = 0, t_prompt_us = 0, t_mel_us = 0;
     int32_t n_sample = 0, n_encode = 0, n_decode = 0, n_batchd = 0, n_prompt = 0, n_fail_p = 0, n_fail_h = 0;
     KVCache kv_self;
@@ -246,12 +248,19 @@ struct whisper_context {
     int            device = 0;
     bool           host_only = false;   // vocabulary + host logic only (tests); every compute call fails loudly
     wmi::BatchWork * batch = nullptr;   // lazily created by wmi_full_batch
+    // the compute code reaches its working set through ctx.state: the *_with_state entry points install the caller's
+    // state for the duration of the call under this lock (calls on one context serialise; the GPU runs them in order anyway)
+    std::recursive_mutex mu;
 };
 
 namespace wmi {
 
+// parse + upload a ggml model image onto `device`; with_state = false leaves ctx->state null (whisper_init_*_no_state)
+whisper_context * init_context(const void * buffer, size_t size, int device, bool with_state);
 bool init_state(whisper_context & ctx);
 void free_state(whisper_context & ctx);
+State * create_state(whisper_context & ctx);      // a further state for the same weights (whisper_init_state); null on failure
+void destroy_state(State * st);
 
 // hot path (device)
 bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, bool samples_on_device, bool sync = true);
@@ -289,6 +298,7 @@ int  wrap_segment(whisper_context & ctx, State & st, int max_len, bool split_on_
 
 int         lang_id(const char * lang);
 const char *lang_str(int id);
+const char *lang_str_full(int id);
 int         lang_max_id();
 int         lang_count();
 

@@ -5,7 +5,7 @@
 
 Godot / godot-cpp / SCons are not in this image, so the node is restated in Python over the
 same C ABI calls, in the same order, with the same parameter set.  It works over ANY library
-that exports the whisper.h subset (`abi.WHISPER_API`): the product `libwhisper_mi355.so`, or —
+that exports whisper.h (`abi.WHISPER_API`): the product `libwhisper_mi355.so`, or —
 in tests only — the compiled reference, which is how the parity tests drive both sides
 through one code path.
 """

@@ -1,11 +1,13 @@
 /*
  * whisper_mi355.h — the drop-in boundary of libwhisper_mi355.so.
  *
- * This is the subset of the reference's public C API (thirdparty/whisper.cpp/whisper.h,
- * v1.5.4; cited below as W/whisper.h:<line>) that the Godot GDExtension host and the
- * reference's own bench/compare tools call.  Symbol names, argument order, by-value struct
- * layouts and return codes are ABI: a host compiled against W/whisper.h links against this
- * library unchanged.  Everything behind these entry points is new (HIP kernels for gfx950).
+ * This is the reference's public C API (thirdparty/whisper.cpp/whisper.h, v1.5.4; cited below
+ * as W/whisper.h:<line>): every WHISPER_API function of that header is exported, first the ones
+ * the Godot GDExtension host and the reference's bench/compare tools call, then the rest
+ * (caller-owned states, older constructors, whisper_full_parallel, bench entry points).
+ * Symbol names, argument order, by-value struct layouts and return codes are ABI: a host
+ * compiled against W/whisper.h links against this library unchanged.  Everything behind these
+ * entry points is new (HIP kernels for gfx950).
  *
  * The 11 entry points the host binds (src/speech_to_text.cpp:332-447, src/register_types.cpp:58)
  * are marked [host].
@@ -47,6 +49,13 @@ typedef struct whisper_token_data {                                      /* W/wh
     int64_t t0, t1;
     float vlen;
 } whisper_token_data;
+
+typedef struct whisper_model_loader {                                    /* W/whisper.h:108-114 */
+    void * context;
+    size_t (*read)(void * ctx, void * output, size_t read_size);
+    bool   (*eof)(void * ctx);
+    void   (*close)(void * ctx);
+} whisper_model_loader;
 
 typedef struct whisper_grammar_element { int type; uint32_t value; } whisper_grammar_element; /* W/whisper.h:130-133 */
 
@@ -153,6 +162,72 @@ WHISPER_API whisper_token whisper_full_get_token_id(struct whisper_context * ctx
 WHISPER_API float whisper_full_get_token_p(struct whisper_context * ctx, int i_segment, int i_token);
 WHISPER_API void whisper_print_timings(struct whisper_context * ctx);
 WHISPER_API void whisper_reset_timings(struct whisper_context * ctx);
+
+/* ---- the remaining constructors (W/whisper.h:150-193).  The loader forms drain the callbacks into memory and close
+ * the loader in every case (W/whisper.cpp:3253-3269); *_no_state leaves the context without a state: create one with
+ * whisper_init_state and use the *_with_state calls ---- */
+WHISPER_API struct whisper_context * whisper_init_with_params(struct whisper_model_loader * loader, struct whisper_context_params params);            /* :152 */
+WHISPER_API struct whisper_context * whisper_init_from_file_with_params_no_state(const char * path_model, struct whisper_context_params params);      /* :156 */
+WHISPER_API struct whisper_context * whisper_init_from_buffer_with_params_no_state(void * buffer, size_t buffer_size, struct whisper_context_params params); /* :157 */
+WHISPER_API struct whisper_context * whisper_init_with_params_no_state(struct whisper_model_loader * loader, struct whisper_context_params params);   /* :158 */
+WHISPER_API struct whisper_context * whisper_init_from_file(const char * path_model);                     /* :160-163, deprecated there */
+WHISPER_API struct whisper_context * whisper_init_from_buffer(void * buffer, size_t buffer_size);         /* :164-167 */
+WHISPER_API struct whisper_context * whisper_init(struct whisper_model_loader * loader);                  /* :168-171 */
+WHISPER_API struct whisper_context * whisper_init_from_file_no_state(const char * path_model);            /* :172-175 */
+WHISPER_API struct whisper_context * whisper_init_from_buffer_no_state(void * buffer, size_t buffer_size);/* :176-179 */
+WHISPER_API struct whisper_context * whisper_init_no_state(struct whisper_model_loader * loader);         /* :180-183 */
+WHISPER_API struct whisper_context_params * whisper_context_default_params_by_ref(void);                  /* :529, free with whisper_free_context_params */
+WHISPER_API struct whisper_full_params * whisper_full_default_params_by_ref(enum whisper_sampling_strategy strategy); /* :531, free with whisper_free_params */
+WHISPER_API void whisper_free_params(struct whisper_full_params * params);                                /* :206 */
+WHISPER_API void whisper_free_context_params(struct whisper_context_params * params);                     /* :207 */
+/* always 1: this library is not an OpenVINO build (the reference's answer without WHISPER_USE_OPENVINO, W/whisper.cpp:3122-3134) */
+WHISPER_API int whisper_ctx_init_openvino_encoder(struct whisper_context * ctx, const char * model_path, const char * device, const char * cache_dir); /* :198 */
+
+/* ---- caller-owned states (W/whisper.h:185, :205).  A state holds everything mutable (KV caches, activation arenas,
+ * its HIP stream and captured decode graph, results) on the context's GPU; the weights stay with the context.
+ * Calls on one context serialise on an internal lock; contexts are independent. ---- */
+WHISPER_API struct whisper_state * whisper_init_state(struct whisper_context * ctx);      /* NULL on allocation failure or a host-only context */
+WHISPER_API void whisper_free_state(struct whisper_state * state);                        /* NULL-safe */
+WHISPER_API int whisper_pcm_to_mel_with_state(struct whisper_context * ctx, struct whisper_state * state, const float * samples, int n_samples, int n_threads); /* :234 */
+WHISPER_API int whisper_set_mel_with_state(struct whisper_context * ctx, struct whisper_state * state, const float * data, int n_len, int n_mel);               /* :263 */
+WHISPER_API int whisper_encode_with_state(struct whisper_context * ctx, struct whisper_state * state, int offset, int n_threads);                               /* :279 */
+WHISPER_API int whisper_decode_with_state(struct whisper_context * ctx, struct whisper_state * state, const whisper_token * tokens, int n_tokens, int n_past, int n_threads); /* :295 */
+WHISPER_API int whisper_lang_auto_detect_with_state(struct whisper_context * ctx, struct whisper_state * state, int offset_ms, int n_threads, float * lang_probs); /* :344 */
+WHISPER_API int whisper_full_with_state(struct whisper_context * ctx, struct whisper_state * state, struct whisper_full_params params, const float * samples, int n_samples); /* :543 */
+/* The x2 phase-vocoder front end: always -1.  The reference evaluates it with an 800-sample frame whose 401 bins index
+ * the 201-bin filterbank out of bounds (W/whisper.cpp:3417-3425 -> :2764-2776), and its own whisper_full refuses
+ * speed_up (:4973-4976): there is no defined result to reproduce. */
+WHISPER_API int whisper_pcm_to_mel_phase_vocoder(struct whisper_context * ctx, const float * samples, int n_samples, int n_threads);                            /* :247 */
+WHISPER_API int whisper_pcm_to_mel_phase_vocoder_with_state(struct whisper_context * ctx, struct whisper_state * state, const float * samples, int n_samples, int n_threads); /* :253 */
+/* Split the audio into n_processors pieces, transcribe each on its own state, merge the segments with the reference's
+ * time shift and no-overlap clamp (W/whisper.cpp:5817-5924).  The pieces run one after the other on the GPU; for
+ * independent chunks in lock-step use wmi_full_batch (wmi_device.h). */
+WHISPER_API int whisper_full_parallel(struct whisper_context * ctx, struct whisper_full_params params, const float * samples, int n_samples, int n_processors); /* :553 */
+
+/* ---- results of a state (W/whisper.h:360-367, :565-602) ---- */
+WHISPER_API int     whisper_n_len_from_state(struct whisper_state * state);
+WHISPER_API float * whisper_get_logits_from_state(struct whisper_state * state);
+WHISPER_API int     whisper_full_n_segments_from_state(struct whisper_state * state);
+WHISPER_API int     whisper_full_lang_id_from_state(struct whisper_state * state);
+WHISPER_API int64_t whisper_full_get_segment_t0_from_state(struct whisper_state * state, int i_segment);
+WHISPER_API int64_t whisper_full_get_segment_t1_from_state(struct whisper_state * state, int i_segment);
+WHISPER_API bool    whisper_full_get_segment_speaker_turn_next(struct whisper_context * ctx, int i_segment);
+WHISPER_API bool    whisper_full_get_segment_speaker_turn_next_from_state(struct whisper_state * state, int i_segment);
+WHISPER_API const char * whisper_full_get_segment_text_from_state(struct whisper_state * state, int i_segment);
+WHISPER_API int     whisper_full_n_tokens_from_state(struct whisper_state * state, int i_segment);
+WHISPER_API const char * whisper_full_get_token_text_from_state(struct whisper_context * ctx, struct whisper_state * state, int i_segment, int i_token);
+WHISPER_API whisper_token whisper_full_get_token_id_from_state(struct whisper_state * state, int i_segment, int i_token);
+WHISPER_API whisper_token_data whisper_full_get_token_data_from_state(struct whisper_state * state, int i_segment, int i_token);
+WHISPER_API float   whisper_full_get_token_p_from_state(struct whisper_state * state, int i_segment, int i_token);
+WHISPER_API const char * whisper_lang_str_full(int id);                                   /* :335: "english" for 0 */
+
+/* ---- bench entry points (W/whisper.h:608-611).  The reference times host memcpy and ggml_mul_mat on n_threads cores;
+ * here they report what does the work on this backend: HBM device-to-device copy bandwidth and the f16 MFMA GEMM on
+ * the same square sizes (64..4096).  n_threads is accepted and ignored; the *_str forms return a static buffer. ---- */
+WHISPER_API int          whisper_bench_memcpy(int n_threads);
+WHISPER_API const char * whisper_bench_memcpy_str(int n_threads);
+WHISPER_API int          whisper_bench_ggml_mul_mat(int n_threads);
+WHISPER_API const char * whisper_bench_ggml_mul_mat_str(int n_threads);
 
 #ifdef __cplusplus
 }

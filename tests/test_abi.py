@@ -98,3 +98,79 @@ def test_no_gpu_means_loud_failure_not_fallback():
     with pytest.raises(runtime.BackendUnavailable):
         runtime.require_gpu()
     runtime.silence_logs(lib)
+
+
+def test_every_function_of_the_reference_header_is_declared_and_exported():
+    """tests/golden/whisper_h_api.txt lists the 104 functions of W/whisper.h (v1.5.4; made by golden/make_api_list.py):
+    a host written against the reference header finds every one of them here."""
+    lib = runtime.load_library()
+    want = (ROOT / "tests" / "golden" / "whisper_h_api.txt").read_text().split()
+    assert len(want) == 104
+    declared = set(declared_symbols())
+    assert not [n for n in want if n not in declared]
+    assert not [n for n in want if not hasattr(lib, n)]
+    bound = {n for n, _, _ in abi.WHISPER_API}
+    assert not [n for n in want if n not in bound]              # and the ctypes table the tests use covers them all
+
+
+def test_parameter_helpers_language_names_and_fixed_answers():
+    """Entry points that need no device (W/whisper.cpp:3122-3134, 3391-3401, 3558-3567, 4295-4309)."""
+    lib = runtime.load_library()
+    runtime.silence_logs(lib)
+    cp = lib.whisper_context_default_params_by_ref()
+    assert cp.contents.use_gpu is True
+    lib.whisper_free_context_params(cp)
+    for strategy in (abi.WHISPER_SAMPLING_GREEDY, abi.WHISPER_SAMPLING_BEAM_SEARCH):
+        fp = lib.whisper_full_default_params_by_ref(strategy)
+        val = lib.whisper_full_default_params(strategy)
+        assert bytes(fp.contents) == bytes(val)                  # the same defaults, field for field
+        lib.whisper_free_params(fp)
+    lib.whisper_free_params(None); lib.whisper_free_context_params(None); lib.whisper_free_state(None)
+    assert lib.whisper_lang_str_full(0) == b"english" and lib.whisper_lang_str_full(2) == b"german"
+    assert lib.whisper_lang_str_full(99) == b"cantonese" and lib.whisper_lang_str_full(100) is None
+    assert all(lib.whisper_lang_id(lib.whisper_lang_str_full(i)) == i for i in range(100))     # full names resolve like codes
+    assert lib.whisper_ctx_init_openvino_encoder(None, None, None, None) == 1
+    pcm = np.zeros(16000, np.float32)
+    assert lib.whisper_pcm_to_mel_phase_vocoder(None, pcm.ctypes.data_as(C.POINTER(C.c_float)), pcm.size, 1) == -1
+
+
+def test_loader_constructors_drain_and_close_the_loader_and_fail_loudly_without_a_gpu():
+    """whisper_init*(loader): read callbacks are drained, close is called exactly once, and without a device the result is
+    NULL — never a context that would compute on the host (W/whisper.cpp:3253-3269, 3301-3314)."""
+    lib = runtime.load_library()
+    if lib.wmi_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    runtime.silence_logs(lib)
+    from godot_whisper_amd import synth
+    mb = synth.make_model("micro.en", seed=1)
+    for ctor in ("whisper_init", "whisper_init_no_state", "whisper_init_with_params", "whisper_init_with_params_no_state"):
+        pos = [0]; closed = [0]
+        L = abi.whisper_model_loader
+        def rd(_, out, n):
+            k = min(n, len(mb) - pos[0]); C.memmove(out, mb[pos[0]:pos[0] + k], k); pos[0] += k; return k
+        loader = L(None, L._fields_[1][1](rd), L._fields_[2][1](lambda _: pos[0] >= len(mb)), L._fields_[3][1](lambda _: closed.__setitem__(0, closed[0] + 1)))
+        args = [C.cast(C.pointer(loader), C.c_void_p)] + ([abi.whisper_context_params(True)] if "with_params" in ctor else [])
+        assert not getattr(lib, ctor)(*args)
+        assert pos[0] == len(mb) and closed[0] == 1, ctor
+    bad = C.create_string_buffer(mb, len(mb))
+    for ctor in ("whisper_init_from_buffer", "whisper_init_from_buffer_no_state"):
+        assert not getattr(lib, ctor)(C.cast(bad, C.c_void_p), len(mb))
+    assert not lib.whisper_init_from_file(b"/nonexistent/model.bin") and not lib.whisper_init_from_file_no_state(b"/nonexistent/model.bin")
+
+
+def test_host_only_context_cannot_create_states():
+    lib = runtime.load_library()
+    runtime.silence_logs(lib)
+    from godot_whisper_amd import synth
+    mb = synth.make_model("micro.en", seed=1)
+    buf = C.create_string_buffer(mb, len(mb))
+    ctx = lib.wmi_init_host_only(C.cast(buf, C.c_void_p), len(mb))
+    try:
+        assert not lib.whisper_init_state(ctx)
+        pcm = np.zeros(16000, np.float32); fp = pcm.ctypes.data_as(C.POINTER(C.c_float))
+        p = lib.whisper_full_default_params(0)
+        assert lib.whisper_full_with_state(ctx, None, p, fp, pcm.size) == -1
+        assert lib.whisper_full_parallel(ctx, p, fp, pcm.size, 2) == -1          # cannot allocate the second state
+        assert lib.whisper_full_parallel(ctx, p, fp, pcm.size, 1) == -2          # = whisper_full: no compute path
+    finally:
+        lib.whisper_free(ctx)
