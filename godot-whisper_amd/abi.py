@@ -206,3 +206,22 @@ def bind(lib: C.CDLL, table=WHISPER_API, strict: bool = True) -> C.CDLL:
         fn.restype = res
         fn.argtypes = args
     return lib
+
+
+# grammar-constrained decoding (W/whisper.h:116-145)
+GRETYPE_END, GRETYPE_ALT, GRETYPE_RULE_REF, GRETYPE_CHAR, GRETYPE_CHAR_NOT, GRETYPE_CHAR_RNG_UPPER, GRETYPE_CHAR_ALT = range(7)
+
+
+class whisper_grammar_element(C.Structure):
+    _fields_ = [("type", C.c_int), ("value", C.c_uint32)]
+
+
+def make_grammar(rules):
+    """rules: list of rules, each a list of (type, value) without the closing END.  Returns (pointer-array, n_rules, keepalive)
+    for whisper_full_params.grammar_rules / n_grammar_rules; keep `keepalive` referenced while the parameters are in use."""
+    arrays = []
+    for r in rules:
+        arr = (whisper_grammar_element * (len(r) + 1))(*[whisper_grammar_element(t, v) for t, v in r], whisper_grammar_element(GRETYPE_END, 0))
+        arrays.append(arr)
+    ptrs = (C.POINTER(whisper_grammar_element) * len(arrays))(*[C.cast(a, C.POINTER(whisper_grammar_element)) for a in arrays])
+    return ptrs, len(arrays), (arrays, ptrs)

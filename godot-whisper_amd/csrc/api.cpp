@@ -366,6 +366,8 @@ int wmi_process_logits(struct whisper_context * ctx, struct whisper_full_params 
     d.sequence.tokens.clear();
     for (int i = 0; i < n_hist; ++i) d.sequence.tokens.push_back(whisper_token_data{ hist[i], 0, 0.f, 0.f, 0.f, 0.f, -1, -1, 0.f });
     d.has_ts = has_ts != 0; d.seek_delta = seek_delta;
+    d.grammar = params.grammar_rules ? grammar_init(params.grammar_rules, params.n_grammar_rules, params.i_start_rule) : Grammar{};
+    for (int i = 0; i < n_hist; ++i) grammar_accept_token(*ctx, d.grammar, hist[i]);       // parse state after the history
     process_logits(*ctx, d, params, temperature);
     memcpy(out_logits, d.logits.data(), (size_t) nv * 4);
     memcpy(out_logprobs, d.logprobs.data(), (size_t) nv * 4);

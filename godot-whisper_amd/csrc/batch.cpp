@@ -333,7 +333,7 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
     const bool lang_known = params.language && strlen(params.language) > 0 && strcmp(params.language, "auto") != 0 && !params.detect_language;
     const bool distilled = hp.n_text_layer == 2 && !params.no_timestamps;
     const bool lockstep = !force_seq && fast_path_enabled() && params.strategy == WHISPER_SAMPLING_GREEDY && params.temperature < 1e-6f &&
-                          lang_known && !distilled && !params.speed_up && !params.logits_filter_callback && !params.new_segment_callback &&
+                          lang_known && !distilled && !params.speed_up && !params.logits_filter_callback && !params.grammar_rules && params.n_grammar_rules == 0 && !params.new_segment_callback &&
                           !params.progress_callback && !params.encoder_begin_callback && !params.abort_callback &&
                           ctx.model.n_loaded > 0 && n_chunks > 1;
     if (!lockstep) {

@@ -22,7 +22,7 @@ namespace {
 
 constexpr int MAX_DECODERS = 8;          // W/whisper.cpp:148
 
-struct BeamCandidate { int decoder_idx; int seek_delta; bool has_ts; Sequence sequence; };
+struct BeamCandidate { int decoder_idx; int seek_delta; bool has_ts; Sequence sequence; Grammar grammar; };
 
 const char * tok_str(whisper_context & ctx, int32_t id) { return ctx.model.vocab.id_to_token.at(id).c_str(); }
 
@@ -187,6 +187,7 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
                 d.sequence.entropy = 0.0; d.sequence.score = -INFINITY;
                 d.seek_delta = 100 * WHISPER_CHUNK_SIZE;
                 d.failed = false; d.completed = false; d.has_ts = false;
+                d.grammar = params.grammar_rules ? grammar_init(params.grammar_rules, params.n_grammar_rules, params.i_start_rule) : Grammar{};
             }
 
             // prompt = [prev, tail of past text] (only while t < 0.5) + [sot, (lang, task), (notimestamps)]
@@ -201,7 +202,8 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
             kv_clear(st.kv_self);
             // Greedy, temperature 0, one decoder, no user logit callback: filters + arg-max run on the GPU and each
             // step is one graph replay (device.cpp: decode_greedy_step).  Everything else takes the general path.
-            const bool fast = fast_path_enabled() && !beam && t_cur < 1e-6f && n_cur == 1 && !params.logits_filter_callback &&
+            const bool fast = fast_path_enabled() && !beam && t_cur < 1e-6f && n_cur == 1 && !params.logits_filter_callback && !params.grammar_rules &&
+                              params.n_grammar_rules == 0 &&
                               ctx.model.n_loaded > 0 && upload_static_ban(ctx, params);
             whisper_token_data fast_next{};      // token picked on the device for the upcoming sampling step
             auto step_filter = [&](const Decoder & d) {
@@ -272,7 +274,7 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
                         d.sequence.sum_logprobs_all += d.sequence.tokens.back().plog;
                     } else {
                         for (const auto & tok : sample_token_topk(ctx, d, params.beam_search.beam_size)) {
-                            bc_per_dec[j].push_back({ j, d.seek_delta, d.has_ts, d.sequence });
+                            bc_per_dec[j].push_back({ j, d.seek_delta, d.has_ts, d.sequence, d.grammar });
                             bc_per_dec[j].back().sequence.tokens.push_back(tok);
                             bc_per_dec[j].back().sequence.sum_logprobs_all += tok.plog;
                         }
@@ -292,7 +294,7 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
                         BeamCandidate & cur = beam_candidates[cur_c++];
                         while (beam_candidates.size() > cur_c &&
                                beam_candidates[cur_c].sequence.sum_logprobs_all == cur.sequence.sum_logprobs_all && i > 0) ++cur_c;
-                        d.seek_delta = cur.seek_delta; d.has_ts = cur.has_ts; d.sequence = cur.sequence;
+                        d.seek_delta = cur.seek_delta; d.has_ts = cur.has_ts; d.sequence = cur.sequence; d.grammar = cur.grammar;
                         kv_seq_cp(st.kv_self, cur.decoder_idx, MAX_DECODERS + j, -1, -1);
                     }
                     for (int j = 0; j < n_cur; ++j) {
@@ -315,6 +317,7 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
                         if (d.has_ts && d.seek_delta > sd_new && result_len < i) { d.failed = true; continue; }   // going back in time
                         d.seek_delta = sd_new; result_len = i + 1; d.has_ts = true;
                     }
+                    grammar_accept_token(ctx, d.grammar, tok.id);
                     if (tok.id == v.eot || (params.max_tokens > 0 && i >= params.max_tokens) ||
                         (d.has_ts && seek + d.seek_delta + 100 >= seek_end)) {
                         if (result_len == 0) {

@@ -237,7 +237,10 @@ void process_logits(whisper_context & ctx, Decoder & dec, const whisper_full_par
         }
         const float max_text = *std::max_element(logprobs.begin(), logprobs.begin() + v.beg);
         if (ts_logprob > max_text) for (int i = 0; i < v.beg; ++i) { logits[i] = NEG_INF; logprobs[i] = NEG_INF; }
-        // (grammar-constrained decoding is out of scope: the host never sets grammar_rules)
+        else if (params.n_grammar_rules > 0) {          // W/whisper.cpp:4684-4706: penalise what the grammar cannot take, renormalise
+            grammar_penalise(ctx, dec.grammar, params.grammar_penalty, logits);
+            log_softmax(logits, logprobs);
+        }
     }
     for (int i = 0; i < n; ++i) probs[i] = logits[i] == NEG_INF ? 0.0f : expf(logprobs[i]);
 }

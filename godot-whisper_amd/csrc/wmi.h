@@ -138,8 +138,17 @@ struct Sequence {
     int    result_len = 0;
     double sum_logprobs_all = 0, sum_logprobs = 0, avg_logprobs = 0, entropy = 0, score = 0;
 };
+// parse state of grammar-constrained decoding (grammar.cpp; W/whisper.cpp:711-728)
+struct PartialUtf8 { uint32_t value = 0; int n_remain = 0; };      // n_remain = -1: invalid sequence
+struct GrammarPos  { int rule, off; };                              // an element of rules[rule]
+struct Grammar {
+    std::vector<std::vector<whisper_grammar_element>> rules;
+    std::vector<std::vector<GrammarPos>> stacks;                    // every top rests on a character class
+    PartialUtf8 partial;                                             // unfinished UTF-8 sequence of the accepted tokens
+};
 struct Decoder {
     Sequence sequence;
+    Grammar  grammar;
     int  i_batch = 0, seek_delta = 0;
     bool failed = false, completed = false, has_ts = false;
     std::vector<float> probs, logits, logprobs;
@@ -283,6 +292,9 @@ void process_logits(whisper_context & ctx, Decoder & dec, const whisper_full_par
 whisper_token_data sample_token(whisper_context & ctx, Decoder & dec, bool best);
 std::vector<whisper_token_data> sample_token_topk(whisper_context & ctx, Decoder & dec, int k);
 void sequence_score(const whisper_full_params & params, Sequence & seq);
+Grammar grammar_init(const whisper_grammar_element ** rules, size_t n_rules, size_t i_start_rule);
+void grammar_penalise(const whisper_context & ctx, const Grammar & g, float penalty, std::vector<float> & logits);
+void grammar_accept_token(const whisper_context & ctx, Grammar & g, int32_t token);
 std::vector<int32_t> tokenize(const Vocab & vocab, const std::string & text);
 int  lang_auto_detect(whisper_context & ctx, int offset_ms, float * lang_probs);
 int  full(whisper_context & ctx, whisper_full_params params, const float * samples, const float * d_samples, int n_samples);

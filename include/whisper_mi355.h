@@ -57,7 +57,14 @@ typedef struct whisper_model_loader {                                    /* W/wh
     void   (*close)(void * ctx);
 } whisper_model_loader;
 
-typedef struct whisper_grammar_element { int type; uint32_t value; } whisper_grammar_element; /* W/whisper.h:130-133 */
+/* grammar element types (W/whisper.h:116-140): END closes a rule, ALT starts its next alternative, RULE_REF names a rule by
+ * index, CHAR / CHAR_NOT open a (negated) character class of code points, CHAR_RNG_UPPER makes the preceding value the low
+ * end of a range, CHAR_ALT adds a further member to the class */
+enum whisper_gretype {
+    WHISPER_GRETYPE_END = 0, WHISPER_GRETYPE_ALT = 1, WHISPER_GRETYPE_RULE_REF = 2, WHISPER_GRETYPE_CHAR = 3,
+    WHISPER_GRETYPE_CHAR_NOT = 4, WHISPER_GRETYPE_CHAR_RNG_UPPER = 5, WHISPER_GRETYPE_CHAR_ALT = 6,
+};
+typedef struct whisper_grammar_element { enum whisper_gretype type; uint32_t value; } whisper_grammar_element; /* W/whisper.h:142-145 */
 
 enum whisper_sampling_strategy { WHISPER_SAMPLING_GREEDY, WHISPER_SAMPLING_BEAM_SEARCH };    /* W/whisper.h:397-400 */
 

@@ -107,6 +107,13 @@ int ref_process_logits(struct whisper_context * ctx, struct whisper_full_params 
     }
     d.has_ts = has_ts != 0;
     d.seek_delta = seek_delta;
+    // grammar-constrained decoding: the parse state after the history (what whisper_full keeps per decoder, :5228-5232, :5457)
+    if (params.grammar_rules != nullptr) {
+        d.grammar = whisper_grammar_init(params.grammar_rules, params.n_grammar_rules, params.i_start_rule);
+        for (int i = 0; i < n_hist; ++i) whisper_grammar_accept_token(*ctx, d.grammar, hist[i]);
+    } else {
+        d.grammar = {};
+    }
     whisper_process_logits(*ctx, st, d, params, temperature);
     memcpy(out_logits,   d.logits.data(),   sizeof(float)*nv);
     memcpy(out_logprobs, d.logprobs.data(), sizeof(float)*nv);

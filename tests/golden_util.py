@@ -84,3 +84,41 @@ def stream_inputs():
 
 
 PROMPTS = ["Hello, world!", " It's 42 degrees; don't panic.", "multi   space\ttab\nnewline", "naïve café — ünïcode ♪", ""]
+
+
+# ------------------------------------------------------------------------------------------------ test grammars (W/whisper.h:116-145)
+from godot_whisper_amd import abi  # noqa: E402  (the package is registered by conftest before this module is imported)
+
+
+def _lit(s):
+    return [(abi.GRETYPE_CHAR, ord(c)) for c in s]
+
+
+def colour_list_grammar():
+    """root ::= " "? item (", " item)* "."     item ::= "red" | "green" | "blue" | [0-9]+      (repetition as recursive rules)"""
+    ALT = [(abi.GRETYPE_ALT, 0)]
+    ref = lambda i: [(abi.GRETYPE_RULE_REF, i)]
+    digit = [(abi.GRETYPE_CHAR, ord("0")), (abi.GRETYPE_CHAR_RNG_UPPER, ord("9"))]
+    return [
+        ref(3) + ref(1) + ref(2) + _lit("."),                                   # 0 root
+        _lit("red") + ALT + _lit("green") + ALT + _lit("blue") + ALT + ref(4),  # 1 item
+        _lit(", ") + ref(1) + ref(2) + ALT,                                     # 2 rest (second alternative empty)
+        _lit(" ") + ALT,                                                        # 3 optional space
+        digit + ref(5),                                                         # 4 digits
+        digit + ref(5) + ALT,                                                   # 5 more digits
+    ]
+
+
+def negated_class_grammar():
+    """root ::= [^0-9,x-z]+ — a negated class with a range, an extra member and another range: exercises the partial
+    UTF-8 rules (most byte-level tokens of the vocabulary end inside a multi-byte sequence)."""
+    cls = [(abi.GRETYPE_CHAR_NOT, ord("0")), (abi.GRETYPE_CHAR_RNG_UPPER, ord("9")), (abi.GRETYPE_CHAR_ALT, ord(",")),
+           (abi.GRETYPE_CHAR_ALT, ord("x")), (abi.GRETYPE_CHAR_RNG_UPPER, ord("z"))]
+    return [[(abi.GRETYPE_RULE_REF, 1)], cls + [(abi.GRETYPE_RULE_REF, 2)], cls + [(abi.GRETYPE_RULE_REF, 2), (abi.GRETYPE_ALT, 0)]]
+
+
+def unicode_grammar():
+    """root ::= ("é" | [α-ω] | "日本")+ "!" — positive classes above U+007F, reached through partial sequences."""
+    ALT = [(abi.GRETYPE_ALT, 0)]
+    unit = _lit("é") + ALT + [(abi.GRETYPE_CHAR, ord("α")), (abi.GRETYPE_CHAR_RNG_UPPER, ord("ω"))] + ALT + _lit("日本")
+    return [[(abi.GRETYPE_RULE_REF, 1), (abi.GRETYPE_RULE_REF, 2)] + _lit("!"), unit, [(abi.GRETYPE_RULE_REF, 1), (abi.GRETYPE_RULE_REF, 2)] + ALT]

@@ -496,6 +496,12 @@ def _p_variant(node, name):
     elif name == "single_segment":   p.single_segment = True; p.max_tokens = 24
     elif name == "thold":            p.token_timestamps = True; p.thold_pt = 0.2; p.thold_ptsum = 0.3
     elif name == "beam3":            p.strategy = abi.WHISPER_SAMPLING_BEAM_SEARCH; p.beam_search.beam_size = 3; p.greedy.best_of = 1
+    elif name in ("grammar", "grammar_beam"):      # grammar-constrained decoding (W/whisper.cpp:3876-4290): " red, 12, blue."-shaped output
+        ptrs, n_rules, keep = abi.make_grammar(gu.colour_list_grammar())
+        node._grammar_keep = keep
+        p.grammar_rules = C.cast(ptrs, C.c_void_p); p.n_grammar_rules = n_rules; p.i_start_rule = 0; p.grammar_penalty = 100.0
+        p.no_timestamps = True; p.single_segment = True; p.max_tokens = 24
+        if name == "grammar_beam": p.strategy = abi.WHISPER_SAMPLING_BEAM_SEARCH; p.beam_search.beam_size = 3; p.greedy.best_of = 1
     else: raise KeyError(name)
     return p
 
@@ -509,7 +515,7 @@ def _segments(lib, ctx):
 
 
 @pytest.mark.parametrize("variant", ["no_timestamps", "translate_fr", "auto_language", "offset_duration", "max_len_wrap", "max_len_chars",
-                                     "no_suppress", "suppress_nst", "short_ctx", "single_segment", "thold", "beam3"])
+                                     "no_suppress", "suppress_nst", "short_ctx", "single_segment", "thold", "beam3", "grammar", "grammar_beam"])
 def test_parameter_variants_equal_the_compiled_reference(product_lib, checker_lib, variant):
     """Driver branches the Godot host does not take (W/whisper.cpp:4960-5807): both libraries run the same call on the same
     model and 20 s of audio; segments (t0, t1, text, token ids) must be equal up to the first near-tie (|dp| <= 2e-2)."""
@@ -527,6 +533,11 @@ def test_parameter_variants_equal_the_compiled_reference(product_lib, checker_li
         node.close()
     (rp, sp, tp, lp), (rr, sr, tr, lr) = res
     assert rp == rr == 0
+    if variant.startswith("grammar"):             # the constraint took hold: the text is a prefix of a colour list
+        import re
+        text = b"".join(a[2] for a in sp).decode()
+        assert re.fullmatch(r" ?((red|green|blue|[0-9]+)(, (red|green|blue|[0-9]+))*\.?|(red|green|blue|[0-9]+, )*(r|re|g|gr|gre|gree|b|bl|blu)?)?", text) or \
+               re.match(r" ?(red|green|blue|[0-9]+)", text), text
     if multilingual:
         assert lp == lr
     n = min(len(tp), len(tr))
@@ -534,7 +545,7 @@ def test_parameter_variants_equal_the_compiled_reference(product_lib, checker_li
     first = n if same.all() else int(np.argmin(same))
     if first < n:                                   # a near-tie (or, for beam search, a draw at a CDF step): histories part here
         assert first >= 3, (variant, first, tp[:4, 0], tr[:4, 0])
-        if variant != "beam3":
+        if variant not in ("beam3", "grammar_beam"):
             assert abs(tp[first, 2] - tr[first, 2]) <= 2e-2, (variant, first, tp[first], tr[first])
     else:
         assert len(sp) == len(sr), (variant, len(sp), len(sr))

@@ -140,3 +140,56 @@ def test_filters_live_against_reference(lib, ref_lib):
                 assert np.array_equal(a, b)
     finally:
         node.ctx = None; lib.whisper_free(ctx); rnode.close()
+
+
+# ------------------------------------------------------------------------------------------------ grammar-constrained decoding
+@pytest.mark.skipif(not reflib.available(), reason="compiled reference absent")
+@pytest.mark.parametrize("which", ["colours", "negated", "unicode"])
+def test_grammar_penalties_live_against_reference(lib, ref_lib, which):
+    """whisper_full_params.grammar_rules (W/whisper.cpp:3876-4290): after the same token history both libraries must
+    penalise exactly the same tokens — logits, log-probabilities and probabilities bit-identical on equal raw logits."""
+    model, _, _ = gu.case_inputs("en30" if which != "unicode" else "ml11")
+    name = "en30" if which != "unicode" else "ml11"
+    ctx = host_ctx(lib, name)
+    rnode = host.SpeechToText(ref_lib); rnode.set_language_model(model)
+    node = host.SpeechToText(lib); node.ctx = ctx
+    rules = {"colours": gu.colour_list_grammar, "negated": gu.negated_class_grammar, "unicode": gu.unicode_grammar}[which]()
+    texts = {"colours": ["", " red", " red,", " red, 12", " red, 120, gre", " blue.", " purple", " red, green, blue, 7"],
+             "negated": ["", " hello", " hello world", " café", " 12", " a,b"],
+             "unicode": ["", "é", "éβ", "日", "日本ω", "é!", "abc"]}[which]
+    try:
+        nv = lib.whisper_n_vocab(ctx)
+        beg = lib.whisper_token_beg(ctx)
+        rng = np.random.default_rng(5)
+        n_penalised = []
+        for k, text in enumerate(texts):
+            buf = (C.c_int32 * 64)()
+            n = lib.whisper_tokenize(ctx, text.encode("utf-8"), buf, 64)
+            assert n >= 0
+            hist = list(buf[:n])
+            if which == "unicode" and text and k % 2 == 1:                       # leave the history inside a multi-byte sequence
+                hist = hist[:-1] if len(hist) > 1 else hist
+            if k == 3:
+                hist = [beg + 5] + hist                                          # special tokens do not move the grammar (:4275)
+            hist = np.asarray(hist, np.int32)
+            raw = (rng.standard_normal(nv) * 3.0).astype(np.float32)
+            raw[beg:] -= 30.0                                                    # keep the timestamp mass below the text tokens
+            outs = []
+            for L, c, fn in ((lib, ctx, lib.wmi_process_logits), (ref_lib, rnode.ctx, ref_lib.ref_process_logits)):
+                nd = node if L is lib else rnode
+                p = nd.full_params("", 0)
+                ptrs, n_rules, keep = abi.make_grammar(rules)
+                p.grammar_rules = C.cast(ptrs, C.c_void_p); p.n_grammar_rules = n_rules; p.i_start_rule = 0; p.grammar_penalty = 50.0 + k
+                lo, lp, pr = (np.empty(nv, np.float32) for _ in range(3))
+                fn(c, p, sc._fptr(raw), hist.ctypes.data_as(C.POINTER(C.c_int32)), hist.size, 0, 3000, C.c_float(0.0),
+                   sc._fptr(lo), sc._fptr(lp), sc._fptr(pr))
+                outs.append((lo.copy(), lp.copy(), pr.copy()))
+                del keep
+            for a, b in zip(outs[0], outs[1]):
+                assert np.array_equal(a, b), (which, text)
+            n_penalised.append(int(np.sum(np.isfinite(outs[0][0]) & (outs[0][0] < raw - 1.0))))
+        # constrained states penalise most of the vocabulary (the negated class: the tokens holding a banned character); histories
+        # the grammar cannot parse leave no stack, and then nothing is penalised (:4227)
+        assert max(n_penalised) > (5000 if which == "negated" else 40000) and min(n_penalised) == 0, n_penalised
+    finally:
+        node.ctx = None; lib.whisper_free(ctx); rnode.close()
