@@ -30,7 +30,15 @@ void emit_segment(whisper_context & ctx, State & st, const whisper_full_params &
                   const std::vector<whisper_token_data> & toks, int i0, int i1_excl, bool speaker_turn_next) {
     const int64_t tt0 = params.speed_up ? 2 * t0 : t0, tt1 = params.speed_up ? 2 * t1 : t1;
     if (params.print_realtime) {
-        if (params.print_timestamps) printf("[%lld --> %lld]  %s\n", (long long) tt0, (long long) tt1, text.c_str());
+        if (params.print_timestamps) {              // hh:mm:ss.mmm of a count of 10 ms units (W/whisper.cpp:2599-2612)
+            auto stamp = [](int64_t t, char (&buf)[32]) {
+                const int64_t ms = t * 10;
+                snprintf(buf, sizeof(buf), "%02d:%02d:%02d.%03d", (int) (ms / 3600000), (int) ((ms / 60000) % 60), (int) ((ms / 1000) % 60), (int) (ms % 1000));
+            };
+            char b0[32], b1[32];
+            stamp(tt0, b0); stamp(tt1, b1);
+            printf("[%s --> %s]  %s\n", b0, b1, text.c_str());
+        }
         else { printf("%s", text.c_str()); fflush(stdout); }
     }
     Segment seg{tt0, tt1, text, {}, speaker_turn_next};

@@ -212,3 +212,34 @@ def test_bench_entry_points_report_the_device(product_lib):
     gf = [float(l.split("F16")[1].split("GFLOPS")[0]) for l in lines]
     assert gf[-1] > 100e3 and gf[-1] > gf[2], m                      # 4096^3 well above 100 TFLOP/s
     print(s, m)
+
+
+def test_print_realtime_output_equals_the_reference(product_lib, capfd):
+    """params.print_realtime (+ print_timestamps): the lines whisper_full prints while it emits segments
+    (W/whisper.cpp:5722-5729, 5769-5776; "[hh:mm:ss.mmm --> hh:mm:ss.mmm]  text") are the reference's, byte for byte."""
+    if not reflib.available():
+        pytest.skip("needs the compiled reference")
+    R = reflib.lib()
+    quiet = abi.ggml_log_callback(lambda lvl, txt, ud: None)
+    R.whisper_log_set(C.cast(quiet, C.c_void_p), None); R._quiet_cb2 = quiet
+    libc = C.CDLL(None)
+    model = synth.make_model("micro.en", seed=91); pcm = synth.make_pcm(45.0, seed=93, gate=True)
+    outs, toks = [], []
+    for stamps in (True, False):
+        for L in (product_lib, R):
+            node = host.SpeechToText(L); node.set_language_model(model)
+            p = _params(L); p.token_timestamps = False; p.print_realtime = True; p.print_timestamps = stamps
+            capfd.readouterr()
+            assert L.whisper_full(node.ctx, p, _fp(pcm), pcm.size) == 0
+            libc.fflush(None)
+            outs.append(capfd.readouterr().out)
+            toks.append([t[0] for s in _ctx_segments(L, node.ctx) for t in s[3]])
+            node.close()
+    for k in (0, 2):
+        assert outs[k].strip(), outs
+        if toks[k] == toks[k + 1]:
+            assert outs[k] == outs[k + 1]
+        else:                                                     # near-tie: compare the lines before the streams part
+            a, b = outs[k].splitlines(), outs[k + 1].splitlines()
+            assert a[0] == b[0]
+    assert outs[0].startswith("[00:00:0")
