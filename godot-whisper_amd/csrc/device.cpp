@@ -442,6 +442,10 @@ bool wait_for_seq(const volatile int32_t * seq, int32_t want, hipStream_t s) {
 
 // the kernels of one greedy step; every per-step quantity is read from DecStep on the device, so the same launch
 // sequence can be replayed as a graph
+// probe only (bench kernel 20): which kernel kinds of the step are enqueued — bit 0 embed, 1 qkv, 2 self-attn+out, 3 cross scores,
+// 4 cross combine+out, 5 mlp.0, 6 mlp.2, 7 logits, 8 filters
+static unsigned g_step_mask = ~0u;
+
 static void enqueue_greedy_step(whisper_context & ctx, int Tc) {
     State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
     KVCache & kv = st.kv_self;
@@ -457,7 +461,8 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc) {
     };
     // step parameters come from pinned host memory, the result goes back into pinned host memory: the replayed
     // graph contains kernels only (memcpy nodes cost tens of microseconds each on this stack)
-    k::dec_embed_step((const k::DecStep *) d.step_host, (k::DecStep *) d.step_dev, S, w.d_te, w.d_pe, d.dx, s); chk("embed", -1);
+    const unsigned M = g_step_mask;
+    if (M & 1) k::dec_embed_step((const k::DecStep *) d.step_host, (k::DecStep *) d.step_dev, S, w.d_te, w.d_pe, d.dx, s); chk("embed", -1);
     auto gv = [&](int epi, const float * lg, const float * lb, const __half * a16, int K, int N, const __half * W, const float * bias,
                   void * C, int ldc, const float * resid, void * aux, void * aux2, float scale, const int32_t * row_off) {
         k::GemvArgs g{};
@@ -469,8 +474,8 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc) {
     for (int il = 0; il < Lt; ++il) {
         const DecLayerW & l = w.dec[il];
         __half * ck = kv.k + ((size_t) il * n_ctx) * S, * cv = kv.v + ((size_t) il * n_ctx) * S;
-        gv(k::EPI_QKV_DEC, l.ln1_g, l.ln1_b, nullptr, S, 3 * S, l.w_qkv, l.b_qkv, d.dq, S, nullptr, ck, cv, kq_scale, &stp->kv_head); chk("qkv", il);
-        {   // self-attention over the cache, recomputed in the out-projection's prologue (one launch fewer)
+        if (M & 2) gv(k::EPI_QKV_DEC, l.ln1_g, l.ln1_b, nullptr, S, 3 * S, l.w_qkv, l.b_qkv, d.dq, S, nullptr, ck, cv, kq_scale, &stp->kv_head); chk("qkv", il);
+        if (M & 4) {   // self-attention over the cache, recomputed in the out-projection's prologue (one launch fewer)
             k::GemvArgs g{};
             g.sa_q = d.dq; g.sa_k = ck; g.sa_v = cv; g.sa_nkv = &stp->n_kv; g.sa_cap = hp.n_text_ctx;
             g.n = 1; g.K = S; g.N = S; g.W = l.w_o; g.bias = l.b_o; g.epi = k::EPI_F32_BIAS_RESID;
@@ -480,7 +485,8 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc) {
         {   // LN2 + cross query folded into the score kernel; partials combined inside the out-projection's prologue
             static const bool unfused_q = getenv("WMI_XATTN_UNFUSED_Q") != nullptr;          // debug / A-B
             const float * po = nullptr, * pl = nullptr; int ns = 0;
-            if (unfused_q || S > 512) {                   // the fused kernel keeps a whole row per wavefront in registers: S <= 512
+            if (!(M & 8)) { k::attn_cross_partials_layout(1, H, Tc, d.xattn, &po, &pl, &ns); }
+            else if (unfused_q || S > 512) {                   // the fused kernel keeps a whole row per wavefront in registers: S <= 512
                 gv(k::EPI_Q_SCALED, l.ln2_g, l.ln2_b, nullptr, S, S, l.w_cq, l.b_cq, d.dq, S, nullptr, nullptr, nullptr, kq_scale, nullptr);
                 k::attn_cross_split_partials(d.dq, 1, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, &po, &pl, &ns, s);
             } else
@@ -490,14 +496,14 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc) {
             k::GemvArgs g{};
             g.comb_o = po; g.comb_l = pl; g.comb_ns = ns; g.n = 1; g.K = S; g.N = S; g.W = l.w_co; g.bias = l.b_co; g.epi = k::EPI_F32_BIAS_RESID;
             g.C = d.dx; g.ldc = S; g.resid = d.dx; g.ldr = S; g.S = S;
-            k::gemv(g, s);
+            if (M & 16) k::gemv(g, s);
         }
-        gv(k::EPI_F16_BIAS_GELU, l.ln3_g, l.ln3_b, nullptr, S, 4 * S, l.w_fc1, l.b_fc1, d.dh, 4 * S, nullptr, nullptr, nullptr, 0.f, nullptr);
-        gv(k::EPI_F32_BIAS_RESID, nullptr, nullptr, d.dh, 4 * S, S, l.w_fc2, l.b_fc2, d.dx, S, d.dx, nullptr, nullptr, 0.f, nullptr);
+        if (M & 32) gv(k::EPI_F16_BIAS_GELU, l.ln3_g, l.ln3_b, nullptr, S, 4 * S, l.w_fc1, l.b_fc1, d.dh, 4 * S, nullptr, nullptr, nullptr, 0.f, nullptr);
+        if (M & 64) gv(k::EPI_F32_BIAS_RESID, nullptr, nullptr, d.dh, 4 * S, S, l.w_fc2, l.b_fc2, d.dx, S, d.dx, nullptr, nullptr, 0.f, nullptr);
     }
     chk("layers", Lt);
-    gv(k::EPI_LOGITS, w.d_ln_g, w.d_ln_b, nullptr, S, NV, w.d_te, nullptr, d.logits, NV, nullptr, nullptr, nullptr, 0.f, nullptr); chk("logits", Lt);
-    k::filter_argmax(d.logits, d.ban_dev, stp, (k::SampleOut *) d.sample_dev, d.filter_scratch, s, (k::SampleOut *) d.sample_host); chk("filter", Lt);
+    if (M & 128) gv(k::EPI_LOGITS, w.d_ln_g, w.d_ln_b, nullptr, S, NV, w.d_te, nullptr, d.logits, NV, nullptr, nullptr, nullptr, 0.f, nullptr); chk("logits", Lt);
+    if (M & 256) k::filter_argmax(d.logits, d.ban_dev, stp, (k::SampleOut *) d.sample_dev, d.filter_scratch, s, (k::SampleOut *) d.sample_host); chk("filter", Lt);
 }
 
 bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const StepFilter & f, whisper_token_data & out) {
@@ -567,6 +573,31 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
     out = whisper_token_data{ r->id, r->tid, r->p, r->plog, r->pt, r->ptsum, -1, -1, 0.0f };
     st.t_decode_us += time_us() - t0; st.n_decode++; st.n_sample++;
     return true;
+}
+
+// probe: the kernels of the last greedy step `iters` times back to back with no host round trip in between
+// (graph replays when the step is captured, eager launches otherwise); microseconds per step on the GPU, -1 without a step
+double bench_greedy_step_chain(whisper_context & ctx, int iters) {
+    State & st = *ctx.state; DeviceState & d = st.dev;
+    if (!d.step_dev || iters <= 0) return -1.0;
+    const char * mask_env = getenv("WMI_STEP_MASK");
+    g_step_mask = mask_env ? (unsigned) strtoul(mask_env, nullptr, 0) : ~0u;
+    k::set_xattn_probe_skip(((g_step_mask >> 9) & 1) | (((g_step_mask >> 10) & 1) << 1));       // bits 9 / 10: skip scores / P.V inside bit 3
+    struct Restore { ~Restore() { g_step_mask = ~0u; k::set_xattn_probe_skip(0); } } restore;
+    const int Tc = st.enc_n_ctx > 0 ? st.enc_n_ctx : ctx.model.hp.n_audio_ctx;
+    hipStream_t s = d.stream;
+    hipEvent_t e0, e1;
+    if (!HIP_OK(hipEventCreate(&e0)) || !HIP_OK(hipEventCreate(&e1))) return -1.0;
+    auto once = [&]() { if (d.step_exec && d.step_graph_T == Tc && g_step_mask == ~0u) (void) hipGraphLaunch(d.step_exec, s); else enqueue_greedy_step(ctx, Tc); };
+    for (int i = 0; i < 4; ++i) once();
+    (void) hipStreamSynchronize(s);
+    (void) hipEventRecord(e0, s);
+    for (int i = 0; i < iters; ++i) once();
+    (void) hipEventRecord(e1, s);
+    (void) hipEventSynchronize(e1);
+    float ms = 0.0f; (void) hipEventElapsedTime(&ms, e0, e1);
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    return (double) ms * 1000.0 / iters;
 }
 
 } // namespace wmi

@@ -583,6 +583,16 @@ void attn_cross_combine(const float * part_o, const float * part_l, int ns, int 
     hipLaunchKernelGGL(k_xattn_combine, dim3(H, n), dim3(64), 0, st, part_o, part_l, ns, S, out);
 }
 
+static int g_xattn_probe_skip = 0;        // probe only: bit 0 skips the score kernel, bit 1 the P.V kernel
+void set_xattn_probe_skip(int mask) { g_xattn_probe_skip = mask; }
+void attn_cross_partials_layout(int n, int H, int T, float * scratch, const float ** po, const float ** pl, int * pns) {
+    int ns = (T + 191) / 192; if (ns < 1) ns = 1; if (ns > XS_MAX_SLICES) ns = XS_MAX_SLICES;
+    const int ld_sc = (T + 63) & ~63;
+    float * pmax = scratch + (size_t) n * H * ld_sc;
+    float * part_l = pmax + (size_t) n * H * ns;
+    *po = part_l + (size_t) n * H * ns; *pl = part_l; *pns = ns;
+}
+
 void attn_cross_qsplit_partials(const float * x32, const float * ln_g, const float * ln_b, float eps, const __half * wq,
                                 const float * bq, float qscale, int n, int S, int H, const __half * kc, const __half * vc, int T,
                                 float * scratch, const float ** po, const float ** pl, int * pns, hipStream_t st,
@@ -594,9 +604,11 @@ void attn_cross_qsplit_partials(const float * x32, const float * ln_g, const flo
     float * pmax = sc + (size_t) n * H * ld_sc;
     float * part_l = pmax + (size_t) n * H * ns;
     float * part_o = part_l + (size_t) n * H * ns;
+    if (!(g_xattn_probe_skip & 1))
     hipLaunchKernelGGL(k_xattn_qscores, dim3(ns, H, n), dim3(256), 0, st, x32, ln_g, ln_b, eps, wq, bq, qscale, S, kc, T, ks, ns,
                        sc, ld_sc, pmax, kv_row_stride);
     const size_t smem = (((size_t) ks + 3) & ~(size_t) 3) * 4 + 4 * 64 * 4;
+    if (!(g_xattn_probe_skip & 2))
     hipLaunchKernelGGL(k_xattn_pv, dim3(ns, H, n), dim3(256), smem, st, vc, S, T, ks, ns, sc, ld_sc, pmax, part_o, part_l, kv_row_stride);
     *po = part_o; *pl = part_l; *pns = ns;
 }

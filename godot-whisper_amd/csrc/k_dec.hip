@@ -54,12 +54,146 @@ __global__ void k_dec_embed_step(const DecStep * __restrict__ host_step, DecStep
 // Numerics as k_attn_dec: scores f16.f16 -> f32, exp through f16, probabilities rounded to f16 before P.V, P.V
 // accumulated in key order (SURVEY App. B rules 1, 4, 5).  sc: [H][cap] floats, qf: [K] floats (LDS); out: [K] f16
 // (LDS or global).  kpre: this thread's first K row if it was requested early (use_pre).
+// Self-attention of one decoder row for n_kv <= 64: NU heads (hs[u] < H; others skipped) by ONE wavefront, no LDS and no
+// workgroup barrier.  The barrier-separated routine below measured 7 us inside the out-projection (q, K, soft-max and V
+// phases each waiting on the slowest wavefront, and a 128-byte K row per lane); here every global load that does not
+// depend on n_kv goes out before n_kv is read, in shapes the L1 likes:
+//   scores   lane = (key group g = lane / 8, dimension octet o = lane % 8); pass t covers keys 8 t + g: one 16-byte load per
+//            lane and pass, 8 fmaf in dimension order, then the three-step butterfly over the octets of the key
+//   soft-max maximum and sum over passes (in pass order) and over the key groups (xor 8, 16, 32); f16 roundings of the reference
+//   P.V      lane = head column; probabilities moved to lane = key, key j broadcast with v_readlane;
+//            one fmaf chain per column in key order; V of the first SA_VG keys requested up front, later keys in groups
+// This fixes the summation order of the path (score: octet-wise then butterfly); every caller — the one-row prologue of
+// k_gemv1, the lock-step row kernels — goes through this routine, which keeps them bit-identical to each other.
+// Returns false, with nothing written, when n_kv > 64 (callers then take self_attn_row).
+constexpr int SA_VG = 16;
+template <int NU>
+__device__ __forceinline__ bool self_attn_wave(const __half * __restrict__ sq, const __half * __restrict__ sk,
+                                               const __half * __restrict__ sv, const int32_t * __restrict__ n_kv_p, int K, int cap,
+                                               const int (&hs)[NU], int H, int lane, __half * out) {
+    const int g = lane >> 3, o = lane & 7;
+    int hh[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) hh[u] = hs[u] < H ? hs[u] : hs[0];
+    uint4 qv[NU], kv[NU][8];
+    __half vv[NU][SA_VG];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        qv[u] = *(const uint4 *) (sq + hh[u] * 64 + o * 8);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {                    // keys [0, 32): the decode loop rarely holds more (rows past n_kv: finite cache garbage)
+            const int j = 8 * t + g;
+            kv[u][t] = *(const uint4 *) (sk + (size_t) (j < cap ? j : 0) * K + hh[u] * 64 + o * 8);
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u)
+#pragma unroll
+        for (int t = 0; t < SA_VG; ++t) vv[u][t] = sv[(size_t) (t < cap ? t : 0) * K + hh[u] * 64 + lane];
+    const int n_kv = *n_kv_p;
+    if (n_kv > 64) return false;
+    if (n_kv > 32) {
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int t = 4; t < 8; ++t) {
+                const int j = 8 * t + g;
+                kv[u][t] = *(const uint4 *) (sk + (size_t) (j < n_kv ? j : 0) * K + hh[u] * 64 + o * 8);
+            }
+    }
+    const int n_pass = n_kv > 32 ? 8 : 4;
+
+    float p[NU][8];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        float qf[8];
+        {
+            const __half2 * qh = (const __half2 *) &qv[u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float2 f = __half22float2(qh[e]); qf[2 * e] = f.x; qf[2 * e + 1] = f.y; }
+        }
+        float m = -INFINITY;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            p[u][t] = -INFINITY;
+            if (t < n_pass) {
+                const __half2 * kh = (const __half2 *) &kv[u][t];
+                float dot = 0.0f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float2 f = __half22float2(kh[e]);
+                    dot = fmaf(f.x, qf[2 * e], dot);
+                    dot = fmaf(f.y, qf[2 * e + 1], dot);
+                }
+                dot += __shfl_xor(dot, 1); dot += __shfl_xor(dot, 2); dot += __shfl_xor(dot, 4);
+                if (8 * t + g < n_kv) { p[u][t] = dot; m = fmaxf(m, dot); }
+            }
+        }
+        m = fmaxf(m, __shfl_xor(m, 8)); m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
+        float l = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float e = (t < n_pass && 8 * t + g < n_kv) ? round_f16(expf(round_f16(p[u][t] - m))) : 0.0f;
+            p[u][t] = e; l += e;
+        }
+        l += __shfl_xor(l, 8); l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
+        const float inv = (float) (1.0 / (double) l);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) p[u][t] = round_f16(p[u][t] * inv);
+    }
+
+    // probabilities to lane = key order (key j of pass j / 8 sits on the lanes of group j % 8): the P.V loop below then stays
+    // a short rolled loop with a scalar lane index (fully unrolled it was 128 predicated steps of cold code per launch)
+    float pk[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        pk[u] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const float v = __shfl(p[u][t], (lane & 7) * 8);
+            if ((lane >> 3) == t) pk[u] = v;
+        }
+    }
+    float acc[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) acc[u] = 0.0f;
+    for (int jg = 0; jg < n_kv; jg += SA_VG) {
+        if (jg > 0) {
+#pragma unroll
+            for (int u = 0; u < NU; ++u)
+#pragma unroll
+                for (int t = 0; t < SA_VG; ++t) vv[u][t] = sv[(size_t) (jg + t < n_kv ? jg + t : n_kv - 1) * K + hh[u] * 64 + lane];
+        }
+#pragma unroll
+        for (int t = 0; t < SA_VG; ++t) {
+            if (jg + t < n_kv) {                         // wave-uniform
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {
+                    const float pj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pk[u]), jg + t));
+                    acc[u] = fmaf(pj, __half2float(vv[u][t]), acc[u]);
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NU; ++u) if (hs[u] < H) out[hs[u] * 64 + lane] = f2h(acc[u]);
+    return true;
+}
+
 __device__ __forceinline__ void self_attn_row(const __half * __restrict__ sq, const __half * __restrict__ sk,
                                               const __half * __restrict__ sv, int n_kv, int K, int cap,
                                               float * sc, float * qf, __half * out, const uint4 (&kpre)[8], bool use_pre) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = K / 64;
-    for (int c = tid; c < K; c += 256) qf[c] = __half2float(sq[c]);
+    {   // q -> f32 in LDS.  All loads of a thread first: as a plain strided loop hipcc emitted one load + vmcnt(0) per
+        // element for short trip counts (K = 512: two dependent round trips before the first score)
+        constexpr int QU = 5;                           // K <= 1280
+        __half qv[QU];
+#pragma unroll
+        for (int u = 0; u < QU; ++u) { const int c = tid + u * 256; qv[u] = sq[c < K ? c : 0]; }
+#pragma unroll
+        for (int u = 0; u < QU; ++u) { const int c = tid + u * 256; if (c < K) qf[c] = __half2float(qv[u]); }
+    }
     __syncthreads();
     for (int p = tid; p < H * n_kv; p += 256) {
         const int j = p / H, h = p - j * H;
@@ -118,6 +252,10 @@ __global__ __launch_bounds__(64) void k_self_attn_rows(const __half * __restrict
     float * qf  = row + cap;                            // [64]
     const int r = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
     const __half * sk = kc + (int64_t) r * cache_row_stride, * sv = vc + (int64_t) r * cache_row_stride;
+    {   // n_kv <= 64 (the decode loop): the wave-level routine shared with the one-row prologue
+        const int hs[1] = { h };
+        if (self_attn_wave<1>(q + (size_t) r * K, sk, sv, n_kv_p + r * step_stride, K, cap, hs, K / 64, lane, out + (size_t) r * K)) return;
+    }
     const int n_kv = n_kv_p[r * step_stride];
     qf[lane] = __half2float(q[(size_t) r * K + h * 64 + lane]);
     __syncthreads();
@@ -278,20 +416,21 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
         const int H = K / 64;
         float * sc = (float *) (smem + (((size_t) R * K * sizeof(__half) + 15) & ~(size_t) 15));   // [H][sa_cap]
         float * qf = sc + (size_t) H * a.sa_cap;                                                   // [K]
-        // pair p <-> (key p / H, head p % H): independent of n_kv, so the first K row of every thread is requested
-        // before n_kv and q have arrived (rows past n_kv are finite cache garbage and never used)
-        uint4 kpre[8];
-        {
-            const int j = tid / H, h = tid - j * H;
-            const uint4 * kp = (const uint4 *) (a.sa_k + (size_t) (j < a.sa_cap ? j : 0) * K + h * 64);
-#pragma unroll
-            for (int c8 = 0; c8 < 8; ++c8) kpre[c8] = kp[c8];
-        }
 #pragma unroll 1
         for (int r = 0; r < R; ++r) {
-            self_attn_row(a.sa_q + (size_t) r * K, a.sa_k + (int64_t) r * a.cache_row_stride, a.sa_v + (int64_t) r * a.cache_row_stride,
-                          a.sa_nkv[r * a.step_stride], K, a.sa_cap, sc, qf, act + (size_t) r * K, kpre, r == 0);
-            if (R > 1) __syncthreads();                         // sc / qf are reused by the next row
+            const __half * rq = a.sa_q + (size_t) r * K, * rk = a.sa_k + (int64_t) r * a.cache_row_stride, * rv = a.sa_v + (int64_t) r * a.cache_row_stride;
+            const int32_t * rn = a.sa_nkv + r * a.step_stride;
+            bool done = true;                               // n_kv <= 64: the wave-level routine of the one-row kernel (bit-identical)
+            for (int h0 = tid >> 6; h0 < H; h0 += 8) {
+                const int hs[2] = { h0, h0 + 4 };
+                done = self_attn_wave<2>(rq, rk, rv, rn, K, a.sa_cap, hs, H, tid & 63, act + (size_t) r * K) && done;
+            }
+            if ((tid >> 6) >= H) done = rn[0] <= 64;
+            if (!done) {
+                const uint4 kpre[8] = {};
+                self_attn_row(rq, rk, rv, rn[0], K, a.sa_cap, sc, qf, act + (size_t) r * K, kpre, false);
+                if (R > 1) __syncthreads();                     // sc / qf are reused by the next row
+            }
         }
     } else if (a.comb_o) {                                  // fused combine of the split cross-attention partials
         const int H = K / 64, ns = a.comb_ns;
@@ -468,30 +607,45 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
             const int H = K / 64;
             float * sc = (float *) (smem + (((size_t) K * sizeof(__half) + 15) & ~(size_t) 15));   // [H][sa_cap]
             float * qf = sc + (size_t) H * a.sa_cap;                                             // [K]
-            uint4 kpre[8];
-            {
-                const int j = tid / H, h = tid - j * H;
-                const uint4 * kp = (const uint4 *) (a.sa_k + (size_t) (j < a.sa_cap ? j : 0) * K + h * 64);
-#pragma unroll
-                for (int c8 = 0; c8 < 8; ++c8) kpre[c8] = kp[c8];
+            // the decode loop's case (n_kv <= 64): per wavefront, barrier-free — heads wave, wave + 4 (and wave + 8, wave + 12, ...)
+            bool done = true;
+            for (int h0 = wave; h0 < H; h0 += 8) {
+                const int hs[2] = { h0, h0 + 4 };
+                done = self_attn_wave<2>(a.sa_q, a.sa_k, a.sa_v, a.sa_nkv, K, a.sa_cap, hs, H, lane, act) && done;
             }
-            self_attn_row(a.sa_q, a.sa_k, a.sa_v, a.sa_nkv[0], K, a.sa_cap, sc, qf, act, kpre, true);
+            if (wave >= H) done = a.sa_nkv[0] <= 64;         // a wavefront without a head (H < 4) still has to agree on the branch
+            if (!done) {                                     // wave-uniform and the same in every wavefront: it only depends on n_kv
+                const uint4 kpre[8] = {};
+                self_attn_row(a.sa_q, a.sa_k, a.sa_v, a.sa_nkv[0], K, a.sa_cap, sc, qf, act, kpre, false);
+            }
             __syncthreads();
             arow = act;
         } else if (a.comb_o) {
             const int H = K / 64, ns = a.comb_ns;
+            if (ns == 8) {
+                // T = 1500: the 2 x 16 loads of a thread's two elements go out before the first add (element by element this
+                // was one round trip per element; a plain loop over the slices one per slice)
+                for (int e0 = tid; e0 < K; e0 += 512) {
+                    float po[2][8], pl[2][8];
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        const int e = e0 + u * 256 < K ? e0 + u * 256 : e0, h = e >> 6, dd = e & 63;
+#pragma unroll
+                        for (int s2 = 0; s2 < 8; ++s2) { po[u][s2] = a.comb_o[((size_t) h * 8 + s2) * 64 + dd]; pl[u][s2] = a.comb_l[(size_t) h * 8 + s2]; }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        float o = 0.0f; double l = 0.0;
+#pragma unroll
+                        for (int s2 = 0; s2 < 8; ++s2) { o += po[u][s2]; l += (double) pl[u][s2]; }
+                        if (e0 + u * 256 < K) act[e0 + u * 256] = f2h(o * (float) (1.0 / l));
+                    }
+                }
+            } else
             for (int e = tid; e < K; e += 256) {
                 const int h = e >> 6, dd = e & 63;
                 float o = 0.0f; double l = 0.0;
-                if (ns == 8) {                           // T = 1500: all 16 loads of an element go out before the first add
-                    float po[8], pl[8];
-#pragma unroll
-                    for (int s2 = 0; s2 < 8; ++s2) { po[s2] = a.comb_o[((size_t) h * 8 + s2) * 64 + dd]; pl[s2] = a.comb_l[(size_t) h * 8 + s2]; }
-#pragma unroll
-                    for (int s2 = 0; s2 < 8; ++s2) { o += po[s2]; l += (double) pl[s2]; }
-                } else {
-                    for (int s2 = 0; s2 < ns; ++s2) { o += a.comb_o[((size_t) h * ns + s2) * 64 + dd]; l += (double) a.comb_l[(size_t) h * ns + s2]; }
-                }
+                for (int s2 = 0; s2 < ns; ++s2) { o += a.comb_o[((size_t) h * ns + s2) * 64 + dd]; l += (double) a.comb_l[(size_t) h * ns + s2]; }
                 act[e] = f2h(o * (float) (1.0 / l));
             }
             (void) H;

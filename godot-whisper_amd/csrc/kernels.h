@@ -123,6 +123,8 @@ struct GemvArgs {
 void self_attn_rows(const __half * q, int n, int K, const __half * kc, const __half * vc, int64_t cache_row_stride,
                     const int32_t * n_kv, int step_stride, int cap, __half * out, hipStream_t st);
 // split cross-attention partials -> out [n][S] f16 (the separate form of GemvArgs::comb_*)
+void set_xattn_probe_skip(int mask);      // probe only
+void attn_cross_partials_layout(int n, int H, int T, float * scratch, const float ** po, const float ** pl, int * pns);
 void attn_cross_combine(const float * part_o, const float * part_l, int ns, int n, int S, int H, __half * out, hipStream_t st);
 enum { EPI_LOGITS = 100 };                    // C f32 [n][N] = acc
 void gemv(const GemvArgs & a, hipStream_t st);

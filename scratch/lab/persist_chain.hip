@@ -1,0 +1,142 @@
+// Lab: is a persistent decoder-layer kernel worth building?  A chain of P dependent GEMV phases y = W_p . x (S = 512,
+// f16 weights, f32 activations) run (a) as P kernel launches on one stream and (b) as ONE launch whose G workgroups hand
+// the activation vector over through data-tagged 8-byte granules {f32 value, u32 tag} written and polled with agent-scope
+// (sc1) accesses — correct on any XCD placement; G = 32 uses the workgroups with blockIdx % 8 == 0 of a 256-block launch
+// (one XCD under round-robin dispatch).  Weights of the next phase are requested BEFORE the poll.  Prints us per phase.
+//   hipcc --offload-arch=gfx950 -O3 persist_chain.hip -o persist_chain && ./persist_chain
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <cmath>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+constexpr int S = 512;
+
+struct Gran { float v; unsigned tag; };
+
+__device__ __forceinline__ float dot8(const uint4 w, const float * x) {
+    const __half2 * h = (const __half2 *) &w;
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float2 f = __half22float2(h[j]); acc += f.x * x[2 * j] + f.y * x[2 * j + 1]; }
+    return acc;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// (a) one launch per phase: N rows, one wave per RPW rows
+template <int RPW>
+__global__ __launch_bounds__(256) void k_phase(const __half * __restrict__ W, const float * __restrict__ x, float * __restrict__ y, int N) {
+    const int lane = threadIdx.x & 63, gw = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int r0 = gw * RPW;
+    if (r0 >= N) return;
+    uint4 w[RPW];
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) w[u] = *(const uint4 *) (W + (size_t) (r0 + u) * S + lane * 8);
+    float xv[8];
+    const float4 a = *(const float4 *) (x + lane * 8), b = *(const float4 *) (x + lane * 8 + 4);
+    xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w; xv[4] = b.x; xv[5] = b.y; xv[6] = b.z; xv[7] = b.w;
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) { const float s = wave_sum(dot8(w[u], xv)); if (lane == 0) y[r0 + u] = s; }
+}
+
+// (b) persistent: G participating workgroups, 4 waves each; wave `gw` owns rows [gw * RPW, +RPW) of every phase
+template <int RPW>
+__global__ __launch_bounds__(256) void k_persist(const __half * __restrict__ W, size_t w_stride, int n_w, Gran * __restrict__ ring, int P,
+                                                 int stride_blocks, int * __restrict__ err) {
+    if (blockIdx.x % stride_blocks != 0) return;
+    const int lane = threadIdx.x & 63, gw = (blockIdx.x / stride_blocks) * 4 + (threadIdx.x >> 6);
+    const int r0 = gw * RPW;
+    uint4 w[RPW];
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) w[u] = *(const uint4 *) (W + (size_t) (r0 + u) * S + lane * 8);
+    for (int p = 0; p < P; ++p) {
+        const Gran * src = ring + (size_t) (p % 3) * S;          // phase p reads buffer p % 3 (tag p), writes buffer (p + 1) % 3 (tag p + 1)
+        float xv[8];
+        unsigned spins = 0;
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const unsigned long long g = __hip_atomic_load((const unsigned long long *) (src + lane * 8 + j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                xv[j] = __uint_as_float((unsigned) g);
+                ok = ok && ((unsigned) (g >> 32) == (unsigned) p);
+            }
+            if (__all(ok)) break;
+            if (++spins > 4000000u) { if (lane == 0) atomicExch(err, p + 1); return; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        float res[RPW];
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) res[u] = wave_sum(dot8(w[u], xv));
+        // next phase's weights: requested before this phase's results are published (they do not depend on anything)
+        if (p + 1 < P) {
+            const __half * Wn = W + (size_t) ((p + 1) % n_w) * w_stride;
+#pragma unroll
+            for (int u = 0; u < RPW; ++u) w[u] = *(const uint4 *) (Wn + (size_t) (r0 + u) * S + lane * 8);
+        }
+        Gran * dst = ring + (size_t) ((p + 1) % 3) * S;
+        if (lane < RPW) {
+            float mine = res[0];
+#pragma unroll
+            for (int u = 1; u < RPW; ++u) if (lane == u) mine = res[u];
+            const unsigned long long g = ((unsigned long long) (unsigned) (p + 1) << 32) | __float_as_uint(mine);
+            __hip_atomic_store((unsigned long long *) (dst + r0 + lane), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
+int main() {
+    const int P = 42 * 8, n_w = 14;
+    std::vector<__half> hW((size_t) n_w * S * S);
+    srand(1);
+    for (auto & h : hW) h = __float2half(((rand() % 2001) - 1000) / 1000.0f * 0.076f);      // spectral radius ~1: values stay finite
+    __half * W; CK(hipMalloc(&W, hW.size() * 2)); CK(hipMemcpy(W, hW.data(), hW.size() * 2, hipMemcpyHostToDevice));
+    std::vector<float> x0(S); for (int i = 0; i < S; ++i) x0[i] = sinf(0.1f * i);
+    float * xa, * xb; CK(hipMalloc(&xa, S * 4)); CK(hipMalloc(&xb, S * 4));
+    Gran * ring; CK(hipMalloc(&ring, 3 * S * sizeof(Gran)));
+    int * err; CK(hipMalloc(&err, 4));
+    hipStream_t st; CK(hipStreamCreate(&st));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<float> ref(S), got(S);
+
+    // (a) launches
+    for (int rep = 0; rep < 3; ++rep) {
+        CK(hipMemcpy(xa, x0.data(), S * 4, hipMemcpyHostToDevice));
+        CK(hipEventRecord(e0, st));
+        float * a = xa, * b = xb;
+        for (int p = 0; p < P; ++p) { hipLaunchKernelGGL(k_phase<4>, dim3(S / 16), dim3(256), 0, st, W + (size_t) (p % n_w) * S * S, a, b, S); std::swap(a, b); }
+        CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+        float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+        CK(hipMemcpy(ref.data(), a, S * 4, hipMemcpyDeviceToHost));
+        printf("launch chain          : %.2f us per phase (x[0] = %g)\n", ms * 1000 / P, ref[0]);
+    }
+    // (b) persistent, G = 32 / 64 / 128 workgroups (rows per wave 4 / 2 / 1)
+    auto run = [&](auto kern, int G, int grid, int stride, const char * what) {
+        for (int rep = 0; rep < 3; ++rep) {
+            std::vector<Gran> init(3 * S, Gran{ 0.f, 0xffffffffu });
+            for (int i = 0; i < S; ++i) init[i] = Gran{ x0[i], 0u };
+            CK(hipMemcpy(ring, init.data(), init.size() * sizeof(Gran), hipMemcpyHostToDevice));
+            CK(hipMemset(err, 0, 4));
+            CK(hipEventRecord(e0, st));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), 0, st, W, (size_t) S * S, n_w, ring, P, stride, err);
+            CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            int herr; CK(hipMemcpy(&herr, err, 4, hipMemcpyDeviceToHost));
+            std::vector<Gran> out(3 * S); CK(hipMemcpy(out.data(), ring, out.size() * sizeof(Gran), hipMemcpyDeviceToHost));
+            double md = 0; for (int i = 0; i < S; ++i) md = fmax(md, fabs(out[(size_t) (P % 3) * S + i].v - ref[i]));
+            printf("persistent %-11s: %.2f us per phase, max |diff| vs launches %.3g, err %d\n", what, ms * 1000 / P, md, herr);
+        }
+    };
+    run(k_persist<4>, 32, 256, 8, "G=32 (1 XCD)");
+    run(k_persist<4>, 32, 32, 1, "G=32 spread");
+    run(k_persist<2>, 64, 256, 4, "G=64 (2 XCD)");
+    run(k_persist<1>, 128, 256, 2, "G=128");
+    return 0;
+}
