@@ -339,26 +339,45 @@ __global__ __launch_bounds__(256) void k_xattn_qscores(const float * __restrict_
     const bool on = lane * 8 < S;                                  // S <= 512, multiple of 8
 
     // 16 weight rows of this wavefront (independent of x: requested first), then x, gain, bias
+    // Loads are unconditional from a clamped column and masked afterwards: written as `on ? load : 0` hipcc put every load
+    // in its own exec-masked block — 24 scalar dword loads for x / gain / bias and a vmcnt(0) after the second weight row
     uint4 w[16];
-    const __half * wrow0 = wq + (size_t) (head * 64 + wave * 16) * S + lane * 8;
+    const int c0 = on ? lane * 8 : 0;
+    const __half * wrow0 = wq + (size_t) (head * 64 + wave * 16) * S + c0;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) w[u] = on ? *(const uint4 *) (wrow0 + (size_t) u * S) : make_uint4(0u, 0u, 0u, 0u);
+    for (int u = 0; u < 16; ++u) w[u] = *(const uint4 *) (wrow0 + (size_t) u * S);
     float xv[8], gv[8], bv[8];
     {
-        const float * xr = x32 + (size_t) i * S + lane * 8;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { xv[e] = on ? xr[e] : 0.0f; gv[e] = on ? ln_g[lane * 8 + e] : 0.0f; bv[e] = on ? ln_b[lane * 8 + e] : 0.0f; }
+        const float * xr = x32 + (size_t) i * S + c0;
+        const float4 x0 = *(const float4 *) xr, x1 = *(const float4 *) (xr + 4);
+        const float4 g0 = *(const float4 *) (ln_g + c0), g1 = *(const float4 *) (ln_g + c0 + 4);
+        const float4 b0 = *(const float4 *) (ln_b + c0), b1 = *(const float4 *) (ln_b + c0 + 4);
+        xv[0] = x0.x; xv[1] = x0.y; xv[2] = x0.z; xv[3] = x0.w; xv[4] = x1.x; xv[5] = x1.y; xv[6] = x1.z; xv[7] = x1.w;
+        gv[0] = g0.x; gv[1] = g0.y; gv[2] = g0.z; gv[3] = g0.w; gv[4] = g1.x; gv[5] = g1.y; gv[6] = g1.z; gv[7] = g1.w;
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
     }
     const float bias = bq ? bq[head * 64 + wave * 16 + ((lane >> 2) & 15)] : 0.0f;
-    // this thread's first key row (128 B of the cross cache): independent of q, requested with everything else
-    uint4 kfirst[8];
-    {
-        const int j0 = slice * ks + tid;
-        const uint4 * kp0 = (const uint4 *) (kc + (size_t) (j0 < T ? j0 : 0) * S + head * 64);
+    // Key rows of this wavefront — a quarter of the slice, 8 keys per pass: lane = (key g = lane / 8, 16-byte octet o = lane % 8),
+    // so one load instruction covers 8 whole 128-byte rows (a lane per row made every instruction touch 64 cache lines for
+    // 16 bytes each: the vector L1 was the bottleneck of the kernel's first 3 us).  Independent of q: requested with everything else.
+    constexpr int KPASS = 6;                                        // 4 wavefronts x 6 passes x 8 keys = 192 >= ks for T <= 1536
+    const int g = lane >> 3, o = lane & 7;
+    const int kpw = (((ks + 3) >> 2) + 7) & ~7;                     // keys per wavefront, whole passes
+    const int t0 = wave * kpw;
+    uint4 kk[KPASS];
 #pragma unroll
-        for (int c = 0; c < 8; ++c) kfirst[c] = kp0[c];
+    for (int p = 0; p < KPASS; ++p) {
+        const int t = t0 + 8 * p + g, j = slice * ks + t;
+        const bool ok = 8 * p < kpw && t < ks && j < T;
+        kk[p] = *(const uint4 *) (kc + (size_t) (ok ? j : 0) * S + head * 64 + o * 8);
     }
     __builtin_amdgcn_sched_barrier(0);          // keep all loads in flight together (the scheduler would sink them to their uses)
+    if (!on) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) w[u] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xv[e] = 0.0f; gv[e] = 0.0f; bv[e] = 0.0f; }
+    }
     float sum = 0.0f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) sum += xv[e];
@@ -415,27 +434,31 @@ __global__ __launch_bounds__(256) void k_xattn_qscores(const float * __restrict_
     if ((lane & 3) == 0) qs[wave * 16 + ((lane >> 2) & 15)] = round_f16((acc[0] + bias) * qscale);
     __syncthreads();
 
+    float qo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qo[e] = qs[o * 8 + e];
     float lmax = -INFINITY;
-    for (int t = tid; t < ks; t += 256) {
-        const int j = slice * ks + t;
-        if (j >= T) break;
-        const uint4 * kp = (const uint4 *) (kc + (size_t) j * S + head * 64);
-        uint4 u[8];
+    for (int p0 = 0; p0 * 8 < kpw; p0 += KPASS) {                   // one trip unless a slice holds more than 192 keys
 #pragma unroll
-        for (int c = 0; c < 8; ++c) u[c] = t == tid ? kfirst[c] : kp[c];
-        float dot = 0.0f;
-#pragma unroll
-        for (int c = 0; c < 8; ++c) {
-            const __half2 * h = (const __half2 *) &u[c];
+        for (int p = 0; p < KPASS; ++p) {
+            const int t = t0 + 8 * (p0 + p) + g, j = slice * ks + t;
+            const bool ok = 8 * (p0 + p) < kpw && t < ks && j < T;
+            uint4 u = kk[p];
+            if (p0 > 0) u = *(const uint4 *) (kc + (size_t) (ok ? j : 0) * S + head * 64 + o * 8);
+            const __half2 * h = (const __half2 *) &u;
+            float dot = 0.0f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float2 f = __half22float2(h[e]);
-                dot = fmaf(f.x, qs[c * 8 + e * 2], dot);
-                dot = fmaf(f.y, qs[c * 8 + e * 2 + 1], dot);
+                dot = fmaf(f.x, qo[2 * e], dot);
+                dot = fmaf(f.y, qo[2 * e + 1], dot);
+            }
+            dot += __shfl_xor(dot, 1); dot += __shfl_xor(dot, 2); dot += __shfl_xor(dot, 4);     // the 8 octets of a key
+            if (ok) {
+                if (o == 0) sc[((size_t) i * H + head) * ld_sc + j] = dot;
+                lmax = fmaxf(lmax, dot);
             }
         }
-        sc[((size_t) i * H + head) * ld_sc + j] = dot;
-        lmax = fmaxf(lmax, dot);
     }
     for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
     if (lane == 0) red[wave] = lmax;
@@ -453,6 +476,19 @@ __global__ __launch_bounds__(256) void k_xattn_pv(const __half * __restrict__ vc
     const int slice = blockIdx.x, head = blockIdx.y, i = blockIdx.z, H = gridDim.y;
     const size_t row = (size_t) i * H + head;
     vc += (int64_t) i * kv_row_stride;
+    const int j0 = slice * ks;
+    const int cnt = max(0, min(ks, T - j0));
+    // e.V: lane = (key sub-index, 16-byte chunk of the 64-wide head slice); 8 keys per wave instruction.  The value rows of this
+    // lane (every 32nd key of the slice; at most 8 for slices of <= 256 keys) do not depend on the scores: requested first,
+    // unconditionally from a clamped row (as `t < cnt ? load : 0` hipcc split them into three dependent groups)
+    const int kg = lane >> 3, ch = lane & 7;
+    uint4 vu[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+        const int t = wave * 8 + kg + 32 * it;
+        const int jr = min(j0 + (t < cnt ? t : 0), T - 1);
+        vu[it] = *(const uint4 *) (vc + (size_t) jr * S + head * 64 + ch * 8);
+    }
     float m = -INFINITY;
     if (ns == 8) {                                  // all loads first (a loop makes them eight dependent round trips)
         float pm[8];
@@ -463,8 +499,6 @@ __global__ __launch_bounds__(256) void k_xattn_pv(const __half * __restrict__ vc
     } else {
         for (int s2 = 0; s2 < ns; ++s2) m = fmaxf(m, pmax[row * ns + s2]);
     }
-    const int j0 = slice * ks;
-    const int cnt = max(0, min(ks, T - j0));
     float lsum = 0.0f;
     for (int t = tid; t < cnt; t += 256) {
         const float v = exp16(sc[row * ld_sc + j0 + t] - m);
@@ -472,19 +506,10 @@ __global__ __launch_bounds__(256) void k_xattn_pv(const __half * __restrict__ vc
     }
     for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
     __syncthreads();
-    // e.V: lane = (key sub-index, 16-byte chunk of the 64-wide head slice); 8 keys per wave instruction
-    const int kg = lane >> 3, ch = lane & 7;
     float acc[8];
 #pragma unroll
     for (int d = 0; d < 8; ++d) acc[d] = 0.0f;
-    // value rows of this lane (every 32nd key of the slice), requested together: at most 8 for slices of <= 256 keys
     if (cnt <= 256) {
-        uint4 vu[8];
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int t = wave * 8 + kg + 32 * it;
-            vu[it] = t < cnt ? *(const uint4 *) (vc + (size_t) (j0 + t) * S + head * 64 + ch * 8) : make_uint4(0u, 0u, 0u, 0u);
-        }
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int t = wave * 8 + kg + 32 * it;

@@ -50,19 +50,24 @@ __global__ __launch_bounds__(NT) void k_filter_stats(const float * __restrict__ 
 
     constexpr int MAXE = 4;                            // ceil(51866 / 64 / 256)
     float lv[MAXE]; bool ok[MAXE];
+    // the static mask and the logits of all MAXE elements first, from clamped indices (element by element this was
+    // mask -> wait -> logit -> wait: eight dependent round trips per thread)
+    unsigned char bn[MAXE]; float lraw[MAXE];
+#pragma unroll
+    for (int e = 0; e < MAXE; ++e) { const int i = i0 + e * NT + tid, ic = i < i1 ? i : i0; bn[e] = ban[ic]; lraw[e] = logits[ic]; }
     MaxIdx m_all = {-INFINITY, 0x7fffffff}, m_txt = m_all, m_ts = m_all;
 #pragma unroll
     for (int e = 0; e < MAXE; ++e) {
         const int i = i0 + e * NT + tid;
         ok[e] = false; lv[e] = -INFINITY;
         if (i < i1) {
-            bool a = !ban[i];
+            bool a = !bn[e];
             if (ban_blank && (i == st.eot || i == st.space_id)) a = false;
             if (last_ts) { if (pen_ts) { if (i >= beg) a = false; } else { if (i < st.eot) a = false; } }
             if (i >= st.ts_initial_start) a = false;
             if (i >= beg && i < st.ts_floor_end) a = false;
             if (a) {
-                ok[e] = true; lv[e] = logits[i];
+                ok[e] = true; lv[e] = lraw[e];
                 const MaxIdx c = {lv[e], i};
                 m_all = better(m_all, c);
                 if (i < beg) m_txt = better(m_txt, c); else m_ts = better(m_ts, c);

@@ -233,7 +233,9 @@ def test_print_realtime_output_equals_the_reference(product_lib, capfd):
             assert L.whisper_full(node.ctx, p, _fp(pcm), pcm.size) == 0
             libc.fflush(None)
             outs.append(capfd.readouterr().out)
-            toks.append([t[0] for s in _ctx_segments(L, node.ctx) for t in s[3]])
+            # (id, tid): segment times are printed from tid, the most probable timestamp at that step (W/whisper.cpp:5715-5716) —
+            # an arg-max of its own, with its own near-ties
+            toks.append([(t[0], t[1]) for s in _ctx_segments(L, node.ctx) for t in s[3]])
             node.close()
     for k in (0, 2):
         assert outs[k].strip(), outs
