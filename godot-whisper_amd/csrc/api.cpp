@@ -505,6 +505,7 @@ double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters) {
         return (double) ms * 1000.0 / iters;
     }
     if (which == 20) { (void) hipEventDestroy(e0); (void) hipEventDestroy(e1); return bench_greedy_step_chain(*ctx, iters); }
+    if (which >= 21 && which <= 36) { (void) hipEventDestroy(e0); (void) hipEventDestroy(e1); return bench_rows_step_chain(*ctx, which - 20, iters); }   // 20 + rows
     if (which == 3) {
         if (d.mel == nullptr) return -1.0;
         const int saved = st.exp_n_audio_ctx;

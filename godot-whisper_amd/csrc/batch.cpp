@@ -197,9 +197,13 @@ bool encode_rows(whisper_context & ctx, const std::vector<int> & rows, const std
 
 // ---------------------------------------------------------------------------------------------- batched greedy step
 // step records are already in b.step_host[0..nb); results land in b.sample_host[0..nb)
-bool decode_rows_step(whisper_context & ctx, int nb) {
+// probe only (bench kernel 21): which kernel kinds of the lock-step step are enqueued — bit 0 embed, 1 qkv, 2 self-attention rows,
+// 3 out, 4 cross scores + P.V, 5 combine, 6 cross out, 7 mlp.0, 8 mlp.2, 9 logits, 10 filters
+static unsigned g_rows_mask = ~0u;
+
+static void enqueue_rows_step(whisper_context & ctx, int nb) {
     BatchWork & b = *ctx.batch; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
-    const int64_t t0 = time_us();
+    const unsigned M = g_rows_mask;
     const int S = hp.n_text_state, H = hp.n_text_head, Lt = hp.n_text_layer, NV = hp.n_vocab, n_ctx = hp.n_text_ctx;
     const int Tc = b.enc_T;
     hipStream_t s = ctx.state->dev.stream;
@@ -209,7 +213,7 @@ bool decode_rows_step(whisper_context & ctx, int nb) {
     const int64_t cache_stride = (int64_t) Lt * n_ctx * S;             // between the chunks' self caches
     const int64_t cross_layer = (int64_t) b.enc_rows * Tc * S;
 
-    k::dec_embed_step((const k::DecStep *) b.step_host, (k::DecStep *) b.step_dev, S, w.d_te, w.d_pe, b.dx, s, nb);
+    if (M & 1) k::dec_embed_step((const k::DecStep *) b.step_host, (k::DecStep *) b.step_dev, S, w.d_te, w.d_pe, b.dx, s, nb);
     auto base = [&](int K, int N, const __half * W, const float * bias, int epi, void * C, int ldc) {
         k::GemvArgs g{};
         g.n = nb; g.K = K; g.N = N; g.W = W; g.bias = bias; g.epi = epi; g.C = C; g.ldc = ldc; g.ldr = S; g.S = S; g.eps = hp.eps;
@@ -223,18 +227,19 @@ bool decode_rows_step(whisper_context & ctx, int nb) {
             k::GemvArgs g = base(S, 3 * S, l.w_qkv, l.b_qkv, k::EPI_QKV_DEC, b.dq, S);
             g.x32 = b.dx; g.ln_g = l.ln1_g; g.ln_b = l.ln1_b; g.aux = ck; g.ldaux = S; g.aux2 = cv; g.ldaux2 = S; g.scale = kq_scale;
             g.row_off = &stp->kv_head;
-            k::gemv(g, s);
+            if (M & 2) k::gemv(g, s);
         }
         {   // self-attention, one workgroup per chunk row (same arithmetic as the single-row fused prologue), then
             // out projection + residual
-            k::self_attn_rows(b.dq, nb, S, ck, cv, cache_stride, &stp->n_kv, step_stride, n_ctx, b.datt, s);
+            if (M & 4) k::self_attn_rows(b.dq, nb, S, ck, cv, cache_stride, &stp->n_kv, step_stride, n_ctx, b.datt, s);
             k::GemvArgs g = base(S, S, l.w_o, l.b_o, k::EPI_F32_BIAS_RESID, b.dx, S);
             g.a16 = b.datt; g.resid = b.dx;
-            k::gemv(g, s);
+            if (M & 8) k::gemv(g, s);
         }
         {   // LN2 + cross query (folded into the score kernel) + cross-attention partials over each row's own chunk
             const float * po = nullptr, * pl = nullptr; int ns = 0;
-            if (S > 512) {                                  // wide models: separate projection launch (see device.cpp)
+            if (!(M & 16)) k::attn_cross_partials_layout(nb, H, Tc, b.xattn, &po, &pl, &ns);
+            else if (S > 512) {                             // wide models: separate projection launch (see device.cpp)
                 k::GemvArgs g = base(S, S, l.w_cq, l.b_cq, k::EPI_Q_SCALED, b.dq, S);
                 g.x32 = b.dx; g.ln_g = l.ln2_g; g.ln_b = l.ln2_b; g.scale = kq_scale;
                 k::gemv(g, s);
@@ -244,29 +249,36 @@ bool decode_rows_step(whisper_context & ctx, int nb) {
             k::attn_cross_qsplit_partials(b.dx, l.ln2_g, l.ln2_b, hp.eps, l.w_cq, l.b_cq, kq_scale, nb, S, H,
                                           b.kvc_k + (size_t) il * cross_layer, b.kvc_v + (size_t) il * cross_layer, Tc,
                                           b.xattn, &po, &pl, &ns, s, (int64_t) Tc * S);
-            k::attn_cross_combine(po, pl, ns, nb, S, H, b.datt, s);
+            if (M & 32) k::attn_cross_combine(po, pl, ns, nb, S, H, b.datt, s);
             k::GemvArgs g = base(S, S, l.w_co, l.b_co, k::EPI_F32_BIAS_RESID, b.dx, S);
             g.a16 = b.datt; g.resid = b.dx;
-            k::gemv(g, s);
+            if (M & 64) k::gemv(g, s);
         }
         {
             k::GemvArgs g = base(S, 4 * S, l.w_fc1, l.b_fc1, k::EPI_F16_BIAS_GELU, b.dh, 4 * S);
             g.x32 = b.dx; g.ln_g = l.ln3_g; g.ln_b = l.ln3_b;
-            k::gemv(g, s);
+            if (M & 128) k::gemv(g, s);
         }
         {
             k::GemvArgs g = base(4 * S, S, l.w_fc2, l.b_fc2, k::EPI_F32_BIAS_RESID, b.dx, S);
             g.a16 = b.dh; g.resid = b.dx;
-            k::gemv(g, s);
+            if (M & 256) k::gemv(g, s);
         }
     }
     {
         k::GemvArgs g = base(S, NV, w.d_te, nullptr, k::EPI_LOGITS, b.logits, NV);
         g.x32 = b.dx; g.ln_g = w.d_ln_g; g.ln_b = w.d_ln_b;
-        k::gemv(g, s);
+        if (M & 512) k::gemv(g, s);
     }
-    k::filter_argmax(b.logits, ctx.state->dev.ban_dev, stp, (k::SampleOut *) b.sample_dev, b.filter_scratch, s,
-                     (k::SampleOut *) b.sample_host, nb);
+    if (M & 1024) k::filter_argmax(b.logits, ctx.state->dev.ban_dev, stp, (k::SampleOut *) b.sample_dev, b.filter_scratch, s,
+                                   (k::SampleOut *) b.sample_host, nb);
+}
+
+bool decode_rows_step(whisper_context & ctx, int nb) {
+    BatchWork & b = *ctx.batch;
+    const int64_t t0 = time_us();
+    hipStream_t s = ctx.state->dev.stream;
+    enqueue_rows_step(ctx, nb);
     {   // every row's result carries the step's sequence number (set by the caller in the step records)
         const k::DecStep * hs = (const k::DecStep *) b.step_host;
         const k::SampleOut * so = (const k::SampleOut *) b.sample_host;
@@ -289,6 +301,26 @@ struct Row {
 };
 
 } // namespace
+
+// probe: the kernels of a lock-step step for nb rows, `iters` times back to back with no host round trip; microseconds per step
+double bench_rows_step_chain(whisper_context & ctx, int nb, int iters) {
+    if (!ctx.batch || ctx.batch->B < nb || !ctx.batch->step_dev || iters <= 0) return -1.0;
+    const char * mask_env = getenv("WMI_STEP_MASK");
+    g_rows_mask = mask_env ? (unsigned) strtoul(mask_env, nullptr, 0) : ~0u;
+    hipStream_t s = ctx.state->dev.stream;
+    hipEvent_t e0, e1;
+    if (!HIP_OK(hipEventCreate(&e0)) || !HIP_OK(hipEventCreate(&e1))) return -1.0;
+    for (int i = 0; i < 3; ++i) enqueue_rows_step(ctx, nb);
+    (void) hipStreamSynchronize(s);
+    (void) hipEventRecord(e0, s);
+    for (int i = 0; i < iters; ++i) enqueue_rows_step(ctx, nb);
+    (void) hipEventRecord(e1, s);
+    (void) hipEventSynchronize(e1);
+    float ms = 0.0f; (void) hipEventElapsedTime(&ms, e0, e1);
+    (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+    g_rows_mask = ~0u;
+    return (double) ms * 1000.0 / iters;
+}
 
 void free_batch(whisper_context & ctx) {
     if (!ctx.batch) return;

@@ -13,6 +13,7 @@
 //   * f32 accumulation, 64-lane butterfly reduction, then the same fused epilogues as the big GEMM.
 
 #include "kernels.h"
+#include <type_traits>
 
 #include <cstdlib>
 
@@ -307,25 +308,25 @@ __global__ __launch_bounds__(64) void k_self_attn_rows(const __half * __restrict
 // LayerNorm of one row by one wavefront, lane L holding the slices x[512 t + 8 L .. + 8) (the slices its dot products
 // need).  y = f16((x - mean) * rstd * g + b) as separate mul / add (SURVEY App. B rule 6); sums in f32: per lane over
 // (t, e) in order, then the 64-lane butterfly.  MAXCH chunks of 512 columns; av[t][e] = 0 outside the row.
+// the loads of ln_row_regs: MAXCH chunks of one f32 vector (x, gain or bias), zeros outside the row
 template <int MAXCH>
-__device__ __forceinline__ void ln_row_regs(const float * __restrict__ xr, const float * __restrict__ g, const float * __restrict__ b,
-                                            int K, float eps, int lane, float (&av)[MAXCH][8]) {
-    float xv[MAXCH][8], gv[MAXCH][8], bv[MAXCH][8];
+__device__ __forceinline__ void ln_row_load(const float * __restrict__ p, int K, int lane, float (&v)[MAXCH][8]) {
 #pragma unroll
     for (int t = 0; t < MAXCH; ++t) {
         const int c = lane * 8 + 512 * t;
         if (c < K) {
-            const float4 x0 = *(const float4 *) (xr + c), x1 = *(const float4 *) (xr + c + 4);
-            const float4 g0 = *(const float4 *) (g + c),  g1 = *(const float4 *) (g + c + 4);
-            const float4 b0 = *(const float4 *) (b + c),  b1 = *(const float4 *) (b + c + 4);
-            xv[t][0] = x0.x; xv[t][1] = x0.y; xv[t][2] = x0.z; xv[t][3] = x0.w; xv[t][4] = x1.x; xv[t][5] = x1.y; xv[t][6] = x1.z; xv[t][7] = x1.w;
-            gv[t][0] = g0.x; gv[t][1] = g0.y; gv[t][2] = g0.z; gv[t][3] = g0.w; gv[t][4] = g1.x; gv[t][5] = g1.y; gv[t][6] = g1.z; gv[t][7] = g1.w;
-            bv[t][0] = b0.x; bv[t][1] = b0.y; bv[t][2] = b0.z; bv[t][3] = b0.w; bv[t][4] = b1.x; bv[t][5] = b1.y; bv[t][6] = b1.z; bv[t][7] = b1.w;
+            const float4 x0 = *(const float4 *) (p + c), x1 = *(const float4 *) (p + c + 4);
+            v[t][0] = x0.x; v[t][1] = x0.y; v[t][2] = x0.z; v[t][3] = x0.w; v[t][4] = x1.x; v[t][5] = x1.y; v[t][6] = x1.z; v[t][7] = x1.w;
         } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { xv[t][e] = 0.0f; gv[t][e] = 0.0f; bv[t][e] = 0.0f; }
+            for (int e = 0; e < 8; ++e) v[t][e] = 0.0f;
         }
     }
+}
+// the arithmetic of ln_row_regs on loaded values (xv is consumed)
+template <int MAXCH>
+__device__ __forceinline__ void ln_row_compute(float (&xv)[MAXCH][8], const float (&gv)[MAXCH][8], const float (&bv)[MAXCH][8],
+                                               int K, float eps, int lane, float (&av)[MAXCH][8]) {
     float sum = 0.0f;
 #pragma unroll
     for (int t = 0; t < MAXCH; ++t)
@@ -348,6 +349,15 @@ __device__ __forceinline__ void ln_row_regs(const float * __restrict__ xr, const
 #pragma unroll
         for (int e = 0; e < 8; ++e) av[t][e] = on ? round_f16(__fadd_rn(__fmul_rn(xv[t][e] * sc, gv[t][e]), bv[t][e])) : 0.0f;
     }
+}
+template <int MAXCH>
+__device__ __forceinline__ void ln_row_regs(const float * __restrict__ xr, const float * __restrict__ g, const float * __restrict__ b,
+                                            int K, float eps, int lane, float (&av)[MAXCH][8]) {
+    float xv[MAXCH][8], gv[MAXCH][8], bv[MAXCH][8];
+    ln_row_load<MAXCH>(xr, K, lane, xv);
+    ln_row_load<MAXCH>(g, K, lane, gv);
+    ln_row_load<MAXCH>(b, K, lane, bv);
+    ln_row_compute<MAXCH>(xv, gv, bv, K, eps, lane, av);
 }
 
 template <bool NT> __device__ __forceinline__ uint4 ldw(const __half * p) {
@@ -821,28 +831,73 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
 
     // ---- prologue: activation rows as f16 in LDS
     if (a.ln_g) {                                           // K <= 1536; same arithmetic as k_gemv / k_gemv1 (ln_row_regs)
-        for (int r = wave; r < n; r += 4) {
-            const int src = a.rows ? a.rows[r] : r;
-            float av[3][8];
-            ln_row_regs<3>(a.x32 + (size_t) src * K, a.ln_g, a.ln_b, K, a.eps, lane, av);
+        // rows wave, wave + 4, ... of this wavefront: the x vectors of all of them and gain / bias go out together — row after
+        // row, each LayerNorm waited for its own loads.  Two instantiations so that n <= 8 does not issue loads for rows it lacks.
+        auto ln_rows = [&](auto rw_tag) {
+            constexpr int RW = decltype(rw_tag)::value;
+            float xv[RW][3][8], gv[3][8], bv[3][8];
+            int src[RW];
 #pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const int c = lane * 8 + 512 * t;
-                if (c < K) {
-                    __half2 h[4];
+            for (int q = 0; q < RW; ++q) { const int r = wave + 4 * q, rc = r < n ? r : (n - 1); src[q] = a.rows ? a.rows[rc] : rc; }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) h[e] = __floats2half2_rn(av[t][2 * e], av[t][2 * e + 1]);
-                    *(uint4 *) (act + r * lda + c) = *(const uint4 *) h;
+            for (int q = 0; q < RW; ++q) ln_row_load<3>(a.x32 + (size_t) src[q] * K, K, lane, xv[q]);
+            ln_row_load<3>(a.ln_g, K, lane, gv);
+            ln_row_load<3>(a.ln_b, K, lane, bv);
+            __builtin_amdgcn_sched_barrier(0);              // keep the loads together: the scheduler sinks each to its first use
+#pragma unroll
+            for (int q = 0; q < RW; ++q) {
+                const int r = wave + 4 * q;
+                if (r < n) {
+                    float av[3][8];
+                    ln_row_compute<3>(xv[q], gv, bv, K, a.eps, lane, av);
+#pragma unroll
+                    for (int t = 0; t < 3; ++t) {
+                        const int c = lane * 8 + 512 * t;
+                        if (c < K) {
+                            __half2 h[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) h[e] = __floats2half2_rn(av[t][2 * e], av[t][2 * e + 1]);
+                            *(uint4 *) (act + r * lda + c) = *(const uint4 *) h;
+                        }
+                    }
                 }
             }
-        }
+        };
+        if (n <= 4) ln_rows(std::integral_constant<int, 1>{});
+        else if (n <= 8) ln_rows(std::integral_constant<int, 2>{});
+        else ln_rows(std::integral_constant<int, 4>{});
     } else {
-        for (int r = 0; r < n; ++r) {
-            const int src = a.rows ? a.rows[r] : r;
-            const uint4 * s4 = (const uint4 *) (a.a16 + (size_t) src * K);
-            uint4 * d4 = (uint4 *) (act + r * lda);
-            for (int c = tid; c < K / 8; c += 256) d4[c] = s4[c];
-        }
+        // n rows of K / 8 16-byte pieces, flattened over the workgroup; the loads of a group of pieces before their LDS stores
+        // (as a row-by-row copy loop this was one dependent round trip per row); group size by the amount of work
+        const int cpr = K >> 3, total = n * cpr;
+        auto copy_rows = [&](auto cp_tag) {
+            constexpr int CP = decltype(cp_tag)::value;
+            for (int e0 = 0; e0 < total; e0 += 256 * CP) {
+                uint4 tmp[CP];
+                int src[CP];
+#pragma unroll
+                for (int q = 0; q < CP; ++q) {
+                    const int e = e0 + tid + 256 * q, ec = e < total ? e : 0;
+                    const int r = ec / cpr;
+                    src[q] = a.rows ? a.rows[r] : r;
+                }
+#pragma unroll
+                for (int q = 0; q < CP; ++q) {
+                    const int e = e0 + tid + 256 * q, ec = e < total ? e : 0;
+                    const int r = ec / cpr, c = ec - r * cpr;
+                    tmp[q] = ((const uint4 *) (a.a16 + (size_t) src[q] * K))[c];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < CP; ++q) {
+                    const int e = e0 + tid + 256 * q;
+                    if (e < total) { const int r = e / cpr, c = e - r * cpr; ((uint4 *) (act + r * lda))[c] = tmp[q]; }
+                }
+            }
+        };
+        if (total <= 512) copy_rows(std::integral_constant<int, 2>{});
+        else if (total <= 1024) copy_rows(std::integral_constant<int, 4>{});
+        else copy_rows(std::integral_constant<int, 8>{});
     }
     __syncthreads();
 

@@ -283,6 +283,7 @@ bool upload_static_ban(whisper_context & ctx, const whisper_full_params & params
 bool wait_for_seq(const volatile int32_t * seq, int32_t want, hipStream_t s);   // spin on a pinned sequence number (device.cpp)
 bool fast_path_enabled();
 double bench_greedy_step_chain(whisper_context & ctx, int iters);
+double bench_rows_step_chain(whisper_context & ctx, int nb, int iters);
 // |x| envelope of the last PCM on the GPU; the D2H copy runs on a side stream while the encoder works.
 // sync = false: state.energy is valid only after signal_energy_wait()
 bool signal_energy_device(whisper_context & ctx, int hw, bool sync = true);
