@@ -100,16 +100,41 @@ __global__ __launch_bounds__(MEL_NT) void k_mel_frames(const float * __restrict_
 
     const int offset = frame * 160;
     int nin = n_valid - offset; if (nin > 400) nin = 400;
-    for (int j = tid; j < 400; j += MEL_NT) xin[j] = j < nin ? c_mel.hann[j] * pad[offset + j] : 0.0f;
-    for (int j = tid; j < 400; j += MEL_NT) {
-        if (j < 25)       { tw25[j] = make_float2(c_mel.cosv[16 * j], c_mel.sinv[16 * j]); tw50[j] = make_float2(c_mel.cosv[8 * j], c_mel.sinv[8 * j]); }
-        if (j < 50)       tw100[j] = make_float2(c_mel.cosv[4 * j], c_mel.sinv[4 * j]);
-        if (j < 100)      tw200[j] = make_float2(c_mel.cosv[2 * j], c_mel.sinv[2 * j]);
-        if (j < 200)      tw400[j] = make_float2(c_mel.cosv[j], c_mel.sinv[j]);
+    {   // samples, window and twiddles: every load of the thread first, from clamped indices, then the LDS stores (in source
+        // order hipcc waited after each table: five dependent round trips at the start of every frame)
+        static_assert(MEL_NT == 256, "two samples per thread");
+        const int j0 = tid, j1 = tid + 256;                         // j1 < 400 for tid < 144
+        const int j1c = j1 < 400 ? j1 : 0, jt = tid < 200 ? tid : 0, j25 = tid < 25 ? tid : 0, j50 = tid < 50 ? tid : 0, j100 = tid < 100 ? tid : 0;
+        const float h0 = c_mel.hann[j0], h1 = c_mel.hann[j1c];
+        const float p0 = pad[offset + (j0 < nin ? j0 : 0)], p1 = pad[offset + (j1c < nin ? j1c : 0)];
+        const float2 w25 = make_float2(c_mel.cosv[16 * j25], c_mel.sinv[16 * j25]), w50 = make_float2(c_mel.cosv[8 * j25], c_mel.sinv[8 * j25]);
+        const float2 w100 = make_float2(c_mel.cosv[4 * j50], c_mel.sinv[4 * j50]);
+        const float2 w200 = make_float2(c_mel.cosv[2 * j100], c_mel.sinv[2 * j100]);
+        const float2 w400 = make_float2(c_mel.cosv[jt], c_mel.sinv[jt]);
+        xin[j0] = j0 < nin ? h0 * p0 : 0.0f;
+        if (j1 < 400) xin[j1] = j1 < nin ? h1 * p1 : 0.0f;
+        if (tid < 25)  { tw25[tid] = w25; tw50[tid] = w50; }
+        if (tid < 50)  tw100[tid] = w100;
+        if (tid < 100) tw200[tid] = w200;
+        if (tid < 200) tw400[tid] = w400;
     }
     // filter rows of this thread's mel bin(s): independent of the transform, requested up front
     int fr0 = 0, fr1 = 0;
     if (tid < n_mel) { fr0 = ranges[2 * tid]; fr1 = ranges[2 * tid + 1]; }
+    // ... and the non-zero taps of that bin themselves (FW groups of 4 cover the widest triangle of the 80- and 128-bin
+    // banks; wider ranges finish from memory below): in flight during the transform instead of one round trip per group after it
+    constexpr int FW = 12;
+    float fw[FW][4], f200 = 0.0f;
+    if (tid < n_mel) {
+        const float * f = filters + (size_t) tid * 201;
+#pragma unroll
+        for (int q = 0; q < FW; ++q) {
+            const int g4 = fr0 + q < 50 ? fr0 + q : 49;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) fw[q][e] = f[4 * g4 + e];
+        }
+        f200 = f[200];
+    }
     __syncthreads();
 
     // 16 leaf DFTs of 25 points: leaf r holds x[r + 16 m]  (W/whisper.cpp:2634-2654)
@@ -149,7 +174,20 @@ __global__ __launch_bounds__(MEL_NT) void k_mel_frames(const float * __restrict_
         double sum = 0.0;
         // W/whisper.cpp:2759-2768 sums 50 groups of 4 taps + the last tap; groups outside [fr0, fr1) are all-zero
         // weights and contribute exactly +0.0 (model.cpp: mel_ranges), so they are skipped
-        for (int g4 = fr0; g4 < fr1; ++g4) {
+        if (j == tid) {
+#pragma unroll
+            for (int q = 0; q < FW; ++q) {
+                if (fr0 + q < fr1) {
+                    const int kk = 4 * (fr0 + q);
+                    float g = pw[kk] * fw[q][0];
+                    g = fmaf(pw[kk + 1], fw[q][1], g);
+                    g = fmaf(pw[kk + 2], fw[q][2], g);
+                    g = fmaf(pw[kk + 3], fw[q][3], g);
+                    sum += (double) g;
+                }
+            }
+        }
+        for (int g4 = (j == tid ? fr0 + FW : fr0); g4 < fr1; ++g4) {
             const int kk = 4 * g4;
             float g = pw[kk] * f[kk];
             g = fmaf(pw[kk + 1], f[kk + 1], g);
@@ -157,7 +195,7 @@ __global__ __launch_bounds__(MEL_NT) void k_mel_frames(const float * __restrict_
             g = fmaf(pw[kk + 3], f[kk + 3], g);
             sum += (double) g;
         }
-        sum += (double) (pw[200] * f[200]);
+        sum += (double) (pw[200] * (j == tid ? f200 : f[200]));
         sum = log10(sum > 1e-10 ? sum : 1e-10);
         const float v = (float) sum;
         mel[(size_t) j * n_len + frame] = v;

@@ -19,12 +19,19 @@ __global__ __launch_bounds__(256) void k_layernorm(const float * __restrict__ x,
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float * xr = x + (size_t) row * S;
-    float4 v[MAXV];
+    // all loads of the row (x, gain, bias) first, from clamped columns: with the load inside the summation loop hipcc waited
+    // for every 16 bytes before requesting the next (MAXV + 2 MAXV dependent round trips per row)
+    float4 v[MAXV], gg[MAXV], bb[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4, cc = c < S ? c : 0;
+        v[i] = *(const float4 *) (xr + cc); gg[i] = *(const float4 *) (g + cc); bb[i] = *(const float4 *) (b + cc);
+    }
     float sum = 0.0f;
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
         const int c = (i * 64 + lane) * 4;
-        if (c < S) { v[i] = *(const float4 *) (xr + c); sum += (v[i].x + v[i].y) + (v[i].z + v[i].w); }
+        if (c < S) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
@@ -44,12 +51,11 @@ __global__ __launch_bounds__(256) void k_layernorm(const float * __restrict__ x,
     for (int i = 0; i < MAXV; ++i) {
         const int c = (i * 64 + lane) * 4;
         if (c < S) {
-            const float4 gg = *(const float4 *) (g + c), bb = *(const float4 *) (b + c);
             float4 y;
-            y.x = __fadd_rn(__fmul_rn(v[i].x * scale, gg.x), bb.x);
-            y.y = __fadd_rn(__fmul_rn(v[i].y * scale, gg.y), bb.y);
-            y.z = __fadd_rn(__fmul_rn(v[i].z * scale, gg.z), bb.z);
-            y.w = __fadd_rn(__fmul_rn(v[i].w * scale, gg.w), bb.w);
+            y.x = __fadd_rn(__fmul_rn(v[i].x * scale, gg[i].x), bb[i].x);
+            y.y = __fadd_rn(__fmul_rn(v[i].y * scale, gg[i].y), bb[i].y);
+            y.z = __fadd_rn(__fmul_rn(v[i].z * scale, gg[i].z), bb[i].z);
+            y.w = __fadd_rn(__fmul_rn(v[i].w * scale, gg[i].w), bb[i].w);
             if (out32) *(float4 *) (out32 + (size_t) row * S + c) = y;
             if (out16) {
                 __half2 h01 = __floats2half2_rn(pin_f32(y.x), pin_f32(y.y)), h23 = __floats2half2_rn(pin_f32(y.z), pin_f32(y.w));
