@@ -207,6 +207,18 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
             const int n = nb + j * 16 + frow;
             if (GUARD && n >= a.N) continue;
             const float bias = biasv[j];
+            // residual / positional operand of this fragment column: all FM x 4 values requested before the first store (the output
+            // is updated in place, so element by element every load had to wait for the previous store: one round trip per element)
+            float rpre[FM][4];
+            if constexpr (EPI == EPI_F32_BIAS_RESID || EPI == EPI_CONV2) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = mb + i * 16 + fq * 4 + r;
+                        rpre[i][r] = a.resid[(size_t) ((GUARD && m >= a.M) ? a.M - 1 : m) * a.ldr + n];
+                    }
+            }
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int mrow = mb + i * 16 + fq * 4;
@@ -252,11 +264,11 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
                     } else if constexpr (EPI == EPI_F16_BIAS_GELU) {
                         ((__half *) a.C)[(size_t) m * a.ldc + n] = f2h(gelu16_fast(v + bias));
                     } else if constexpr (EPI == EPI_F32_BIAS_RESID) {
-                        ((float *) a.C)[(size_t) m * a.ldc + n] = (v + bias) + a.resid[(size_t) m * a.ldr + n];
+                        ((float *) a.C)[(size_t) m * a.ldc + n] = (v + bias) + rpre[i][r];
                     } else if constexpr (EPI == EPI_CONV2) {
                         const float g = gelu16_fast(v + bias);
                         if (a.aux) ((float *) a.aux)[(size_t) m * a.ldaux + n] = g;
-                        ((float *) a.C)[(size_t) m * a.ldc + n] = a.resid[(size_t) m * a.ldr + n] + g;
+                        ((float *) a.C)[(size_t) m * a.ldc + n] = rpre[i][r] + g;
                     } else if constexpr (EPI == EPI_QKV_DEC) {
                         // The q | k | v segment is decided per 16-column fragment on a WAVE-UNIFORM value
                         // (S is a multiple of 16, so a fragment never straddles a segment).  A per-lane
