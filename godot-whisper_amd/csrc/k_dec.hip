@@ -62,12 +62,11 @@ __global__ void k_dec_embed_step(const DecStep * __restrict__ host_step, DecStep
 //   scores   lane = (key group g = lane / 8, dimension octet o = lane % 8); pass t covers keys 8 t + g: one 16-byte load per
 //            lane and pass, 8 fmaf in dimension order, then the three-step butterfly over the octets of the key
 //   soft-max maximum and sum over passes (in pass order) and over the key groups (xor 8, 16, 32); f16 roundings of the reference
-//   P.V      lane = head column; probabilities moved to lane = key, key j broadcast with v_readlane;
-//            one fmaf chain per column in key order; V of the first SA_VG keys requested up front, later keys in groups
-// This fixes the summation order of the path (score: octet-wise then butterfly); every caller — the one-row prologue of
+//   P.V      same layout: lane (g, o) accumulates the 8 columns of its octet over its keys in pass order, then the butterfly
+//            over the key groups; the V rows of keys [0, 32) are requested up front like the K rows
+// This fixes the summation order of the path (octet-wise, then butterflies); every caller — the one-row prologue of
 // k_gemv1, the lock-step row kernels — goes through this routine, which keeps them bit-identical to each other.
 // Returns false, with nothing written, when n_kv > 64 (callers then take self_attn_row).
-constexpr int SA_VG = 16;
 template <int NU>
 __device__ __forceinline__ bool self_attn_wave(const __half * __restrict__ sq, const __half * __restrict__ sk,
                                                const __half * __restrict__ sv, const int32_t * __restrict__ n_kv_p, int K, int cap,
@@ -76,8 +75,7 @@ __device__ __forceinline__ bool self_attn_wave(const __half * __restrict__ sq, c
     int hh[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) hh[u] = hs[u] < H ? hs[u] : hs[0];
-    uint4 qv[NU], kv[NU][8];
-    __half vv[NU][SA_VG];
+    uint4 qv[NU], kv[NU][8], vv[NU][8];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
         qv[u] = *(const uint4 *) (sq + hh[u] * 64 + o * 8);
@@ -90,7 +88,10 @@ __device__ __forceinline__ bool self_attn_wave(const __half * __restrict__ sq, c
 #pragma unroll
     for (int u = 0; u < NU; ++u)
 #pragma unroll
-        for (int t = 0; t < SA_VG; ++t) vv[u][t] = sv[(size_t) (t < cap ? t : 0) * K + hh[u] * 64 + lane];
+        for (int t = 0; t < 4; ++t) {
+            const int j = 8 * t + g;
+            vv[u][t] = *(const uint4 *) (sv + (size_t) (j < cap ? j : 0) * K + hh[u] * 64 + o * 8);
+        }
     const int n_kv = *n_kv_p;
     if (n_kv > 64) return false;
     if (n_kv > 32) {
@@ -98,8 +99,9 @@ __device__ __forceinline__ bool self_attn_wave(const __half * __restrict__ sq, c
         for (int u = 0; u < NU; ++u)
 #pragma unroll
             for (int t = 4; t < 8; ++t) {
-                const int j = 8 * t + g;
-                kv[u][t] = *(const uint4 *) (sk + (size_t) (j < n_kv ? j : 0) * K + hh[u] * 64 + o * 8);
+                const int j = 8 * t + g, jc = j < n_kv ? j : 0;
+                kv[u][t] = *(const uint4 *) (sk + (size_t) jc * K + hh[u] * 64 + o * 8);
+                vv[u][t] = *(const uint4 *) (sv + (size_t) jc * K + hh[u] * 64 + o * 8);
             }
     }
     const int n_pass = n_kv > 32 ? 8 : 4;
@@ -143,41 +145,35 @@ __device__ __forceinline__ bool self_attn_wave(const __half * __restrict__ sq, c
         for (int t = 0; t < 8; ++t) p[u][t] = round_f16(p[u][t] * inv);
     }
 
-    // probabilities to lane = key order (key j of pass j / 8 sits on the lanes of group j % 8): the P.V loop below then stays
-    // a short rolled loop with a scalar lane index (fully unrolled it was 128 predicated steps of cold code per launch)
-    float pk[NU];
+    // P.V in the same lane layout: lane (g, o) accumulates the 8 columns of octet o over its keys 8 t + g (pass order), then the
+    // key groups are summed with the butterfly xor 8, 16, 32; lanes of group 0 store the octet.  No broadcast chain, no transpose.
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-        pk[u] = 0.0f;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
-            const float v = __shfl(p[u][t], (lane & 7) * 8);
-            if ((lane >> 3) == t) pk[u] = v;
-        }
-    }
-    float acc[NU];
+            if (t < n_pass && 8 * t + g < n_kv) {
+                const __half2 * vh = (const __half2 *) &vv[u][t];
+                const float w = p[u][t];
 #pragma unroll
-    for (int u = 0; u < NU; ++u) acc[u] = 0.0f;
-    for (int jg = 0; jg < n_kv; jg += SA_VG) {
-        if (jg > 0) {
-#pragma unroll
-            for (int u = 0; u < NU; ++u)
-#pragma unroll
-                for (int t = 0; t < SA_VG; ++t) vv[u][t] = sv[(size_t) (jg + t < n_kv ? jg + t : n_kv - 1) * K + hh[u] * 64 + lane];
-        }
-#pragma unroll
-        for (int t = 0; t < SA_VG; ++t) {
-            if (jg + t < n_kv) {                         // wave-uniform
-#pragma unroll
-                for (int u = 0; u < NU; ++u) {
-                    const float pj = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(pk[u]), jg + t));
-                    acc[u] = fmaf(pj, __half2float(vv[u][t]), acc[u]);
+                for (int e = 0; e < 4; ++e) {
+                    const float2 f = __half22float2(vh[e]);
+                    acc[2 * e]     = fmaf(w, f.x, acc[2 * e]);
+                    acc[2 * e + 1] = fmaf(w, f.y, acc[2 * e + 1]);
                 }
             }
         }
-    }
 #pragma unroll
-    for (int u = 0; u < NU; ++u) if (hs[u] < H) out[hs[u] * 64 + lane] = f2h(acc[u]);
+        for (int e = 0; e < 8; ++e) { float v = acc[e]; v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); acc[e] = v; }
+        if (g == 0 && hs[u] < H) {
+            __half2 h4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h4[e] = __halves2half2(f2h(acc[2 * e]), f2h(acc[2 * e + 1]));
+            *(uint4 *) (out + hs[u] * 64 + o * 8) = *(const uint4 *) h4;
+        }
+    }
     return true;
 }
 
