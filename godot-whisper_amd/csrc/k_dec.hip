@@ -565,8 +565,16 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
 // round trip + barrier on the critical path of a ~5 us kernel).  All NCH x RIF weight loads of a row tile are issued
 // together (K = 2048: 16 loads in flight per lane instead of four dependent rounds of four).  The fused attention
 // prologues (sa_*, comb_*) still stage through LDS, once.  K <= 512 NCH.
-template <int RIF, int NCH, bool NT>
+// PRO / EPI >= 0 fix the prologue kind (0 f16 row, 1 LayerNorm, 2 self-attention, 3 cross-attention combine) and the epilogue at
+// compile time: the decode step's six hot combinations get kernels without the other kinds' code and without the dispatch on
+// kernel arguments (a launch on the step's critical path pays for every instruction and scalar load in front of its first
+// memory request); -1 keeps the run-time dispatch.
+template <int RIF, int NCH, bool NT, int PRO = -1, int EPI = -1>
 __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
+    const bool pro_ln = PRO < 0 ? a.ln_g != nullptr : PRO == 1;
+    const bool pro_sa = PRO < 0 ? a.sa_q != nullptr : PRO == 2;
+    const bool pro_comb = PRO < 0 ? a.comb_o != nullptr : PRO == 3;
+    const int epi = EPI < 0 ? a.epi : EPI;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __half * act = (__half *) smem;                         // [K], attention prologues only
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -599,7 +607,7 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
 
     float av[NCH][8];
     const int src = a.rows ? a.rows[0] : 0;
-    if (a.ln_g) {
+    if (pro_ln) {
         // same instantiation as k_gemv<R>'s prologue: the lock-step VALU path must stay bit-identical to this kernel
         float av3[3][8];
         ln_row_regs<3>(a.x32 + (size_t) src * K, a.ln_g, a.ln_b, K, a.eps, lane, av3);
@@ -609,7 +617,7 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
             for (int e = 0; e < 8; ++e) av[t][e] = t < 3 ? av3[t < 3 ? t : 0][e] : 0.0f;
     } else {
         const __half * arow = a.a16 + (size_t) src * K;
-        if (a.sa_q) {
+        if (pro_sa) {
             const int H = K / 64;
             float * sc = (float *) (smem + (((size_t) K * sizeof(__half) + 15) & ~(size_t) 15));   // [H][sa_cap]
             float * qf = sc + (size_t) H * a.sa_cap;                                             // [K]
@@ -626,7 +634,7 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
             }
             __syncthreads();
             arow = act;
-        } else if (a.comb_o) {
+        } else if (pro_comb) {
             const int H = K / 64, ns = a.comb_ns;
             if (ns == 8) {
                 // T = 1500: the 2 x 16 loads of a thread's two elements go out before the first add (element by element this
@@ -732,7 +740,7 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
                 const bool pre = o0 == gw * RIF;
                 const float bias = pre ? bias_pre : (a.bias ? a.bias[n] : 0.0f);
                 const float resid = a.resid ? (pre ? resid_pre : a.resid[n]) : 0.0f;
-                switch (a.epi) {
+                switch (epi) {
                     case EPI_F16_BIAS:       ((__half *) a.C)[n] = f2h(v + bias); break;
                     case EPI_F16_BIAS_GELU:  ((__half *) a.C)[n] = f2h(gelu16(v + bias)); break;
                     case EPI_F32_BIAS_RESID: ((float *) a.C)[n] = (v + bias) + resid; break;
@@ -754,7 +762,7 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
     }
 }
 
-template <int RIF, int NCH, bool NT = false>
+template <int RIF, int NCH, bool NT = false, int PRO = -1, int EPI = -1>
 void launch_gemv1(const GemvArgs & a, hipStream_t st, int max_blocks = 512) {
     size_t smem = 0;
     if (a.sa_q)        smem = ((((size_t) a.K * sizeof(__half)) + 15) & ~(size_t) 15) + ((size_t) (a.K / 64) * a.sa_cap + a.K) * sizeof(float);
@@ -763,10 +771,29 @@ void launch_gemv1(const GemvArgs & a, hipStream_t st, int max_blocks = 512) {
     if (blocks > max_blocks) blocks = max_blocks;
     static size_t attr_bytes = 0;
     if (smem > 48 * 1024 && smem > attr_bytes) {
-        (void) hipFuncSetAttribute((const void *) k_gemv1<RIF, NCH, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+        (void) hipFuncSetAttribute((const void *) k_gemv1<RIF, NCH, NT, PRO, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
         attr_bytes = smem;
     }
-    hipLaunchKernelGGL((k_gemv1<RIF, NCH, NT>), dim3(blocks), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((k_gemv1<RIF, NCH, NT, PRO, EPI>), dim3(blocks), dim3(256), smem, st, a);
+}
+
+// the decode step's hot (prologue, epilogue) combinations at one row; false = no specialised kernel for these arguments
+static bool launch_gemv1_special(const GemvArgs & a, int nch, hipStream_t st) {
+    static const bool off = getenv("WMI_GEMV1_GENERIC") != nullptr;       // debug / A-B
+    if (off || a.rows) return false;
+    const int pro = a.ln_g ? 1 : a.sa_q ? 2 : a.comb_o ? 3 : 0;
+    if (a.N >= 16384) return false;
+    if (nch == 1) {
+        if (pro == 1 && a.epi == EPI_QKV_DEC)        { launch_gemv1<4, 1, false, 1, EPI_QKV_DEC>(a, st); return true; }
+        if (pro == 1 && a.epi == EPI_F16_BIAS_GELU)  { launch_gemv1<4, 1, false, 1, EPI_F16_BIAS_GELU>(a, st); return true; }
+        if (pro == 2 && a.epi == EPI_F32_BIAS_RESID) { launch_gemv1<4, 1, false, 2, EPI_F32_BIAS_RESID>(a, st); return true; }
+        if (pro == 3 && a.epi == EPI_F32_BIAS_RESID) { launch_gemv1<4, 1, false, 3, EPI_F32_BIAS_RESID>(a, st); return true; }
+    }
+    if (pro == 0 && a.epi == EPI_F32_BIAS_RESID) {
+        if (nch == 3) { launch_gemv1<4, 3, false, 0, EPI_F32_BIAS_RESID>(a, st); return true; }
+        if (nch == 4) { launch_gemv1<4, 4, false, 0, EPI_F32_BIAS_RESID>(a, st); return true; }
+    }
+    return false;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1042,6 +1069,7 @@ void gemv(const GemvArgs & a, hipStream_t st) {
     const int kind = a.ln_g ? 1 : a.sa_q ? 2 : a.comb_o ? 4 : 8;
     if (a.n == 1 && !a.lanes && a.K <= 2048 && (a.K % 8) == 0 && !gemv1_off && !(gemv1_mask & kind) && (!a.ln_g || a.K <= 1536)) {
         const int nch = (a.K + 511) / 512;
+        if (launch_gemv1_special(a, nch, st)) return;
         if (a.N >= 16384) {                       // vocabulary projection: 8 rows (8 KB) per wavefront in flight
             if (nch == 1) launch_gemv1<8, 1>(a, st); else if (nch == 2) launch_gemv1<8, 2>(a, st); else if (nch == 3) launch_gemv1<8, 3>(a, st); else launch_gemv1<4, 4>(a, st);
         } else {
