@@ -582,13 +582,19 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
     const int nwaves = gridDim.x * 4;
     const int gw = blockIdx.x * 4 + wave;
 
-    uint4 wpre[RIF];
-    const bool have_pre = gw * RIF < a.N && lane * 8 < K;
+    // ALL chunks of the first row tile are requested before anything else (with only the first chunk up front, K > 512 paid a
+    // second round trip after the prologue).  Columns past K read column 0 instead: the activation there is exactly 0.
+    uint4 wpre[NCH][RIF];
+    const bool have_pre = gw * RIF < a.N;
     if (have_pre) {
 #pragma unroll
-        for (int u = 0; u < RIF; ++u) {
-            int o = gw * RIF + u; if (o > a.N - 1) o = a.N - 1;
-            wpre[u] = ldw<NT>(a.W + (size_t) o * K + lane * 8);
+        for (int t = 0; t < NCH; ++t) {
+            const int c = lane * 8 + 512 * t, cc = c < K ? c : 0;
+#pragma unroll
+            for (int u = 0; u < RIF; ++u) {
+                int o = gw * RIF + u; if (o > a.N - 1) o = a.N - 1;
+                wpre[t][u] = ldw<NT>(a.W + (size_t) o * K + cc);
+            }
         }
     }
     // after the halving reduction below, row u of a tile ends up on the lanes with (lane / LPR) % RIF == u; lane u * LPR writes it
@@ -666,12 +672,14 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
             __syncthreads();
             arow = act;
         }
+        uint4 u4[NCH];                                       // unconditional clamped loads, masked afterwards
+#pragma unroll
+        for (int t = 0; t < NCH; ++t) { const int c = lane * 8 + 512 * t; u4[t] = *(const uint4 *) (arow + (c < K ? c : 0)); }
 #pragma unroll
         for (int t = 0; t < NCH; ++t) {
             const int c = lane * 8 + 512 * t;
-            uint4 u4 = make_uint4(0u, 0u, 0u, 0u);
-            if (c < K) u4 = *(const uint4 *) (arow + c);
-            const __half2 * h = (const __half2 *) &u4;
+            if (c >= K) u4[t] = make_uint4(0u, 0u, 0u, 0u);
+            const __half2 * h = (const __half2 *) &u4[t];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float2 f = __half22float2(h[e]); av[t][2 * e] = f.x; av[t][2 * e + 1] = f.y; }
         }
@@ -681,25 +689,22 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
     for (int o0 = gw * RIF; o0 < a.N; o0 += nwaves * RIF) {
         uint4 w[NCH][RIF];
 #pragma unroll
-        for (int t = 0; t < NCH; ++t) {
-            const int c = lane * 8 + 512 * t;
+        for (int t = 0; t < NCH; ++t)
 #pragma unroll
-            for (int u = 0; u < RIF; ++u) {
-                int o = o0 + u; if (o > a.N - 1) o = a.N - 1;
-                if (t == 0 && first) w[t][u] = wpre[u];
-                else w[t][u] = c < K ? ldw<NT>(a.W + (size_t) o * K + c) : make_uint4(0u, 0u, 0u, 0u);
-            }
-        }
-        {   // software pipeline over the row tiles: first chunk of the NEXT tile is requested before this one is reduced
+            for (int u = 0; u < RIF; ++u) w[t][u] = wpre[t][u];
+        (void) first;
+        {   // software pipeline over the row tiles: the NEXT tile is requested before this one is reduced
             const int on = o0 + nwaves * RIF;
-            first = false;
-            if (on < a.N && lane * 8 < K) {
+            if (on < a.N) {
 #pragma unroll
-                for (int u = 0; u < RIF; ++u) {
-                    int o = on + u; if (o > a.N - 1) o = a.N - 1;
-                    wpre[u] = ldw<NT>(a.W + (size_t) o * K + lane * 8);
+                for (int t = 0; t < NCH; ++t) {
+                    const int c = lane * 8 + 512 * t, cc = c < K ? c : 0;
+#pragma unroll
+                    for (int u = 0; u < RIF; ++u) {
+                        int o = on + u; if (o > a.N - 1) o = a.N - 1;
+                        wpre[t][u] = ldw<NT>(a.W + (size_t) o * K + cc);
+                    }
                 }
-                first = true;
             }
         }
         float acc[RIF];
