@@ -313,7 +313,14 @@ template <int EPI>
 void dispatch(const GemmArgs & a, hipStream_t st) {
     // 256 CUs: prefer the 128x128 tile only when it still yields >= ~1.5 waves of workgroups
     const long t128 = (long) ((a.M + 127) / 128) * ((a.N + 127) / 128);
+    static const bool no_narrow = getenv("WMI_GEMM_NO_NARROW") != nullptr;  // debug / A-B
+    const long t64 = (long) ((a.M + 63) / 64) * ((a.N + 63) / 64);
     if (t128 >= 384 || (t128 >= 256 && a.K >= 1024)) launch<128, 128, EPI>(a, st);
+    else if constexpr (EPI == EPI_F32_BIAS_RESID) {
+        // one chunk, N = S: 64x64 tiles give fewer workgroups than CUs (192 for base.en) and each walks K alone with nothing to
+        // overlap its loads; 64x32 tiles double the workgroups
+        if (t64 < 256 && !no_narrow) launch<64, 32, EPI>(a, st); else launch<64, 64, EPI>(a, st);
+    }
     else             launch<64, 64, EPI>(a, st);
 }
 
