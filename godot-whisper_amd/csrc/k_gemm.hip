@@ -57,7 +57,9 @@ __device__ __forceinline__ uint32_t lds_off(int row, int chunk) {      // byte o
     return (uint32_t) (row * 128 + ((chunk ^ (row & 7)) << 4));
 }
 
-template <int BM, int BN, int EPI>
+// NST = depth of the LDS ring of the global_load_lds path: 2 where several workgroups share a CU and hide each other's loads
+// (the ring costs LDS, i.e. occupancy: mlp.0 at one chunk, 768 tiles, is 20 % slower with 4), 4 where a workgroup is alone
+template <int BM, int BN, int EPI, int NST = 2>
 __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
     constexpr int FM = BM / 32, FN = BN / 32;          // fragments per wavefront
     constexpr int LA = BM / 32, LB = BN / 32;          // 16-byte loads per thread per tile
@@ -168,12 +170,19 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
             for (int p = 0; p < PB; ++p)
                 __builtin_amdgcn_global_load_lds((const void *) (qB[p] + kt * BK), (__attribute__((address_space(3))) void *) (sB(buf) + (wave * PB + p) * 1024), 16, 0, 0);
         };
-        issue(0, 0);
+        // NST-deep ring: NST - 1 tiles are in flight while one is multiplied.  At one chunk a workgroup has its CU (almost) to
+        // itself and nothing else hides the ~0.5 us a tile takes to arrive: with a distance of one every K step cost a full
+        // load latency (mlp.2, 32 steps: 18 us).  The wait is counted: tile kt has landed when at most (NST - 2) tiles' worth of
+        // this wavefront's loads are still outstanding.
+        constexpr int LPT = PA + PB;                          // load instructions per wavefront and tile
+#pragma unroll
+        for (int s0 = 0; s0 < NST - 1; ++s0) if (s0 < nk) issue(s0, s0);
         for (int kt = 0; kt < nk; ++kt) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                  // tile kt landed for everyone; buffer (kt + 1) & 1 is free again
-            if (kt + 1 < nk) issue(kt + 1, (kt + 1) & 1);
-            compute(kt & 1);
+            if (nk - 1 - kt >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * LPT) : "memory");
+            else                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();                                  // tile kt landed for everyone; the buffer multiplied last step is free
+            if (kt + NST - 1 < nk) issue(kt + NST - 1, (kt + NST - 1) % NST);
+            compute(kt % NST);
         }
     } else {
         load_tile(0);
@@ -297,16 +306,24 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
     else                                  epilogue(std::true_type{});
 }
 
-template <int BM, int BN, int EPI>
-void launch(const GemmArgs & a, hipStream_t st) {
+template <int BM, int BN, int EPI, int NST>
+void launch_n(const GemmArgs & a, hipStream_t st) {
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
-    const size_t smem = 2 * (size_t) (BM + BN) * 128;
+    const size_t smem = NST * (size_t) (BM + BN) * 128;
     static bool attr_done = false;
     if (!attr_done) {
-        (void) hipFuncSetAttribute((const void *) k_gemm<BM, BN, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+        (void) hipFuncSetAttribute((const void *) k_gemm<BM, BN, EPI, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
         attr_done = true;
     }
-    hipLaunchKernelGGL((k_gemm<BM, BN, EPI>), dim3(ntm * ntn), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((k_gemm<BM, BN, EPI, NST>), dim3(ntm * ntn), dim3(256), smem, st, a);
+}
+template <int BM, int BN, int EPI>
+void launch(const GemmArgs & a, hipStream_t st) {
+    static const bool shallow = getenv("WMI_GEMM_RING2") != nullptr;         // debug / A-B
+    const long nwg = (long) ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    // (a 3-deep ring for the grids in between — q|k|v 576, mlp.0 768 tiles — measured the same as 2)
+    if (BM < 128 && nwg <= 400 && !shallow) launch_n<BM, BN, EPI, 4>(a, st);
+    else                                    launch_n<BM, BN, EPI, 2>(a, st);
 }
 
 template <int EPI>
