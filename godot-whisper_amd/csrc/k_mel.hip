@@ -84,7 +84,7 @@ __global__ void k_mel_tail(float * __restrict__ mel, int n_len, int n_mel, int n
 constexpr int MEL_NT = 256;            // threads per frame (4 wavefronts: 1.6 leaf-DFT outputs per thread)
 __global__ __launch_bounds__(MEL_NT) void k_mel_frames(const float * __restrict__ pad, int n_valid, int n_fft_frames,
                                                     int n_len, int n_mel, const float * __restrict__ filters,
-                                                    const int32_t * __restrict__ ranges,
+                                                    const int32_t * __restrict__ ranges, const float * __restrict__ taps,
                                                     float * __restrict__ mel, int * __restrict__ gmax) {
     __shared__ float xin[400];
     __shared__ __attribute__((aligned(8))) float bufA[800];
@@ -125,15 +125,14 @@ __global__ __launch_bounds__(MEL_NT) void k_mel_frames(const float * __restrict_
     // banks; wider ranges finish from memory below): in flight during the transform instead of one round trip per group after it
     constexpr int FW = 12;
     float fw[FW][4], f200 = 0.0f;
-    if (tid < n_mel) {
-        const float * f = filters + (size_t) tid * 201;
+    {   // from the compact table (model.cpp: 13 aligned float4 per bin): independent of the ranges, 13 loads instead of 49
+        const float4 * tp = (const float4 *) taps + (size_t) (tid < n_mel ? tid : 0) * 13;
+        float4 tv[FW + 1];
 #pragma unroll
-        for (int q = 0; q < FW; ++q) {
-            const int g4 = fr0 + q < 50 ? fr0 + q : 49;
+        for (int q = 0; q <= FW; ++q) tv[q] = tp[q];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) fw[q][e] = f[4 * g4 + e];
-        }
-        f200 = f[200];
+        for (int q = 0; q < FW; ++q) { fw[q][0] = tv[q].x; fw[q][1] = tv[q].y; fw[q][2] = tv[q].z; fw[q][3] = tv[q].w; }
+        f200 = tv[FW].x;
     }
     __syncthreads();
 
@@ -280,12 +279,12 @@ void mel_pad(const float * pcm, int n_samples, float * pcm_pad, int n_pad_total,
 }
 
 void mel_frames(const float * pcm_pad, int n_valid, int n_fft_frames, int n_len, int n_mel, const float * filters,
-                const int32_t * ranges, float * mel, int * gmax, hipStream_t st) {
+                const int32_t * ranges, const float * taps, float * mel, int * gmax, hipStream_t st) {
     std::call_once(g_tables_once, upload_tables);
     hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, gmax, INT_MIN);
     if (n_fft_frames > 0)
         hipLaunchKernelGGL(k_mel_frames, dim3(n_fft_frames), dim3(MEL_NT), 0, st, pcm_pad, n_valid, n_fft_frames, n_len, n_mel,
-                           filters, ranges, mel, gmax);
+                           filters, ranges, taps, mel, gmax);
     const int tail = (n_len - n_fft_frames) * n_mel;
     if (tail > 0) hipLaunchKernelGGL(k_mel_tail, dim3((tail + 255) / 256), dim3(256), 0, st, mel, n_len, n_mel, n_fft_frames, gmax);
 }

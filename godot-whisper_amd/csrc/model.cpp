@@ -375,6 +375,24 @@ bool upload_weights(const ModelFile & mf, const uint8_t * host_buf, const void *
             rng[2 * j] = g0; rng[2 * j + 1] = g1;
         }
     }
+    // ... and those groups themselves, compact and 16-byte aligned: [n_mel][13][4] = the first 12 groups from g0 (zero-padded), then
+    // {tap 200, 0, 0, 0}.  A filter row of the file has 201 floats (804 bytes): read in place, every lane's four taps were four
+    // misaligned scalar loads from a different cache line (k_mel.hip).
+    const size_t o_taps = ar.reserve((size_t) std::max(n_filt, 1) * 13 * 4 * 4);
+    {
+        const int32_t * rng = (const int32_t *) (ar.host.data() + o_rng);
+        float * taps = (float *) (ar.host.data() + o_taps);
+        for (int j = 0; j < n_filt; ++j) {
+            const float * f = mf.filters.data() + (size_t) j * n_fft;
+            float * t = taps + (size_t) j * 13 * 4;
+            for (int q = 0; q < 12; ++q)
+                for (int e = 0; e < 4; ++e) {
+                    const int g = rng[2 * j] + q, k = 4 * g + e;
+                    t[q * 4 + e] = (g < rng[2 * j + 1] && k < n_fft) ? f[k] : 0.0f;
+                }
+            t[48] = n_fft > 200 ? f[200] : 0.0f; t[49] = t[50] = t[51] = 0.0f;
+        }
+    }
     ar.reserve(4096);                                  // tail slack: GEMM tiles may over-read clamped rows
 
     if (!b.ok) return false;
@@ -408,6 +426,7 @@ bool upload_weights(const ModelFile & mf, const uint8_t * host_buf, const void *
     w.d_ln_g = F(o_dlng); w.d_ln_b = F(o_dlnb);
     w.mel_filters = F(o_filt);
     w.mel_ranges = (const int32_t *) (base + o_rng);
+    w.mel_taps = F(o_taps);
     WMI_INFO("%s: device weight arena = %.2f MB\n", __func__, w.arena_bytes / 1e6);
     return true;
 }

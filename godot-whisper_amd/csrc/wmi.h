@@ -106,6 +106,7 @@ struct Weights {
     std::vector<DecLayerW> dec;
     const float  *d_ln_g, *d_ln_b;
     const float  *mel_filters;                                        // [n_mel][201]
+    const float   *mel_taps;                                          // [n_mel][13][4]: the first 12 non-zero groups of each filter, then tap 200
     const int32_t *mel_ranges;                                        // [n_mel][2]: non-zero 4-tap groups [g0, g1) of each filter
 };
 
