@@ -840,6 +840,16 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
 #pragma unroll
         for (int f = 0; f < MAXF; ++f) if (f < nf0) wf[f] = *(const uint4 *) (wp + f * 32);
     }
+    // f16 activation rows without a LayerNorm in front (out projections, mlp.2): the B fragments of the first pass are requested
+    // straight from global memory next to the weights — no LDS copy, no barrier before the first MFMA (the staged copy measured
+    // 4 us of a 7.5 us launch at 8 rows x 2048)
+    const bool direct_b = !a.ln_g && !a.rows;
+    uint4 bf[MAXF];
+    const __half * brow = a.a16 + (size_t) (col < n ? col : 0) * K + kq * 8;
+    if (direct_b && tile < ntiles) {
+#pragma unroll
+        for (int f = 0; f < MAXF; ++f) if (f < nf0) bf[f] = *(const uint4 *) (brow + kbeg + f * 32);
+    }
     int ro_pre = 0;
     if (a.row_off && col < n) ro_pre = a.lanes ? a.row_off[col * a.step_stride] : *a.row_off;
 
@@ -894,7 +904,7 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
         if (n <= 4) ln_rows(std::integral_constant<int, 1>{});
         else if (n <= 8) ln_rows(std::integral_constant<int, 2>{});
         else ln_rows(std::integral_constant<int, 4>{});
-    } else {
+    } else if (!direct_b) {
         // n rows of K / 8 16-byte pieces, flattened over the workgroup; the loads of a group of pieces before their LDS stores
         // (as a row-by-row copy loop this was one dependent round trip per row); group size by the amount of work
         const int cpr = K >> 3, total = n * cpr;
@@ -940,12 +950,17 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
             if (!(first && k0 == kbeg)) {
 #pragma unroll
                 for (int f = 0; f < MAXF; ++f) if (f < nf) wf[f] = *(const uint4 *) (wrow + k0 + f * 32);
+                if (direct_b) {
+#pragma unroll
+                    for (int f = 0; f < MAXF; ++f) if (f < nf) bf[f] = *(const uint4 *) (brow + k0 + f * 32);
+                }
             }
 #pragma unroll
             for (int f = 0; f < MAXF; ++f) {
                 if (f < nf) {
                     uint4 bu = make_uint4(0u, 0u, 0u, 0u);
-                    if (col < n) bu = *(const uint4 *) (act + col * lda + k0 + f * 32 + kq * 8);
+                    if (direct_b) { if (col < n) bu = bf[f]; }
+                    else if (col < n) bu = *(const uint4 *) (act + col * lda + k0 + f * 32 + kq * 8);
                     acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(*(const half8 *) &wf[f], *(const half8 *) &bu, acc, 0, 0, 0);
                 }
             }
