@@ -202,13 +202,13 @@ def main():
             gbs = alg_bytes / (us_gemv * 1e-6) / 1e9
             out["roofline"] = {"kernel": "k_gemv1<8,1> logits = d_te[51864x512] . LN(x)  (f16 weight stream, LN + activations in registers)",
                                "bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
-                               "frac": round(gbs / 8000.0, 4), "traffic": pmc_traffic("k_gemv1<8, 1, false>"),
+                               "frac": round(gbs / 8000.0, 4), "traffic": pmc_traffic("k_gemv1<8, 1, false*"),
                                "algorithmic_bytes": alg_bytes, "avg_us": round(us_gemv, 3)}
             flops = 2.0 * T * 4 * hp_S * hp_S
             tf = flops / (us_gemm * 1e-6) / 1e12
             out["roofline_encoder_gemm"] = {"kernel": "k_gemm<64,64,EPI_F16_BIAS_GELU> encoder mlp.0 [1500x2048x512] f16 MFMA",
                                             "bound": "mfma", "achieved": round(tf, 2), "peak": 2500.0, "unit": "TFLOP/s",
-                                            "frac": round(tf / 2500.0, 4), "traffic": pmc_traffic("k_gemm<64, 64, 1> grid=196608"),
+                                            "frac": round(tf / 2500.0, 4), "traffic": pmc_traffic("k_gemm<64, 64, 1,* grid=196608"),
                                             "avg_us": round(us_gemm, 3)}
             if batch8:                                  # the same GEMM / attention over the 8 lock-step chunks (M = 12 000)
                 us_g8 = lib.wmi_bench_kernel(ctx, 4, 100); us_a8 = lib.wmi_bench_kernel(ctx, 5, 30)
@@ -216,7 +216,7 @@ def main():
                     tf8 = 8 * flops / (us_g8 * 1e-6) / 1e12
                     out["roofline_encoder_gemm_batch8"] = {"kernel": "k_gemm<128,128,EPI_F16_BIAS_GELU> encoder mlp.0 [12000x2048x512] f16 MFMA, global_load_lds staging",
                                                            "bound": "mfma", "achieved": round(tf8, 2), "peak": 2500.0, "unit": "TFLOP/s",
-                                                           "frac": round(tf8 / 2500.0, 4), "traffic": pmc_traffic("k_gemm<128, 128, 1> grid=385024"),
+                                                           "frac": round(tf8 / 2500.0, 4), "traffic": pmc_traffic("k_gemm<128, 128, 1,* grid=385024"),
                                                            "avg_us": round(us_g8, 3)}
                 if us_a8 > 0:
                     out["attn_layer_batch8_us"] = round(us_a8, 2)
@@ -303,8 +303,9 @@ def pmc_traffic(kernel_key: str):
             d = json.load(open(path))
         except Exception:
             continue
+        head, _, tail = kernel_key.partition("*")          # "name prefix*suffix": template tails (ring depth, specialisation) may vary
         for k, e in d.items():
-            if k.startswith(kernel_key) and "fetch_bytes_x2_corrected" in e:
+            if k.startswith(head) and k.endswith(tail) and "fetch_bytes_x2_corrected" in e:
                 best = int(e["fetch_bytes_x2_corrected"] + e.get("write_bytes_raw", 0))
     return best
 
