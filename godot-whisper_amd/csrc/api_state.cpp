@@ -166,6 +166,8 @@ int whisper_full_parallel(struct whisper_context * ctx, struct whisper_full_para
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     const int offset_samples = (WHISPER_SAMPLE_RATE * params.offset_ms) / 1000;
     const int per = (n_samples - offset_samples) / n_processors;
+    // nothing to split (the reference would hand negative sample counts to its workers here): one plain call
+    if (per <= 0) return whisper_full(ctx, params, samples, n_samples);
 
     std::vector<struct whisper_state *> states;
     for (int i = 0; i < n_processors - 1; ++i) {
