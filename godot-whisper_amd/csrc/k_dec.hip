@@ -628,10 +628,25 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
             float * sc = (float *) (smem + (((size_t) K * sizeof(__half) + 15) & ~(size_t) 15));   // [H][sa_cap]
             float * qf = sc + (size_t) H * a.sa_cap;                                             // [K]
             // the decode loop's case (n_kv <= 64): per wavefront, barrier-free — heads wave, wave + 4 (and wave + 8, wave + 12, ...)
+            // all heads of a wavefront in ONE call (ceil(H / 4) of them: 2 for base, 3 small, 4 medium, 5 large): a second call
+            // would be a second round trip of loads (small, H = 12: 9.6 -> 6.5 us per launch)
+            // (only in the self-attention instantiations: 3-5 heads per wavefront need ~400 VGPRs, which must not leak into the
+            // generic kernel that also serves the vocabulary projection at two workgroups per CU)
             bool done = true;
-            for (int h0 = wave; h0 < H; h0 += 8) {
+            if (PRO != 2 || H <= 8) {
+                for (int h0 = wave; h0 < H; h0 += 8) {
+                    const int hs[2] = { h0, h0 + 4 };
+                    done = self_attn_wave<2>(a.sa_q, a.sa_k, a.sa_v, a.sa_nkv, K, a.sa_cap, hs, H, lane, act) && done;
+                }
+            }
+            else if constexpr (PRO == 2) {
+            if (H <= 12) { const int hs[3] = { wave, wave + 4, wave + 8 };                          done = self_attn_wave<3>(a.sa_q, a.sa_k, a.sa_v, a.sa_nkv, K, a.sa_cap, hs, H, lane, act); }
+            else if (H <= 16) { const int hs[4] = { wave, wave + 4, wave + 8, wave + 12 };               done = self_attn_wave<4>(a.sa_q, a.sa_k, a.sa_v, a.sa_nkv, K, a.sa_cap, hs, H, lane, act); }
+            else if (H <= 20) { const int hs[5] = { wave, wave + 4, wave + 8, wave + 12, wave + 16 };    done = self_attn_wave<5>(a.sa_q, a.sa_k, a.sa_v, a.sa_nkv, K, a.sa_cap, hs, H, lane, act); }
+            else for (int h0 = wave; h0 < H; h0 += 8) {
                 const int hs[2] = { h0, h0 + 4 };
                 done = self_attn_wave<2>(a.sa_q, a.sa_k, a.sa_v, a.sa_nkv, K, a.sa_cap, hs, H, lane, act) && done;
+            }
             }
             if (wave >= H) done = a.sa_nkv[0] <= 64;         // a wavefront without a head (H < 4) still has to agree on the branch
             if (!done) {                                     // wave-uniform and the same in every wavefront: it only depends on n_kv
@@ -792,6 +807,12 @@ static bool launch_gemv1_special(const GemvArgs & a, int nch, hipStream_t st) {
         if (pro == 1 && a.epi == EPI_QKV_DEC)        { launch_gemv1<4, 1, false, 1, EPI_QKV_DEC>(a, st); return true; }
         if (pro == 1 && a.epi == EPI_F16_BIAS_GELU)  { launch_gemv1<4, 1, false, 1, EPI_F16_BIAS_GELU>(a, st); return true; }
         if (pro == 2 && a.epi == EPI_F32_BIAS_RESID) { launch_gemv1<4, 1, false, 2, EPI_F32_BIAS_RESID>(a, st); return true; }
+    }
+    if (pro == 2 && a.epi == EPI_F32_BIAS_RESID) {           // wider models: all heads of a wavefront in one call need this instantiation
+        if (nch == 2) { launch_gemv1<4, 2, false, 2, EPI_F32_BIAS_RESID>(a, st); return true; }
+        if (nch == 3) { launch_gemv1<4, 3, false, 2, EPI_F32_BIAS_RESID>(a, st); return true; }
+    }
+    if (nch == 1) {
         if (pro == 3 && a.epi == EPI_F32_BIAS_RESID) { launch_gemv1<4, 1, false, 3, EPI_F32_BIAS_RESID>(a, st); return true; }
     }
     if (pro == 0 && a.epi == EPI_F32_BIAS_RESID) {
