@@ -239,7 +239,7 @@ static void enqueue_rows_step(whisper_context & ctx, int nb) {
         {   // LN2 + cross query (folded into the score kernel) + cross-attention partials over each row's own chunk
             const float * po = nullptr, * pl = nullptr; int ns = 0;
             if (!(M & 16)) k::attn_cross_partials_layout(nb, H, Tc, b.xattn, &po, &pl, &ns);
-            else if (S > 512) {                             // wide models: separate projection launch (see device.cpp)
+            else if (S > 1536) {                            // wider than three 512-column chunks: separate projection launch (see device.cpp)
                 k::GemvArgs g = base(S, S, l.w_cq, l.b_cq, k::EPI_Q_SCALED, b.dq, S);
                 g.x32 = b.dx; g.ln_g = l.ln2_g; g.ln_b = l.ln2_b; g.scale = kq_scale;
                 k::gemv(g, s);

@@ -486,7 +486,7 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc) {
             static const bool unfused_q = getenv("WMI_XATTN_UNFUSED_Q") != nullptr;          // debug / A-B
             const float * po = nullptr, * pl = nullptr; int ns = 0;
             if (!(M & 8)) { k::attn_cross_partials_layout(1, H, Tc, d.xattn, &po, &pl, &ns); }
-            else if (unfused_q || S > 512) {                   // the fused kernel keeps a whole row per wavefront in registers: S <= 512
+            else if (unfused_q || S > 1536) {                  // the fused kernel keeps a whole row per wavefront in registers: S <= 1536
                 gv(k::EPI_Q_SCALED, l.ln2_g, l.ln2_b, nullptr, S, S, l.w_cq, l.b_cq, d.dq, S, nullptr, nullptr, nullptr, kq_scale, nullptr);
                 k::attn_cross_split_partials(d.dq, 1, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, &po, &pl, &ns, s);
             } else

@@ -325,6 +325,7 @@ __global__ __launch_bounds__(256) void k_xattn_scores(const __half * __restrict_
 // the LayerNorm, and reduces the 16 partial dot products with a halving exchange (17 shuffles instead of 96).
 // Roundings as in k_gemv + EPI_Q_SCALED (LN output f16, f32 accumulation, (dot + b) * scale -> f16); the f32
 // summation order differs from that kernel's.
+template <int NC>                                              // 512-column chunks of the row: S <= 512 NC
 __global__ __launch_bounds__(256) void k_xattn_qscores(const float * __restrict__ x32, const float * __restrict__ ln_g,
                                                        const float * __restrict__ ln_b, float eps,
                                                        const __half * __restrict__ wq, const float * __restrict__ bq, float qscale,
@@ -336,25 +337,29 @@ __global__ __launch_bounds__(256) void k_xattn_qscores(const float * __restrict_
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int slice = blockIdx.x, head = blockIdx.y, i = blockIdx.z, H = gridDim.y;
     kc += (int64_t) i * kv_row_stride;
-    const bool on = lane * 8 < S;                                  // S <= 512, multiple of 8
+    bool on[NC]; int c0[NC];                                       // S multiple of 8
+#pragma unroll
+    for (int t = 0; t < NC; ++t) { on[t] = lane * 8 + 512 * t < S; c0[t] = on[t] ? lane * 8 + 512 * t : 0; }
 
     // 16 weight rows of this wavefront (independent of x: requested first), then x, gain, bias
     // Loads are unconditional from a clamped column and masked afterwards: written as `on ? load : 0` hipcc put every load
     // in its own exec-masked block — 24 scalar dword loads for x / gain / bias and a vmcnt(0) after the second weight row
-    uint4 w[16];
-    const int c0 = on ? lane * 8 : 0;
-    const __half * wrow0 = wq + (size_t) (head * 64 + wave * 16) * S + c0;
+    uint4 w[NC][16];
+    const __half * wrow0 = wq + (size_t) (head * 64 + wave * 16) * S;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) w[u] = *(const uint4 *) (wrow0 + (size_t) u * S);
-    float xv[8], gv[8], bv[8];
-    {
-        const float * xr = x32 + (size_t) i * S + c0;
+    for (int t = 0; t < NC; ++t)
+#pragma unroll
+        for (int u = 0; u < 16; ++u) w[t][u] = *(const uint4 *) (wrow0 + (size_t) u * S + c0[t]);
+    float xv[NC][8], gv[NC][8], bv[NC][8];
+#pragma unroll
+    for (int t = 0; t < NC; ++t) {
+        const float * xr = x32 + (size_t) i * S + c0[t];
         const float4 x0 = *(const float4 *) xr, x1 = *(const float4 *) (xr + 4);
-        const float4 g0 = *(const float4 *) (ln_g + c0), g1 = *(const float4 *) (ln_g + c0 + 4);
-        const float4 b0 = *(const float4 *) (ln_b + c0), b1 = *(const float4 *) (ln_b + c0 + 4);
-        xv[0] = x0.x; xv[1] = x0.y; xv[2] = x0.z; xv[3] = x0.w; xv[4] = x1.x; xv[5] = x1.y; xv[6] = x1.z; xv[7] = x1.w;
-        gv[0] = g0.x; gv[1] = g0.y; gv[2] = g0.z; gv[3] = g0.w; gv[4] = g1.x; gv[5] = g1.y; gv[6] = g1.z; gv[7] = g1.w;
-        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+        const float4 g0 = *(const float4 *) (ln_g + c0[t]), g1 = *(const float4 *) (ln_g + c0[t] + 4);
+        const float4 b0 = *(const float4 *) (ln_b + c0[t]), b1 = *(const float4 *) (ln_b + c0[t] + 4);
+        xv[t][0] = x0.x; xv[t][1] = x0.y; xv[t][2] = x0.z; xv[t][3] = x0.w; xv[t][4] = x1.x; xv[t][5] = x1.y; xv[t][6] = x1.z; xv[t][7] = x1.w;
+        gv[t][0] = g0.x; gv[t][1] = g0.y; gv[t][2] = g0.z; gv[t][3] = g0.w; gv[t][4] = g1.x; gv[t][5] = g1.y; gv[t][6] = g1.z; gv[t][7] = g1.w;
+        bv[t][0] = b0.x; bv[t][1] = b0.y; bv[t][2] = b0.z; bv[t][3] = b0.w; bv[t][4] = b1.x; bv[t][5] = b1.y; bv[t][6] = b1.z; bv[t][7] = b1.w;
     }
     const float bias = bq ? bq[head * 64 + wave * 16 + ((lane >> 2) & 15)] : 0.0f;
     // Key rows of this wavefront — a quarter of the slice, 8 keys per pass: lane = (key g = lane / 8, 16-byte octet o = lane % 8),
@@ -372,35 +377,47 @@ __global__ __launch_bounds__(256) void k_xattn_qscores(const float * __restrict_
         kk[p] = *(const uint4 *) (kc + (size_t) (ok ? j : 0) * S + head * 64 + o * 8);
     }
     __builtin_amdgcn_sched_barrier(0);          // keep all loads in flight together (the scheduler would sink them to their uses)
-    if (!on) {
 #pragma unroll
-        for (int u = 0; u < 16; ++u) w[u] = make_uint4(0u, 0u, 0u, 0u);
+    for (int t = 0; t < NC; ++t) {
+        if (!on[t]) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { xv[e] = 0.0f; gv[e] = 0.0f; bv[e] = 0.0f; }
+            for (int u = 0; u < 16; ++u) w[t][u] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { xv[t][e] = 0.0f; gv[t][e] = 0.0f; bv[t][e] = 0.0f; }
+        }
     }
     float sum = 0.0f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) sum += xv[e];
+    for (int t = 0; t < NC; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += xv[t][e];
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     const float mean = sum / (float) S;
     float sq = 0.0f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { if (on) { xv[e] -= mean; sq += xv[e] * xv[e]; } }
+    for (int t = 0; t < NC; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { if (on[t]) { xv[t][e] -= mean; sq += xv[t][e] * xv[t][e]; } }
     for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
     const float scl = 1.0f / sqrtf(sq / (float) S + eps);
-    float av[8];
+    float av[NC][8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) av[e] = round_f16(__fadd_rn(__fmul_rn(xv[e] * scl, gv[e]), bv[e]));
+    for (int t = 0; t < NC; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) av[t][e] = round_f16(__fadd_rn(__fmul_rn(xv[t][e] * scl, gv[t][e]), bv[t][e]));
     float acc[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-        const __half2 * wh = (const __half2 *) &w[u];
         float a = 0.0f;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const float2 f = __half22float2(wh[e]);
-            a = fmaf(f.x, av[2 * e], a);
-            a = fmaf(f.y, av[2 * e + 1], a);
+        for (int t = 0; t < NC; ++t) {
+            const __half2 * wh = (const __half2 *) &w[t][u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float2 f = __half22float2(wh[e]);
+                a = fmaf(f.x, av[t][2 * e], a);
+                a = fmaf(f.y, av[t][2 * e + 1], a);
+            }
         }
         acc[u] = a;
     }
@@ -630,8 +647,11 @@ void attn_cross_qsplit_partials(const float * x32, const float * ln_g, const flo
     float * part_l = pmax + (size_t) n * H * ns;
     float * part_o = part_l + (size_t) n * H * ns;
     if (!(g_xattn_probe_skip & 1))
-    hipLaunchKernelGGL(k_xattn_qscores, dim3(ns, H, n), dim3(256), 0, st, x32, ln_g, ln_b, eps, wq, bq, qscale, S, kc, T, ks, ns,
-                       sc, ld_sc, pmax, kv_row_stride);
+    {
+        auto kern = S <= 512 ? k_xattn_qscores<1> : S <= 1024 ? k_xattn_qscores<2> : k_xattn_qscores<3>;      // S <= 1536
+        hipLaunchKernelGGL(kern, dim3(ns, H, n), dim3(256), 0, st, x32, ln_g, ln_b, eps, wq, bq, qscale, S, kc, T, ks, ns,
+                           sc, ld_sc, pmax, kv_row_stride);
+    }
     const size_t smem = (((size_t) ks + 3) & ~(size_t) 3) * 4 + 4 * 64 * 4;
     if (!(g_xattn_probe_skip & 2))
     hipLaunchKernelGGL(k_xattn_pv, dim3(ns, H, n), dim3(256), smem, st, vc, S, T, ks, ns, sc, ld_sc, pmax, part_o, part_l, kv_row_stride);
