@@ -748,6 +748,9 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
             for (int u = 0; u < 2; ++u) { const bool hi = lane & 16; const float keep = hi ? acc[u + 2] : acc[u], send = hi ? acc[u] : acc[u + 2]; acc[u] = keep + __shfl_xor(send, 16); }
             { const bool hi = lane & 8; const float keep = hi ? acc[1] : acc[0], send = hi ? acc[0] : acc[1]; v = keep + __shfl_xor(send, 8); }
             v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+        } else if (RIF == 2) {
+            { const bool hi = lane & 32; const float keep = hi ? acc[RIF - 1] : acc[0], send = hi ? acc[0] : acc[RIF - 1]; v = keep + __shfl_xor(send, 32); }
+            v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
         } else {
 #pragma unroll
             for (int u = 0; u < 2; ++u) { const bool hi = lane & 32; const float keep = hi ? acc[u + 2] : acc[u], send = hi ? acc[u] : acc[u + 2]; acc[u] = keep + __shfl_xor(send, 32); }
@@ -818,6 +821,10 @@ static bool launch_gemv1_special(const GemvArgs & a, int nch, hipStream_t st) {
     if (pro == 0 && a.epi == EPI_F32_BIAS_RESID) {
         if (nch == 3) { launch_gemv1<4, 3, false, 0, EPI_F32_BIAS_RESID>(a, st); return true; }
         if (nch == 4) { launch_gemv1<4, 4, false, 0, EPI_F32_BIAS_RESID>(a, st); return true; }
+        // mlp.2 of the wider models (K = 4 S = 3072 / 4096 / 5120): register budget = activation row + two row tiles of weights
+        if (nch == 5 || nch == 6)  { launch_gemv1<4, 6, false, 0, EPI_F32_BIAS_RESID>(a, st); return true; }
+        if (nch == 7 || nch == 8)  { launch_gemv1<2, 8, false, 0, EPI_F32_BIAS_RESID>(a, st); return true; }
+        if (nch == 9 || nch == 10) { launch_gemv1<2, 10, false, 0, EPI_F32_BIAS_RESID>(a, st); return true; }
     }
     return false;
 }
@@ -1108,6 +1115,8 @@ void gemv(const GemvArgs & a, hipStream_t st) {
     static const bool gemv1_off = getenv("WMI_GEMV1_OFF") != nullptr;       // debug / A-B: LDS-staged one-row path
     static const int gemv1_mask = getenv("WMI_GEMV1_MASK") ? atoi(getenv("WMI_GEMV1_MASK")) : 0;   // debug: per-prologue opt-out
     const int kind = a.ln_g ? 1 : a.sa_q ? 2 : a.comb_o ? 4 : 8;
+    if (a.n == 1 && !a.lanes && a.K > 2048 && a.K <= 5120 && (a.K % 8) == 0 && !gemv1_off && !(gemv1_mask & kind) && kind == 8 &&
+        launch_gemv1_special(a, (a.K + 511) / 512, st)) return;
     if (a.n == 1 && !a.lanes && a.K <= 2048 && (a.K % 8) == 0 && !gemv1_off && !(gemv1_mask & kind) && (!a.ln_g || a.K <= 1536)) {
         const int nch = (a.K + 511) / 512;
         if (launch_gemv1_special(a, nch, st)) return;
