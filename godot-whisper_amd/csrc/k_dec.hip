@@ -346,6 +346,51 @@ __device__ __forceinline__ void ln_row_compute(float (&xv)[MAXCH][8], const floa
         for (int e = 0; e < 8; ++e) av[t][e] = on ? round_f16(__fadd_rn(__fmul_rn(xv[t][e] * sc, gv[t][e]), bv[t][e])) : 0.0f;
     }
 }
+// ln_row_compute for RW rows at once, in place (xv becomes the normalised row): every stage runs across the rows, so the
+// two 6-step butterflies of a row overlap with the other rows' instead of forming RW dependent chains (lock-step q|k|v at
+// 16 rows: 5.3 -> ~2.5 us of LayerNorm per launch).  Per row the operations and their order are ln_row_compute's.
+template <int RW, int MAXCH>
+__device__ __forceinline__ void ln_rows_compute(float (&xv)[RW][MAXCH][8], const float (&gv)[MAXCH][8], const float (&bv)[MAXCH][8],
+                                                int K, float eps, int lane) {
+    float sum[RW], sq[RW], sc[RW];
+#pragma unroll
+    for (int q = 0; q < RW; ++q) {
+        sum[q] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < MAXCH; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum[q] += xv[q][t][e];
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int q = 0; q < RW; ++q) sum[q] += __shfl_xor(sum[q], o);
+    }
+#pragma unroll
+    for (int q = 0; q < RW; ++q) {
+        const float mean = sum[q] / (float) K;
+        sq[q] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < MAXCH; ++t) {
+            const bool on = lane * 8 + 512 * t < K;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) if (on) { xv[q][t][e] -= mean; sq[q] += xv[q][t][e] * xv[q][t][e]; }
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+        for (int q = 0; q < RW; ++q) sq[q] += __shfl_xor(sq[q], o);
+    }
+#pragma unroll
+    for (int q = 0; q < RW; ++q) {
+        sc[q] = 1.0f / sqrtf(sq[q] / (float) K + eps);
+#pragma unroll
+        for (int t = 0; t < MAXCH; ++t) {
+            const bool on = lane * 8 + 512 * t < K;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xv[q][t][e] = on ? round_f16(__fadd_rn(__fmul_rn(xv[q][t][e] * sc[q], gv[t][e]), bv[t][e])) : 0.0f;
+        }
+    }
+}
 template <int MAXCH>
 __device__ __forceinline__ void ln_row_regs(const float * __restrict__ xr, const float * __restrict__ g, const float * __restrict__ b,
                                             int K, float eps, int lane, float (&av)[MAXCH][8]) {
@@ -871,7 +916,7 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
     // f16 activation rows without a LayerNorm in front (out projections, mlp.2): the B fragments of the first pass are requested
     // straight from global memory next to the weights — no LDS copy, no barrier before the first MFMA (the staged copy measured
     // 4 us of a 7.5 us launch at 8 rows x 2048)
-    const bool direct_b = !a.ln_g && !a.rows;
+    const bool direct_b = KSPLIT && !a.ln_g && !a.rows;      // (the vocabulary projection always has its LayerNorm: no registers for bf there)
     uint4 bf[MAXF];
     const __half * brow = a.a16 + (size_t) (col < n ? col : 0) * K + kq * 8;
     if (direct_b && tile < ntiles) {
@@ -899,6 +944,26 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
     if (a.ln_g) {                                           // K <= 1536; same arithmetic as k_gemv / k_gemv1 (ln_row_regs)
         // rows wave, wave + 4, ... of this wavefront: the x vectors of all of them and gain / bias go out together — row after
         // row, each LayerNorm waited for its own loads.  Two instantiations so that n <= 8 does not issue loads for rows it lacks.
+        if constexpr (!KSPLIT) {
+            // vocabulary projection: 53 MB streamed by several workgroups per CU — the register budget decides the occupancy, so
+            // the rows are normalised one after the other with the loads inside (measured: 19.8 us at 8 rows against 30 us with
+            // the all-rows-at-once form below)
+            for (int r = wave; r < n; r += 4) {
+                const int src = a.rows ? a.rows[r] : r;
+                float av[3][8];
+                ln_row_regs<3>(a.x32 + (size_t) src * K, a.ln_g, a.ln_b, K, a.eps, lane, av);
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int c = lane * 8 + 512 * t;
+                    if (c < K) {
+                        __half2 h[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) h[e] = __floats2half2_rn(av[t][2 * e], av[t][2 * e + 1]);
+                        *(uint4 *) (act + r * lda + c) = *(const uint4 *) h;
+                    }
+                }
+            }
+        } else {
         auto ln_rows = [&](auto rw_tag) {
             constexpr int RW = decltype(rw_tag)::value;
             float xv[RW][3][8], gv[3][8], bv[3][8];
@@ -910,19 +975,19 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
             ln_row_load<3>(a.ln_g, K, lane, gv);
             ln_row_load<3>(a.ln_b, K, lane, bv);
             __builtin_amdgcn_sched_barrier(0);              // keep the loads together: the scheduler sinks each to its first use
+            // K-split launches (one tile per workgroup, a CU to itself): the rows' LayerNorms interleaved
+            ln_rows_compute<RW, 3>(xv, gv, bv, K, a.eps, lane);
 #pragma unroll
             for (int q = 0; q < RW; ++q) {
                 const int r = wave + 4 * q;
                 if (r < n) {
-                    float av[3][8];
-                    ln_row_compute<3>(xv[q], gv, bv, K, a.eps, lane, av);
 #pragma unroll
                     for (int t = 0; t < 3; ++t) {
                         const int c = lane * 8 + 512 * t;
                         if (c < K) {
                             __half2 h[4];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) h[e] = __floats2half2_rn(av[t][2 * e], av[t][2 * e + 1]);
+                            for (int e = 0; e < 4; ++e) h[e] = __floats2half2_rn(xv[q][t][2 * e], xv[q][t][2 * e + 1]);
                             *(uint4 *) (act + r * lda + c) = *(const uint4 *) h;
                         }
                     }
@@ -932,6 +997,7 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
         if (n <= 4) ln_rows(std::integral_constant<int, 1>{});
         else if (n <= 8) ln_rows(std::integral_constant<int, 2>{});
         else ln_rows(std::integral_constant<int, 4>{});
+        }
     } else if (!direct_b) {
         // n rows of K / 8 16-byte pieces, flattened over the workgroup; the loads of a group of pieces before their LDS stores
         // (as a row-by-row copy loop this was one dependent round trip per row); group size by the amount of work
