@@ -850,7 +850,13 @@ static bool launch_gemv1_special(const GemvArgs & a, int nch, hipStream_t st) {
     static const bool off = getenv("WMI_GEMV1_GENERIC") != nullptr;       // debug / A-B
     if (off || a.rows) return false;
     const int pro = a.ln_g ? 1 : a.sa_q ? 2 : a.comb_o ? 3 : 0;
-    if (a.N >= 16384) return false;
+    if (a.N >= 16384) {                                      // vocabulary projection: its own lean instantiation (the generic kernel carries
+        // the attention prologues: 251 VGPRs, 2 workgroups per CU; this one 143).  768 workgroups = 3 per CU: 9.55 us = 5.56 TB/s
+        // (512: 10.6, 1024: 10.8, the generic kernel at 512: 11.4)
+        static const int lb = getenv("WMI_LOGITS_BLOCKS") ? atoi(getenv("WMI_LOGITS_BLOCKS")) : 768;
+        if (pro == 1 && a.epi == EPI_LOGITS && nch == 1) { launch_gemv1<8, 1, false, 1, EPI_LOGITS>(a, st, lb); return true; }
+        return false;
+    }
     if (nch == 1) {
         if (pro == 1 && a.epi == EPI_QKV_DEC)        { launch_gemv1<4, 1, false, 1, EPI_QKV_DEC>(a, st); return true; }
         if (pro == 1 && a.epi == EPI_F16_BIAS_GELU)  { launch_gemv1<4, 1, false, 1, EPI_F16_BIAS_GELU>(a, st); return true; }
