@@ -1066,6 +1066,15 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
             }
         }
         first = false;
+        if (!KSPLIT && (kend - kbeg) <= MAXF * 32 && tile + tstride < ntiles) {
+            // grid-stride over tiles (the vocabulary projection): the next tile's weights are requested before this tile's epilogue,
+            // so a wavefront's stream never waits a whole round trip between tiles
+            int nrow = (tile + tstride) * 16 + col; if (nrow > a.N - 1) nrow = a.N - 1;
+            const __half * wp = a.W + (size_t) nrow * K + kbeg + kq * 8;
+#pragma unroll
+            for (int f = 0; f < MAXF; ++f) if (f < nf0) wf[f] = *(const uint4 *) (wp + f * 32);
+            first = true;
+        }
         if (KSPLIT) {
             if (tile != (int) blockIdx.x) __syncthreads();          // red reused across tiles (grid-stride)
             *(floatx4 *) (red + ((size_t) wave * 64 + lane) * 4) = acc;
@@ -1114,7 +1123,11 @@ void launch_rows_mfma(const GemvArgs & a, hipStream_t st) {
     size_t smem = (((size_t) a.n * (a.K + 8) * sizeof(__half) + 15) & ~(size_t) 15) + (KSPLIT ? 4 * 64 * 4 * sizeof(float) : 0);
     const int ntiles = (a.N + 15) / 16;
     int blocks = KSPLIT ? ntiles : (ntiles + 3) / 4;
+    // vocabulary projection: 2 workgroups per CU, all resident at once, each wavefront walking ~1.6 tiles with the next tile's
+    // weights in flight (811 workgroups, one tile per wavefront: 19.9 us at 8 rows; 512: 15.9; 576 and more: 20.5)
+    static const int cap = getenv("WMI_ROWS_BLOCKS") ? atoi(getenv("WMI_ROWS_BLOCKS")) : 512;        // A/B knob
     if (blocks > 1024) blocks = 1024;
+    if (!KSPLIT && blocks > cap) blocks = cap;
     static size_t attr_bytes = 0;
     if (smem > 48 * 1024 && smem > attr_bytes) {
         (void) hipFuncSetAttribute((const void *) k_rows_mfma<KSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
