@@ -375,6 +375,17 @@ int wmi_process_logits(struct whisper_context * ctx, struct whisper_full_params 
     return nv;
 }
 
+// worker-pool self-test (no device needed): reps jobs of n_tasks tasks, each task adds its index + 1 once; returns the total
+int64_t wmi_selftest_pool(int n_tasks, int reps) {
+    std::vector<int> hits((size_t) std::max(n_tasks, 0), 0);
+    int64_t total = 0;
+    for (int r = 0; r < reps; ++r) {
+        pool_run(n_tasks, [&](int i) { hits[i] += 1; pool_run(3, [&](int) {}); });          // a nested call runs inline
+        for (int i = 0; i < n_tasks; ++i) total += (int64_t) (i + 1) * (hits[i] == r + 1);
+    }
+    return total;
+}
+
 int wmi_sample_draws(struct whisper_context * ctx, const float * probs, const float * logprobs, int n_draw, int reseed,
                      whisper_token_data * out) {
     Decoder & d = ctx->state->decoders[0];

@@ -570,10 +570,7 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
                     row.seek += ls.decoders[0].seek_delta;
                 };
                 if (params.token_timestamps && !params.print_realtime && emit.size() > 1) {
-                    std::vector<std::thread> pool;
-                    for (size_t e = 1; e < emit.size(); ++e) pool.emplace_back(emit_row, emit[e]);
-                    emit_row(emit[0]);
-                    for (auto & t : pool) t.join();
+                    pool_run((int) emit.size(), [&](int e) { emit_row(emit[e]); });       // persistent workers (pool.cpp)
                 } else {
                     for (int ri : emit) emit_row(ri);
                 }

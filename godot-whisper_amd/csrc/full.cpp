@@ -579,8 +579,13 @@ void token_level_timestamps(whisper_context & ctx, State & st, int i_segment, fl
     {
         std::vector<int> idx;
         for (int j = 0; j < n; ++j) if (tokens[j].id < v.eot) idx.push_back(j);
-        for (size_t g0 = 0; g0 < idx.size(); g0 += 8) {
-            const int ng = (int) std::min<size_t>(8, idx.size() - g0);
+        // groups of up to 8 tokens; with more than one group the groups go to the worker pool (6 tokens per group then: a 30 s
+        // chunk's 17 tokens become three tasks instead of 8 + 8 + 1 one after the other)
+        const size_t gsz = idx.size() > 8 ? 6 : 8;
+        const int n_groups = (int) ((idx.size() + gsz - 1) / gsz);
+        auto sum_group = [&](int gi) {
+            const size_t g0 = (size_t) gi * gsz;
+            const int ng = (int) std::min<size_t>(gsz, idx.size() - g0);
             const float * base[8]; int len[8]; float acc[8];
             int common = INT32_MAX;
             for (int t = 0; t < 8; ++t) {
@@ -603,7 +608,8 @@ void token_level_timestamps(whisper_context & ctx, State & st, int i_segment, fl
                 for (int t = 0; t < 8; ++t) acc[t] += i < len[t] ? base[t][i] : 0.0f;
             }
             for (int t = 0; t < ng; ++t) win_sum[idx[g0 + t]] = acc[t];
-        }
+        };
+        pool_run(n_groups, sum_group);
     }
     const int64_t ts1 = time_us();
     struct TsReport { bool on; int64_t a, b; ~TsReport() { if (on) fprintf(stderr, "[wmi] token timestamps: window sums %lld us, walks %lld us\n", (long long) (b - a), (long long) (time_us() - b)); } } ts_report{dbg_ts, ts0, ts1};

@@ -8,6 +8,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <map>
+#include <functional>
 #include <mutex>
 #include <random>
 #include <set>
@@ -283,6 +284,8 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
 bool upload_static_ban(whisper_context & ctx, const whisper_full_params & params);
 bool wait_for_seq(const volatile int32_t * seq, int32_t want, hipStream_t s);   // spin on a pinned sequence number (device.cpp)
 bool fast_path_enabled();
+// host worker pool (pool.cpp): fn(0..n_tasks-1) on a few persistent threads + the caller; nested calls run inline
+void pool_run(int n_tasks, const std::function<void(int)> & fn);
 double bench_greedy_step_chain(whisper_context & ctx, int iters);
 double bench_rows_step_chain(whisper_context & ctx, int nb, int iters);
 // |x| envelope of the last PCM on the GPU; the D2H copy runs on a side stream while the encoder works.

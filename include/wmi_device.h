@@ -119,6 +119,10 @@ WHISPER_API double wmi_selftest_proj(struct whisper_context * ctx, int op, int n
  */
 WHISPER_API double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters);
 
+/* Host worker pool self-test (no device needed): `reps` jobs of `n_tasks` tasks; returns reps * n_tasks * (n_tasks + 1) / 2
+ * when every task of every job ran exactly once. */
+WHISPER_API int64_t wmi_selftest_pool(int n_tasks, int reps);
+
 #ifdef __cplusplus
 }
 #endif

@@ -174,3 +174,10 @@ def test_host_only_context_cannot_create_states():
         assert lib.whisper_full_parallel(ctx, p, fp, pcm.size, 1) == -2          # = whisper_full: no compute path
     finally:
         lib.whisper_free(ctx)
+
+
+def test_host_worker_pool_runs_every_task_exactly_once():
+    """pool.cpp (segment emission on a few persistent threads): many small jobs back to back, nested calls inline."""
+    lib = runtime.load_library()
+    for n, reps in ((1, 50), (3, 2000), (17, 2000), (64, 500)):
+        assert lib.wmi_selftest_pool(n, reps) == reps * n * (n + 1) // 2, (n, reps)
