@@ -222,7 +222,9 @@ bool encode(whisper_context & ctx, int mel_offset) {
         a.bias = w.conv1_b; a.C = d.conv1 + S; a.ldc = S;                       // rows 1..2T ; rows 0 and 2T+1 stay zero
         k::gemm(k::EPI_F16_BIAS_GELU, a, s);
     }
-    k::fill_zero(d.conv1 + (size_t) (2 * T + 1) * S, (size_t) S * sizeof(__half), s);   // stale row when audio_ctx shrank
+    // the zero row behind the last frame holds stale data only if an earlier call ran with a larger audio_ctx (one launch fewer otherwise)
+    if (d.conv1_max_T > T) k::fill_zero(d.conv1 + (size_t) (2 * T + 1) * S, (size_t) S * sizeof(__half), s);
+    d.conv1_max_T = std::max(d.conv1_max_T, T);
     {
         k::GemmArgs a{};
         a.A = d.conv1; a.lda = 2 * S; a.W = w.conv2_w; a.ldw = w.conv2_k; a.M = T; a.N = S; a.K = w.conv2_k;

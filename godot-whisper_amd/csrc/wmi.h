@@ -188,6 +188,7 @@ struct DeviceState {
     __half * enc_out_h = nullptr;                             // [T][S] f16
     __half * kvc_k = nullptr, * kvc_v = nullptr;              // cross cache [L][T][S] each
     int      Tpad = 0;
+    int      conv1_max_T = 0;                                  // largest audio_ctx the conv1 buffer has held (rows 1..2T written)
     // decoder activations (n <= n_text_ctx)
     int32_t * d_tokens = nullptr, * d_pos = nullptr;          // [n]
     float   * d_mask = nullptr;                               // [n][n_kv_max]
