@@ -145,7 +145,7 @@ bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, boo
         src = stage;
     }
     d.last_pcm = src; d.last_pcm_n = n_samples;
-    k::mel_pad(src, n_samples, d.pcm, (int) n_pad, ms);
+    k::mel_pad(src, n_samples, d.pcm, (int) n_pad, ms, (int *) d.mel_max);
     k::mel_frames(d.pcm, n_valid, n_fft_frames, n_len, n_mel, ctx.w.mel_filters, ctx.w.mel_ranges, ctx.w.mel_taps, d.mel, (int *) d.mel_max, ms);
     k::mel_normalize(d.mel, n_mel * n_len, (const int *) d.mel_max, ms);
     if (sync) HIP_TRY(hipStreamSynchronize(ms));          // lock-step chunks: one sync for all chunks (batch.cpp)

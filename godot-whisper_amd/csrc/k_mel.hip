@@ -36,8 +36,9 @@ void upload_tables() {
 __device__ inline int enc_ordered(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
 __device__ inline float dec_ordered(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
 
-__global__ void k_mel_pad(const float * __restrict__ pcm, int n, float * __restrict__ out, int total) {
+__global__ void k_mel_pad(const float * __restrict__ pcm, int n, float * __restrict__ out, int total, int * __restrict__ gmax) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0 && gmax) *gmax = INT_MIN;     // running maximum of the frame kernel that follows on the stream (was a launch of its own)
     if (i >= total) return;
     float v = 0.0f;
     if (i < 200) {                       // reflect: out[i] = pcm[200 - i]   (W/whisper.cpp:2827)
@@ -274,14 +275,13 @@ __global__ void k_set_int(int * p, int v) { *p = v; }
 
 } // namespace
 
-void mel_pad(const float * pcm, int n_samples, float * pcm_pad, int n_pad_total, hipStream_t st) {
-    hipLaunchKernelGGL(k_mel_pad, dim3((n_pad_total + 255) / 256), dim3(256), 0, st, pcm, n_samples, pcm_pad, n_pad_total);
+void mel_pad(const float * pcm, int n_samples, float * pcm_pad, int n_pad_total, hipStream_t st, int * gmax_reset) {
+    hipLaunchKernelGGL(k_mel_pad, dim3((n_pad_total + 255) / 256), dim3(256), 0, st, pcm, n_samples, pcm_pad, n_pad_total, gmax_reset);
 }
 
 void mel_frames(const float * pcm_pad, int n_valid, int n_fft_frames, int n_len, int n_mel, const float * filters,
                 const int32_t * ranges, const float * taps, float * mel, int * gmax, hipStream_t st) {
     std::call_once(g_tables_once, upload_tables);
-    hipLaunchKernelGGL(k_set_int, dim3(1), dim3(1), 0, st, gmax, INT_MIN);
     if (n_fft_frames > 0)
         hipLaunchKernelGGL(k_mel_frames, dim3(n_fft_frames), dim3(MEL_NT), 0, st, pcm_pad, n_valid, n_fft_frames, n_len, n_mel,
                            filters, ranges, taps, mel, gmax);

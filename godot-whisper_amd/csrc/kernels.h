@@ -21,7 +21,7 @@ __device__ __forceinline__ __half f2h(float x) { return __float2half_rn(pin_f32(
 // ---------------------------------------------------------------- mel (k_mel.hip)
 // pcm_pad: [200 reflect | n_samples | zeros] ; frames [0, n_fft_frames) get an FFT, the rest up to
 // n_len the constant log10(1e-10).  mel: [n_mel][n_len] f32.  gmax: ordered-int encoded running max.
-void mel_pad(const float * pcm, int n_samples, float * pcm_pad, int n_pad_total, hipStream_t st);
+void mel_pad(const float * pcm, int n_samples, float * pcm_pad, int n_pad_total, hipStream_t st, int * gmax_reset);   // also resets mel_frames' gmax
 void mel_frames(const float * pcm_pad, int n_valid, int n_fft_frames, int n_len, int n_mel,
                 const float * filters, const int32_t * ranges, const float * taps, float * mel, int * gmax, hipStream_t st);
 void mel_normalize(float * mel, int n, const int * gmax, hipStream_t st);
