@@ -10,7 +10,9 @@
 //   * GELU and exp go through 65536-entry f16 tables (W/ggml.c:1400-1423, 2222-2235, 11176-11186);
 //   * LayerNorm uses double accumulators (W/ggml.c:9329-9348);
 //   * K/V are stored f16 (W/whisper.cpp:1887-1909, 2057-2066, 2280-2288);
-//   * log-mel follows W/whisper.cpp:2614-2887 step by step (table sin/cos, radix-2 down to 25-point DFT).
+//   * log-mel follows W/whisper.cpp:2614-2887 step by step (table sin/cos, radix-2 down to 25-point DFT);
+//   * block-quantised weights (q4_0 q4_1 q5_0 q5_1 q8_0) stay quantised: activations go to q8 blocks and the dot is the
+//     reference's integer dot with per-block scales (oracle/port_quants.c; W/ggml-quants.c:837-870, 2442-3560).
 //
 // Pinning: tests/test_oracle_port.py checks this file against the compiled reference
 // (oracle/_ref/libwhisper_ref.so) in the build container and against the committed golden vectors
@@ -40,6 +42,14 @@ inline f16   f2h(float f) { return _cvtss_sh(f, 0); }
 
 f16 g_gelu[65536], g_exp[65536];
 extern "C" void port_fill_tables(uint16_t * gelu, uint16_t * expt);   // oracle/port_tables.c (compiled as C, like ggml.c)
+// oracle/port_quants.c (compiled as C with ggml's flags): the reference's block-quantised arithmetic
+extern "C" {
+int   port_q_block_bytes(int type);
+int   port_q_act_has_sum(int type);
+void  port_quantize_row_q8(const float * x, int k, int with_sum, int8_t * qs, float * d, float * s);
+float port_vec_dot_q(int type, int k, const uint8_t * wrow, const int8_t * qs, const float * d, const float * s);
+void  port_dequantize_row(int type, const uint8_t * wrow, float * y, int k);
+}
 void init_tables() {
     static bool done = false;
     if (done) return;
@@ -85,7 +95,7 @@ void row_to_f16(const float * src, f16 * dst, int n) {
     for (; i < n; ++i) dst[i] = f2h(src[i]);
 }
 
-struct Tensor { std::vector<f16> h; std::vector<float> f; int64_t ne[4] = {1, 1, 1, 1}; bool is_f16 = false; };
+struct Tensor { std::vector<f16> h; std::vector<float> f; std::vector<uint8_t> q; int qtype = 0; int64_t ne[4] = {1, 1, 1, 1}; bool is_f16 = false; };
 
 struct Model {
     int n_vocab, n_audio_ctx, S, H, La, n_text_ctx, St, Ht, Lt, n_mels, ftype;
@@ -111,7 +121,12 @@ bool load(const uint8_t * p, size_t n, Model & m) {
         const std::string name((const char *) p + off, nl); off += nl;
         if (tt == 1) { t.is_f16 = true; t.h.resize(ne); memcpy(t.h.data(), p + off, ne * 2); off += ne * 2; }
         else if (tt == 0) { t.f.resize(ne); memcpy(t.f.data(), p + off, ne * 4); off += ne * 4; }
-        else return false;                                     // the port handles f16 / f32 models only
+        else if (port_q_block_bytes(tt) > 0 && ne % 32 == 0) {   // block-quantised 2-D tensor: kept as the file's blocks
+            const size_t nbytes = ne / 32 * (size_t) port_q_block_bytes(tt);
+            if (off + nbytes > n) return false;
+            t.qtype = tt; t.q.assign(p + off, p + off + nbytes); off += nbytes;
+        }
+        else return false;
         m.t[name] = std::move(t);
     }
     return true;
@@ -215,6 +230,8 @@ void matmul_f32act(const Ctx & c, const f16 * W, int N, int K, const float * act
     for (int j = 0; j < M; ++j) row_to_f16(act + (size_t) j * K, a16.data() + (size_t) j * K, K);
     matmul(c, W, N, K, a16.data(), M, out);
 }
+struct Ctx;
+void matmul_w(const Ctx & c, const std::string & name, int N, int K, const float * act, int M, float * out);
 void add_bias(float * x, int M, int N, const float * b) { for (int j = 0; j < M; ++j) for (int i = 0; i < N; ++i) x[(size_t) j * N + i] += b[i]; }
 
 void layernorm(const float * x, int M, int S, const float * g, const float * b, float * y) {
@@ -269,6 +286,21 @@ void attention(const Ctx & c, const float * q, int nq, const f16 * k, const f16 
 const f16 * W16(const Ctx & c, const std::string & n) { return c.m.get(n).h.data(); }
 const float * F32(const Ctx & c, const std::string & n) { return c.m.get(n).f.data(); }
 
+// out[j][i] = W[i][:] . act[j][:] with the reference's operand rule for the weight's type (SURVEY App. B rule 1):
+// f16 weights -> activations rounded to f16; quantised weights -> activations to q8_0 / q8_1 blocks, integer dot
+void matmul_w(const Ctx & c, const std::string & name, int N, int K, const float * act, int M, float * out) {
+    const Tensor & t = c.m.get(name);
+    if (!t.qtype) { matmul_f32act(c, t.h.data(), N, K, act, M, out); return; }
+    const int nb = K / 32, has_s = port_q_act_has_sum(t.qtype);
+    std::vector<int8_t> qs((size_t) M * K); std::vector<float> d((size_t) M * nb), s((size_t) M * nb);
+    for (int j = 0; j < M; ++j) port_quantize_row_q8(act + (size_t) j * K, K, has_s, qs.data() + (size_t) j * K, d.data() + (size_t) j * nb, s.data() + (size_t) j * nb);
+    const size_t rb = (size_t) nb * port_q_block_bytes(t.qtype);
+    parallel_for(M, c.n_threads, [&](int a, int b) {
+        for (int j = a; j < b; ++j) for (int i = 0; i < N; ++i)
+            out[(size_t) j * N + i] = port_vec_dot_q(t.qtype, K, t.q.data() + (size_t) i * rb, qs.data() + (size_t) j * K, d.data() + (size_t) j * nb, s.data() + (size_t) j * nb);
+    });
+}
+
 // ------------------------------------------------------------------------------------------------ encoder
 void encode(Ctx & c, int mel_offset, int audio_ctx) {
     init_tables();
@@ -315,18 +347,18 @@ void encode(Ctx & c, int mel_offset, int audio_ctx) {
     for (int il = 0; il < m.La; ++il) {
         const std::string p = "encoder.blocks." + std::to_string(il) + ".";
         layernorm(x.data(), T, S, F32(c, p + "attn_ln.weight"), F32(c, p + "attn_ln.bias"), xn.data());
-        matmul_f32act(c, W16(c, p + "attn.query.weight"), S, S, xn.data(), T, q.data());  add_bias(q.data(), T, S, F32(c, p + "attn.query.bias"));
-        matmul_f32act(c, W16(c, p + "attn.key.weight"),   S, S, xn.data(), T, kf.data());
-        matmul_f32act(c, W16(c, p + "attn.value.weight"), S, S, xn.data(), T, vf.data()); add_bias(vf.data(), T, S, F32(c, p + "attn.value.bias"));
+        matmul_w(c, p + "attn.query.weight", S, S, xn.data(), T, q.data());  add_bias(q.data(), T, S, F32(c, p + "attn.query.bias"));
+        matmul_w(c, p + "attn.key.weight",   S, S, xn.data(), T, kf.data());
+        matmul_w(c, p + "attn.value.weight", S, S, xn.data(), T, vf.data()); add_bias(vf.data(), T, S, F32(c, p + "attn.value.bias"));
         for (int t = 0; t < T; ++t) row_to_f16(kf.data() + (size_t) t * S, k16.data() + (size_t) t * S, S);
         for (int t = 0; t < T; ++t) for (int s = 0; s < S; ++s) vt16[(size_t) s * T + t] = f2h(vf[(size_t) t * S + s]);
         attention(c, q.data(), T, k16.data(), vt16.data(), T, T, S, H, kq, nullptr, att.data());
-        matmul_f32act(c, W16(c, p + "attn.out.weight"), S, S, att.data(), T, tmp.data()); add_bias(tmp.data(), T, S, F32(c, p + "attn.out.bias"));
+        matmul_w(c, p + "attn.out.weight", S, S, att.data(), T, tmp.data()); add_bias(tmp.data(), T, S, F32(c, p + "attn.out.bias"));
         for (size_t i = 0; i < x.size(); ++i) x[i] = tmp[i] + x[i];
         layernorm(x.data(), T, S, F32(c, p + "mlp_ln.weight"), F32(c, p + "mlp_ln.bias"), xn.data());
-        matmul_f32act(c, W16(c, p + "mlp.0.weight"), 4 * S, S, xn.data(), T, h1.data()); add_bias(h1.data(), T, 4 * S, F32(c, p + "mlp.0.bias"));
+        matmul_w(c, p + "mlp.0.weight", 4 * S, S, xn.data(), T, h1.data()); add_bias(h1.data(), T, 4 * S, F32(c, p + "mlp.0.bias"));
         for (float & v : h1) v = gelu_tab(v);
-        matmul_f32act(c, W16(c, p + "mlp.2.weight"), S, 4 * S, h1.data(), T, tmp.data()); add_bias(tmp.data(), T, S, F32(c, p + "mlp.2.bias"));
+        matmul_w(c, p + "mlp.2.weight", S, 4 * S, h1.data(), T, tmp.data()); add_bias(tmp.data(), T, S, F32(c, p + "mlp.2.bias"));
         for (size_t i = 0; i < x.size(); ++i) x[i] = tmp[i] + x[i];
     }
     c.embd_enc.assign((size_t) T * S, 0.0f);
@@ -336,9 +368,9 @@ void encode(Ctx & c, int mel_offset, int audio_ctx) {
     const float ks = powf((float) S / H, -0.25f);
     for (int il = 0; il < m.Lt; ++il) {
         const std::string p = "decoder.blocks." + std::to_string(il) + ".";
-        matmul_f32act(c, W16(c, p + "cross_attn.key.weight"), S, S, c.embd_enc.data(), T, kf.data());
+        matmul_w(c, p + "cross_attn.key.weight", S, S, c.embd_enc.data(), T, kf.data());
         for (float & v : kf) v *= ks;
-        matmul_f32act(c, W16(c, p + "cross_attn.value.weight"), S, S, c.embd_enc.data(), T, vf.data()); add_bias(vf.data(), T, S, F32(c, p + "cross_attn.value.bias"));
+        matmul_w(c, p + "cross_attn.value.weight", S, S, c.embd_enc.data(), T, vf.data()); add_bias(vf.data(), T, S, F32(c, p + "cross_attn.value.bias"));
         row_to_f16(kf.data(), c.cross_k.data() + (size_t) il * T * S, T * S);
         row_to_f16(vf.data(), c.cross_v.data() + (size_t) il * T * S, T * S);
     }
@@ -352,8 +384,17 @@ void decode(Ctx & c, const int32_t * tokens, int n, int n_past) {
     const int S = m.St, H = m.Ht, NV = m.n_vocab, NC = m.n_text_ctx, T = c.T;
     if (c.self_k.empty()) { c.self_k.assign((size_t) m.Lt * NC * S, 0); c.self_v.assign((size_t) m.Lt * NC * S, 0); }
     const int n_kv = n_past + n;
-    const f16 * te = W16(c, "decoder.token_embedding.weight"); const float * pe = F32(c, "decoder.positional_embedding");
+    const Tensor & tte = c.m.get("decoder.token_embedding.weight");
+    const f16 * te = tte.h.data(); const float * pe = F32(c, "decoder.positional_embedding");
     std::vector<float> x((size_t) n * S), xn((size_t) n * S), q((size_t) n * S), kf((size_t) n * S), vf((size_t) n * S), att((size_t) n * S), tmp((size_t) n * S), h1((size_t) n * 4 * S);
+    if (tte.qtype) {                                            // get_rows on a quantised matrix: the row dequantised to f32
+        const size_t rb = (size_t) (S / 32) * port_q_block_bytes(tte.qtype);
+        std::vector<float> row(S);
+        for (int j = 0; j < n; ++j) {
+            port_dequantize_row(tte.qtype, tte.q.data() + (size_t) tokens[j] * rb, row.data(), S);
+            for (int s = 0; s < S; ++s) x[(size_t) j * S + s] = row[s] + pe[(size_t) (n_past + j) * S + s];
+        }
+    } else
     for (int j = 0; j < n; ++j) for (int s = 0; s < S; ++s) x[(size_t) j * S + s] = h2f(te[(size_t) tokens[j] * S + s]) + pe[(size_t) (n_past + j) * S + s];
     std::vector<float> mask((size_t) n * n_kv, 0.0f);
     for (int j = 0; j < n; ++j) for (int i = 0; i < n_kv; ++i) if (i > n_past + j) mask[(size_t) j * n_kv + i] = -INFINITY;
@@ -363,38 +404,46 @@ void decode(Ctx & c, const int32_t * tokens, int n, int n_past) {
         const std::string p = "decoder.blocks." + std::to_string(il) + ".";
         f16 * ck = c.self_k.data() + (size_t) il * NC * S, * cv = c.self_v.data() + (size_t) il * NC * S;
         layernorm(x.data(), n, S, F32(c, p + "attn_ln.weight"), F32(c, p + "attn_ln.bias"), xn.data());
-        matmul_f32act(c, W16(c, p + "attn.query.weight"), S, S, xn.data(), n, q.data()); add_bias(q.data(), n, S, F32(c, p + "attn.query.bias"));
+        matmul_w(c, p + "attn.query.weight", S, S, xn.data(), n, q.data()); add_bias(q.data(), n, S, F32(c, p + "attn.query.bias"));
         for (float & v : q) v *= ks;
-        matmul_f32act(c, W16(c, p + "attn.key.weight"), S, S, xn.data(), n, kf.data());
+        matmul_w(c, p + "attn.key.weight", S, S, xn.data(), n, kf.data());
         for (float & v : kf) v *= ks;
-        matmul_f32act(c, W16(c, p + "attn.value.weight"), S, S, xn.data(), n, vf.data()); add_bias(vf.data(), n, S, F32(c, p + "attn.value.bias"));
+        matmul_w(c, p + "attn.value.weight", S, S, xn.data(), n, vf.data()); add_bias(vf.data(), n, S, F32(c, p + "attn.value.bias"));
         row_to_f16(kf.data(), ck + (size_t) n_past * S, n * S);
         row_to_f16(vf.data(), cv + (size_t) n_past * S, n * S);
         vt.assign((size_t) S * n_kv, 0);
         for (int i = 0; i < n_kv; ++i) for (int s = 0; s < S; ++s) vt[(size_t) s * n_kv + i] = cv[(size_t) i * S + s];
         attention(c, q.data(), n, ck, vt.data(), n_kv, n_kv, S, H, 1.0f, mask.data(), att.data());
-        matmul_f32act(c, W16(c, p + "attn.out.weight"), S, S, att.data(), n, tmp.data()); add_bias(tmp.data(), n, S, F32(c, p + "attn.out.bias"));
+        matmul_w(c, p + "attn.out.weight", S, S, att.data(), n, tmp.data()); add_bias(tmp.data(), n, S, F32(c, p + "attn.out.bias"));
         for (size_t i = 0; i < x.size(); ++i) x[i] = tmp[i] + x[i];
         layernorm(x.data(), n, S, F32(c, p + "cross_attn_ln.weight"), F32(c, p + "cross_attn_ln.bias"), xn.data());
-        matmul_f32act(c, W16(c, p + "cross_attn.query.weight"), S, S, xn.data(), n, q.data()); add_bias(q.data(), n, S, F32(c, p + "cross_attn.query.bias"));
+        matmul_w(c, p + "cross_attn.query.weight", S, S, xn.data(), n, q.data()); add_bias(q.data(), n, S, F32(c, p + "cross_attn.query.bias"));
         for (float & v : q) v *= ks;
         vt.assign((size_t) S * T, 0);
         const f16 * xv = c.cross_v.data() + (size_t) il * T * S;
         for (int i = 0; i < T; ++i) for (int s = 0; s < S; ++s) vt[(size_t) s * T + i] = xv[(size_t) i * S + s];
         attention(c, q.data(), n, c.cross_k.data() + (size_t) il * T * S, vt.data(), T, T, S, H, 1.0f, nullptr, att.data());
-        matmul_f32act(c, W16(c, p + "cross_attn.out.weight"), S, S, att.data(), n, tmp.data()); add_bias(tmp.data(), n, S, F32(c, p + "cross_attn.out.bias"));
+        matmul_w(c, p + "cross_attn.out.weight", S, S, att.data(), n, tmp.data()); add_bias(tmp.data(), n, S, F32(c, p + "cross_attn.out.bias"));
         for (size_t i = 0; i < x.size(); ++i) x[i] = tmp[i] + x[i];
         layernorm(x.data(), n, S, F32(c, p + "mlp_ln.weight"), F32(c, p + "mlp_ln.bias"), xn.data());
-        matmul_f32act(c, W16(c, p + "mlp.0.weight"), 4 * S, S, xn.data(), n, h1.data()); add_bias(h1.data(), n, 4 * S, F32(c, p + "mlp.0.bias"));
+        matmul_w(c, p + "mlp.0.weight", 4 * S, S, xn.data(), n, h1.data()); add_bias(h1.data(), n, 4 * S, F32(c, p + "mlp.0.bias"));
         for (float & v : h1) v = gelu_tab(v);
-        matmul_f32act(c, W16(c, p + "mlp.2.weight"), S, 4 * S, h1.data(), n, tmp.data()); add_bias(tmp.data(), n, S, F32(c, p + "mlp.2.bias"));
+        matmul_w(c, p + "mlp.2.weight", S, 4 * S, h1.data(), n, tmp.data()); add_bias(tmp.data(), n, S, F32(c, p + "mlp.2.bias"));
         for (size_t i = 0; i < x.size(); ++i) x[i] = tmp[i] + x[i];
     }
     layernorm(x.data(), n, S, F32(c, "decoder.ln.weight"), F32(c, "decoder.ln.bias"), xn.data());
     // logits of the last row only (the reference computes all rows and copies out the flagged one)
-    std::vector<f16> a16(S); row_to_f16(xn.data() + (size_t) (n - 1) * S, a16.data(), S);
     c.logits.resize(NV);
+    if (tte.qtype) {
+        const int nb = S / 32, has_s = port_q_act_has_sum(tte.qtype);
+        std::vector<int8_t> qs(S); std::vector<float> d(nb), sa(nb);
+        port_quantize_row_q8(xn.data() + (size_t) (n - 1) * S, S, has_s, qs.data(), d.data(), sa.data());
+        const size_t rb = (size_t) nb * port_q_block_bytes(tte.qtype);
+        parallel_for(NV, c.n_threads, [&](int a, int b) { for (int i = a; i < b; ++i) c.logits[i] = port_vec_dot_q(tte.qtype, S, tte.q.data() + (size_t) i * rb, qs.data(), d.data(), sa.data()); });
+    } else {
+    std::vector<f16> a16(S); row_to_f16(xn.data() + (size_t) (n - 1) * S, a16.data(), S);
     parallel_for(NV, c.n_threads, [&](int a, int b) { for (int i = a; i < b; ++i) c.logits[i] = dot_f16(S, te + (size_t) i * S, a16.data()); });
+    }
     c.n_past = n_past + n;
 }
 
