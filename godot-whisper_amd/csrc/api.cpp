@@ -465,6 +465,55 @@ double wmi_selftest_proj(struct whisper_context * ctx, int op, int n, int layer)
     return worst;
 }
 
+int wmi_selftest_quant(int device, int qtype, int mode, const void * w_blocks, const float * x, const int32_t * tokens,
+                       int M, int N, int K, float * out, int8_t * out_qs, float * out_ds) {
+    const k::QGeom g = k::q_geom(qtype);
+    if (!g.qb || M < 1 || N < 1 || K < 64 || (K % 64) != 0 || !w_blocks || !out) return -1;
+    if ((mode == 0 && M > 32) || (mode == 1 && (N % 128) != 0) || mode < 0 || mode > 2 || (mode == 2 ? !tokens : !x)) return -1;
+    if (!HIP_OK(hipSetDevice(device))) return -2;
+    const int nb = K / 32;
+    std::vector<uint8_t> tiles(k::q_matrix_bytes(qtype, N, K));
+    k::q_repack_host(qtype, (const uint8_t *) w_blocks, N, K, tiles.data());
+    uint8_t * d_t = nullptr; float * d_x = nullptr, * d_o = nullptr, * d_z = nullptr; int8_t * d_qs = nullptr; float2 * d_ds = nullptr; int32_t * d_tok = nullptr;
+    const size_t n_out = (size_t) M * (mode == 2 ? K : N);
+    bool ok = HIP_OK(hipMalloc((void **) &d_t, tiles.size() + 4096)) && HIP_OK(hipMalloc((void **) &d_x, (size_t) M * K * 4)) &&
+              HIP_OK(hipMalloc((void **) &d_o, n_out * 4)) && HIP_OK(hipMalloc((void **) &d_z, n_out * 4)) &&
+              HIP_OK(hipMalloc((void **) &d_qs, (size_t) M * K)) && HIP_OK(hipMalloc((void **) &d_ds, (size_t) M * nb * 8)) &&
+              HIP_OK(hipMalloc((void **) &d_tok, (size_t) M * 4 * 2));
+    hipStream_t st = nullptr;
+    ok = ok && HIP_OK(hipStreamCreate(&st));
+    if (ok) {
+        ok = HIP_OK(hipMemcpy(d_t, tiles.data(), tiles.size(), hipMemcpyHostToDevice)) && HIP_OK(hipMemset(d_z, 0, n_out * 4)) && HIP_OK(hipMemset(d_o, 0, n_out * 4));
+        if (x) ok = ok && HIP_OK(hipMemcpy(d_x, x, (size_t) M * K * 4, hipMemcpyHostToDevice));
+        const k::QMat W{d_t, qtype};
+        if (ok && mode == 2) {
+            std::vector<int32_t> tp((size_t) 2 * M, 0);
+            for (int i = 0; i < M; ++i) tp[i] = tokens[i];
+            ok = HIP_OK(hipMemcpy(d_tok, tp.data(), tp.size() * 4, hipMemcpyHostToDevice));
+            k::qdec_embed(d_tok, d_tok + M, M, K, W, d_z, d_o, st);           // "positional embedding" = zeros
+        } else if (ok) {
+            const k::Q8Rows A{d_qs, d_ds};
+            k::quantize_rows(d_x, nullptr, M, K, nullptr, nullptr, 0.f, qtype, A, nullptr, nullptr, st);
+            if (mode == 0) {
+                k::GemvArgs ga{};
+                ga.n = M; ga.K = K; ga.N = N; ga.epi = k::EPI_LOGITS; ga.C = d_o; ga.ldc = N;
+                k::qrows(ga, d_x, W, st);
+            } else {
+                k::GemmArgs a{};
+                a.M = M; a.N = N; a.K = K; a.C = d_o; a.ldc = N; a.resid = d_z; a.ldr = N;
+                k::qgemm(k::EPI_F32_BIAS_RESID, a, A, W, st);
+            }
+        }
+        ok = ok && HIP_OK(hipStreamSynchronize(st)) && HIP_OK(hipGetLastError());
+        ok = ok && HIP_OK(hipMemcpy(out, d_o, n_out * 4, hipMemcpyDeviceToHost));
+        if (ok && mode != 2 && out_qs) ok = HIP_OK(hipMemcpy(out_qs, d_qs, (size_t) M * K, hipMemcpyDeviceToHost));
+        if (ok && mode != 2 && out_ds) ok = HIP_OK(hipMemcpy(out_ds, d_ds, (size_t) M * nb * 8, hipMemcpyDeviceToHost));
+    }
+    if (st) (void) hipStreamDestroy(st);
+    (void) hipFree(d_t); (void) hipFree(d_x); (void) hipFree(d_o); (void) hipFree(d_z); (void) hipFree(d_qs); (void) hipFree(d_ds); (void) hipFree(d_tok);
+    return ok ? 0 : -3;
+}
+
 double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters) {
     (void) hipSetDevice(ctx->device);
     State & st = *ctx->state; DeviceState & d = st.dev; const HParams & hp = ctx->model.hp; const Weights & w = ctx->w;

@@ -1,0 +1,825 @@
+// Block-quantised weights on gfx950 (BASELINE configs[4]: large-v3 q5_1).
+//
+// The reference's arithmetic for a mul_mat whose weight operand is q4_0 / q4_1 / q5_0 / q5_1 / q8_0
+// (W/ggml.c:9841-9857 + type table :397-583; W/ggml-quants.c:837-870 row quantiser, :2442-3560 dots):
+//
+//   activations  every f32 row -> q8 blocks of 32: d = amax / 127, q = rne(x * (127 / amax)), q8_1 also s = d * sum(q)
+//                (the q8_0 kinds store d as f16)
+//   dot          per block  isum = sum_k w_k * q_k  (integers),  out += isum * (d_w * d_a)  [+ m_w * s_a]
+//
+// Kept here: the weights stay in their 18..34-byte blocks in HBM (2.7x fewer bytes per decoded token than the f16
+// expansion of round 1), the activation rows are quantised with the reference's own formula, and the block dot runs on
+// v_mfma_i32_32x32x32_i8 — its K is exactly one block, so isum is exact; what is left in floating point is the same
+// per-block f32 scale-and-add the reference does (its AVX2 body keeps eight partial sums per output and adds them at
+// the end; here there is one — an f32 rounding-order difference of ~1e-6 relative, measured in
+// tests/test_oracle_quants.py).
+//
+// Kernels:
+//   k_q8_rows   rows (f32, LayerNorm(f32) or f16) -> q8 blocks in global memory (the GEMM's A operand)      HBM-bound
+//   k_qgemm     C = A_q8 . W_q^T, 128 x 128 x 64 tiles, A via global_load_lds, W tiles unpacked to int8 in LDS   VALU-bound:
+//               each 32 x 32 x 32 MFMA (8 passes) is followed by 16 x (cvt, mul, fma) per lane to apply d_w * d_a;
+//               the m_w * s_a terms of a K step go through one v_mfma_f32_32x32x2_f32 per output tile
+//   k_qrows     <= 32 activation rows (a decode step, a beam, lock-step chunks): weight tiles streamed once from HBM,
+//               rows quantised in the prologue, K split over the wavefronts of a workgroup                  HBM-bound
+//   k_qembed    token embedding gather with dequantisation
+
+#include "kernels.h"
+
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+namespace wmi { namespace k {
+
+QGeom q_geom(int qtype) {
+    switch (qtype) {
+        case QT_Q4_0: return {16, 4, 18, false};
+        case QT_Q4_1: return {16, 4, 20, true};
+        case QT_Q5_0: return {16, 8, 22, false};
+        case QT_Q5_1: return {16, 8, 24, true};
+        case QT_Q8_0: return {32, 4, 34, false};
+        default:      return {0, 0, 0, false};
+    }
+}
+
+void q_repack_host(int qtype, const uint8_t * src, int64_t N, int64_t K, uint8_t * dst) {
+    const QGeom g = q_geom(qtype);
+    const int64_t nb = K / 32, np = K / 64, ntn = (N + 31) / 32;
+    const size_t tile = q_tile_bytes(qtype);
+    memset(dst, 0, (size_t) ntn * np * tile);
+    for (int64_t n = 0; n < N; ++n) {
+        const int64_t tn = n / 32, nl = n % 32;
+        for (int64_t b = 0; b < nb; ++b) {
+            const uint8_t * s = src + ((size_t) n * nb + b) * g.file_bytes;
+            const int64_t tp = b / 2, lane = nl + 32 * (b % 2);
+            uint8_t * t = dst + ((size_t) tn * np + tp) * tile;
+            uint8_t * qs = t + (size_t) lane * g.qb, * hd = t + (size_t) 64 * g.qb + (size_t) lane * g.hb;
+            switch (qtype) {
+                case QT_Q4_0: memcpy(hd, s, 2);                         memcpy(qs, s + 2, 16); break;
+                case QT_Q4_1: memcpy(hd, s, 4);                         memcpy(qs, s + 4, 16); break;
+                case QT_Q5_0: memcpy(hd, s, 2); memcpy(hd + 4, s + 2, 4); memcpy(qs, s + 6, 16); break;
+                case QT_Q5_1: memcpy(hd, s, 8);                         memcpy(qs, s + 8, 16); break;
+                case QT_Q8_0: memcpy(hd, s, 2);                         memcpy(qs, s + 2, 32); break;
+                default: break;
+            }
+        }
+    }
+}
+
+namespace {
+
+typedef int      intx4  __attribute__((ext_vector_type(4)));
+typedef int      intx16 __attribute__((ext_vector_type(16)));
+typedef float    floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float round_f16(float x) { return __half2float(f2h(x)); }
+__device__ __forceinline__ float gelu16(float x) {
+    const float xh = round_f16(x);
+    const float g  = 0.5f * xh * (1.0f + tanhf(0.79788456080286535587989211986876f * xh * (1.0f + 0.044715f * xh * xh)));
+    return round_f16(g);
+}
+__device__ __forceinline__ float gelu16_fast(float x) {          // k_gemm.hip: the encoder GEMMs' form
+    const float xh = round_f16(x);
+    const float u  = 0.79788456080286535587989211986876f * xh * (1.0f + 0.044715f * xh * xh);
+    const float t  = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * u) + 1.0f);
+    return round_f16(0.5f * xh * (1.0f + t));
+}
+
+// ------------------------------------------------------------------------------------------------ block unpacking
+template <int QT> struct Geo;
+template <> struct Geo<QT_Q4_0> { static constexpr int QW = 4, HW = 1; static constexpr bool M = false, F16D = true;  };
+template <> struct Geo<QT_Q4_1> { static constexpr int QW = 4, HW = 1; static constexpr bool M = true,  F16D = false; };
+template <> struct Geo<QT_Q5_0> { static constexpr int QW = 4, HW = 2; static constexpr bool M = false, F16D = true;  };
+template <> struct Geo<QT_Q5_1> { static constexpr int QW = 4, HW = 2; static constexpr bool M = true,  F16D = false; };
+template <> struct Geo<QT_Q8_0> { static constexpr int QW = 8, HW = 1; static constexpr bool M = false, F16D = true;  };
+template <int QT> constexpr int tile_bytes() { return 64 * 4 * (Geo<QT>::QW + Geo<QT>::HW); }
+
+// bits 0..3 of x -> bit 4 of bytes 0..3 (the fifth bit of four q5 quants)
+__device__ __forceinline__ uint32_t spread4(uint32_t x) { return ((__umul24(x & 0xFu, 0x00204081u)) & 0x01010101u) << 4; }
+
+// one block -> 32 signed 8-bit integers: lo = elements 0..15, hi = elements 16..31 (four per dword, element order);
+// d, m as f32 (m = 0 for the symmetric kinds)
+template <int QT>
+__device__ __forceinline__ void unpack(const uint32_t (&qs)[Geo<QT>::QW], const uint32_t (&hd)[Geo<QT>::HW],
+                                       uint32_t (&lo)[4], uint32_t (&hi)[4], float & d, float & m) {
+    const __half2 dm = *(const __half2 *) &hd[0];
+    d = __low2float(dm); m = Geo<QT>::M ? __high2float(dm) : 0.0f;
+    if constexpr (QT == QT_Q8_0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { lo[i] = qs[i]; hi[i] = qs[4 + i]; }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint32_t l = qs[i] & 0x0F0F0F0Fu, h = (qs[i] >> 4) & 0x0F0F0F0Fu;
+            if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) {
+                const uint32_t qh = hd[1];
+                l |= spread4(qh >> (4 * i)); h |= spread4(qh >> (16 + 4 * i));
+            }
+            if constexpr (QT == QT_Q4_0) {           // x - 8: flip bit 3 (offset binary -> two's complement), sign-extend the nibble
+                l ^= 0x08080808u; h ^= 0x08080808u;
+                const uint32_t sl = l & 0x08080808u, sh = h & 0x08080808u;
+                l |= (sl << 1) | (sl << 2) | (sl << 3) | (sl << 4); h |= (sh << 1) | (sh << 2) | (sh << 3) | (sh << 4);
+            }
+            if constexpr (QT == QT_Q5_0) {           // x - 16: flip bit 4, sign-extend the 5-bit value
+                l ^= 0x10101010u; h ^= 0x10101010u;
+                const uint32_t sl = l & 0x10101010u, sh = h & 0x10101010u;
+                l |= (sl << 1) | (sl << 2) | (sl << 3); h |= (sh << 1) | (sh << 2) | (sh << 3);
+            }
+            lo[i] = l; hi[i] = h;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ row quantiser
+// Four consecutive values of a row per lane; a q8 block = 8 consecutive lanes.  Returns the packed quants, d (as the
+// dot will use it) and s.  The reference's AVX2 body: d = amax / 127, id = 127 / amax, round to nearest even.
+template <bool F16D>
+__device__ __forceinline__ uint32_t quant4(float y0, float y1, float y2, float y3, float & d_out, float & s_out) {
+    float amax = fmaxf(fmaxf(fabsf(y0), fabsf(y1)), fmaxf(fabsf(y2), fabsf(y3)));
+    amax = fmaxf(amax, __shfl_xor(amax, 1)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 4));
+    const float d  = amax / 127.0f;
+    const float id = amax != 0.0f ? 127.0f / amax : 0.0f;
+    const int q0 = (int) rintf(y0 * id), q1 = (int) rintf(y1 * id), q2 = (int) rintf(y2 * id), q3 = (int) rintf(y3 * id);
+    int sum = (q0 + q1) + (q2 + q3);
+    sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+    if (F16D) { d_out = round_f16(d); s_out = 0.0f; }
+    else      { d_out = d; s_out = d * (float) sum; }
+    return (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
+}
+
+// LayerNorm of a row held as MAXV float4 per lane (columns (i * 64 + lane) * 4), k_norm.hip's arithmetic
+template <int MAXV>
+__device__ __forceinline__ void ln_inplace(float4 (&v)[MAXV], const float4 (&gg)[MAXV], const float4 (&bb)[MAXV], int S, float eps, int lane) {
+    float sum = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < S) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float) S;
+    float sq = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < S) {
+            v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+            sq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+        }
+    }
+    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    const float scale = 1.0f / sqrtf(sq / (float) S + eps);
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) {
+        const int c = (i * 64 + lane) * 4;
+        if (c < S) {
+            v[i].x = __fadd_rn(__fmul_rn(v[i].x * scale, gg[i].x), bb[i].x);
+            v[i].y = __fadd_rn(__fmul_rn(v[i].y * scale, gg[i].y), bb[i].y);
+            v[i].z = __fadd_rn(__fmul_rn(v[i].z * scale, gg[i].z), bb[i].z);
+            v[i].w = __fadd_rn(__fmul_rn(v[i].w * scale, gg[i].w), bb[i].w);
+        }
+    }
+}
+
+// SRC: 0 = f32 rows, 1 = LayerNorm of f32 rows (K <= 256 * MAXV), 2 = f16 rows
+template <int MAXV, int SRC, bool F16D>
+__global__ __launch_bounds__(256) void k_q8_rows(const float * __restrict__ x32, const __half * __restrict__ x16, int M, int K,
+                                                 const float * __restrict__ g, const float * __restrict__ b, float eps,
+                                                 int8_t * __restrict__ qs, float2 * __restrict__ ds,
+                                                 float * __restrict__ out32, __half * __restrict__ out16) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const int nb = K >> 5;
+    if constexpr (SRC == 1) {
+        const float * xr = x32 + (size_t) row * K;
+        float4 v[MAXV], gg[MAXV], bb[MAXV];
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (i * 64 + lane) * 4, cc = c < K ? c : 0;
+            v[i] = *(const float4 *) (xr + cc); gg[i] = *(const float4 *) (g + cc); bb[i] = *(const float4 *) (b + cc);
+        }
+        ln_inplace<MAXV>(v, gg, bb, K, eps, lane);
+#pragma unroll
+        for (int i = 0; i < MAXV; ++i) {
+            const int c = (i * 64 + lane) * 4;
+            float d, s;
+            const uint32_t q = quant4<F16D>(v[i].x, v[i].y, v[i].z, v[i].w, d, s);        // all lanes shuffle; columns past K hold zeros
+            if (c < K) {
+                *(uint32_t *) (qs + (size_t) row * K + c) = q;
+                if ((lane & 7) == 0) ds[(size_t) row * nb + (c >> 5)] = make_float2(d, s);
+                if (out32) *(float4 *) (out32 + (size_t) row * K + c) = v[i];
+                if (out16) {
+                    __half2 h01 = __floats2half2_rn(pin_f32(v[i].x), pin_f32(v[i].y)), h23 = __floats2half2_rn(pin_f32(v[i].z), pin_f32(v[i].w));
+                    uint2 pk; pk.x = *(uint32_t *) &h01; pk.y = *(uint32_t *) &h23;
+                    *(uint2 *) (out16 + (size_t) row * K + c) = pk;
+                }
+            }
+        }
+    } else {
+        for (int c0 = 0; c0 < K; c0 += 256 * MAXV) {
+            float4 v[MAXV];
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int c = c0 + (i * 64 + lane) * 4, cc = c < K ? c : 0;
+                if constexpr (SRC == 0) v[i] = *(const float4 *) (x32 + (size_t) row * K + cc);
+                else {
+                    const uint2 u = *(const uint2 *) (x16 + (size_t) row * K + cc);
+                    const float2 a = __half22float2(*(const __half2 *) &u.x), bq = __half22float2(*(const __half2 *) &u.y);
+                    v[i] = make_float4(a.x, a.y, bq.x, bq.y);
+                }
+                if (c >= K) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int c = c0 + (i * 64 + lane) * 4;
+                float d, s;
+                const uint32_t q = quant4<F16D>(v[i].x, v[i].y, v[i].z, v[i].w, d, s);
+                if (c < K) {
+                    *(uint32_t *) (qs + (size_t) row * K + c) = q;
+                    if ((lane & 7) == 0) ds[(size_t) row * nb + (c >> 5)] = make_float2(d, s);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ GEMM
+// LDS image of an operand tile: [rows][64 bytes] int8, the 16-byte chunk c of row r stored at slot c ^ ((r >> 2) & 3):
+// the MFMA fragment read (lane = (row, k half): 16 bytes) is then conflict-free per 16-lane group of ds_read_b128.
+__device__ __forceinline__ uint32_t q_lds_off(int row, int chunk) { return (uint32_t) (row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4)); }
+
+// shared epilogue of k_qgemm: element (m, n) of the accumulator, by kind
+template <int EPI, bool GUARD>
+__device__ __forceinline__ void q_store(const GemmArgs & a, int m, int n, float v, float bias, float rpre) {
+    if (GUARD && m >= a.M) return;
+    if constexpr (EPI == EPI_F16_BIAS)            ((__half *) a.C)[(size_t) m * a.ldc + n] = f2h(v + bias);
+    else if constexpr (EPI == EPI_F16_BIAS_GELU)  ((__half *) a.C)[(size_t) m * a.ldc + n] = f2h(gelu16_fast(v + bias));
+    else if constexpr (EPI == EPI_F32_BIAS_RESID) ((float *) a.C)[(size_t) m * a.ldc + n] = (v + bias) + rpre;
+    else if constexpr (EPI == EPI_Q_SCALED)       ((__half *) a.C)[(size_t) m * a.ldc + n] = f2h((v + bias) * a.scale);
+    else if constexpr (EPI == EPI_CROSS_KV) {
+        const int il = n / (2 * a.S), c = n - il * 2 * a.S;
+        if (c < a.S) ((__half *) a.C)[il * a.layer_stride + (size_t) m * a.ldc + c] = f2h(v * a.scale);
+        else         ((__half *) a.aux)[il * a.layer_stride + (size_t) m * a.ldaux + (c - a.S)] = f2h(v + bias);
+    }
+}
+
+template <int QT, int BM, int EPI>
+__global__ __launch_bounds__(256) void k_qgemm(const GemmArgs a, const int8_t * __restrict__ Aq, const float2 * __restrict__ Ads,
+                                               const uint8_t * __restrict__ Wt) {
+    constexpr int BN = 128;
+    constexpr int FM = BM / 64, FN = 2;                    // 32 x 32 fragments per wavefront (2 x 2 wavefronts)
+    constexpr int QW = Geo<QT>::QW, HW = Geo<QT>::HW;
+    constexpr bool HAS_M = Geo<QT>::M;
+    // one stage: A int8 [BM][64] | B int8 [BN][64] | A scales d [2][BM], s [2][BM] | B scales d [2][BN], m [2][BN]
+    constexpr int OFF_B = BM * 64, OFF_AD = OFF_B + BN * 64, OFF_AS = OFF_AD + 2 * BM * 4, OFF_BD = OFF_AS + 2 * BM * 4,
+                  OFF_BM = OFF_BD + 2 * BN * 4, STAGE = OFF_BM + 2 * BN * 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN, nwg = ntm * ntn;
+    int wg = blockIdx.x;
+    {   // XCD-aware tile order (k_gemm.hip): an XCD's L2 sees a contiguous run of tiles sharing A panels
+        const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, idx = wg / 8;
+        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = wg / ntn, tn = wg % ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int np = a.K >> 6, nb = a.K >> 5;
+
+    // A quants: pieces of 16 rows x 64 B go global -> LDS directly; lane p of a piece fetches the chunk that belongs at position p
+    constexpr int PA = BM / 64;                             // pieces per wavefront
+    const int8_t * qA[PA];
+#pragma unroll
+    for (int p = 0; p < PA; ++p) {
+        const int lrow = (wave * PA + p) * 16 + (lane >> 2), ch = (lane & 3) ^ ((lrow >> 2) & 3);
+        int r = m0 + lrow; if (r > a.M - 1) r = a.M - 1;
+        qA[p] = Aq + (size_t) r * a.K + ch * 16;
+    }
+    // A scales: thread -> (row, block of the pair)
+    const int srow = tid % BM, sblk = tid / BM;              // BM = 128: 256 threads = 128 rows x 2 blocks; BM = 64: threads < 128
+    const bool sact = tid < 2 * BM;
+    const float2 * gS; { int r = m0 + srow; if (r > a.M - 1) r = a.M - 1; gS = Ads + (size_t) r * nb + sblk; }
+    // B: wavefront w owns row group (n0 / 32 + w) of the tile
+    const uint8_t * gW = Wt + ((size_t) (n0 / 32 + wave) * np) * tile_bytes<QT>();
+
+    uint32_t rq[QW], rh[HW]; float2 rs = make_float2(0.f, 0.f);
+    auto issue_a = [&](int kt, int buf) {
+#pragma unroll
+        for (int p = 0; p < PA; ++p)
+            __builtin_amdgcn_global_load_lds((const void *) (qA[p] + kt * 64), (__attribute__((address_space(3))) void *) (smem + buf * STAGE + (wave * PA + p) * 1024), 16, 0, 0);
+    };
+    auto load_b = [&](int kt) {
+        const uint8_t * t = gW + (size_t) kt * tile_bytes<QT>();
+        if constexpr (QW == 4) { const uint4 u = *(const uint4 *) (t + lane * 16); rq[0] = u.x; rq[1] = u.y; rq[2] = u.z; rq[3] = u.w; }
+        else { const uint4 u = *(const uint4 *) (t + lane * 32), w = *(const uint4 *) (t + lane * 32 + 16);
+               rq[0] = u.x; rq[1] = u.y; rq[2] = u.z; rq[3] = u.w; rq[4] = w.x; rq[5] = w.y; rq[6] = w.z; rq[7] = w.w; }
+        if constexpr (HW == 2) { const uint2 h = *(const uint2 *) (t + 64 * QW * 4 + lane * 8); rh[0] = h.x; rh[1] = h.y; }
+        else rh[0] = *(const uint32_t *) (t + 64 * QW * 4 + lane * 4);
+        if (sact) rs = gS[2 * kt];
+    };
+    auto store_b = [&](int buf) {
+        unsigned char * st = smem + buf * STAGE;
+        uint32_t lo[4], hi[4]; float d, m;
+        unpack<QT>(rq, rh, lo, hi, d, m);
+        const int n = wave * 32 + (lane & 31), g = lane >> 5;                       // tile row, block of the pair
+        *(uint4 *) (st + OFF_B + q_lds_off(n, 2 * g))     = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        *(uint4 *) (st + OFF_B + q_lds_off(n, 2 * g + 1)) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        ((float *) (st + OFF_BD))[g * BN + n] = d;
+        if (HAS_M) ((float *) (st + OFF_BM))[g * BN + n] = m;
+        if (sact) { ((float *) (st + OFF_AD))[sblk * BM + srow] = rs.x; ((float *) (st + OFF_AS))[sblk * BM + srow] = rs.y; }
+    };
+
+    floatx16 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+    const int frow = lane & 31, fk = lane >> 5;
+    auto compute = [&](int buf) {
+        const unsigned char * st = smem + buf * STAGE;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            intx4 fa[FM], fb[FN]; float dw[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) fa[i] = *(const intx4 *) (st + q_lds_off(wm * (BM / 2) + i * 32 + frow, 2 * kk + fk));
+#pragma unroll
+            for (int j = 0; j < FN; ++j) {
+                fb[j] = *(const intx4 *) (st + OFF_B + q_lds_off(wn * 64 + j * 32 + frow, 2 * kk + fk));
+                dw[j] = ((const float *) (st + OFF_BD))[kk * BN + wn * 64 + j * 32 + frow];
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                // d_a of this lane's 16 rows: rows (e & 3) + 8 (e >> 2) + 4 fk of the fragment
+                float da[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float4 t = *(const float4 *) ((const float *) (st + OFF_AD) + kk * BM + wm * (BM / 2) + i * 32 + 8 * q + 4 * fk);
+                    da[4 * q] = t.x; da[4 * q + 1] = t.y; da[4 * q + 2] = t.z; da[4 * q + 3] = t.w;
+                }
+#pragma unroll
+                for (int j = 0; j < FN; ++j) {
+                    intx16 z;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) z[e] = 0;
+                    const intx16 ia = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], z, 0, 0, 0);
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaf((float) ia[e], da[e] * dw[j], acc[i][j][e]);
+                }
+            }
+        }
+        if constexpr (HAS_M) {
+            // sum over the two blocks of m_w * s_a: an f32 MFMA with K = 2 (exact f32 FMAs in block order) into the same accumulators
+            float sa[FM], mw[FN];
+#pragma unroll
+            for (int i = 0; i < FM; ++i) sa[i] = ((const float *) (st + OFF_AS))[fk * BM + wm * (BM / 2) + i * 32 + frow];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) mw[j] = ((const float *) (st + OFF_BM))[fk * BN + wn * 64 + j * 32 + frow];
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(sa[i], mw[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    issue_a(0, 0); load_b(0);
+    for (int kt = 0; kt < np; ++kt) {
+        const int buf = kt & 1;
+        store_b(buf);                                        // waits for this tile's W registers (the A pieces were issued before them)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (kt + 1 < np) { issue_a(kt + 1, buf ^ 1); load_b(kt + 1); }
+        compute(buf);
+    }
+
+    // ------------------------------------------------------------------ epilogue
+    // fragment (i, j): column n = nb0 + j * 32 + frow, rows m = mb + i * 32 + (e & 3) + 8 (e >> 2) + 4 fk
+    const int mb = m0 + wm * (BM / 2), nbase = n0 + wn * 64;
+    auto epilogue = [&](auto guard_tag) {
+        constexpr bool GUARD = decltype(guard_tag)::value;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = nbase + j * 32 + frow;
+            const float bias = a.bias ? a.bias[n] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                float rpre[16];
+                if constexpr (EPI == EPI_F32_BIAS_RESID) {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = mb + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fk;
+                        rpre[e] = a.resid[(size_t) ((GUARD && m >= a.M) ? a.M - 1 : m) * a.ldr + n];
+                    }
+                }
+                if constexpr (EPI == EPI_QKV_ENC) {
+                    const int seg = __builtin_amdgcn_readfirstlane((nbase + j * 32) / a.S);   // wave-uniform: 32 | S
+                    const int c = n - seg * a.S;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int mrow = mb + i * 32 + 8 * q + 4 * fk;
+                        if (seg == 2) {                  // V^T [chunk][S][Tpad]: four consecutive time steps -> one 8-byte store
+                            const int rpc = a.rows_per_chunk > 0 ? a.rows_per_chunk : a.M;
+                            const int cb = mrow / rpc, t0 = mrow - cb * rpc;
+                            __half * vt = (__half *) a.aux2 + (size_t) cb * a.chunk_stride_aux2 + (size_t) c * a.ldaux2;
+                            if ((!GUARD || mrow + 3 < a.M) && t0 + 3 < rpc && ((t0 & 3) == 0)) {
+                                half4 v;
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) v[r] = (_Float16) pin_f32(acc[i][j][4 * q + r] + bias);
+                                *(half4 *) (vt + t0) = v;
+                            } else {
+                                for (int r = 0; r < 4; ++r) {
+                                    const int m = mrow + r;
+                                    if (m >= a.M) continue;
+                                    const int cb2 = m / rpc, t = m - cb2 * rpc;
+                                    ((__half *) a.aux2)[(size_t) cb2 * a.chunk_stride_aux2 + (size_t) c * a.ldaux2 + t] = f2h(acc[i][j][4 * q + r] + bias);
+                                }
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) {
+                                const int m = mrow + r;
+                                if (GUARD && m >= a.M) continue;
+                                const float v = acc[i][j][4 * q + r] + bias;
+                                if (seg == 0) ((__half *) a.C)[(size_t) m * a.ldc + c] = f2h(v);
+                                else          ((__half *) a.aux)[(size_t) m * a.ldaux + c] = f2h(v);
+                            }
+                        }
+                    }
+                } else if constexpr (EPI == EPI_QKV_DEC) {
+                    const int seg = __builtin_amdgcn_readfirstlane((nbase + j * 32) / a.S);
+                    const int c = n - seg * a.S;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = mb + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fk;
+                        if (GUARD && m >= a.M) continue;
+                        const float v = acc[i][j][e];
+                        __half * dst; float val;
+                        if (seg == 0)      { dst = (__half *) a.C    + (size_t) m * a.ldc;    val = (v + bias) * a.scale; }
+                        else if (seg == 1) { dst = (__half *) a.aux  + (size_t) m * a.ldaux;  val = v * a.scale; }
+                        else               { dst = (__half *) a.aux2 + (size_t) m * a.ldaux2; val = v + bias; }
+                        dst[c] = f2h(val);
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int m = mb + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * fk;
+                        q_store<EPI, GUARD>(a, m, n, acc[i][j][e], bias, EPI == EPI_F32_BIAS_RESID ? rpre[e] : 0.0f);
+                    }
+                }
+            }
+        }
+    };
+    if (m0 + BM <= a.M) epilogue(std::false_type{}); else epilogue(std::true_type{});
+}
+
+template <int QT, int BM, int EPI>
+void launch_qgemm(const GemmArgs & a, Q8Rows A, const uint8_t * Wt, hipStream_t st) {
+    constexpr int BN = 128;
+    constexpr size_t stage = (size_t) BM * 64 + BN * 64 + 4 * BM * 4 + 4 * BN * 4;
+    const size_t smem = 2 * stage;
+    static bool attr_done = false;
+    if (!attr_done) { (void) hipFuncSetAttribute((const void *) k_qgemm<QT, BM, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem); attr_done = true; }
+    const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
+    hipLaunchKernelGGL((k_qgemm<QT, BM, EPI>), dim3(ntm * ntn), dim3(256), smem, st, a, A.qs, A.ds, Wt);
+}
+
+template <int QT, int EPI>
+void qgemm_tile(const GemmArgs & a, Q8Rows A, const uint8_t * Wt, hipStream_t st) {
+    // 256 CUs: 128-row tiles only when they still give every CU a workgroup and a half
+    const long t128 = (long) ((a.M + 127) / 128) * (a.N / 128);
+    if (t128 >= 384) launch_qgemm<QT, 128, EPI>(a, A, Wt, st); else launch_qgemm<QT, 64, EPI>(a, A, Wt, st);
+}
+
+template <int QT>
+void qgemm_epi(int epi, const GemmArgs & a, Q8Rows A, const uint8_t * Wt, hipStream_t st) {
+    switch (epi) {
+        case EPI_F16_BIAS:       qgemm_tile<QT, EPI_F16_BIAS>(a, A, Wt, st); break;
+        case EPI_F16_BIAS_GELU:  qgemm_tile<QT, EPI_F16_BIAS_GELU>(a, A, Wt, st); break;
+        case EPI_F32_BIAS_RESID: qgemm_tile<QT, EPI_F32_BIAS_RESID>(a, A, Wt, st); break;
+        case EPI_QKV_ENC:        qgemm_tile<QT, EPI_QKV_ENC>(a, A, Wt, st); break;
+        case EPI_QKV_DEC:        qgemm_tile<QT, EPI_QKV_DEC>(a, A, Wt, st); break;
+        case EPI_CROSS_KV:       qgemm_tile<QT, EPI_CROSS_KV>(a, A, Wt, st); break;
+        case EPI_Q_SCALED:       qgemm_tile<QT, EPI_Q_SCALED>(a, A, Wt, st); break;
+        default: break;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ rows (decode)
+// R <= 8 NR4 rows: activations are the MFMA's row operand (rows >= n read row 0 and are never stored), the 32 weight rows of a
+// row group its columns: lane (col = lane % 32) keeps out[r] for rows r = (e & 3) + 8 (e >> 2) + 4 (lane / 32), e < 4 NR4.
+// SRC as in k_q8_rows (0 f32 rows, 1 LayerNorm(f32), 2 f16 rows).
+template <int QT, int NR4, int SRC>
+__global__ __launch_bounds__(256) void k_qrows(const GemvArgs a, const float * __restrict__ a32, const uint8_t * __restrict__ Wt) {
+    constexpr int QW = Geo<QT>::QW, HW = Geo<QT>::HW;
+    constexpr bool HAS_M = Geo<QT>::M, F16D = Geo<QT>::F16D;
+    constexpr int R8 = NR4 * 8;                             // row slots
+    constexpr int CH = 5;                                    // weight tiles in flight per wavefront
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int K = a.K, n = a.n, nb = K >> 5, np = K >> 6;
+    const int lda = K + 16;                                  // bytes per quantised row in LDS (+16: the fragment reads of 16 rows spread over the banks)
+    int8_t * sq = (int8_t *) smem;                           // [n][lda]
+    float  * sd = (float *) (smem + (((size_t) n * lda + 15) & ~(size_t) 15));     // [nb][R8]
+    float  * ss = sd + (size_t) nb * R8;                     // [nb][R8]
+    float  * red = ss + (size_t) nb * R8;                    // [4][32][R8]
+
+    const int ngroups = (a.N + 31) >> 5;
+    int rg = blockIdx.x;
+
+    // ---- first weight tiles of this wavefront (independent of the activations)
+    uint32_t wq[CH][QW], wh[CH][HW];
+    auto load_tiles = [&](int g, int c0) {
+#pragma unroll
+        for (int u = 0; u < CH; ++u) {
+            int tp = wave + 4 * (c0 + u); if (tp > np - 1) tp = np - 1;
+            const uint8_t * t = Wt + ((size_t) g * np + tp) * tile_bytes<QT>();
+            if constexpr (QW == 4) { const uint4 v = *(const uint4 *) (t + lane * 16); wq[u][0] = v.x; wq[u][1] = v.y; wq[u][2] = v.z; wq[u][3] = v.w; }
+            else { const uint4 v = *(const uint4 *) (t + lane * 32), w = *(const uint4 *) (t + lane * 32 + 16);
+                   wq[u][0] = v.x; wq[u][1] = v.y; wq[u][2] = v.z; wq[u][3] = v.w; wq[u][4] = w.x; wq[u][5] = w.y; wq[u][6] = w.z; wq[u][7] = w.w; }
+            if constexpr (HW == 2) { const uint2 h = *(const uint2 *) (t + 64 * QW * 4 + lane * 8); wh[u][0] = h.x; wh[u][1] = h.y; }
+            else wh[u][0] = *(const uint32_t *) (t + 64 * QW * 4 + lane * 4);
+        }
+    };
+    if (rg < ngroups) load_tiles(rg, 0);
+
+    // ---- prologue: the activation rows as q8 blocks in LDS (wavefront w: rows w, w + 4, ...)
+    for (int r = wave; r < n; r += 4) {
+        const int src = a.rows ? a.rows[r] : r;
+        if constexpr (SRC == 1) {
+            constexpr int MAXV = 6;                          // K <= 1536
+            float4 v[MAXV], gg[MAXV], bb[MAXV];
+            const float * xr = a.x32 + (size_t) src * K;
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int c = (i * 64 + lane) * 4, cc = c < K ? c : 0;
+                v[i] = *(const float4 *) (xr + cc); gg[i] = *(const float4 *) (a.ln_g + cc); bb[i] = *(const float4 *) (a.ln_b + cc);
+            }
+            ln_inplace<MAXV>(v, gg, bb, K, a.eps, lane);
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int c = (i * 64 + lane) * 4;
+                float d, s;
+                const uint32_t q = quant4<F16D>(v[i].x, v[i].y, v[i].z, v[i].w, d, s);
+                if (c < K) {
+                    *(uint32_t *) (sq + (size_t) r * lda + c) = q;
+                    if ((lane & 7) == 0) { sd[(c >> 5) * R8 + r] = d; ss[(c >> 5) * R8 + r] = s; }
+                }
+            }
+        } else {
+            for (int c0 = 0; c0 < K; c0 += 1024) {
+                float4 v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = c0 + (i * 64 + lane) * 4, cc = c < K ? c : 0;
+                    if constexpr (SRC == 0) v[i] = *(const float4 *) (a32 + (size_t) src * K + cc);
+                    else {
+                        const uint2 u = *(const uint2 *) (a.a16 + (size_t) src * K + cc);
+                        const float2 p = __half22float2(*(const __half2 *) &u.x), q2 = __half22float2(*(const __half2 *) &u.y);
+                        v[i] = make_float4(p.x, p.y, q2.x, q2.y);
+                    }
+                    if (c >= K) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int c = c0 + (i * 64 + lane) * 4;
+                    float d, s;
+                    const uint32_t q = quant4<F16D>(v[i].x, v[i].y, v[i].z, v[i].w, d, s);
+                    if (c < K) {
+                        *(uint32_t *) (sq + (size_t) r * lda + c) = q;
+                        if ((lane & 7) == 0) { sd[(c >> 5) * R8 + r] = d; ss[(c >> 5) * R8 + r] = s; }
+                    }
+                }
+            }
+        }
+    }
+    // scale slots of absent rows: finite zeros (they are multiplied, never stored)
+    for (int e = tid; e < nb * R8; e += 256) { if ((e % R8) >= n) { sd[e] = 0.0f; ss[e] = 0.0f; } }
+    __syncthreads();
+
+    const int arow = (lane & 31) < n ? (lane & 31) : 0;     // activation row this lane feeds the MFMA with
+    const int fk = lane >> 5;
+    const int8_t * afrag = sq + (size_t) arow * lda + fk * 16;
+    int ro_pre = 0;
+
+    for (; rg < ngroups; rg += gridDim.x) {
+        float out[4 * NR4];
+#pragma unroll
+        for (int e = 0; e < 4 * NR4; ++e) out[e] = 0.0f;
+        for (int c0 = 0; wave + 4 * c0 < np; c0 += CH) {
+            if (!(rg == (int) blockIdx.x && c0 == 0)) load_tiles(rg, c0);
+#pragma unroll
+            for (int u = 0; u < CH; ++u) {
+                const int tp = wave + 4 * (c0 + u);
+                if (tp < np) {                               // wave-uniform
+                    uint32_t lo[4], hi[4]; float d, m;
+                    unpack<QT>(wq[u], wh[u], lo, hi, d, m);
+                    // lane (n, g) unpacked block 2 tp + g; the MFMA of block 2 tp wants elements 0..15 of it on lanes < 32 and 16..31 on
+                    // lanes >= 32: exchange the upper half of the even block with the lower half of the odd one
+                    float d0 = d, d1 = d, m0 = m, m1 = m;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        const auto r2 = __builtin_amdgcn_permlane32_swap(lo[i], hi[i], false, false);
+                        lo[i] = r2[0]; hi[i] = r2[1];
+                    }
+                    { const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d0), __float_as_uint(d1), false, false); d0 = __uint_as_float(r2[0]); d1 = __uint_as_float(r2[1]); }
+                    if (HAS_M) { const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(m0), __float_as_uint(m1), false, false); m0 = __uint_as_float(r2[0]); m1 = __uint_as_float(r2[1]); }
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int b = 2 * tp + h;
+                        const intx4 fa = *(const intx4 *) (afrag + b * 32);
+                        intx4 fb; if (h == 0) { fb[0] = lo[0]; fb[1] = lo[1]; fb[2] = lo[2]; fb[3] = lo[3]; } else { fb[0] = hi[0]; fb[1] = hi[1]; fb[2] = hi[2]; fb[3] = hi[3]; }
+                        intx16 z;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) z[e] = 0;
+                        const intx16 ia = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb, z, 0, 0, 0);
+                        const float dwv = h == 0 ? d0 : d1, mwv = h == 0 ? m0 : m1;
+#pragma unroll
+                        for (int q = 0; q < NR4; ++q) {
+                            const float4 da = *(const float4 *) (sd + (size_t) b * R8 + 8 * q + 4 * fk);
+                            const float dav[4] = {da.x, da.y, da.z, da.w};
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) out[4 * q + r] = fmaf((float) ia[4 * q + r], dav[r] * dwv, out[4 * q + r]);
+                            if (HAS_M) {
+                                const float4 sa = *(const float4 *) (ss + (size_t) b * R8 + 8 * q + 4 * fk);
+                                const float sav[4] = {sa.x, sa.y, sa.z, sa.w};
+#pragma unroll
+                                for (int r = 0; r < 4; ++r) out[4 * q + r] = fmaf(mwv, sav[r], out[4 * q + r]);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        // next row group's first tiles go out before this one is reduced
+        const int rgn = rg + gridDim.x;
+        // ---- K-split partials of the four wavefronts, added in wavefront order
+        if (rg != (int) blockIdx.x) __syncthreads();            // red is reused
+#pragma unroll
+        for (int q = 0; q < NR4; ++q)
+            *(float4 *) (red + ((size_t) (wave * 32 + (lane & 31)) * R8 + 8 * q + 4 * fk)) = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
+        __syncthreads();
+        for (int e = tid; e < 32 * R8; e += 256) {
+            const int nl = e & 31, r = e >> 5;
+            if (r >= n) continue;
+            const int nf = rg * 32 + nl;
+            if (nf >= a.N) continue;
+            const float v = ((red[(size_t) nl * R8 + r] + red[(size_t) (32 + nl) * R8 + r]) + red[(size_t) (64 + nl) * R8 + r]) + red[(size_t) (96 + nl) * R8 + r];
+            const float bias = a.bias ? a.bias[nf] : 0.0f;
+            switch (a.epi) {
+                case EPI_F16_BIAS:       ((__half *) a.C)[(size_t) r * a.ldc + nf] = f2h(v + bias); break;
+                case EPI_F16_BIAS_GELU:  ((__half *) a.C)[(size_t) r * a.ldc + nf] = f2h(gelu16(v + bias)); break;
+                case EPI_F32_BIAS_RESID: ((float *) a.C)[(size_t) r * a.ldc + nf] = (v + bias) + a.resid[(size_t) r * a.ldr + nf]; break;
+                case EPI_Q_SCALED:       ((__half *) a.C)[(size_t) r * a.ldc + nf] = f2h((v + bias) * a.scale); break;
+                case EPI_QKV_DEC: {
+                    const int seg = nf / a.S, c = nf - seg * a.S;
+                    const int ro = a.row_off ? (a.lanes ? a.row_off[r * a.step_stride] : *a.row_off) : 0;
+                    const int64_t crow = a.lanes ? (int64_t) r * a.cache_row_stride : 0;
+                    const int slot = a.lanes ? ro : r + ro;
+                    if (seg == 0)      ((__half *) a.C)[(size_t) r * a.ldc + c] = f2h((v + bias) * a.scale);
+                    else if (seg == 1) ((__half *) a.aux)[crow + (size_t) slot * a.ldaux + c] = f2h(v * a.scale);
+                    else               ((__half *) a.aux2)[crow + (size_t) slot * a.ldaux2 + c] = f2h(v + bias);
+                } break;
+                case EPI_LOGITS:         ((float *) a.C)[(size_t) r * a.ldc + nf] = v; break;
+                default: break;
+            }
+        }
+        (void) rgn; (void) ro_pre;
+    }
+}
+
+template <int QT, int NR4, int SRC>
+void launch_qrows(const GemvArgs & a, const float * a32, const uint8_t * Wt, hipStream_t st) {
+    const int nb = a.K / 32, R8 = NR4 * 8;
+    const size_t smem = (((size_t) a.n * (a.K + 16) + 15) & ~(size_t) 15) + (size_t) 2 * nb * R8 * 4 + (size_t) 4 * 32 * R8 * 4;
+    const int ngroups = (a.N + 31) / 32;
+    int blocks = ngroups; if (blocks > 1024) blocks = 1024;
+    static size_t attr_bytes = 0;
+    if (smem > 48 * 1024 && smem > attr_bytes) {
+        (void) hipFuncSetAttribute((const void *) k_qrows<QT, NR4, SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
+        attr_bytes = smem;
+    }
+    hipLaunchKernelGGL((k_qrows<QT, NR4, SRC>), dim3(blocks), dim3(256), smem, st, a, a32, Wt);
+}
+
+template <int QT, int NR4>
+void qrows_src(const GemvArgs & a, const float * a32, const uint8_t * Wt, hipStream_t st) {
+    if (a.ln_g)   launch_qrows<QT, NR4, 1>(a, a32, Wt, st);
+    else if (a32) launch_qrows<QT, NR4, 0>(a, a32, Wt, st);
+    else          launch_qrows<QT, NR4, 2>(a, a32, Wt, st);
+}
+
+template <int QT>
+void qrows_t(const GemvArgs & a, const float * a32, const uint8_t * Wt, hipStream_t st) {
+    if (a.n <= 8)       qrows_src<QT, 1>(a, a32, Wt, st);
+    else if (a.n <= 16) qrows_src<QT, 2>(a, a32, Wt, st);
+    else                qrows_src<QT, 4>(a, a32, Wt, st);
+}
+
+// ------------------------------------------------------------------------------------------------ embedding
+template <int QT>
+__global__ void k_qembed(const int32_t * __restrict__ tokens, const int32_t * __restrict__ pos, const DecStep * __restrict__ host_step,
+                         DecStep * __restrict__ dev_step, int S, const uint8_t * __restrict__ Wt, const float * __restrict__ pe, float * __restrict__ x) {
+    constexpr int QW = Geo<QT>::QW, HW = Geo<QT>::HW;
+    __shared__ DecStep st;
+    const int i = blockIdx.x;
+    int tok, ps;
+    if (host_step) {                                          // graph-replay form: the step record comes from pinned host memory
+        if (threadIdx.x < sizeof(DecStep) / 4) ((int32_t *) &st)[threadIdx.x] = ((const volatile int32_t *) (host_step + i))[threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x < sizeof(DecStep) / 4) ((int32_t *) (dev_step + i))[threadIdx.x] = ((const int32_t *) &st)[threadIdx.x];
+        tok = st.token; ps = st.pos;
+    } else { tok = tokens[i]; ps = pos[i]; }
+    const int np = S >> 6, tn = tok >> 5, nl = tok & 31;
+    // thread -> (block b, dword i4 of its 8 dwords of 4 elements)
+    for (int e = threadIdx.x; e < (S >> 5) * 8; e += blockDim.x) {
+        const int b = e >> 3, part = e & 7;                   // part: 0..3 -> elements 4 part .. (lo), 4..7 -> 16 + 4 (part - 4) .. (hi)
+        const uint8_t * t = Wt + ((size_t) tn * np + (b >> 1)) * tile_bytes<QT>();
+        const int ln = nl + 32 * (b & 1);
+        uint32_t qs[QW], hd[HW];
+#pragma unroll
+        for (int w = 0; w < QW; ++w) qs[w] = *(const uint32_t *) (t + ln * QW * 4 + w * 4);
+#pragma unroll
+        for (int w = 0; w < HW; ++w) hd[w] = *(const uint32_t *) (t + 64 * QW * 4 + ln * HW * 4 + w * 4);
+        uint32_t lo[4], hi[4]; float d, m;
+        unpack<QT>(qs, hd, lo, hi, d, m);
+        uint32_t pk = 0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { if (part == w) pk = lo[w]; if (part == 4 + w) pk = hi[w]; }
+        const int c = b * 32 + (part & 3) * 4 + (part >> 2) * 16;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int wv = (int) (int8_t) (pk >> (8 * u));
+            const float y = Geo<QT>::M ? __fadd_rn(__fmul_rn((float) wv, d), m) : __fmul_rn((float) wv, d);
+            x[(size_t) i * S + c + u] = y + pe[(size_t) ps * S + c + u];
+        }
+    }
+}
+
+} // namespace
+
+void quantize_rows(const float * x32, const __half * x16, int M, int K, const float * ln_g, const float * ln_b, float eps,
+                   int qtype, Q8Rows out, float * out32, __half * out16, hipStream_t st) {
+    if (M <= 0) return;
+    const dim3 grid((M + 3) / 4), block(256);
+    const bool f16d = !q_geom(qtype).has_m;
+#define WMI_Q8(MAXV, SRC) do { if (f16d) hipLaunchKernelGGL((k_q8_rows<MAXV, SRC, true>), grid, block, 0, st, x32, x16, M, K, ln_g, ln_b, eps, out.qs, out.ds, out32, out16); \
+                               else      hipLaunchKernelGGL((k_q8_rows<MAXV, SRC, false>), grid, block, 0, st, x32, x16, M, K, ln_g, ln_b, eps, out.qs, out.ds, out32, out16); } while (0)
+    if (ln_g) {
+        const int nv = (K + 255) / 256;
+        if (nv <= 2) WMI_Q8(2, 1); else if (nv <= 4) WMI_Q8(4, 1); else WMI_Q8(6, 1);
+    } else if (x32) WMI_Q8(4, 0);
+    else            WMI_Q8(4, 2);
+#undef WMI_Q8
+}
+
+void qgemm(int epi, const GemmArgs & a, Q8Rows A, QMat W, hipStream_t st) {
+    switch (W.qtype) {
+        case QT_Q4_0: qgemm_epi<QT_Q4_0>(epi, a, A, W.tiles, st); break;
+        case QT_Q4_1: qgemm_epi<QT_Q4_1>(epi, a, A, W.tiles, st); break;
+        case QT_Q5_0: qgemm_epi<QT_Q5_0>(epi, a, A, W.tiles, st); break;
+        case QT_Q5_1: qgemm_epi<QT_Q5_1>(epi, a, A, W.tiles, st); break;
+        case QT_Q8_0: qgemm_epi<QT_Q8_0>(epi, a, A, W.tiles, st); break;
+        default: break;
+    }
+}
+
+void qrows(const GemvArgs & a, const float * a32, QMat W, hipStream_t st) {
+    switch (W.qtype) {
+        case QT_Q4_0: qrows_t<QT_Q4_0>(a, a32, W.tiles, st); break;
+        case QT_Q4_1: qrows_t<QT_Q4_1>(a, a32, W.tiles, st); break;
+        case QT_Q5_0: qrows_t<QT_Q5_0>(a, a32, W.tiles, st); break;
+        case QT_Q5_1: qrows_t<QT_Q5_1>(a, a32, W.tiles, st); break;
+        case QT_Q8_0: qrows_t<QT_Q8_0>(a, a32, W.tiles, st); break;
+        default: break;
+    }
+}
+
+template <int QT> static void qembed_launch(const int32_t * tokens, const int32_t * pos, const DecStep * hs, DecStep * ds, int n, int S,
+                                            const uint8_t * Wt, const float * pe, float * x, hipStream_t st) {
+    hipLaunchKernelGGL((k_qembed<QT>), dim3(n), dim3(256), 0, st, tokens, pos, hs, ds, S, Wt, pe, x);
+}
+static void qembed_any(const int32_t * tokens, const int32_t * pos, const DecStep * hs, DecStep * ds, int n, int S, QMat te,
+                       const float * pe, float * x, hipStream_t st) {
+    switch (te.qtype) {
+        case QT_Q4_0: qembed_launch<QT_Q4_0>(tokens, pos, hs, ds, n, S, te.tiles, pe, x, st); break;
+        case QT_Q4_1: qembed_launch<QT_Q4_1>(tokens, pos, hs, ds, n, S, te.tiles, pe, x, st); break;
+        case QT_Q5_0: qembed_launch<QT_Q5_0>(tokens, pos, hs, ds, n, S, te.tiles, pe, x, st); break;
+        case QT_Q5_1: qembed_launch<QT_Q5_1>(tokens, pos, hs, ds, n, S, te.tiles, pe, x, st); break;
+        case QT_Q8_0: qembed_launch<QT_Q8_0>(tokens, pos, hs, ds, n, S, te.tiles, pe, x, st); break;
+        default: break;
+    }
+}
+void qdec_embed(const int32_t * tokens, const int32_t * pos, int n, int S, QMat te, const float * pe, float * x, hipStream_t st) {
+    qembed_any(tokens, pos, nullptr, nullptr, n, S, te, pe, x, st);
+}
+void qdec_embed_step(const DecStep * host_step, DecStep * dev_step, int S, QMat te, const float * pe, float * x, hipStream_t st, int n_rows) {
+    qembed_any(nullptr, nullptr, host_step, dev_step, n_rows, S, te, pe, x, st);
+}
+
+}} // namespace wmi::k

@@ -154,6 +154,49 @@ size_t filter_scratch_bytes(int n_rows = 1);
 void dec_embed_step(const DecStep * host_step, DecStep * dev_step, int S, const __half * te, const float * pe, float * x, hipStream_t st,
                     int n_rows = 1);
 
+// ---------------------------------------------------------------- block-quantised weights (k_quant.hip)
+// The reference keeps q4_0 / q4_1 / q5_0 / q5_1 / q8_0 matrices quantised, turns every activation row of a mul_mat into
+// q8_0 / q8_1 blocks and takes an integer dot per 32-element block, scaled by d_w * d_a (+ m_w * s_a)
+// (SURVEY App. B rule 1; W/ggml-quants.c:837-870, 2442-3560).  Same here: the blocks stay quantised in HBM, the integer
+// dots run on v_mfma_i32_32x32x32_i8 (one q block = the K of one instruction, so the dot of a block is exact), the
+// per-block f32 scales are applied on the way out of the accumulator.
+//
+// HBM layout of a quantised matrix [N][K] ("tiles"): a tile = 32 weight rows x 2 blocks (K = 64) = 64 blocks, one per
+// lane: lane (n = lane % 32, g = lane / 32) owns block 2 * tp + g of row 32 * tn + n.  A tile stores the 64 quant
+// payloads first ([lane][QB bytes]), then the 64 headers ([lane][HB bytes]); tiles of a row group are consecutive
+// in tp, row groups follow each other: tile index = tn * (K / 64) + tp.  A wavefront reads a tile with two fully
+// coalesced loads; nothing is rewritten, the file's blocks are only permuted (headers of the 2- and 6-byte kinds are
+// padded to 4 / 8 bytes).  N is padded to a multiple of 32 with zero blocks.
+enum QType : int { QT_NONE = 0, QT_Q4_0 = 2, QT_Q4_1 = 3, QT_Q5_0 = 6, QT_Q5_1 = 7, QT_Q8_0 = 8 };   // ggml_type ids
+struct QGeom { int qb, hb, file_bytes; bool has_m; };     // payload / header bytes of a block in the tile layout; *_1 kinds carry m
+QGeom  q_geom(int qtype);
+inline size_t q_tile_bytes(int qtype) { const QGeom g = q_geom(qtype); return (size_t) 64 * (g.qb + g.hb); }
+inline size_t q_matrix_bytes(int qtype, int64_t N, int64_t K) { return (size_t) ((N + 31) / 32) * (size_t) (K / 64) * q_tile_bytes(qtype); }
+// host: permute the ggml blocks of rows [0, N) (row stride K / 32 blocks of file_bytes) into the tile layout at dst
+void   q_repack_host(int qtype, const uint8_t * src, int64_t N, int64_t K, uint8_t * dst);
+struct QMat { const uint8_t * tiles = nullptr; int qtype = QT_NONE; };
+
+// activation rows as q8 blocks in global memory (the GEMM's A operand): qs [M][K] int8, ds [M][K / 32] {d, s}
+// (s = d * sum(q) for the q8_1 kinds; for the q8_0 kinds d is rounded to f16 as the reference stores it and s = 0)
+struct Q8Rows { int8_t * qs; float2 * ds; };
+// rows -> q8.  Exactly one source: x32 (+ optional LayerNorm gain/bias: y = LN(x) * g + b in f32, the reference quantises that
+// f32 tensor) or x16 (an f16 tensor, e.g. the GELU output, widened exactly).  out32 / out16: optional copy of the LN result.
+void quantize_rows(const float * x32, const __half * x16, int M, int K, const float * ln_g, const float * ln_b, float eps,
+                   int qtype, Q8Rows out, float * out32, __half * out16, hipStream_t st);
+
+// C[M][N] = A_q8[M][K] . W_q[N][K]^T with the GEMM's epilogues (Epi above; GemmArgs fields A / W / lda / ldw unused).
+// N % 128 == 0, K % 64 == 0.
+void qgemm(int epi, const GemmArgs & a, Q8Rows A, QMat W, hipStream_t st);
+
+// <= 32 activation rows against a quantised matrix: the weight tiles are streamed once, the rows are quantised in the
+// prologue of every workgroup (LayerNorm of x32 if ln_g, plain f32 rows a32, or f16 rows a16) — GemvArgs as for gemv();
+// the fused attention prologues (sa_*, comb_*) are not available here.
+void qrows(const GemvArgs & a, const float * a32, QMat W, hipStream_t st);
+
+// token embedding gather from a quantised matrix: x[i] = dequant(te[token[i]]) + pe[pos[i]]   (W/ggml.c get_rows, dequantize_row_*)
+void qdec_embed(const int32_t * tokens, const int32_t * pos, int n, int S, QMat te, const float * pe, float * x, hipStream_t st);
+void qdec_embed_step(const DecStep * host_step, DecStep * dev_step, int S, QMat te, const float * pe, float * x, hipStream_t st, int n_rows = 1);
+
 // misc
 void touch(int * p, int blocks, hipStream_t st);     // trivial dependent kernel (launch-floor probe)
 void fill_zero(void * p, size_t bytes, hipStream_t st);

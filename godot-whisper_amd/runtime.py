@@ -37,6 +37,8 @@ DEVICE_API = [
                                     C.POINTER(abi.whisper_token_data)]),
     ("wmi_selftest_proj", C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     ("wmi_bench_kernel", C.c_double, [C.c_void_p, C.c_int, C.c_int]),
+    ("wmi_selftest_quant", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                     C.c_void_p, C.c_void_p, C.c_void_p]),
 ]
 
 _lib = None

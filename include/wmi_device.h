@@ -107,6 +107,17 @@ WHISPER_API int wmi_sample_draws(struct whisper_context * ctx, const float * pro
  * Returns the largest absolute difference over all outputs (negative on error). */
 WHISPER_API double wmi_selftest_proj(struct whisper_context * ctx, int op, int n, int layer);
 
+/* Block-quantised kernels on caller data (parity tests, no context needed): w_blocks = the ggml blocks of an [N][K] matrix of
+ * type `qtype` (ggml_type id: 2 q4_0, 3 q4_1, 6 q5_0, 7 q5_1, 8 q8_0; W/ggml-quants.h:10-47) exactly as a model file holds them,
+ * x = f32 activation rows [M][K], all host pointers.  The rows are quantised to q8 blocks as the reference's mul_mat does
+ * (W/ggml-quants.c:837-870) and multiplied with the integer-dot kernels:
+ *   mode 0  weight-streaming row kernel (M <= 32)        mode 1  tiled GEMM (N % 128 == 0)
+ *   mode 2  x ignored; M token ids in `tokens`: out[M][K] = dequantised rows `tokens[i]` of the matrix (get_rows)
+ * out [M][N] f32 (mode 2: [M][K]); out_qs [M][K] int8 and out_ds [M][K/32][2] {d, s} receive the quantised rows when non-NULL.
+ * Returns 0, or a negative value on a bad argument / device error. */
+WHISPER_API int wmi_selftest_quant(int device, int qtype, int mode, const void * w_blocks, const float * x, const int32_t * tokens,
+                                   int M, int N, int K, float * out, int8_t * out_qs, float * out_ds);
+
 /* Kernel micro-benchmarks on synthetic operands (used by bench.py for the roofline line):
  * runs `iters` launches on the context stream between two HIP events, returns average microseconds.
  *   which = 0  encoder MLP-0 GEMM  [T x 4S x S] f16 MFMA   (flops = 2*T*4S*S)
