@@ -9,6 +9,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstring>
+#include <exception>
 #include <fstream>
 
 namespace wmi {
@@ -50,16 +51,26 @@ whisper_context * init_context(const void * buffer, size_t size, int device, boo
         return nullptr;
     }
     if (device < 0 || device >= n_dev) { WMI_ERR("whisper_mi355: invalid device %d (have %d)\n", device, n_dev); return nullptr; }
-    whisper_context * ctx = new whisper_context();
-    ctx->device = device;
-    ctx->t_start_us = t0;
-    WMI_INFO("%s: loading model from buffer\n", __func__);
-    if (!parse_model((const uint8_t *) buffer, size, ctx->model)) { WMI_ERR("%s: failed to load model\n", __func__); delete ctx; return nullptr; }
-    if (!HIP_OK(hipSetDevice(device))) { delete ctx; return nullptr; }
-    if (with_state && !init_state(*ctx)) { free_state(*ctx); delete ctx; return nullptr; }
-    if (!upload_weights(ctx->model, (const uint8_t *) buffer, nullptr, ctx->w, ctx->state ? ctx->state->dev.stream : nullptr)) {
-        WMI_ERR("%s: failed to load model\n", __func__);
-        free_state(*ctx); free_weights(ctx->w); delete ctx; return nullptr;
+    if (!buffer || size < 4) { WMI_ERR("%s: empty model buffer\n", __func__); return nullptr; }
+    whisper_context * ctx = nullptr;
+    // nothing may throw across the C boundary: an allocation failure on a hostile size is a load error like any other
+    try {
+        ctx = new whisper_context();
+        ctx->device = device;
+        ctx->t_start_us = t0;
+        WMI_INFO("%s: loading model from buffer\n", __func__);
+        if (!parse_model((const uint8_t *) buffer, size, ctx->model)) { WMI_ERR("%s: failed to load model\n", __func__); delete ctx; return nullptr; }
+        if (!HIP_OK(hipSetDevice(device))) { delete ctx; return nullptr; }
+        if (with_state && !init_state(*ctx)) { free_state(*ctx); delete ctx; return nullptr; }
+        hipStream_t ls = ctx->state ? ctx->state->dev.stream : nullptr;
+        if (!upload_weights(ctx->model, ctx->model.directory_only ? nullptr : (const uint8_t *) buffer, ctx->w, ls)) {
+            WMI_ERR("%s: failed to load model\n", __func__);
+            free_state(*ctx); free_weights(ctx->w); delete ctx; return nullptr;
+        }
+    } catch (const std::exception & e) {
+        WMI_ERR("%s: failed to load model (%s)\n", __func__, e.what());
+        if (ctx) { free_state(*ctx); free_weights(ctx->w); delete ctx; }
+        return nullptr;
     }
     ctx->t_load_us = time_us() - t0;
     return ctx;
@@ -524,6 +535,12 @@ double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters) {
     auto once = [&]() {
         switch (which) {
             case 0: {
+                if (ctx->model.quantised) {             // block-quantised mlp.0: q8 rows of the last encode x quantised tiles
+                    k::GemmArgs a{};
+                    a.M = T; a.N = 4 * S; a.K = S; a.bias = w.enc[0].b_fc1; a.C = d.h; a.ldc = 4 * S;
+                    k::qgemm(k::EPI_F16_BIAS_GELU, a, k::Q8Rows{d.aq, d.ads}, w.enc[0].q_fc1, s);
+                    break;
+                }
                 k::GemmArgs a{};
                 a.A = d.xn; a.lda = S; a.W = w.enc[0].w_fc1; a.ldw = S; a.M = T; a.N = 4 * S; a.K = S; a.bias = w.enc[0].b_fc1;
                 a.C = d.h; a.ldc = 4 * S;
@@ -533,6 +550,7 @@ double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters) {
                 k::GemvArgs g{};
                 g.x32 = d.dx; g.ln_g = w.d_ln_g; g.ln_b = w.d_ln_b; g.eps = hp.eps; g.n = 1; g.K = S; g.N = hp.n_vocab; g.W = w.d_te;
                 g.epi = k::EPI_LOGITS; g.C = d.logits; g.ldc = hp.n_vocab; g.rows = nullptr;
+                if (ctx->model.quantised) k::qrows(g, nullptr, w.q_te, s); else
                 k::gemv(g, s);
             } break;
             case 2: k::attn_encoder(d.q, d.k, d.vt, T, d.Tpad, S, H, 0.125f, d.att, s); break;

@@ -364,7 +364,7 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
     static const bool force_seq = getenv("WMI_BATCH_SEQUENTIAL") != nullptr;     // debug / A-B
     const bool lang_known = params.language && strlen(params.language) > 0 && strcmp(params.language, "auto") != 0 && !params.detect_language;
     const bool distilled = hp.n_text_layer == 2 && !params.no_timestamps;
-    const bool lockstep = !force_seq && fast_path_enabled() && params.strategy == WHISPER_SAMPLING_GREEDY && params.temperature < 1e-6f &&
+    const bool lockstep = !force_seq && fast_path_enabled() && !ctx.model.quantised && params.strategy == WHISPER_SAMPLING_GREEDY && params.temperature < 1e-6f &&
                           lang_known && !distilled && !params.speed_up && !params.logits_filter_callback && !params.grammar_rules && params.n_grammar_rules == 0 && !params.new_segment_callback &&
                           !params.progress_callback && !params.encoder_begin_callback && !params.abort_callback &&
                           ctx.model.n_loaded > 0 && n_chunks > 1;

@@ -53,6 +53,10 @@ bool init_state(whisper_context & ctx) {
             && dalloc(d.h, T * 4 * S) && dalloc(d.rowmax, H * T) && dalloc(d.enc_out, T * S) && dalloc(d.enc_out_h, T * S)
             && dalloc(d.mel_max, 4);
     const size_t n = hp.n_text_ctx;
+    if (ctx.model.quantised) {                              // q8 activation rows + f32 attention outputs (device_q.cpp)
+        const size_t rows = std::max<size_t>(T, n);
+        ok = ok && dalloc(d.aq, rows * 4 * S) && dalloc(d.ads, rows * (4 * S / 32)) && dalloc(d.att32, T * S) && dalloc(d.datt32, n * S);
+    }
     d.logits_rows_cap = 8;
     ok = ok && dalloc(d.d_tokens, n) && dalloc(d.d_pos, n) && dalloc(d.d_mask, n * n_self) && dalloc(d.d_rows, n)
             && dalloc(d.dx, n * S) && dalloc(d.dxn, n * S) && dalloc(d.dq, n * S) && dalloc(d.datt, n * S)
@@ -106,6 +110,7 @@ void destroy_state(State * st) {
     dfree(d.xn); dfree(d.q); dfree(d.k); dfree(d.vt); dfree(d.att); dfree(d.h); dfree(d.rowmax); dfree(d.enc_out);
     dfree(d.enc_out_h); dfree(d.d_tokens); dfree(d.d_pos); dfree(d.d_mask); dfree(d.d_rows); dfree(d.dx); dfree(d.dxn);
     dfree(d.dq); dfree(d.datt); dfree(d.dh); dfree(d.logits); dfree(d.xattn); dfree(d.ban_dev);
+    dfree(d.aq); dfree(d.ads); dfree(d.att32); dfree(d.datt32);
     if (d.step_exec) (void) hipGraphExecDestroy(d.step_exec);
     if (d.step_graph) (void) hipGraphDestroy(d.step_graph);
     if (d.step_dev) (void) hipFree(d.step_dev);
@@ -233,6 +238,8 @@ bool encode(whisper_context & ctx, int mel_offset) {
     }
     // encoder blocks (row a3)
     const float kq_scale = 1.0f / sqrtf((float) S / H);
+    if (ctx.model.quantised) { if (!encode_layers_q(ctx, T)) return false; }
+    else {
     for (int il = 0; il < La; ++il) {
         const EncLayerW & l = w.enc[il];
         k::layernorm(d.x, T, S, l.ln1_g, l.ln1_b, hp.eps, d.xn, nullptr, s);
@@ -271,6 +278,7 @@ bool encode(whisper_context & ctx, int mel_offset) {
         a.C = d.kvc_k; a.ldc = S; a.aux = d.kvc_v; a.ldaux = S; a.S = S; a.layer_stride = (int64_t) T * S;
         a.scale = powf((float) S / H, -0.25f);
         k::gemm(k::EPI_CROSS_KV, a, s);
+    }
     }
     HIP_TRY(hipStreamSynchronize(s));
     if (!HIP_OK(hipGetLastError())) return false;
@@ -311,6 +319,16 @@ bool decode(whisper_context & ctx, const Batch & batch) {
     if (!rows.empty()) HIP_TRY(hipMemcpyAsync(d.d_rows, p_rows, rows.size() * 4, hipMemcpyHostToDevice, s));
     HIP_TRY(hipMemcpyAsync(d.d_mask, p_mask, (size_t) n * n_kv * 4, hipMemcpyHostToDevice, s));
 
+    if (ctx.model.quantised) {
+        if (!decode_layers_q(ctx, n, n_kv, kv_head, Tc, rows)) return false;
+        HIP_TRY(hipStreamSynchronize(s));
+        if (!HIP_OK(hipGetLastError())) return false;
+        const int64_t dtq = time_us() - t0;
+        if (n == 1)      { st.t_decode_us += dtq; st.n_decode++; }
+        else if (n < 16) { st.t_batchd_us += dtq; st.n_batchd += n; }
+        else             { st.t_prompt_us += dtq; st.n_prompt += n; }
+        return true;
+    }
     k::dec_embed(d.d_tokens, d.d_pos, n, S, w.d_te, w.d_pe, d.dx, s);
     const float kq_scale = powf((float) S / H, -0.25f);
     // WMI_DECODE_PATH=gemm|gemv forces one projection path (debug / A-B measurements); default: by batch size

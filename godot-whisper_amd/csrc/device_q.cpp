@@ -1,0 +1,149 @@
+// Block-quantised models (BASELINE configs[4]: large-v3 q5_1): the encoder and decoder layer loops with the weights kept in
+// their ggml blocks (reference: the same graphs, W/whisper.cpp:1756-2074 and :2148-2505, whose
+// mul_mat nodes take the quantised branch W/ggml.c:9841-9857 for every 2-D weight).
+//
+// What changes against the f16 loops of device.cpp is the operand rule of every projection: the reference quantises the
+// f32 activation tensor of the mul_mat to q8 blocks, so
+//   * LayerNorm feeds the quantiser in f32 (no f16 rounding in between),
+//   * the attention outputs are kept f32 (KQV_merged is an f32 tensor in the reference) and quantised from there,
+//   * the GELU output is f16-representable by construction (f16 table), so the f16 buffer is widened exactly.
+// The attention products themselves (K, V caches, Q) stay f16 x f16 as in the f16 models, and so does the conv front-end
+// (the quantize tool leaves the 3-D conv weights f16, W/examples/common-ggml.cpp:112-131).
+
+#include "wmi.h"
+#include "kernels.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace wmi {
+
+namespace {
+
+// activation source of a projection
+struct Src { const float * x32 = nullptr; const float * ln_g = nullptr, * ln_b = nullptr; const __half * x16 = nullptr; };
+
+// rows * K quantised rows + scales + reduction scratch must fit the 160 KB of LDS for the weight-streaming kernel
+bool rows_fit(int n, int K) {
+    if (n > 32) return false;
+    const int r8 = n <= 8 ? 8 : n <= 16 ? 16 : 32, nb = K / 32;
+    const size_t smem = (((size_t) n * (K + 16) + 15) & ~(size_t) 15) + (size_t) 2 * nb * r8 * 4 + (size_t) 4 * 32 * r8 * 4;
+    return smem <= 150 * 1024;
+}
+
+} // namespace
+
+bool encode_layers_q(whisper_context & ctx, int T) {
+    State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
+    const int S = hp.n_audio_state, H = hp.n_audio_head, La = hp.n_audio_layer, Lt = hp.n_text_layer;
+    hipStream_t s = d.stream;
+    const k::Q8Rows A{d.aq, d.ads};
+    const int qt = w.qtype;
+    const float kq_scale = 1.0f / sqrtf((float) S / H);
+    for (int il = 0; il < La; ++il) {
+        const EncLayerW & l = w.enc[il];
+        k::quantize_rows(d.x, nullptr, T, S, l.ln1_g, l.ln1_b, hp.eps, qt, A, nullptr, nullptr, s);
+        {
+            k::GemmArgs a{};
+            a.M = T; a.N = 3 * S; a.K = S; a.bias = l.b_qkv;
+            a.C = d.q; a.ldc = S; a.aux = d.k; a.ldaux = S; a.aux2 = d.vt; a.ldaux2 = d.Tpad; a.S = S;
+            k::qgemm(k::EPI_QKV_ENC, a, A, l.q_qkv, s);
+        }
+        k::attn_encoder(d.q, d.k, d.vt, T, d.Tpad, S, H, kq_scale, nullptr, s, 1, d.att32);
+        k::quantize_rows(d.att32, nullptr, T, S, nullptr, nullptr, 0.f, qt, A, nullptr, nullptr, s);
+        {
+            k::GemmArgs a{};
+            a.M = T; a.N = S; a.K = S; a.bias = l.b_o; a.C = d.x; a.ldc = S; a.resid = d.x; a.ldr = S;
+            k::qgemm(k::EPI_F32_BIAS_RESID, a, A, l.q_o, s);
+        }
+        k::quantize_rows(d.x, nullptr, T, S, l.ln2_g, l.ln2_b, hp.eps, qt, A, nullptr, nullptr, s);
+        {
+            k::GemmArgs a{};
+            a.M = T; a.N = 4 * S; a.K = S; a.bias = l.b_fc1; a.C = d.h; a.ldc = 4 * S;
+            k::qgemm(k::EPI_F16_BIAS_GELU, a, A, l.q_fc1, s);
+        }
+        k::quantize_rows(nullptr, d.h, T, 4 * S, nullptr, nullptr, 0.f, qt, A, nullptr, nullptr, s);
+        {
+            k::GemmArgs a{};
+            a.M = T; a.N = S; a.K = 4 * S; a.bias = l.b_fc2; a.C = d.x; a.ldc = S; a.resid = d.x; a.ldr = S;
+            k::qgemm(k::EPI_F32_BIAS_RESID, a, A, l.q_fc2, s);
+        }
+    }
+    // ln_post -> embd_enc (f32, kept for inspection) and its q8 image; cross K/V of every decoder layer in one GEMM
+    k::quantize_rows(d.x, nullptr, T, S, w.e_ln_g, w.e_ln_b, hp.eps, qt, A, d.enc_out, d.enc_out_h, s);
+    {
+        k::GemmArgs a{};
+        a.M = T; a.N = Lt * 2 * S; a.K = S; a.bias = w.b_ckv;
+        a.C = d.kvc_k; a.ldc = S; a.aux = d.kvc_v; a.ldaux = S; a.S = S; a.layer_stride = (int64_t) T * S;
+        a.scale = powf((float) S / H, -0.25f);
+        k::qgemm(k::EPI_CROSS_KV, a, A, w.q_ckv, s);
+    }
+    return true;
+}
+
+bool decode_layers_q(whisper_context & ctx, int n, int n_kv, int kv_head, int Tc, const std::vector<int> & rows) {
+    State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
+    KVCache & kv = st.kv_self;
+    const int S = hp.n_text_state, H = hp.n_text_head, Lt = hp.n_text_layer, NV = hp.n_vocab, n_ctx = (int) kv.size;
+    hipStream_t s = d.stream;
+    const int qt = w.qtype;
+    const k::Q8Rows A{d.aq, d.ads};
+    const float kq_scale = powf((float) S / H, -0.25f);
+
+    k::qdec_embed(d.d_tokens, d.d_pos, n, S, w.q_te, w.d_pe, d.dx, s);
+
+    // y = W . q8(src) with a fused epilogue: <= 32 rows stream the weight tiles once (rows quantised in the kernel's prologue);
+    // prompt-sized batches quantise once and go through the tiled GEMM
+    auto proj = [&](int epi, const Src & src, int K, int N, const k::QMat & W, const float * bias, void * C, int ldc,
+                    const float * resid, void * aux, int ldaux, void * aux2, int ldaux2, float scale) {
+        if (rows_fit(n, K)) {
+            k::GemvArgs g{};
+            g.x32 = src.x32; g.ln_g = src.ln_g; g.ln_b = src.ln_b; g.eps = hp.eps; g.a16 = src.x16; g.n = n; g.K = K; g.N = N;
+            g.bias = bias; g.epi = epi; g.C = C; g.ldc = ldc; g.resid = resid; g.ldr = S; g.aux = aux; g.ldaux = ldaux;
+            g.aux2 = aux2; g.ldaux2 = ldaux2; g.scale = scale; g.S = S;
+            k::qrows(g, src.ln_g ? nullptr : src.x32, W, s);
+        } else {
+            k::quantize_rows(src.x32, src.x16, n, K, src.ln_g, src.ln_b, hp.eps, qt, A, nullptr, nullptr, s);
+            k::GemmArgs a{};
+            a.M = n; a.N = N; a.K = K; a.bias = bias; a.C = C; a.ldc = ldc; a.resid = resid; a.ldr = S;
+            a.aux = aux; a.ldaux = ldaux; a.aux2 = aux2; a.ldaux2 = ldaux2; a.scale = scale; a.S = S;
+            k::qgemm(epi, a, A, W, s);
+        }
+    };
+
+    for (int il = 0; il < Lt; ++il) {
+        const DecLayerW & l = w.dec[il];
+        __half * ck = kv.k + ((size_t) il * n_ctx) * S, * cv = kv.v + ((size_t) il * n_ctx) * S;
+        Src ln1; ln1.x32 = d.dx; ln1.ln_g = l.ln1_g; ln1.ln_b = l.ln1_b;
+        proj(k::EPI_QKV_DEC, ln1, S, 3 * S, l.q_qkv, l.b_qkv, d.dq, S, nullptr, ck + (size_t) kv_head * S, S, cv + (size_t) kv_head * S, S, kq_scale);
+        k::attn_decoder(d.dq, n, S, H, ck, cv, n_kv, d.d_mask, n_kv, nullptr, s, nullptr, 0, d.datt32);
+        Src att; att.x32 = d.datt32;
+        proj(k::EPI_F32_BIAS_RESID, att, S, S, l.q_o, l.b_o, d.dx, S, d.dx, nullptr, 0, nullptr, 0, 0.f);
+        Src ln2; ln2.x32 = d.dx; ln2.ln_g = l.ln2_g; ln2.ln_b = l.ln2_b;
+        proj(k::EPI_Q_SCALED, ln2, S, S, l.q_cq, l.b_cq, d.dq, S, nullptr, nullptr, 0, nullptr, 0, kq_scale);
+        k::attn_cross_split(d.dq, n, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, nullptr, s, 0, d.datt32);
+        proj(k::EPI_F32_BIAS_RESID, att, S, S, l.q_co, l.b_co, d.dx, S, d.dx, nullptr, 0, nullptr, 0, 0.f);
+        Src ln3; ln3.x32 = d.dx; ln3.ln_g = l.ln3_g; ln3.ln_b = l.ln3_b;
+        proj(k::EPI_F16_BIAS_GELU, ln3, S, 4 * S, l.q_fc1, l.b_fc1, d.dh, 4 * S, nullptr, nullptr, 0, nullptr, 0, 0.f);
+        Src hh; hh.x16 = d.dh;
+        proj(k::EPI_F32_BIAS_RESID, hh, 4 * S, S, l.q_fc2, l.b_fc2, d.dx, S, d.dx, nullptr, 0, nullptr, 0, 0.f);
+    }
+
+    // final LN + logits for the flagged rows
+    st.logits.resize((size_t) n * NV);
+    for (size_t r0 = 0; r0 < rows.size(); r0 += 8) {
+        const int nr = (int) std::min<size_t>(8, rows.size() - r0);
+        k::GemvArgs g{};
+        g.x32 = d.dx; g.ln_g = w.d_ln_g; g.ln_b = w.d_ln_b; g.eps = hp.eps; g.n = nr; g.K = S; g.N = NV;
+        g.epi = k::EPI_LOGITS; g.C = d.logits; g.ldc = NV; g.rows = d.d_rows + r0;
+        k::qrows(g, nullptr, w.q_te, s);
+        HIP_TRY(hipMemcpyAsync(d.pinned, d.logits, (size_t) nr * NV * 4, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        for (int r = 0; r < nr; ++r)
+            memcpy(st.logits.data() + (size_t) rows[r0 + r] * NV, (const float *) d.pinned + (size_t) r * NV, (size_t) NV * 4);
+    }
+    return true;
+}
+
+} // namespace wmi

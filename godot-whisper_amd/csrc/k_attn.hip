@@ -43,7 +43,7 @@ __device__ __forceinline__ uint32_t lds_off(int row, int chunk) { return (uint32
 template <int NW, int KS>
 __global__ __launch_bounds__(NW * 64 * KS) void k_attn_enc(const __half * __restrict__ q, const __half * __restrict__ k,
                                                   const __half * __restrict__ vt, int T, int Tpad, int S, float scale,
-                                                  __half * __restrict__ out) {
+                                                  __half * __restrict__ out, float * __restrict__ out32) {
     __shared__ __attribute__((aligned(16))) unsigned char sK_[KS][64 * 128];
     __shared__ __attribute__((aligned(16))) unsigned char sV_[KS][64 * 128];
     const int half = KS == 1 ? 0 : (int) (threadIdx.x / (NW * 64));       // key half of this wavefront group
@@ -54,7 +54,8 @@ __global__ __launch_bounds__(NW * 64 * KS) void k_attn_enc(const __half * __rest
     const int q0 = blockIdx.x * (NW * 16) + wave * 16;
     {   // chunk (lane of a batched encode): activations are [B][T][S], V^T is [B][S][Tpad]
         const size_t zb = blockIdx.z;
-        q += zb * (size_t) T * S; k += zb * (size_t) T * S; out += zb * (size_t) T * S; vt += zb * (size_t) S * Tpad;
+        q += zb * (size_t) T * S; k += zb * (size_t) T * S; vt += zb * (size_t) S * Tpad;
+        if (out32) out32 += zb * (size_t) T * S; else out += zb * (size_t) T * S;
     }
 
     half8 qf[2];
@@ -192,9 +193,15 @@ __global__ __launch_bounds__(NW * 64 * KS) void k_attn_enc(const __half * __rest
         const float li = __shfl(inv, qrow);
         const int qg = q0 + qrow;
         if (qg < T) {
+            // a quantised out-projection quantises the f32 tensor (the reference's KQV_merged is f32): no f16 rounding in between
+            if (out32) {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
-                out[(size_t) qg * S + head * 64 + nt * 16 + fr] = f2h(o[nt][r] * li);
+                for (int nt = 0; nt < 4; ++nt) out32[(size_t) qg * S + head * 64 + nt * 16 + fr] = o[nt][r] * li;
+            } else {
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    out[(size_t) qg * S + head * 64 + nt * 16 + fr] = f2h(o[nt][r] * li);
+            }
         }
     }
 }
@@ -206,7 +213,7 @@ __global__ __launch_bounds__(NW * 64 * KS) void k_attn_enc(const __half * __rest
 __global__ __launch_bounds__(256) void k_attn_dec(const __half * __restrict__ q, int S, const __half * __restrict__ kc,
                                                   const __half * __restrict__ vc, int n_kv_arg,
                                                   const float * __restrict__ mask, int ld_mask, __half * __restrict__ out,
-                                                  const int32_t * __restrict__ n_kv_dev, int n_kv_cap) {
+                                                  const int32_t * __restrict__ n_kv_dev, int n_kv_cap, float * __restrict__ out32) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int n_kv = n_kv_dev ? *n_kv_dev : n_kv_arg;
     float * sc  = (float *) smem;                 // [n_kv]  (sized for n_kv_cap under graph replay)
@@ -266,7 +273,8 @@ __global__ __launch_bounds__(256) void k_attn_dec(const __half * __restrict__ q,
     __syncthreads();
     if (tid < 64) {
         const float r = (red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid]);
-        out[(size_t) i * S + head * 64 + tid] = f2h(r);
+        if (out32) out32[(size_t) i * S + head * 64 + tid] = r;
+        else       out[(size_t) i * S + head * 64 + tid] = f2h(r);
     }
 }
 
@@ -571,7 +579,7 @@ __global__ __launch_bounds__(256) void k_xattn_pv(const __half * __restrict__ vc
 }
 
 __global__ __launch_bounds__(64) void k_xattn_combine(const float * __restrict__ part_o, const float * __restrict__ part_l,
-                                                      int ns, int S, __half * __restrict__ out) {
+                                                      int ns, int S, __half * __restrict__ out, float * __restrict__ out32) {
     const int head = blockIdx.x, i = blockIdx.y, H = gridDim.x, d = threadIdx.x;
     const size_t row = (size_t) i * H + head;
     float o = 0.0f; double l = 0.0;
@@ -584,13 +592,14 @@ __global__ __launch_bounds__(64) void k_xattn_combine(const float * __restrict__
     } else {
         for (int s2 = 0; s2 < ns; ++s2) { o += part_o[(row * ns + s2) * 64 + d]; l += (double) part_l[row * ns + s2]; }
     }
-    out[(size_t) i * S + head * 64 + d] = f2h(o * (float) (1.0 / l));
+    if (out32) out32[(size_t) i * S + head * 64 + d] = o * (float) (1.0 / l);
+    else       out[(size_t) i * S + head * 64 + d] = f2h(o * (float) (1.0 / l));
 }
 
 } // namespace
 
 void attn_cross_split(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int T,
-                      float * scratch, __half * out, hipStream_t st, int64_t kv_row_stride) {
+                      float * scratch, __half * out, hipStream_t st, int64_t kv_row_stride, float * out32) {
     // scratch layout: scores [n][H][Tpad] | pmax [n][H][NS] | part_l [n][H][NS] | part_o [n][H][NS][64]
     int ns = (T + 191) / 192; if (ns < 1) ns = 1; if (ns > XS_MAX_SLICES) ns = XS_MAX_SLICES;
     const int ks = (T + ns - 1) / ns;
@@ -602,7 +611,7 @@ void attn_cross_split(const __half * q, int n, int S, int H, const __half * kc, 
     hipLaunchKernelGGL(k_xattn_scores, dim3(ns, H, n), dim3(256), 0, st, q, S, kc, T, ks, ns, sc, ld_sc, pmax, kv_row_stride);
     const size_t smem = (((size_t) ks + 3) & ~(size_t) 3) * 4 + 4 * 64 * 4;
     hipLaunchKernelGGL(k_xattn_pv, dim3(ns, H, n), dim3(256), smem, st, vc, S, T, ks, ns, sc, ld_sc, pmax, part_o, part_l, kv_row_stride);
-    hipLaunchKernelGGL(k_xattn_combine, dim3(H, n), dim3(64), 0, st, part_o, part_l, ns, S, out);
+    hipLaunchKernelGGL(k_xattn_combine, dim3(H, n), dim3(64), 0, st, part_o, part_l, ns, S, out, out32);
 }
 
 void attn_cross_split_partials(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int T,
@@ -621,8 +630,8 @@ void attn_cross_split_partials(const __half * q, int n, int S, int H, const __ha
     *po = part_o; *pl = part_l; *pns = ns;
 }
 
-void attn_cross_combine(const float * part_o, const float * part_l, int ns, int n, int S, int H, __half * out, hipStream_t st) {
-    hipLaunchKernelGGL(k_xattn_combine, dim3(H, n), dim3(64), 0, st, part_o, part_l, ns, S, out);
+void attn_cross_combine(const float * part_o, const float * part_l, int ns, int n, int S, int H, __half * out, hipStream_t st, float * out32) {
+    hipLaunchKernelGGL(k_xattn_combine, dim3(H, n), dim3(64), 0, st, part_o, part_l, ns, S, out, out32);
 }
 
 static int g_xattn_probe_skip = 0;        // probe only: bit 0 skips the score kernel, bit 1 the P.V kernel
@@ -667,21 +676,21 @@ static bool g_attn_one_group = false;
 void set_attn_one_group(bool on) { g_attn_one_group = on; }
 
 void attn_encoder(const __half * q, const __half * k, const __half * vt, int T, int Tpad, int S, int H, float scale,
-                  __half * out, hipStream_t st, int B) {
+                  __half * out, hipStream_t st, int B, float * out32) {
     static const int nw = getenv("WMI_ATTN_NW") ? atoi(getenv("WMI_ATTN_NW")) : 4;      // wavefronts per workgroup (A/B knob)
     static const int ksplit = getenv("WMI_ATTN_KSPLIT") ? atoi(getenv("WMI_ATTN_KSPLIT")) : -1;      // A/B knob; default: by grid size
     const int nblk = ((T + 63) / 64) * H * B;
     const bool ks2 = ksplit >= 0 ? ksplit == 2 : (nblk <= 512 && T >= 256 && !g_attn_one_group);
-    if (nw == 4 && ks2) hipLaunchKernelGGL((k_attn_enc<4, 2>), dim3((T + 63) / 64, H, B), dim3(512), 0, st, q, k, vt, T, Tpad, S, scale, out);
-    else if (nw == 4)   hipLaunchKernelGGL((k_attn_enc<4, 1>), dim3((T + 63) / 64, H, B), dim3(256), 0, st, q, k, vt, T, Tpad, S, scale, out);
-    else                hipLaunchKernelGGL((k_attn_enc<2, 1>), dim3((T + 31) / 32, H, B), dim3(128), 0, st, q, k, vt, T, Tpad, S, scale, out);
+    if (nw == 4 && ks2) hipLaunchKernelGGL((k_attn_enc<4, 2>), dim3((T + 63) / 64, H, B), dim3(512), 0, st, q, k, vt, T, Tpad, S, scale, out, out32);
+    else if (nw == 4)   hipLaunchKernelGGL((k_attn_enc<4, 1>), dim3((T + 63) / 64, H, B), dim3(256), 0, st, q, k, vt, T, Tpad, S, scale, out, out32);
+    else                hipLaunchKernelGGL((k_attn_enc<2, 1>), dim3((T + 31) / 32, H, B), dim3(128), 0, st, q, k, vt, T, Tpad, S, scale, out, out32);
 }
 
 void attn_decoder(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int n_kv,
-                  const float * mask, int ld_mask, __half * out, hipStream_t st, const int32_t * n_kv_dev, int n_kv_max) {
+                  const float * mask, int ld_mask, __half * out, hipStream_t st, const int32_t * n_kv_dev, int n_kv_max, float * out32) {
     const int cap = n_kv_dev ? n_kv_max : n_kv;
     const size_t smem = (((size_t) cap + 3) & ~(size_t) 3) * 4 + 64 * 4 + 256 * 4;
-    hipLaunchKernelGGL(k_attn_dec, dim3(n, H), dim3(256), smem, st, q, S, kc, vc, n_kv, mask, ld_mask, out, n_kv_dev, cap);
+    hipLaunchKernelGGL(k_attn_dec, dim3(n, H), dim3(256), smem, st, q, S, kc, vc, n_kv, mask, ld_mask, out, n_kv_dev, cap, out32);
 }
 
 }} // namespace wmi::k

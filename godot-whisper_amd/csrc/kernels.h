@@ -71,16 +71,19 @@ void layernorm(const float * x, int rows, int S, const float * g, const float * 
 // ---------------------------------------------------------------- attention (k_attn.hip)
 // encoder: q,k [T][S] f16 ; vt [S][Tpad] f16 ; out [T][S] f16 ; scale applied to q.k before softmax
 // B > 1: B chunks back to back (q,k,out [B][T][S]; vt [B][S][Tpad]), one grid.z slice each
+// out32 != null: the result is written as f32 to out32 instead (models whose out-projection is block-quantised quantise that
+// f32 tensor directly, as the reference does); same for the decoder kernels below
 void attn_encoder(const __half * q, const __half * k, const __half * vt, int T, int Tpad, int S, int H,
-                  float scale, __half * out, hipStream_t st, int B = 1);
+                  float scale, __half * out, hipStream_t st, int B = 1, float * out32 = nullptr);
 // decoder: one (token, head) per workgroup.  kc/vc: [n_kv][S] caches (this layer), mask: [n][ld_mask] or null
 void attn_decoder(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int n_kv,
                   const float * mask, int ld_mask, __half * out, hipStream_t st,
-                  const int32_t * n_kv_dev = nullptr, int n_kv_max = 0);   // n_kv_dev: read n_kv on the device (graph replay)
+                  const int32_t * n_kv_dev = nullptr, int n_kv_max = 0,    // n_kv_dev: read n_kv on the device (graph replay)
+                  float * out32 = nullptr);
 
 // decoder cross-attention split over the key axis (3 small launches, NS x H x n workgroups); same numerics
 void attn_cross_split(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int T,
-                      float * scratch, __half * out, hipStream_t st, int64_t kv_row_stride = 0);
+                      float * scratch, __half * out, hipStream_t st, int64_t kv_row_stride = 0, float * out32 = nullptr);
 // same without the combine launch: the consumer GEMV combines the partials in its prologue (GemvArgs::comb_*)
 void attn_cross_split_partials(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int T,
                                float * scratch, const float ** part_o, const float ** part_l, int * ns, hipStream_t st,
@@ -125,7 +128,8 @@ void self_attn_rows(const __half * q, int n, int K, const __half * kc, const __h
 // split cross-attention partials -> out [n][S] f16 (the separate form of GemvArgs::comb_*)
 void set_xattn_probe_skip(int mask);      // probe only
 void attn_cross_partials_layout(int n, int H, int T, float * scratch, const float ** po, const float ** pl, int * pns);
-void attn_cross_combine(const float * part_o, const float * part_l, int ns, int n, int S, int H, __half * out, hipStream_t st);
+void attn_cross_combine(const float * part_o, const float * part_l, int ns, int n, int S, int H, __half * out, hipStream_t st,
+                        float * out32 = nullptr);
 enum { EPI_LOGITS = 100 };                    // C f32 [n][N] = acc
 void gemv(const GemvArgs & a, hipStream_t st);
 void set_attn_one_group(bool on);              // encoder attention: never split the keys over two wave groups (bit-identical for any batch)

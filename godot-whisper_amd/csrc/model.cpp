@@ -3,14 +3,20 @@
 //
 // The caller's buffer is only borrowed during the call (the Godot host frees its PackedByteArray
 // right after whisper_init_from_buffer_with_params, src/speech_to_text.cpp:338-345).  Payloads go
-// host -> device through one staging pass; matrices are kept f16 and re-laid where a kernel wants a
-// different operand order (conv taps, stacked q|k|v rows).  Quantised ggml types are expanded to f16
-// at load (block formats: W/ggml-quants.h:10-47).
+// host -> device through one staging pass.  f16 / f32 matrices are kept f16 and re-laid where a kernel wants a
+// different operand order (conv taps, stacked q|k|v rows).  Block-quantised matrices (W/ggml-quants.h:10-47) keep
+// their blocks: they are only permuted into the tile layout the kernels stream (kernels.h, k_quant.hip) —
+// large-v3 q5_1 occupies ~1.1 GB of HBM instead of the 3.1 GB of an f16 expansion.
+//
+// The file is untrusted input: every length is checked against the buffer before it is used, every tensor must
+// have exactly the rank, dimensions and element count the architecture implies (the reference rejects the same
+// files with "wrong shape / size", W/whisper.cpp:1560-1600), and nothing is copied beyond the size reserved for it.
 
 #include "wmi.h"
 
 #include <cmath>
 #include <cstring>
+#include <new>
 
 namespace wmi {
 
@@ -21,11 +27,11 @@ struct Reader {
     bool eof() const { return off >= n; }
     template <typename T> T get() {
         T v{};
-        if (off + sizeof(T) > n) { ok = false; off = n; return v; }
+        if (off > n || sizeof(T) > n - off) { ok = false; off = n; return v; }
         memcpy(&v, p + off, sizeof(T)); off += sizeof(T); return v;
     }
     const uint8_t * bytes(size_t k) {
-        if (off + k > n) { ok = false; off = n; return nullptr; }
+        if (off > n || k > n - off) { ok = false; off = n; return nullptr; }     // (off + k would wrap for a huge k)
         const uint8_t * r = p + off; off += k; return r;
     }
 };
@@ -57,17 +63,16 @@ float h2f(uint16_t h) { __half v; memcpy(&v, &h, 2); return __half2float(v); }
 uint16_t f2h(float f) { __half v = __float2half_rn(f); uint16_t h; memcpy(&h, &v, 2); return h; }
 
 // expand a tensor payload to f32 (vectors) — small tensors only
-void to_f32(const FileTensor & t, const uint8_t * src, std::vector<float> & out) {
-    size_t ne = 1; for (int i = 0; i < 4; ++i) ne *= (size_t) t.ne[i];
+void to_f32(const FileTensor & t, const uint8_t * src, size_t ne, std::vector<float> & out) {
     out.resize(ne);
     if (t.ttype == T_F32) memcpy(out.data(), src, ne * 4);
     else if (t.ttype == T_F16) { const uint16_t * h = (const uint16_t *) src; for (size_t i = 0; i < ne; ++i) out[i] = h2f(h[i]); }
     else out.assign(ne, 0.0f);
 }
 
-// expand a matrix payload to f16 bit patterns (W/ggml-quants.c dequantize_row_q*)
-void to_f16(const FileTensor & t, const uint8_t * src, std::vector<uint16_t> & out) {
-    size_t ne = 1; for (int i = 0; i < 4; ++i) ne *= (size_t) t.ne[i];
+// matrix payload -> f16 bit patterns.  (The quantised cases dequantise as W/ggml-quants.c dequantize_row_q* and are only
+// reached for 3-D tensors — the quantize tool leaves those f16 — 2-D quantised matrices keep their blocks, see qmat_into.)
+void to_f16(const FileTensor & t, const uint8_t * src, size_t ne, std::vector<uint16_t> & out) {
     out.resize(ne);
     switch (t.ttype) {
         case T_F16: memcpy(out.data(), src, ne * 2); break;
@@ -125,7 +130,14 @@ void to_f16(const FileTensor & t, const uint8_t * src, std::vector<uint16_t> & o
 
 bool parse_model(const uint8_t * buf, size_t n, ModelFile & mf) {
     Reader rd{buf, n};
-    if (rd.get<uint32_t>() != 0x67676d6c) { WMI_ERR("%s: invalid model data (bad magic)\n", __func__); return false; }
+    const uint32_t magic = rd.get<uint32_t>();
+    size_t arena_hint = 0;
+    if (magic == 0x686d6977u) {                       // "wmih": a model image without tensor payloads (export_header)
+        mf.directory_only = true;
+        arena_hint = (size_t) rd.get<uint64_t>();
+        (void) arena_hint;
+        if (rd.get<uint32_t>() != 0x67676d6c) { WMI_ERR("%s: invalid header image\n", __func__); return false; }
+    } else if (magic != 0x67676d6c) { WMI_ERR("%s: invalid model data (bad magic)\n", __func__); return false; }
     HParams & hp = mf.hp;
     hp.n_vocab = rd.get<int32_t>();       hp.n_audio_ctx = rd.get<int32_t>();   hp.n_audio_state = rd.get<int32_t>();
     hp.n_audio_head = rd.get<int32_t>();  hp.n_audio_layer = rd.get<int32_t>(); hp.n_text_ctx = rd.get<int32_t>();
@@ -134,10 +146,19 @@ bool parse_model(const uint8_t * buf, size_t n, ModelFile & mf) {
     if (!rd.ok) { WMI_ERR("%s: truncated header\n", __func__); return false; }
     switch (hp.n_audio_layer) { case 4: mf.model_type = 1; break; case 6: mf.model_type = 2; break; case 12: mf.model_type = 3; break;
                                 case 24: mf.model_type = 4; break; case 32: mf.model_type = 5; break; default: mf.model_type = 0; }
-    const int qntvr = hp.ftype / 1000;
-    hp.ftype %= 1000;
+    const int qntvr = hp.ftype >= 0 ? hp.ftype / 1000 : 0;
+    if (hp.ftype >= 0) hp.ftype %= 1000;
     if (ftype_to_type(hp.ftype) < 0) { WMI_ERR("%s: invalid model (bad ftype value %d)\n", __func__, hp.ftype); return false; }
-    if (hp.n_audio_state != hp.n_text_state || hp.n_audio_state % hp.n_audio_head != 0 ||
+    mf.quantised = hp.ftype >= 2;
+    // every size that later becomes a divisor, an allocation or a kernel bound
+    auto in = [](int32_t v, int32_t lo, int32_t hi) { return v >= lo && v <= hi; };
+    if (!in(hp.n_vocab, 1, 65536) || !in(hp.n_audio_ctx, 1, 1 << 16) || !in(hp.n_text_ctx, 8, 1 << 14) ||
+        !in(hp.n_audio_state, 64, 1 << 14) || !in(hp.n_text_state, 64, 1 << 14) || !in(hp.n_audio_head, 1, 256) || !in(hp.n_text_head, 1, 256) ||
+        !in(hp.n_audio_layer, 1, 256) || !in(hp.n_text_layer, 1, 256) || !in(hp.n_mels, 1, 256)) {
+        WMI_ERR("%s: invalid model (hyper-parameter out of range)\n", __func__);
+        return false;
+    }
+    if (hp.n_audio_state != hp.n_text_state || hp.n_audio_state % hp.n_audio_head != 0 || hp.n_text_state % hp.n_text_head != 0 ||
         hp.n_audio_state / hp.n_audio_head != 64 || hp.n_text_state / hp.n_text_head != 64) {
         WMI_ERR("%s: unsupported geometry (state %d/%d heads %d/%d; head size must be 64)\n", __func__,
                 hp.n_audio_state, hp.n_text_state, hp.n_audio_head, hp.n_text_head);
@@ -148,7 +169,7 @@ bool parse_model(const uint8_t * buf, size_t n, ModelFile & mf) {
              hp.n_audio_head, hp.n_audio_layer, hp.n_text_ctx, hp.n_text_state, hp.n_text_head, hp.n_text_layer, hp.n_mels, hp.ftype, qntvr);
 
     mf.n_filt_mel = rd.get<int32_t>(); mf.n_filt_fft = rd.get<int32_t>();
-    if (!rd.ok || mf.n_filt_mel <= 0 || mf.n_filt_mel > 256 || mf.n_filt_fft != 201) { WMI_ERR("%s: bad mel filter header\n", __func__); return false; }
+    if (!rd.ok || mf.n_filt_mel != hp.n_mels || mf.n_filt_fft != 201) { WMI_ERR("%s: bad mel filter header (%d x %d for n_mels %d)\n", __func__, mf.n_filt_mel, mf.n_filt_fft, hp.n_mels); return false; }
     {
         const size_t nf = (size_t) mf.n_filt_mel * mf.n_filt_fft;
         const uint8_t * p = rd.bytes(nf * 4);
@@ -174,6 +195,7 @@ bool parse_model(const uint8_t * buf, size_t n, ModelFile & mf) {
         const int dt = v.num_languages() - 98;
         v.translate += dt; v.transcribe += dt; v.solm += dt; v.prev += dt; v.nosp += dt; v.not_ += dt; v.beg += dt;
     }
+    if (v.beg >= hp.n_vocab || v.eot >= hp.n_vocab) { WMI_ERR("%s: invalid model (n_vocab %d too small for the special tokens)\n", __func__, hp.n_vocab); return false; }
     if (n_vocab_file < hp.n_vocab) {                  // synthesised names for the special ids (W/whisper.cpp:1258-1289)
         for (int i = n_vocab_file; i < hp.n_vocab; ++i) {
             std::string w;
@@ -195,26 +217,37 @@ bool parse_model(const uint8_t * buf, size_t n, ModelFile & mf) {
             v.id_to_token[i] = w;
         }
     }
+    mf.header_bytes = rd.off - (mf.directory_only ? 12 : 0);
 
     // tensor directory
     mf.tensors.clear();
     while (true) {
         const int32_t n_dims = rd.get<int32_t>(), name_len = rd.get<int32_t>(), ttype = rd.get<int32_t>();
-        if (rd.eof() && !rd.ok) break;                // clean end of file
-        if (!rd.ok) break;
+        if (!rd.ok) break;                            // clean end of file (or a truncated record head: the count check below catches it)
         if (n_dims < 1 || n_dims > 4 || name_len <= 0 || name_len > 256) { WMI_ERR("%s: corrupt tensor header\n", __func__); return false; }
         FileTensor t; t.n_dims = n_dims; t.ttype = ttype;
         size_t ne = 1;
-        for (int i = 0; i < n_dims; ++i) { t.ne[i] = rd.get<int32_t>(); ne *= (size_t) t.ne[i]; }
+        for (int i = 0; i < n_dims; ++i) {
+            t.ne[i] = rd.get<int32_t>();
+            if (!rd.ok || t.ne[i] <= 0 || t.ne[i] > (1 << 24) || ne > ((size_t) 1 << 40) / (size_t) t.ne[i]) { WMI_ERR("%s: corrupt tensor header (dimension)\n", __func__); return false; }
+            ne *= (size_t) t.ne[i];
+        }
         const uint8_t * nm = rd.bytes(name_len);
         if (!rd.ok) { WMI_ERR("%s: truncated tensor header\n", __func__); return false; }
         t.name.assign((const char *) nm, name_len);
         int blck, bpb;
         if (!type_geom(ttype, blck, bpb)) { WMI_ERR("%s: tensor '%s' has unsupported type %d\n", __func__, t.name.c_str(), ttype); return false; }
-        t.nbytes = ne / blck * bpb; t.offset = rd.off;
-        if (!rd.bytes(t.nbytes)) { WMI_ERR("%s: tensor '%s' is truncated\n", __func__, t.name.c_str()); return false; }
+        if (t.ne[0] % blck != 0) { WMI_ERR("%s: tensor '%s': row length %lld is not a multiple of the block size %d\n", __func__, t.name.c_str(), (long long) t.ne[0], blck); return false; }
+        t.nbytes = ne / blck * bpb;
+        if (mf.directory_only) t.offset = 0;
+        else {
+            t.offset = rd.off;
+            if (!rd.bytes(t.nbytes)) { WMI_ERR("%s: tensor '%s' is truncated\n", __func__, t.name.c_str()); return false; }
+        }
+        if (mf.tensors.count(t.name)) { WMI_ERR("%s: tensor '%s' appears twice\n", __func__, t.name.c_str()); return false; }
         mf.tensors[t.name] = t;
     }
+    if (!rd.eof()) { WMI_ERR("%s: trailing bytes after the last tensor\n", __func__); return false; }
     mf.n_loaded = (int) mf.tensors.size();
     {
         const int expected = 7 + 15 * hp.n_audio_layer + 4 + 24 * hp.n_text_layer;   // names at W/whisper.cpp:1354-1510
@@ -228,140 +261,209 @@ bool parse_model(const uint8_t * buf, size_t n, ModelFile & mf) {
     return true;
 }
 
+std::vector<uint8_t> export_header(const ModelFile & mf, const uint8_t * buf, size_t arena_bytes) {
+    std::vector<uint8_t> out;
+    auto put = [&](const void * p, size_t k) { const uint8_t * b = (const uint8_t *) p; out.insert(out.end(), b, b + k); };
+    const uint32_t magic = 0x686d6977u; const uint64_t ab = arena_bytes;
+    put(&magic, 4); put(&ab, 8);
+    put(buf, mf.header_bytes);                            // the file's own magic, hparams, filters, vocabulary
+    for (const auto & kv : mf.tensors) {
+        const FileTensor & t = kv.second;
+        const int32_t h[3] = { t.n_dims, (int32_t) t.name.size(), t.ttype };
+        put(h, 12);
+        for (int i = 0; i < t.n_dims; ++i) { const int32_t e = (int32_t) t.ne[i]; put(&e, 4); }
+        put(t.name.data(), t.name.size());
+    }
+    return out;
+}
+
 // ------------------------------------------------------------------------------------------------
 namespace {
 
+// Two passes over the same sequence of reservations: pass 1 (fill = false) only lays the arena out, pass 2 copies into a
+// staging image of exactly that size.  The layout depends on the tensor directory alone, so every rank of a multi-GPU job
+// derives the same offsets and the arena of rank 0 can be broadcast as is.
 struct Arena {
-    std::vector<uint8_t> host;            // staging image of the whole arena
-    size_t reserve(size_t bytes) { const size_t o = (host.size() + 255) & ~(size_t) 255; host.resize(o + bytes, 0); return o; }
+    uint8_t * host = nullptr;             // staging image (pass 2)
+    size_t size = 0;
+    bool fill = false;
+    size_t reserve(size_t bytes) { const size_t o = (size + 255) & ~(size_t) 255; size = o + bytes; return o; }
 };
 
 struct Builder {
     const ModelFile & mf; const uint8_t * buf; Arena & ar; bool ok = true;
+    int qtype = 0; size_t matrix_bytes = 0;
+    // a tensor of exactly this rank and these dimensions (ggml order: ne[0] fastest), or null + an error
     const FileTensor * find(const std::string & name, std::initializer_list<int64_t> ne) {
         auto it = mf.tensors.find(name);
         if (it == mf.tensors.end() && mf.n_loaded == 0) return nullptr;   // empty test model: zero weights (W/whisper.cpp:1627-1628)
         if (it == mf.tensors.end()) { WMI_ERR("upload_weights: tensor '%s' missing from model file\n", name.c_str()); ok = false; return nullptr; }
+        const FileTensor & t = it->second;
+        bool good = t.n_dims == (int) ne.size();
         int i = 0;
-        for (int64_t e : ne) { if (it->second.ne[i] != e) { WMI_ERR("upload_weights: tensor '%s' has wrong shape in model file\n", name.c_str()); ok = false; return nullptr; } ++i; }
-        return &it->second;
+        for (int64_t e : ne) { good = good && t.ne[i] == e; ++i; }
+        if (!good) { WMI_ERR("upload_weights: tensor '%s' has wrong shape in model file\n", name.c_str()); ok = false; return nullptr; }
+        return &t;
     }
+    bool quantised(const FileTensor * t) const { return t && t->ttype != T_F32 && t->ttype != T_F16; }
+    const uint8_t * payload(const FileTensor * t) const { return (ar.fill && buf && t) ? buf + t->offset : nullptr; }
+
     size_t vec(const std::string & name, int64_t n, bool as_2d = false) {          // f32 vector
         const size_t off = ar.reserve((size_t) n * 4);
         const FileTensor * t = as_2d ? find(name, {1, n}) : find(name, {n});
         if (!t) return off;
-        std::vector<float> f; to_f32(*t, buf + t->offset, f);
-        memcpy(ar.host.data() + off, f.data(), (size_t) n * 4);
+        if (t->ttype != T_F32 && t->ttype != T_F16) { WMI_ERR("upload_weights: tensor '%s': vectors must be f32 or f16\n", name.c_str()); ok = false; return off; }
+        if (const uint8_t * p = payload(t)) { std::vector<float> f; to_f32(*t, p, (size_t) n, f); memcpy(ar.host + off, f.data(), (size_t) n * 4); }
         return off;
     }
     size_t mat_f32(const std::string & name, int64_t k, int64_t n) {                // f32 matrix (pos. embeddings)
         const size_t off = ar.reserve((size_t) (k * n) * 4);
         const FileTensor * t = find(name, {k, n});
         if (!t) return off;
-        std::vector<float> f; to_f32(*t, buf + t->offset, f);
-        memcpy(ar.host.data() + off, f.data(), f.size() * 4);
+        if (t->ttype != T_F32 && t->ttype != T_F16) { WMI_ERR("upload_weights: tensor '%s': expected f32 or f16\n", name.c_str()); ok = false; return off; }
+        if (const uint8_t * p = payload(t)) { std::vector<float> f; to_f32(*t, p, (size_t) (k * n), f); memcpy(ar.host + off, f.data(), (size_t) (k * n) * 4); }
         return off;
     }
-    void mat_into(const std::string & name, int64_t k, int64_t n, size_t off) {     // f16 [n][k] at a fixed arena offset
-        const FileTensor * t = find(name, {k, n});
-        if (!t) return;
-        std::vector<uint16_t> h; to_f16(*t, buf + t->offset, h);
-        memcpy(ar.host.data() + off, h.data(), h.size() * 2);
-    }
-    size_t mat(const std::string & name, int64_t k, int64_t n) {
-        const size_t off = ar.reserve((size_t) (k * n) * 2);
-        mat_into(name, k, n, off);
+    // A matrix [n][k] that may be stacked from `parts` tensors of [rows_each][k] (q | k | v rows): either f16 rows or quantised
+    // tiles — one kind for the whole stack.  Returns the arena offset; `qt` = 0 (f16) or the ggml type of the tiles.
+    size_t stack(const std::vector<std::string> & names, int64_t k, int64_t rows_each, int & qt) {
+        const int64_t parts = (int64_t) names.size();
+        std::vector<const FileTensor *> ts;
+        qt = 0; bool any_q = false, any_f = false;
+        for (const std::string & nm : names) {
+            const FileTensor * t = find(nm, {k, rows_each});
+            ts.push_back(t);
+            if (t) { if (quantised(t)) { any_q = true; if (qt && qt != t->ttype) ok = false; qt = t->ttype; } else any_f = true; }
+        }
+        if ((any_q && any_f) || !ok) { if (ok) WMI_ERR("upload_weights: tensors stacked with '%s' mix quantised and plain types\n", names[0].c_str()); ok = false; qt = 0; }
+        // the reference allocates every 2-D weight with the type the header's ftype names and rejects a file whose tensor has another
+        // size (W/whisper.cpp:1295-1296, 1580-1600): the same rule here
+        if (ok && (any_q || any_f) && mf.n_loaded > 0) {
+            const int want = ftype_to_type(mf.hp.ftype);
+            const bool good = mf.quantised ? (any_q && qt == want) : !any_q;
+            if (!good) { WMI_ERR("upload_weights: tensor '%s' has wrong size in model file (type does not match ftype %d)\n", names[0].c_str(), mf.hp.ftype); ok = false; qt = 0; }
+        }
+        if (qt) {
+            // stacked parts must start on a row-group boundary (the last row group of a lone matrix is padded with zero blocks)
+            if (k % 64 != 0 || (parts > 1 && rows_each % 32 != 0)) { WMI_ERR("upload_weights: tensor '%s': quantised matrices need K %% 64 == 0 (and stacked rows %% 32 == 0)\n", names[0].c_str()); ok = false; qt = 0; }
+            else if (qtype && qtype != qt) { WMI_ERR("upload_weights: more than one quantisation type in one model (%d and %d)\n", qtype, qt); ok = false; qt = 0; }
+            else qtype = qt;
+        }
+        if (qt) {
+            const size_t each = k::q_matrix_bytes(qt, rows_each, k);
+            const size_t off = ar.reserve(each * parts);
+            matrix_bytes += each * parts;
+            for (int64_t p = 0; p < parts; ++p)
+                if (const uint8_t * src = payload(ts[p])) k::q_repack_host(qt, src, rows_each, k, ar.host + off + each * p);
+            return off;
+        }
+        const size_t each = (size_t) (k * rows_each) * 2;
+        const size_t off = ar.reserve(each * parts);
+        matrix_bytes += each * parts;
+        for (int64_t p = 0; p < parts; ++p)
+            if (const uint8_t * src = payload(ts[p])) { std::vector<uint16_t> h; to_f16(*ts[p], src, (size_t) (k * rows_each), h); memcpy(ar.host + off + each * p, h.data(), each); }
         return off;
     }
+    size_t mat(const std::string & name, int64_t k, int64_t n, int & qt) { return stack({name}, k, n, qt); }
     // conv weight ggml [3][IC][OC] (tap fastest) -> [OC][tap][IC] f16, row padded with zeros to kpad
     size_t conv(const std::string & name, int64_t ic, int64_t oc, int kpad) {
         const size_t off = ar.reserve((size_t) oc * kpad * 2);
         const FileTensor * t = find(name, {3, ic, oc});
         if (!t) return off;
-        std::vector<uint16_t> h; to_f16(*t, buf + t->offset, h);
-        uint16_t * dst = (uint16_t *) (ar.host.data() + off);
-        for (int64_t o = 0; o < oc; ++o)
-            for (int64_t c = 0; c < ic; ++c)
-                for (int tap = 0; tap < 3; ++tap)
-                    dst[o * kpad + tap * ic + c] = h[(o * ic + c) * 3 + tap];
+        matrix_bytes += (size_t) oc * kpad * 2;
+        if (const uint8_t * p = payload(t)) {
+            std::vector<uint16_t> h; to_f16(*t, p, (size_t) (3 * ic * oc), h);
+            uint16_t * dst = (uint16_t *) (ar.host + off);
+            for (int64_t o = 0; o < oc; ++o)
+                for (int64_t c = 0; c < ic; ++c)
+                    for (int tap = 0; tap < 3; ++tap)
+                        dst[o * kpad + tap * ic + c] = h[(o * ic + c) * 3 + tap];
+        }
         return off;
     }
 };
 
-} // namespace
+struct EncOff { size_t ln1g, ln1b, ln2g, ln2b, wqkv, bqkv, wo, bo, w1, b1, w2, b2; int tqkv, to, t1, t2; };
+struct DecOff { size_t ln1g, ln1b, ln2g, ln2b, ln3g, ln3b, wqkv, bqkv, wo, bo, wcq, bcq, wco, bco, w1, b1, w2, b2; int tqkv, to, tcq, tco, t1, t2; };
+struct Plan {
+    size_t c1w, c1b, c2w, c2b, epe, elng, elnb, wckv, bckv, dpe, dte, dlng, dlnb, filt, rng, taps;
+    int tckv = 0, tte = 0;
+    std::vector<EncOff> eo; std::vector<DecOff> dof;
+};
 
-bool upload_weights(const ModelFile & mf, const uint8_t * host_buf, const void * /*dev_image*/, Weights & w, hipStream_t st) {
+// one pass over the architecture's tensors in a fixed order (W/whisper.cpp:1298-1513)
+bool build(const ModelFile & mf, const uint8_t * buf, Arena & ar, Plan & pl, Weights & w) {
     const HParams & hp = mf.hp;
     const int64_t S = hp.n_audio_state, La = hp.n_audio_layer, Lt = hp.n_text_layer;
-    Arena ar;
-    Builder b{mf, host_buf, ar};
-
-    struct EncOff { size_t ln1g, ln1b, ln2g, ln2b, wqkv, bqkv, wo, bo, w1, b1, w2, b2; };
-    struct DecOff { size_t ln1g, ln1b, ln2g, ln2b, ln3g, ln3b, wqkv, bqkv, wo, bo, wcq, bcq, wco, bco, w1, b1, w2, b2; };
-    std::vector<EncOff> eo(La); std::vector<DecOff> dof(Lt);
-
+    Builder b{mf, buf, ar};
+    pl.eo.assign(La, EncOff{}); pl.dof.assign(Lt, DecOff{});
     w.conv1_k = (int) ((3 * hp.n_mels + 31) / 32 * 32);
     w.conv2_k = (int) (3 * S);
-    const size_t o_c1w = b.conv("encoder.conv1.weight", hp.n_mels, S, w.conv1_k);
-    const size_t o_c1b = b.vec("encoder.conv1.bias", S, true);
-    const size_t o_c2w = b.conv("encoder.conv2.weight", S, S, w.conv2_k);
-    const size_t o_c2b = b.vec("encoder.conv2.bias", S, true);
-    const size_t o_epe = b.mat_f32("encoder.positional_embedding", S, hp.n_audio_ctx);
+    pl.c1w = b.conv("encoder.conv1.weight", hp.n_mels, S, w.conv1_k);
+    pl.c1b = b.vec("encoder.conv1.bias", S, true);
+    pl.c2w = b.conv("encoder.conv2.weight", S, S, w.conv2_k);
+    pl.c2b = b.vec("encoder.conv2.bias", S, true);
+    pl.epe = b.mat_f32("encoder.positional_embedding", S, hp.n_audio_ctx);
+    auto qkv_bias = [&](const std::string & p, size_t & off) {
+        off = ar.reserve((size_t) 3 * S * 4);
+        const size_t q = b.vec(p + "attn.query.bias", S), v = b.vec(p + "attn.value.bias", S);
+        if (ar.fill) { memcpy(ar.host + off, ar.host + q, S * 4); memset(ar.host + off + S * 4, 0, S * 4); memcpy(ar.host + off + 2 * S * 4, ar.host + v, S * 4); }
+    };
     for (int64_t i = 0; i < La; ++i) {
         const std::string p = "encoder.blocks." + std::to_string(i) + ".";
-        EncOff & e = eo[i];
+        EncOff & e = pl.eo[i];
         e.ln1g = b.vec(p + "attn_ln.weight", S); e.ln1b = b.vec(p + "attn_ln.bias", S);
-        e.wqkv = ar.reserve((size_t) 3 * S * S * 2);
-        b.mat_into(p + "attn.query.weight", S, S, e.wqkv);
-        b.mat_into(p + "attn.key.weight",   S, S, e.wqkv + (size_t) S * S * 2);
-        b.mat_into(p + "attn.value.weight", S, S, e.wqkv + (size_t) 2 * S * S * 2);
-        e.bqkv = ar.reserve((size_t) 3 * S * 4);
-        { const size_t q = b.vec(p + "attn.query.bias", S), v = b.vec(p + "attn.value.bias", S);
-          memcpy(ar.host.data() + e.bqkv, ar.host.data() + q, S * 4); memcpy(ar.host.data() + e.bqkv + 2 * S * 4, ar.host.data() + v, S * 4); }
-        e.wo = b.mat(p + "attn.out.weight", S, S); e.bo = b.vec(p + "attn.out.bias", S);
+        e.wqkv = b.stack({p + "attn.query.weight", p + "attn.key.weight", p + "attn.value.weight"}, S, S, e.tqkv);
+        qkv_bias(p, e.bqkv);
+        e.wo = b.mat(p + "attn.out.weight", S, S, e.to); e.bo = b.vec(p + "attn.out.bias", S);
         e.ln2g = b.vec(p + "mlp_ln.weight", S);    e.ln2b = b.vec(p + "mlp_ln.bias", S);
-        e.w1 = b.mat(p + "mlp.0.weight", S, 4 * S); e.b1 = b.vec(p + "mlp.0.bias", 4 * S);
-        e.w2 = b.mat(p + "mlp.2.weight", 4 * S, S); e.b2 = b.vec(p + "mlp.2.bias", S);
+        e.w1 = b.mat(p + "mlp.0.weight", S, 4 * S, e.t1); e.b1 = b.vec(p + "mlp.0.bias", 4 * S);
+        e.w2 = b.mat(p + "mlp.2.weight", 4 * S, S, e.t2); e.b2 = b.vec(p + "mlp.2.bias", S);
     }
-    const size_t o_elng = b.vec("encoder.ln_post.weight", S), o_elnb = b.vec("encoder.ln_post.bias", S);
+    pl.elng = b.vec("encoder.ln_post.weight", S); pl.elnb = b.vec("encoder.ln_post.bias", S);
 
-    const size_t o_wckv = ar.reserve((size_t) Lt * 2 * S * S * 2);
-    const size_t o_bckv = ar.reserve((size_t) Lt * 2 * S * 4);
-    const size_t o_dpe = b.mat_f32("decoder.positional_embedding", S, hp.n_text_ctx);
-    const size_t o_dte = b.mat("decoder.token_embedding.weight", S, hp.n_vocab);
+    {   // cross-attention k | v of every decoder layer stacked: [L][2S][S]; bias [L][2S] (k part zero)
+        std::vector<std::string> names;
+        for (int64_t i = 0; i < Lt; ++i) {
+            const std::string p = "decoder.blocks." + std::to_string(i) + ".";
+            names.push_back(p + "cross_attn.key.weight"); names.push_back(p + "cross_attn.value.weight");
+        }
+        pl.wckv = b.stack(names, S, S, pl.tckv);
+        pl.bckv = ar.reserve((size_t) Lt * 2 * S * 4);
+        if (ar.fill) memset(ar.host + pl.bckv, 0, (size_t) Lt * 2 * S * 4);
+    }
+    pl.dpe = b.mat_f32("decoder.positional_embedding", S, hp.n_text_ctx);
+    pl.dte = b.mat("decoder.token_embedding.weight", S, hp.n_vocab, pl.tte);
     for (int64_t i = 0; i < Lt; ++i) {
         const std::string p = "decoder.blocks." + std::to_string(i) + ".";
-        DecOff & d = dof[i];
+        DecOff & d = pl.dof[i];
         d.ln1g = b.vec(p + "attn_ln.weight", S); d.ln1b = b.vec(p + "attn_ln.bias", S);
-        d.wqkv = ar.reserve((size_t) 3 * S * S * 2);
-        b.mat_into(p + "attn.query.weight", S, S, d.wqkv);
-        b.mat_into(p + "attn.key.weight",   S, S, d.wqkv + (size_t) S * S * 2);
-        b.mat_into(p + "attn.value.weight", S, S, d.wqkv + (size_t) 2 * S * S * 2);
-        d.bqkv = ar.reserve((size_t) 3 * S * 4);
-        { const size_t q = b.vec(p + "attn.query.bias", S), v = b.vec(p + "attn.value.bias", S);
-          memcpy(ar.host.data() + d.bqkv, ar.host.data() + q, S * 4); memcpy(ar.host.data() + d.bqkv + 2 * S * 4, ar.host.data() + v, S * 4); }
-        d.wo = b.mat(p + "attn.out.weight", S, S); d.bo = b.vec(p + "attn.out.bias", S);
+        d.wqkv = b.stack({p + "attn.query.weight", p + "attn.key.weight", p + "attn.value.weight"}, S, S, d.tqkv);
+        qkv_bias(p, d.bqkv);
+        d.wo = b.mat(p + "attn.out.weight", S, S, d.to); d.bo = b.vec(p + "attn.out.bias", S);
         d.ln2g = b.vec(p + "cross_attn_ln.weight", S); d.ln2b = b.vec(p + "cross_attn_ln.bias", S);
-        d.wcq = b.mat(p + "cross_attn.query.weight", S, S); d.bcq = b.vec(p + "cross_attn.query.bias", S);
-        b.mat_into(p + "cross_attn.key.weight",   S, S, o_wckv + (size_t) (i * 2) * S * S * 2);
-        b.mat_into(p + "cross_attn.value.weight", S, S, o_wckv + (size_t) (i * 2 + 1) * S * S * 2);
+        d.wcq = b.mat(p + "cross_attn.query.weight", S, S, d.tcq); d.bcq = b.vec(p + "cross_attn.query.bias", S);
         { const size_t v = b.vec(p + "cross_attn.value.bias", S);
-          memcpy(ar.host.data() + o_bckv + (size_t) (i * 2 + 1) * S * 4, ar.host.data() + v, S * 4); }
-        d.wco = b.mat(p + "cross_attn.out.weight", S, S); d.bco = b.vec(p + "cross_attn.out.bias", S);
+          if (ar.fill) memcpy(ar.host + pl.bckv + (size_t) (i * 2 + 1) * S * 4, ar.host + v, S * 4); }
+        d.wco = b.mat(p + "cross_attn.out.weight", S, S, d.tco); d.bco = b.vec(p + "cross_attn.out.bias", S);
         d.ln3g = b.vec(p + "mlp_ln.weight", S); d.ln3b = b.vec(p + "mlp_ln.bias", S);
-        d.w1 = b.mat(p + "mlp.0.weight", S, 4 * S); d.b1 = b.vec(p + "mlp.0.bias", 4 * S);
-        d.w2 = b.mat(p + "mlp.2.weight", 4 * S, S); d.b2 = b.vec(p + "mlp.2.bias", S);
+        d.w1 = b.mat(p + "mlp.0.weight", S, 4 * S, d.t1); d.b1 = b.vec(p + "mlp.0.bias", 4 * S);
+        d.w2 = b.mat(p + "mlp.2.weight", 4 * S, S, d.t2); d.b2 = b.vec(p + "mlp.2.bias", S);
     }
-    const size_t o_dlng = b.vec("decoder.ln.weight", S), o_dlnb = b.vec("decoder.ln.bias", S);
-    const size_t o_filt = ar.reserve(mf.filters.size() * 4);
-    memcpy(ar.host.data() + o_filt, mf.filters.data(), mf.filters.size() * 4);
+    pl.dlng = b.vec("decoder.ln.weight", S); pl.dlnb = b.vec("decoder.ln.bias", S);
+    pl.filt = ar.reserve(mf.filters.size() * 4);
+    if (ar.fill) memcpy(ar.host + pl.filt, mf.filters.data(), mf.filters.size() * 4);
     // per mel filter: the range of 4-tap groups that hold a non-zero weight.  The reference sums all 201 taps
     // (W/whisper.cpp:2759-2768); groups of zeros add exactly +0.0 to its double accumulator, so skipping them is
     // bit-identical and cuts the filterbank work ~8x (triangular filters are narrow).
     const int n_filt = mf.n_filt_mel, n_fft = mf.n_filt_fft;
-    const size_t o_rng = ar.reserve((size_t) std::max(n_filt, 1) * 2 * 4);
-    {
-        int32_t * rng = (int32_t *) (ar.host.data() + o_rng);
+    pl.rng = ar.reserve((size_t) std::max(n_filt, 1) * 2 * 4);
+    // ... and those groups themselves, compact and 16-byte aligned: [n_mel][13][4] = the first 12 groups from g0 (zero-padded), then
+    // {tap 200, 0, 0, 0}.  A filter row of the file has 201 floats (804 bytes): read in place, every lane's four taps were four
+    // misaligned scalar loads from a different cache line (k_mel.hip).
+    pl.taps = ar.reserve((size_t) std::max(n_filt, 1) * 13 * 4 * 4);
+    if (ar.fill) {
+        int32_t * rng = (int32_t *) (ar.host + pl.rng);
         const int n_groups = (n_fft - 1) / 4 + ((n_fft - 1) % 4 ? 1 : 0);     // 201 taps: groups 0..49 cover taps 0..199
         for (int j = 0; j < n_filt; ++j) {
             const float * f = mf.filters.data() + (size_t) j * n_fft;
@@ -374,14 +476,7 @@ bool upload_weights(const ModelFile & mf, const uint8_t * host_buf, const void *
             if (g0 > g1) g0 = g1 = 0;
             rng[2 * j] = g0; rng[2 * j + 1] = g1;
         }
-    }
-    // ... and those groups themselves, compact and 16-byte aligned: [n_mel][13][4] = the first 12 groups from g0 (zero-padded), then
-    // {tap 200, 0, 0, 0}.  A filter row of the file has 201 floats (804 bytes): read in place, every lane's four taps were four
-    // misaligned scalar loads from a different cache line (k_mel.hip).
-    const size_t o_taps = ar.reserve((size_t) std::max(n_filt, 1) * 13 * 4 * 4);
-    {
-        const int32_t * rng = (const int32_t *) (ar.host.data() + o_rng);
-        float * taps = (float *) (ar.host.data() + o_taps);
+        float * taps = (float *) (ar.host + pl.taps);
         for (int j = 0; j < n_filt; ++j) {
             const float * f = mf.filters.data() + (size_t) j * n_fft;
             float * t = taps + (size_t) j * 13 * 4;
@@ -394,40 +489,65 @@ bool upload_weights(const ModelFile & mf, const uint8_t * host_buf, const void *
         }
     }
     ar.reserve(4096);                                  // tail slack: GEMM tiles may over-read clamped rows
+    w.qtype = b.qtype; w.matrix_bytes = b.matrix_bytes;
+    return b.ok;
+}
 
-    if (!b.ok) return false;
+} // namespace
 
-    w.arena_bytes = ar.host.size();
+bool upload_weights(const ModelFile & mf, const uint8_t * host_buf, Weights & w, hipStream_t st) {
+    const HParams & hp = mf.hp;
+    const int64_t La = hp.n_audio_layer, Lt = hp.n_text_layer;
+    Plan pl;
+    Arena dry;
+    if (!build(mf, nullptr, dry, pl, w)) return false;
+    w.arena_bytes = (dry.size + 255) & ~(size_t) 255;
     if (!HIP_OK(hipMalloc(&w.arena, w.arena_bytes))) { w.arena = nullptr; return false; }
-    if (!HIP_OK(hipMemcpyAsync(w.arena, ar.host.data(), w.arena_bytes, hipMemcpyHostToDevice, st)) ||
-        !HIP_OK(hipStreamSynchronize(st))) { free_weights(w); return false; }
+    if (host_buf && !mf.directory_only) {
+        std::vector<uint8_t> stage;
+        try { stage.assign(w.arena_bytes, 0); }
+        catch (const std::bad_alloc &) { WMI_ERR("%s: out of host memory staging %.1f MB of weights\n", __func__, w.arena_bytes / 1e6); free_weights(w); return false; }
+        Arena ar; ar.host = stage.data(); ar.fill = true;
+        Plan pl2;
+        if (!build(mf, host_buf, ar, pl2, w) || ar.size != dry.size) { free_weights(w); return false; }
+        if (!HIP_OK(hipMemcpyAsync(w.arena, stage.data(), w.arena_bytes, hipMemcpyHostToDevice, st)) ||
+            !HIP_OK(hipStreamSynchronize(st))) { free_weights(w); return false; }
+    }
 
     uint8_t * base = (uint8_t *) w.arena;
-    auto H = [&](size_t o) { return (const __half *) (base + o); };
+    auto H = [&](size_t o, int qt) { return qt ? (const __half *) nullptr : (const __half *) (base + o); };
+    auto Q = [&](size_t o, int qt) { k::QMat m; if (qt) { m.tiles = base + o; m.qtype = qt; } return m; };
     auto F = [&](size_t o) { return (const float *) (base + o); };
-    w.conv1_w = H(o_c1w); w.conv1_b = F(o_c1b); w.conv2_w = H(o_c2w); w.conv2_b = F(o_c2b); w.e_pe = F(o_epe);
+    w.conv1_w = (const __half *) (base + pl.c1w); w.conv1_b = F(pl.c1b); w.conv2_w = (const __half *) (base + pl.c2w); w.conv2_b = F(pl.c2b); w.e_pe = F(pl.epe);
     w.enc.resize(La);
     for (int64_t i = 0; i < La; ++i) {
-        const EncOff & e = eo[i]; EncLayerW & l = w.enc[i];
+        const EncOff & e = pl.eo[i]; EncLayerW & l = w.enc[i];
         l.ln1_g = F(e.ln1g); l.ln1_b = F(e.ln1b); l.ln2_g = F(e.ln2g); l.ln2_b = F(e.ln2b);
-        l.w_qkv = H(e.wqkv); l.b_qkv = F(e.bqkv); l.w_o = H(e.wo); l.b_o = F(e.bo);
-        l.w_fc1 = H(e.w1); l.b_fc1 = F(e.b1); l.w_fc2 = H(e.w2); l.b_fc2 = F(e.b2);
+        l.w_qkv = H(e.wqkv, e.tqkv); l.q_qkv = Q(e.wqkv, e.tqkv); l.b_qkv = F(e.bqkv);
+        l.w_o = H(e.wo, e.to); l.q_o = Q(e.wo, e.to); l.b_o = F(e.bo);
+        l.w_fc1 = H(e.w1, e.t1); l.q_fc1 = Q(e.w1, e.t1); l.b_fc1 = F(e.b1);
+        l.w_fc2 = H(e.w2, e.t2); l.q_fc2 = Q(e.w2, e.t2); l.b_fc2 = F(e.b2);
     }
-    w.e_ln_g = F(o_elng); w.e_ln_b = F(o_elnb);
-    w.w_ckv = H(o_wckv); w.b_ckv = F(o_bckv); w.d_pe = F(o_dpe); w.d_te = H(o_dte);
+    w.e_ln_g = F(pl.elng); w.e_ln_b = F(pl.elnb);
+    w.w_ckv = H(pl.wckv, pl.tckv); w.q_ckv = Q(pl.wckv, pl.tckv); w.b_ckv = F(pl.bckv);
+    w.d_pe = F(pl.dpe); w.d_te = H(pl.dte, pl.tte); w.q_te = Q(pl.dte, pl.tte);
     w.dec.resize(Lt);
     for (int64_t i = 0; i < Lt; ++i) {
-        const DecOff & d = dof[i]; DecLayerW & l = w.dec[i];
+        const DecOff & d = pl.dof[i]; DecLayerW & l = w.dec[i];
         l.ln1_g = F(d.ln1g); l.ln1_b = F(d.ln1b); l.ln2_g = F(d.ln2g); l.ln2_b = F(d.ln2b); l.ln3_g = F(d.ln3g); l.ln3_b = F(d.ln3b);
-        l.w_qkv = H(d.wqkv); l.b_qkv = F(d.bqkv); l.w_o = H(d.wo); l.b_o = F(d.bo);
-        l.w_cq = H(d.wcq); l.b_cq = F(d.bcq); l.w_co = H(d.wco); l.b_co = F(d.bco);
-        l.w_fc1 = H(d.w1); l.b_fc1 = F(d.b1); l.w_fc2 = H(d.w2); l.b_fc2 = F(d.b2);
+        l.w_qkv = H(d.wqkv, d.tqkv); l.q_qkv = Q(d.wqkv, d.tqkv); l.b_qkv = F(d.bqkv);
+        l.w_o = H(d.wo, d.to); l.q_o = Q(d.wo, d.to); l.b_o = F(d.bo);
+        l.w_cq = H(d.wcq, d.tcq); l.q_cq = Q(d.wcq, d.tcq); l.b_cq = F(d.bcq);
+        l.w_co = H(d.wco, d.tco); l.q_co = Q(d.wco, d.tco); l.b_co = F(d.bco);
+        l.w_fc1 = H(d.w1, d.t1); l.q_fc1 = Q(d.w1, d.t1); l.b_fc1 = F(d.b1);
+        l.w_fc2 = H(d.w2, d.t2); l.q_fc2 = Q(d.w2, d.t2); l.b_fc2 = F(d.b2);
     }
-    w.d_ln_g = F(o_dlng); w.d_ln_b = F(o_dlnb);
-    w.mel_filters = F(o_filt);
-    w.mel_ranges = (const int32_t *) (base + o_rng);
-    w.mel_taps = F(o_taps);
-    WMI_INFO("%s: device weight arena = %.2f MB\n", __func__, w.arena_bytes / 1e6);
+    w.d_ln_g = F(pl.dlng); w.d_ln_b = F(pl.dlnb);
+    w.mel_filters = F(pl.filt);
+    w.mel_ranges = (const int32_t *) (base + pl.rng);
+    w.mel_taps = F(pl.taps);
+    WMI_INFO("%s: device weight arena = %.2f MB (matrices %.2f MB%s)\n", __func__, w.arena_bytes / 1e6, w.matrix_bytes / 1e6,
+             w.qtype ? ", block-quantised, kept quantised" : "");
     return true;
 }
 

@@ -17,6 +17,7 @@
 
 #include "../../include/whisper_mi355.h"
 #include "../../include/wmi_device.h"
+#include "kernels.h"
 
 namespace wmi {
 
@@ -56,7 +57,7 @@ struct FileTensor {
     int32_t     ttype = 0;          // ggml_type
     int32_t     n_dims = 0;
     int64_t     ne[4] = {1, 1, 1, 1};
-    size_t      offset = 0, nbytes = 0;
+    size_t      offset = 0, nbytes = 0;     // payload position in the model buffer (offset = 0, nbytes known: directory-only image)
 };
 
 struct ModelFile {
@@ -67,20 +68,28 @@ struct ModelFile {
     Vocab   vocab;
     std::map<std::string, FileTensor> tensors;
     int     n_loaded = 0;
+    bool    quantised = false;      // ftype names a block-quantised weight type: the 2-D tensors are q4_0 .. q8_0 blocks
+    size_t  header_bytes = 0;       // bytes of the file in front of the first tensor record (hparams, filters, vocabulary)
+    bool    directory_only = false; // image without tensor payloads (wmi_export_header): weights arrive as a device arena
 };
 
 // parse header + vocab + tensor directory out of an in-memory ggml file (W/whisper.cpp:1102-1640)
 bool parse_model(const uint8_t * buf, size_t n, ModelFile & mf);
+// the same file without its tensor payloads ("wmih" image): what a rank needs besides the device arena (multi-GPU load)
+std::vector<uint8_t> export_header(const ModelFile & mf, const uint8_t * buf, size_t arena_bytes);
 
 // ---------------------------------------------------------------- weights (device view)
-// All matrices are f16, row-major [out][in] with `in` contiguous (the ggml ne0 order), which is
-// the K-contiguous "B^T" operand layout of the MFMA GEMM.  Vectors are f32.
+// f16 / f32 files: all matrices are f16, row-major [out][in] with `in` contiguous (the ggml ne0 order), which is
+// the K-contiguous "B^T" operand layout of the MFMA GEMM.  Block-quantised files (q4_0 q4_1 q5_0 q5_1 q8_0): the 2-D
+// tensors keep their blocks, permuted into the tile layout of k_quant.hip (kernels.h); the w_* pointer of such a matrix
+// is null and its q_* member holds the tiles.  Vectors are f32.
 struct EncLayerW {
     const float *ln1_g, *ln1_b, *ln2_g, *ln2_b;
     const __half *w_qkv;  const float *b_qkv;    // [3S][S]; rows q | k | v; k-bias = 0
     const __half *w_o;    const float *b_o;      // [S][S]
     const __half *w_fc1;  const float *b_fc1;    // [4S][S]
     const __half *w_fc2;  const float *b_fc2;    // [S][4S]
+    k::QMat q_qkv, q_o, q_fc1, q_fc2;
 };
 struct DecLayerW {
     const float *ln1_g, *ln1_b, *ln2_g, *ln2_b, *ln3_g, *ln3_b;
@@ -90,6 +99,7 @@ struct DecLayerW {
     const __half *w_co;   const float *b_co;
     const __half *w_fc1;  const float *b_fc1;
     const __half *w_fc2;  const float *b_fc2;
+    k::QMat q_qkv, q_o, q_cq, q_co, q_fc1, q_fc2;
 };
 struct Weights {
     void *  arena = nullptr;  size_t arena_bytes = 0;
@@ -102,8 +112,12 @@ struct Weights {
     const float  *e_ln_g, *e_ln_b;
     // cross-attention K/V projections of all decoder layers stacked: [L][2S][S] (k rows, v rows)
     const __half *w_ckv;   const float *b_ckv;                        // bias [L][2S] (k part 0)
+    k::QMat       q_ckv;
     const float  *d_pe;                                               // [n_text_ctx][S]
     const __half *d_te;                                               // [n_vocab][S]
+    k::QMat       q_te;
+    int           qtype = 0;                                          // ggml type of the quantised matrices (0: none); one kind per model
+    size_t        matrix_bytes = 0;                                   // bytes of all matrices as stored in the arena (decode roofline)
     std::vector<DecLayerW> dec;
     const float  *d_ln_g, *d_ln_b;
     const float  *mel_filters;                                        // [n_mel][201]
@@ -111,9 +125,10 @@ struct Weights {
     const int32_t *mel_ranges;                                        // [n_mel][2]: non-zero 4-tap groups [g0, g1) of each filter
 };
 
-// src selects where tensor payloads are read from: a host pointer (H2D copies) or a device image
-// of the same ggml file (D2D, used after an RCCL broadcast of the file image).
-bool upload_weights(const ModelFile & mf, const uint8_t * host_buf, const void * dev_image, Weights & w, hipStream_t st);
+// Builds the device weight arena.  host_buf = the model file (tensor payloads are converted / permuted into a staging
+// image and uploaded); host_buf == nullptr (directory-only model): the arena is only allocated and laid out — the same
+// offsets for the same tensor directory — and the caller fills it (one RCCL broadcast of rank 0's arena, wmi_arena_ptr).
+bool upload_weights(const ModelFile & mf, const uint8_t * host_buf, Weights & w, hipStream_t st);
 void free_weights(Weights & w);
 
 // ---------------------------------------------------------------- KV cache bookkeeping (host)
@@ -184,6 +199,10 @@ struct DeviceState {
     __half * att   = nullptr;                                 // [T][S] f16
     __half * h     = nullptr;                                 // [T][4S] f16
     float  * rowmax = nullptr;                                // [H][T] f32 (attention pass A)
+    // block-quantised models only: activation rows as q8 blocks (the quantised GEMMs' A operand) and f32 attention outputs
+    int8_t * aq = nullptr;  float2 * ads = nullptr;           // [max(T, n_text_ctx)][4S] int8, [rows][4S / 32] {d, s}
+    float  * att32 = nullptr;                                 // [T][S] f32
+    float  * datt32 = nullptr;                                // [n_text_ctx][S] f32
     float  * enc_out = nullptr;                               // [T][S] f32  (embd_enc)
     __half * enc_out_h = nullptr;                             // [T][S] f16
     __half * kvc_k = nullptr, * kvc_v = nullptr;              // cross cache [L][T][S] each
@@ -279,6 +298,9 @@ bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, boo
 bool set_mel(whisper_context & ctx, const float * data, int n_len, int n_mel);
 bool encode(whisper_context & ctx, int mel_offset);
 bool decode(whisper_context & ctx, const Batch & batch);
+// block-quantised models (device_q.cpp): the layer loops of encode() / decode() with the quantised kernels
+bool encode_layers_q(whisper_context & ctx, int T);
+bool decode_layers_q(whisper_context & ctx, int n, int n_kv, int kv_head, int Tc, const std::vector<int> & rows);
 // greedy fast path: decode ONE token of sequence 0 at position `pos` and pick the next token on the device
 struct StepFilter { bool ban_blank, last_ts, penult_ts; int ts_floor_end, ts_initial_start; };
 bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const StepFilter & f, whisper_token_data & out);

@@ -35,6 +35,7 @@ class RefSide:
         self.L = lib.whisper_model_n_text_layer(self.ctx)
         self.NV = lib.whisper_n_vocab(self.ctx)
         self.n_audio_ctx = lib.whisper_n_audio_ctx(self.ctx)
+        self.n_threads = 4                      # results do not depend on it (SURVEY App. B rule 11); big models raise it
 
     def close(self):
         self.lib.whisper_free(self.ctx); self.ctx = None
@@ -49,7 +50,7 @@ class RefSide:
 
     def encode(self, offset=0, audio_ctx=0):
         self.lib.ref_set_audio_ctx(self.ctx, audio_ctx)
-        assert self.lib.whisper_encode(self.ctx, offset, 4) == 0
+        assert self.lib.whisper_encode(self.ctx, offset, self.n_threads) == 0
         T = audio_ctx if audio_ctx > 0 else self.n_audio_ctx
         S, L = self.S, self.L
         conv = np.empty(T * S, np.float32); self.lib.ref_embd_conv(self.ctx, _fptr(conv), conv.size)
@@ -65,7 +66,7 @@ class RefSide:
 
     def decode(self, tokens, n_past):
         t = np.asarray(tokens, np.int32)
-        assert self.lib.whisper_decode(self.ctx, t.ctypes.data_as(C.POINTER(C.c_int32)), t.size, n_past, 4) == 0
+        assert self.lib.whisper_decode(self.ctx, t.ctypes.data_as(C.POINTER(C.c_int32)), t.size, n_past, self.n_threads) == 0
         lp = self.lib.whisper_get_logits(self.ctx)
         full = np.ctypeslib.as_array(lp, shape=(t.size * self.NV,)).reshape(t.size, self.NV)
         return full[-1].copy()

@@ -252,28 +252,114 @@ def test_base_en_transcription_equals_checker_tokens(product_lib, checker_lib):
     assert np.abs(got[:, 2] - want[:, 2]).max() <= 1e-2
 
 
-@pytest.mark.parametrize("qtype", ["q5_1", "q8_0", "q4_0"])
-def test_quantised_models_load_and_track_the_reference(product_lib, checker_lib, qtype):
-    """ggml block-quantised files (config 5 uses q5_1): the product expands the blocks to f16 at load
-    (csrc/model.cpp) and runs the f16 MFMA path, whereas the reference keeps the weights quantised and ALSO
-    quantises the activations to q8 blocks (SURVEY App. B rule 1) — so the comparison is bounded by that
-    activation-quantisation noise, not by the usual 2e-3.  Stated tolerance: logits rms-rel <= 3e-2."""
-    if checker_lib is None:
-        pytest.skip("needs the compiled reference (the port handles f16/f32 files only)")
-    model = synth.quantize_model(synth.make_model("micro.en", seed=1234), qtype)
-    pcm = synth.make_pcm(6.0, seed=9)
-    prod = sc.ProductSide(product_lib, model); chk = sc.RefSide(checker_lib, model)
+# ------------------------------------------------------------------------------------------------ block-quantised models
+# The reference quantises the activation rows of every projection to 8-bit blocks (SURVEY App. B rule 1).  A quantiser is
+# discontinuous: an input that moves by one f32 rounding can flip a quant, i.e. move that element by d = amax / 127, so the
+# reference's OWN outputs respond to a 1e-6 relative change of the PCM with ~5e-3 rms on the encoder output and ~1e-2 on the
+# logits of a 2-layer model, where the f16 models respond with 3e-4 (measured: tests/test_oracle_quants.py::
+# test_reference_sensitivity_of_quantised_models).  No implementation with a different f32 summation order anywhere upstream
+# (conv, attention, LayerNorm) can agree with the reference more closely than the reference agrees with itself under such a
+# perturbation, so that response is the yardstick: every tensor must be within 2x of it (rms) / 3x (max), and never worse
+# than the fixed caps below.  What IS exact is pinned separately: identical q8 quants and scales, exact integer block dots,
+# bit-exact dequantisation (tests/test_gpu_quant.py).
+Q_CAP = {"tensor_rms": 3e-2, "logit_rms": 5e-2}
+
+
+def _run_stages(side, pcm, actx, prompt, fed, extra_batches=()):
+    side.mel(pcm)
+    out = dict(side.encode(0, actx))
+    out.pop("embd_conv", None)
+    lg = [side.decode(prompt, 0)]
+    for i, tok in enumerate(fed):
+        lg.append(side.decode([int(tok)], len(prompt) + i))
+    for bt in extra_batches:
+        lg.append(side.decode(list(bt), 0))
+    out["logits"] = lg
+    return out
+
+
+def _assert_within_reference_sensitivity(got, ref, ref_pert, what):
+    for k in ("embd_enc", "cross_k", "cross_v"):
+        e, n = sc.err_stats(got[k], ref[k]), sc.err_stats(ref_pert[k], ref[k])
+        assert e["rms_rel"] <= max(TOL[k][1], 2.0 * n["rms_rel"]) and e["rms_rel"] <= Q_CAP["tensor_rms"], (what, k, e, n)
+        assert e["max_abs"] <= max(TOL[k][0], 3.0 * n["max_abs"]), (what, k, e, n)
+    for i, (lp, lr, ln) in enumerate(zip(got["logits"], ref["logits"], ref_pert["logits"])):
+        e, n = sc.err_stats(lp, lr), sc.err_stats(ln, lr)
+        assert e["rms_rel"] <= max(LOGIT_RMS, 2.0 * n["rms_rel"]) and e["rms_rel"] <= Q_CAP["logit_rms"], (what, "logits", i, e, n)
+        assert e["max_abs"] <= max(LOGIT_ABS, 3.0 * n["max_abs"]), (what, "logits", i, e, n)
+        top2 = np.partition(lr, -2)[-2:]                     # arg-max wherever the margin exceeds what the reference itself moves by
+        if top2[1] - top2[0] > 2 * max(LOGIT_ABS, 3.0 * n["max_abs"]):
+            assert int(np.argmax(lp)) == int(np.argmax(lr)), (what, "argmax", i)
+
+
+def _quantised_case(product_lib, checker_lib, model, pcm, actx, n_steps, extra, what, ref_threads=4):
+    prod = sc.ProductSide(product_lib, model)
+    refs = [make_checker(model, checker_lib) for _ in range(2)]
+    for r in refs:
+        r.n_threads = ref_threads
     try:
-        assert product_lib.whisper_model_ftype(prod.ctx) == synth.QTYPES[qtype][1]
-        chk.mel(pcm); prod.mel(pcm)
-        er = chk.encode(0, 428); ep = prod.encode(0, 428)
-        st = sc.err_stats(ep["embd_enc"], er["embd_enc"])
-        assert st["rms_rel"] <= 3e-2, st
-        lr = chk.decode([50257], 0); lp = prod.decode([50257], 0)
-        st = sc.err_stats(lp, lr)
-        assert st["rms_rel"] <= 3e-2, st
+        prompt = sot_prompt(refs[0], prod)
+        # tokens to feed: the reference's own greedy choices
+        refs[0].mel(pcm); refs[0].encode(0, actx)
+        fed, lr = [], refs[0].decode(prompt, 0)
+        for i in range(n_steps):
+            fed.append(int(np.argmax(lr[:50256])))
+            lr = refs[0].decode([fed[-1]], len(prompt) + i)
+        batches = [prompt + list(b) for b in extra]
+        ref = _run_stages(refs[0], pcm, actx, prompt, fed, batches)
+        pert = _run_stages(refs[1], (pcm * np.float32(1.0 + 1e-6)).astype(np.float32), actx, prompt, fed, batches)
+        got = _run_stages(prod, pcm, actx, prompt, fed, batches)
+        _assert_within_reference_sensitivity(got, ref, pert, what)
+        return got, ref, pert
     finally:
-        prod.close(); chk.close()
+        prod.close()
+        for r in refs:
+            r.close()
+
+
+@pytest.mark.parametrize("qtype", ["q5_1", "q8_0", "q4_0", "q4_1", "q5_0"])
+def test_quantised_models_against_the_reference(product_lib, checker_lib, qtype):
+    """ggml block-quantised files (BASELINE configs[4] uses q5_1): the weights stay quantised in HBM and every projection
+    follows the reference's quantised mul_mat — activation rows to q8 blocks, exact integer block dots, per-block f32
+    scales (csrc/k_quant.hip)."""
+    model = synth.quantize_model(synth.make_model("micro.en", seed=1234), qtype)
+    assert synth.QTYPES[qtype][1] == int(np.frombuffer(model[44:48], np.int32)[0]) % 1000
+    extra = [[int(x) for x in (np.arange(40) * 997 + 1000)],          # 41 rows: the tiled quantised GEMM
+             [1000, 2000, 3000, 4000]]                                 # 5 rows: a beam's step shape
+    _quantised_case(product_lib, checker_lib, model, synth.make_pcm(6.0, seed=9), 428, 4, extra, ("micro.en", qtype))
+
+
+def test_quantised_transcription_equals_reference_tokens(product_lib, checker_lib):
+    """whisper_full on a q5_1 model against the compiled reference: identical token ids / timestamps up to the first near-tie
+    (the yard-stick above applies to every logit, so a decision with a margin below it may go either way); no temperature
+    fallback, whose logprob threshold is one more such decision."""
+    if checker_lib is None:
+        pytest.skip("token-stream comparison needs the compiled reference (host logic is not in the port)")
+    model = synth.quantize_model(synth.make_model("micro.en", seed=1234), "q5_1")
+    pcm = synth.make_pcm(11.0, seed=77)
+    outs = []
+    for L in (product_lib, checker_lib):
+        node = host.SpeechToText(L); node.set_language_model(model)
+        p = node.full_params("", 0); p.temperature_inc = 0.0
+        outs.append(node.transcribe(pcm, params=p))
+        node.close()
+    g, w = gu.tokens_array(outs[0]), gu.tokens_array(outs[1])
+    n = min(len(g), len(w))
+    same = g[:n, 0] == w[:n, 0]
+    first = n if same.all() else int(np.argmin(same))
+    assert first >= 3, (g[:, 0], w[:, 0])
+    assert np.abs(g[:first, 2] - w[:first, 2]).max() <= 5e-2            # token probabilities: within the quantised yard-stick
+    if first == n:
+        assert g.shape == w.shape
+
+
+def test_large_v3_widths_q5_1_against_checker(product_lib, checker_lib):
+    """configs[4]'s widths (1280 state, 20 heads, 128 mels, 51866 tokens) in q5_1 on the 2 + 3 layer slice: K = 1280 / 5120
+    block rows, N = 51866 (not a multiple of 32) for the vocabulary projection."""
+    import os
+    model = synth.quantize_model(synth.make_model("v3-slice", seed=31), "q5_1")
+    _quantised_case(product_lib, checker_lib, model, synth.make_pcm(20.0, seed=31), 0, 4, [[1000, 2000, 3000, 4000, 5000, 6000]],
+                    "v3-slice q5_1", ref_threads=min(32, os.cpu_count() or 4))
 
 
 def test_streaming_node_call_pattern_matches_reference_goldens(product_lib):

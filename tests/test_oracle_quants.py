@@ -123,3 +123,27 @@ def test_port_is_bit_exact_on_a_quantised_model(ref_lib, qtype):
         assert np.array_equal(ref.decode([1000, 2000, 3000], 1), ps.decode([1000, 2000, 3000], 1))
     finally:
         ref.close(); ps.close()
+
+
+def test_reference_sensitivity_of_quantised_models():
+    """The yardstick of the GPU parity tests for quantised models: the reference arithmetic's own response to a 1e-6 relative
+    change of the input.  f16 weights: ~3e-4 on the encoder output; quantised weights (8-bit activation blocks, a
+    discontinuous map): an order of magnitude more.  Uses the restatement, which is bit-exact to the reference above."""
+    pcm = synth.make_pcm(6.0, seed=9)
+    res = {}
+    for q in (None, "q5_1"):
+        m = synth.make_model("micro.en", seed=1234)
+        if q:
+            m = synth.quantize_model(m, q)
+        outs = []
+        for scale in (1.0, 1.0 + 1e-6):
+            ps = port.PortSide(m)
+            try:
+                ps.mel((pcm * np.float32(scale)).astype(np.float32))
+                e = ps.encode(0, 428)["embd_enc"]
+                outs.append((e, ps.decode([ps.sot], 0)))
+            finally:
+                ps.close()
+        res[q] = (sc.err_stats(outs[1][0], outs[0][0])["rms_rel"], sc.err_stats(outs[1][1], outs[0][1])["rms_rel"])
+    assert res[None][0] < 1e-3 and res[None][1] < 1.5e-3, res
+    assert 2e-3 < res["q5_1"][0] < 2e-2 and 3e-3 < res["q5_1"][1] < 4e-2, res
