@@ -263,13 +263,36 @@ struct whisper_context * wmi_init_from_buffer_on_device(const void * buffer, siz
 }
 
 struct whisper_context * wmi_init_host_only(const void * buffer, size_t buffer_size) {
-    whisper_context * ctx = new whisper_context();
-    ctx->host_only = true;
-    ctx->t_start_us = time_us();
-    if (!parse_model((const uint8_t *) buffer, buffer_size, ctx->model)) { WMI_ERR("%s: failed to load model\n", __func__); delete ctx; return nullptr; }
-    ctx->state = new State();
-    for (auto & dec : ctx->state->decoders) dec.rng = std::mt19937(0);
+    if (!buffer || buffer_size < 4) return nullptr;
+    whisper_context * ctx = nullptr;
+    try {
+        ctx = new whisper_context();
+        ctx->host_only = true;
+        ctx->t_start_us = time_us();
+        if (!parse_model((const uint8_t *) buffer, buffer_size, ctx->model)) { WMI_ERR("%s: failed to load model\n", __func__); delete ctx; return nullptr; }
+        ctx->state = new State();
+        for (auto & dec : ctx->state->decoders) dec.rng = std::mt19937(0);
+    } catch (const std::exception & e) {
+        WMI_ERR("%s: failed to load model (%s)\n", __func__, e.what());
+        delete ctx; return nullptr;
+    }
     return ctx;
+}
+
+size_t wmi_model_header(const void * model, size_t model_size, void * out, size_t cap) {
+    if (!model || model_size < 4) return 0;
+    try {
+        ModelFile mf;
+        if (!parse_model((const uint8_t *) model, model_size, mf) || mf.directory_only) return 0;
+        const std::vector<uint8_t> img = export_header(mf, (const uint8_t *) model, 0);
+        if (out && cap >= img.size()) memcpy(out, img.data(), img.size());
+        return img.size();
+    } catch (const std::exception &) { return 0; }
+}
+void * wmi_arena_ptr(struct whisper_context * ctx) { return ctx ? ctx->w.arena : nullptr; }
+size_t wmi_weights_bytes(struct whisper_context * ctx, int which) {
+    if (!ctx) return 0;
+    return which == 0 ? ctx->w.arena_bytes : which == 1 ? ctx->w.matrix_bytes : which == 2 ? (size_t) ctx->w.qtype : 0;
 }
 
 int wmi_pcm_to_mel_device(struct whisper_context * ctx, const float * d_samples, int n_samples) {

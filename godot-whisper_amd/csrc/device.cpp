@@ -296,6 +296,8 @@ bool decode(whisper_context & ctx, const Batch & batch) {
     KVCache & kv = st.kv_self;
     const int n = batch.n_tokens;
     if (n <= 0) return false;
+    // the device and pinned staging buffers hold n_text_ctx rows (the reference's decoder graph is measured for that many, W/whisper.cpp:3098-3110)
+    if (n > hp.n_text_ctx) { WMI_ERR("%s: %d tokens in one batch, the model's text context is %d\n", __func__, n, hp.n_text_ctx); return false; }
     if (!kv_find_slot(kv, batch)) return false;                   // W/whisper.cpp:2540
     kv.n = (uint32_t) kv_cell_max(kv);
     const int n_kv = (int) kv.n, kv_head = (int) kv.head, n_ctx = (int) kv.size;
@@ -564,7 +566,7 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
     // the buffer), so a step is only captured once the same encoder length has been decoded for a while — until then the
     // launches go out eagerly (measured equal to replay within 1 %: the step is bound by dependent-kernel latency on the GPU)
     if (d.step_seen_T != Tc) { d.step_seen_T = Tc; d.step_seen_n = 0; }
-    const bool capture_now = use_graph && !d.step_exec && ++d.step_seen_n > 64;
+    const bool capture_now = use_graph && !d.step_exec && !d.step_capture_failed && ++d.step_seen_n > 64;
     if (capture_now) {
         // first use: run once eagerly (lets the launchers set their function attributes), then capture
         enqueue_greedy_step(ctx, Tc);
@@ -572,13 +574,18 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
         if (HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal))) {
             enqueue_greedy_step(ctx, Tc);
             hipGraph_t g = nullptr;
-            if (HIP_OK(hipStreamEndCapture(s, &g)) && g && HIP_OK(hipGraphInstantiate(&d.step_exec, g, nullptr, nullptr, 0))) {
+            const bool ended = HIP_OK(hipStreamEndCapture(s, &g));
+            if (ended && g && HIP_OK(hipGraphInstantiate(&d.step_exec, g, nullptr, nullptr, 0))) {
                 d.step_graph = g; d.step_graph_T = Tc;
             } else {
+                // latched: without this every later step paid an eager step, a sync and a new capture attempt
                 WMI_WARN("%s: graph capture failed - staying on eager launches\n", __func__);
-                d.step_exec = nullptr;
+                if (g) (void) hipGraphDestroy(g);
+                d.step_exec = nullptr; d.step_capture_failed = true;
+                hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) { hipGraph_t junk = nullptr; (void) hipStreamEndCapture(s, &junk); if (junk) (void) hipGraphDestroy(junk); }
             }
-        }
+        } else d.step_capture_failed = true;
     }
     hs->seq = ++d.step_seq;
     if (use_graph && d.step_exec) {

@@ -837,11 +837,8 @@ void launch_gemv1(const GemvArgs & a, hipStream_t st, int max_blocks = 512) {
     else if (a.comb_o) smem = (size_t) a.K * sizeof(__half);
     int blocks = (a.N + 4 * RIF - 1) / (4 * RIF);
     if (blocks > max_blocks) blocks = max_blocks;
-    static size_t attr_bytes = 0;
-    if (smem > 48 * 1024 && smem > attr_bytes) {
-        (void) hipFuncSetAttribute((const void *) k_gemv1<RIF, NCH, NT, PRO, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
-        attr_bytes = smem;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    if (smem > 48 * 1024) allow_full_lds((const void *) k_gemv1<RIF, NCH, NT, PRO, EPI>, lds_ok);
     hipLaunchKernelGGL((k_gemv1<RIF, NCH, NT, PRO, EPI>), dim3(blocks), dim3(256), smem, st, a);
 }
 
@@ -1128,11 +1125,8 @@ void launch_rows_mfma(const GemvArgs & a, hipStream_t st) {
     static const int cap = getenv("WMI_ROWS_BLOCKS") ? atoi(getenv("WMI_ROWS_BLOCKS")) : 512;        // A/B knob
     if (blocks > 1024) blocks = 1024;
     if (!KSPLIT && blocks > cap) blocks = cap;
-    static size_t attr_bytes = 0;
-    if (smem > 48 * 1024 && smem > attr_bytes) {
-        (void) hipFuncSetAttribute((const void *) k_rows_mfma<KSPLIT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
-        attr_bytes = smem;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    if (smem > 48 * 1024) allow_full_lds((const void *) k_rows_mfma<KSPLIT>, lds_ok);
     hipLaunchKernelGGL((k_rows_mfma<KSPLIT>), dim3(blocks), dim3(256), smem, st, a);
 }
 
@@ -1142,11 +1136,8 @@ void launch_gemv_t(const GemvArgs & a, hipStream_t st, int max_blocks = 512) {
     if (a.sa_q) smem = ((smem + 15) & ~(size_t) 15) + ((size_t) (a.K / 64) * a.sa_cap + a.K) * sizeof(float);
     int blocks = (a.N + 4 * RIF - 1) / (4 * RIF);
     if (blocks > max_blocks) blocks = max_blocks;       // 2 workgroups per CU; longer rows-per-wave loops are software-pipelined
-    static size_t attr_bytes = 0;
-    if (smem > 48 * 1024 && smem > attr_bytes) {
-        (void) hipFuncSetAttribute((const void *) k_gemv<R, RIF, NT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
-        attr_bytes = smem;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    if (smem > 48 * 1024) allow_full_lds((const void *) k_gemv<R, RIF, NT>, lds_ok);
     hipLaunchKernelGGL((k_gemv<R, RIF, NT>), dim3(blocks), dim3(256), smem, st, a);
 }
 

@@ -310,11 +310,8 @@ template <int BM, int BN, int EPI, int NST>
 void launch_n(const GemmArgs & a, hipStream_t st) {
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
     const size_t smem = NST * (size_t) (BM + BN) * 128;
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void) hipFuncSetAttribute((const void *) k_gemm<BM, BN, EPI, NST>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
-        attr_done = true;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    allow_full_lds((const void *) k_gemm<BM, BN, EPI, NST>, lds_ok);
     hipLaunchKernelGGL((k_gemm<BM, BN, EPI, NST>), dim3(ntm * ntn), dim3(256), smem, st, a);
 }
 template <int BM, int BN, int EPI>

@@ -483,8 +483,8 @@ void launch_qgemm(const GemmArgs & a, Q8Rows A, const uint8_t * Wt, hipStream_t 
     constexpr int BN = 128;
     constexpr size_t stage = (size_t) BM * 64 + BN * 64 + 4 * BM * 4 + 4 * BN * 4;
     const size_t smem = 2 * stage;
-    static bool attr_done = false;
-    if (!attr_done) { (void) hipFuncSetAttribute((const void *) k_qgemm<QT, BM, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem); attr_done = true; }
+    static std::atomic<uint64_t> lds_ok{0};
+    allow_full_lds((const void *) k_qgemm<QT, BM, EPI>, lds_ok);
     const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
     hipLaunchKernelGGL((k_qgemm<QT, BM, EPI>), dim3(ntm * ntn), dim3(256), smem, st, a, A.qs, A.ds, Wt);
 }
@@ -699,11 +699,8 @@ void launch_qrows(const GemvArgs & a, const float * a32, const uint8_t * Wt, hip
     const size_t smem = (((size_t) a.n * (a.K + 16) + 15) & ~(size_t) 15) + (size_t) 2 * nb * R8 * 4 + (size_t) 4 * 32 * R8 * 4;
     const int ngroups = (a.N + 31) / 32;
     int blocks = ngroups; if (blocks > 1024) blocks = 1024;
-    static size_t attr_bytes = 0;
-    if (smem > 48 * 1024 && smem > attr_bytes) {
-        (void) hipFuncSetAttribute((const void *) k_qrows<QT, NR4, SRC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) smem);
-        attr_bytes = smem;
-    }
+    static std::atomic<uint64_t> lds_ok{0};
+    if (smem > 48 * 1024) allow_full_lds((const void *) k_qrows<QT, NR4, SRC>, lds_ok);
     hipLaunchKernelGGL((k_qrows<QT, NR4, SRC>), dim3(blocks), dim3(256), smem, st, a, a32, Wt);
 }
 

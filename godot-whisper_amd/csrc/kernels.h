@@ -4,9 +4,22 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
+#include <atomic>
 #include <cstdint>
 
 namespace wmi { namespace k {
+
+// Kernels with more than 48 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize once per device (a context per
+// GPU, launches from several host threads).  The attribute is set to the whole 160 KB of a CU — it permits, the launch decides —
+// so it never depends on the sizes seen so far; `mask` = one bit per device, one static per kernel instantiation.
+inline void allow_full_lds(const void * kernel, std::atomic<uint64_t> & mask) {
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (mask.load(std::memory_order_acquire) & bit) return;
+    (void) hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    mask.fetch_or(bit, std::memory_order_release);        // two threads may both set it: idempotent
+}
 
 // f32 -> f16 with the value pinned in a register first.  Without the empty asm the AMDGPU back end folds SOME of the
 // `cvt(mul)` / `cvt(add)` pairs of an unrolled epilogue into v_fma_mixlo_f16 — one rounding instead of the reference's

@@ -223,6 +223,7 @@ struct DeviceState {
     uint8_t * ban_dev = nullptr;   uint64_t ban_sig = ~0ull;          // static suppress mask + its parameter signature
     hipGraph_t step_graph = nullptr; hipGraphExec_t step_exec = nullptr; int step_graph_T = -1;
     int32_t step_seq = 0;                                             // sequence number of the last greedy step launched
+    bool    step_capture_failed = false;                               // a failed capture is not retried
     int     step_seen_T = -1, step_seen_n = 0;                        // encoder length of recent steps / how many in a row
 };
 

@@ -37,6 +37,9 @@ DEVICE_API = [
                                     C.POINTER(abi.whisper_token_data)]),
     ("wmi_selftest_proj", C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     ("wmi_bench_kernel", C.c_double, [C.c_void_p, C.c_int, C.c_int]),
+    ("wmi_model_header", C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
+    ("wmi_arena_ptr", C.c_void_p, [C.c_void_p]),
+    ("wmi_weights_bytes", C.c_size_t, [C.c_void_p, C.c_int]),
     ("wmi_selftest_quant", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),
 ]

@@ -36,3 +36,19 @@ def ref_lib():
     lib.whisper_log_set(C.cast(cb, C.c_void_p), None)
     lib._cb = cb
     return lib
+
+
+@pytest.fixture(scope="session")
+def checker_lib():
+    """The checker of the -m gpu parity tests: the compiled reference when its prebuilt library travelled with the snapshot
+    (oracle/_ref/libwhisper_ref.so), else None = the CPU restatement (oracle/libwhisper_port.so)."""
+    import ctypes as C
+    from godot_whisper_amd import abi
+    from oracle import port, reflib
+    if reflib.available():
+        lib = reflib.lib()
+        cb = abi.ggml_log_callback(lambda lvl, txt, ud: None)
+        lib.whisper_log_set(C.cast(cb, C.c_void_p), None); lib._cb = cb
+        return lib
+    assert port.available(), "no checker available: build oracle/libwhisper_port.so (python __graft_entry__.py build)"
+    return None

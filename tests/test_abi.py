@@ -181,3 +181,49 @@ def test_host_worker_pool_runs_every_task_exactly_once():
     lib = runtime.load_library()
     for n, reps in ((1, 50), (3, 2000), (17, 2000), (64, 500)):
         assert lib.wmi_selftest_pool(n, reps) == reps * n * (n + 1) // 2, (n, reps)
+
+
+def test_malformed_model_files_are_rejected_not_trusted():
+    """The model buffer is untrusted input (the reference rejects all of these with a load error, W/whisper.cpp:1113-1600):
+    truncated payloads, zero / negative / absurd hyper-parameters (a zero head count was a division by zero), lengths that
+    would wrap a bounds check, block-quantised rows that are not a whole number of blocks, duplicate tensors."""
+    import struct
+    from godot_whisper_amd import synth
+    lib = runtime.load_library()
+    runtime.silence_logs(lib)
+
+    def loads(b):
+        buf = C.create_string_buffer(bytes(b), len(b))
+        ctx = lib.wmi_init_host_only(C.cast(buf, C.c_void_p), len(b))
+        if ctx:
+            lib.whisper_free(ctx)
+        return bool(ctx)
+
+    good = bytearray(synth.make_model("micro.en", seed=1))
+    assert loads(good)
+    assert not loads(good[:len(good) - 7])                                  # last tensor truncated
+    assert not loads(good[:40])                                             # header truncated
+    assert not loads(b"\x00" * 64)                                          # bad magic
+    for field, val in ((3, 0), (3, -2), (7, 0), (0, 0), (0, 1 << 20), (1, -5), (5, 0), (9, 0), (2, 1 << 30), (10, 55)):
+        bad = bytearray(good); struct.pack_into("<i", bad, 4 + 4 * field, val)
+        assert not loads(bad), (field, val)
+    bad = bytearray(good); struct.pack_into("<i", bad, 4 + 44, 81)          # n_mel of the filterbank != n_mels
+    assert not loads(bad)
+    # first tensor record: find it behind the vocabulary
+    off = 4 + 44
+    n_mel, n_fft = struct.unpack_from("<2i", good, off); off += 8 + 4 * n_mel * n_fft
+    (nv,) = struct.unpack_from("<i", good, off); off += 4
+    for _ in range(nv):
+        (ln,) = struct.unpack_from("<I", good, off); off += 4 + ln
+    bad = bytearray(good); struct.pack_into("<I", bad, 4 + 44 + 8 + 4 * n_mel * n_fft + 4, 0xFFFFFFF0)   # a vocabulary length that wraps off + len
+    assert not loads(bad)
+    nd, nl, tt = struct.unpack_from("<3i", good, off)
+    bad = bytearray(good); struct.pack_into("<i", bad, off + 12, 0)         # a dimension of 0
+    assert not loads(bad)
+    bad = bytearray(good); struct.pack_into("<i", bad, off + 12, -4)        # a negative dimension
+    assert not loads(bad)
+    bad = bytearray(good); struct.pack_into("<i", bad, off, 9)              # n_dims out of range
+    assert not loads(bad)
+    bad = bytearray(good); struct.pack_into("<i", bad, off + 8, 7)          # claims q5_1 for a payload of another size
+    assert not loads(bad)
+    assert not loads(good + good[off:off + 12 + 4 * nd + nl + 64])          # trailing garbage / duplicate record

@@ -37,17 +37,6 @@ def make_checker(model, ref_lib_or_none):
     return port.PortSide(model)
 
 
-@pytest.fixture(scope="module")
-def checker_lib():
-    if reflib.available():
-        lib = reflib.lib()
-        cb = abi.ggml_log_callback(lambda lvl, txt, ud: None)
-        lib.whisper_log_set(C.cast(cb, C.c_void_p), None); lib._cb = cb
-        return lib
-    assert port.available(), "no checker available: build oracle/libwhisper_port.so (python __graft_entry__.py build)"
-    return None
-
-
 def sot_prompt(chk, prod):
     sot = prod.lib.whisper_token_sot(prod.ctx)
     if prod.lib.whisper_is_multilingual(prod.ctx):
