@@ -469,6 +469,7 @@ bool wait_for_seq(const volatile int32_t * seq, int32_t want, hipStream_t s) {
 static unsigned g_step_mask = ~0u;
 
 static void enqueue_greedy_step(whisper_context & ctx, int Tc) {
+    if (ctx.model.quantised) { enqueue_greedy_step_q(ctx, Tc); return; }
     State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
     KVCache & kv = st.kv_self;
     const int S = hp.n_text_state, H = hp.n_text_head, Lt = hp.n_text_layer, NV = hp.n_vocab, n_ctx = (int) kv.size;

@@ -28,7 +28,7 @@ struct Src { const float * x32 = nullptr; const float * ln_g = nullptr, * ln_b =
 bool rows_fit(int n, int K) {
     if (n > 32) return false;
     const int r8 = n <= 8 ? 8 : n <= 16 ? 16 : 32, nb = K / 32;
-    const size_t smem = (((size_t) n * (K + 16) + 15) & ~(size_t) 15) + (size_t) 2 * nb * r8 * 4 + (size_t) 4 * 32 * r8 * 4;
+    const size_t smem = (((size_t) n * (K + 16) + 15) & ~(size_t) 15) + (size_t) 2 * nb * r8 * 4 + (size_t) 16 * 32 * r8 * 4;
     return smem <= 150 * 1024;
 }
 
@@ -144,6 +144,49 @@ bool decode_layers_q(whisper_context & ctx, int n, int n_kv, int kv_head, int Tc
             memcpy(st.logits.data() + (size_t) rows[r0 + r] * NV, (const float *) d.pinned + (size_t) r * NV, (size_t) NV * 4);
     }
     return true;
+}
+
+// One greedy decode step of a block-quantised model as a fixed launch sequence (graph-replayable: every per-step quantity
+// is read from DecStep on the device, device.cpp: decode_greedy_step): 9 launches per layer —
+//   q|k|v (LayerNorm + q8 in the prologue) -> self-attention (f32 out) -> out projection -> cross query ->
+//   cross scores -> cross P.V -> cross out projection (combines the key slices in its prologue) -> mlp.0 -> mlp.2
+void enqueue_greedy_step_q(whisper_context & ctx, int Tc) {
+    State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
+    KVCache & kv = st.kv_self;
+    const int S = hp.n_text_state, H = hp.n_text_head, Lt = hp.n_text_layer, NV = hp.n_vocab, n_ctx = (int) kv.size;
+    hipStream_t s = d.stream;
+    const k::DecStep * stp = (const k::DecStep *) d.step_dev;
+    const float kq_scale = powf((float) S / H, -0.25f);
+    k::qdec_embed_step((const k::DecStep *) d.step_host, (k::DecStep *) d.step_dev, S, w.q_te, w.d_pe, d.dx, s);
+    auto rows = [&](int epi, const Src & src, int K, int N, const k::QMat & W, const float * bias, void * C, int ldc, const float * resid,
+                    void * aux, void * aux2, float scale, const int32_t * row_off, const float * co = nullptr, const float * cl = nullptr, int cns = 0) {
+        k::GemvArgs g{};
+        g.x32 = src.x32; g.ln_g = src.ln_g; g.ln_b = src.ln_b; g.eps = hp.eps; g.a16 = src.x16; g.n = 1; g.K = K; g.N = N;
+        g.bias = bias; g.epi = epi; g.C = C; g.ldc = ldc; g.resid = resid; g.ldr = S; g.aux = aux; g.ldaux = S; g.aux2 = aux2; g.ldaux2 = S;
+        g.scale = scale; g.S = S; g.row_off = row_off; g.comb_o = co; g.comb_l = cl; g.comb_ns = cns;
+        k::qrows(g, src.ln_g ? nullptr : src.x32, W, s);
+    };
+    for (int il = 0; il < Lt; ++il) {
+        const DecLayerW & l = w.dec[il];
+        __half * ck = kv.k + ((size_t) il * n_ctx) * S, * cv = kv.v + ((size_t) il * n_ctx) * S;
+        Src ln1; ln1.x32 = d.dx; ln1.ln_g = l.ln1_g; ln1.ln_b = l.ln1_b;
+        rows(k::EPI_QKV_DEC, ln1, S, 3 * S, l.q_qkv, l.b_qkv, d.dq, S, nullptr, ck, cv, kq_scale, &stp->kv_head);
+        k::self_attn_rows(d.dq, 1, S, ck, cv, 0, &stp->n_kv, 0, hp.n_text_ctx, nullptr, s, d.datt32);
+        Src att; att.x32 = d.datt32;
+        rows(k::EPI_F32_BIAS_RESID, att, S, S, l.q_o, l.b_o, d.dx, S, d.dx, nullptr, nullptr, 0.f, nullptr);
+        Src ln2; ln2.x32 = d.dx; ln2.ln_g = l.ln2_g; ln2.ln_b = l.ln2_b;
+        rows(k::EPI_Q_SCALED, ln2, S, S, l.q_cq, l.b_cq, d.dq, S, nullptr, nullptr, nullptr, kq_scale, nullptr);
+        const float * po = nullptr, * pl = nullptr; int ns = 0;
+        k::attn_cross_split_partials(d.dq, 1, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, &po, &pl, &ns, s);
+        rows(k::EPI_F32_BIAS_RESID, Src{}, S, S, l.q_co, l.b_co, d.dx, S, d.dx, nullptr, nullptr, 0.f, nullptr, po, pl, ns);
+        Src ln3; ln3.x32 = d.dx; ln3.ln_g = l.ln3_g; ln3.ln_b = l.ln3_b;
+        rows(k::EPI_F16_BIAS_GELU, ln3, S, 4 * S, l.q_fc1, l.b_fc1, d.dh, 4 * S, nullptr, nullptr, nullptr, 0.f, nullptr);
+        Src hh; hh.x16 = d.dh;
+        rows(k::EPI_F32_BIAS_RESID, hh, 4 * S, S, l.q_fc2, l.b_fc2, d.dx, S, d.dx, nullptr, nullptr, 0.f, nullptr);
+    }
+    Src lnf; lnf.x32 = d.dx; lnf.ln_g = w.d_ln_g; lnf.ln_b = w.d_ln_b;
+    rows(k::EPI_LOGITS, lnf, S, NV, w.q_te, nullptr, d.logits, NV, nullptr, nullptr, nullptr, 0.f, nullptr);
+    k::filter_argmax(d.logits, d.ban_dev, stp, (k::SampleOut *) d.sample_dev, d.filter_scratch, s, (k::SampleOut *) d.sample_host);
 }
 
 } // namespace wmi

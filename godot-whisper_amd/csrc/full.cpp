@@ -210,7 +210,7 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
             kv_clear(st.kv_self);
             // Greedy, temperature 0, one decoder, no user logit callback: filters + arg-max run on the GPU and each
             // step is one graph replay (device.cpp: decode_greedy_step).  Everything else takes the general path.
-            const bool fast = fast_path_enabled() && !ctx.model.quantised && !beam && t_cur < 1e-6f && n_cur == 1 && !params.logits_filter_callback && !params.grammar_rules &&
+            const bool fast = fast_path_enabled() && !beam && t_cur < 1e-6f && n_cur == 1 && !params.logits_filter_callback && !params.grammar_rules &&
                               params.n_grammar_rules == 0 &&
                               ctx.model.n_loaded > 0 && upload_static_ban(ctx, params);
             whisper_token_data fast_next{};      // token picked on the device for the upcoming sampling step

@@ -70,7 +70,7 @@ __global__ void k_dec_embed_step(const DecStep * __restrict__ host_step, DecStep
 template <int NU>
 __device__ __forceinline__ bool self_attn_wave(const __half * __restrict__ sq, const __half * __restrict__ sk,
                                                const __half * __restrict__ sv, const int32_t * __restrict__ n_kv_p, int K, int cap,
-                                               const int (&hs)[NU], int H, int lane, __half * out) {
+                                               const int (&hs)[NU], int H, int lane, __half * out, float * out32 = nullptr) {
     const int g = lane >> 3, o = lane & 7;
     int hh[NU];
 #pragma unroll
@@ -168,10 +168,15 @@ __device__ __forceinline__ bool self_attn_wave(const __half * __restrict__ sq, c
 #pragma unroll
         for (int e = 0; e < 8; ++e) { float v = acc[e]; v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); acc[e] = v; }
         if (g == 0 && hs[u] < H) {
+            if (out32) {                                  // block-quantised out-projection: the f32 result is quantised as is
+                *(float4 *) (out32 + hs[u] * 64 + o * 8)     = make_float4(acc[0], acc[1], acc[2], acc[3]);
+                *(float4 *) (out32 + hs[u] * 64 + o * 8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+            } else {
             __half2 h4[4];
 #pragma unroll
             for (int e = 0; e < 4; ++e) h4[e] = __halves2half2(f2h(acc[2 * e]), f2h(acc[2 * e + 1]));
             *(uint4 *) (out + hs[u] * 64 + o * 8) = *(const uint4 *) h4;
+            }
         }
     }
     return true;
@@ -243,7 +248,7 @@ __device__ __forceinline__ void self_attn_row(const __half * __restrict__ sq, co
 __global__ __launch_bounds__(64) void k_self_attn_rows(const __half * __restrict__ q, const __half * __restrict__ kc,
                                                        const __half * __restrict__ vc, int64_t cache_row_stride,
                                                        const int32_t * __restrict__ n_kv_p, int step_stride, int K, int cap,
-                                                       __half * __restrict__ out) {
+                                                       __half * __restrict__ out, float * __restrict__ out32) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float * row = (float *) smem;                       // [cap] scores -> probabilities of this head
     float * qf  = row + cap;                            // [64]
@@ -251,7 +256,8 @@ __global__ __launch_bounds__(64) void k_self_attn_rows(const __half * __restrict
     const __half * sk = kc + (int64_t) r * cache_row_stride, * sv = vc + (int64_t) r * cache_row_stride;
     {   // n_kv <= 64 (the decode loop): the wave-level routine shared with the one-row prologue
         const int hs[1] = { h };
-        if (self_attn_wave<1>(q + (size_t) r * K, sk, sv, n_kv_p + r * step_stride, K, cap, hs, K / 64, lane, out + (size_t) r * K)) return;
+        if (self_attn_wave<1>(q + (size_t) r * K, sk, sv, n_kv_p + r * step_stride, K, cap, hs, K / 64, lane, out + (size_t) r * K,
+                              out32 ? out32 + (size_t) r * K : nullptr)) return;
     }
     const int n_kv = n_kv_p[r * step_stride];
     qf[lane] = __half2float(q[(size_t) r * K + h * 64 + lane]);
@@ -297,6 +303,7 @@ __global__ __launch_bounds__(64) void k_self_attn_rows(const __half * __restrict
 #pragma unroll
             for (int t = 0; t < 8; ++t) if (j + t < n_kv) acc = fmaf(row[j + t], __half2float(vv[t]), acc);
         }
+        if (out32) out32[(size_t) r * K + c] = acc; else
         out[(size_t) r * K + c] = f2h(acc);
     }
 }
@@ -1168,9 +1175,9 @@ void dec_embed_step(const DecStep * host_step, DecStep * dev_step, int S, const 
 }
 
 void self_attn_rows(const __half * q, int n, int K, const __half * kc, const __half * vc, int64_t cache_row_stride,
-                    const int32_t * n_kv, int step_stride, int cap, __half * out, hipStream_t st) {
+                    const int32_t * n_kv, int step_stride, int cap, __half * out, hipStream_t st, float * out32) {
     const size_t smem = ((size_t) cap + 64) * sizeof(float);
-    hipLaunchKernelGGL(k_self_attn_rows, dim3(n, K / 64), dim3(64), smem, st, q, kc, vc, cache_row_stride, n_kv, step_stride, K, cap, out);
+    hipLaunchKernelGGL(k_self_attn_rows, dim3(n, K / 64), dim3(64), smem, st, q, kc, vc, cache_row_stride, n_kv, step_stride, K, cap, out, out32);
 }
 
 static bool g_rows_valu = false;

@@ -511,15 +511,20 @@ void qgemm_epi(int epi, const GemmArgs & a, Q8Rows A, const uint8_t * Wt, hipStr
 }
 
 // ------------------------------------------------------------------------------------------------ rows (decode)
-// R <= 8 NR4 rows: activations are the MFMA's row operand (rows >= n read row 0 and are never stored), the 32 weight rows of a
-// row group its columns: lane (col = lane % 32) keeps out[r] for rows r = (e & 3) + 8 (e >> 2) + 4 (lane / 32), e < 4 NR4.
-// SRC as in k_q8_rows (0 f32 rows, 1 LayerNorm(f32), 2 f16 rows).
-template <int QT, int NR4, int SRC>
-__global__ __launch_bounds__(256) void k_qrows(const GemvArgs a, const float * __restrict__ a32, const uint8_t * __restrict__ Wt) {
+// <= 8 NR4 activation rows against a quantised matrix.  The activations are the MFMA's row operand (rows >= n read row 0 and
+// are never stored), the 32 weight rows of a row group its columns: lane (col = lane % 32) keeps out[r] for rows
+// r = (e & 3) + 8 (e >> 2) + 4 (lane / 32), e < 4 NR4.  A workgroup of NW wavefronts owns one row group at a time; K is split
+// over its wavefronts (wavefront w: tile pairs w, w + NW, ...: at most CH of them, all requested before the prologue), the
+// partial sums meet in LDS and are added in wavefront order.
+// SRC: 0 f32 rows, 1 LayerNorm of f32 rows (K <= 1536), 2 f16 rows, 3 the combined partials of the split cross-attention
+// (GemvArgs::comb_*: o / l per head, f32 — what attn_cross_combine writes with out32).
+template <int QT, int NR4, int SRC, int NW>
+__global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float * __restrict__ a32, const uint8_t * __restrict__ Wt) {
     constexpr int QW = Geo<QT>::QW, HW = Geo<QT>::HW;
     constexpr bool HAS_M = Geo<QT>::M, F16D = Geo<QT>::F16D;
     constexpr int R8 = NR4 * 8;                             // row slots
-    constexpr int CH = 5;                                    // weight tiles in flight per wavefront
+    constexpr int CH = NW == 16 ? 5 : NW == 8 ? 3 : 5;      // weight tiles in flight per wavefront (K = 5120 / 1280: everything at once)
+    constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, n = a.n, nb = K >> 5, np = K >> 6;
@@ -527,7 +532,7 @@ __global__ __launch_bounds__(256) void k_qrows(const GemvArgs a, const float * _
     int8_t * sq = (int8_t *) smem;                           // [n][lda]
     float  * sd = (float *) (smem + (((size_t) n * lda + 15) & ~(size_t) 15));     // [nb][R8]
     float  * ss = sd + (size_t) nb * R8;                     // [nb][R8]
-    float  * red = ss + (size_t) nb * R8;                    // [4][32][R8]
+    float  * red = ss + (size_t) nb * R8;                    // [NW][32][R8]
 
     const int ngroups = (a.N + 31) >> 5;
     int rg = blockIdx.x;
@@ -537,7 +542,7 @@ __global__ __launch_bounds__(256) void k_qrows(const GemvArgs a, const float * _
     auto load_tiles = [&](int g, int c0) {
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-            int tp = wave + 4 * (c0 + u); if (tp > np - 1) tp = np - 1;
+            int tp = wave + NW * (c0 + u); if (tp > np - 1) tp = np - 1;
             const uint8_t * t = Wt + ((size_t) g * np + tp) * tile_bytes<QT>();
             if constexpr (QW == 4) { const uint4 v = *(const uint4 *) (t + lane * 16); wq[u][0] = v.x; wq[u][1] = v.y; wq[u][2] = v.z; wq[u][3] = v.w; }
             else { const uint4 v = *(const uint4 *) (t + lane * 32), w = *(const uint4 *) (t + lane * 32 + 16);
@@ -548,10 +553,10 @@ __global__ __launch_bounds__(256) void k_qrows(const GemvArgs a, const float * _
     };
     if (rg < ngroups) load_tiles(rg, 0);
 
-    // ---- prologue: the activation rows as q8 blocks in LDS (wavefront w: rows w, w + 4, ...)
-    for (int r = wave; r < n; r += 4) {
-        const int src = a.rows ? a.rows[r] : r;
-        if constexpr (SRC == 1) {
+    // ---- prologue: the activation rows as q8 blocks in LDS
+    if constexpr (SRC == 1) {                                // LayerNorm needs the whole row: wavefront w takes rows w, w + NW, ...
+        for (int r = wave; r < n; r += NW) {
+            const int src = a.rows ? a.rows[r] : r;
             constexpr int MAXV = 6;                          // K <= 1536
             float4 v[MAXV], gg[MAXV], bb[MAXV];
             const float * xr = a.x32 + (size_t) src * K;
@@ -571,51 +576,64 @@ __global__ __launch_bounds__(256) void k_qrows(const GemvArgs a, const float * _
                     if ((lane & 7) == 0) { sd[(c >> 5) * R8 + r] = d; ss[(c >> 5) * R8 + r] = s; }
                 }
             }
-        } else {
-            for (int c0 = 0; c0 < K; c0 += 1024) {
-                float4 v[4];
+        }
+    } else {
+        // blocks quantise independently: (row, 256-column slice) pairs spread over all wavefronts
+        const int nsl = (K + 255) >> 8;
+        for (int sl = wave; sl < n * nsl; sl += NW) {
+            const int r = sl / nsl, c = (sl - r * nsl) * 256 + lane * 4, cc = c < K ? c : 0;
+            const int src = a.rows ? a.rows[r] : r;
+            float4 v;
+            if constexpr (SRC == 0) v = *(const float4 *) (a32 + (size_t) src * K + cc);
+            else if constexpr (SRC == 2) {
+                const uint2 u = *(const uint2 *) (a.a16 + (size_t) src * K + cc);
+                const float2 p = __half22float2(*(const __half2 *) &u.x), q2 = __half22float2(*(const __half2 *) &u.y);
+                v = make_float4(p.x, p.y, q2.x, q2.y);
+            } else {                                         // o / l of head cc / 64 over the key slices (k_xattn_combine's arithmetic)
+                const int H = K >> 6, h = cc >> 6, dd = cc & 63, ns = a.comb_ns;
+                const size_t row = (size_t) src * H + h;
+                float4 o = make_float4(0.f, 0.f, 0.f, 0.f); double l = 0.0;
+                if (ns == 8) {
+                    float4 po[8]; float pl[8];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c = c0 + (i * 64 + lane) * 4, cc = c < K ? c : 0;
-                    if constexpr (SRC == 0) v[i] = *(const float4 *) (a32 + (size_t) src * K + cc);
-                    else {
-                        const uint2 u = *(const uint2 *) (a.a16 + (size_t) src * K + cc);
-                        const float2 p = __half22float2(*(const __half2 *) &u.x), q2 = __half22float2(*(const __half2 *) &u.y);
-                        v[i] = make_float4(p.x, p.y, q2.x, q2.y);
-                    }
-                    if (c >= K) v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+                    for (int s2 = 0; s2 < 8; ++s2) { po[s2] = *(const float4 *) (a.comb_o + (row * 8 + s2) * 64 + dd); pl[s2] = a.comb_l[row * 8 + s2]; }
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int c = c0 + (i * 64 + lane) * 4;
-                    float d, s;
-                    const uint32_t q = quant4<F16D>(v[i].x, v[i].y, v[i].z, v[i].w, d, s);
-                    if (c < K) {
-                        *(uint32_t *) (sq + (size_t) r * lda + c) = q;
-                        if ((lane & 7) == 0) { sd[(c >> 5) * R8 + r] = d; ss[(c >> 5) * R8 + r] = s; }
+                    for (int s2 = 0; s2 < 8; ++s2) { o.x += po[s2].x; o.y += po[s2].y; o.z += po[s2].z; o.w += po[s2].w; l += (double) pl[s2]; }
+                } else {
+                    for (int s2 = 0; s2 < ns; ++s2) {
+                        const float4 t = *(const float4 *) (a.comb_o + (row * ns + s2) * 64 + dd);
+                        o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; l += (double) a.comb_l[row * ns + s2];
                     }
                 }
+                const float inv = (float) (1.0 / l);
+                v = make_float4(o.x * inv, o.y * inv, o.z * inv, o.w * inv);
+            }
+            if (c >= K) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            float d, s;
+            const uint32_t q = quant4<F16D>(v.x, v.y, v.z, v.w, d, s);
+            if (c < K) {
+                *(uint32_t *) (sq + (size_t) r * lda + c) = q;
+                if ((lane & 7) == 0) { sd[(c >> 5) * R8 + r] = d; ss[(c >> 5) * R8 + r] = s; }
             }
         }
     }
     // scale slots of absent rows: finite zeros (they are multiplied, never stored)
-    for (int e = tid; e < nb * R8; e += 256) { if ((e % R8) >= n) { sd[e] = 0.0f; ss[e] = 0.0f; } }
+    if (n < R8) for (int e = tid; e < nb * R8; e += NT) { if ((e % R8) >= n) { sd[e] = 0.0f; ss[e] = 0.0f; } }
     __syncthreads();
 
     const int arow = (lane & 31) < n ? (lane & 31) : 0;     // activation row this lane feeds the MFMA with
     const int fk = lane >> 5;
     const int8_t * afrag = sq + (size_t) arow * lda + fk * 16;
-    int ro_pre = 0;
 
     for (; rg < ngroups; rg += gridDim.x) {
         float out[4 * NR4];
 #pragma unroll
         for (int e = 0; e < 4 * NR4; ++e) out[e] = 0.0f;
-        for (int c0 = 0; wave + 4 * c0 < np; c0 += CH) {
+        for (int c0 = 0; wave + NW * c0 < np; c0 += CH) {
             if (!(rg == (int) blockIdx.x && c0 == 0)) load_tiles(rg, c0);
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
-                const int tp = wave + 4 * (c0 + u);
+                const int tp = wave + NW * (c0 + u);
                 if (tp < np) {                               // wave-uniform
                     uint32_t lo[4], hi[4]; float d, m;
                     unpack<QT>(wq[u], wh[u], lo, hi, d, m);
@@ -656,20 +674,23 @@ __global__ __launch_bounds__(256) void k_qrows(const GemvArgs a, const float * _
                 }
             }
         }
-        // next row group's first tiles go out before this one is reduced
-        const int rgn = rg + gridDim.x;
-        // ---- K-split partials of the four wavefronts, added in wavefront order
+        // the next row group's first tiles go out before this one is reduced (the vocabulary projection walks ~1.6 groups per workgroup)
+        const int rgn = rg + (int) gridDim.x;
+        const bool more = rgn < ngroups;
+        // ---- K-split partials of the wavefronts, added in wavefront order
         if (rg != (int) blockIdx.x) __syncthreads();            // red is reused
 #pragma unroll
         for (int q = 0; q < NR4; ++q)
             *(float4 *) (red + ((size_t) (wave * 32 + (lane & 31)) * R8 + 8 * q + 4 * fk)) = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
         __syncthreads();
-        for (int e = tid; e < 32 * R8; e += 256) {
+        for (int e = tid; e < 32 * R8; e += NT) {
             const int nl = e & 31, r = e >> 5;
             if (r >= n) continue;
             const int nf = rg * 32 + nl;
             if (nf >= a.N) continue;
-            const float v = ((red[(size_t) nl * R8 + r] + red[(size_t) (32 + nl) * R8 + r]) + red[(size_t) (64 + nl) * R8 + r]) + red[(size_t) (96 + nl) * R8 + r];
+            float v = red[(size_t) nl * R8 + r];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) v += red[(size_t) (w * 32 + nl) * R8 + r];
             const float bias = a.bias ? a.bias[nf] : 0.0f;
             switch (a.epi) {
                 case EPI_F16_BIAS:       ((__half *) a.C)[(size_t) r * a.ldc + nf] = f2h(v + bias); break;
@@ -689,26 +710,39 @@ __global__ __launch_bounds__(256) void k_qrows(const GemvArgs a, const float * _
                 default: break;
             }
         }
-        (void) rgn; (void) ro_pre;
+        (void) more;
     }
 }
 
-template <int QT, int NR4, int SRC>
+template <int QT, int NR4, int SRC, int NW>
 void launch_qrows(const GemvArgs & a, const float * a32, const uint8_t * Wt, hipStream_t st) {
     const int nb = a.K / 32, R8 = NR4 * 8;
-    const size_t smem = (((size_t) a.n * (a.K + 16) + 15) & ~(size_t) 15) + (size_t) 2 * nb * R8 * 4 + (size_t) 4 * 32 * R8 * 4;
+    const size_t smem = (((size_t) a.n * (a.K + 16) + 15) & ~(size_t) 15) + (size_t) 2 * nb * R8 * 4 + (size_t) NW * 32 * R8 * 4;
     const int ngroups = (a.N + 31) / 32;
     int blocks = ngroups; if (blocks > 1024) blocks = 1024;
     static std::atomic<uint64_t> lds_ok{0};
-    if (smem > 48 * 1024) allow_full_lds((const void *) k_qrows<QT, NR4, SRC>, lds_ok);
-    hipLaunchKernelGGL((k_qrows<QT, NR4, SRC>), dim3(blocks), dim3(256), smem, st, a, a32, Wt);
+    if (smem > 48 * 1024) allow_full_lds((const void *) k_qrows<QT, NR4, SRC, NW>, lds_ok);
+    hipLaunchKernelGGL((k_qrows<QT, NR4, SRC, NW>), dim3(blocks), dim3(NW * 64), smem, st, a, a32, Wt);
+}
+
+template <int QT, int NR4, int SRC>
+void qrows_nw(const GemvArgs & a, const float * a32, const uint8_t * Wt, hipStream_t st) {
+    // K split: every wavefront should find all of its tiles in one round of loads (<= 5, resp. 3 with 8 wavefronts)
+    const int np = a.K / 64;
+    if constexpr (SRC == 1) { if (np <= 8) launch_qrows<QT, NR4, SRC, 4>(a, a32, Wt, st); else launch_qrows<QT, NR4, SRC, 8>(a, a32, Wt, st); }
+    else {
+        if (np <= 8)       launch_qrows<QT, NR4, SRC, 4>(a, a32, Wt, st);
+        else if (np <= 24) launch_qrows<QT, NR4, SRC, 8>(a, a32, Wt, st);
+        else               launch_qrows<QT, NR4, SRC, 16>(a, a32, Wt, st);
+    }
 }
 
 template <int QT, int NR4>
 void qrows_src(const GemvArgs & a, const float * a32, const uint8_t * Wt, hipStream_t st) {
-    if (a.ln_g)   launch_qrows<QT, NR4, 1>(a, a32, Wt, st);
-    else if (a32) launch_qrows<QT, NR4, 0>(a, a32, Wt, st);
-    else          launch_qrows<QT, NR4, 2>(a, a32, Wt, st);
+    if (a.ln_g)        qrows_nw<QT, NR4, 1>(a, a32, Wt, st);
+    else if (a.comb_o) qrows_nw<QT, NR4, 3>(a, a32, Wt, st);
+    else if (a32)      qrows_nw<QT, NR4, 0>(a, a32, Wt, st);
+    else               qrows_nw<QT, NR4, 2>(a, a32, Wt, st);
 }
 
 template <int QT>

@@ -302,6 +302,7 @@ bool decode(whisper_context & ctx, const Batch & batch);
 // block-quantised models (device_q.cpp): the layer loops of encode() / decode() with the quantised kernels
 bool encode_layers_q(whisper_context & ctx, int T);
 bool decode_layers_q(whisper_context & ctx, int n, int n_kv, int kv_head, int Tc, const std::vector<int> & rows);
+void enqueue_greedy_step_q(whisper_context & ctx, int Tc);
 // greedy fast path: decode ONE token of sequence 0 at position `pos` and pick the next token on the device
 struct StepFilter { bool ban_blank, last_ts, penult_ts; int ts_floor_end, ts_initial_start; };
 bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const StepFilter & f, whisper_token_data & out);
