@@ -3,10 +3,14 @@
 
   python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
 
-A step = one complete transcription of one 30 s chunk of synthetic 16 kHz PCM that is already
-resident in HBM, with the Godot host's parameter set (src/speech_to_text.cpp:403-413: greedy,
-max_tokens 16, single_segment, token timestamps): log-mel -> conv -> 6 encoder blocks -> cross K/V ->
-prompt + <=17 KV-cached decoder steps with the reference's logit filters and sampling.
+A step = one complete transcription of one 30 s chunk of synthetic 16 kHz PCM through the boundary the Godot
+host binds — whisper_full(ctx, params, const float * pcm, n) with HOST samples, i.e. the 1.92 MB H2D copy is inside
+the timed region — with the host's parameter set (src/speech_to_text.cpp:403-413: greedy, max_tokens 16,
+single_segment, token timestamps): log-mel -> conv -> 6 encoder blocks -> cross K/V -> prompt + <=17 KV-cached
+decoder steps with the reference's logit filters and sampling.  Secondary figures in the same line: the same with the
+PCM already resident in HBM, the uncapped (max_tokens = 0) transcription, 8 / 16 chunks per call in lock-step,
+BASELINE configs[4] (large-v3 q5_1, beam 5), the roofline of the kernel with the largest share of GPU time, of the
+whole decode step and of the encoder, and the reference's CPU path on this box's cores.
 Rank r transcribes its own chunks (independent units, no collective in the hot loop: SURVEY §8(e));
 the only collective is the RCCL broadcast of the ggml model image before timing starts.
 Prints ONE JSON line on rank 0.
@@ -34,13 +38,15 @@ DEC_MB_PER_TOKEN = 115.6
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=40)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=1500)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--shape", default=SHAPE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stream-seconds", type=float, default=0.0,
                     help="secondary figure: BASELINE configs[2] — CaptureStreamToText over this many seconds of synthetic microphone "
                          "audio with the `small` multilingual shape (every 0.3 s the grown buffer is transcribed again, ragged audio_ctx)")
+    ap.add_argument("--no-config4", action="store_true", help="skip the BASELINE configs[4] figure (large-v3 q5_1, beam 5: ~1 min of model synthesis)")
+    ap.add_argument("--device-pcm", action="store_true", help="headline loop over PCM that is already resident in HBM (round-1 behaviour)")
     ap.add_argument("--chunks", type=int, default=1,
                     help="chunks per GPU per step: 1 = BASELINE configs[1] (headline); 8 = configs[3]'s per-GPU share, lock-step")
     args = ap.parse_args()
@@ -103,9 +109,12 @@ def main():
         if args.chunks > 1:                      # lock-step chunks (include/wmi_device.h: wmi_full_batch)
             ptrs, lens = batch_args(i, args.chunks)
             ret = lib.wmi_full_batch(ctx, params, ptrs, lens, args.chunks, 1)
-        else:
+        elif args.device_pcm:
             t = pcm_dev[i % n_distinct]
             ret = lib.wmi_full_device_pcm(ctx, params, C.c_void_p(t.data_ptr()), t.numel(), None)
+        else:                                    # the reference contract: host samples (W/whisper.h:537-541)
+            h = pcm_host[i % n_distinct]
+            ret = lib.whisper_full(ctx, params, h.ctypes.data_as(C.POINTER(C.c_float)), int(h.size))
         assert ret == 0, ret
 
     for i in range(args.warmup):
@@ -127,7 +136,32 @@ def main():
         lib.wmi_batch_select(ctx, 0)
     n_tokens = sum(lib.whisper_full_n_tokens(ctx, s) for s in range(lib.whisper_full_n_segments(ctx)))
 
-    # ---- secondary figure in the same run (N = 1, headline configuration only): 8 chunks in lock-step
+    # ---- secondary figures in the same run (N = 1, headline configuration only)
+    dev_pcm = None; uncapped = None
+    if args.chunks == 1 and world == 1 and not args.device_pcm:
+        reps = max(20, min(300, args.steps // 5))
+        for i in range(3):
+            t = pcm_dev[i % n_distinct]; assert lib.wmi_full_device_pcm(ctx, params, C.c_void_p(t.data_ptr()), t.numel(), None) == 0
+        torch.cuda.synchronize(); td0 = time.perf_counter()
+        for i in range(reps):
+            t = pcm_dev[i % n_distinct]; assert lib.wmi_full_device_pcm(ctx, params, C.c_void_p(t.data_ptr()), t.numel(), None) == 0
+        torch.cuda.synchronize(); td = (time.perf_counter() - td0) / reps
+        dev_pcm = {"workload": "same step with the PCM already resident in HBM (wmi_full_device_pcm)", "value": round(CHUNK_S / td, 1),
+                   "unit": "x realtime", "ms_per_step": round(td * 1e3, 4)}
+        # the uncapped transcription (max_tokens = 0: the decoder runs until EOT / end of audio / n_text_ctx/2 - 4)
+        # (temperature_inc = 0: on synthetic weights the 190-token stream fails the entropy threshold and the reference's fallback
+        # would re-decode it up to five times with best_of sampling — a property of the random weights, not of the path)
+        p0 = node.full_params("", 0); p0.max_tokens = 0; p0.temperature_inc = 0.0
+        h = pcm_host[0]
+        def full0():
+            assert lib.whisper_full(ctx, p0, h.ctypes.data_as(C.POINTER(C.c_float)), int(h.size)) == 0
+            return sum(lib.whisper_full_n_tokens(ctx, sg) for sg in range(lib.whisper_full_n_segments(ctx)))
+        full0(); full0()
+        torch.cuda.synchronize(); tu0 = time.perf_counter(); nrep = 10
+        for _ in range(nrep): ntok0 = full0()
+        torch.cuda.synchronize(); tu = (time.perf_counter() - tu0) / nrep
+        uncapped = {"workload": "same chunk with max_tokens = 0 (no cap on the decoded tokens), whisper_full with host PCM",
+                    "value": round(CHUNK_S / tu, 1), "unit": "x realtime", "ms_per_step": round(tu * 1e3, 3), "tokens": int(ntok0)}
     batch8 = None
     if args.chunks == 1 and world == 1:
         nb, reps = 8, max(3, args.steps // 8)
@@ -174,7 +208,8 @@ def main():
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic" + (" (REHEARSAL: ranks share GPUs, gloo)" if rehearsal else ""),
             "config": {"workload": (f"base.en, single 30 s chunk per step per GPU ({world}x MI355X), greedy decode, host params "
-                                    "(max_tokens=16, single_segment, token_timestamps)") if args.chunks == 1 else
+                                    "(max_tokens=16, single_segment, token_timestamps), whisper_full with "
+                                    + ("device-resident PCM" if args.device_pcm else "host PCM (H2D inside the timed region)")) if args.chunks == 1 else
                                    (f"base.en, {args.chunks} x 30 s chunks per GPU per step in lock-step, greedy decode, host params"),
                        "chunks_per_gpu_per_step": args.chunks, "tokens_per_chunk": int(n_tokens),
                        "weights": "synthetic seed 1234 (f16 ggml, base.en shape)"},
@@ -184,26 +219,71 @@ def main():
             "sample_ms_per_step": round((t6[5] / 1e3) / args.steps, 4),
             "weight_bcast_ms": round(1e3 * t_bcast, 3),
         }
+        if dev_pcm:
+            out["device_pcm"] = dev_pcm
+        if uncapped:
+            out["uncapped_tokens"] = uncapped
         if batch8:
             out["batch8"] = batch8
 
         if stream:
             out["stream_small"] = stream
-        # ---- roofline of the dominant kernel, measured live with HIP events on the context's stream.
-        # Dominant by GPU time (profiles/*_kernel_stats.csv) is the decoder's weight-streaming k_gemv; its largest
-        # instance — the vocabulary projection, 53.1 MB of f16 weights per launch — is the one reported: HBM bound.
-        # The encoder's MFMA GEMM is reported next to it.
+        # ---- rooflines, measured live with HIP events on the context's stream (wmi_bench_kernel).
+        # `roofline` = the kernel kind with the largest share of GPU time in the headline configuration.  The decode step is a
+        # chain of dependent kernels; each kind is timed in its own back-to-back chain (which = 20 + WMI_STEP_MASK, no host in
+        # the loop), its algorithmic bytes are the weights + cache rows it has to read once.
         try:
+            step(0)                                          # the step record / caches of a headline transcription (17 cells)
             hp_S = lib.whisper_model_n_audio_state(ctx); T = lib.whisper_model_n_audio_ctx(ctx); NV = lib.whisper_n_vocab(ctx)
+            Lt = lib.whisper_model_n_text_layer(ctx)
+            S2 = hp_S * hp_S * 2
+            nkv = max(int(n_tokens) // 2, 1)                                    # mean self-attention cache length over the steps of a chunk
+            kinds = [   # (mask bit, name, launches per step, algorithmic bytes per launch)
+                (1, "k_gemv1<4,1,false,1,EPI_QKV_DEC> LN + q|k|v projection", Lt, 3 * S2),
+                (2, "k_gemv1<4,1,false,2,EPI_F32_BIAS_RESID> self-attention over the KV cache + out projection", Lt, S2 + 2 * nkv * hp_S * 2),
+                (3, "k_xattn_qscores + k_xattn_pv: LN + cross query, scores and P.V over the cross K/V", 2 * Lt, (S2 + 2 * T * hp_S * 2) // 2),
+                (4, "k_gemv1<4,1,false,3,EPI_F32_BIAS_RESID> cross-attention combine + out projection", Lt, S2),
+                (5, "k_gemv1<4,1,false,1,EPI_F16_BIAS_GELU> LN + mlp.0", Lt, 4 * S2),
+                (6, "k_gemv1<4,4,false,0,EPI_F32_BIAS_RESID> mlp.2", Lt, 4 * S2),
+                (7, "k_gemv1<8,1,false,1,EPI_LOGITS> LN + vocabulary projection", 1, NV * hp_S * 2),
+                (8, "k_filter_stats + k_filter_pick: logit filters, soft-max statistics, arg-max", 2, NV * 4 // 2),
+            ]
+            table = []
+            for bit, name, nl, alg in kinds:
+                os.environ["WMI_STEP_MASK"] = str(1 << bit)
+                us = lib.wmi_bench_kernel(ctx, 20, 200) / nl
+                gbs = alg / (us * 1e-6) / 1e9
+                table.append({"kernel": name, "launches_per_step": nl, "avg_us": round(us, 3), "algorithmic_bytes": int(alg),
+                              "achieved": round(gbs, 1), "frac": round(gbs / 8000.0, 4), "step_share_us": round(us * nl, 2)})
+            os.environ.pop("WMI_STEP_MASK", None)
+            us_step = lib.wmi_bench_kernel(ctx, 20, 200)
+            tot = sum(t["step_share_us"] for t in table)
+            for t in table:
+                t["step_share"] = round(t["step_share_us"] / tot, 3)
+            dom = max(table, key=lambda t: t["step_share_us"])
+            out["roofline"] = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["achieved"], "peak": 8000.0, "unit": "GB/s",
+                               "frac": dom["frac"], "traffic": None, "algorithmic_bytes": dom["algorithmic_bytes"], "avg_us": dom["avg_us"],
+                               "launches_per_step": dom["launches_per_step"], "share_of_decode_step": dom["step_share"],
+                               "note": "latency-bound: a dependent chain of small launches, see decode_step_kernels"}
+            out["decode_step_kernels"] = table
+            step_bytes = DEC_MB_PER_TOKEN * 1e6
+            out["roofline_decode_step"] = {"bound": "hbm", "achieved": round(step_bytes / (us_step * 1e-6) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                           "frac": round(step_bytes / (us_step * 1e-6) / 1e9 / 8000.0, 4), "algorithmic_bytes": int(step_bytes),
+                                           "avg_us": round(us_step, 2), "launches": int(sum(t["launches_per_step"] for t in table) + 1)}
+            out["roofline_encoder"] = {"bound": "mfma", "achieved": round(ENC_GFLOP / enc_ms, 2), "peak": 2500.0, "unit": "TFLOP/s",
+                                       "frac": round(ENC_GFLOP / enc_ms / 2500.0, 4), "algorithmic_gflop": ENC_GFLOP, "encode_ms": round(enc_ms, 4)}
+            # the vocabulary projection alone: on one matrix (Infinity-Cache resident after the first pass) and on a rotating > 256 MiB stream
             us_gemv = lib.wmi_bench_kernel(ctx, 1, 300)
+            us_rot = lib.wmi_bench_kernel(ctx, 6, 300)
             us_gemm = lib.wmi_bench_kernel(ctx, 0, 300)
             us_attn = lib.wmi_bench_kernel(ctx, 2, 60)
             alg_bytes = NV * hp_S * 2                       # V*S*2 bytes of d_te per token
-            gbs = alg_bytes / (us_gemv * 1e-6) / 1e9
-            out["roofline"] = {"kernel": "k_gemv1<8,1> logits = d_te[51864x512] . LN(x)  (f16 weight stream, LN + activations in registers)",
-                               "bound": "hbm", "achieved": round(gbs, 1), "peak": 8000.0, "unit": "GB/s",
-                               "frac": round(gbs / 8000.0, 4), "traffic": pmc_traffic("k_gemv1<8, 1, false*"),
-                               "algorithmic_bytes": alg_bytes, "avg_us": round(us_gemv, 3)}
+            out["roofline_logits"] = {"kernel": "k_gemv1<8,1> logits = d_te[51864x512] . LN(x)  (f16 weight stream, LN + activations in registers)",
+                                      "bound": "hbm", "achieved": round(alg_bytes / (us_rot * 1e-6) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                      "frac": round(alg_bytes / (us_rot * 1e-6) / 1e9 / 8000.0, 4), "traffic": pmc_traffic("k_gemv1<8, 1, false*"),
+                                      "algorithmic_bytes": alg_bytes, "avg_us": round(us_rot, 3),
+                                      "stream": "rotating copies of the matrix, > 256 MiB in total (HBM)",
+                                      "same_matrix_avg_us": round(us_gemv, 3), "same_matrix_gbs_l3_plus_hbm": round(alg_bytes / (us_gemv * 1e-6) / 1e9, 1)}
             flops = 2.0 * T * 4 * hp_S * hp_S
             tf = flops / (us_gemm * 1e-6) / 1e12
             out["roofline_encoder_gemm"] = {"kernel": "k_gemm<64,64,EPI_F16_BIAS_GELU> encoder mlp.0 [1500x2048x512] f16 MFMA",
@@ -244,16 +324,94 @@ def main():
         # ---- CPU baseline on this box's host cores (bounded sample), rank 0 / N=1 only
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model_bytes, pcm_host[0])
-            # SURVEY §8(d) asks for the host's wider setting too: the same transcription with more worker threads
-            wide = min(os.cpu_count() or 4, 32)
-            if wide > 4:
-                out["cpu_baseline_threads%d" % wide] = cpu_baseline(model_bytes, pcm_host[0], n_threads=wide, budget_s=5.0)
+            # SURVEY §8(d) asks for the host's wider settings too: n_threads = hardware concurrency, and an intermediate count
+            # (whisper.cpp's spin-barrier thread pool does not scale to hundreds of threads on a 1500 x 512 problem)
+            # (n_threads = all 256 hardware threads of this box was measured once — 545 s per chunk, 0.06x realtime: whisper.cpp's
+            # spin-barrier pool collapses — and is not repeated in the default run; profiles/README.md)
+            hw = os.cpu_count() or 4
+            for nt in sorted({min(hw, 32), min(hw, 64)}):
+                if nt > 4:
+                    out["cpu_baseline_threads%d" % nt] = cpu_baseline(model_bytes, pcm_host[0], n_threads=nt, budget_s=5.0)
+        # ---- BASELINE configs[4]: large-v3 q5_1, beam_size = 5 — this GPU's share of "batch = 8 on 8 GPUs" is one chunk
+        if world == 1 and args.chunks == 1 and not args.no_config4:
+            lib.whisper_free(ctx); node.ctx = None; ctx = None          # release base.en before the 1.2 GB model
+            try:
+                out["config4_large_v3_q5_1_beam5"] = config4(lib)
+            except Exception as e:  # pragma: no cover
+                out["config4_error"] = repr(e)
         print(json.dumps(out), flush=True)
 
-    lib.whisper_free(ctx)
+    if ctx:
+        lib.whisper_free(ctx)
     node.ctx = None
     if world > 1:
         dist.destroy_process_group()
+
+
+def config4(lib) -> dict:
+    """BASELINE configs[4]: large-v3 (32 + 32 layers, 1280 wide, 128 mels) as q5_1 ggml blocks, beam_size = 5, one 30 s chunk
+    on this GPU.  The weights stay quantised in HBM (csrc/k_quant.hip); the roofline of a decode step uses the q5_1 bytes."""
+    from godot_whisper_amd import abi, host, synth
+    t0 = time.perf_counter()
+    f16 = synth.make_model("large-v3", seed=2024)
+    model = None
+    try:                                             # the reference's own block quantiser when its library travelled along (fast, byte-identical)
+        entry.load_oracle()
+        from oracle import reflib
+        if reflib.available():
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
+            import test_gpu_large_v3 as tl
+            model = tl._ref_quantize_model(reflib.lib(), f16, "q5_1")
+    except Exception:
+        model = None
+    if model is None:
+        model = synth.quantize_model(f16, "q5_1")
+    del f16
+    t_model = time.perf_counter() - t0
+    node = host.SpeechToText(lib); node.set_language_model(model); node.language = "en"
+    file_mb = len(model) / 1e6
+    del model
+    ctx = node.ctx
+    arena = lib.wmi_weights_bytes(ctx, 0); mats = lib.wmi_weights_bytes(ctx, 1)
+    pcm = synth.make_pcm(CHUNK_S, seed=4321)
+    S, T, Lt, NV = 1280, 1500, 32, 51866
+    res = {"workload": "large-v3 q5_1 (synthetic seed 2024), one 30 s chunk, whisper_full with host PCM, host params",
+           "model_file_mb": round(file_mb, 1), "weights_in_hbm_mb": round(arena / 1e6, 1), "model_synthesis_s": round(t_model, 1)}
+    q = node.full_params("", 0)
+    for name, strat, bs in (("beam5", abi.WHISPER_SAMPLING_BEAM_SEARCH, 5), ("greedy", abi.WHISPER_SAMPLING_GREEDY, 1)):
+        p = lib.whisper_full_default_params(strat)
+        for f in ("language", "audio_ctx", "split_on_word", "token_timestamps", "suppress_non_speech_tokens", "single_segment",
+                  "max_tokens", "entropy_thold", "initial_prompt"):
+            setattr(p, f, getattr(q, f))
+        if strat == abi.WHISPER_SAMPLING_BEAM_SEARCH:
+            p.beam_search.beam_size = bs
+        node.transcribe(pcm, params=p); node.transcribe(pcm, params=p)
+        lib.whisper_reset_timings(ctx)
+        n = 5; t1 = time.perf_counter()
+        for _ in range(n):
+            r = node.transcribe(pcm, params=p)
+        dt = (time.perf_counter() - t1) / n
+        t6 = (C.c_int64 * 6)(); n5 = (C.c_int32 * 5)(); lib.wmi_get_timings(ctx, t6, n5)
+        res[name] = {"value": round(CHUNK_S / dt, 1), "unit": "x realtime", "ms_per_chunk": round(dt * 1e3, 2), "tokens": max(len(r) - 1, 0),
+                     "encode_ms": round(t6[1] / 1e3 / max(n5[0], 1), 3),
+                     "decode_ms_total": round((t6[2] + t6[3] + t6[4]) / 1e3 / n, 3), "sample_ms_total": round(t6[5] / 1e3 / n, 3)}
+    # decode-step roofline, greedy step chain on the GPU: q5_1 decoder matrices + vocabulary projection + cross K/V (f16) once per step
+    dec_bytes = Lt * 14 * S * S * 24 // 32 + (NV + 31) // 32 * 32 * S * 24 // 32 + Lt * 2 * T * S * 2
+    us_step = lib.wmi_bench_kernel(ctx, 20, 30)
+    if us_step > 0:
+        res["roofline_decode_step"] = {"bound": "hbm", "achieved": round(dec_bytes / (us_step * 1e-6) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                                       "frac": round(dec_bytes / (us_step * 1e-6) / 1e9 / 8000.0, 4), "algorithmic_bytes": int(dec_bytes),
+                                       "avg_us": round(us_step, 1), "note": "greedy step, 9 launches per layer; q5_1 bytes per token"}
+    enc_gflop = 2588.3
+    res["roofline_encoder"] = {"bound": "mfma", "achieved": round(enc_gflop / res["greedy"]["encode_ms"], 1), "peak": 2500.0, "unit": "TFLOP/s (2 x MAC of the i8 block dots)",
+                               "frac": round(enc_gflop / res["greedy"]["encode_ms"] / 2500.0, 4), "algorithmic_gflop": enc_gflop}
+    us_rot = lib.wmi_bench_kernel(ctx, 6, 100)
+    vb = (NV + 31) // 32 * 32 * S * 24 // 32
+    res["roofline_logits"] = {"kernel": "k_qrows<q5_1> vocabulary projection, rotating > 256 MiB stream", "bound": "hbm",
+                              "achieved": round(vb / (us_rot * 1e-6) / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(vb / (us_rot * 1e-6) / 1e9 / 8000.0, 4),
+                              "algorithmic_bytes": int(vb), "avg_us": round(us_rot, 2)}
+    node.close()
+    return res
 
 
 def stream_config(lib, seconds: float) -> dict:

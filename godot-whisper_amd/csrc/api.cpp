@@ -605,6 +605,34 @@ double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters) {
         (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
         return (double) ms * 1000.0 / iters;
     }
+    if (which == 6) {
+        // vocabulary projection over a ROTATING set of copies of the token embedding, > 256 MiB in total: the matrix of one launch
+        // has been evicted from the 256 MiB Infinity Cache by the time it is read again, so bytes / time is an HBM figure
+        // (which = 1 re-streams the same 53 MB, i.e. measures L3 + HBM)
+        const bool q = ctx->model.quantised;
+        const size_t bytes = q ? k::q_matrix_bytes(w.qtype, hp.n_vocab, S) : (size_t) hp.n_vocab * S * 2;
+        const int copies = (int) ((size_t) 320 * 1024 * 1024 / bytes) + 2;
+        uint8_t * pool = nullptr;
+        if (!HIP_OK(hipMalloc((void **) &pool, bytes * copies + 4096))) { (void) hipEventDestroy(e0); (void) hipEventDestroy(e1); return -1.0; }
+        const void * src = q ? (const void *) w.q_te.tiles : (const void *) w.d_te;
+        for (int c = 0; c < copies; ++c) (void) hipMemcpyAsync(pool + (size_t) c * bytes, src, bytes, hipMemcpyDeviceToDevice, s);
+        auto launch = [&](int c) {
+            k::GemvArgs g{};
+            g.x32 = d.dx; g.ln_g = w.d_ln_g; g.ln_b = w.d_ln_b; g.eps = hp.eps; g.n = 1; g.K = S; g.N = hp.n_vocab;
+            g.epi = k::EPI_LOGITS; g.C = d.logits; g.ldc = hp.n_vocab;
+            if (q) k::qrows(g, nullptr, k::QMat{pool + (size_t) c * bytes, w.qtype}, s);
+            else { g.W = (const __half *) (pool + (size_t) c * bytes); k::gemv(g, s); }
+        };
+        for (int c = 0; c < copies; ++c) launch(c);
+        (void) hipStreamSynchronize(s);
+        (void) hipEventRecord(e0, s);
+        for (int i = 0; i < iters; ++i) launch(i % copies);
+        (void) hipEventRecord(e1, s);
+        (void) hipEventSynchronize(e1);
+        float ms6 = 0.0f; (void) hipEventElapsedTime(&ms6, e0, e1);
+        (void) hipEventDestroy(e0); (void) hipEventDestroy(e1); (void) hipFree(pool);
+        return (double) ms6 * 1000.0 / iters;
+    }
     if (which == 20) { (void) hipEventDestroy(e0); (void) hipEventDestroy(e1); return bench_greedy_step_chain(*ctx, iters); }
     if (which >= 21 && which <= 36) { (void) hipEventDestroy(e0); (void) hipEventDestroy(e1); return bench_rows_step_chain(*ctx, which - 20, iters); }   // 20 + rows
     if (which == 3) {

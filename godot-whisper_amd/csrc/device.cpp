@@ -468,7 +468,10 @@ bool wait_for_seq(const volatile int32_t * seq, int32_t want, hipStream_t s) {
 // 4 cross combine+out, 5 mlp.0, 6 mlp.2, 7 logits, 8 filters
 static unsigned g_step_mask = ~0u;
 
-static void enqueue_greedy_step(whisper_context & ctx, int Tc) {
+// long_kv: the self cache holds more than 64 cells.  The attention fused into the out projection's prologue is a per-wavefront
+// routine for <= 64 keys (every workgroup recomputes it); beyond that its barrier-separated fall-back ran at ~95 us per
+// layer (bench: the uncapped transcription), so long caches take the (row, head)-parallel attention kernel + a plain projection.
+static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = false) {
     if (ctx.model.quantised) { enqueue_greedy_step_q(ctx, Tc); return; }
     State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
     KVCache & kv = st.kv_self;
@@ -498,6 +501,10 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc) {
         const DecLayerW & l = w.dec[il];
         __half * ck = kv.k + ((size_t) il * n_ctx) * S, * cv = kv.v + ((size_t) il * n_ctx) * S;
         if (M & 2) gv(k::EPI_QKV_DEC, l.ln1_g, l.ln1_b, nullptr, S, 3 * S, l.w_qkv, l.b_qkv, d.dq, S, nullptr, ck, cv, kq_scale, &stp->kv_head); chk("qkv", il);
+        if ((M & 4) && long_kv) {
+            k::self_attn_rows(d.dq, 1, S, ck, cv, 0, &stp->n_kv, 0, hp.n_text_ctx, d.datt, s);
+            gv(k::EPI_F32_BIAS_RESID, nullptr, nullptr, d.datt, S, S, l.w_o, l.b_o, d.dx, S, d.dx, nullptr, nullptr, 0.f, nullptr); chk("self-attn, out", il);
+        } else
         if (M & 4) {   // self-attention over the cache, recomputed in the out-projection's prologue (one launch fewer)
             k::GemvArgs g{};
             g.sa_q = d.dq; g.sa_k = ck; g.sa_v = cv; g.sa_nkv = &stp->n_kv; g.sa_cap = hp.n_text_ctx;
@@ -589,10 +596,11 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
         } else d.step_capture_failed = true;
     }
     hs->seq = ++d.step_seq;
-    if (use_graph && d.step_exec) {
+    const bool long_kv = (int) kv.n > 64;
+    if (use_graph && d.step_exec && !long_kv) {
         HIP_TRY(hipGraphLaunch(d.step_exec, s));
     } else {
-        enqueue_greedy_step(ctx, Tc);
+        enqueue_greedy_step(ctx, Tc, long_kv);
     }
     const k::SampleOut * r = (const k::SampleOut *) d.sample_host;
     if (!wait_for_seq(&r->seq, d.step_seq, s)) return false;
@@ -616,7 +624,8 @@ double bench_greedy_step_chain(whisper_context & ctx, int iters) {
     hipStream_t s = d.stream;
     hipEvent_t e0, e1;
     if (!HIP_OK(hipEventCreate(&e0)) || !HIP_OK(hipEventCreate(&e1))) return -1.0;
-    auto once = [&]() { if (d.step_exec && d.step_graph_T == Tc && g_step_mask == ~0u) (void) hipGraphLaunch(d.step_exec, s); else enqueue_greedy_step(ctx, Tc); };
+    const bool long_kv = ((const k::DecStep *) d.step_host)->n_kv > 64;
+    auto once = [&]() { if (d.step_exec && d.step_graph_T == Tc && g_step_mask == ~0u && !long_kv) (void) hipGraphLaunch(d.step_exec, s); else enqueue_greedy_step(ctx, Tc, long_kv); };
     for (int i = 0; i < 4; ++i) once();
     (void) hipStreamSynchronize(s);
     (void) hipEventRecord(e0, s);

@@ -140,7 +140,13 @@ WHISPER_API int wmi_selftest_quant(int device, int qtype, int mode, const void *
  *   which = 3  full encode (conv + L blocks + cross) — same as whisper_encode without the host sync per call
  *   which = 4  encoder MLP-0 GEMM over the lock-step work buffers [chunks*T x 4S x S] (after a wmi_full_batch call)
  *   which = 5  encoder attention, all lock-step chunks, one layer
+ *   which = 6  the logits projection over a rotating set of copies of the matrix (> 256 MiB in total): an HBM figure, where
+ *              which = 1 re-streams one matrix that the 256 MiB Infinity Cache holds
  *   which = 10..12  chains of trivial dependent kernels on 1 / 32 / 256 workgroups (launch floor)
+ *   which = 20  the kernels of the last greedy decode step back to back, no host in the loop (microseconds per step);
+ *               the environment variable WMI_STEP_MASK selects kernel kinds (bit 0 embed, 1 q|k|v, 2 self-attention + out,
+ *               3 cross scores, 4 cross combine + out, 5 mlp.0, 6 mlp.2, 7 logits, 8 filters)
+ *   which = 21..36  the same for the lock-step step of (which - 20) chunks
  */
 WHISPER_API double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters);
 

@@ -9,8 +9,8 @@ TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trace -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_trace.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o pmc_fetch -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o pmc_write -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_pmc_write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $OUT -o pmc_mfma -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_pmc_mfma.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trace -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-config4 > $OUT/bench_trace.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o pmc_fetch -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-config4 > $OUT/bench_pmc_fetch.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o pmc_write -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-config4 > $OUT/bench_pmc_write.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $OUT -o pmc_mfma -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-config4 > $OUT/bench_pmc_mfma.log 2>&1
 ls -la $OUT
