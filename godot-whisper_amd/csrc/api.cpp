@@ -295,6 +295,49 @@ size_t wmi_weights_bytes(struct whisper_context * ctx, int which) {
     return which == 0 ? ctx->w.arena_bytes : which == 1 ? ctx->w.matrix_bytes : which == 2 ? (size_t) ctx->w.qtype : 0;
 }
 
+int wmi_downmix_stereo(struct whisper_context * ctx, const float * frames, int n_frames, int on_device, float * mono_out) {
+    if (!ctx || !ctx->state || ctx->host_only || !frames || !mono_out || n_frames < 0) return -1;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!HIP_OK(hipSetDevice(ctx->device))) return -2;
+    hipStream_t s = ctx->state->dev.stream;
+    if (n_frames == 0) return 0;
+    if (on_device) { k::downmix_stereo(frames, n_frames, mono_out, s); return HIP_OK(hipStreamSynchronize(s)) ? 0 : -3; }
+    float * d_in = nullptr, * d_out = nullptr;
+    bool ok = HIP_OK(hipMalloc((void **) &d_in, (size_t) n_frames * 8)) && HIP_OK(hipMalloc((void **) &d_out, (size_t) n_frames * 4));
+    ok = ok && HIP_OK(hipMemcpyAsync(d_in, frames, (size_t) n_frames * 8, hipMemcpyHostToDevice, s));
+    if (ok) k::downmix_stereo(d_in, n_frames, d_out, s);
+    ok = ok && HIP_OK(hipMemcpyAsync(mono_out, d_out, (size_t) n_frames * 4, hipMemcpyDeviceToHost, s)) && HIP_OK(hipStreamSynchronize(s));
+    (void) hipFree(d_in); (void) hipFree(d_out);
+    return ok ? 0 : -3;
+}
+
+int wmi_vad(struct whisper_context * ctx, const float * pcm, int n_samples, int on_device, float vad_thold, float freq_thold, float * energies) {
+    if (!ctx || !ctx->state || ctx->host_only || !pcm || n_samples < 0) return -1;
+    const int n_win = WHISPER_SAMPLE_RATE * 3, n_last = (WHISPER_SAMPLE_RATE * 500) / 1000;      // src/speech_to_text.cpp:381-386
+    if (n_samples < n_win) return 0;                                                              // not enough accumulated audio
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!HIP_OK(hipSetDevice(ctx->device))) return -2;
+    hipStream_t s = ctx->state->dev.stream;
+    // alpha exactly as the host computes it (:54-56): Math_PI is a double constant, rc is rounded to float
+    const float rc = (float) (1.0f / (2.0f * 3.14159265358979323846 * freq_thold));
+    const float dt = 1.0f / (float) WHISPER_SAMPLE_RATE;
+    const float alpha = dt / (rc + dt);
+    float * d_win = nullptr, * d_res = nullptr;
+    bool ok = HIP_OK(hipMalloc((void **) &d_res, 16));
+    const float * win = pcm + (n_samples - n_win);
+    if (ok && !on_device) {
+        ok = HIP_OK(hipMalloc((void **) &d_win, (size_t) n_win * 4)) && HIP_OK(hipMemcpyAsync(d_win, win, (size_t) n_win * 4, hipMemcpyHostToDevice, s));
+        win = d_win;
+    }
+    float res[3] = {0.f, 0.f, 0.f};
+    if (ok) k::vad_window(win, n_win, n_last, alpha, freq_thold > 0.0f, vad_thold, d_res, s);
+    ok = ok && HIP_OK(hipMemcpyAsync(res, d_res, 12, hipMemcpyDeviceToHost, s)) && HIP_OK(hipStreamSynchronize(s));
+    (void) hipFree(d_win); (void) hipFree(d_res);
+    if (!ok) return -3;
+    if (energies) { energies[0] = res[1]; energies[1] = res[2]; }
+    return res[0] != 0.0f ? 1 : 0;
+}
+
 int wmi_pcm_to_mel_device(struct whisper_context * ctx, const float * d_samples, int n_samples) {
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void) hipSetDevice(ctx->device);

@@ -265,6 +265,51 @@ __global__ __launch_bounds__(256) void k_signal_energy(const float * __restrict_
     }
 }
 
+// ---------------------------------------------------------------- host-adjacent DSP
+// stereo frames -> mono, the streaming node's down-mix in front of the resampler (src/speech_to_text.cpp:45-51):
+// out[i] = (float) ((x + y) / 2.0) — a float add, then an exact halving
+__global__ void k_downmix(const float2 * __restrict__ frames, int n, float * __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const float2 f = frames[i]; out[i] = (float) ((double) (f.x + f.y) / 2.0); }
+}
+
+// SpeechToText::voice_activity_detection on a window of n samples (the caller passes the last 3 s): the reference's
+// _high_pass_filter + _vad_simple (src/speech_to_text.cpp:53-104), operation for operation.  The filter runs IN PLACE, so its
+// "previous input" data[i - 1] is the previous OUTPUT: y_i = alpha * ((y_{i-1} + x_i) - y_{i-1}) — a recurrence through f32
+// rounding only, but a recurrence: it and the two running f32 energy sums are evaluated by ONE lane in sample order (48 000
+// samples x ~15 dependent cycles = 0.3 ms against a 300 ms cadence); the other lanes stage the samples through LDS.
+// res: {decision (1.0 = "no activity"), energy_all, energy_last}
+__global__ __launch_bounds__(256) void k_vad(const float * __restrict__ x, int n, int n_last, float alpha, int filter, float vad_thold,
+                                             float * __restrict__ res) {
+    constexpr int CHUNK = 8192;
+    __shared__ float buf[CHUNK];
+    float y = 0.0f, e_all = 0.0f, e_last = 0.0f;
+    for (int c0 = 0; c0 < n; c0 += CHUNK) {
+        const int m = min(CHUNK, n - c0);
+        for (int i = threadIdx.x; i < m; i += 256) buf[i] = x[c0 + i];
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int i = 0; i < m; ++i) {
+                const int gi = c0 + i;
+                float v = buf[i];
+                if (filter) {
+                    if (gi == 0) y = v;
+                    else { y = __fmul_rn(alpha, __fsub_rn(__fadd_rn(y, v), y)); v = y; }
+                }
+                e_all = __fadd_rn(e_all, fabsf(v));
+                if (gi >= n - n_last) e_last = __fadd_rn(e_last, fabsf(v));
+            }
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        e_all /= (float) n;
+        if (n_last != 0) e_last /= (float) n_last;
+        const bool quiet = !(!(e_all < 0.0001f && e_last < 0.0001f) || e_last > vad_thold * e_all);
+        res[0] = quiet ? 1.0f : 0.0f; res[1] = e_all; res[2] = e_last;
+    }
+}
+
 __global__ void k_fill_zero(uint32_t * p, size_t n) {
     size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     const size_t stride = (size_t) gridDim.x * blockDim.x;
@@ -301,6 +346,13 @@ void mel_slice(const float * mel, int n_len, int n_mel, int offset, int n_frames
 
 void signal_energy(const float * pcm, int n, int hw, float * out, float * bmin, float * bmax, hipStream_t st) {
     hipLaunchKernelGGL(k_signal_energy, dim3((n + 255) / 256), dim3(256), 0, st, pcm, n, hw, out, bmin, bmax);
+}
+
+void downmix_stereo(const float * frames, int n_frames, float * out, hipStream_t st) {
+    if (n_frames > 0) hipLaunchKernelGGL(k_downmix, dim3((n_frames + 255) / 256), dim3(256), 0, st, (const float2 *) frames, n_frames, out);
+}
+void vad_window(const float * x, int n, int n_last, float alpha, bool filter, float vad_thold, float * res, hipStream_t st) {
+    hipLaunchKernelGGL(k_vad, dim3(1), dim3(256), 0, st, x, n, n_last, alpha, filter ? 1 : 0, vad_thold, res);
 }
 
 __global__ void k_touch(int * p, int nblk) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] += 1; }

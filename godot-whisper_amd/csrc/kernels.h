@@ -47,6 +47,11 @@ void mel_slice(const float * mel, int n_len, int n_mel, int offset, int n_frames
 // out[n] plus the minimum / maximum of each 256-sample block of out (bmin, bmax: ceil(n / 256) entries)
 void signal_energy(const float * pcm, int n, int hw, float * out, float * bmin, float * bmax, hipStream_t st);
 
+// host-adjacent DSP of the streaming node: stereo -> mono and the energy VAD, bit-identical to the host's C++
+// (src/speech_to_text.cpp:45-51, 53-104).  res = {no-activity decision, energy_all, energy_last}
+void downmix_stereo(const float * frames, int n_frames, float * out, hipStream_t st);
+void vad_window(const float * x, int n, int n_last, float alpha, bool filter, float vad_thold, float * res, hipStream_t st);
+
 // ---------------------------------------------------------------- GEMM (k_gemm.hip)
 enum Epi : int {
     EPI_F16_BIAS = 0,       // C f16 = acc + bias

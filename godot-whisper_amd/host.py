@@ -144,6 +144,14 @@ class SpeechToText:
         n_win = abi.WHISPER_SAMPLE_RATE * 3
         if buffer.size < n_win:
             return False
+        if getattr(self, "device_vad", False) and hasattr(self.lib, "wmi_vad") and self.ctx:
+            # the product's device kernel (include/wmi_device.h): same decision, no per-sample host loop
+            b = np.ascontiguousarray(buffer[-n_win:], dtype=np.float32)
+            r = self.lib.wmi_vad(self.ctx, b.ctypes.data_as(C.c_void_p), int(b.size), 0,
+                                 float(self.settings["audio/input/transcribe/vad_treshold"]),
+                                 float(self.settings["audio/input/transcribe/freq_treshold"]), None)
+            assert r >= 0, r
+            return bool(r)
         pcm = np.array(buffer[-n_win:], dtype=np.float32)
         return vad_simple(pcm, abi.WHISPER_SAMPLE_RATE, 500,
                           float(self.settings["audio/input/transcribe/vad_treshold"]),
@@ -151,15 +159,15 @@ class SpeechToText:
 
 
 def high_pass_filter(data: np.ndarray, cutoff: float, sample_rate: float) -> None:
-    rc = np.float32(1.0) / np.float32(2.0 * math.pi * cutoff)
+    """src/speech_to_text.cpp:53-66, operation for operation.  The reference filters IN PLACE and reads data[i - 1] after it
+    has been overwritten, so its "previous input" is the previous OUTPUT: y = alpha * ((y + x_i) - y).  (Math_PI is a double:
+    rc is computed in double and rounded to float.)"""
+    rc = np.float32(1.0 / (2.0 * math.pi * float(np.float32(cutoff))))
     dt = np.float32(1.0) / np.float32(sample_rate)
-    alpha = np.float32(dt / (rc + dt))
+    alpha = np.float32(dt / np.float32(rc + dt))
     y = np.float32(data[0])
-    prev = np.float32(data[0])
     for i in range(1, data.size):
-        cur = np.float32(data[i])
-        y = np.float32(alpha * np.float32(y + cur - prev))
-        prev = cur
+        y = np.float32(alpha * np.float32(np.float32(y + np.float32(data[i])) - np.float32(data[i - 1])))
         data[i] = y
 
 
@@ -171,8 +179,11 @@ def vad_simple(pcm: np.ndarray, sample_rate: int, last_ms: int, vad_thold: float
     if freq_thold > 0.0:
         high_pass_filter(pcm, freq_thold, sample_rate)
     a = np.abs(pcm.astype(np.float32))
-    e_all = float(np.add.reduce(a, dtype=np.float32)) / n
-    e_last = float(np.add.reduce(a[n - n_last:], dtype=np.float32)) / max(n_last, 1)
+    # running f32 sums in sample order, as the reference's loop (np.cumsum accumulates sequentially; np.add.reduce would pair)
+    e_all = np.float32(np.cumsum(a, dtype=np.float32)[-1]) / np.float32(n)
+    e_last = np.float32(np.cumsum(a[n - n_last:], dtype=np.float32)[-1]) / np.float32(max(n_last, 1))
+    vad_simple.last_energies = (float(e_all), float(e_last))
+    vad_thold = np.float32(vad_thold)
     # note the host's extra "not both < 1e-4" clause vs upstream vad_simple
     if not (e_all < 0.0001 and e_last < 0.0001) or e_last > vad_thold * e_all:
         return False

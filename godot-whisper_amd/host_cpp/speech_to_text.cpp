@@ -113,7 +113,7 @@ std::vector<Transcription> SpeechToText::transcribe_batch(const std::vector<std:
 
 // ------------------------------------------------------------------------------------------------ VAD
 void high_pass_filter(std::vector<float> & data, float cutoff, float sample_rate) {          // src/speech_to_text.cpp:53-66
-    const float rc = 1.0f / (2.0f * (float) M_PI * cutoff);
+    const float rc = 1.0f / (2.0f * 3.14159265358979323846 * cutoff);      // Math_PI is a double in the reference: double arithmetic, rounded to float
     const float dt = 1.0f / sample_rate;
     const float alpha = dt / (rc + dt);
     float y = data[0];

@@ -37,6 +37,8 @@ DEVICE_API = [
                                     C.POINTER(abi.whisper_token_data)]),
     ("wmi_selftest_proj", C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     ("wmi_bench_kernel", C.c_double, [C.c_void_p, C.c_int, C.c_int]),
+    ("wmi_downmix_stereo", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    ("wmi_vad", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     ("wmi_model_header", C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     ("wmi_arena_ptr", C.c_void_p, [C.c_void_p]),
     ("wmi_weights_bytes", C.c_size_t, [C.c_void_p, C.c_int]),

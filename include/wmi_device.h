@@ -58,6 +58,18 @@ WHISPER_API int wmi_pcm_to_mel_device(struct whisper_context * ctx, const float 
 WHISPER_API int wmi_full_device_pcm(struct whisper_context * ctx, struct whisper_full_params params,
                                     const float * d_samples, int n_samples, const float * h_samples_for_timestamps);
 
+/* Host-adjacent DSP of the streaming node on the device, so that raw capture frames need not be touched by the
+ * CPU.  The 16 kHz resampler between the two (libsamplerate, SRC_SINC_FASTEST) stays with the host: north star "keep".
+ *   wmi_downmix_stereo   interleaved stereo f32 frames [n_frames][2] -> mono (x + y) / 2
+ *                        replaces: _vector2_array_to_float_array, src/speech_to_text.cpp:45-51
+ *   wmi_vad              SpeechToText::voice_activity_detection (src/speech_to_text.cpp:53-104, 378-399) on the last 3 s of
+ *                        `pcm` (16 kHz mono): 1 = no voice activity in the last 500 ms, 0 = activity or fewer than 3 s of audio.
+ *                        energies (optional, 2 floats) receives energy_all, energy_last.
+ * `on_device` != 0: the input (and `mono_out`) are device pointers on the context's device, else host pointers. */
+WHISPER_API int wmi_downmix_stereo(struct whisper_context * ctx, const float * frames, int n_frames, int on_device, float * mono_out);
+WHISPER_API int wmi_vad(struct whisper_context * ctx, const float * pcm, int n_samples, int on_device, float vad_thold, float freq_thold,
+                        float * energies);
+
 /* Several independent chunks on one GPU in lock-step (BASELINE config 4: 8 chunks per GPU).  Every chunk is
  * transcribed as by whisper_full(ctx, params, pcm[c], n_samples[c]) on a freshly initialised context
  * (params.no_context = true, decoder RNGs at their initial seed);

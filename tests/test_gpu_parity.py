@@ -757,3 +757,125 @@ def test_small_multilingual_shape_against_checker(product_lib, checker_lib):
             p = node.full_params("", 578); p.temperature_inc = 0.0
             outs.append(node.transcribe(pcm, params=p)); node.close()
         _assert_same_transcription(outs[0], outs[1], "small", False, ref_last_t1=True)
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE configs[0] shape, batch vs reference, 10-minute stream
+def test_tiny_en_shape_against_checker(product_lib, checker_lib):
+    """BASELINE.json configs[0]'s model shape (tiny.en: 384 wide, 6 heads, 4 + 4 layers) at full size: stages, and the
+    AudioStreamToText call pattern (jfk.wav, host parameters) token for token against the reference."""
+    model = synth.make_model("tiny.en", seed=404); pcm = synth.make_pcm(30.0, seed=404)
+    prod = sc.ProductSide(product_lib, model); chk = make_checker(model, checker_lib)
+    try:
+        mel_r, _ = chk.mel(pcm); mel_p, _ = prod.mel(pcm)
+        assert np.abs(mel_p - mel_r).max() <= TOL["mel"][0]
+        er = chk.encode(0, 0); ep = prod.encode(0, 0)
+        for k in er:
+            st = sc.err_stats(ep[k], er[k])
+            assert st["max_abs"] <= TOL[k][0] and st["rms_rel"] <= TOL[k][1], (k, st)
+        prompt = sot_prompt(chk, prod)
+        lr = chk.decode(prompt, 0); lp = prod.decode(prompt, 0)
+        assert_logits(lp, lr, "prompt")
+        for i in range(6):
+            tok = int(np.argmax(lr[:50256]))
+            lr = chk.decode([tok], len(prompt) + i); lp = prod.decode([tok], len(prompt) + i)
+            assert_logits(lp, lr, f"step{i}")
+        batch = prompt + [1000, 2000, 3000, 4000, 5000, 6000, 7000, 8000, 9000]
+        assert_logits(prod.decode(batch, 0), chk.decode(batch, 0), "batch10")
+    finally:
+        prod.close(); chk.close()
+    if checker_lib is None:
+        return
+    jfk = synth.read_wav_mono16(gu.GOLDEN / "jfk.wav")
+    outs = []
+    for L in (product_lib, checker_lib):
+        node = host.AudioStreamToText(L); node.set_language_model(model)
+        outs.append((node.transcribe(jfk, "", 0), node.get_text(jfk)))
+        node.close()
+    _assert_same_transcription(outs[0][0], outs[1][0], "tiny.en jfk.wav", False, ref_last_t1=True)
+    first = next((i for i, (a, b) in enumerate(zip(gu.tokens_array(outs[0][0])[:, 0], gu.tokens_array(outs[1][0])[:, 0])) if a != b), None)
+    if first is None:
+        assert outs[0][1] == outs[1][1]
+
+
+def test_lockstep_batch_equals_the_compiled_reference(product_lib, checker_lib):
+    """wmi_full_batch against the REFERENCE (not against the product's own one-chunk path): every chunk's token stream is what
+    whisper_full of the compiled reference returns for it on a fresh context."""
+    if checker_lib is None:
+        pytest.skip("needs the compiled reference")
+    model = synth.make_model("micro.en", seed=1234)
+    pcms = [synth.make_pcm(6.0 + 1.5 * i, seed=500 + i) for i in range(5)]
+    node = host.SpeechToText(product_lib); node.set_language_model(model)
+    ref = host.SpeechToText(checker_lib); ref.set_language_model(model)
+    try:
+        for variant in ("host", "default_greedy"):
+            p = gu.param_variants(node)[variant]; p.temperature_inc = 0.0
+            pr = gu.param_variants(ref)[variant]; pr.temperature_inc = 0.0
+            got = node.transcribe_batch(pcms, params=p)
+            assert node.last_ret == 0 and len(got) == len(pcms)
+            for c, b in enumerate(pcms):
+                want = ref.transcribe(b, params=pr)
+                _assert_same_transcription(got[c], want, ("batch vs reference", variant, c, node.last_modes[c]), False, ref_last_t1=True)
+    finally:
+        node.close(); ref.close()
+
+
+def test_ten_minute_stream_small_shape(product_lib, checker_lib):
+    """BASELINE.json configs[2]: CaptureStreamToText over 10 minutes of synthetic microphone audio (2 s on / 1 s off) with the
+    `small` multilingual shape — the whole grown buffer is transcribed again every 0.3 s with audio_ctx = total_s * 50 + 128.
+    At full length: structural properties of every call (the KV cache and ragged encoder lengths are reused ~2000 times); the
+    first calls are compared with the compiled reference; a replay of one late call on a fresh context must reproduce it."""
+    model = synth.make_model("small", seed=77)
+    pcm = synth.make_pcm(600.0, seed=21, gate=True)
+    node = host.CaptureStreamToText(product_lib, transcribe_interval=0.3)
+    node.language = "de"; node.device_vad = True
+    node.set_language_model(model)
+    calls = []
+    try:
+        for fin, text, n_used, actx, toks in node.stream(pcm):
+            calls.append((fin, n_used, actx, gu.tokens_array([b""] + toks)))
+        assert len(calls) >= 1900
+        finals = sum(1 for c in calls if c[0])
+        assert finals >= 30                                                  # a sentence at least every 15 s
+        for fin, n_used, actx, tk in calls:
+            assert actx == min(int(n_used / 16000 * 50 + 128), 1500) and 16000 <= n_used <= 16000 * 15.3 + 1
+            assert tk.shape[0] <= 17 and np.all(tk[:, 0] >= 0) and np.all(tk[:, 0] < 51865)
+            assert np.all(np.isfinite(tk[:, 2])) and np.all((tk[:, 2] >= 0) & (tk[:, 2] <= 1.0 + 1e-6))
+            if tk.shape[0]:
+                assert np.all(np.diff(tk[:, 6]) >= 0) and tk[:, 7].max() <= n_used / 160 + 2      # t0 monotone, t1 inside the buffer (10 ms units)
+        # determinism across the whole run: replaying a late call on a fresh context gives the same tokens
+        fresh = host.SpeechToText(product_lib); fresh.language = "de"; fresh.set_language_model(model)
+        sr = 16000; step = int(round(0.3 * sr))
+        # reconstruct the buffer of the last call from the recorded sentence boundaries
+        start, pos, idx = 0, 0, -1
+        while pos < pcm.size:
+            pos = min(pos + step, pcm.size)
+            if (pos - start) / sr < 1.0:
+                continue
+            idx += 1
+            if idx == len(calls) - 1:
+                break
+            if calls[idx][0]:
+                start = max(pos - int(0.2 * sr), 0)
+        buf = pcm[start:pos]
+        assert buf.size == calls[-1][1]
+        again = gu.tokens_array(fresh.transcribe(buf, "", calls[-1][2]))
+        fresh.close()
+        assert np.array_equal(again[:, 0], calls[-1][3][:, 0])
+    finally:
+        node.close()
+    if checker_lib is None:
+        return
+    # the first calls against the compiled reference (same call pattern, reference library behind the same host mirror)
+    ref = host.CaptureStreamToText(checker_lib, transcribe_interval=0.3); ref.language = "de"; ref.set_language_model(model)
+    try:
+        n_cmp = 0
+        for (fin, text, n_used, actx, toks), mine in zip(ref.stream(pcm[: 16000 * 12], max_calls=12), calls):
+            assert (n_used, actx) == (mine[1], mine[2])
+            w = gu.tokens_array([b""] + toks); g = mine[3]
+            n = min(len(g), len(w)); same = g[:n, 0] == w[:n, 0]
+            first = n if same.all() else int(np.argmin(same))
+            assert first >= min(n, 3), (n_cmp, g[:, 0], w[:, 0])
+            n_cmp += 1
+        assert n_cmp >= 8
+    finally:
+        ref.close()
