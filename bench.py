@@ -79,17 +79,11 @@ def main():
     lib = runtime.require_gpu()
     runtime.silence_logs(lib)
 
-    # ---- model: rank 0 makes the ggml image; everyone else gets it by ONE RCCL broadcast over xGMI
-    model = synth.make_model(args.shape, seed=1234) if rank == 0 else None
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    model_bytes = shard.broadcast_model(model, rank, world, dist, dev)
-    torch.cuda.synchronize()
-    t_bcast = (time.perf_counter() - t0) if world > 1 else 0.0
-    buf = C.create_string_buffer(model_bytes, len(model_bytes))
-    ctx = lib.wmi_init_from_buffer_on_device(C.cast(buf, C.c_void_p), len(model_bytes), local_rank)
+    # ---- model: rank 0 makes the ggml image, parses it and builds the device weight arena; every other rank gets the ~1 MB header
+    # image and then the arena itself by ONE RCCL broadcast over xGMI, straight into its own arena allocation (shard.load_replicated)
+    model_bytes = synth.make_model(args.shape, seed=1234) if (rank == 0 or world == 1) else None
+    ctx, t_bcast = shard.load_replicated(lib, model_bytes, rank, world, dist, local_rank, dev)
     assert ctx, "model load failed"
-    del buf
 
     # ---- inputs: a few distinct seeded chunks per rank, already in HBM
     n_distinct = 8
@@ -217,7 +211,7 @@ def main():
             "decode_ms_per_token": round((t6[2] / 1e3) / dec_calls, 4),
             "mel_ms": round((t6[0] / 1e3) / args.steps, 4),
             "sample_ms_per_step": round((t6[5] / 1e3) / args.steps, 4),
-            "weight_bcast_ms": round(1e3 * t_bcast, 3),
+            "weight_bcast_ms": round(1e3 * t_bcast, 3), "weight_bcast": "one RCCL broadcast of the packed device arena (no re-parse on the other ranks)",
         }
         if dev_pcm:
             out["device_pcm"] = dev_pcm
@@ -233,6 +227,17 @@ def main():
         # chain of dependent kernels; each kind is timed in its own back-to-back chain (which = 20 + WMI_STEP_MASK, no host in
         # the loop), its algorithmic bytes are the weights + cache rows it has to read once.
         try:
+          if args.chunks > 1:
+            # lock-step configuration (configs[3] per-GPU share): the whole decode step of `chunks` rows in its own chain
+            step(0)
+            hp_S = lib.whisper_model_n_audio_state(ctx); T = lib.whisper_model_n_audio_ctx(ctx); NV = lib.whisper_n_vocab(ctx)
+            Lt = lib.whisper_model_n_text_layer(ctx)
+            us_step = lib.wmi_bench_kernel(ctx, 20 + min(args.chunks, 16), 100)
+            step_bytes = (DEC_MB_PER_TOKEN - 18.4) * 1e6 + min(args.chunks, 16) * 18.4e6      # weights once, cross K/V per chunk
+            out["roofline"] = {"kernel": "lock-step decode step (k_rows_mfma projections, per-row attention, filters): %d rows" % min(args.chunks, 16),
+                               "bound": "hbm", "achieved": round(step_bytes / (us_step * 1e-6) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                               "frac": round(step_bytes / (us_step * 1e-6) / 1e9 / 8000.0, 4), "traffic": None, "algorithmic_bytes": int(step_bytes), "avg_us": round(us_step, 2)}
+          else:
             step(0)                                          # the step record / caches of a headline transcription (17 cells)
             hp_S = lib.whisper_model_n_audio_state(ctx); T = lib.whisper_model_n_audio_ctx(ctx); NV = lib.whisper_n_vocab(ctx)
             Lt = lib.whisper_model_n_text_layer(ctx)

@@ -272,6 +272,7 @@ struct whisper_context * wmi_init_host_only(const void * buffer, size_t buffer_s
         if (!parse_model((const uint8_t *) buffer, buffer_size, ctx->model)) { WMI_ERR("%s: failed to load model\n", __func__); delete ctx; return nullptr; }
         ctx->state = new State();
         for (auto & dec : ctx->state->decoders) dec.rng = std::mt19937(0);
+        if (!plan_weights(ctx->model, ctx->w)) { WMI_ERR("%s: failed to load model\n", __func__); delete ctx->state; delete ctx; return nullptr; }
     } catch (const std::exception & e) {
         WMI_ERR("%s: failed to load model (%s)\n", __func__, e.what());
         delete ctx; return nullptr;

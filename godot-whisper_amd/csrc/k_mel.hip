@@ -20,7 +20,7 @@ namespace {
 struct MelTables { float hann[400]; float sinv[400]; float cosv[400]; };
 __constant__ MelTables c_mel;
 
-std::once_flag g_tables_once;
+std::atomic<uint64_t> g_tables_mask{0};        // one bit per device: a __constant__ symbol has an instance on every GPU of the process
 
 void upload_tables() {
     MelTables t;
@@ -326,7 +326,11 @@ void mel_pad(const float * pcm, int n_samples, float * pcm_pad, int n_pad_total,
 
 void mel_frames(const float * pcm_pad, int n_valid, int n_fft_frames, int n_len, int n_mel, const float * filters,
                 const int32_t * ranges, const float * taps, float * mel, int * gmax, hipStream_t st) {
-    std::call_once(g_tables_once, upload_tables);
+    {
+        int dev = 0; (void) hipGetDevice(&dev);
+        const uint64_t bit = 1ull << (dev & 63);
+        if (!(g_tables_mask.load(std::memory_order_acquire) & bit)) { upload_tables(); g_tables_mask.fetch_or(bit, std::memory_order_release); }
+    }
     if (n_fft_frames > 0)
         hipLaunchKernelGGL(k_mel_frames, dim3(n_fft_frames), dim3(MEL_NT), 0, st, pcm_pad, n_valid, n_fft_frames, n_len, n_mel,
                            filters, ranges, taps, mel, gmax);

@@ -495,6 +495,13 @@ bool build(const ModelFile & mf, const uint8_t * buf, Arena & ar, Plan & pl, Wei
 
 } // namespace
 
+bool plan_weights(const ModelFile & mf, Weights & w) {
+    Plan pl; Arena dry;
+    if (!build(mf, nullptr, dry, pl, w)) return false;
+    w.arena_bytes = (dry.size + 255) & ~(size_t) 255;
+    return true;
+}
+
 bool upload_weights(const ModelFile & mf, const uint8_t * host_buf, Weights & w, hipStream_t st) {
     const HParams & hp = mf.hp;
     const int64_t La = hp.n_audio_layer, Lt = hp.n_text_layer;

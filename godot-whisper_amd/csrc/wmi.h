@@ -129,6 +129,8 @@ struct Weights {
 // image and uploaded); host_buf == nullptr (directory-only model): the arena is only allocated and laid out — the same
 // offsets for the same tensor directory — and the caller fills it (one RCCL broadcast of rank 0's arena, wmi_arena_ptr).
 bool upload_weights(const ModelFile & mf, const uint8_t * host_buf, Weights & w, hipStream_t st);
+// layout only (no device): arena_bytes / matrix_bytes / qtype of the arena upload_weights would build
+bool plan_weights(const ModelFile & mf, Weights & w);
 void free_weights(Weights & w);
 
 // ---------------------------------------------------------------- KV cache bookkeeping (host)

@@ -37,6 +37,13 @@ DEVICE_API = [
                                     C.POINTER(abi.whisper_token_data)]),
     ("wmi_selftest_proj", C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     ("wmi_bench_kernel", C.c_double, [C.c_void_p, C.c_int, C.c_int]),
+    ("wmi_pool_init", C.c_void_p, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.c_int]),
+    ("wmi_pool_free", None, [C.c_void_p]),
+    ("wmi_pool_size", C.c_int, [C.c_void_p]),
+    ("wmi_pool_context", C.c_void_p, [C.c_void_p, C.c_int]),
+    ("wmi_pool_full", C.c_int, [C.c_void_p, abi.whisper_full_params, C.POINTER(C.c_void_p), C.POINTER(C.c_int), C.c_int]),
+    ("wmi_pool_select", C.c_void_p, [C.c_void_p, C.c_int]),
+    ("wmi_pool_device_time_us", C.c_int64, [C.c_void_p, C.c_int]),
     ("wmi_downmix_stereo", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     ("wmi_vad", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     ("wmi_model_header", C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),

@@ -58,6 +58,25 @@ WHISPER_API int wmi_pcm_to_mel_device(struct whisper_context * ctx, const float 
 WHISPER_API int wmi_full_device_pcm(struct whisper_context * ctx, struct whisper_full_params params,
                                     const float * d_samples, int n_samples, const float * h_samples_for_timestamps);
 
+/* Several GPUs behind ONE host process (a Godot host is one process).  Ownership as in whisper_full_parallel
+ * (W/whisper.cpp:5837-5913: shared read-only model, one state + one worker thread per piece, results gathered by the caller),
+ * with a GPU per worker: devices[0] parses the file, the others receive the header image and a peer-to-peer copy of the
+ * weight arena (nothing is re-parsed or re-quantised); chunk c -> devices[c mod n]; the chunks of a device advance in lock-step
+ * (wmi_full_batch) on their own host thread; no collective and no cross-device traffic after the load.
+ *   wmi_pool_full     host PCM pointers; returns whisper_full's codes (first failing device wins)
+ *   wmi_pool_select   routes the whisper_full_n_segments / whisper_full_get_* accessors: returns the context that owns the
+ *                     chunk's result, already selected (NULL for a bad index)
+ * A device id may repeat (several contexts on one GPU: used by the tests on a one-GPU box). */
+struct wmi_pool;
+WHISPER_API struct wmi_pool * wmi_pool_init(const void * model, size_t model_size, const int * devices, int n_devices);
+WHISPER_API void wmi_pool_free(struct wmi_pool * pool);
+WHISPER_API int  wmi_pool_size(struct wmi_pool * pool);
+WHISPER_API struct whisper_context * wmi_pool_context(struct wmi_pool * pool, int i);
+WHISPER_API int  wmi_pool_full(struct wmi_pool * pool, struct whisper_full_params params, const float * const * pcm,
+                               const int * n_samples, int n_chunks);
+WHISPER_API struct whisper_context * wmi_pool_select(struct wmi_pool * pool, int chunk);
+WHISPER_API int64_t wmi_pool_device_time_us(struct wmi_pool * pool, int i);
+
 /* Host-adjacent DSP of the streaming node on the device, so that raw capture frames need not be touched by the
  * CPU.  The 16 kHz resampler between the two (libsamplerate, SRC_SINC_FASTEST) stays with the host: north star "keep".
  *   wmi_downmix_stereo   interleaved stereo f32 frames [n_frames][2] -> mono (x + y) / 2

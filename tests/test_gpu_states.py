@@ -245,3 +245,35 @@ def test_print_realtime_output_equals_the_reference(product_lib, capfd):
             a, b = outs[k].splitlines(), outs[k + 1].splitlines()
             assert a[0] == b[0]
     assert outs[0].startswith("[00:00:0")
+
+
+def test_in_process_device_pool_equals_one_context(product_lib):
+    """wmi_pool_*: several GPUs behind one host process — here two contexts on the one GPU of the test box.  The second
+    context is built from the header image + a device copy of the first one's weight arena (no re-parse); chunks go to
+    context c mod 2 and must come back exactly as one context transcribes them."""
+    model = synth.make_model("micro.en", seed=1234)
+    pcms = [synth.make_pcm(5.0 + i, seed=900 + i) for i in range(5)]
+    buf = C.create_string_buffer(model, len(model))
+    devs = (C.c_int * 2)(0, 0)
+    pool = product_lib.wmi_pool_init(C.cast(buf, C.c_void_p), len(model), devs, 2)
+    assert pool and product_lib.wmi_pool_size(pool) == 2
+    one = host.SpeechToText(product_lib); one.set_language_model(model)
+    try:
+        c0, c1 = product_lib.wmi_pool_context(pool, 0), product_lib.wmi_pool_context(pool, 1)
+        assert product_lib.wmi_weights_bytes(c0, 0) == product_lib.wmi_weights_bytes(c1, 0) > 0
+        assert product_lib.wmi_arena_ptr(c0) != product_lib.wmi_arena_ptr(c1)
+        p = one.full_params("", 0); p.temperature_inc = 0.0
+        ptrs = (C.c_void_p * len(pcms))(*[b.ctypes.data for b in pcms]); lens = (C.c_int * len(pcms))(*[b.size for b in pcms])
+        assert product_lib.wmi_pool_full(pool, p, ptrs, lens, len(pcms)) == 0
+        want = one.transcribe_batch(pcms, params=p)
+        for c in range(len(pcms)):
+            ctx = product_lib.wmi_pool_select(pool, c)
+            assert ctx == (c0 if c % 2 == 0 else c1)
+            node = host.SpeechToText(product_lib); node.ctx = ctx
+            got = node.collect(); node.ctx = None
+            g, w = gu.tokens_array(got), gu.tokens_array(want[c])
+            assert g.shape == w.shape and np.array_equal(g[:, [0, 1, 6, 7]], w[:, [0, 1, 6, 7]]) and bytes(got[0]) == bytes(want[c][0]), c
+        assert product_lib.wmi_pool_select(pool, len(pcms)) is None
+        assert product_lib.wmi_pool_device_time_us(pool, 0) > 0
+    finally:
+        one.close(); product_lib.wmi_pool_free(pool)

@@ -98,3 +98,36 @@ def test_quantiser_is_byte_identical_to_the_reference_tool(qtype, tmp_path):
     r = subprocess.run([str(tool), str(tmp_path / "m.bin"), str(tmp_path / "o.bin"), qtype], capture_output=True)
     assert r.returncode == 0
     assert (tmp_path / "o.bin").read_bytes() == synth.quantize_model(mb, qtype)
+
+
+@pytest.mark.parametrize("qtype", [None, "q5_1"])
+def test_header_image_reproduces_the_arena_layout(qtype):
+    """Multi-GPU load: the other ranks get a payload-less header image and the packed device arena.  Without a
+    GPU: the image parses to the same model (hyper-parameters, vocabulary, special tokens) and yields the same arena plan —
+    byte sizes of the arena and of its matrices, quantisation kind — as the full file, so rank 0's arena fits every rank's."""
+    import ctypes as C
+    from godot_whisper_amd import runtime
+    lib = runtime.load_library(); runtime.silence_logs(lib)
+    model = synth.make_model("micro", seed=9)
+    if qtype:
+        model = synth.quantize_model(model, qtype)
+    buf = C.create_string_buffer(model, len(model))
+    n = lib.wmi_model_header(C.cast(buf, C.c_void_p), len(model), None, 0)
+    assert 0 < n < len(model) // 4
+    hdr = C.create_string_buffer(n)
+    assert lib.wmi_model_header(C.cast(buf, C.c_void_p), len(model), C.cast(hdr, C.c_void_p), n) == n
+    full = lib.wmi_init_host_only(C.cast(buf, C.c_void_p), len(model))
+    img = lib.wmi_init_host_only(C.cast(hdr, C.c_void_p), n)
+    assert full and img
+    try:
+        for which in (0, 1, 2):
+            assert lib.wmi_weights_bytes(full, which) == lib.wmi_weights_bytes(img, which) and (which == 2 or lib.wmi_weights_bytes(full, which) > 0)
+        assert lib.wmi_weights_bytes(full, 2) == (7 if qtype else 0)
+        for fn in ("whisper_n_vocab", "whisper_n_audio_ctx", "whisper_model_n_text_layer", "whisper_token_eot", "whisper_token_beg", "whisper_is_multilingual", "whisper_model_ftype"):
+            assert getattr(lib, fn)(full) == getattr(lib, fn)(img), fn
+        assert lib.whisper_token_to_str(full, 1234) == lib.whisper_token_to_str(img, 1234)
+        # an image is not a model: truncated or re-exported images are rejected
+        assert lib.wmi_model_header(C.cast(hdr, C.c_void_p), n, None, 0) == 0
+        assert not lib.wmi_init_host_only(C.cast(hdr, C.c_void_p), n - 5)
+    finally:
+        lib.whisper_free(full); lib.whisper_free(img)
