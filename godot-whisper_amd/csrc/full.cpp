@@ -270,7 +270,20 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
                 const int64_t ts = time_us();
                 if (beam) for (auto & bc : bc_per_dec) bc.clear();
 
-                // sample (each decoder owns its RNG, so the result does not depend on threading)
+                // sample (each decoder owns its RNG, so the result does not depend on threading): the beams of a step draw on the
+                // host worker pool — a 51 866-entry CDF per decoder is ~0.15 ms of one core, five of them in a row were a third of a
+                // large-v3 beam step
+                std::vector<std::vector<whisper_token_data>> drawn;
+                if (beam && n_cur > 1) {
+                    drawn.resize(n_cur);
+                    int n_live = 0;
+                    for (int j = 0; j < n_cur; ++j) if (!st.decoders[j].completed && !st.decoders[j].failed) ++n_live;
+                    pool_run(n_cur, [&](int j) {
+                        Decoder & d = st.decoders[j];
+                        if (!d.completed && !d.failed) drawn[j] = sample_token_topk(ctx, d, params.beam_search.beam_size, false);
+                    });
+                    st.n_sample += n_live;
+                }
                 for (int j = 0; j < n_cur; ++j) {
                     Decoder & d = st.decoders[j];
                     if (d.completed || d.failed) continue;
@@ -281,7 +294,7 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
                         d.sequence.tokens.push_back(sample_token(ctx, d, t_cur < 1e-6f));
                         d.sequence.sum_logprobs_all += d.sequence.tokens.back().plog;
                     } else {
-                        for (const auto & tok : sample_token_topk(ctx, d, params.beam_search.beam_size)) {
+                        for (const auto & tok : (drawn.empty() ? sample_token_topk(ctx, d, params.beam_search.beam_size) : drawn[j])) {
                             bc_per_dec[j].push_back({ j, d.seek_delta, d.has_ts, d.sequence, d.grammar });
                             bc_per_dec[j].back().sequence.tokens.push_back(tok);
                             bc_per_dec[j].back().sequence.sum_logprobs_all += tok.plog;
@@ -371,6 +384,13 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
                     return -8;
                 }
                 const int64_t ts2 = time_us();
+                if (n_cur > 1 && !params.logits_filter_callback && !params.grammar_rules) {
+                    // the decoders' filter + log-soft-max passes are independent (own logits row, own arrays): one pool task each
+                    pool_run(n_cur, [&](int j) {
+                        Decoder & d = st.decoders[j];
+                        if (!d.failed && !d.completed) process_logits(ctx, d, params, t_cur);
+                    });
+                } else
                 for (int j = 0; j < n_cur; ++j) {
                     Decoder & d = st.decoders[j];
                     if (d.failed || d.completed) continue;

@@ -274,7 +274,7 @@ whisper_token_data sample_token(whisper_context & ctx, Decoder & dec, bool best)
     return r;
 }
 
-std::vector<whisper_token_data> sample_token_topk(whisper_context & ctx, Decoder & dec, int k) {
+std::vector<whisper_token_data> sample_token_topk(whisper_context & ctx, Decoder & dec, int k, bool count) {
     // v1.5.4 "top-k" = k independent draws from the full distribution; the partial sort
     // the reference performs first has no effect on the result and is not reproduced.
     const Vocab & v = ctx.model.vocab;
@@ -289,7 +289,7 @@ std::vector<whisper_token_data> sample_token_topk(whisper_context & ctx, Decoder
         if (t.id >= v.beg) { t.tid = t.id; t.pt = t.p; }
         out.push_back(t);
     }
-    ctx.state->n_sample++;
+    if (count) ctx.state->n_sample++;
     return out;
 }
 

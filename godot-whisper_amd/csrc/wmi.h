@@ -323,7 +323,7 @@ bool signal_energy_wait(State & st);
 // host logic (logits filters, sampling, driver)
 void process_logits(whisper_context & ctx, Decoder & dec, const whisper_full_params & params, float temperature);
 whisper_token_data sample_token(whisper_context & ctx, Decoder & dec, bool best);
-std::vector<whisper_token_data> sample_token_topk(whisper_context & ctx, Decoder & dec, int k);
+std::vector<whisper_token_data> sample_token_topk(whisper_context & ctx, Decoder & dec, int k, bool count = true);   // count = false: the caller adds to n_sample (parallel decoders)
 void sequence_score(const whisper_full_params & params, Sequence & seq);
 Grammar grammar_init(const whisper_grammar_element ** rules, size_t n_rules, size_t i_start_rule);
 void grammar_penalise(const whisper_context & ctx, const Grammar & g, float penalty, std::vector<float> & logits);

@@ -879,3 +879,110 @@ def test_ten_minute_stream_small_shape(product_lib, checker_lib):
         assert n_cmp >= 8
     finally:
         ref.close()
+
+
+# ------------------------------------------------------------------------------------------------ the beam-search driver, pinned
+def _synthetic_logits_callback(n_vocab, eot, beg, record=None):
+    """A logits_filter_callback that REPLACES the model's logits by a deterministic function of the decoder's token history:
+    both libraries then sample from identical distributions, whatever their own numerics — what remains is the driver
+    (mt19937 + discrete_distribution draws, candidate ranking, KV sequence bookkeeping, completion rules, scoring)."""
+    def cb(ctx, state, tokens, n_tokens, logits, user):
+        hist = [tokens[i].id for i in range(n_tokens)]
+        seed = (1469598103934665603 ^ len(hist)) & 0xFFFFFFFF
+        for t in hist:
+            seed = ((seed ^ (t + 1)) * 16777619) & 0xFFFFFFFF
+        rng = np.random.default_rng(seed)
+        arr = np.ctypeslib.as_array(logits, shape=(n_vocab,))
+        keep = np.isneginf(arr)                                            # rules applied before the callback stay
+        new = rng.standard_normal(n_vocab).astype(np.float32) * 1.5
+        hot = rng.integers(0, 50000, size=6)
+        new[hot] += np.float32(7.0) + rng.standard_normal(6).astype(np.float32)
+        new[beg:] = np.float32(-14.0) + new[beg:] * np.float32(0.2)       # the 1500 timestamp ids: little mass ...
+        new[beg + 2 * (len(hist) + 1): beg + 2 * (len(hist) + 1) + 3] = np.float32(5.0) + rng.standard_normal(3).astype(np.float32)   # ... except a few plausible ones moving forward
+        if len(hist) > 9:
+            new[eot] += np.float32(8.0)
+        new[keep] = -np.inf
+        arr[:] = new
+        if record is not None:
+            record.append(tuple(hist))
+    return abi.whisper_logits_filter_callback(cb)
+
+
+@pytest.mark.parametrize("variant", ["beam5", "beam3_multi_window", "best_of_t04"])
+def test_beam_driver_reproduces_the_reference_stream_on_equal_logits(product_lib, checker_lib, variant):
+    """beam-mode parity = "identical token stream when fed the oracle's logits".  Both libraries get the same
+    synthetic logits through logits_filter_callback; the complete results — ids, probabilities, log-probabilities,
+    timestamps statistics, segment boundaries, text — must then be IDENTICAL, for every window."""
+    if checker_lib is None:
+        pytest.skip("needs the compiled reference")
+    model = synth.make_model("micro.en", seed=1234)
+    pcm = synth.make_pcm(21.0 if variant == "beam3_multi_window" else 9.0, seed=55)
+    outs = []
+    for L in (product_lib, checker_lib):
+        node = host.SpeechToText(L); node.set_language_model(model)
+        nv, eot, beg = L.whisper_n_vocab(node.ctx), L.whisper_token_eot(node.ctx), L.whisper_token_beg(node.ctx)
+        cb = _synthetic_logits_callback(nv, eot, beg)
+        if variant == "best_of_t04":
+            p = node.full_params("", 0); p.temperature = 0.4; p.temperature_inc = 0.0; p.greedy.best_of = 4; p.max_tokens = 24
+        else:
+            p = L.whisper_full_default_params(abi.WHISPER_SAMPLING_BEAM_SEARCH)
+            p.language = b"en"; p.temperature_inc = 0.0
+            p.beam_search.beam_size = 5 if variant == "beam5" else 3
+            if variant == "beam5":
+                p.single_segment = True; p.max_tokens = 20
+        p.logits_filter_callback = C.cast(cb, C.c_void_p)
+        ret = L.whisper_full(node.ctx, p, pcm.ctypes.data_as(C.POINTER(C.c_float)), pcm.size)
+        assert ret == 0
+        segs = []
+        for s in range(L.whisper_full_n_segments(node.ctx)):
+            toks = [L.whisper_full_get_token_data(node.ctx, s, j) for j in range(L.whisper_full_n_tokens(node.ctx, s))]
+            segs.append((L.whisper_full_get_segment_t0(node.ctx, s), L.whisper_full_get_segment_t1(node.ctx, s),
+                         L.whisper_full_get_segment_text(node.ctx, s),
+                         [(t.id, t.tid, t.p, t.plog, t.pt, t.ptsum) for t in toks]))
+        outs.append(segs)
+        node.close()
+    got, want = outs
+    assert len(want) >= 1 and sum(len(s[3]) for s in want) >= 8
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g[:3] == w[:3]
+        assert [t[:2] for t in g[3]] == [t[:2] for t in w[3]]
+        assert np.allclose(np.array([t[2:] for t in g[3]]), np.array([t[2:] for t in w[3]]), rtol=0, atol=1e-6)
+
+
+def test_beam_kv_bookkeeping_gives_each_beam_its_own_history(product_lib):
+    """The beams of a step share physical KV cells through sequence-id sets (kv_seq_cp / kv_seq_rm, W/whisper.cpp:1038-1054,
+    5402-5417); the mask built from them must give every beam exactly its own history.  Check: the logits the beam step
+    produced for a recorded history equal the logits of decoding that history alone on a fresh cache."""
+    model = synth.make_model("micro.en", seed=1234)
+    pcm = synth.make_pcm(9.0, seed=56)
+    node = host.SpeechToText(product_lib); node.set_language_model(model)
+    nv = product_lib.whisper_n_vocab(node.ctx)
+    beg_id, eot_id = product_lib.whisper_token_beg(node.ctx), product_lib.whisper_token_eot(node.ctx)
+    seen = {}
+    def cb(ctx, state, tokens, n_tokens, logits, user):
+        hist = tuple(tokens[i].id for i in range(n_tokens))
+        a = np.ctypeslib.as_array(logits, shape=(nv,))
+        if 2 <= len(hist) <= 7 and hist not in seen:
+            seen[hist] = a.copy()
+        a *= np.float32(0.02)                      # flatten what the sampler sees: the draws of the beams diverge ...
+        a[beg_id:] = -np.inf; a[eot_id] = -np.inf   # ... and keep them running (no timestamps, no end of text)
+    cbk = abi.whisper_logits_filter_callback(cb)
+    try:
+        p = product_lib.whisper_full_default_params(abi.WHISPER_SAMPLING_BEAM_SEARCH)
+        p.language = b"en"; p.temperature_inc = 0.0; p.beam_search.beam_size = 5; p.single_segment = True; p.max_tokens = 10
+        p.logits_filter_callback = C.cast(cbk, C.c_void_p)
+        assert product_lib.whisper_full(node.ctx, p, pcm.ctypes.data_as(C.POINTER(C.c_float)), pcm.size) == 0
+        assert len(seen) >= 10 and len({h[:2] for h in seen}) >= 2            # beams did diverge
+        sot = product_lib.whisper_token_sot(node.ctx)
+        checked = 0
+        for hist, lg in list(seen.items())[:24]:
+            seq = np.asarray([sot] + list(hist), np.int32)
+            assert product_lib.whisper_decode(node.ctx, seq.ctypes.data_as(C.POINTER(C.c_int32)), seq.size, 0, 4) == 0
+            lp = np.ctypeslib.as_array(product_lib.whisper_get_logits(node.ctx), shape=(seq.size * nv,)).reshape(seq.size, nv)[-1]
+            ok = ~np.isneginf(lg)                                               # entries the filters had not yet suppressed
+            assert np.abs(lp[ok] - lg[ok]).max() <= 2e-2, hist                  # batch-of-n vs one-row kernels: f32 summation order
+            checked += 1
+        assert checked >= 10
+    finally:
+        node.close()
