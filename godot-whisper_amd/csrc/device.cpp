@@ -116,6 +116,9 @@ void destroy_state(State * st) {
     if (d.step_dev) (void) hipFree(d.step_dev);
     if (d.sample_dev) (void) hipFree(d.sample_dev);
     if (d.filter_scratch) (void) hipFree(d.filter_scratch);
+    if (d.draw_dev) (void) hipFree(d.draw_dev);
+    if (d.draw_scratch) (void) hipFree(d.draw_scratch);
+    if (d.draw_host) (void) hipHostFree(d.draw_host);
     if (d.step_host) (void) hipHostFree(d.step_host);
     if (d.sample_host) (void) hipHostFree(d.sample_host);
     if (d.pinned) (void) hipHostFree(d.pinned);
@@ -388,6 +391,7 @@ bool decode(whisper_context & ctx, const Batch & batch) {
         g.x32 = d.dx; g.ln_g = w.d_ln_g; g.ln_b = w.d_ln_b; g.eps = hp.eps; g.n = nr; g.K = S; g.N = NV; g.W = w.d_te;
         g.epi = k::EPI_LOGITS; g.C = d.logits; g.ldc = NV; g.rows = d.d_rows + r0;
         k::gemv(g, s);
+        if (d.keep_logits_on_device && rows.size() <= 8) continue;        // sample_rows_device() reads them where they are
         HIP_TRY(hipMemcpyAsync(d.pinned, d.logits, (size_t) nr * NV * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         for (int r = 0; r < nr; ++r)
@@ -460,6 +464,49 @@ bool wait_for_seq(const volatile int32_t * seq, int32_t want, hipStream_t s) {
     }
     if (!HIP_OK(hipStreamSynchronize(s))) return false;
     return *seq == want;
+}
+
+// Draws on the device ("argmax / top-k on GPU so only ~k numbers cross PCIe per step").  The logits rows of the
+// last decode() stay in d.logits; per row the filters of process_logits (same rules as the greedy step), p = exp(l - lse) and the
+// CDF search run in k_sample.hip; the mt19937 generators stay on the host and supply the uniform numbers.
+bool sample_rows_device(whisper_context & ctx, const StepFilter * f, const int * rows, int n_rows, float temperature, int k,
+                        const double * u, int tid_default, whisper_token_data * out) {
+    State & st = *ctx.state; DeviceState & d = st.dev; const Vocab & v = ctx.model.vocab;
+    if (n_rows < 1 || n_rows > 8 || k < 1 || k > 8) return false;
+    const int64_t t0 = time_us();
+    constexpr size_t OFF_U = 8 * sizeof(k::DecStep), OFF_OUT = OFF_U + 64 * sizeof(double), TOTAL = OFF_OUT + 64 * sizeof(k::SampleOut);
+    if (!d.draw_dev) {
+        if (!HIP_OK(hipMalloc(&d.draw_dev, TOTAL)) || !HIP_OK(hipHostMalloc(&d.draw_host, TOTAL, hipHostMallocDefault)) ||
+            !HIP_OK(hipMalloc(&d.draw_scratch, k::filter_draw_scratch_bytes(8)))) return false;
+    }
+    hipStream_t s = d.stream;
+    const int NV = v.n_vocab;
+    int space_id = -1; { auto sp = v.token_to_id.find(" "); if (sp != v.token_to_id.end()) space_id = sp->second; }
+    k::DecStep * hs = (k::DecStep *) d.draw_host; double * hu = (double *) ((char *) d.draw_host + OFF_U);
+    for (int r = 0; r < n_rows; ++r) {
+        memset(&hs[r], 0, sizeof(k::DecStep));
+        hs[r].flags = (f[r].ban_blank ? 1 : 0) | (f[r].last_ts ? 2 : 0) | (f[r].penult_ts ? 4 : 0);
+        hs[r].space_id = space_id; hs[r].eot = v.eot; hs[r].beg = v.beg; hs[r].n_vocab = NV;
+        hs[r].ts_floor_end = f[r].ts_floor_end; hs[r].ts_initial_start = f[r].ts_initial_start;
+        hs[r].temperature = temperature > 0.0f ? temperature : 0.0f;
+        for (int c = 0; c < k; ++c) hu[r * k + c] = u[r * k + c];
+    }
+    HIP_TRY(hipMemcpyAsync(d.draw_dev, d.draw_host, OFF_OUT, hipMemcpyHostToDevice, s));
+    const k::DecStep * ds = (const k::DecStep *) d.draw_dev; const double * du = (const double *) ((char *) d.draw_dev + OFF_U);
+    k::SampleOut * dout = (k::SampleOut *) ((char *) d.draw_dev + OFF_OUT);
+    // rows that sit next to each other in d.logits go in one launch; the first step of a window draws every decoder from row 0
+    bool contiguous = true;
+    for (int r = 0; r < n_rows; ++r) contiguous = contiguous && rows[r] == rows[0] + r;
+    if (contiguous) k::filter_draw(d.logits + (size_t) rows[0] * NV, d.ban_dev, ds, du, k, dout, d.draw_scratch, s, n_rows, tid_default);
+    else for (int r = 0; r < n_rows; ++r)
+        k::filter_draw(d.logits + (size_t) rows[r] * NV, d.ban_dev, ds + r, du + r * k, k, dout + r * k, d.draw_scratch, s, 1, tid_default);
+    k::SampleOut * hout = (k::SampleOut *) ((char *) d.draw_host + OFF_OUT);
+    HIP_TRY(hipMemcpyAsync(hout, dout, (size_t) n_rows * k * sizeof(k::SampleOut), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (int i = 0; i < n_rows * k; ++i)
+        out[i] = whisper_token_data{ hout[i].id, hout[i].tid, hout[i].p, hout[i].plog, hout[i].pt, hout[i].ptsum, -1, -1, 0.0f };
+    st.t_sample_us += time_us() - t0; st.n_sample += n_rows;
+    return true;
 }
 
 // the kernels of one greedy step; every per-step quantity is read from DecStep on the device, so the same launch

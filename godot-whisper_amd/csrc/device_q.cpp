@@ -138,6 +138,7 @@ bool decode_layers_q(whisper_context & ctx, int n, int n_kv, int kv_head, int Tc
         g.x32 = d.dx; g.ln_g = w.d_ln_g; g.ln_b = w.d_ln_b; g.eps = hp.eps; g.n = nr; g.K = S; g.N = NV;
         g.epi = k::EPI_LOGITS; g.C = d.logits; g.ldc = NV; g.rows = d.d_rows + r0;
         k::qrows(g, nullptr, w.q_te, s);
+        if (d.keep_logits_on_device && rows.size() <= 8) continue;
         HIP_TRY(hipMemcpyAsync(d.pinned, d.logits, (size_t) nr * NV * 4, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
         for (int r = 0; r < nr; ++r)

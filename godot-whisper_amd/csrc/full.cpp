@@ -213,6 +213,15 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
             const bool fast = fast_path_enabled() && !beam && t_cur < 1e-6f && n_cur == 1 && !params.logits_filter_callback && !params.grammar_rules &&
                               params.n_grammar_rules == 0 &&
                               ctx.model.n_loaded > 0 && upload_static_ban(ctx, params);
+            // Beam search and t > 0 (whisper_sample_token_topk / whisper_sample_token(best = false)): the filters, the soft-max and the
+            // CDF search of the draws run on the device as well (device.cpp: sample_rows_device) — the decoders' mt19937 generators stay
+            // here and supply the uniform numbers.  User callbacks and grammars need the host arrays and keep the host path.
+            const bool no_dev_draw = getenv("WMI_HOST_DRAWS") != nullptr;             // debug / A-B and the tests (read per window)
+            const bool dev_draw = !fast && !no_dev_draw && fast_path_enabled() && (beam || t_cur > 0.0f) && n_cur <= MAX_DECODERS &&
+                                  !params.logits_filter_callback && !params.grammar_rules && params.n_grammar_rules == 0 &&
+                                  ctx.model.n_loaded > 0 && upload_static_ban(ctx, params);
+            st.dev.keep_logits_on_device = dev_draw;
+            struct KeepOff { bool & f; ~KeepOff() { f = false; } } keep_off{st.dev.keep_logits_on_device};
             whisper_token_data fast_next{};      // token picked on the device for the upcoming sampling step
             auto step_filter = [&](const Decoder & d) {
                 const auto & h = d.sequence.tokens;
@@ -255,12 +264,13 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
             {
                 const int64_t ts = time_us();
                 st.decoders[0].i_batch = (int) prompt.size() - 1;
-                process_logits(ctx, st.decoders[0], params, t_cur);
+                if (!dev_draw) process_logits(ctx, st.decoders[0], params, t_cur);
                 for (int j = 1; j < n_cur; ++j) {
                     Decoder & d = st.decoders[j];
                     kv_seq_cp(st.kv_self, 0, j, -1, -1);
-                    d.probs = st.decoders[0].probs; d.logits = st.decoders[0].logits; d.logprobs = st.decoders[0].logprobs;
+                    if (!dev_draw) { d.probs = st.decoders[0].probs; d.logits = st.decoders[0].logits; d.logprobs = st.decoders[0].logprobs; }
                 }
+                for (int j = 0; j < n_cur; ++j) st.decoders[j].i_batch = 0;      // device draws: every decoder reads logits row 0 first
                 st.t_sample_us += time_us() - ts;
             }
             }
@@ -274,6 +284,27 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
                 // host worker pool — a 51 866-entry CDF per decoder is ~0.15 ms of one core, five of them in a row were a third of a
                 // large-v3 beam step
                 std::vector<std::vector<whisper_token_data>> drawn;
+                if (dev_draw) {
+                    // uniform numbers exactly as std::discrete_distribution would take them from each decoder's generator
+                    const int k = beam ? params.beam_search.beam_size : 1;
+                    StepFilter fl[MAX_DECODERS]; int rows_[MAX_DECODERS], live[MAX_DECODERS]; double u[MAX_DECODERS * MAX_DECODERS];
+                    int nl = 0;
+                    for (int j = 0; j < n_cur; ++j) {
+                        Decoder & d = st.decoders[j];
+                        if (d.completed || d.failed) continue;
+                        fl[nl] = step_filter(d); rows_[nl] = i == 0 ? 0 : d.i_batch; live[nl] = j;
+                        for (int c = 0; c < std::min(k, (int) MAX_DECODERS); ++c) u[nl * std::min(k, (int) MAX_DECODERS) + c] = std::generate_canonical<double, 53>(d.rng);
+                        ++nl;
+                    }
+                    const int kk = std::min(k, (int) MAX_DECODERS);
+                    std::vector<whisper_token_data> res((size_t) nl * kk);
+                    if (nl > 0 && !sample_rows_device(ctx, fl, rows_, nl, t_cur, kk, u, beam ? v.beg : 0, res.data())) {
+                        WMI_ERR("%s: device sampling failed\n", __func__);
+                        return -8;
+                    }
+                    drawn.resize(n_cur);
+                    for (int r = 0; r < nl; ++r) drawn[live[r]].assign(res.begin() + (size_t) r * kk, res.begin() + (size_t) (r + 1) * kk);
+                } else
                 if (beam && n_cur > 1) {
                     drawn.resize(n_cur);
                     int n_live = 0;
@@ -291,7 +322,7 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
                         d.sequence.tokens.push_back(fast_next);
                         d.sequence.sum_logprobs_all += fast_next.plog;
                     } else if (!beam) {
-                        d.sequence.tokens.push_back(sample_token(ctx, d, t_cur < 1e-6f));
+                        d.sequence.tokens.push_back(dev_draw ? drawn[j][0] : sample_token(ctx, d, t_cur < 1e-6f));
                         d.sequence.sum_logprobs_all += d.sequence.tokens.back().plog;
                     } else {
                         for (const auto & tok : (drawn.empty() ? sample_token_topk(ctx, d, params.beam_search.beam_size) : drawn[j])) {
@@ -384,7 +415,8 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
                     return -8;
                 }
                 const int64_t ts2 = time_us();
-                if (n_cur > 1 && !params.logits_filter_callback && !params.grammar_rules) {
+                if (dev_draw) { /* the logits stay on the device: filters and draws happen in sample_rows_device next iteration */ }
+                else if (n_cur > 1 && !params.logits_filter_callback && !params.grammar_rules) {
                     // the decoders' filter + log-soft-max passes are independent (own logits row, own arrays): one pool task each
                     pool_run(n_cur, [&](int j) {
                         Decoder & d = st.decoders[j];

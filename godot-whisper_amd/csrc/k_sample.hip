@@ -67,7 +67,7 @@ __global__ __launch_bounds__(NT) void k_filter_stats(const float * __restrict__ 
             if (i >= st.ts_initial_start) a = false;
             if (i >= beg && i < st.ts_floor_end) a = false;
             if (a) {
-                ok[e] = true; lv[e] = lraw[e];
+                ok[e] = true; lv[e] = st.temperature > 0.0f ? lraw[e] / st.temperature : lraw[e];
                 const MaxIdx c = {lv[e], i};
                 m_all = better(m_all, c);
                 if (i < beg) m_txt = better(m_txt, c); else m_ts = better(m_ts, c);
@@ -144,7 +144,119 @@ __global__ __launch_bounds__(64) void k_filter_pick(const Partial * __restrict__
     }
 }
 
+// ---- draws (beam search / t > 0).  Same filter predicate as k_filter_stats.
+__device__ __forceinline__ bool allowed(const DecStep & st, unsigned char bn, int i) {
+    const bool ban_blank = st.flags & 1, last_ts = st.flags & 2, pen_ts = st.flags & 4;
+    bool a = !bn;
+    if (ban_blank && (i == st.eot || i == st.space_id)) a = false;
+    if (last_ts) { if (pen_ts) { if (i >= st.beg) a = false; } else { if (i < st.eot) a = false; } }
+    if (i >= st.ts_initial_start) a = false;
+    if (i >= st.beg && i < st.ts_floor_end) a = false;
+    return a;
+}
+struct RowStats { float M, lse; int force_ts; MaxIdx ts; float sum_ts; };
+// the 64 partials of a row -> global max, log-sum-exp, "timestamp mass beats every text token" (all lanes get the result)
+__device__ __forceinline__ RowStats row_stats(const Partial * part, int lane) {
+    const Partial p = part[lane];
+    const MaxIdx a = wave_max(p.all), t = wave_max(p.txt), z = wave_max(p.ts);
+    const float M = a.v;
+    const float w = p.all.v > -INFINITY ? expf(p.all.v - M) : 0.0f;
+    const float sum = wave_sum(p.sum * w), sum_ts = wave_sum(p.sum_ts * w);
+    RowStats r;
+    r.M = M; r.lse = logf(sum) + M;
+    const float ts_logprob = sum_ts > 0.0f ? logf(sum_ts) + M - r.lse : -INFINITY;
+    const float max_text = t.v > -INFINITY ? t.v - r.lse : -INFINITY;
+    r.force_ts = ts_logprob > max_text ? 1 : 0;
+    r.ts = z; r.sum_ts = sum_ts;
+    return r;
+}
+__device__ __forceinline__ float prob_of(const DecStep & st, const RowStats & rs, float lraw, unsigned char bn, int i) {
+    if (!allowed(st, bn, i) || (rs.force_ts && i < st.beg)) return 0.0f;
+    const float l = st.temperature > 0.0f ? lraw / st.temperature : lraw;
+    return expf(l - rs.lse);
+}
+// block sums of the probabilities in double: grid (NB, rows); block b covers the same index range as in k_filter_stats
+__global__ __launch_bounds__(NT) void k_prob_blocks(const float * __restrict__ logits, const uint8_t * __restrict__ ban,
+                                                    const DecStep * __restrict__ stp, const Partial * __restrict__ part,
+                                                    double * __restrict__ bsum) {
+    __shared__ double s_w[4];
+    const DecStep st = stp[blockIdx.y];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int NV = st.n_vocab;
+    logits += (size_t) blockIdx.y * NV;
+    const RowStats rs = row_stats(part + (size_t) blockIdx.y * NB, lane);
+    const int per = (NV + NB - 1) / NB, i0 = blockIdx.x * per, i1 = min(NV, i0 + per);
+    double acc = 0.0;
+    for (int i = i0 + tid; i < i1; i += NT) acc += (double) prob_of(st, rs, logits[i], ban[i], i);
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    if (lane == 0) s_w[wave] = acc;
+    __syncthreads();
+    if (tid == 0) bsum[(size_t) blockIdx.y * NB + blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
+}
+// one wavefront per (draw, row): block by prefix of the 64 block sums, then the element inside the block
+__global__ __launch_bounds__(64) void k_draw(const float * __restrict__ logits, const uint8_t * __restrict__ ban,
+                                             const DecStep * __restrict__ stp, const Partial * __restrict__ part,
+                                             const double * __restrict__ bsum, const double * __restrict__ u, int k,
+                                             int tid_default, SampleOut * __restrict__ out) {
+    const int lane = threadIdx.x, dr = blockIdx.x, row = blockIdx.y;
+    const DecStep st = stp[row];
+    const int NV = st.n_vocab;
+    logits += (size_t) row * NV;
+    const RowStats rs = row_stats(part + (size_t) row * NB, lane);
+    // inclusive prefix of the block sums over the lanes
+    const double mine = bsum[(size_t) row * NB + lane];
+    double pre = mine;
+    for (int o = 1; o < 64; o <<= 1) { const double t = __shfl_up(pre, o); if (lane >= o) pre += t; }
+    const double total = __shfl(pre, 63);
+    const double target = u[(size_t) row * k + dr] * total;
+    // first block whose inclusive prefix reaches the target (the last non-empty one if rounding left the target above the total)
+    const unsigned long long hit = __ballot(pre >= target && mine > 0.0);
+    const unsigned long long nz = __ballot(mine > 0.0);
+    int b = hit ? __ffsll((long long) hit) - 1 : (nz ? 63 - __clzll((long long) nz) : 0);
+    const double before = __shfl(pre, b) - __shfl(mine, b);
+    const int per = (NV + NB - 1) / NB, i0 = b * per, i1 = min(NV, i0 + per);
+    // inside the block: lane L owns a contiguous run of elements
+    const int run = (per + 63) / 64, j0 = i0 + lane * run, j1 = min(i1, j0 + run);
+    double loc = 0.0;
+    for (int i = j0; i < j1; ++i) loc += (double) prob_of(st, rs, logits[i], ban[i], i);
+    double lpre = loc;
+    for (int o = 1; o < 64; o <<= 1) { const double t = __shfl_up(lpre, o); if (lane >= o) lpre += t; }
+    const double want = target - before;
+    const unsigned long long lh = __ballot(lpre >= want && loc > 0.0), lnz = __ballot(loc > 0.0);
+    const int L = lh ? __ffsll((long long) lh) - 1 : (lnz ? 63 - __clzll((long long) lnz) : 0);
+    const double lbefore = __shfl(lpre, L) - __shfl(loc, L);
+    if (lane == L) {
+        int pick = -1, last_nz = -1; double c = lbefore;
+        for (int i = j0; i < j1; ++i) {
+            const float p = prob_of(st, rs, logits[i], ban[i], i);
+            if (p > 0.0f) { last_nz = i; c += (double) p; if (pick < 0 && c >= want) pick = i; }
+        }
+        if (pick < 0) pick = last_nz >= 0 ? last_nz : 0;
+        SampleOut r;
+        const float lraw = logits[pick];
+        const float l = st.temperature > 0.0f ? lraw / st.temperature : lraw;
+        r.id = pick; r.plog = l - rs.lse; r.p = expf(r.plog); r.forced_ts = rs.force_ts; r.seq = dr;
+        const float p_ts_max = rs.ts.v > -INFINITY ? expf(rs.ts.v - rs.lse) : 0.0f;
+        const double sum_ts_p = (double) rs.sum_ts * (double) expf(rs.M - rs.lse);
+        r.tid = p_ts_max > 0.0f ? rs.ts.i : tid_default;      // the reference's initial value: token_beg (top-k) or 0 (single draw)
+        r.pt = (float) ((double) p_ts_max / (sum_ts_p + 1e-10));
+        r.ptsum = (float) sum_ts_p;
+        if (r.id >= st.beg) { r.tid = r.id; r.pt = r.p; }
+        out[(size_t) row * k + dr] = r;
+    }
+}
+
 } // namespace
+
+void filter_draw(const float * logits, const uint8_t * static_ban, const DecStep * step, const double * u, int k, SampleOut * out,
+                 void * scratch, hipStream_t st, int n_rows, int tid_default) {
+    Partial * part = (Partial *) scratch;
+    double * bsum = (double *) ((char *) scratch + filter_scratch_bytes(n_rows));
+    hipLaunchKernelGGL(k_filter_stats, dim3(NB, n_rows), dim3(NT), 0, st, logits, static_ban, step, part);
+    hipLaunchKernelGGL(k_prob_blocks, dim3(NB, n_rows), dim3(NT), 0, st, logits, static_ban, step, part, bsum);
+    hipLaunchKernelGGL(k_draw, dim3(k, n_rows), dim3(64), 0, st, logits, static_ban, step, part, bsum, u, k, tid_default, out);
+}
+size_t filter_draw_scratch_bytes(int n_rows) { return filter_scratch_bytes(n_rows) + (size_t) n_rows * NB * sizeof(double); }
 
 void filter_argmax(const float * logits, const uint8_t * static_ban, const DecStep * step, SampleOut * out, void * scratch,
                    hipStream_t st, SampleOut * out_host, int n_rows) {

@@ -164,7 +164,8 @@ struct DecStep {
     int32_t ts_floor_end;          // timestamps in [beg, ts_floor_end) are banned (monotonic rule) ; = beg when inactive
     int32_t ts_initial_start;      // timestamps in [ts_initial_start, n_vocab) are banned (max_initial_ts) ; = n_vocab when inactive
     int32_t seq;                   // step sequence number, echoed in SampleOut::seq (the host polls pinned memory for it)
-    int32_t pad[4];
+    float   temperature;           // > 0: logits are divided by it before the filters (W/whisper.cpp:4500-4506); 0 = as they are
+    int32_t pad[3];
 };
 struct SampleOut { int32_t id, tid; float p, plog, pt, ptsum; int32_t forced_ts; int32_t seq; };
 // logits [n_vocab] -> filtered soft-max statistics and the arg-max token (W/whisper.cpp:4493-4830 at temperature 0)
@@ -172,6 +173,15 @@ struct SampleOut { int32_t id, tid; float p, plog, pt, ptsum; int32_t forced_ts;
 void filter_argmax(const float * logits, const uint8_t * static_ban, const DecStep * step, SampleOut * out, void * scratch, hipStream_t st,
                    SampleOut * out_host = nullptr, int n_rows = 1);
 size_t filter_scratch_bytes(int n_rows = 1);
+// Draws from the filtered distribution on the device (beam search candidates, t > 0 sampling: whisper_sample_token(best = false)
+// and whisper_sample_token_topk, W/whisper.cpp:4777-4909).  The reference draws with std::discrete_distribution on the 51 866
+// probabilities: id = first i with cdf(i) >= u, u = generate_canonical(mt19937).  The host keeps the generator and passes the
+// uniform numbers u [n_rows][k]; the device filters the logits (same rules as filter_argmax), forms p = exp(l - lse), sums them in
+// double (tree order) and finds the k ids per row — k (id, p, plog) and the timestamp statistics come back instead of 207 KB
+// of logits per row.  out [n_rows][k] (SampleOut::seq = draw index); scratch: filter_draw_scratch_bytes.
+void filter_draw(const float * logits, const uint8_t * static_ban, const DecStep * step, const double * u, int k, SampleOut * out,
+                 void * scratch, hipStream_t st, int n_rows, int tid_default);
+size_t filter_draw_scratch_bytes(int n_rows);
 // first kernel of a replayed step: fetch DecStep from pinned host memory, mirror it on the device, embed the token
 void dec_embed_step(const DecStep * host_step, DecStep * dev_step, int S, const __half * te, const float * pe, float * x, hipStream_t st,
                     int n_rows = 1);

@@ -225,6 +225,10 @@ struct DeviceState {
     uint8_t * ban_dev = nullptr;   uint64_t ban_sig = ~0ull;          // static suppress mask + its parameter signature
     hipGraph_t step_graph = nullptr; hipGraphExec_t step_exec = nullptr; int step_graph_T = -1;
     int32_t step_seq = 0;                                             // sequence number of the last greedy step launched
+    // device-side draws (beam search, t > 0): decode() leaves the logits rows in d.logits, sample_rows_device() draws from them
+    bool    keep_logits_on_device = false;
+    void  * draw_dev = nullptr;  void * draw_host = nullptr;          // DecStep[8] | u[8][8] | SampleOut[8][8] (device / pinned)
+    void  * draw_scratch = nullptr;
     bool    step_capture_failed = false;                               // a failed capture is not retried
     int     step_seen_T = -1, step_seen_n = 0;                        // encoder length of recent steps / how many in a row
 };
@@ -309,6 +313,10 @@ void enqueue_greedy_step_q(whisper_context & ctx, int Tc);
 struct StepFilter { bool ban_blank, last_ts, penult_ts; int ts_floor_end, ts_initial_start; };
 bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const StepFilter & f, whisper_token_data & out);
 bool upload_static_ban(whisper_context & ctx, const whisper_full_params & params);
+// k draws per row from the filtered distribution of logits row `rows[r]` of the last decode() (keep_logits_on_device), r < n_rows <= 8;
+// u [n_rows][k] uniform numbers in [0, 1) from the decoders' generators.  out [n_rows][k].
+bool sample_rows_device(whisper_context & ctx, const StepFilter * f, const int * rows, int n_rows, float temperature, int k,
+                        const double * u, int tid_default, whisper_token_data * out);
 bool wait_for_seq(const volatile int32_t * seq, int32_t want, hipStream_t s);   // spin on a pinned sequence number (device.cpp)
 bool fast_path_enabled();
 // host worker pool (pool.cpp): fn(0..n_tasks-1) on a few persistent threads + the caller; nested calls run inline

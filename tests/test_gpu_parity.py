@@ -986,3 +986,46 @@ def test_beam_kv_bookkeeping_gives_each_beam_its_own_history(product_lib):
         assert checked >= 10
     finally:
         node.close()
+
+
+@pytest.mark.parametrize("variant", ["beam5", "beam3_default", "best_of_t04", "fallback"])
+@pytest.mark.parametrize("shape", ["micro.en", "micro"])
+def test_device_draws_equal_host_draws(product_lib, variant, shape):
+    """beam-search candidates and t > 0 samples are drawn on the device (k (id, p, plog) per row cross PCIe instead
+    of 207 KB of logits).  The generators stay on the host, so the device path must pick the same ids as the host's
+    std::discrete_distribution (bit-exact vs the reference: tests/test_host_logic.py) — the only difference is the order of the
+    f32 / f64 sums behind the CDF (a draw within ~1e-6 of a CDF step could flip; none does on these inputs)."""
+    import os
+    model = synth.make_model(shape, seed=1234)
+    pcm = synth.make_pcm(12.0, seed=61)
+    res = {}
+    for mode in ("device", "host"):
+        if mode == "host":
+            os.environ["WMI_HOST_DRAWS"] = "1"
+        else:
+            os.environ.pop("WMI_HOST_DRAWS", None)
+        node = host.SpeechToText(product_lib); node.set_language_model(model)
+        if shape == "micro":
+            node.language = "fr"
+        try:
+            if variant == "best_of_t04":
+                p = node.full_params("", 0); p.temperature = 0.4; p.temperature_inc = 0.0; p.greedy.best_of = 4
+            elif variant == "fallback":
+                p = node.full_params("", 0); p.logprob_thold = 10.0; p.greedy.best_of = 3           # every temperature fails: walks 0.0 .. 1.0
+            else:
+                p = product_lib.whisper_full_default_params(abi.WHISPER_SAMPLING_BEAM_SEARCH)
+                p.language = node.language.encode(); p.temperature_inc = 0.0
+                node._keep = [p.language]
+                p.beam_search.beam_size = 5 if variant == "beam5" else 3
+                if variant == "beam5":
+                    p.single_segment = True; p.max_tokens = 16
+            res[mode] = gu.tokens_array(node.transcribe(pcm, params=p))
+            t6 = (C.c_int64 * 6)(); n5 = (C.c_int32 * 5)(); product_lib.wmi_get_timings(node.ctx, t6, n5)
+            res[mode + "_sample_us"] = t6[5]
+        finally:
+            node.close()
+    os.environ.pop("WMI_HOST_DRAWS", None)
+    g, w = res["device"], res["host"]
+    assert len(w) >= 4
+    assert g.shape == w.shape and np.array_equal(g[:, [0, 1, 6, 7]], w[:, [0, 1, 6, 7]]), (g[:, 0], w[:, 0])
+    assert np.abs(g[:, 2:6] - w[:, 2:6]).max() <= 1e-4              # log-sum-exp of 51 864 terms: f32 tree vs sequential order
