@@ -552,7 +552,7 @@ int wmi_selftest_quant(int device, int qtype, int mode, const void * w_blocks, c
     const int nb = K / 32;
     std::vector<uint8_t> tiles(k::q_matrix_bytes(qtype, N, K));
     k::q_repack_host(qtype, (const uint8_t *) w_blocks, N, K, tiles.data());
-    uint8_t * d_t = nullptr; float * d_x = nullptr, * d_o = nullptr, * d_z = nullptr; int8_t * d_qs = nullptr; float2 * d_ds = nullptr; int32_t * d_tok = nullptr;
+    uint8_t * d_t = nullptr; float * d_x = nullptr, * d_o = nullptr, * d_z = nullptr; int8_t * d_qs = nullptr; float * d_ds = nullptr; int32_t * d_tok = nullptr;
     const size_t n_out = (size_t) M * (mode == 2 ? K : N);
     bool ok = HIP_OK(hipMalloc((void **) &d_t, tiles.size() + 4096)) && HIP_OK(hipMalloc((void **) &d_x, (size_t) M * K * 4)) &&
               HIP_OK(hipMalloc((void **) &d_o, n_out * 4)) && HIP_OK(hipMalloc((void **) &d_z, n_out * 4)) &&
@@ -570,7 +570,7 @@ int wmi_selftest_quant(int device, int qtype, int mode, const void * w_blocks, c
             ok = HIP_OK(hipMemcpy(d_tok, tp.data(), tp.size() * 4, hipMemcpyHostToDevice));
             k::qdec_embed(d_tok, d_tok + M, M, K, W, d_z, d_o, st);           // "positional embedding" = zeros
         } else if (ok) {
-            const k::Q8Rows A{d_qs, d_ds};
+            const k::Q8Rows A{d_qs, d_ds, d_ds + (size_t) nb * M, M};
             k::quantize_rows(d_x, nullptr, M, K, nullptr, nullptr, 0.f, qtype, A, nullptr, nullptr, st);
             if (mode == 0) {
                 k::GemvArgs ga{};
@@ -585,7 +585,13 @@ int wmi_selftest_quant(int device, int qtype, int mode, const void * w_blocks, c
         ok = ok && HIP_OK(hipStreamSynchronize(st)) && HIP_OK(hipGetLastError());
         ok = ok && HIP_OK(hipMemcpy(out, d_o, n_out * 4, hipMemcpyDeviceToHost));
         if (ok && mode != 2 && out_qs) ok = HIP_OK(hipMemcpy(out_qs, d_qs, (size_t) M * K, hipMemcpyDeviceToHost));
-        if (ok && mode != 2 && out_ds) ok = HIP_OK(hipMemcpy(out_ds, d_ds, (size_t) M * nb * 8, hipMemcpyDeviceToHost));
+        if (ok && mode != 2 && out_ds) {                      // device layout: d [nb][M] | s [nb][M]  ->  [M][nb][2]
+            std::vector<float> tmp((size_t) 2 * nb * M);
+            ok = HIP_OK(hipMemcpy(tmp.data(), d_ds, tmp.size() * 4, hipMemcpyDeviceToHost));
+            for (int m = 0; m < M && ok; ++m) for (int b = 0; b < nb; ++b) {
+                out_ds[((size_t) m * nb + b) * 2] = tmp[(size_t) b * M + m]; out_ds[((size_t) m * nb + b) * 2 + 1] = tmp[(size_t) nb * M + (size_t) b * M + m];
+            }
+        }
     }
     if (st) (void) hipStreamDestroy(st);
     (void) hipFree(d_t); (void) hipFree(d_x); (void) hipFree(d_o); (void) hipFree(d_z); (void) hipFree(d_qs); (void) hipFree(d_ds); (void) hipFree(d_tok);
@@ -605,7 +611,7 @@ double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters) {
                 if (ctx->model.quantised) {             // block-quantised mlp.0: q8 rows of the last encode x quantised tiles
                     k::GemmArgs a{};
                     a.M = T; a.N = 4 * S; a.K = S; a.bias = w.enc[0].b_fc1; a.C = d.h; a.ldc = 4 * S;
-                    k::qgemm(k::EPI_F16_BIAS_GELU, a, k::Q8Rows{d.aq, d.ads}, w.enc[0].q_fc1, s);
+                    k::qgemm(k::EPI_F16_BIAS_GELU, a, q8_rows(d, S), w.enc[0].q_fc1, s);
                     break;
                 }
                 k::GemmArgs a{};

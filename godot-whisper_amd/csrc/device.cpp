@@ -55,7 +55,8 @@ bool init_state(whisper_context & ctx) {
     const size_t n = hp.n_text_ctx;
     if (ctx.model.quantised) {                              // q8 activation rows + f32 attention outputs (device_q.cpp)
         const size_t rows = std::max<size_t>(T, n);
-        ok = ok && dalloc(d.aq, rows * 4 * S) && dalloc(d.ads, rows * (4 * S / 32)) && dalloc(d.att32, T * S) && dalloc(d.datt32, n * S);
+        d.aq_rows = (int) rows;
+        ok = ok && dalloc(d.aq, rows * 4 * S) && dalloc(d.ads, 2 * rows * (4 * S / 32)) && dalloc(d.att32, T * S) && dalloc(d.datt32, n * S);
     }
     d.logits_rows_cap = 8;
     ok = ok && dalloc(d.d_tokens, n) && dalloc(d.d_pos, n) && dalloc(d.d_mask, n * n_self) && dalloc(d.d_rows, n)

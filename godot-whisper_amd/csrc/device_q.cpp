@@ -38,7 +38,7 @@ bool encode_layers_q(whisper_context & ctx, int T) {
     State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
     const int S = hp.n_audio_state, H = hp.n_audio_head, La = hp.n_audio_layer, Lt = hp.n_text_layer;
     hipStream_t s = d.stream;
-    const k::Q8Rows A{d.aq, d.ads};
+    const k::Q8Rows A = q8_rows(d, S), A4 = q8_rows(d, 4 * S);
     const int qt = w.qtype;
     const float kq_scale = 1.0f / sqrtf((float) S / H);
     for (int il = 0; il < La; ++il) {
@@ -63,11 +63,11 @@ bool encode_layers_q(whisper_context & ctx, int T) {
             a.M = T; a.N = 4 * S; a.K = S; a.bias = l.b_fc1; a.C = d.h; a.ldc = 4 * S;
             k::qgemm(k::EPI_F16_BIAS_GELU, a, A, l.q_fc1, s);
         }
-        k::quantize_rows(nullptr, d.h, T, 4 * S, nullptr, nullptr, 0.f, qt, A, nullptr, nullptr, s);
+        k::quantize_rows(nullptr, d.h, T, 4 * S, nullptr, nullptr, 0.f, qt, A4, nullptr, nullptr, s);
         {
             k::GemmArgs a{};
             a.M = T; a.N = S; a.K = 4 * S; a.bias = l.b_fc2; a.C = d.x; a.ldc = S; a.resid = d.x; a.ldr = S;
-            k::qgemm(k::EPI_F32_BIAS_RESID, a, A, l.q_fc2, s);
+            k::qgemm(k::EPI_F32_BIAS_RESID, a, A4, l.q_fc2, s);
         }
     }
     // ln_post -> embd_enc (f32, kept for inspection) and its q8 image; cross K/V of every decoder layer in one GEMM
@@ -88,7 +88,6 @@ bool decode_layers_q(whisper_context & ctx, int n, int n_kv, int kv_head, int Tc
     const int S = hp.n_text_state, H = hp.n_text_head, Lt = hp.n_text_layer, NV = hp.n_vocab, n_ctx = (int) kv.size;
     hipStream_t s = d.stream;
     const int qt = w.qtype;
-    const k::Q8Rows A{d.aq, d.ads};
     const float kq_scale = powf((float) S / H, -0.25f);
 
     k::qdec_embed(d.d_tokens, d.d_pos, n, S, w.q_te, w.d_pe, d.dx, s);
@@ -104,6 +103,7 @@ bool decode_layers_q(whisper_context & ctx, int n, int n_kv, int kv_head, int Tc
             g.aux2 = aux2; g.ldaux2 = ldaux2; g.scale = scale; g.S = S;
             k::qrows(g, src.ln_g ? nullptr : src.x32, W, s);
         } else {
+            const k::Q8Rows A = q8_rows(d, K);
             k::quantize_rows(src.x32, src.x16, n, K, src.ln_g, src.ln_b, hp.eps, qt, A, nullptr, nullptr, s);
             k::GemmArgs a{};
             a.M = n; a.N = N; a.K = K; a.bias = bias; a.C = C; a.ldc = ldc; a.resid = resid; a.ldr = S;

@@ -187,12 +187,11 @@ __device__ __forceinline__ void ln_inplace(float4 (&v)[MAXV], const float4 (&gg)
 template <int MAXV, int SRC, bool F16D>
 __global__ __launch_bounds__(256) void k_q8_rows(const float * __restrict__ x32, const __half * __restrict__ x16, int M, int K,
                                                  const float * __restrict__ g, const float * __restrict__ b, float eps,
-                                                 int8_t * __restrict__ qs, float2 * __restrict__ ds,
+                                                 int8_t * __restrict__ qs, float * __restrict__ dT, float * __restrict__ sT, int ldm,
                                                  float * __restrict__ out32, __half * __restrict__ out16) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
-    const int nb = K >> 5;
     if constexpr (SRC == 1) {
         const float * xr = x32 + (size_t) row * K;
         float4 v[MAXV], gg[MAXV], bb[MAXV];
@@ -209,7 +208,7 @@ __global__ __launch_bounds__(256) void k_q8_rows(const float * __restrict__ x32,
             const uint32_t q = quant4<F16D>(v[i].x, v[i].y, v[i].z, v[i].w, d, s);        // all lanes shuffle; columns past K hold zeros
             if (c < K) {
                 *(uint32_t *) (qs + (size_t) row * K + c) = q;
-                if ((lane & 7) == 0) ds[(size_t) row * nb + (c >> 5)] = make_float2(d, s);
+                if ((lane & 7) == 0) { dT[(size_t) (c >> 5) * ldm + row] = d; sT[(size_t) (c >> 5) * ldm + row] = s; }
                 if (out32) *(float4 *) (out32 + (size_t) row * K + c) = v[i];
                 if (out16) {
                     __half2 h01 = __floats2half2_rn(pin_f32(v[i].x), pin_f32(v[i].y)), h23 = __floats2half2_rn(pin_f32(v[i].z), pin_f32(v[i].w));
@@ -239,7 +238,7 @@ __global__ __launch_bounds__(256) void k_q8_rows(const float * __restrict__ x32,
                 const uint32_t q = quant4<F16D>(v[i].x, v[i].y, v[i].z, v[i].w, d, s);
                 if (c < K) {
                     *(uint32_t *) (qs + (size_t) row * K + c) = q;
-                    if ((lane & 7) == 0) ds[(size_t) row * nb + (c >> 5)] = make_float2(d, s);
+                    if ((lane & 7) == 0) { dT[(size_t) (c >> 5) * ldm + row] = d; sT[(size_t) (c >> 5) * ldm + row] = s; }
                 }
             }
         }
@@ -266,19 +265,46 @@ __device__ __forceinline__ void q_store(const GemmArgs & a, int m, int n, float 
     }
 }
 
-template <int QT, int BM, int EPI>
-__global__ __launch_bounds__(256) void k_qgemm(const GemmArgs a, const int8_t * __restrict__ Aq, const float2 * __restrict__ Ads,
-                                               const uint8_t * __restrict__ Wt) {
+// LDS-DMA issued from inline assembly: hipcc (ROCm 7.2) tracks a __builtin_amdgcn_global_load_lds as a pending LDS write and puts
+// `s_waitcnt vmcnt(0)` in front of the next ds_read it cannot prove disjoint — here in front of the fragment reads of EVERY K
+// step, i.e. the whole ring was drained right after it had been refilled (ISA dump: vmcnt(0) at the head of the compute block;
+// 56 % of the wave cycles in SQ_WAIT_ANY).  An asm statement is invisible to that bookkeeping; the counted waits below are the
+// only ones.  M0 = LDS byte address of the wavefront's destination (lane L lands at M0 + L * size); saved and restored because
+// the compiler owns M0 (cdna_hip_programming.md §5.7).
+template <int BYTES>
+__device__ __forceinline__ void glds_asm(const void * gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    if constexpr (BYTES == 16)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void * p) { return (uint32_t) (uintptr_t) (__attribute__((address_space(3))) const void *) p; }
+
+// All operands arrive by global_load_lds into an NST-deep ring (NST - 1 K steps in flight, counted vmcnt waits, one raw
+// s_barrier per K step: an LDS-DMA in flight makes __syncthreads() drain the queue): one wavefront per row group fetches its
+// RAW quantised tile, unpacks it to int8 when its K step comes up and stores it into one of two B images; the A quants (q8 rows)
+// land in fragment order directly, the A scales come from the block-major arrays.  With one tile in flight (round 2a) the
+// kernel waited a full memory round trip per K step: 70 - 108 us for the large-v3 projections at one chunk.
+template <int QT, int BM, int EPI, int NST>
+__global__ __launch_bounds__(256, 2) void k_qgemm(const GemmArgs a, const int8_t * __restrict__ Aq, const float * __restrict__ AdT,
+                                                  const float * __restrict__ AsT, int ldm, const uint8_t * __restrict__ Wt) {
     constexpr int BN = 128;
     constexpr int FM = BM / 64, FN = 2;                    // 32 x 32 fragments per wavefront (2 x 2 wavefronts)
     constexpr int QW = Geo<QT>::QW, HW = Geo<QT>::HW;
     constexpr bool HAS_M = Geo<QT>::M;
-    // one stage: A int8 [BM][64] | B int8 [BN][64] | A scales d [2][BM], s [2][BM] | B scales d [2][BN], m [2][BN]
-    constexpr int OFF_B = BM * 64, OFF_AD = OFF_B + BN * 64, OFF_AS = OFF_AD + 2 * BM * 4, OFF_BD = OFF_AS + 2 * BM * 4,
-                  OFF_BM = OFF_BD + 2 * BN * 4, STAGE = OFF_BM + 2 * BN * 4;
+    // ring stage: A int8 [BM][64] | raw W tiles of the 4 row groups: quants [4][64][QW] dwords, headers [4][HW][64] dwords |
+    //             A scales d [2][BM], s [2][BM]
+    constexpr int R_WQ = BM * 64, R_WH = R_WQ + 4 * 64 * QW * 4, R_AD = R_WH + 4 * HW * 64 * 4, R_AS = R_AD + 2 * BM * 4, RSTAGE = R_AS + 2 * BM * 4;
+    // unpacked B image (two of them): int8 [BN][64] | d [2][BN] | m [2][BN]
+    constexpr int B_D = BN * 64, B_M = B_D + 2 * BN * 4, BSTAGE = B_M + 2 * BN * 4;
+    constexpr int OFF_BIMG = NST * RSTAGE;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN, nwg = ntm * ntn;
     int wg = blockIdx.x;
@@ -288,10 +314,10 @@ __global__ __launch_bounds__(256) void k_qgemm(const GemmArgs a, const int8_t * 
     }
     const int tm = wg / ntn, tn = wg % ntn;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int np = a.K >> 6, nb = a.K >> 5;
+    const int np = a.K >> 6;
 
-    // A quants: pieces of 16 rows x 64 B go global -> LDS directly; lane p of a piece fetches the chunk that belongs at position p
-    constexpr int PA = BM / 64;                             // pieces per wavefront
+    // ---- per-lane source addresses of one stage
+    constexpr int PA = BM / 64;                             // A pieces (16 rows x 64 B) per wavefront
     const int8_t * qA[PA];
 #pragma unroll
     for (int p = 0; p < PA; ++p) {
@@ -299,38 +325,51 @@ __global__ __launch_bounds__(256) void k_qgemm(const GemmArgs a, const int8_t * 
         int r = m0 + lrow; if (r > a.M - 1) r = a.M - 1;
         qA[p] = Aq + (size_t) r * a.K + ch * 16;
     }
-    // A scales: thread -> (row, block of the pair)
-    const int srow = tid % BM, sblk = tid / BM;              // BM = 128: 256 threads = 128 rows x 2 blocks; BM = 64: threads < 128
-    const bool sact = tid < 2 * BM;
-    const float2 * gS; { int r = m0 + srow; if (r > a.M - 1) r = a.M - 1; gS = Ads + (size_t) r * nb + sblk; }
-    // B: wavefront w owns row group (n0 / 32 + w) of the tile
-    const uint8_t * gW = Wt + ((size_t) (n0 / 32 + wave) * np) * tile_bytes<QT>();
+    const uint8_t * gW = Wt + ((size_t) (n0 / 32 + wave) * np) * tile_bytes<QT>();      // this wavefront's row group
+    // A scales: wavefront w fetches (block w & 1, d or s by w >> 1) for rows m0 + [0, BM): BM / 64 loads of 64 floats
+    const float * gSc; { int r = m0 + lane; if (r > a.M - 1) r = a.M - 1; gSc = ((wave >> 1) ? AsT : AdT) + r; }
+    int sc_r1 = m0 + 64 + lane; if (sc_r1 > a.M - 1) sc_r1 = a.M - 1;
+    const float * gSc1 = ((wave >> 1) ? AsT : AdT) + sc_r1;
+    constexpr int LPT = PA + 1 + HW + PA;                   // loads per wavefront and stage
 
-    uint32_t rq[QW], rh[HW]; float2 rs = make_float2(0.f, 0.f);
-    auto issue_a = [&](int kt, int buf) {
+    const uint32_t lds0 = lds_addr(smem);
+    auto issue = [&](int kt, int slot) {
+        const uint32_t st = lds0 + slot * RSTAGE;
 #pragma unroll
-        for (int p = 0; p < PA; ++p)
-            __builtin_amdgcn_global_load_lds((const void *) (qA[p] + kt * 64), (__attribute__((address_space(3))) void *) (smem + buf * STAGE + (wave * PA + p) * 1024), 16, 0, 0);
-    };
-    auto load_b = [&](int kt) {
+        for (int p = 0; p < PA; ++p) glds_asm<16>(qA[p] + kt * 64, st + (wave * PA + p) * 1024);
         const uint8_t * t = gW + (size_t) kt * tile_bytes<QT>();
-        if constexpr (QW == 4) { const uint4 u = *(const uint4 *) (t + lane * 16); rq[0] = u.x; rq[1] = u.y; rq[2] = u.z; rq[3] = u.w; }
-        else { const uint4 u = *(const uint4 *) (t + lane * 32), w = *(const uint4 *) (t + lane * 32 + 16);
-               rq[0] = u.x; rq[1] = u.y; rq[2] = u.z; rq[3] = u.w; rq[4] = w.x; rq[5] = w.y; rq[6] = w.z; rq[7] = w.w; }
-        if constexpr (HW == 2) { const uint2 h = *(const uint2 *) (t + 64 * QW * 4 + lane * 8); rh[0] = h.x; rh[1] = h.y; }
-        else rh[0] = *(const uint32_t *) (t + 64 * QW * 4 + lane * 4);
-        if (sact) rs = gS[2 * kt];
+        if constexpr (QW == 4) glds_asm<16>(t + lane * 16, st + R_WQ + wave * 1024);
+        else {   // q8_0: 32 payload bytes per block: two 16-byte halves, each its own lane-linear image
+            glds_asm<16>(t + lane * 32, st + R_WQ + wave * 2048);
+            glds_asm<16>(t + lane * 32 + 16, st + R_WQ + wave * 2048 + 1024);
+        }
+#pragma unroll
+        for (int h = 0; h < HW; ++h) glds_asm<4>(t + 64 * QW * 4 + lane * HW * 4 + h * 4, st + R_WH + (wave * HW + h) * 256);
+        const size_t boff = (size_t) (2 * kt + (wave & 1)) * ldm;
+        const int soff = (wave >> 1) ? R_AS : R_AD;
+        glds_asm<4>(gSc + boff, st + soff + ((wave & 1) * BM) * 4);
+        if constexpr (BM == 128) glds_asm<4>(gSc1 + boff, st + soff + ((wave & 1) * BM + 64) * 4);
     };
-    auto store_b = [&](int buf) {
-        unsigned char * st = smem + buf * STAGE;
+    constexpr int LPT_REAL = PA + (QW == 4 ? 1 : 2) + HW + PA;
+    static_assert(LPT_REAL >= LPT, "load count");
+
+    // this wavefront's raw tile of ring slot -> int8 rows + scales in B image `img`
+    auto unpack_b = [&](int slot, int img) {
+        const unsigned char * st = smem + slot * RSTAGE;
+        unsigned char * bi = smem + OFF_BIMG + img * BSTAGE;
+        uint32_t rq[QW], rh[HW];
+        if constexpr (QW == 4) { const uint4 u = *(const uint4 *) (st + R_WQ + wave * 1024 + lane * 16); rq[0] = u.x; rq[1] = u.y; rq[2] = u.z; rq[3] = u.w; }
+        else { const uint4 u = *(const uint4 *) (st + R_WQ + wave * 2048 + lane * 16), w2 = *(const uint4 *) (st + R_WQ + wave * 2048 + 1024 + lane * 16);
+               rq[0] = u.x; rq[1] = u.y; rq[2] = u.z; rq[3] = u.w; rq[4] = w2.x; rq[5] = w2.y; rq[6] = w2.z; rq[7] = w2.w; }
+#pragma unroll
+        for (int h = 0; h < HW; ++h) rh[h] = *(const uint32_t *) (st + R_WH + (wave * HW + h) * 256 + lane * 4);
         uint32_t lo[4], hi[4]; float d, m;
         unpack<QT>(rq, rh, lo, hi, d, m);
         const int n = wave * 32 + (lane & 31), g = lane >> 5;                       // tile row, block of the pair
-        *(uint4 *) (st + OFF_B + q_lds_off(n, 2 * g))     = make_uint4(lo[0], lo[1], lo[2], lo[3]);
-        *(uint4 *) (st + OFF_B + q_lds_off(n, 2 * g + 1)) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
-        ((float *) (st + OFF_BD))[g * BN + n] = d;
-        if (HAS_M) ((float *) (st + OFF_BM))[g * BN + n] = m;
-        if (sact) { ((float *) (st + OFF_AD))[sblk * BM + srow] = rs.x; ((float *) (st + OFF_AS))[sblk * BM + srow] = rs.y; }
+        *(uint4 *) (bi + q_lds_off(n, 2 * g))     = make_uint4(lo[0], lo[1], lo[2], lo[3]);
+        *(uint4 *) (bi + q_lds_off(n, 2 * g + 1)) = make_uint4(hi[0], hi[1], hi[2], hi[3]);
+        ((float *) (bi + B_D))[g * BN + n] = d;
+        if (HAS_M) ((float *) (bi + B_M))[g * BN + n] = m;
     };
 
     floatx16 acc[FM][FN];
@@ -342,25 +381,25 @@ __global__ __launch_bounds__(256) void k_qgemm(const GemmArgs a, const int8_t * 
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
     const int frow = lane & 31, fk = lane >> 5;
-    auto compute = [&](int buf) {
-        const unsigned char * st = smem + buf * STAGE;
+    auto compute = [&](int slot, int img) {
+        const unsigned char * st = smem + slot * RSTAGE;
+        const unsigned char * bi = smem + OFF_BIMG + img * BSTAGE;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            intx4 fa[FM], fb[FN]; float dw[FN];
-#pragma unroll
-            for (int i = 0; i < FM; ++i) fa[i] = *(const intx4 *) (st + q_lds_off(wm * (BM / 2) + i * 32 + frow, 2 * kk + fk));
+            intx4 fb[FN]; float dw[FN];
 #pragma unroll
             for (int j = 0; j < FN; ++j) {
-                fb[j] = *(const intx4 *) (st + OFF_B + q_lds_off(wn * 64 + j * 32 + frow, 2 * kk + fk));
-                dw[j] = ((const float *) (st + OFF_BD))[kk * BN + wn * 64 + j * 32 + frow];
+                fb[j] = *(const intx4 *) (bi + q_lds_off(wn * 64 + j * 32 + frow, 2 * kk + fk));
+                dw[j] = ((const float *) (bi + B_D))[kk * BN + wn * 64 + j * 32 + frow];
             }
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
+                const intx4 fa = *(const intx4 *) (st + q_lds_off(wm * (BM / 2) + i * 32 + frow, 2 * kk + fk));
                 // d_a of this lane's 16 rows: rows (e & 3) + 8 (e >> 2) + 4 fk of the fragment
                 float da[16];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float4 t = *(const float4 *) ((const float *) (st + OFF_AD) + kk * BM + wm * (BM / 2) + i * 32 + 8 * q + 4 * fk);
+                    const float4 t = *(const float4 *) ((const float *) (st + R_AD) + kk * BM + wm * (BM / 2) + i * 32 + 8 * q + 4 * fk);
                     da[4 * q] = t.x; da[4 * q + 1] = t.y; da[4 * q + 2] = t.z; da[4 * q + 3] = t.w;
                 }
 #pragma unroll
@@ -368,7 +407,7 @@ __global__ __launch_bounds__(256) void k_qgemm(const GemmArgs a, const int8_t * 
                     intx16 z;
 #pragma unroll
                     for (int e = 0; e < 16; ++e) z[e] = 0;
-                    const intx16 ia = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa[i], fb[j], z, 0, 0, 0);
+                    const intx16 ia = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb[j], z, 0, 0, 0);
 #pragma unroll
                     for (int e = 0; e < 16; ++e) acc[i][j][e] = fmaf((float) ia[e], da[e] * dw[j], acc[i][j][e]);
                 }
@@ -378,9 +417,9 @@ __global__ __launch_bounds__(256) void k_qgemm(const GemmArgs a, const int8_t * 
             // sum over the two blocks of m_w * s_a: an f32 MFMA with K = 2 (exact f32 FMAs in block order) into the same accumulators
             float sa[FM], mw[FN];
 #pragma unroll
-            for (int i = 0; i < FM; ++i) sa[i] = ((const float *) (st + OFF_AS))[fk * BM + wm * (BM / 2) + i * 32 + frow];
+            for (int i = 0; i < FM; ++i) sa[i] = ((const float *) (st + R_AS))[fk * BM + wm * (BM / 2) + i * 32 + frow];
 #pragma unroll
-            for (int j = 0; j < FN; ++j) mw[j] = ((const float *) (st + OFF_BM))[fk * BN + wn * 64 + j * 32 + frow];
+            for (int j = 0; j < FN; ++j) mw[j] = ((const float *) (bi + B_M))[fk * BN + wn * 64 + j * 32 + frow];
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -388,14 +427,17 @@ __global__ __launch_bounds__(256) void k_qgemm(const GemmArgs a, const int8_t * 
         }
     };
 
-    issue_a(0, 0); load_b(0);
+#pragma unroll
+    for (int s0 = 0; s0 < NST - 1; ++s0) if (s0 < np) issue(s0, s0);
     for (int kt = 0; kt < np; ++kt) {
-        const int buf = kt & 1;
-        store_b(buf);                                        // waits for this tile's W registers (the A pieces were issued before them)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (kt + 1 < np) { issue_a(kt + 1, buf ^ 1); load_b(kt + 1); }
-        compute(buf);
+        // stage kt has landed when at most (NST - 2) stages' worth of this wavefront's loads are still outstanding
+        if (np - 1 - kt >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * LPT_REAL) : "memory");
+        else                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unpack_b(kt % NST, kt & 1);                          // own DMA data: ordered by the wait above
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                        // everyone's stage kt (A, scales) and B image kt & 1 are visible; slot (kt - 1) % NST is free
+        if (kt + NST - 1 < np) issue(kt + NST - 1, (kt + NST - 1) % NST);
+        compute(kt % NST, kt & 1);
     }
 
     // ------------------------------------------------------------------ epilogue
@@ -478,22 +520,31 @@ __global__ __launch_bounds__(256) void k_qgemm(const GemmArgs a, const int8_t * 
     if (m0 + BM <= a.M) epilogue(std::false_type{}); else epilogue(std::true_type{});
 }
 
-template <int QT, int BM, int EPI>
+template <int QT, int BM, int EPI, int NST>
 void launch_qgemm(const GemmArgs & a, Q8Rows A, const uint8_t * Wt, hipStream_t st) {
     constexpr int BN = 128;
-    constexpr size_t stage = (size_t) BM * 64 + BN * 64 + 4 * BM * 4 + 4 * BN * 4;
-    const size_t smem = 2 * stage;
+    constexpr int QW = Geo<QT>::QW, HW = Geo<QT>::HW;
+    constexpr size_t rstage = (size_t) BM * 64 + 4 * 64 * QW * 4 + 4 * HW * 64 * 4 + 4 * BM * 4;
+    constexpr size_t bstage = (size_t) BN * 64 + 4 * BN * 4;
+    const size_t smem = NST * rstage + 2 * bstage;
     static std::atomic<uint64_t> lds_ok{0};
-    allow_full_lds((const void *) k_qgemm<QT, BM, EPI>, lds_ok);
+    allow_full_lds((const void *) k_qgemm<QT, BM, EPI, NST>, lds_ok);
     const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN;
-    hipLaunchKernelGGL((k_qgemm<QT, BM, EPI>), dim3(ntm * ntn), dim3(256), smem, st, a, A.qs, A.ds, Wt);
+    hipLaunchKernelGGL((k_qgemm<QT, BM, EPI, NST>), dim3(ntm * ntn), dim3(256), smem, st, a, A.qs, A.d, A.s, A.ldm, Wt);
 }
 
 template <int QT, int EPI>
 void qgemm_tile(const GemmArgs & a, Q8Rows A, const uint8_t * Wt, hipStream_t st) {
-    // 256 CUs: 128-row tiles only when they still give every CU a workgroup and a half
+    // 64-row tiles: 158 VGPRs, three workgroups per CU with a 3-deep ring (53 KB of LDS each): the per-block scaling is a chain
+    // MFMA -> 48 VALU per fragment, so a SIMD wants several wavefronts to interleave; 128-row tiles (256 VGPRs, two per CU) only
+    // where the grid is large enough to keep them busy anyway
+    static const int force_bm = getenv("WMI_QGEMM_BM") ? atoi(getenv("WMI_QGEMM_BM")) : 0;       // A/B knobs
+    static const int nst64 = getenv("WMI_QGEMM_NST") ? atoi(getenv("WMI_QGEMM_NST")) : 3;
     const long t128 = (long) ((a.M + 127) / 128) * (a.N / 128);
-    if (t128 >= 384) launch_qgemm<QT, 128, EPI>(a, A, Wt, st); else launch_qgemm<QT, 64, EPI>(a, A, Wt, st);
+    const bool big = force_bm ? force_bm == 128 : t128 >= 1536;
+    if (big) launch_qgemm<QT, 128, EPI, 3>(a, A, Wt, st);
+    else if (nst64 == 4) launch_qgemm<QT, 64, EPI, 4>(a, A, Wt, st);
+    else launch_qgemm<QT, 64, EPI, 3>(a, A, Wt, st);
 }
 
 template <int QT>
@@ -799,8 +850,8 @@ void quantize_rows(const float * x32, const __half * x16, int M, int K, const fl
     if (M <= 0) return;
     const dim3 grid((M + 3) / 4), block(256);
     const bool f16d = !q_geom(qtype).has_m;
-#define WMI_Q8(MAXV, SRC) do { if (f16d) hipLaunchKernelGGL((k_q8_rows<MAXV, SRC, true>), grid, block, 0, st, x32, x16, M, K, ln_g, ln_b, eps, out.qs, out.ds, out32, out16); \
-                               else      hipLaunchKernelGGL((k_q8_rows<MAXV, SRC, false>), grid, block, 0, st, x32, x16, M, K, ln_g, ln_b, eps, out.qs, out.ds, out32, out16); } while (0)
+#define WMI_Q8(MAXV, SRC) do { if (f16d) hipLaunchKernelGGL((k_q8_rows<MAXV, SRC, true>), grid, block, 0, st, x32, x16, M, K, ln_g, ln_b, eps, out.qs, out.d, out.s, out.ldm, out32, out16); \
+                               else      hipLaunchKernelGGL((k_q8_rows<MAXV, SRC, false>), grid, block, 0, st, x32, x16, M, K, ln_g, ln_b, eps, out.qs, out.d, out.s, out.ldm, out32, out16); } while (0)
     if (ln_g) {
         const int nv = (K + 255) / 256;
         if (nv <= 2) WMI_Q8(2, 1); else if (nv <= 4) WMI_Q8(4, 1); else WMI_Q8(6, 1);

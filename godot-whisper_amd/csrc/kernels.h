@@ -208,9 +208,10 @@ inline size_t q_matrix_bytes(int qtype, int64_t N, int64_t K) { return (size_t) 
 void   q_repack_host(int qtype, const uint8_t * src, int64_t N, int64_t K, uint8_t * dst);
 struct QMat { const uint8_t * tiles = nullptr; int qtype = QT_NONE; };
 
-// activation rows as q8 blocks in global memory (the GEMM's A operand): qs [M][K] int8, ds [M][K / 32] {d, s}
-// (s = d * sum(q) for the q8_1 kinds; for the q8_0 kinds d is rounded to f16 as the reference stores it and s = 0)
-struct Q8Rows { int8_t * qs; float2 * ds; };
+// activation rows as q8 blocks in global memory (the GEMM's A operand): qs [M][K] int8; scales block-major d [K / 32][ldm],
+// s [K / 32][ldm] (the GEMM fetches the scales of 64 / 128 consecutive rows of one block with one load per wavefront);
+// s = d * sum(q) for the q8_1 kinds; for the q8_0 kinds d is rounded to f16 as the reference stores it and s = 0
+struct Q8Rows { int8_t * qs; float * d; float * s; int ldm; };
 // rows -> q8.  Exactly one source: x32 (+ optional LayerNorm gain/bias: y = LN(x) * g + b in f32, the reference quantises that
 // f32 tensor) or x16 (an f16 tensor, e.g. the GELU output, widened exactly).  out32 / out16: optional copy of the LN result.
 void quantize_rows(const float * x32, const __half * x16, int M, int K, const float * ln_g, const float * ln_b, float eps,

@@ -202,7 +202,7 @@ struct DeviceState {
     __half * h     = nullptr;                                 // [T][4S] f16
     float  * rowmax = nullptr;                                // [H][T] f32 (attention pass A)
     // block-quantised models only: activation rows as q8 blocks (the quantised GEMMs' A operand) and f32 attention outputs
-    int8_t * aq = nullptr;  float2 * ads = nullptr;           // [max(T, n_text_ctx)][4S] int8, [rows][4S / 32] {d, s}
+    int8_t * aq = nullptr;  float * ads = nullptr;  int aq_rows = 0;   // [rows][4S] int8; scales d [K / 32][rows] | s [K / 32][rows], rows = max(T, n_text_ctx)
     float  * att32 = nullptr;                                 // [T][S] f32
     float  * datt32 = nullptr;                                // [n_text_ctx][S] f32
     float  * enc_out = nullptr;                               // [T][S] f32  (embd_enc)
@@ -306,6 +306,7 @@ bool set_mel(whisper_context & ctx, const float * data, int n_len, int n_mel);
 bool encode(whisper_context & ctx, int mel_offset);
 bool decode(whisper_context & ctx, const Batch & batch);
 // block-quantised models (device_q.cpp): the layer loops of encode() / decode() with the quantised kernels
+inline k::Q8Rows q8_rows(const DeviceState & d, int K) { return k::Q8Rows{d.aq, d.ads, d.ads + (size_t) (K / 32) * d.aq_rows, d.aq_rows}; }
 bool encode_layers_q(whisper_context & ctx, int T);
 bool decode_layers_q(whisper_context & ctx, int n, int n_kv, int kv_head, int Tc, const std::vector<int> & rows);
 void enqueue_greedy_step_q(whisper_context & ctx, int Tc);
