@@ -47,9 +47,15 @@ def main():
                          "audio with the `small` multilingual shape (every 0.3 s the grown buffer is transcribed again, ragged audio_ctx)")
     ap.add_argument("--no-config4", action="store_true", help="skip the BASELINE configs[4] figure (large-v3 q5_1, beam 5: ~1 min of model synthesis)")
     ap.add_argument("--device-pcm", action="store_true", help="headline loop over PCM that is already resident in HBM (round-1 behaviour)")
+    ap.add_argument("--profile", action="store_true",
+                    help="the run profiles/collect.sh puts under rocprofv3: the headline loop + the per-kernel chains only (short), no secondary "
+                         "figures, no CPU baseline, no configs[4]")
     ap.add_argument("--chunks", type=int, default=1,
                     help="chunks per GPU per step: 1 = BASELINE configs[1] (headline); 8 = configs[3]'s per-GPU share, lock-step")
     args = ap.parse_args()
+    if args.profile:
+        args.no_cpu_baseline = True; args.no_config4 = True
+    IT = 20 if args.profile else 200                 # launches per micro-benchmark chain
 
     import torch
     import torch.distributed as dist
@@ -132,7 +138,7 @@ def main():
 
     # ---- secondary figures in the same run (N = 1, headline configuration only)
     dev_pcm = None; uncapped = None
-    if args.chunks == 1 and world == 1 and not args.device_pcm:
+    if args.chunks == 1 and world == 1 and not args.device_pcm and not args.profile:
         reps = max(20, min(300, args.steps // 5))
         for i in range(3):
             t = pcm_dev[i % n_distinct]; assert lib.wmi_full_device_pcm(ctx, params, C.c_void_p(t.data_ptr()), t.numel(), None) == 0
@@ -157,7 +163,7 @@ def main():
         uncapped = {"workload": "same chunk with max_tokens = 0 (no cap on the decoded tokens), whisper_full with host PCM",
                     "value": round(CHUNK_S / tu, 1), "unit": "x realtime", "ms_per_step": round(tu * 1e3, 3), "tokens": int(ntok0)}
     batch8 = None
-    if args.chunks == 1 and world == 1:
+    if args.chunks == 1 and world == 1 and not args.profile:
         nb, reps = 8, max(3, args.steps // 8)
         ptrs, lens = batch_args(0, nb)
         for _ in range(2):
@@ -256,12 +262,12 @@ def main():
             table = []
             for bit, name, nl, alg in kinds:
                 os.environ["WMI_STEP_MASK"] = str(1 << bit)
-                us = lib.wmi_bench_kernel(ctx, 20, 200) / nl
+                us = lib.wmi_bench_kernel(ctx, 20, IT) / nl
                 gbs = alg / (us * 1e-6) / 1e9
                 table.append({"kernel": name, "launches_per_step": nl, "avg_us": round(us, 3), "algorithmic_bytes": int(alg),
                               "achieved": round(gbs, 1), "frac": round(gbs / 8000.0, 4), "step_share_us": round(us * nl, 2)})
             os.environ.pop("WMI_STEP_MASK", None)
-            us_step = lib.wmi_bench_kernel(ctx, 20, 200)
+            us_step = lib.wmi_bench_kernel(ctx, 20, IT)
             tot = sum(t["step_share_us"] for t in table)
             for t in table:
                 t["step_share"] = round(t["step_share_us"] / tot, 3)
@@ -278,10 +284,10 @@ def main():
             out["roofline_encoder"] = {"bound": "mfma", "achieved": round(ENC_GFLOP / enc_ms, 2), "peak": 2500.0, "unit": "TFLOP/s",
                                        "frac": round(ENC_GFLOP / enc_ms / 2500.0, 4), "algorithmic_gflop": ENC_GFLOP, "encode_ms": round(enc_ms, 4)}
             # the vocabulary projection alone: on one matrix (Infinity-Cache resident after the first pass) and on a rotating > 256 MiB stream
-            us_gemv = lib.wmi_bench_kernel(ctx, 1, 300)
-            us_rot = lib.wmi_bench_kernel(ctx, 6, 300)
-            us_gemm = lib.wmi_bench_kernel(ctx, 0, 300)
-            us_attn = lib.wmi_bench_kernel(ctx, 2, 60)
+            us_gemv = lib.wmi_bench_kernel(ctx, 1, IT + IT // 2)
+            us_rot = lib.wmi_bench_kernel(ctx, 6, IT + IT // 2)
+            us_gemm = lib.wmi_bench_kernel(ctx, 0, IT + IT // 2)
+            us_attn = lib.wmi_bench_kernel(ctx, 2, max(IT // 3, 10))
             alg_bytes = NV * hp_S * 2                       # V*S*2 bytes of d_te per token
             out["roofline_logits"] = {"kernel": "k_gemv1<8,1> logits = d_te[51864x512] . LN(x)  (f16 weight stream, LN + activations in registers)",
                                       "bound": "hbm", "achieved": round(alg_bytes / (us_rot * 1e-6) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",

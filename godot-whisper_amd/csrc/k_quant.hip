@@ -605,27 +605,53 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
     if (rg < ngroups) load_tiles(rg, 0);
 
     // ---- prologue: the activation rows as q8 blocks in LDS
-    if constexpr (SRC == 1) {                                // LayerNorm needs the whole row: wavefront w takes rows w, w + NW, ...
-        for (int r = wave; r < n; r += NW) {
+    if constexpr (SRC == 1) {
+        // LayerNorm needs the statistics of the whole row, the quantiser only a 256-column slice: (row, slice) tasks are spread over
+        // the wavefronts, each task recomputes the row's mean / variance from L2 (ln_inplace's arithmetic and order) and
+        // normalises + quantises its own slice — one wavefront walking all slices of a row cost ~1 us more per launch, three
+        // launches per decoder layer
+        constexpr int MAXV = 6;                              // K <= 1536
+        const int nsl = (K + 255) >> 8;
+        for (int task = wave; task < n * nsl; task += NW) {
+            const int r = task / nsl, sl = task - r * nsl;
             const int src = a.rows ? a.rows[r] : r;
-            constexpr int MAXV = 6;                          // K <= 1536
-            float4 v[MAXV], gg[MAXV], bb[MAXV];
             const float * xr = a.x32 + (size_t) src * K;
+            float4 v[MAXV];
 #pragma unroll
-            for (int i = 0; i < MAXV; ++i) {
-                const int c = (i * 64 + lane) * 4, cc = c < K ? c : 0;
-                v[i] = *(const float4 *) (xr + cc); gg[i] = *(const float4 *) (a.ln_g + cc); bb[i] = *(const float4 *) (a.ln_b + cc);
-            }
-            ln_inplace<MAXV>(v, gg, bb, K, a.eps, lane);
+            for (int i = 0; i < MAXV; ++i) { const int c = (i * 64 + lane) * 4; v[i] = *(const float4 *) (xr + (c < K ? c : 0)); }
+            const int cs = (sl * 64 + lane) * 4, ccs = cs < K ? cs : 0;
+            const float4 gg = *(const float4 *) (a.ln_g + ccs), bb = *(const float4 *) (a.ln_b + ccs);
+            float sum = 0.0f;
 #pragma unroll
             for (int i = 0; i < MAXV; ++i) {
                 const int c = (i * 64 + lane) * 4;
-                float d, s;
-                const uint32_t q = quant4<F16D>(v[i].x, v[i].y, v[i].z, v[i].w, d, s);
+                if (c < K) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+                else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            const float mean = sum / (float) K;
+            float sqs = 0.0f;
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) {
+                const int c = (i * 64 + lane) * 4;
                 if (c < K) {
-                    *(uint32_t *) (sq + (size_t) r * lda + c) = q;
-                    if ((lane & 7) == 0) { sd[(c >> 5) * R8 + r] = d; ss[(c >> 5) * R8 + r] = s; }
+                    v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+                    sqs += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
                 }
+            }
+            for (int o = 32; o > 0; o >>= 1) sqs += __shfl_xor(sqs, o);
+            const float scale = 1.0f / sqrtf(sqs / (float) K + a.eps);
+            float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) if (i == sl) y = v[i];                      // wave-uniform select: the array stays in registers
+            y.x = __fadd_rn(__fmul_rn(y.x * scale, gg.x), bb.x); y.y = __fadd_rn(__fmul_rn(y.y * scale, gg.y), bb.y);
+            y.z = __fadd_rn(__fmul_rn(y.z * scale, gg.z), bb.z); y.w = __fadd_rn(__fmul_rn(y.w * scale, gg.w), bb.w);
+            if (cs >= K) y = make_float4(0.f, 0.f, 0.f, 0.f);
+            float d, sv;
+            const uint32_t q = quant4<F16D>(y.x, y.y, y.z, y.w, d, sv);
+            if (cs < K) {
+                *(uint32_t *) (sq + (size_t) r * lda + cs) = q;
+                if ((lane & 7) == 0) { sd[(cs >> 5) * R8 + r] = d; ss[(cs >> 5) * R8 + r] = sv; }
             }
         }
     } else {

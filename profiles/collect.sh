@@ -9,8 +9,12 @@ TAG=${1:-r01}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trace -- python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-config4 > $OUT/bench_trace.log 2>&1
-rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o pmc_fetch -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-config4 > $OUT/bench_pmc_fetch.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o pmc_write -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-config4 > $OUT/bench_pmc_write.log 2>&1
-rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $OUT -o pmc_mfma -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-config4 > $OUT/bench_pmc_mfma.log 2>&1
-ls -la $OUT
+timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trace -- python bench.py --steps 10 --warmup 2 --profile > $OUT/bench_trace.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o pmc_fetch -- python bench.py --steps 2 --warmup 1 --profile > $OUT/bench_pmc_fetch.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o pmc_write -- python bench.py --steps 2 --warmup 1 --profile > $OUT/bench_pmc_write.log 2>&1
+timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $OUT -o pmc_mfma -- python bench.py --steps 2 --warmup 1 --profile > $OUT/bench_pmc_mfma.log 2>&1
+# condense on the box: the raw per-dispatch CSVs are tens of MB per pass and gpurun merges back at most 64 MiB
+python profiles/summarise.py $TAG > $OUT/summary.txt 2>&1
+cp profiles/${TAG}_* $OUT/ 2>/dev/null
+find $OUT -name '*_kernel_trace.csv' -delete; find $OUT -name '*_counter_collection.csv' -delete; find $OUT -name '*_agent_info.csv' -delete
+ls -la $OUT; du -sh $OUT
