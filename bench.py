@@ -252,7 +252,7 @@ def main():
             kinds = [   # (mask bit, name, launches per step, algorithmic bytes per launch)
                 (1, "k_gemv1<4,1,false,1,EPI_QKV_DEC> LN + q|k|v projection", Lt, 3 * S2),
                 (2, "k_gemv1<4,1,false,2,EPI_F32_BIAS_RESID> self-attention over the KV cache + out projection", Lt, S2 + 2 * nkv * hp_S * 2),
-                (3, "k_xattn_qscores + k_xattn_pv: LN + cross query, scores and P.V over the cross K/V", 2 * Lt, (S2 + 2 * T * hp_S * 2) // 2),
+                (3, "k_xattn_fused<1,true>: LN + cross query, scores, soft-max numerators and P.V over the cross K/V (one launch)", Lt, S2 + 2 * T * hp_S * 2),
                 (4, "k_gemv1<4,1,false,3,EPI_F32_BIAS_RESID> cross-attention combine + out projection", Lt, S2),
                 (5, "k_gemv1<4,1,false,1,EPI_F16_BIAS_GELU> LN + mlp.0", Lt, 4 * S2),
                 (6, "k_gemv1<4,4,false,0,EPI_F32_BIAS_RESID> mlp.2", Lt, 4 * S2),

@@ -237,19 +237,19 @@ static void enqueue_rows_step(whisper_context & ctx, int nb) {
             if (M & 8) k::gemv(g, s);
         }
         {   // LN2 + cross query (folded into the score kernel) + cross-attention partials over each row's own chunk
-            const float * po = nullptr, * pl = nullptr; int ns = 0;
-            if (!(M & 16)) k::attn_cross_partials_layout(nb, H, Tc, b.xattn, &po, &pl, &ns);
+            const float * po = nullptr, * pl = nullptr, * pm = nullptr; int ns = 0;
+            if (!(M & 16)) k::attn_cross_partials_layout(nb, H, Tc, b.xattn, &po, &pl, &pm, &ns);
             else if (S > 1536) {                            // wider than three 512-column chunks: separate projection launch (see device.cpp)
                 k::GemvArgs g = base(S, S, l.w_cq, l.b_cq, k::EPI_Q_SCALED, b.dq, S);
                 g.x32 = b.dx; g.ln_g = l.ln2_g; g.ln_b = l.ln2_b; g.scale = kq_scale;
                 k::gemv(g, s);
                 k::attn_cross_split_partials(b.dq, nb, S, H, b.kvc_k + (size_t) il * cross_layer, b.kvc_v + (size_t) il * cross_layer, Tc,
-                                             b.xattn, &po, &pl, &ns, s, (int64_t) Tc * S);
+                                             b.xattn, &po, &pl, &pm, &ns, s, (int64_t) Tc * S);
             } else
             k::attn_cross_qsplit_partials(b.dx, l.ln2_g, l.ln2_b, hp.eps, l.w_cq, l.b_cq, kq_scale, nb, S, H,
                                           b.kvc_k + (size_t) il * cross_layer, b.kvc_v + (size_t) il * cross_layer, Tc,
-                                          b.xattn, &po, &pl, &ns, s, (int64_t) Tc * S);
-            if (M & 32) k::attn_cross_combine(po, pl, ns, nb, S, H, b.datt, s);
+                                          b.xattn, &po, &pl, &pm, &ns, s, (int64_t) Tc * S);
+            if (M & 32) k::attn_cross_combine(po, pl, pm, ns, nb, S, H, b.datt, s);
             k::GemvArgs g = base(S, S, l.w_co, l.b_co, k::EPI_F32_BIAS_RESID, b.dx, S);
             g.a16 = b.datt; g.resid = b.dx;
             if (M & 64) k::gemv(g, s);

@@ -562,17 +562,17 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = fa
         }
         {   // LN2 + cross query folded into the score kernel; partials combined inside the out-projection's prologue
             static const bool unfused_q = getenv("WMI_XATTN_UNFUSED_Q") != nullptr;          // debug / A-B
-            const float * po = nullptr, * pl = nullptr; int ns = 0;
-            if (!(M & 8)) { k::attn_cross_partials_layout(1, H, Tc, d.xattn, &po, &pl, &ns); }
+            const float * po = nullptr, * pl = nullptr, * pm = nullptr; int ns = 0;
+            if (!(M & 8)) { k::attn_cross_partials_layout(1, H, Tc, d.xattn, &po, &pl, &pm, &ns); }
             else if (unfused_q || S > 1536) {                  // the fused kernel keeps a whole row per wavefront in registers: S <= 1536
                 gv(k::EPI_Q_SCALED, l.ln2_g, l.ln2_b, nullptr, S, S, l.w_cq, l.b_cq, d.dq, S, nullptr, nullptr, nullptr, kq_scale, nullptr);
-                k::attn_cross_split_partials(d.dq, 1, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, &po, &pl, &ns, s);
+                k::attn_cross_split_partials(d.dq, 1, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, &po, &pl, &pm, &ns, s);
             } else
             k::attn_cross_qsplit_partials(d.dx, l.ln2_g, l.ln2_b, hp.eps, l.w_cq, l.b_cq, kq_scale, 1, S, H,
-                                          d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, &po, &pl, &ns, s);
+                                          d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, &po, &pl, &pm, &ns, s);
             chk("cross-attn", il);
             k::GemvArgs g{};
-            g.comb_o = po; g.comb_l = pl; g.comb_ns = ns; g.n = 1; g.K = S; g.N = S; g.W = l.w_co; g.bias = l.b_co; g.epi = k::EPI_F32_BIAS_RESID;
+            g.comb_o = po; g.comb_l = pl; g.comb_m = pm; g.comb_ns = ns; g.n = 1; g.K = S; g.N = S; g.W = l.w_co; g.bias = l.b_co; g.epi = k::EPI_F32_BIAS_RESID;
             g.C = d.dx; g.ldc = S; g.resid = d.dx; g.ldr = S; g.S = S;
             if (M & 16) k::gemv(g, s);
         }

@@ -160,11 +160,11 @@ void enqueue_greedy_step_q(whisper_context & ctx, int Tc) {
     const float kq_scale = powf((float) S / H, -0.25f);
     k::qdec_embed_step((const k::DecStep *) d.step_host, (k::DecStep *) d.step_dev, S, w.q_te, w.d_pe, d.dx, s);
     auto rows = [&](int epi, const Src & src, int K, int N, const k::QMat & W, const float * bias, void * C, int ldc, const float * resid,
-                    void * aux, void * aux2, float scale, const int32_t * row_off, const float * co = nullptr, const float * cl = nullptr, int cns = 0) {
+                    void * aux, void * aux2, float scale, const int32_t * row_off, const float * co = nullptr, const float * cl = nullptr, int cns = 0, const float * cm = nullptr) {
         k::GemvArgs g{};
         g.x32 = src.x32; g.ln_g = src.ln_g; g.ln_b = src.ln_b; g.eps = hp.eps; g.a16 = src.x16; g.n = 1; g.K = K; g.N = N;
         g.bias = bias; g.epi = epi; g.C = C; g.ldc = ldc; g.resid = resid; g.ldr = S; g.aux = aux; g.ldaux = S; g.aux2 = aux2; g.ldaux2 = S;
-        g.scale = scale; g.S = S; g.row_off = row_off; g.comb_o = co; g.comb_l = cl; g.comb_ns = cns;
+        g.scale = scale; g.S = S; g.row_off = row_off; g.comb_o = co; g.comb_l = cl; g.comb_ns = cns; g.comb_m = cm;
         k::qrows(g, src.ln_g ? nullptr : src.x32, W, s);
     };
     for (int il = 0; il < Lt; ++il) {
@@ -177,9 +177,9 @@ void enqueue_greedy_step_q(whisper_context & ctx, int Tc) {
         rows(k::EPI_F32_BIAS_RESID, att, S, S, l.q_o, l.b_o, d.dx, S, d.dx, nullptr, nullptr, 0.f, nullptr);
         Src ln2; ln2.x32 = d.dx; ln2.ln_g = l.ln2_g; ln2.ln_b = l.ln2_b;
         rows(k::EPI_Q_SCALED, ln2, S, S, l.q_cq, l.b_cq, d.dq, S, nullptr, nullptr, nullptr, kq_scale, nullptr);
-        const float * po = nullptr, * pl = nullptr; int ns = 0;
-        k::attn_cross_split_partials(d.dq, 1, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, &po, &pl, &ns, s);
-        rows(k::EPI_F32_BIAS_RESID, Src{}, S, S, l.q_co, l.b_co, d.dx, S, d.dx, nullptr, nullptr, 0.f, nullptr, po, pl, ns);
+        const float * po = nullptr, * pl = nullptr, * pm = nullptr; int ns = 0;
+        k::attn_cross_split_partials(d.dq, 1, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, &po, &pl, &pm, &ns, s);
+        rows(k::EPI_F32_BIAS_RESID, Src{}, S, S, l.q_co, l.b_co, d.dx, S, d.dx, nullptr, nullptr, 0.f, nullptr, po, pl, ns, pm);
         Src ln3; ln3.x32 = d.dx; ln3.ln_g = l.ln3_g; ln3.ln_b = l.ln3_b;
         rows(k::EPI_F16_BIAS_GELU, ln3, S, 4 * S, l.q_fc1, l.b_fc1, d.dh, 4 * S, nullptr, nullptr, nullptr, 0.f, nullptr);
         Src hh; hh.x16 = d.dh;

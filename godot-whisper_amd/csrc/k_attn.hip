@@ -578,12 +578,230 @@ __global__ __launch_bounds__(256) void k_xattn_pv(const __half * __restrict__ vc
     if (tid == 0) part_l[row * ns + slice] = (lred[0] + lred[1]) + (lred[2] + lred[3]);
 }
 
+// Scores, soft-max numerators and P.V of a key slice in ONE launch (flash-decoding form): every (slice, head, row) workgroup
+// keeps its <= 192 scores in registers, takes the SLICE maximum m_s, e = exp16(s - m_s), and writes (m_s, l_s = sum e,
+// o_s = e.V); the consumer rescales by exp(m_s - max m) when it combines (GemvArgs::comb_m, k_xattn_combine).  The two-launch
+// form above evaluates the reference's soft-max literally (global maximum before the f16 exponent table); here an element's
+// f16 roundings happen relative to its slice's maximum instead — the same two roundings per element, a different argument —
+// and the step saves one dependent launch per decoder layer (~3.5 us of ~9).  PROJ: the query projection of k_xattn_qscores
+// (LN2(x) . W_cq rows of this head, S <= 512 NC) runs first, else q comes as f16.
+// Lane = (key g = lane / 8, 16-byte octet o = lane % 8) for K and V alike; a wavefront owns 6 passes x 8 keys.
+template <int NC, bool PROJ>
+__global__ __launch_bounds__(256) void k_xattn_fused(const float * __restrict__ x32, const float * __restrict__ ln_g,
+                                                     const float * __restrict__ ln_b, float eps,
+                                                     const __half * __restrict__ wq, const float * __restrict__ bq, float qscale,
+                                                     const __half * __restrict__ q16,
+                                                     int S, const __half * __restrict__ kc, const __half * __restrict__ vc, int T, int ks, int ns,
+                                                     float * __restrict__ pmax, float * __restrict__ part_o, float * __restrict__ part_l,
+                                                     int64_t kv_row_stride) {
+    __shared__ float qs[64];
+    __shared__ float red[4], lred[4];
+    __shared__ float ored[4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int slice = blockIdx.x, head = blockIdx.y, i = blockIdx.z, H = gridDim.y;
+    const size_t row = (size_t) i * H + head;
+    kc += (int64_t) i * kv_row_stride; vc += (int64_t) i * kv_row_stride;
+    constexpr int KPASS = 6;                                        // 4 wavefronts x 6 passes x 8 keys = 192 >= ks
+    const int g = lane >> 3, o = lane & 7;
+    const int kpw = (((ks + 3) >> 2) + 7) & ~7;                     // keys per wavefront, whole passes
+    const int t0 = wave * kpw;
+    bool ok[KPASS]; size_t off[KPASS];
+#pragma unroll
+    for (int p = 0; p < KPASS; ++p) {
+        const int t = t0 + 8 * p + g, j = slice * ks + t;
+        ok[p] = 8 * p < kpw && t < ks && j < T;
+        off[p] = (size_t) (ok[p] ? j : 0) * S + head * 64 + o * 8;
+    }
+    uint4 kk[KPASS], vv[KPASS];
+    if constexpr (PROJ) {
+        bool on[NC]; int c0[NC];
+#pragma unroll
+        for (int t = 0; t < NC; ++t) { on[t] = lane * 8 + 512 * t < S; c0[t] = on[t] ? lane * 8 + 512 * t : 0; }
+        uint4 w[NC][16];
+        const __half * wrow0 = wq + (size_t) (head * 64 + wave * 16) * S;
+#pragma unroll
+        for (int t = 0; t < NC; ++t)
+#pragma unroll
+            for (int u = 0; u < 16; ++u) w[t][u] = *(const uint4 *) (wrow0 + (size_t) u * S + c0[t]);
+        float xv[NC][8], gv[NC][8], bv[NC][8];
+#pragma unroll
+        for (int t = 0; t < NC; ++t) {
+            const float * xr = x32 + (size_t) i * S + c0[t];
+            const float4 x0 = *(const float4 *) xr, x1 = *(const float4 *) (xr + 4);
+            const float4 g0 = *(const float4 *) (ln_g + c0[t]), g1 = *(const float4 *) (ln_g + c0[t] + 4);
+            const float4 b0 = *(const float4 *) (ln_b + c0[t]), b1 = *(const float4 *) (ln_b + c0[t] + 4);
+            xv[t][0] = x0.x; xv[t][1] = x0.y; xv[t][2] = x0.z; xv[t][3] = x0.w; xv[t][4] = x1.x; xv[t][5] = x1.y; xv[t][6] = x1.z; xv[t][7] = x1.w;
+            gv[t][0] = g0.x; gv[t][1] = g0.y; gv[t][2] = g0.z; gv[t][3] = g0.w; gv[t][4] = g1.x; gv[t][5] = g1.y; gv[t][6] = g1.z; gv[t][7] = g1.w;
+            bv[t][0] = b0.x; bv[t][1] = b0.y; bv[t][2] = b0.z; bv[t][3] = b0.w; bv[t][4] = b1.x; bv[t][5] = b1.y; bv[t][6] = b1.z; bv[t][7] = b1.w;
+        }
+        const float bias = bq ? bq[head * 64 + wave * 16 + ((lane >> 2) & 15)] : 0.0f;
+#pragma unroll
+        for (int p = 0; p < KPASS; ++p) kk[p] = *(const uint4 *) (kc + off[p]);
+        if constexpr (NC == 1) {
+#pragma unroll
+            for (int p = 0; p < KPASS; ++p) vv[p] = *(const uint4 *) (vc + off[p]);
+        }
+        __builtin_amdgcn_sched_barrier(0);          // everything this workgroup reads is in flight before the first use
+#pragma unroll
+        for (int t = 0; t < NC; ++t) {
+            if (!on[t]) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) w[t][u] = make_uint4(0u, 0u, 0u, 0u);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { xv[t][e] = 0.0f; gv[t][e] = 0.0f; bv[t][e] = 0.0f; }
+            }
+        }
+        float sum = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NC; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += xv[t][e];
+        for (int x = 32; x > 0; x >>= 1) sum += __shfl_xor(sum, x);
+        const float mean = sum / (float) S;
+        float sq = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NC; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { if (on[t]) { xv[t][e] -= mean; sq += xv[t][e] * xv[t][e]; } }
+        for (int x = 32; x > 0; x >>= 1) sq += __shfl_xor(sq, x);
+        const float scl = 1.0f / sqrtf(sq / (float) S + eps);
+        float av[NC][8];
+#pragma unroll
+        for (int t = 0; t < NC; ++t)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) av[t][e] = round_f16(__fadd_rn(__fmul_rn(xv[t][e] * scl, gv[t][e]), bv[t][e]));
+        float acc[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            float a = 0.0f;
+#pragma unroll
+            for (int t = 0; t < NC; ++t) {
+                const __half2 * wh = (const __half2 *) &w[t][u];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float2 f = __half22float2(wh[e]);
+                    a = fmaf(f.x, av[t][2 * e], a);
+                    a = fmaf(f.y, av[t][2 * e + 1], a);
+                }
+            }
+            acc[u] = a;
+        }
+        // halving exchange (k_xattn_qscores): lane L ends with the dot product of row (L >> 2) & 15
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool hi = lane & 32;
+            const float keep = hi ? acc[u + 8] : acc[u], send = hi ? acc[u] : acc[u + 8];
+            acc[u] = keep + __shfl_xor(send, 32);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool hi = lane & 16;
+            const float keep = hi ? acc[u + 4] : acc[u], send = hi ? acc[u] : acc[u + 4];
+            acc[u] = keep + __shfl_xor(send, 16);
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const bool hi = lane & 8;
+            const float keep = hi ? acc[u + 2] : acc[u], send = hi ? acc[u] : acc[u + 2];
+            acc[u] = keep + __shfl_xor(send, 8);
+        }
+        {
+            const bool hi = lane & 4;
+            const float keep = hi ? acc[1] : acc[0], send = hi ? acc[0] : acc[1];
+            acc[0] = keep + __shfl_xor(send, 4);
+        }
+        acc[0] += __shfl_xor(acc[0], 2);
+        acc[0] += __shfl_xor(acc[0], 1);
+        if ((lane & 3) == 0) qs[wave * 16 + ((lane >> 2) & 15)] = round_f16((acc[0] + bias) * qscale);
+        if constexpr (NC > 1) {                      // the projection's weights held the registers: V goes out now, behind the scores
+#pragma unroll
+            for (int p = 0; p < KPASS; ++p) vv[p] = *(const uint4 *) (vc + off[p]);
+        }
+    } else {
+        if (tid < 64) qs[tid] = __half2float(q16[(size_t) i * S + head * 64 + tid]);
+#pragma unroll
+        for (int p = 0; p < KPASS; ++p) kk[p] = *(const uint4 *) (kc + off[p]);
+#pragma unroll
+        for (int p = 0; p < KPASS; ++p) vv[p] = *(const uint4 *) (vc + off[p]);
+    }
+    __syncthreads();
+
+    float qo[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qo[e] = qs[o * 8 + e];
+    float sv[KPASS];
+    float lmax = -INFINITY;
+#pragma unroll
+    for (int p = 0; p < KPASS; ++p) {
+        const __half2 * h = (const __half2 *) &kk[p];
+        float dot = 0.0f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float2 f = __half22float2(h[e]);
+            dot = fmaf(f.x, qo[2 * e], dot);
+            dot = fmaf(f.y, qo[2 * e + 1], dot);
+        }
+        dot += __shfl_xor(dot, 1); dot += __shfl_xor(dot, 2); dot += __shfl_xor(dot, 4);     // the 8 octets of a key
+        sv[p] = ok[p] ? dot : -INFINITY;
+        lmax = fmaxf(lmax, sv[p]);
+    }
+    for (int x = 32; x > 4; x >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, x));       // the octet lanes of a key agree already
+    if (lane == 0) red[wave] = lmax;
+    __syncthreads();
+    const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float acc[8], lsum = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 8; ++d) acc[d] = 0.0f;
+#pragma unroll
+    for (int p = 0; p < KPASS; ++p) {
+        const float e = ok[p] ? exp16(sv[p] - m) : 0.0f;
+        if (o == 0) lsum += e;
+        const __half2 * h = (const __half2 *) &vv[p];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float2 f = __half22float2(h[q]);
+            acc[2 * q]     = fmaf(e, f.x, acc[2 * q]);
+            acc[2 * q + 1] = fmaf(e, f.y, acc[2 * q + 1]);
+        }
+    }
+    for (int x = 32; x > 0; x >>= 1) lsum += __shfl_xor(lsum, x);
+#pragma unroll
+    for (int d = 0; d < 8; ++d) {
+        float v = acc[d];
+        v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        acc[d] = v;
+    }
+    if (g == 0) {
+#pragma unroll
+        for (int d = 0; d < 8; ++d) ored[wave][o * 8 + d] = acc[d];
+    }
+    if (lane == 0) lred[wave] = lsum;
+    __syncthreads();
+    if (tid < 64) part_o[(row * ns + slice) * 64 + tid] = (ored[0][tid] + ored[1][tid]) + (ored[2][tid] + ored[3][tid]);
+    if (tid == 0) { part_l[row * ns + slice] = (lred[0] + lred[1]) + (lred[2] + lred[3]); pmax[row * ns + slice] = m; }
+}
+
+// weight of slice s2 when partials are relative to their own slice maximum (part_m != null), else 1
+__device__ __forceinline__ float slice_weight(const float * part_m, size_t base, int ns, int s2, float M) {
+    (void) ns;
+    const float ms = part_m[base + s2];
+    return ms > -INFINITY ? expf(ms - M) : 0.0f;
+}
+
 __global__ __launch_bounds__(64) void k_xattn_combine(const float * __restrict__ part_o, const float * __restrict__ part_l,
+                                                      const float * __restrict__ part_m,
                                                       int ns, int S, __half * __restrict__ out, float * __restrict__ out32) {
     const int head = blockIdx.x, i = blockIdx.y, H = gridDim.x, d = threadIdx.x;
     const size_t row = (size_t) i * H + head;
     float o = 0.0f; double l = 0.0;
-    if (ns == 8) {
+    if (part_m) {
+        float M = -INFINITY;
+        for (int s2 = 0; s2 < ns; ++s2) M = fmaxf(M, part_m[row * ns + s2]);
+        for (int s2 = 0; s2 < ns; ++s2) {
+            const float w = slice_weight(part_m, row * ns, ns, s2, M);
+            o += part_o[(row * ns + s2) * 64 + d] * w; l += (double) part_l[row * ns + s2] * (double) w;
+        }
+    } else if (ns == 8) {
         float po[8], pl[8];
 #pragma unroll
         for (int s2 = 0; s2 < 8; ++s2) { po[s2] = part_o[(row * 8 + s2) * 64 + d]; pl[s2] = part_l[row * 8 + s2]; }
@@ -598,73 +816,84 @@ __global__ __launch_bounds__(64) void k_xattn_combine(const float * __restrict__
 
 } // namespace
 
+// scratch layout: scores [n][H][Tpad] | pmax [n][H][NS] | part_l [n][H][NS] | part_o [n][H][NS][64]
+struct XLayout { int ns, ks, ld_sc; float * sc, * pmax, * part_l, * part_o; bool fused; };
+static XLayout xattn_layout(int n, int H, int T, float * scratch) {
+    // WMI_XATTN_TWO_PASS: the literal two-launch form (global maximum before the f16 exponent), kept for A/B and as the S-agnostic fall-back
+    static const bool two_pass = getenv("WMI_XATTN_TWO_PASS") != nullptr;
+    XLayout L;
+    L.ns = (T + 191) / 192; if (L.ns < 1) L.ns = 1; if (L.ns > XS_MAX_SLICES) L.ns = XS_MAX_SLICES;
+    L.ks = (T + L.ns - 1) / L.ns;
+    L.ld_sc = (T + 63) & ~63;
+    L.sc = scratch;
+    L.pmax = L.sc + (size_t) n * H * L.ld_sc;
+    L.part_l = L.pmax + (size_t) n * H * L.ns;
+    L.part_o = L.part_l + (size_t) n * H * L.ns;
+    L.fused = !two_pass && L.ks <= 192;               // one pass keeps a slice's scores in registers: 4 wavefronts x 6 x 8 keys
+    return L;
+}
+static int g_xattn_probe_skip = 0;        // probe only: bit 0 skips the score kernel, bit 1 the P.V kernel (two-pass form)
+void set_xattn_probe_skip(int mask) { g_xattn_probe_skip = mask; }
+
+static void xattn_run(const XLayout & L, const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int T,
+                      hipStream_t st, int64_t kv_row_stride) {
+    if (L.fused) {
+        hipLaunchKernelGGL((k_xattn_fused<1, false>), dim3(L.ns, H, n), dim3(256), 0, st, nullptr, nullptr, nullptr, 0.0f, nullptr, nullptr, 0.0f,
+                           q, S, kc, vc, T, L.ks, L.ns, L.pmax, L.part_o, L.part_l, kv_row_stride);
+        return;
+    }
+    hipLaunchKernelGGL(k_xattn_scores, dim3(L.ns, H, n), dim3(256), 0, st, q, S, kc, T, L.ks, L.ns, L.sc, L.ld_sc, L.pmax, kv_row_stride);
+    const size_t smem = (((size_t) L.ks + 3) & ~(size_t) 3) * 4 + 4 * 64 * 4;
+    hipLaunchKernelGGL(k_xattn_pv, dim3(L.ns, H, n), dim3(256), smem, st, vc, S, T, L.ks, L.ns, L.sc, L.ld_sc, L.pmax, L.part_o, L.part_l, kv_row_stride);
+}
+
 void attn_cross_split(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int T,
                       float * scratch, __half * out, hipStream_t st, int64_t kv_row_stride, float * out32) {
-    // scratch layout: scores [n][H][Tpad] | pmax [n][H][NS] | part_l [n][H][NS] | part_o [n][H][NS][64]
-    int ns = (T + 191) / 192; if (ns < 1) ns = 1; if (ns > XS_MAX_SLICES) ns = XS_MAX_SLICES;
-    const int ks = (T + ns - 1) / ns;
-    const int ld_sc = (T + 63) & ~63;
-    float * sc = scratch;
-    float * pmax = sc + (size_t) n * H * ld_sc;
-    float * part_l = pmax + (size_t) n * H * ns;
-    float * part_o = part_l + (size_t) n * H * ns;
-    hipLaunchKernelGGL(k_xattn_scores, dim3(ns, H, n), dim3(256), 0, st, q, S, kc, T, ks, ns, sc, ld_sc, pmax, kv_row_stride);
-    const size_t smem = (((size_t) ks + 3) & ~(size_t) 3) * 4 + 4 * 64 * 4;
-    hipLaunchKernelGGL(k_xattn_pv, dim3(ns, H, n), dim3(256), smem, st, vc, S, T, ks, ns, sc, ld_sc, pmax, part_o, part_l, kv_row_stride);
-    hipLaunchKernelGGL(k_xattn_combine, dim3(H, n), dim3(64), 0, st, part_o, part_l, ns, S, out, out32);
+    const XLayout L = xattn_layout(n, H, T, scratch);
+    xattn_run(L, q, n, S, H, kc, vc, T, st, kv_row_stride);
+    hipLaunchKernelGGL(k_xattn_combine, dim3(H, n), dim3(64), 0, st, L.part_o, L.part_l, L.fused ? L.pmax : nullptr, L.ns, S, out, out32);
 }
 
 void attn_cross_split_partials(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int T,
-                               float * scratch, const float ** po, const float ** pl, int * pns, hipStream_t st,
+                               float * scratch, const float ** po, const float ** pl, const float ** pm, int * pns, hipStream_t st,
                                int64_t kv_row_stride) {
-    int ns = (T + 191) / 192; if (ns < 1) ns = 1; if (ns > XS_MAX_SLICES) ns = XS_MAX_SLICES;
-    const int ks = (T + ns - 1) / ns;
-    const int ld_sc = (T + 63) & ~63;
-    float * sc = scratch;
-    float * pmax = sc + (size_t) n * H * ld_sc;
-    float * part_l = pmax + (size_t) n * H * ns;
-    float * part_o = part_l + (size_t) n * H * ns;
-    hipLaunchKernelGGL(k_xattn_scores, dim3(ns, H, n), dim3(256), 0, st, q, S, kc, T, ks, ns, sc, ld_sc, pmax, kv_row_stride);
-    const size_t smem = (((size_t) ks + 3) & ~(size_t) 3) * 4 + 4 * 64 * 4;
-    hipLaunchKernelGGL(k_xattn_pv, dim3(ns, H, n), dim3(256), smem, st, vc, S, T, ks, ns, sc, ld_sc, pmax, part_o, part_l, kv_row_stride);
-    *po = part_o; *pl = part_l; *pns = ns;
+    const XLayout L = xattn_layout(n, H, T, scratch);
+    xattn_run(L, q, n, S, H, kc, vc, T, st, kv_row_stride);
+    *po = L.part_o; *pl = L.part_l; *pm = L.fused ? L.pmax : nullptr; *pns = L.ns;
 }
 
-void attn_cross_combine(const float * part_o, const float * part_l, int ns, int n, int S, int H, __half * out, hipStream_t st, float * out32) {
-    hipLaunchKernelGGL(k_xattn_combine, dim3(H, n), dim3(64), 0, st, part_o, part_l, ns, S, out, out32);
+void attn_cross_combine(const float * part_o, const float * part_l, const float * part_m, int ns, int n, int S, int H, __half * out,
+                        hipStream_t st, float * out32) {
+    hipLaunchKernelGGL(k_xattn_combine, dim3(H, n), dim3(64), 0, st, part_o, part_l, part_m, ns, S, out, out32);
 }
 
-static int g_xattn_probe_skip = 0;        // probe only: bit 0 skips the score kernel, bit 1 the P.V kernel
-void set_xattn_probe_skip(int mask) { g_xattn_probe_skip = mask; }
-void attn_cross_partials_layout(int n, int H, int T, float * scratch, const float ** po, const float ** pl, int * pns) {
-    int ns = (T + 191) / 192; if (ns < 1) ns = 1; if (ns > XS_MAX_SLICES) ns = XS_MAX_SLICES;
-    const int ld_sc = (T + 63) & ~63;
-    float * pmax = scratch + (size_t) n * H * ld_sc;
-    float * part_l = pmax + (size_t) n * H * ns;
-    *po = part_l + (size_t) n * H * ns; *pl = part_l; *pns = ns;
+void attn_cross_partials_layout(int n, int H, int T, float * scratch, const float ** po, const float ** pl, const float ** pm, int * pns) {
+    const XLayout L = xattn_layout(n, H, T, scratch);
+    *po = L.part_o; *pl = L.part_l; *pm = L.fused ? L.pmax : nullptr; *pns = L.ns;
 }
 
 void attn_cross_qsplit_partials(const float * x32, const float * ln_g, const float * ln_b, float eps, const __half * wq,
                                 const float * bq, float qscale, int n, int S, int H, const __half * kc, const __half * vc, int T,
-                                float * scratch, const float ** po, const float ** pl, int * pns, hipStream_t st,
+                                float * scratch, const float ** po, const float ** pl, const float ** pm, int * pns, hipStream_t st,
                                 int64_t kv_row_stride) {
-    int ns = (T + 191) / 192; if (ns < 1) ns = 1; if (ns > XS_MAX_SLICES) ns = XS_MAX_SLICES;
-    const int ks = (T + ns - 1) / ns;
-    const int ld_sc = (T + 63) & ~63;
-    float * sc = scratch;
-    float * pmax = sc + (size_t) n * H * ld_sc;
-    float * part_l = pmax + (size_t) n * H * ns;
-    float * part_o = part_l + (size_t) n * H * ns;
+    const XLayout L = xattn_layout(n, H, T, scratch);
+    *po = L.part_o; *pl = L.part_l; *pm = L.fused ? L.pmax : nullptr; *pns = L.ns;
+    if (L.fused) {
+        if (g_xattn_probe_skip & 1) return;
+        auto kern = S <= 512 ? k_xattn_fused<1, true> : S <= 1024 ? k_xattn_fused<2, true> : k_xattn_fused<3, true>;      // S <= 1536
+        hipLaunchKernelGGL(kern, dim3(L.ns, H, n), dim3(256), 0, st, x32, ln_g, ln_b, eps, wq, bq, qscale, nullptr, S, kc, vc, T, L.ks, L.ns,
+                           L.pmax, L.part_o, L.part_l, kv_row_stride);
+        return;
+    }
     if (!(g_xattn_probe_skip & 1))
     {
         auto kern = S <= 512 ? k_xattn_qscores<1> : S <= 1024 ? k_xattn_qscores<2> : k_xattn_qscores<3>;      // S <= 1536
-        hipLaunchKernelGGL(kern, dim3(ns, H, n), dim3(256), 0, st, x32, ln_g, ln_b, eps, wq, bq, qscale, S, kc, T, ks, ns,
-                           sc, ld_sc, pmax, kv_row_stride);
+        hipLaunchKernelGGL(kern, dim3(L.ns, H, n), dim3(256), 0, st, x32, ln_g, ln_b, eps, wq, bq, qscale, S, kc, T, L.ks, L.ns,
+                           L.sc, L.ld_sc, L.pmax, kv_row_stride);
     }
-    const size_t smem = (((size_t) ks + 3) & ~(size_t) 3) * 4 + 4 * 64 * 4;
+    const size_t smem = (((size_t) L.ks + 3) & ~(size_t) 3) * 4 + 4 * 64 * 4;
     if (!(g_xattn_probe_skip & 2))
-    hipLaunchKernelGGL(k_xattn_pv, dim3(ns, H, n), dim3(256), smem, st, vc, S, T, ks, ns, sc, ld_sc, pmax, part_o, part_l, kv_row_stride);
-    *po = part_o; *pl = part_l; *pns = ns;
+    hipLaunchKernelGGL(k_xattn_pv, dim3(L.ns, H, n), dim3(256), smem, st, vc, S, T, L.ks, L.ns, L.sc, L.ld_sc, L.pmax, L.part_o, L.part_l, kv_row_stride);
 }
 
 size_t attn_cross_scratch_floats(int n, int H, int T) {

@@ -67,6 +67,14 @@ __global__ void k_dec_embed_step(const DecStep * __restrict__ host_step, DecStep
 // This fixes the summation order of the path (octet-wise, then butterflies); every caller — the one-row prologue of
 // k_gemv1, the lock-step row kernels — goes through this routine, which keeps them bit-identical to each other.
 // Returns false, with nothing written, when n_kv > 64 (callers then take self_attn_row).
+// weight of a cross-attention slice partial in the combine: 1 when the partials are relative to the row's global maximum
+// (comb_m == null), else exp(m_slice - M) (k_xattn_fused, k_attn.hip)
+__device__ __forceinline__ float comb_weight(const float * comb_m, size_t idx, float M) {
+    if (!comb_m) return 1.0f;
+    const float ms = comb_m[idx];
+    return ms > -INFINITY ? expf(ms - M) : 0.0f;
+}
+
 template <int NU>
 __device__ __forceinline__ bool self_attn_wave(const __half * __restrict__ sq, const __half * __restrict__ sk,
                                                const __half * __restrict__ sv, const int32_t * __restrict__ n_kv_p, int K, int cap,
@@ -495,8 +503,12 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
         for (int e = tid; e < R * K; e += 256) {
             const int r = e / K, c = e - r * K, h = c >> 6, dd = c & 63;
             const size_t row = (size_t) r * H + h;
-            float o = 0.0f; double l = 0.0;
-            for (int s2 = 0; s2 < ns; ++s2) { o += a.comb_o[(row * ns + s2) * 64 + dd]; l += (double) a.comb_l[row * ns + s2]; }
+            float o = 0.0f; double l = 0.0, M = -INFINITY;
+            if (a.comb_m) for (int s2 = 0; s2 < ns; ++s2) M = fmax(M, (double) a.comb_m[row * ns + s2]);
+            for (int s2 = 0; s2 < ns; ++s2) {
+                const float w = comb_weight(a.comb_m, row * ns + s2, (float) M);
+                o += a.comb_o[(row * ns + s2) * 64 + dd] * w; l += (double) a.comb_l[row * ns + s2] * (double) w;
+            }
             act[e] = f2h(o * (float) (1.0 / l));
         }
     } else {
@@ -713,26 +725,38 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
                 // T = 1500: the 2 x 16 loads of a thread's two elements go out before the first add (element by element this
                 // was one round trip per element; a plain loop over the slices one per slice)
                 for (int e0 = tid; e0 < K; e0 += 512) {
-                    float po[2][8], pl[2][8];
+                    float po[2][8], pl[2][8], pm[2][8];
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         const int e = e0 + u * 256 < K ? e0 + u * 256 : e0, h = e >> 6, dd = e & 63;
 #pragma unroll
-                        for (int s2 = 0; s2 < 8; ++s2) { po[u][s2] = a.comb_o[((size_t) h * 8 + s2) * 64 + dd]; pl[u][s2] = a.comb_l[(size_t) h * 8 + s2]; }
+                        for (int s2 = 0; s2 < 8; ++s2) {
+                            po[u][s2] = a.comb_o[((size_t) h * 8 + s2) * 64 + dd]; pl[u][s2] = a.comb_l[(size_t) h * 8 + s2];
+                            pm[u][s2] = a.comb_m ? a.comb_m[(size_t) h * 8 + s2] : 0.0f;
+                        }
                     }
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
-                        float o = 0.0f; double l = 0.0;
+                        float o = 0.0f, M = -INFINITY; double l = 0.0;
 #pragma unroll
-                        for (int s2 = 0; s2 < 8; ++s2) { o += po[u][s2]; l += (double) pl[u][s2]; }
+                        for (int s2 = 0; s2 < 8; ++s2) M = fmaxf(M, pm[u][s2]);
+#pragma unroll
+                        for (int s2 = 0; s2 < 8; ++s2) {
+                            const float w = !a.comb_m ? 1.0f : pm[u][s2] > -INFINITY ? expf(pm[u][s2] - M) : 0.0f;
+                            o += po[u][s2] * w; l += (double) pl[u][s2] * (double) w;
+                        }
                         if (e0 + u * 256 < K) act[e0 + u * 256] = f2h(o * (float) (1.0 / l));
                     }
                 }
             } else
             for (int e = tid; e < K; e += 256) {
                 const int h = e >> 6, dd = e & 63;
-                float o = 0.0f; double l = 0.0;
-                for (int s2 = 0; s2 < ns; ++s2) { o += a.comb_o[((size_t) h * ns + s2) * 64 + dd]; l += (double) a.comb_l[(size_t) h * ns + s2]; }
+                float o = 0.0f, M = -INFINITY; double l = 0.0;
+                if (a.comb_m) for (int s2 = 0; s2 < ns; ++s2) M = fmaxf(M, a.comb_m[(size_t) h * ns + s2]);
+                for (int s2 = 0; s2 < ns; ++s2) {
+                    const float w = comb_weight(a.comb_m, (size_t) h * ns + s2, M);
+                    o += a.comb_o[((size_t) h * ns + s2) * 64 + dd] * w; l += (double) a.comb_l[(size_t) h * ns + s2] * (double) w;
+                }
                 act[e] = f2h(o * (float) (1.0 / l));
             }
             (void) H;

@@ -671,15 +671,28 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
                 const size_t row = (size_t) src * H + h;
                 float4 o = make_float4(0.f, 0.f, 0.f, 0.f); double l = 0.0;
                 if (ns == 8) {
-                    float4 po[8]; float pl[8];
+                    float4 po[8]; float pl[8], pm[8];
 #pragma unroll
-                    for (int s2 = 0; s2 < 8; ++s2) { po[s2] = *(const float4 *) (a.comb_o + (row * 8 + s2) * 64 + dd); pl[s2] = a.comb_l[row * 8 + s2]; }
+                    for (int s2 = 0; s2 < 8; ++s2) {
+                        po[s2] = *(const float4 *) (a.comb_o + (row * 8 + s2) * 64 + dd); pl[s2] = a.comb_l[row * 8 + s2];
+                        pm[s2] = a.comb_m ? a.comb_m[row * 8 + s2] : 0.0f;
+                    }
+                    float M = -INFINITY;
 #pragma unroll
-                    for (int s2 = 0; s2 < 8; ++s2) { o.x += po[s2].x; o.y += po[s2].y; o.z += po[s2].z; o.w += po[s2].w; l += (double) pl[s2]; }
+                    for (int s2 = 0; s2 < 8; ++s2) M = fmaxf(M, pm[s2]);
+#pragma unroll
+                    for (int s2 = 0; s2 < 8; ++s2) {
+                        const float w = !a.comb_m ? 1.0f : pm[s2] > -INFINITY ? expf(pm[s2] - M) : 0.0f;
+                        o.x += po[s2].x * w; o.y += po[s2].y * w; o.z += po[s2].z * w; o.w += po[s2].w * w; l += (double) pl[s2] * (double) w;
+                    }
                 } else {
+                    float M = -INFINITY;
+                    if (a.comb_m) for (int s2 = 0; s2 < ns; ++s2) M = fmaxf(M, a.comb_m[row * ns + s2]);
                     for (int s2 = 0; s2 < ns; ++s2) {
+                        const float ms = a.comb_m ? a.comb_m[row * ns + s2] : 0.0f;
+                        const float w = !a.comb_m ? 1.0f : ms > -INFINITY ? expf(ms - M) : 0.0f;
                         const float4 t = *(const float4 *) (a.comb_o + (row * ns + s2) * 64 + dd);
-                        o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w; l += (double) a.comb_l[row * ns + s2];
+                        o.x += t.x * w; o.y += t.y * w; o.z += t.z * w; o.w += t.w * w; l += (double) a.comb_l[row * ns + s2] * (double) w;
                     }
                 }
                 const float inv = (float) (1.0 / l);

@@ -104,13 +104,15 @@ void attn_cross_split(const __half * q, int n, int S, int H, const __half * kc, 
                       float * scratch, __half * out, hipStream_t st, int64_t kv_row_stride = 0, float * out32 = nullptr);
 // same without the combine launch: the consumer GEMV combines the partials in its prologue (GemvArgs::comb_*)
 void attn_cross_split_partials(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int T,
-                               float * scratch, const float ** part_o, const float ** part_l, int * ns, hipStream_t st,
+                               float * scratch, const float ** part_o, const float ** part_l, const float ** part_m, int * ns, hipStream_t st,
                                int64_t kv_row_stride = 0);   // row i reads kc/vc + i * kv_row_stride (lock-step chunks)
+// part_m: null when the partials are relative to the row's global maximum (two-launch form), else the slice maxima the
+// consumer rescales by (one-launch form, k_xattn_fused) — pass it on as GemvArgs::comb_m / to attn_cross_combine
 // the same with the query projection folded into the score kernel: q = (W_cq . LN(x32) + b_cq) * qscale is recomputed per
 // (slice, head) workgroup (bit-identical to gemv + EPI_Q_SCALED); saves one launch per decoder layer
 void attn_cross_qsplit_partials(const float * x32, const float * ln_g, const float * ln_b, float eps, const __half * wq,
                                 const float * bq, float qscale, int n, int S, int H, const __half * kc, const __half * vc, int T,
-                                float * scratch, const float ** part_o, const float ** part_l, int * ns, hipStream_t st,
+                                float * scratch, const float ** part_o, const float ** part_l, const float ** part_m, int * ns, hipStream_t st,
                                 int64_t kv_row_stride = 0);
 size_t attn_cross_scratch_floats(int n, int H, int T);
 
@@ -132,6 +134,7 @@ struct GemvArgs {
     const int32_t * rows;                     // optional row gather for the A operand (logits)
     const int32_t * row_off;                  // optional device scalar: aux/aux2 row offset (KV cache head), graph replay
     const float * comb_o; const float * comb_l; int comb_ns;   // optional: A operand = combined split cross-attention partials
+    const float * comb_m;                     // slice maxima the partials are relative to (null: the row's global maximum)
     // optional (n == 1): A operand = self-attention output computed in the prologue from q and this layer's KV cache
     const __half * sa_q; const __half * sa_k; const __half * sa_v; const int32_t * sa_nkv; int sa_cap;
     // lock-step chunks (lanes != 0): row r belongs to chunk r with its own KV cache and step record.
@@ -145,8 +148,8 @@ void self_attn_rows(const __half * q, int n, int K, const __half * kc, const __h
                     const int32_t * n_kv, int step_stride, int cap, __half * out, hipStream_t st, float * out32 = nullptr);
 // split cross-attention partials -> out [n][S] f16 (the separate form of GemvArgs::comb_*)
 void set_xattn_probe_skip(int mask);      // probe only
-void attn_cross_partials_layout(int n, int H, int T, float * scratch, const float ** po, const float ** pl, int * pns);
-void attn_cross_combine(const float * part_o, const float * part_l, int ns, int n, int S, int H, __half * out, hipStream_t st,
+void attn_cross_partials_layout(int n, int H, int T, float * scratch, const float ** po, const float ** pl, const float ** pm, int * pns);
+void attn_cross_combine(const float * part_o, const float * part_l, const float * part_m, int ns, int n, int S, int H, __half * out, hipStream_t st,
                         float * out32 = nullptr);
 enum { EPI_LOGITS = 100 };                    // C f32 [n][N] = acc
 void gemv(const GemvArgs & a, hipStream_t st);

@@ -17,7 +17,7 @@ def chain(mask, it=100):
     return lib.wmi_bench_kernel(node.ctx, 20, it)
 full = chain(0x1ff)
 print("whole step: %.1f us" % full)
-kinds = [("embed", 1, 1), ("qkv (LN)", 2, 6), ("self-attn + out", 4, 6), ("cross scores + P.V", 8, 12), ("  scores only", 8 | 1024, 6), ("  P.V only", 8 | 512, 6),
+kinds = [("embed", 1, 1), ("qkv (LN)", 2, 6), ("self-attn + out", 4, 6), ("cross-attention (fused)", 8, 6),
          ("combine + cross out", 16, 6), ("mlp.0 (LN, GELU)", 32, 6), ("mlp.2 (K = 4S)", 64, 6), ("logits", 128, 1), ("filters (2 kernels)", 256, 2)]
 tot = 0.0
 for name, m, n in kinds:
