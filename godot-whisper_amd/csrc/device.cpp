@@ -666,7 +666,8 @@ double bench_greedy_step_chain(whisper_context & ctx, int iters) {
     if (!d.step_dev || iters <= 0) return -1.0;
     const char * mask_env = getenv("WMI_STEP_MASK");
     g_step_mask = mask_env ? (unsigned) strtoul(mask_env, nullptr, 0) : ~0u;
-    k::set_xattn_probe_skip(((g_step_mask >> 9) & 1) | (((g_step_mask >> 10) & 1) << 1));       // bits 9 / 10: skip scores / P.V inside bit 3
+    // bits 9 / 10 (only with an explicit mask): skip scores / P.V inside bit 3 — without this guard the eager chain ran without cross-attention
+    k::set_xattn_probe_skip(mask_env ? ((g_step_mask >> 9) & 1) | (((g_step_mask >> 10) & 1) << 1) : 0);
     struct Restore { ~Restore() { g_step_mask = ~0u; k::set_xattn_probe_skip(0); } } restore;
     const int Tc = st.enc_n_ctx > 0 ? st.enc_n_ctx : ctx.model.hp.n_audio_ctx;
     hipStream_t s = d.stream;

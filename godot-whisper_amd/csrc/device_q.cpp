@@ -122,8 +122,17 @@ bool decode_layers_q(whisper_context & ctx, int n, int n_kv, int kv_head, int Tc
         proj(k::EPI_F32_BIAS_RESID, att, S, S, l.q_o, l.b_o, d.dx, S, d.dx, nullptr, 0, nullptr, 0, 0.f);
         Src ln2; ln2.x32 = d.dx; ln2.ln_g = l.ln2_g; ln2.ln_b = l.ln2_b;
         proj(k::EPI_Q_SCALED, ln2, S, S, l.q_cq, l.b_cq, d.dq, S, nullptr, nullptr, 0, nullptr, 0, kq_scale);
+        if (rows_fit(n, S)) {                     // the out projection combines the key-slice partials in its prologue (one launch fewer)
+            const float * po = nullptr, * pl = nullptr, * pm = nullptr; int ns = 0;
+            k::attn_cross_split_partials(d.dq, n, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, &po, &pl, &pm, &ns, s);
+            k::GemvArgs g{};
+            g.eps = hp.eps; g.n = n; g.K = S; g.N = S; g.bias = l.b_co; g.epi = k::EPI_F32_BIAS_RESID; g.C = d.dx; g.ldc = S; g.resid = d.dx; g.ldr = S;
+            g.S = S; g.comb_o = po; g.comb_l = pl; g.comb_m = pm; g.comb_ns = ns;
+            k::qrows(g, nullptr, l.q_co, s);
+        } else {
         k::attn_cross_split(d.dq, n, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, nullptr, s, 0, d.datt32);
         proj(k::EPI_F32_BIAS_RESID, att, S, S, l.q_co, l.b_co, d.dx, S, d.dx, nullptr, 0, nullptr, 0, 0.f);
+        }
         Src ln3; ln3.x32 = d.dx; ln3.ln_g = l.ln3_g; ln3.ln_b = l.ln3_b;
         proj(k::EPI_F16_BIAS_GELU, ln3, S, 4 * S, l.q_fc1, l.b_fc1, d.dh, 4 * S, nullptr, nullptr, 0, nullptr, 0, 0.f);
         Src hh; hh.x16 = d.dh;

@@ -6,7 +6,7 @@ mkdir -p $OUT
 cd $GRAFT_REPO_ROOT
 ONLY=${ONLY:-2} rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o v3 -- python scratch/time_v3.py > $OUT/run.log 2>&1
 tail -5 $OUT/run.log
-ls $OUT
+rm -f $OUT/*kernel_trace.csv $OUT/*.db; ls $OUT
 python - <<'PY'
 import csv, glob, os
 f = glob.glob(os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/prof_v3/**/*kernel_stats.csv", recursive=True)
