@@ -83,8 +83,12 @@ __global__ __launch_bounds__(NW * 64 * KS) void k_attn_enc(const __half * __rest
         rv0 = src_[0]; rv1 = src_[1]; if constexpr (CPT == 4) { rv2 = src_[2]; rv3 = src_[3]; } } while (0)
 #define STORE_K() do { *(uint4 *) (sK + lds_off(srow, sch)) = rk0; *(uint4 *) (sK + lds_off(srow, sch + 1)) = rk1;   \
         if constexpr (CPT == 4) { *(uint4 *) (sK + lds_off(srow, sch + 2)) = rk2; *(uint4 *) (sK + lds_off(srow, sch + 3)) = rk3; } } while (0)
-#define STORE_V() do { *(uint4 *) (sV + lds_off(srow, sch)) = rv0; *(uint4 *) (sV + lds_off(srow, sch + 1)) = rv1;   \
-        if constexpr (CPT == 4) { *(uint4 *) (sV + lds_off(srow, sch + 2)) = rv2; *(uint4 *) (sV + lds_off(srow, sch + 3)) = rv3; } } while (0)
+// V^T tile: its fragments are 8-byte reads, 16 rows x {lower, upper half of a 16-byte chunk} per half-wave (ds_read_b64: lanes 0-31
+// in one LDS cycle, bank = (a / 4) mod 64); rows r and r + 8 share parity and slot, i.e. banks (PMC: SQ_LDS_BANK_CONFLICT = 26 % of
+// SQ_LDS_IDX_ACTIVE).  Rows 8-15 of every 16 therefore keep the two halves of each chunk swapped: same 16-byte stores, reads conflict-free.
+#define SWAPV(v_) ((srow & 8) ? make_uint4((v_).z, (v_).w, (v_).x, (v_).y) : (v_))
+#define STORE_V() do { *(uint4 *) (sV + lds_off(srow, sch)) = SWAPV(rv0); *(uint4 *) (sV + lds_off(srow, sch + 1)) = SWAPV(rv1);   \
+        if constexpr (CPT == 4) { *(uint4 *) (sV + lds_off(srow, sch + 2)) = SWAPV(rv2); *(uint4 *) (sV + lds_off(srow, sch + 3)) = SWAPV(rv3); } } while (0)
     auto score_tile = [&](int kt) -> floatx4 {                // S^T for keys kt*16..+15 of the staged tile
         floatx4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -155,8 +159,9 @@ __global__ __launch_bounds__(NW * 64 * KS) void k_attn_enc(const __half * __rest
             for (int nt = 0; nt < 4; ++nt) {
                 const int dv = nt * 16 + fr;
                 const int ch = ks * 4 + (fq >> 1);
-                const half4 v0 = *(const half4 *) (sV + lds_off(dv, ch) + (fq & 1) * 8);
-                const half4 v1 = *(const half4 *) (sV + lds_off(dv, ch + 2) + (fq & 1) * 8);
+                const int hv = ((fq & 1) ^ ((fr >> 3) & 1)) * 8;              // rows 8-15: halves swapped (STORE_V)
+                const half4 v0 = *(const half4 *) (sV + lds_off(dv, ch) + hv);
+                const half4 v1 = *(const half4 *) (sV + lds_off(dv, ch + 2) + hv);
                 half8 vf;
                 vf[0] = v0[0]; vf[1] = v0[1]; vf[2] = v0[2]; vf[3] = v0[3];
                 vf[4] = v1[0]; vf[5] = v1[1]; vf[6] = v1[2]; vf[7] = v1[3];
