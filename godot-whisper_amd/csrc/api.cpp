@@ -354,18 +354,21 @@ int wmi_full_device_pcm(struct whisper_context * ctx, struct whisper_full_params
 }
 
 int wmi_set_audio_ctx(struct whisper_context * ctx, int n_audio_ctx) {
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     if (n_audio_ctx < 0 || n_audio_ctx > ctx->model.hp.n_audio_ctx) return -5;
     ctx->state->exp_n_audio_ctx = n_audio_ctx;
     return 0;
 }
 
 int wmi_mel_dims(struct whisper_context * ctx, int * n_len, int * n_len_org, int * n_mel) {
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     const Mel & m = ctx->state->mel;
     if (n_len) *n_len = m.n_len; if (n_len_org) *n_len_org = m.n_len_org; if (n_mel) *n_mel = m.n_mel;
     return m.n_len * m.n_mel;
 }
 
 int wmi_get_tensor(struct whisper_context * ctx, const char * name, float * dst, int n) {
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void) hipSetDevice(ctx->device);
     State & st = *ctx->state; DeviceState & d = st.dev; const HParams & hp = ctx->model.hp;
     const int S = hp.n_audio_state, T = st.enc_n_ctx > 0 ? st.enc_n_ctx : hp.n_audio_ctx, Lt = hp.n_text_layer;
@@ -398,6 +401,7 @@ int wmi_get_tensor(struct whisper_context * ctx, const char * name, float * dst,
 }
 
 void wmi_get_timings(struct whisper_context * ctx, int64_t * t6, int32_t * n5) {
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     const State & s = *ctx->state;
     t6[0] = s.t_mel_us; t6[1] = s.t_encode_us; t6[2] = s.t_decode_us; t6[3] = s.t_batchd_us; t6[4] = s.t_prompt_us; t6[5] = s.t_sample_us;
     n5[0] = s.n_encode; n5[1] = s.n_decode; n5[2] = s.n_batchd; n5[3] = s.n_prompt; n5[4] = s.n_sample;
@@ -406,6 +410,7 @@ void wmi_get_timings(struct whisper_context * ctx, int64_t * t6, int32_t * n5) {
 int wmi_full_batch(struct whisper_context * ctx, struct whisper_full_params params, const float * const * pcm, const int * n_samples,
                    int n_chunks, int pcm_on_device) {
     if (!ctx || !ctx->state || !pcm || !n_samples || n_chunks < 0) return -1;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     (void) hipSetDevice(ctx->device);
     params.no_context = true;                 // chunks are independent transcriptions
     return full_batch(*ctx, params, pcm, n_samples, n_chunks, pcm_on_device != 0);
@@ -414,20 +419,26 @@ int wmi_full_batch(struct whisper_context * ctx, struct whisper_full_params para
 void wmi_set_lockstep_exact(int on) { k::set_rows_valu(on != 0); k::set_attn_one_group(on != 0); }
 
 int wmi_batch_select(struct whisper_context * ctx, int chunk) {
-    if (!ctx || !ctx->state || !ctx->batch || chunk < 0 || chunk >= (int) ctx->batch->results.size()) return -1;
+    if (!ctx) return -1;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!ctx->state || !ctx->batch || chunk < 0 || chunk >= (int) ctx->batch->results.size()) return -1;
     ctx->state->result_all = ctx->batch->results[chunk];
     return (int) ctx->state->result_all.size();
 }
 
 void wmi_get_batch_timings(struct whisper_context * ctx, int64_t * t4, int32_t * n_steps) {
     t4[0] = t4[1] = t4[2] = t4[3] = 0; *n_steps = 0;
-    if (!ctx || !ctx->batch) return;
+    if (!ctx) return;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!ctx->batch) return;
     const BatchWork & b = *ctx->batch;
     t4[0] = b.t_mel_us; t4[1] = b.t_encode_us; t4[2] = b.t_decode_us; t4[3] = b.t_emit_us; *n_steps = b.n_steps;
 }
 
 int wmi_batch_chunk_mode(struct whisper_context * ctx, int chunk) {
-    if (!ctx || !ctx->batch || chunk < 0 || chunk >= (int) ctx->batch->redo.size()) return -1;
+    if (!ctx) return -1;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!ctx->batch || chunk < 0 || chunk >= (int) ctx->batch->redo.size()) return -1;
     return ctx->batch->redo[chunk];
 }
 

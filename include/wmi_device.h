@@ -8,6 +8,12 @@
  * Shape follows the reference's encoder-plugin precedent
  * (W/openvino/whisper-openvino-encoder.h:12-27, W/coreml/whisper-encoder.h:14-22):
  * init / encode / free with plain pointers and sizes.  No torch types, no C++ types.
+ *
+ * Threading: a context owns one HIP stream and one set of activation / cache arenas; every entry point that touches them
+ * (whisper_full*, whisper_encode / decode, *_with_state, wmi_full_batch, wmi_get_tensor, wmi_set_audio_ctx, the timers and
+ * batch accessors) takes the context's recursive mutex, so calls on ONE context serialise (whisper.h:535 asks callers for
+ * that anyway).  Concurrency comes from several contexts — one per device (wmi_pool_*) or several per device — which share
+ * nothing but the process-wide switches wmi_set_lockstep_exact / WMI_* environment knobs.
  */
 #ifndef WMI_DEVICE_H
 #define WMI_DEVICE_H
