@@ -347,7 +347,7 @@ def main():
         if world == 1 and args.chunks == 1 and not args.no_config4:
             lib.whisper_free(ctx); node.ctx = None; ctx = None          # release base.en before the 1.2 GB model
             try:
-                out["config4_large_v3_q5_1_beam5"] = config4(lib)
+                out["config4_large_v3_q5_1_beam5"] = config4(lib, cpu=not args.no_cpu_baseline)
             except Exception as e:  # pragma: no cover
                 out["config4_error"] = repr(e)
         print(json.dumps(out), flush=True)
@@ -359,7 +359,7 @@ def main():
         dist.destroy_process_group()
 
 
-def config4(lib) -> dict:
+def config4(lib, cpu: bool = True) -> dict:
     """BASELINE configs[4]: large-v3 (32 + 32 layers, 1280 wide, 128 mels) as q5_1 ggml blocks, beam_size = 5, one 30 s chunk
     on this GPU.  The weights stay quantised in HBM (csrc/k_quant.hip); the roofline of a decode step uses the q5_1 bytes."""
     from godot_whisper_amd import abi, host, synth
@@ -381,7 +381,6 @@ def config4(lib) -> dict:
     t_model = time.perf_counter() - t0
     node = host.SpeechToText(lib); node.set_language_model(model); node.language = "en"
     file_mb = len(model) / 1e6
-    del model
     ctx = node.ctx
     arena = lib.wmi_weights_bytes(ctx, 0); mats = lib.wmi_weights_bytes(ctx, 1)
     pcm = synth.make_pcm(CHUNK_S, seed=4321)
@@ -422,6 +421,21 @@ def config4(lib) -> dict:
                               "achieved": round(vb / (us_rot * 1e-6) / 1e9, 1), "peak": 8000.0, "unit": "GB/s", "frac": round(vb / (us_rot * 1e-6) / 1e9 / 8000.0, 4),
                               "algorithmic_bytes": int(vb), "avg_us": round(us_rot, 2)}
     node.close()
+    if cpu:
+        try:
+            entry.load_oracle()
+            from oracle import reflib
+            cpu = reflib.available()                    # the scalar port would need minutes for this model: compiled reference only
+        except Exception:
+            cpu = False
+    if cpu:
+        # the reference's CPU path on the same model and chunk, beam 5: ONE transcription (tens of seconds), 32 threads — its fastest
+        # setting on this box for base.en (bench cpu_baseline_threads32)
+        try:
+            res["cpu_baseline"] = cpu_baseline(model, pcm, n_threads=min(os.cpu_count() or 4, 32), budget_s=0.0, beam_size=5, warm=False)
+        except Exception as e:  # pragma: no cover
+            res["cpu_baseline"] = {"value": None, "error": repr(e)}
+    del model
     return res
 
 
@@ -479,7 +493,8 @@ def pmc_traffic(kernel_key: str):
     return best
 
 
-def cpu_baseline(model_bytes: bytes, pcm: np.ndarray, n_threads: int | None = None, budget_s: float = 10.0) -> dict:
+def cpu_baseline(model_bytes: bytes, pcm: np.ndarray, n_threads: int | None = None, budget_s: float = 10.0, beam_size: int = 0,
+                 warm: bool = True) -> dict:
     """The reference's own CPU path (oracle/_ref, kind "reference") when its prebuilt library travelled
     with the snapshot, else this repository's CPU restatement (kind "port").  Sample: the same
     transcription (same model, same 30 s chunk, same host params), run a few times, ~10-30 s of CPU work."""
@@ -505,10 +520,18 @@ def cpu_baseline(model_bytes: bytes, pcm: np.ndarray, n_threads: int | None = No
     node = host.SpeechToText(lib)
     node.set_language_model(model_bytes)
     p = node.full_params("", 0)
+    if beam_size > 0:                                   # the host parameter set on the reference's beam-search defaults
+        from godot_whisper_amd import abi
+        q = p; p = lib.whisper_full_default_params(abi.WHISPER_SAMPLING_BEAM_SEARCH)
+        for f in ("language", "audio_ctx", "split_on_word", "token_timestamps", "suppress_non_speech_tokens", "single_segment",
+                  "max_tokens", "entropy_thold", "initial_prompt"):
+            setattr(p, f, getattr(q, f))
+        p.beam_search.beam_size = beam_size
     if n_threads:
         p.n_threads = int(n_threads)
     threads = int(p.n_threads)
-    node.transcribe(pcm, params=p)                      # warm
+    if warm:
+        node.transcribe(pcm, params=p)
     t0 = time.perf_counter(); n = 0
     while True:
         node.transcribe(pcm, params=p); n += 1
