@@ -405,13 +405,31 @@ def config4(lib, cpu: bool = True) -> dict:
         res[name] = {"value": round(CHUNK_S / dt, 1), "unit": "x realtime", "ms_per_chunk": round(dt * 1e3, 2), "tokens": max(len(r) - 1, 0),
                      "encode_ms": round(t6[1] / 1e3 / max(n5[0], 1), 3),
                      "decode_ms_total": round((t6[2] + t6[3] + t6[4]) / 1e3 / n, 3), "sample_ms_total": round(t6[5] / 1e3 / n, 3)}
+    # 8 chunks of this model in lock-step on one GPU (greedy; configs[3]'s arrangement with configs[4]'s model)
+    try:
+        nb8 = 8
+        pcms = [synth.make_pcm(CHUNK_S, seed=5000 + i) for i in range(nb8)]
+        p8 = node.full_params("", 0); p8.temperature_inc = 0.0
+        node.transcribe_batch(pcms, params=p8)
+        t1 = time.perf_counter(); reps8 = 3
+        for _ in range(reps8):
+            node.transcribe_batch(pcms, params=p8)
+        dt8 = (time.perf_counter() - t1) / reps8
+        t4 = (C.c_int64 * 4)(); ns = C.c_int32(); lib.wmi_get_batch_timings(ctx, t4, C.byref(ns))
+        res["lockstep8_greedy"] = {"value": round(nb8 * CHUNK_S / dt8, 1), "unit": "x realtime", "ms_per_call": round(dt8 * 1e3, 2),
+                                   "encode_ms": round(t4[1] / 1e3, 2), "decode_ms": round(t4[2] / 1e3, 2), "decode_steps": int(ns.value),
+                                   "chunks_run_alone": int(sum(node.last_modes)),
+                                   "encoder_tflops_equivalent": round(nb8 * 2588.3 / (t4[1] / 1e3), 1)}
+        node.transcribe(pcm, params=q)                      # back to the one-chunk state for the probes below
+    except Exception as e:  # pragma: no cover
+        res["lockstep8_error"] = repr(e)
     # decode-step roofline, greedy step chain on the GPU: q5_1 decoder matrices + vocabulary projection + cross K/V (f16) once per step
     dec_bytes = Lt * 14 * S * S * 24 // 32 + (NV + 31) // 32 * 32 * S * 24 // 32 + Lt * 2 * T * S * 2
     us_step = lib.wmi_bench_kernel(ctx, 20, 30)
     if us_step > 0:
         res["roofline_decode_step"] = {"bound": "hbm", "achieved": round(dec_bytes / (us_step * 1e-6) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                        "frac": round(dec_bytes / (us_step * 1e-6) / 1e9 / 8000.0, 4), "algorithmic_bytes": int(dec_bytes),
-                                       "avg_us": round(us_step, 1), "note": "greedy step, 9 launches per layer; q5_1 bytes per token"}
+                                       "avg_us": round(us_step, 1), "note": "greedy step, 8 launches per layer; q5_1 bytes per token"}
     enc_gflop = 2588.3
     res["roofline_encoder"] = {"bound": "mfma", "achieved": round(enc_gflop / res["greedy"]["encode_ms"], 1), "peak": 2500.0, "unit": "TFLOP/s (2 x MAC of the i8 block dots)",
                                "frac": round(enc_gflop / res["greedy"]["encode_ms"] / 2500.0, 4), "algorithmic_gflop": enc_gflop}

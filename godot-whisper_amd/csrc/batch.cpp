@@ -70,7 +70,7 @@ bool ensure_batch(whisper_context & ctx, int B) {
     (void) hipStreamSynchronize(s);
     dfree(w.mel_t); dfree(w.conv1); dfree(w.x); dfree(w.xn); dfree(w.q); dfree(w.k); dfree(w.att); dfree(w.vt); dfree(w.h);
     dfree(w.enc_out_h); dfree(w.kvc_k); dfree(w.kvc_v); dfree(w.self_k); dfree(w.self_v); dfree(w.dx); dfree(w.dq); dfree(w.datt); dfree(w.dh);
-    dfree(w.logits); dfree(w.xattn);
+    dfree(w.logits); dfree(w.xattn); dfree(w.aq); dfree(w.ads); dfree(w.att32); dfree(w.datt32);
     if (w.step_dev) (void) hipFree(w.step_dev);
     if (w.sample_dev) (void) hipFree(w.sample_dev);
     if (w.filter_scratch) (void) hipFree(w.filter_scratch);
@@ -90,6 +90,10 @@ bool ensure_batch(whisper_context & ctx, int B) {
            && dalloc(w.self_k, nb * Lt * n_ctx * S) && dalloc(w.self_v, nb * Lt * n_ctx * S)
            && dalloc(w.dx, nb * S) && dalloc(w.dq, nb * S) && dalloc(w.datt, nb * S) && dalloc(w.dh, nb * 4 * S) && dalloc(w.logits, nb * hp.n_vocab)
            && dalloc(w.xattn, k::attn_cross_scratch_floats(B, (int) H, (int) T));
+    if (ctx.model.quantised) {                               // q8 activation rows of all chunks + f32 attention outputs (device_q.cpp)
+        w.aq_rows = (int) (nb * T);
+        ok = ok && dalloc(w.aq, nb * T * 4 * S) && dalloc(w.ads, 2 * nb * T * (4 * S / 32)) && dalloc(w.att32, nb * T * S) && dalloc(w.datt32, nb * S);
+    }
     ok = ok && HIP_OK(hipMalloc(&w.step_dev, nb * sizeof(k::DecStep))) && HIP_OK(hipMalloc(&w.sample_dev, nb * sizeof(k::SampleOut)))
             && HIP_OK(hipMalloc(&w.filter_scratch, k::filter_scratch_bytes(B)))
             && HIP_OK(hipHostMalloc(&w.step_host, nb * sizeof(k::DecStep), hipHostMallocDefault))
@@ -148,6 +152,19 @@ bool encode_rows(whisper_context & ctx, const std::vector<int> & rows, const std
             k::gemm(k::EPI_CONV2, a, s);
         }
     }
+    if (ctx.model.quantised) {                               // block-quantised weights: the q8 layer loop over the stacked chunks
+        EncBufsQ e{};
+        e.T = T; e.nb = nb; e.Tpad = b.Tpad; e.x = b.x; e.q = b.q; e.k = b.k; e.vt = b.vt; e.h = b.h; e.att32 = b.att32;
+        e.enc_out = nullptr; e.enc_out_h = b.enc_out_h; e.kvc_k = b.kvc_k; e.kvc_v = b.kvc_v;
+        e.A = k::Q8Rows{b.aq, b.ads, b.ads + (size_t) (S / 32) * b.aq_rows, b.aq_rows};
+        e.A4 = k::Q8Rows{b.aq, b.ads, b.ads + (size_t) (4 * S / 32) * b.aq_rows, b.aq_rows};
+        if (!encode_layers_q_on(ctx, e, s)) return false;
+        HIP_TRY(hipStreamSynchronize(s));
+        if (!HIP_OK(hipGetLastError())) return false;
+        b.enc_rows = nb; b.enc_T = T;
+        b.t_encode_us += time_us() - t0;
+        return true;
+    }
     const float kq_scale = 1.0f / sqrtf((float) S / H);
     for (int il = 0; il < La; ++il) {
         const EncLayerW & l = w.enc[il];
@@ -202,6 +219,7 @@ bool encode_rows(whisper_context & ctx, const std::vector<int> & rows, const std
 static unsigned g_rows_mask = ~0u;
 
 static void enqueue_rows_step(whisper_context & ctx, int nb) {
+    if (ctx.model.quantised) { enqueue_rows_step_q(ctx, nb); return; }
     BatchWork & b = *ctx.batch; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
     const unsigned M = g_rows_mask;
     const int S = hp.n_text_state, H = hp.n_text_head, Lt = hp.n_text_layer, NV = hp.n_vocab, n_ctx = hp.n_text_ctx;
@@ -327,7 +345,7 @@ void free_batch(whisper_context & ctx) {
     BatchWork & w = *ctx.batch;
     dfree(w.mel_t); dfree(w.conv1); dfree(w.x); dfree(w.xn); dfree(w.q); dfree(w.k); dfree(w.att); dfree(w.vt); dfree(w.h);
     dfree(w.enc_out_h); dfree(w.kvc_k); dfree(w.kvc_v); dfree(w.self_k); dfree(w.self_v); dfree(w.dx); dfree(w.dq); dfree(w.datt); dfree(w.dh);
-    dfree(w.logits); dfree(w.xattn);
+    dfree(w.logits); dfree(w.xattn); dfree(w.aq); dfree(w.ads); dfree(w.att32); dfree(w.datt32);
     if (w.step_dev) (void) hipFree(w.step_dev);
     if (w.sample_dev) (void) hipFree(w.sample_dev);
     if (w.filter_scratch) (void) hipFree(w.filter_scratch);
@@ -364,7 +382,7 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
     static const bool force_seq = getenv("WMI_BATCH_SEQUENTIAL") != nullptr;     // debug / A-B
     const bool lang_known = params.language && strlen(params.language) > 0 && strcmp(params.language, "auto") != 0 && !params.detect_language;
     const bool distilled = hp.n_text_layer == 2 && !params.no_timestamps;
-    const bool lockstep = !force_seq && fast_path_enabled() && !ctx.model.quantised && params.strategy == WHISPER_SAMPLING_GREEDY && params.temperature < 1e-6f &&
+    const bool lockstep = !force_seq && fast_path_enabled() && params.strategy == WHISPER_SAMPLING_GREEDY && params.temperature < 1e-6f &&
                           lang_known && !distilled && !params.speed_up && !params.logits_filter_callback && !params.grammar_rules && params.n_grammar_rules == 0 && !params.new_segment_callback &&
                           !params.progress_callback && !params.encoder_begin_callback && !params.abort_callback &&
                           ctx.model.n_loaded > 0 && n_chunks > 1;

@@ -35,47 +35,57 @@ bool rows_fit(int n, int K) {
 } // namespace
 
 bool encode_layers_q(whisper_context & ctx, int T) {
-    State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
+    DeviceState & d = ctx.state->dev; const int S = ctx.model.hp.n_audio_state;
+    EncBufsQ e{};
+    e.T = T; e.nb = 1; e.Tpad = d.Tpad; e.x = d.x; e.q = d.q; e.k = d.k; e.vt = d.vt; e.h = d.h; e.att32 = d.att32;
+    e.enc_out = d.enc_out; e.enc_out_h = d.enc_out_h; e.kvc_k = d.kvc_k; e.kvc_v = d.kvc_v;
+    e.A = q8_rows(d, S); e.A4 = q8_rows(d, 4 * S);
+    return encode_layers_q_on(ctx, e, d.stream);
+}
+
+bool encode_layers_q_on(whisper_context & ctx, const EncBufsQ & e, hipStream_t s) {
+    const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
     const int S = hp.n_audio_state, H = hp.n_audio_head, La = hp.n_audio_layer, Lt = hp.n_text_layer;
-    hipStream_t s = d.stream;
-    const k::Q8Rows A = q8_rows(d, S), A4 = q8_rows(d, 4 * S);
+    const int T = e.T, M = e.nb * e.T;
+    const k::Q8Rows A = e.A, A4 = e.A4;
     const int qt = w.qtype;
     const float kq_scale = 1.0f / sqrtf((float) S / H);
     for (int il = 0; il < La; ++il) {
         const EncLayerW & l = w.enc[il];
-        k::quantize_rows(d.x, nullptr, T, S, l.ln1_g, l.ln1_b, hp.eps, qt, A, nullptr, nullptr, s);
+        k::quantize_rows(e.x, nullptr, M, S, l.ln1_g, l.ln1_b, hp.eps, qt, A, nullptr, nullptr, s);
         {
             k::GemmArgs a{};
-            a.M = T; a.N = 3 * S; a.K = S; a.bias = l.b_qkv;
-            a.C = d.q; a.ldc = S; a.aux = d.k; a.ldaux = S; a.aux2 = d.vt; a.ldaux2 = d.Tpad; a.S = S;
+            a.M = M; a.N = 3 * S; a.K = S; a.bias = l.b_qkv;
+            a.C = e.q; a.ldc = S; a.aux = e.k; a.ldaux = S; a.aux2 = e.vt; a.ldaux2 = e.Tpad; a.S = S;
+            a.rows_per_chunk = T; a.chunk_stride_aux2 = (int64_t) S * e.Tpad;
             k::qgemm(k::EPI_QKV_ENC, a, A, l.q_qkv, s);
         }
-        k::attn_encoder(d.q, d.k, d.vt, T, d.Tpad, S, H, kq_scale, nullptr, s, 1, d.att32);
-        k::quantize_rows(d.att32, nullptr, T, S, nullptr, nullptr, 0.f, qt, A, nullptr, nullptr, s);
+        k::attn_encoder(e.q, e.k, e.vt, T, e.Tpad, S, H, kq_scale, nullptr, s, e.nb, e.att32);
+        k::quantize_rows(e.att32, nullptr, M, S, nullptr, nullptr, 0.f, qt, A, nullptr, nullptr, s);
         {
             k::GemmArgs a{};
-            a.M = T; a.N = S; a.K = S; a.bias = l.b_o; a.C = d.x; a.ldc = S; a.resid = d.x; a.ldr = S;
+            a.M = M; a.N = S; a.K = S; a.bias = l.b_o; a.C = e.x; a.ldc = S; a.resid = e.x; a.ldr = S;
             k::qgemm(k::EPI_F32_BIAS_RESID, a, A, l.q_o, s);
         }
-        k::quantize_rows(d.x, nullptr, T, S, l.ln2_g, l.ln2_b, hp.eps, qt, A, nullptr, nullptr, s);
+        k::quantize_rows(e.x, nullptr, M, S, l.ln2_g, l.ln2_b, hp.eps, qt, A, nullptr, nullptr, s);
         {
             k::GemmArgs a{};
-            a.M = T; a.N = 4 * S; a.K = S; a.bias = l.b_fc1; a.C = d.h; a.ldc = 4 * S;
+            a.M = M; a.N = 4 * S; a.K = S; a.bias = l.b_fc1; a.C = e.h; a.ldc = 4 * S;
             k::qgemm(k::EPI_F16_BIAS_GELU, a, A, l.q_fc1, s);
         }
-        k::quantize_rows(nullptr, d.h, T, 4 * S, nullptr, nullptr, 0.f, qt, A4, nullptr, nullptr, s);
+        k::quantize_rows(nullptr, e.h, M, 4 * S, nullptr, nullptr, 0.f, qt, A4, nullptr, nullptr, s);
         {
             k::GemmArgs a{};
-            a.M = T; a.N = S; a.K = 4 * S; a.bias = l.b_fc2; a.C = d.x; a.ldc = S; a.resid = d.x; a.ldr = S;
+            a.M = M; a.N = S; a.K = 4 * S; a.bias = l.b_fc2; a.C = e.x; a.ldc = S; a.resid = e.x; a.ldr = S;
             k::qgemm(k::EPI_F32_BIAS_RESID, a, A4, l.q_fc2, s);
         }
     }
     // ln_post -> embd_enc (f32, kept for inspection) and its q8 image; cross K/V of every decoder layer in one GEMM
-    k::quantize_rows(d.x, nullptr, T, S, w.e_ln_g, w.e_ln_b, hp.eps, qt, A, d.enc_out, d.enc_out_h, s);
+    k::quantize_rows(e.x, nullptr, M, S, w.e_ln_g, w.e_ln_b, hp.eps, qt, A, e.enc_out, e.enc_out_h, s);
     {
         k::GemmArgs a{};
-        a.M = T; a.N = Lt * 2 * S; a.K = S; a.bias = w.b_ckv;
-        a.C = d.kvc_k; a.ldc = S; a.aux = d.kvc_v; a.ldaux = S; a.S = S; a.layer_stride = (int64_t) T * S;
+        a.M = M; a.N = Lt * 2 * S; a.K = S; a.bias = w.b_ckv;
+        a.C = e.kvc_k; a.ldc = S; a.aux = e.kvc_v; a.ldaux = S; a.S = S; a.layer_stride = (int64_t) M * S;
         a.scale = powf((float) S / H, -0.25f);
         k::qgemm(k::EPI_CROSS_KV, a, A, w.q_ckv, s);
     }
@@ -197,6 +207,55 @@ void enqueue_greedy_step_q(whisper_context & ctx, int Tc) {
     Src lnf; lnf.x32 = d.dx; lnf.ln_g = w.d_ln_g; lnf.ln_b = w.d_ln_b;
     rows(k::EPI_LOGITS, lnf, S, NV, w.q_te, nullptr, d.logits, NV, nullptr, nullptr, nullptr, 0.f, nullptr);
     k::filter_argmax(d.logits, d.ban_dev, stp, (k::SampleOut *) d.sample_dev, d.filter_scratch, s, (k::SampleOut *) d.sample_host);
+}
+
+// One lock-step greedy step of a block-quantised model: nb chunk rows through the same launches (batch.cpp: enqueue_rows_step is
+// the f16 form).  Row r has its own self cache (+ r * cache_stride), cross-cache slice and step record.
+void enqueue_rows_step_q(whisper_context & ctx, int nb) {
+    BatchWork & b = *ctx.batch; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
+    const int S = hp.n_text_state, H = hp.n_text_head, Lt = hp.n_text_layer, NV = hp.n_vocab, n_ctx = hp.n_text_ctx;
+    const int Tc = b.enc_T;
+    hipStream_t s = ctx.state->dev.stream;
+    const k::DecStep * stp = (const k::DecStep *) b.step_dev;
+    const float kq_scale = powf((float) S / H, -0.25f);
+    const int step_stride = (int) (sizeof(k::DecStep) / sizeof(int32_t));
+    const int64_t cache_stride = (int64_t) Lt * n_ctx * S;
+    const int64_t cross_layer = (int64_t) b.enc_rows * Tc * S;
+    k::qdec_embed_step((const k::DecStep *) b.step_host, (k::DecStep *) b.step_dev, S, w.q_te, w.d_pe, b.dx, s, nb);
+    auto rows = [&](int epi, const Src & src, int K, int N, const k::QMat & W, const float * bias, void * C, int ldc, const float * resid,
+                    void * aux, void * aux2, float scale, const int32_t * row_off) {
+        k::GemvArgs g{};
+        g.x32 = src.x32; g.ln_g = src.ln_g; g.ln_b = src.ln_b; g.eps = hp.eps; g.a16 = src.x16; g.n = nb; g.K = K; g.N = N;
+        g.bias = bias; g.epi = epi; g.C = C; g.ldc = ldc; g.resid = resid; g.ldr = S; g.aux = aux; g.ldaux = S; g.aux2 = aux2; g.ldaux2 = S;
+        g.scale = scale; g.S = S; g.row_off = row_off; g.lanes = 1; g.step_stride = step_stride; g.cache_row_stride = cache_stride;
+        return g;
+    };
+    for (int il = 0; il < Lt; ++il) {
+        const DecLayerW & l = w.dec[il];
+        __half * ck = b.self_k + (size_t) il * n_ctx * S, * cv = b.self_v + (size_t) il * n_ctx * S;     // chunk 0; + r * cache_stride
+        Src ln1; ln1.x32 = b.dx; ln1.ln_g = l.ln1_g; ln1.ln_b = l.ln1_b;
+        k::qrows(rows(k::EPI_QKV_DEC, ln1, S, 3 * S, l.q_qkv, l.b_qkv, b.dq, S, nullptr, ck, cv, kq_scale, &stp->kv_head), nullptr, l.q_qkv, s);
+        k::self_attn_rows(b.dq, nb, S, ck, cv, cache_stride, &stp->n_kv, step_stride, n_ctx, nullptr, s, b.datt32);
+        Src att; att.x32 = b.datt32;
+        k::qrows(rows(k::EPI_F32_BIAS_RESID, att, S, S, l.q_o, l.b_o, b.dx, S, b.dx, nullptr, nullptr, 0.f, nullptr), att.x32, l.q_o, s);
+        Src ln2; ln2.x32 = b.dx; ln2.ln_g = l.ln2_g; ln2.ln_b = l.ln2_b;
+        k::qrows(rows(k::EPI_Q_SCALED, ln2, S, S, l.q_cq, l.b_cq, b.dq, S, nullptr, nullptr, nullptr, kq_scale, nullptr), nullptr, l.q_cq, s);
+        const float * po = nullptr, * pl = nullptr, * pm = nullptr; int ns = 0;
+        k::attn_cross_split_partials(b.dq, nb, S, H, b.kvc_k + (size_t) il * cross_layer, b.kvc_v + (size_t) il * cross_layer, Tc,
+                                     b.xattn, &po, &pl, &pm, &ns, s, (int64_t) Tc * S);
+        {
+            k::GemvArgs g = rows(k::EPI_F32_BIAS_RESID, Src{}, S, S, l.q_co, l.b_co, b.dx, S, b.dx, nullptr, nullptr, 0.f, nullptr);
+            g.comb_o = po; g.comb_l = pl; g.comb_m = pm; g.comb_ns = ns;
+            k::qrows(g, nullptr, l.q_co, s);
+        }
+        Src ln3; ln3.x32 = b.dx; ln3.ln_g = l.ln3_g; ln3.ln_b = l.ln3_b;
+        k::qrows(rows(k::EPI_F16_BIAS_GELU, ln3, S, 4 * S, l.q_fc1, l.b_fc1, b.dh, 4 * S, nullptr, nullptr, nullptr, 0.f, nullptr), nullptr, l.q_fc1, s);
+        Src hh; hh.x16 = b.dh;
+        k::qrows(rows(k::EPI_F32_BIAS_RESID, hh, 4 * S, S, l.q_fc2, l.b_fc2, b.dx, S, b.dx, nullptr, nullptr, 0.f, nullptr), nullptr, l.q_fc2, s);
+    }
+    Src lnf; lnf.x32 = b.dx; lnf.ln_g = w.d_ln_g; lnf.ln_b = w.d_ln_b;
+    k::qrows(rows(k::EPI_LOGITS, lnf, S, NV, w.q_te, nullptr, b.logits, NV, nullptr, nullptr, nullptr, 0.f, nullptr), nullptr, w.q_te, s);
+    k::filter_argmax(b.logits, ctx.state->dev.ban_dev, stp, (k::SampleOut *) b.sample_dev, b.filter_scratch, s, (k::SampleOut *) b.sample_host, nb);
 }
 
 } // namespace wmi

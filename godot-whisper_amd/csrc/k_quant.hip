@@ -612,6 +612,56 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
         // launches per decoder layer
         constexpr int MAXV = 6;                              // K <= 1536
         const int nsl = (K + 255) >> 8;
+        if (n * nsl > 2 * NW) {
+            // many rows (lock-step chunks, beams): the statistics once per row (wavefront w: rows w, w + NW, ...), parked in the
+            // reduction scratch, then the (row, slice) tasks only load their own 256 columns — same arithmetic, same order
+            float * stat = red;                              // [n][2]: mean, 1 / sqrt(var + eps)  (red is not in use yet)
+            for (int r = wave; r < n; r += NW) {
+                const int src = a.rows ? a.rows[r] : r;
+                const float * xr = a.x32 + (size_t) src * K;
+                float4 v[MAXV];
+#pragma unroll
+                for (int i = 0; i < MAXV; ++i) { const int c = (i * 64 + lane) * 4; v[i] = *(const float4 *) (xr + (c < K ? c : 0)); }
+                float sum = 0.0f;
+#pragma unroll
+                for (int i = 0; i < MAXV; ++i) {
+                    const int c = (i * 64 + lane) * 4;
+                    if (c < K) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+                }
+                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                const float mean = sum / (float) K;
+                float sqs = 0.0f;
+#pragma unroll
+                for (int i = 0; i < MAXV; ++i) {
+                    const int c = (i * 64 + lane) * 4;
+                    if (c < K) {
+                        v[i].x -= mean; v[i].y -= mean; v[i].z -= mean; v[i].w -= mean;
+                        sqs += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
+                    }
+                }
+                for (int o = 32; o > 0; o >>= 1) sqs += __shfl_xor(sqs, o);
+                if (lane == 0) { stat[2 * r] = mean; stat[2 * r + 1] = 1.0f / sqrtf(sqs / (float) K + a.eps); }
+            }
+            __syncthreads();
+            for (int task = wave; task < n * nsl; task += NW) {
+                const int r = task / nsl, sl = task - r * nsl;
+                const int src = a.rows ? a.rows[r] : r;
+                const int cs = (sl * 64 + lane) * 4, ccs = cs < K ? cs : 0;
+                float4 y = *(const float4 *) (a.x32 + (size_t) src * K + ccs);
+                const float4 gg = *(const float4 *) (a.ln_g + ccs), bb = *(const float4 *) (a.ln_b + ccs);
+                const float mean = stat[2 * r], scale = stat[2 * r + 1];
+                y.x -= mean; y.y -= mean; y.z -= mean; y.w -= mean;
+                y.x = __fadd_rn(__fmul_rn(y.x * scale, gg.x), bb.x); y.y = __fadd_rn(__fmul_rn(y.y * scale, gg.y), bb.y);
+                y.z = __fadd_rn(__fmul_rn(y.z * scale, gg.z), bb.z); y.w = __fadd_rn(__fmul_rn(y.w * scale, gg.w), bb.w);
+                if (cs >= K) y = make_float4(0.f, 0.f, 0.f, 0.f);
+                float d, sv;
+                const uint32_t q = quant4<F16D>(y.x, y.y, y.z, y.w, d, sv);
+                if (cs < K) {
+                    *(uint32_t *) (sq + (size_t) r * lda + cs) = q;
+                    if ((lane & 7) == 0) { sd[(cs >> 5) * R8 + r] = d; ss[(cs >> 5) * R8 + r] = sv; }
+                }
+            }
+        } else                                               // (stat is read before the barrier that ends the prologue; red is written after it)
         for (int task = wave; task < n * nsl; task += NW) {
             const int r = task / nsl, sl = task - r * nsl;
             const int src = a.rows ? a.rows[r] : r;

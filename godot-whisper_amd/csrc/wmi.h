@@ -266,6 +266,8 @@ struct BatchWork {
     __half * kvc_k = nullptr, * kvc_v = nullptr;              // cross cache [L][B*T][S]
     __half * self_k = nullptr, * self_v = nullptr;            // self cache  [B][L][n_ctx][S]
     float  * dx = nullptr; __half * dq = nullptr, * datt = nullptr, * dh = nullptr; float * logits = nullptr, * xattn = nullptr;
+    // block-quantised models: q8 activation rows [B*T][4S] + block scales, f32 attention outputs (device_q.cpp)
+    int8_t * aq = nullptr; float * ads = nullptr; int aq_rows = 0; float * att32 = nullptr, * datt32 = nullptr;
     void   * step_dev = nullptr, * step_host = nullptr, * sample_dev = nullptr, * sample_host = nullptr, * filter_scratch = nullptr;
     int      enc_rows = 0, enc_T = 0;                         // chunk rows / encoder length of the last batched encode
     int32_t  step_seq = 0;                                    // sequence number of the last lock-step decode step
@@ -308,6 +310,15 @@ bool decode(whisper_context & ctx, const Batch & batch);
 // block-quantised models (device_q.cpp): the layer loops of encode() / decode() with the quantised kernels
 inline k::Q8Rows q8_rows(const DeviceState & d, int K) { return k::Q8Rows{d.aq, d.ads, d.ads + (size_t) (K / 32) * d.aq_rows, d.aq_rows}; }
 bool encode_layers_q(whisper_context & ctx, int T);
+// the same layer loop over caller-supplied buffers: nb chunks stacked along M (lock-step, batch.cpp) — activations [nb*T][S],
+// V^T [nb][S][Tpad], cross cache [L][nb*T][S]
+struct EncBufsQ {
+    int T, nb, Tpad;
+    float * x; __half * q, * k, * vt, * h; float * att32; float * enc_out; __half * enc_out_h; __half * kvc_k, * kvc_v;
+    k::Q8Rows A, A4;
+};
+bool encode_layers_q_on(whisper_context & ctx, const EncBufsQ & e, hipStream_t s);
+void enqueue_rows_step_q(whisper_context & ctx, int nb);
 bool decode_layers_q(whisper_context & ctx, int n, int n_kv, int kv_head, int Tc, const std::vector<int> & rows);
 void enqueue_greedy_step_q(whisper_context & ctx, int Tc);
 // greedy fast path: decode ONE token of sequence 0 at position `pos` and pick the next token on the device

@@ -33,5 +33,13 @@ for name, strat, bs, mt in cases:
     dt = (time.perf_counter() - t0) / n
     t6 = (C.c_int64 * 6)(); n5 = (C.c_int32 * 5)(); lib.wmi_get_timings(node.ctx, t6, n5)
     print(f"{name}: {dt*1e3:.1f} ms/chunk ({30/dt:.0f}x) tokens {len(r)-1 if r else 0} | mel {t6[0]/n/1e3:.2f} enc {t6[1]/n/1e3:.2f} dec {t6[2]/n/1e3:.2f} ({n5[1]//n} calls) batchd {t6[3]/n/1e3:.2f} ({n5[2]//n} tok) prompt {t6[4]/n/1e3:.2f} sample {t6[5]/n/1e3:.2f}", flush=True)
+if os.environ.get("BATCH"):
+    nb = int(os.environ["BATCH"])
+    pcms = [synth.make_pcm(30.0, seed=50 + i) for i in range(nb)]
+    p = node.full_params("", 0); p.temperature_inc = 0.0
+    node.transcribe_batch(pcms, params=p)
+    t0 = time.perf_counter(); r = node.transcribe_batch(pcms, params=p); dt = time.perf_counter() - t0
+    t4 = (C.c_int64 * 4)(); ns = C.c_int32(); lib.wmi_get_batch_timings(node.ctx, t4, C.byref(ns))
+    print(f"lock-step {nb} chunks: {dt*1e3:.1f} ms per call ({nb*30/dt:.0f}x) modes {list(node.last_modes)} | mel {t4[0]/1e3:.2f} enc {t4[1]/1e3:.2f} dec {t4[2]/1e3:.2f} ({ns.value} steps) emit {t4[3]/1e3:.2f}", flush=True)
 print('greedy step chain on the GPU, us per step:', lib.wmi_bench_kernel(node.ctx, 20, 20), flush=True)
 node.close()

@@ -462,6 +462,37 @@ def test_lockstep_chunks_equal_one_at_a_time(product_lib, lockstep_mode, shape, 
         node.close()
 
 
+@pytest.mark.parametrize("qtype", ["q5_1", "q8_0", "q4_0"])
+def test_lockstep_chunks_of_quantised_models_equal_one_at_a_time(product_lib, lockstep_mode, qtype):
+    """Block-quantised weights in lock-step: the chunks are rows of the same q8 x block-quantised kernels (per-row arithmetic does
+    not depend on the number of rows: exact integer block dots, blocks added in K order).  With the one-group encoder attention
+    of the exact mode everything is bit-identical to whisper_full per chunk; the default mode differs in the encoder attention's
+    key split only, which the activation quantiser can amplify — compared up to the first near-tie."""
+    model = synth.quantize_model(synth.make_model("micro.en", seed=77), qtype)
+    secs = [30.0, 12.0, 30.0, 0.5, 21.0, 30.0, 7.0, 30.0, 30.0, 16.0]
+    pcms = [synth.make_pcm(s, seed=300 + i, gate=(i % 3 == 2)) for i, s in enumerate(secs)]
+
+    def params(node):
+        p = node.full_params("", 0); p.temperature_inc = 0.0
+        return p
+    want = []
+    for b in pcms:
+        node = host.SpeechToText(product_lib); node.set_language_model(model)
+        want.append(node.transcribe(b, params=params(node)))
+        assert node.last_ret == 0
+        node.close()
+    node = host.SpeechToText(product_lib); node.set_language_model(model)
+    try:
+        got = node.transcribe_batch(pcms, params=params(node))
+        assert node.last_ret == 0 and len(got) == len(pcms)
+        modes = list(node.last_modes)
+        assert modes == [0] * len(pcms), modes                      # all chunks went through the lock-step kernels
+        for c, (g, w) in enumerate(zip(got, want)):
+            _assert_same_transcription(g, w, (qtype, c), lockstep_mode == "exact")
+    finally:
+        node.close()
+
+
 def test_lockstep_chunks_with_audio_ctx_and_device_pcm(product_lib, lockstep_mode):
     model = synth.make_model("micro.en", seed=5)
     pcms = [synth.make_pcm(6.0, seed=40 + i) for i in range(3)]
