@@ -249,23 +249,24 @@ def main():
             Lt = lib.whisper_model_n_text_layer(ctx)
             S2 = hp_S * hp_S * 2
             nkv = max(int(n_tokens) // 2, 1)                                    # mean self-attention cache length over the steps of a chunk
-            kinds = [   # (mask bit, name, launches per step, algorithmic bytes per launch)
-                (1, "k_gemv1<4,1,false,1,EPI_QKV_DEC> LN + q|k|v projection", Lt, 3 * S2),
-                (2, "k_gemv1<4,1,false,2,EPI_F32_BIAS_RESID> self-attention over the KV cache + out projection", Lt, S2 + 2 * nkv * hp_S * 2),
-                (3, "k_xattn_fused<1,true>: LN + cross query, scores, soft-max numerators and P.V over the cross K/V (one launch)", Lt, S2 + 2 * T * hp_S * 2),
-                (4, "k_gemv1<4,1,false,3,EPI_F32_BIAS_RESID> cross-attention combine + out projection", Lt, S2),
-                (5, "k_gemv1<4,1,false,1,EPI_F16_BIAS_GELU> LN + mlp.0", Lt, 4 * S2),
-                (6, "k_gemv1<4,4,false,0,EPI_F32_BIAS_RESID> mlp.2", Lt, 4 * S2),
-                (7, "k_gemv1<8,1,false,1,EPI_LOGITS> LN + vocabulary projection", 1, NV * hp_S * 2),
-                (8, "k_filter_stats + k_filter_pick: logit filters, soft-max statistics, arg-max", 2, NV * 4 // 2),
+            kinds = [   # (mask bit, name, launches per step, algorithmic bytes per launch, key in profiles/*_pmc_summary.json)
+                (1, "k_gemv1<4,1,false,1,EPI_QKV_DEC> LN + q|k|v projection", Lt, 3 * S2, "k_gemv1<4, 1, false, 1, 5>"),
+                (2, "k_gemv1<4,1,false,2,EPI_F32_BIAS_RESID> self-attention over the KV cache + out projection", Lt, S2 + 2 * nkv * hp_S * 2, "k_gemv1<4, 1, false, 2, 2>"),
+                (3, "k_xattn_fused<1,true>: LN + cross query, scores, soft-max numerators and P.V over the cross K/V (one launch)", Lt, S2 + 2 * T * hp_S * 2, "k_xattn_fused<1, true>"),
+                (4, "k_gemv1<4,1,false,3,EPI_F32_BIAS_RESID> cross-attention combine + out projection", Lt, S2, "k_gemv1<4, 1, false, 3, 2>"),
+                (5, "k_gemv1<4,1,false,1,EPI_F16_BIAS_GELU> LN + mlp.0", Lt, 4 * S2, "k_gemv1<4, 1, false, 1, 1>"),
+                (6, "k_gemv1<4,4,false,0,EPI_F32_BIAS_RESID> mlp.2", Lt, 4 * S2, "k_gemv1<4, 4, false, 0, 2>"),
+                (7, "k_gemv1<8,1,false,1,EPI_LOGITS> LN + vocabulary projection", 1, NV * hp_S * 2, "k_gemv1<8, 1, false, 1, 100>"),
+                (8, "k_filter_stats + k_filter_pick: logit filters, soft-max statistics, arg-max", 2, NV * 4 // 2, "k_filter_stats"),
             ]
             table = []
-            for bit, name, nl, alg in kinds:
+            for bit, name, nl, alg, pkey in kinds:
                 os.environ["WMI_STEP_MASK"] = str(1 << bit)
                 us = lib.wmi_bench_kernel(ctx, 20, IT) / nl
                 gbs = alg / (us * 1e-6) / 1e9
                 table.append({"kernel": name, "launches_per_step": nl, "avg_us": round(us, 3), "algorithmic_bytes": int(alg),
-                              "achieved": round(gbs, 1), "frac": round(gbs / 8000.0, 4), "step_share_us": round(us * nl, 2)})
+                              "achieved": round(gbs, 1), "frac": round(gbs / 8000.0, 4), "step_share_us": round(us * nl, 2),
+                              "traffic": pmc_traffic(pkey)})
             os.environ.pop("WMI_STEP_MASK", None)
             us_step = lib.wmi_bench_kernel(ctx, 20, IT)
             tot = sum(t["step_share_us"] for t in table)
@@ -273,7 +274,7 @@ def main():
                 t["step_share"] = round(t["step_share_us"] / tot, 3)
             dom = max(table, key=lambda t: t["step_share_us"])
             out["roofline"] = {"kernel": dom["kernel"], "bound": "hbm", "achieved": dom["achieved"], "peak": 8000.0, "unit": "GB/s",
-                               "frac": dom["frac"], "traffic": None, "algorithmic_bytes": dom["algorithmic_bytes"], "avg_us": dom["avg_us"],
+                               "frac": dom["frac"], "traffic": dom["traffic"], "algorithmic_bytes": dom["algorithmic_bytes"], "avg_us": dom["avg_us"],
                                "launches_per_step": dom["launches_per_step"], "share_of_decode_step": dom["step_share"],
                                "note": "latency-bound: a dependent chain of small launches, see decode_step_kernels"}
             out["decode_step_kernels"] = table

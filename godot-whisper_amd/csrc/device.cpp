@@ -114,6 +114,8 @@ void destroy_state(State * st) {
     dfree(d.aq); dfree(d.ads); dfree(d.att32); dfree(d.datt32);
     if (d.step_exec) (void) hipGraphExecDestroy(d.step_exec);
     if (d.step_graph) (void) hipGraphDestroy(d.step_graph);
+    if (d.step_exec_long) (void) hipGraphExecDestroy(d.step_exec_long);
+    if (d.step_graph_long) (void) hipGraphDestroy(d.step_graph_long);
     if (d.step_dev) (void) hipFree(d.step_dev);
     if (d.sample_dev) (void) hipFree(d.sample_dev);
     if (d.filter_scratch) (void) hipFree(d.filter_scratch);
@@ -550,7 +552,7 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = fa
         __half * ck = kv.k + ((size_t) il * n_ctx) * S, * cv = kv.v + ((size_t) il * n_ctx) * S;
         if (M & 2) gv(k::EPI_QKV_DEC, l.ln1_g, l.ln1_b, nullptr, S, 3 * S, l.w_qkv, l.b_qkv, d.dq, S, nullptr, ck, cv, kq_scale, &stp->kv_head); chk("qkv", il);
         if ((M & 4) && long_kv) {
-            k::self_attn_rows(d.dq, 1, S, ck, cv, 0, &stp->n_kv, 0, hp.n_text_ctx, d.datt, s);
+            k::self_attn_rows(d.dq, 1, S, ck, cv, 0, &stp->n_kv, 0, hp.n_text_ctx, d.datt, s, nullptr, true);
             gv(k::EPI_F32_BIAS_RESID, nullptr, nullptr, d.datt, S, S, l.w_o, l.b_o, d.dx, S, d.dx, nullptr, nullptr, 0.f, nullptr); chk("self-attn, out", il);
         } else
         if (M & 4) {   // self-attention over the cache, recomputed in the out-projection's prologue (one launch fewer)
@@ -614,39 +616,45 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
 
     hipStream_t s = d.stream;
     static const bool use_graph = getenv("WMI_NO_GRAPH") == nullptr;
-    if (use_graph && d.step_exec && d.step_graph_T != Tc) {             // encoder length changed: the captured step is stale
-        (void) hipGraphExecDestroy(d.step_exec); (void) hipGraphDestroy(d.step_graph);
-        d.step_exec = nullptr; d.step_graph = nullptr;
+    // two captured forms of the step: caches of <= 64 cells (self-attention inside the out projection) and longer ones
+    const bool long_kv = (int) kv.n > 64 && !ctx.model.quantised;          // (the quantised step has one form for every length)
+    hipGraph_t & graph = long_kv ? d.step_graph_long : d.step_graph;
+    hipGraphExec_t & exec = long_kv ? d.step_exec_long : d.step_exec;
+    int & graph_T = long_kv ? d.step_graph_long_T : d.step_graph_T;
+    if (use_graph && exec && graph_T != Tc) {                           // encoder length changed: the captured step is stale
+        (void) hipGraphExecDestroy(exec); (void) hipGraphDestroy(graph);
+        exec = nullptr; graph = nullptr;
     }
     // Capture + instantiate costs tens of milliseconds; the streaming node changes audio_ctx on every call (it grows with
     // the buffer), so a step is only captured once the same encoder length has been decoded for a while — until then the
-    // launches go out eagerly (measured equal to replay within 1 %: the step is bound by dependent-kernel latency on the GPU)
-    if (d.step_seen_T != Tc) { d.step_seen_T = Tc; d.step_seen_n = 0; }
-    const bool capture_now = use_graph && !d.step_exec && !d.step_capture_failed && ++d.step_seen_n > 64;
+    // launches go out eagerly (the host then pays ~4 us per launch: equal to the replay for the 40-launch short-cache step,
+    // twice the replay's time for the long-cache form)
+    if (d.step_seen_T != Tc) { d.step_seen_T = Tc; d.step_seen_n = 0; d.step_seen_long_n = 0; }
+    int & seen = long_kv ? d.step_seen_long_n : d.step_seen_n;
+    const bool capture_now = use_graph && !exec && !d.step_capture_failed && ++seen > 64;
     if (capture_now) {
         // first use: run once eagerly (lets the launchers set their function attributes), then capture
-        enqueue_greedy_step(ctx, Tc);
+        enqueue_greedy_step(ctx, Tc, long_kv);
         HIP_TRY(hipStreamSynchronize(s));
         if (HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal))) {
-            enqueue_greedy_step(ctx, Tc);
+            enqueue_greedy_step(ctx, Tc, long_kv);
             hipGraph_t g = nullptr;
             const bool ended = HIP_OK(hipStreamEndCapture(s, &g));
-            if (ended && g && HIP_OK(hipGraphInstantiate(&d.step_exec, g, nullptr, nullptr, 0))) {
-                d.step_graph = g; d.step_graph_T = Tc;
+            if (ended && g && HIP_OK(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0))) {
+                graph = g; graph_T = Tc;
             } else {
                 // latched: without this every later step paid an eager step, a sync and a new capture attempt
                 WMI_WARN("%s: graph capture failed - staying on eager launches\n", __func__);
                 if (g) (void) hipGraphDestroy(g);
-                d.step_exec = nullptr; d.step_capture_failed = true;
+                exec = nullptr; d.step_capture_failed = true;
                 hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
                 if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) { hipGraph_t junk = nullptr; (void) hipStreamEndCapture(s, &junk); if (junk) (void) hipGraphDestroy(junk); }
             }
         } else d.step_capture_failed = true;
     }
     hs->seq = ++d.step_seq;
-    const bool long_kv = (int) kv.n > 64;
-    if (use_graph && d.step_exec && !long_kv) {
-        HIP_TRY(hipGraphLaunch(d.step_exec, s));
+    if (use_graph && exec) {
+        HIP_TRY(hipGraphLaunch(exec, s));
     } else {
         enqueue_greedy_step(ctx, Tc, long_kv);
     }
@@ -673,8 +681,10 @@ double bench_greedy_step_chain(whisper_context & ctx, int iters) {
     hipStream_t s = d.stream;
     hipEvent_t e0, e1;
     if (!HIP_OK(hipEventCreate(&e0)) || !HIP_OK(hipEventCreate(&e1))) return -1.0;
-    const bool long_kv = ((const k::DecStep *) d.step_host)->n_kv > 64;
-    auto once = [&]() { if (d.step_exec && d.step_graph_T == Tc && g_step_mask == ~0u && !long_kv) (void) hipGraphLaunch(d.step_exec, s); else enqueue_greedy_step(ctx, Tc, long_kv); };
+    const bool long_kv = ((const k::DecStep *) d.step_host)->n_kv > 64 && !ctx.model.quantised;
+    hipGraphExec_t exec = long_kv ? d.step_exec_long : d.step_exec;
+    const int exec_T = long_kv ? d.step_graph_long_T : d.step_graph_T;
+    auto once = [&]() { if (exec && exec_T == Tc && g_step_mask == ~0u) (void) hipGraphLaunch(exec, s); else enqueue_greedy_step(ctx, Tc, long_kv); };
     for (int i = 0; i < 4; ++i) once();
     (void) hipStreamSynchronize(s);
     (void) hipEventRecord(e0, s);

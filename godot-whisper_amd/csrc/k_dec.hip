@@ -316,6 +316,79 @@ __global__ __launch_bounds__(64) void k_self_attn_rows(const __half * __restrict
     }
 }
 
+// Long caches (the host knows that some row has more than 64 cells: uncapped transcriptions, context prompts): four wavefronts
+// per (row, head).  Scores one key per thread, exact maximum, e = exp16(s - m), l in f32, P = f16(e / l) — the steps of
+// k_self_attn_rows' barrier form — and P.V with the keys cut into four contiguous quarters, one per wavefront (lane = column,
+// keys in ascending order inside a quarter), the quarters added in order.  Rows of <= 64 cells take the same arithmetic as
+// any other here (they do not occur in the callers that pick this kernel more than transiently).
+__global__ __launch_bounds__(256) void k_self_attn_rows_long(const __half * __restrict__ q, const __half * __restrict__ kc,
+                                                            const __half * __restrict__ vc, int64_t cache_row_stride,
+                                                            const int32_t * __restrict__ n_kv_p, int step_stride, int K, int cap,
+                                                            __half * __restrict__ out, float * __restrict__ out32) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float * row = (float *) smem;                       // [cap] scores -> probabilities of this head
+    float * qf  = row + cap;                            // [64]
+    float * part = qf + 64;                             // [4][64] partial outputs
+    float * red = part + 256;                           // [4]
+    const int r = blockIdx.x, h = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const __half * sk = kc + (int64_t) r * cache_row_stride, * sv = vc + (int64_t) r * cache_row_stride;
+    const int n_kv = n_kv_p[r * step_stride];
+    if (tid < 64) qf[tid] = __half2float(q[(size_t) r * K + h * 64 + tid]);
+    __syncthreads();
+    float m = -INFINITY;
+    for (int j = tid; j < n_kv; j += 256) {
+        const uint4 * kp = (const uint4 *) (sk + (size_t) j * K + h * 64);
+        uint4 u[8];
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) u[c8] = kp[c8];
+        float dot = 0.0f;
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) {
+            const __half2 * hh = (const __half2 *) &u[c8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float2 f = __half22float2(hh[e]);
+                dot = fmaf(f.x, qf[c8 * 8 + e * 2], dot);
+                dot = fmaf(f.y, qf[c8 * 8 + e * 2 + 1], dot);
+            }
+        }
+        row[j] = dot;
+        m = fmaxf(m, dot);
+    }
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();                                    // red is reused for the sums
+    float l = 0.0f;
+    for (int j = tid; j < n_kv; j += 256) { const float e = round_f16(expf(round_f16(row[j] - m))); row[j] = e; l += e; }
+    for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
+    if (lane == 0) red[wave] = l;
+    __syncthreads();
+    const float inv = (float) (1.0 / (double) ((red[0] + red[1]) + (red[2] + red[3])));
+    for (int j = tid; j < n_kv; j += 256) row[j] = round_f16(row[j] * inv);
+    __syncthreads();
+    {
+        const int per = (n_kv + 3) >> 2, j0 = wave * per, j1 = min(n_kv, j0 + per);
+        const __half * vp = sv + h * 64 + lane;
+        float acc = 0.0f;
+        for (int j = j0; j < j1; j += 8) {
+            __half vv[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) vv[t] = vp[(size_t) (j + t < j1 ? j + t : j1 - 1) * K];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) if (j + t < j1) acc = fmaf(row[j + t], __half2float(vv[t]), acc);
+        }
+        part[wave * 64 + lane] = acc;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const float acc = (part[tid] + part[64 + tid]) + (part[128 + tid] + part[192 + tid]);
+        const int c = h * 64 + tid;
+        if (out32) out32[(size_t) r * K + c] = acc; else out[(size_t) r * K + c] = f2h(acc);
+    }
+}
+
 // LayerNorm of one row by one wavefront, lane L holding the slices x[512 t + 8 L .. + 8) (the slices its dot products
 // need).  y = f16((x - mean) * rstd * g + b) as separate mul / add (SURVEY App. B rule 6); sums in f32: per lane over
 // (t, e) in order, then the 64-lane butterfly.  MAXCH chunks of 512 columns; av[t][e] = 0 outside the row.
@@ -1199,7 +1272,12 @@ void dec_embed_step(const DecStep * host_step, DecStep * dev_step, int S, const 
 }
 
 void self_attn_rows(const __half * q, int n, int K, const __half * kc, const __half * vc, int64_t cache_row_stride,
-                    const int32_t * n_kv, int step_stride, int cap, __half * out, hipStream_t st, float * out32) {
+                    const int32_t * n_kv, int step_stride, int cap, __half * out, hipStream_t st, float * out32, bool long_cache) {
+    if (long_cache) {
+        const size_t smem = ((size_t) cap + 64 + 256 + 4) * sizeof(float);
+        hipLaunchKernelGGL(k_self_attn_rows_long, dim3(n, K / 64), dim3(256), smem, st, q, kc, vc, cache_row_stride, n_kv, step_stride, K, cap, out, out32);
+        return;
+    }
     const size_t smem = ((size_t) cap + 64) * sizeof(float);
     hipLaunchKernelGGL(k_self_attn_rows, dim3(n, K / 64), dim3(64), smem, st, q, kc, vc, cache_row_stride, n_kv, step_stride, K, cap, out, out32);
 }

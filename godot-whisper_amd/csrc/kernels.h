@@ -145,7 +145,8 @@ struct GemvArgs {
 // lock-step chunks: single-token self-attention of n rows, row r against the cache at kc/vc + r * cache_row_stride with
 // n_kv[r * step_stride] cells; same arithmetic as the fused prologue of gemv (GemvArgs::sa_*).  out [n][K] f16
 void self_attn_rows(const __half * q, int n, int K, const __half * kc, const __half * vc, int64_t cache_row_stride,
-                    const int32_t * n_kv, int step_stride, int cap, __half * out, hipStream_t st, float * out32 = nullptr);
+                    const int32_t * n_kv, int step_stride, int cap, __half * out, hipStream_t st, float * out32 = nullptr,
+                    bool long_cache = false);   // long_cache: the host knows a row has > 64 cells: four wavefronts per (row, head)
 // split cross-attention partials -> out [n][S] f16 (the separate form of GemvArgs::comb_*)
 void set_xattn_probe_skip(int mask);      // probe only
 void attn_cross_partials_layout(int n, int H, int T, float * scratch, const float ** po, const float ** pl, const float ** pm, int * pns);

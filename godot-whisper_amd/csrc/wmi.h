@@ -224,6 +224,8 @@ struct DeviceState {
     void   * filter_scratch = nullptr;
     uint8_t * ban_dev = nullptr;   uint64_t ban_sig = ~0ull;          // static suppress mask + its parameter signature
     hipGraph_t step_graph = nullptr; hipGraphExec_t step_exec = nullptr; int step_graph_T = -1;
+    // the same for caches past 64 cells (f16 models: (row, head)-parallel self-attention + plain out projection, device.cpp)
+    hipGraph_t step_graph_long = nullptr; hipGraphExec_t step_exec_long = nullptr; int step_graph_long_T = -1; int step_seen_long_n = 0;
     int32_t step_seq = 0;                                             // sequence number of the last greedy step launched
     // device-side draws (beam search, t > 0): decode() leaves the logits rows in d.logits, sample_rows_device() draws from them
     bool    keep_logits_on_device = false;
