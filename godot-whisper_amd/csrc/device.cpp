@@ -116,6 +116,8 @@ void destroy_state(State * st) {
     if (d.step_graph) (void) hipGraphDestroy(d.step_graph);
     if (d.step_exec_long) (void) hipGraphExecDestroy(d.step_exec_long);
     if (d.step_graph_long) (void) hipGraphDestroy(d.step_graph_long);
+    if (d.step_exec_chain) (void) hipGraphExecDestroy(d.step_exec_chain);
+    if (d.step_graph_chain) (void) hipGraphDestroy(d.step_graph_chain);
     if (d.step_dev) (void) hipFree(d.step_dev);
     if (d.sample_dev) (void) hipFree(d.sample_dev);
     if (d.filter_scratch) (void) hipFree(d.filter_scratch);
@@ -219,6 +221,7 @@ bool encode(whisper_context & ctx, int mel_offset) {
     if (ctx.host_only) { WMI_ERR("%s: host-only context has no compute path (this backend has no CPU fallback)\n", __func__); return false; }
     State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
     const int64_t t0 = time_us();
+    d.chain_valid = false;
     const int T = st.exp_n_audio_ctx > 0 ? st.exp_n_audio_ctx : hp.n_audio_ctx;
     const int S = hp.n_audio_state, H = hp.n_audio_head, La = hp.n_audio_layer, Lt = hp.n_text_layer, nm = hp.n_mels;
     hipStream_t s = d.stream;
@@ -299,6 +302,7 @@ bool decode(whisper_context & ctx, const Batch & batch) {
     if (ctx.host_only) { WMI_ERR("%s: host-only context has no compute path (this backend has no CPU fallback)\n", __func__); return false; }
     State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
     const int64_t t0 = time_us();
+    d.chain_valid = false;                                  // this path overwrites the activation row a chained greedy step would start from
     KVCache & kv = st.kv_self;
     const int n = batch.n_tokens;
     if (n <= 0) return false;
@@ -521,7 +525,10 @@ static unsigned g_step_mask = ~0u;
 // long_kv: the self cache holds more than 64 cells.  The attention fused into the out projection's prologue is a per-wavefront
 // routine for <= 64 keys (every workgroup recomputes it); beyond that its barrier-separated fall-back ran at ~95 us per
 // layer (bench: the uncapped transcription), so long caches take the (row, head)-parallel attention kernel + a plain projection.
-static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = false) {
+// chained: the step starts from what the previous step's pick kernel prepared on the device (token, position, cache head, activation
+// row): no embedding launch; the host's record (filter flags, sequence number) reaches the device through the extra workgroup of
+// the last mlp.2 launch.
+static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = false, bool chained = false) {
     if (ctx.model.quantised) { enqueue_greedy_step_q(ctx, Tc); return; }
     State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
     KVCache & kv = st.kv_self;
@@ -538,7 +545,7 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = fa
     // step parameters come from pinned host memory, the result goes back into pinned host memory: the replayed
     // graph contains kernels only (memcpy nodes cost tens of microseconds each on this stack)
     const unsigned M = g_step_mask;
-    if (M & 1) k::dec_embed_step((const k::DecStep *) d.step_host, (k::DecStep *) d.step_dev, S, w.d_te, w.d_pe, d.dx, s); chk("embed", -1);
+    if ((M & 1) && !chained) k::dec_embed_step((const k::DecStep *) d.step_host, (k::DecStep *) d.step_dev, S, w.d_te, w.d_pe, d.dx, s); chk("embed", -1);
     auto gv = [&](int epi, const float * lg, const float * lb, const __half * a16, int K, int N, const __half * W, const float * bias,
                   void * C, int ldc, const float * resid, void * aux, void * aux2, float scale, const int32_t * row_off) {
         k::GemvArgs g{};
@@ -579,11 +586,20 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = fa
             if (M & 16) k::gemv(g, s);
         }
         if (M & 32) gv(k::EPI_F16_BIAS_GELU, l.ln3_g, l.ln3_b, nullptr, S, 4 * S, l.w_fc1, l.b_fc1, d.dh, 4 * S, nullptr, nullptr, nullptr, 0.f, nullptr);
+        if ((M & 64) && chained && il == Lt - 1) {             // + the workgroup that mirrors the host's step record (filter flags, seq)
+            k::GemvArgs g{};
+            g.x32 = d.dx; g.eps = hp.eps; g.a16 = d.dh; g.n = 1; g.K = 4 * S; g.N = S; g.W = l.w_fc2; g.bias = l.b_fc2; g.epi = k::EPI_F32_BIAS_RESID;
+            g.C = d.dx; g.ldc = S; g.resid = d.dx; g.ldr = S; g.ldaux = S; g.ldaux2 = S; g.S = S;
+            g.step_copy_src = d.step_host; g.step_copy_dst = d.step_dev;
+            k::gemv(g, s);
+        } else
         if (M & 64) gv(k::EPI_F32_BIAS_RESID, nullptr, nullptr, d.dh, 4 * S, S, l.w_fc2, l.b_fc2, d.dx, S, d.dx, nullptr, nullptr, 0.f, nullptr);
     }
     chk("layers", Lt);
     if (M & 128) gv(k::EPI_LOGITS, w.d_ln_g, w.d_ln_b, nullptr, S, NV, w.d_te, nullptr, d.logits, NV, nullptr, nullptr, nullptr, 0.f, nullptr); chk("logits", Lt);
-    if (M & 256) k::filter_argmax(d.logits, d.ban_dev, stp, (k::SampleOut *) d.sample_dev, d.filter_scratch, s, (k::SampleOut *) d.sample_host); chk("filter", Lt);
+    // the pick also prepares the next step on the device (token = pick, position / cache head + 1, x = te[pick] + pe[pos + 1])
+    const k::ChainNext cn{ (k::DecStep *) d.step_dev, w.d_te, w.d_pe, d.dx, S, hp.n_text_ctx };
+    if (M & 256) k::filter_argmax(d.logits, d.ban_dev, stp, (k::SampleOut *) d.sample_dev, d.filter_scratch, s, (k::SampleOut *) d.sample_host, 1, &cn); chk("filter", Lt);
 }
 
 bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const StepFilter & f, whisper_token_data & out) {
@@ -618,9 +634,13 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
     static const bool use_graph = getenv("WMI_NO_GRAPH") == nullptr;
     // two captured forms of the step: caches of <= 64 cells (self-attention inside the out projection) and longer ones
     const bool long_kv = (int) kv.n > 64 && !ctx.model.quantised;          // (the quantised step has one form for every length)
-    hipGraph_t & graph = long_kv ? d.step_graph_long : d.step_graph;
-    hipGraphExec_t & exec = long_kv ? d.step_exec_long : d.step_exec;
-    int & graph_T = long_kv ? d.step_graph_long_T : d.step_graph_T;
+    static const bool no_chain = getenv("WMI_NO_CHAIN") != nullptr;         // debug / A-B
+    const bool chained = !no_chain && !long_kv && !ctx.model.quantised && d.chain_valid && token == d.chain_token && pos == d.chain_pos &&
+                         (int) kv.head == d.chain_head;
+    d.chain_valid = false;
+    hipGraph_t & graph = long_kv ? d.step_graph_long : chained ? d.step_graph_chain : d.step_graph;
+    hipGraphExec_t & exec = long_kv ? d.step_exec_long : chained ? d.step_exec_chain : d.step_exec;
+    int & graph_T = long_kv ? d.step_graph_long_T : chained ? d.step_graph_chain_T : d.step_graph_T;
     if (use_graph && exec && graph_T != Tc) {                           // encoder length changed: the captured step is stale
         (void) hipGraphExecDestroy(exec); (void) hipGraphDestroy(graph);
         exec = nullptr; graph = nullptr;
@@ -629,15 +649,19 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
     // the buffer), so a step is only captured once the same encoder length has been decoded for a while — until then the
     // launches go out eagerly (the host then pays ~4 us per launch: equal to the replay for the 40-launch short-cache step,
     // twice the replay's time for the long-cache form)
-    if (d.step_seen_T != Tc) { d.step_seen_T = Tc; d.step_seen_n = 0; d.step_seen_long_n = 0; }
-    int & seen = long_kv ? d.step_seen_long_n : d.step_seen_n;
+    if (d.step_seen_T != Tc) { d.step_seen_T = Tc; d.step_seen_n = 0; d.step_seen_long_n = 0; d.step_seen_chain_n = 0; }
+    int & seen = long_kv ? d.step_seen_long_n : chained ? d.step_seen_chain_n : d.step_seen_n;
     const bool capture_now = use_graph && !exec && !d.step_capture_failed && ++seen > 64;
     if (capture_now) {
         // first use: run once eagerly (lets the launchers set their function attributes), then capture
-        enqueue_greedy_step(ctx, Tc, long_kv);
-        HIP_TRY(hipStreamSynchronize(s));
+        // (not for the chained form: a step's pick kernel advances the device-side record, so the step must not run twice — and its
+        // kernels are the plain form's, which has run many times by now)
+        if (!chained) {
+            enqueue_greedy_step(ctx, Tc, long_kv, false);
+            HIP_TRY(hipStreamSynchronize(s));
+        }
         if (HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal))) {
-            enqueue_greedy_step(ctx, Tc, long_kv);
+            enqueue_greedy_step(ctx, Tc, long_kv, chained);
             hipGraph_t g = nullptr;
             const bool ended = HIP_OK(hipStreamEndCapture(s, &g));
             if (ended && g && HIP_OK(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0))) {
@@ -656,10 +680,13 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
     if (use_graph && exec) {
         HIP_TRY(hipGraphLaunch(exec, s));
     } else {
-        enqueue_greedy_step(ctx, Tc, long_kv);
+        enqueue_greedy_step(ctx, Tc, long_kv, chained);
     }
     const k::SampleOut * r = (const k::SampleOut *) d.sample_host;
     if (!wait_for_seq(&r->seq, d.step_seq, s)) return false;
+    // what the pick kernel has left on the device for the next step
+    d.chain_valid = !ctx.model.quantised && pos + 1 < hp.n_text_ctx;
+    d.chain_token = r->id; d.chain_pos = pos + 1; d.chain_head = (int32_t) kv.head + 1;
     if (getenv("WMI_DEBUG_SYNC")) fprintf(stderr, "[wmi] step token=%d pos=%d n_kv=%d head=%d flags=%d floor=%d init=%d -> id=%d tid=%d p=%g plog=%g pt=%g ptsum=%g forced=%d\n",
         token, pos, hs->n_kv, hs->kv_head, hs->flags, hs->ts_floor_end, hs->ts_initial_start, r->id, r->tid, r->p, r->plog, r->pt, r->ptsum, r->forced_ts);
     out = whisper_token_data{ r->id, r->tid, r->p, r->plog, r->pt, r->ptsum, -1, -1, 0.0f };
@@ -672,6 +699,7 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
 double bench_greedy_step_chain(whisper_context & ctx, int iters) {
     State & st = *ctx.state; DeviceState & d = st.dev;
     if (!d.step_dev || iters <= 0) return -1.0;
+    d.chain_valid = false;                                  // the replays below advance the device-side step record
     const char * mask_env = getenv("WMI_STEP_MASK");
     g_step_mask = mask_env ? (unsigned) strtoul(mask_env, nullptr, 0) : ~0u;
     // bits 9 / 10 (only with an explicit mask): skip scores / P.V inside bit 3 — without this guard the eager chain ran without cross-attention

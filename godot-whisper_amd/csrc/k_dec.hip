@@ -36,6 +36,10 @@ __global__ void k_dec_embed(const int32_t * __restrict__ tokens, const int32_t *
     for (int c = threadIdx.x; c < S; c += blockDim.x) x[(size_t) i * S + c] = __half2float(t[c]) + p[c];
 }
 
+__global__ void k_step_mirror(const int32_t * __restrict__ host_step, int32_t * __restrict__ dev_step) {
+    if (threadIdx.x < sizeof(DecStep) / 4) dev_step[threadIdx.x] = ((const volatile int32_t *) host_step)[threadIdx.x];
+}
+
 // Graph-replay variant: the step parameters are read straight from pinned HOST memory (one PCIe read, no memcpy
 // node in the graph) and mirrored into device memory for the kernels that follow.
 __global__ void k_dec_embed_step(const DecStep * __restrict__ host_step, DecStep * __restrict__ dev_step, int S,
@@ -716,7 +720,19 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
     __half * act = (__half *) smem;                         // [K], attention prologues only
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K;
-    const int nwaves = gridDim.x * 4;
+    int nblk = gridDim.x;
+    if constexpr (PRO <= 0 && (EPI < 0 || EPI == EPI_F32_BIAS_RESID)) {
+        // chained greedy steps (device.cpp): the launch carries ONE extra workgroup that mirrors the host's step record into device
+        // memory for the filter kernels — a PCIe read that costs this small-grid launch nothing (32 workgroups on 256 CUs)
+        if (a.step_copy_src) {
+            nblk -= 1;
+            if ((int) blockIdx.x == nblk) {
+                if (tid < (int) (sizeof(DecStep) / 4)) ((int32_t *) a.step_copy_dst)[tid] = ((const volatile int32_t *) a.step_copy_src)[tid];
+                return;
+            }
+        }
+    }
+    const int nwaves = nblk * 4;
     const int gw = blockIdx.x * 4 + wave;
 
     // ALL chunks of the first row tile are requested before anything else (with only the first chunk up front, K > 512 paid a
@@ -943,6 +959,7 @@ void launch_gemv1(const GemvArgs & a, hipStream_t st, int max_blocks = 512) {
     if (blocks > max_blocks) blocks = max_blocks;
     static std::atomic<uint64_t> lds_ok{0};
     if (smem > 48 * 1024) allow_full_lds((const void *) k_gemv1<RIF, NCH, NT, PRO, EPI>, lds_ok);
+    if (PRO <= 0 && (EPI < 0 || EPI == EPI_F32_BIAS_RESID) && a.step_copy_src) blocks += 1;       // the step-record mirror (see the kernel)
     hipLaunchKernelGGL((k_gemv1<RIF, NCH, NT, PRO, EPI>), dim3(blocks), dim3(256), smem, st, a);
 }
 
@@ -1312,6 +1329,8 @@ void gemv(const GemvArgs & a, hipStream_t st) {
         }
         return;
     }
+    // (the LDS-staged kernels below do not carry the step-record mirror of the chained greedy step: its own tiny launch then)
+    if (a.step_copy_src) hipLaunchKernelGGL(k_step_mirror, dim3(1), dim3(64), 0, st, (const int32_t *) a.step_copy_src, (int32_t *) a.step_copy_dst);
     switch (a.n) {
         case 1: launch_gemv<1>(a, st); break;
         case 2: launch_gemv<2>(a, st); break;

@@ -106,7 +106,7 @@ __global__ __launch_bounds__(NT) void k_filter_stats(const float * __restrict__ 
 }
 
 __global__ __launch_bounds__(64) void k_filter_pick(const Partial * __restrict__ part, const DecStep * __restrict__ stp,
-                                                    SampleOut * __restrict__ out, SampleOut * __restrict__ out_host) {
+                                                    SampleOut * __restrict__ out, SampleOut * __restrict__ out_host, const ChainNext chain) {
     const int lane = threadIdx.x;
     part += (size_t) blockIdx.x * NB; stp += blockIdx.x; out += blockIdx.x; if (out_host) out_host += blockIdx.x;
     const Partial p = part[lane];                       // NB == 64: one partial per lane
@@ -114,6 +114,7 @@ __global__ __launch_bounds__(64) void k_filter_pick(const Partial * __restrict__
     const float M = a.v;
     const float w = p.all.v > -INFINITY ? expf(p.all.v - M) : 0.0f;      // rescale the local sums to the global max
     const float sum = wave_sum(p.sum * w), sum_ts = wave_sum(p.sum_ts * w);
+    int id = 0;
     if (lane == 0) {
         const int beg = stp->beg;
         const float lse = logf(sum) + M;
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(64) void k_filter_pick(const Partial * __restrict__
         r.ptsum = (float) sum_ts_p;
         if (r.id >= beg) { r.tid = r.id; r.pt = r.p; }
         *out = r;
+        id = r.id;
         if (out_host) {
             // result straight into pinned host memory; the sequence number goes last, behind a system-scope fence: the host
             // spins on it instead of paying a stream synchronisation per token
@@ -140,6 +142,20 @@ __global__ __launch_bounds__(64) void k_filter_pick(const Partial * __restrict__
             __threadfence_system();
             *(volatile int32_t *) &out_host->seq = r.seq;
             __threadfence_system();
+        }
+    }
+    if (chain.step_rw) {
+        // the next greedy step feeds this pick at the next position (the host checks that before it replays the chained step)
+        id = __shfl(id, 0);
+        const int pos1 = stp->pos + 1;
+        if (pos1 < chain.n_pos) {
+            const __half * tr = chain.te + (size_t) id * chain.S;
+            const float * pr = chain.pe + (size_t) pos1 * chain.S;
+            for (int c = lane; c < chain.S; c += 64) chain.x[c] = __half2float(tr[c]) + pr[c];      // k_dec_embed_step's arithmetic
+        }
+        if (lane == 0) {
+            const int n_kv = stp->n_kv, head = stp->kv_head;
+            chain.step_rw->token = id; chain.step_rw->pos = pos1; chain.step_rw->n_kv = n_kv + 1; chain.step_rw->kv_head = head + 1;
         }
     }
 }
@@ -259,10 +275,12 @@ void filter_draw(const float * logits, const uint8_t * static_ban, const DecStep
 size_t filter_draw_scratch_bytes(int n_rows) { return filter_scratch_bytes(n_rows) + (size_t) n_rows * NB * sizeof(double); }
 
 void filter_argmax(const float * logits, const uint8_t * static_ban, const DecStep * step, SampleOut * out, void * scratch,
-                   hipStream_t st, SampleOut * out_host, int n_rows) {
+                   hipStream_t st, SampleOut * out_host, int n_rows, const ChainNext * chain) {
     Partial * part = (Partial *) scratch;
     hipLaunchKernelGGL(k_filter_stats, dim3(NB, n_rows), dim3(NT), 0, st, logits, static_ban, step, part);
-    hipLaunchKernelGGL(k_filter_pick, dim3(n_rows), dim3(64), 0, st, part, step, out, out_host);
+    ChainNext cn{};                                         // chaining is a one-row affair (the greedy step of device.cpp)
+    if (chain && n_rows == 1) cn = *chain;
+    hipLaunchKernelGGL(k_filter_pick, dim3(n_rows), dim3(64), 0, st, part, step, out, out_host, cn);
 }
 size_t filter_scratch_bytes(int n_rows) { return (size_t) n_rows * NB * sizeof(Partial); }
 

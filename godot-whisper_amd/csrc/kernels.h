@@ -141,6 +141,9 @@ struct GemvArgs {
     //   aux/aux2 row = row_off[r * step_stride] (no "+ r"), cache base + r * cache_row_stride ; sa_nkv[r * step_stride] ;
     //   sa_k / sa_v + r * cache_row_stride
     int lanes; int step_stride; int64_t cache_row_stride;
+    // chained greedy steps: mirror *step_copy_src (DecStep in pinned host memory) into *step_copy_dst by an extra workgroup
+    // (one-row f16 rows x plain projection + residual only: the last mlp.2 of the step)
+    const void * step_copy_src; void * step_copy_dst;
 };
 // lock-step chunks: single-token self-attention of n rows, row r against the cache at kc/vc + r * cache_row_stride with
 // n_kv[r * step_stride] cells; same arithmetic as the fused prologue of gemv (GemvArgs::sa_*).  out [n][K] f16
@@ -174,8 +177,11 @@ struct DecStep {
 struct SampleOut { int32_t id, tid; float p, plog, pt, ptsum; int32_t forced_ts; int32_t seq; };
 // logits [n_vocab] -> filtered soft-max statistics and the arg-max token (W/whisper.cpp:4493-4830 at temperature 0)
 // n_rows > 1: lock-step chunks — logits [n_rows][n_vocab], step[n_rows], out[n_rows]
+// chain (one row): the pick kernel also prepares the NEXT greedy step on the device — token = the pick, pos / n_kv / kv_head + 1 in
+// *step_rw, and the next activation row x = te[pick] + pe[pos + 1] — so that the next step needs no embedding launch
+struct ChainNext { DecStep * step_rw; const __half * te; const float * pe; float * x; int S; int n_pos; };
 void filter_argmax(const float * logits, const uint8_t * static_ban, const DecStep * step, SampleOut * out, void * scratch, hipStream_t st,
-                   SampleOut * out_host = nullptr, int n_rows = 1);
+                   SampleOut * out_host = nullptr, int n_rows = 1, const ChainNext * chain = nullptr);
 size_t filter_scratch_bytes(int n_rows = 1);
 // Draws from the filtered distribution on the device (beam search candidates, t > 0 sampling: whisper_sample_token(best = false)
 // and whisper_sample_token_topk, W/whisper.cpp:4777-4909).  The reference draws with std::discrete_distribution on the 51 866

@@ -226,6 +226,10 @@ struct DeviceState {
     hipGraph_t step_graph = nullptr; hipGraphExec_t step_exec = nullptr; int step_graph_T = -1;
     // the same for caches past 64 cells (f16 models: (row, head)-parallel self-attention + plain out projection, device.cpp)
     hipGraph_t step_graph_long = nullptr; hipGraphExec_t step_exec_long = nullptr; int step_graph_long_T = -1; int step_seen_long_n = 0;
+    // chained form (f16 models, short caches): no embedding launch — the previous step's pick kernel left the token, the position,
+    // the cache head and the next activation row on the device; valid while the host feeds exactly that token at that position
+    hipGraph_t step_graph_chain = nullptr; hipGraphExec_t step_exec_chain = nullptr; int step_graph_chain_T = -1; int step_seen_chain_n = 0;
+    bool chain_valid = false; int32_t chain_token = 0, chain_pos = 0, chain_head = 0;
     int32_t step_seq = 0;                                             // sequence number of the last greedy step launched
     // device-side draws (beam search, t > 0): decode() leaves the logits rows in d.logits, sample_rows_device() draws from them
     bool    keep_logits_on_device = false;
