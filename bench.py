@@ -281,7 +281,8 @@ def main():
             step_bytes = DEC_MB_PER_TOKEN * 1e6
             out["roofline_decode_step"] = {"bound": "hbm", "achieved": round(step_bytes / (us_step * 1e-6) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                            "frac": round(step_bytes / (us_step * 1e-6) / 1e9 / 8000.0, 4), "algorithmic_bytes": int(step_bytes),
-                                           "avg_us": round(us_step, 2), "launches": int(sum(t["launches_per_step"] for t in table) + 1)}
+                                           "avg_us": round(us_step, 2), "launches": int(sum(t["launches_per_step"] for t in table) + 1),
+                                           "note": "the probe replays the step with its embedding launch; inside a transcription every step after the first is chained (the pick kernel prepares the next step on the device): one launch fewer, see decode_ms_per_token"}
             out["roofline_encoder"] = {"bound": "mfma", "achieved": round(ENC_GFLOP / enc_ms, 2), "peak": 2500.0, "unit": "TFLOP/s",
                                        "frac": round(ENC_GFLOP / enc_ms / 2500.0, 4), "algorithmic_gflop": ENC_GFLOP, "encode_ms": round(enc_ms, 4)}
             # the vocabulary projection alone: on one matrix (Infinity-Cache resident after the first pass) and on a rotating > 256 MiB stream
