@@ -112,12 +112,7 @@ void destroy_state(State * st) {
     dfree(d.enc_out_h); dfree(d.d_tokens); dfree(d.d_pos); dfree(d.d_mask); dfree(d.d_rows); dfree(d.dx); dfree(d.dxn);
     dfree(d.dq); dfree(d.datt); dfree(d.dh); dfree(d.logits); dfree(d.xattn); dfree(d.ban_dev);
     dfree(d.aq); dfree(d.ads); dfree(d.att32); dfree(d.datt32);
-    if (d.step_exec) (void) hipGraphExecDestroy(d.step_exec);
-    if (d.step_graph) (void) hipGraphDestroy(d.step_graph);
-    if (d.step_exec_long) (void) hipGraphExecDestroy(d.step_exec_long);
-    if (d.step_graph_long) (void) hipGraphDestroy(d.step_graph_long);
-    if (d.step_exec_chain) (void) hipGraphExecDestroy(d.step_exec_chain);
-    if (d.step_graph_chain) (void) hipGraphDestroy(d.step_graph_chain);
+    for (auto & sg : d.step_graphs) { if (sg.exec) (void) hipGraphExecDestroy(sg.exec); if (sg.graph) (void) hipGraphDestroy(sg.graph); sg = DeviceState::StepGraph{}; }
     if (d.step_dev) (void) hipFree(d.step_dev);
     if (d.sample_dev) (void) hipFree(d.sample_dev);
     if (d.filter_scratch) (void) hipFree(d.filter_scratch);
@@ -635,12 +630,11 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
     // two captured forms of the step: caches of <= 64 cells (self-attention inside the out projection) and longer ones
     const bool long_kv = (int) kv.n > 64 && !ctx.model.quantised;          // (the quantised step has one form for every length)
     static const bool no_chain = getenv("WMI_NO_CHAIN") != nullptr;         // debug / A-B
-    const bool chained = !no_chain && !long_kv && !ctx.model.quantised && d.chain_valid && token == d.chain_token && pos == d.chain_pos &&
+    const bool chained = !no_chain && !ctx.model.quantised && d.chain_valid && token == d.chain_token && pos == d.chain_pos &&
                          (int) kv.head == d.chain_head;
     d.chain_valid = false;
-    hipGraph_t & graph = long_kv ? d.step_graph_long : chained ? d.step_graph_chain : d.step_graph;
-    hipGraphExec_t & exec = long_kv ? d.step_exec_long : chained ? d.step_exec_chain : d.step_exec;
-    int & graph_T = long_kv ? d.step_graph_long_T : chained ? d.step_graph_chain_T : d.step_graph_T;
+    DeviceState::StepGraph & sg = d.step_graphs[(long_kv ? 1 : 0) | (chained ? 2 : 0)];
+    hipGraph_t & graph = sg.graph; hipGraphExec_t & exec = sg.exec; int & graph_T = sg.T;
     if (use_graph && exec && graph_T != Tc) {                           // encoder length changed: the captured step is stale
         (void) hipGraphExecDestroy(exec); (void) hipGraphDestroy(graph);
         exec = nullptr; graph = nullptr;
@@ -649,8 +643,8 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
     // the buffer), so a step is only captured once the same encoder length has been decoded for a while — until then the
     // launches go out eagerly (the host then pays ~4 us per launch: equal to the replay for the 40-launch short-cache step,
     // twice the replay's time for the long-cache form)
-    if (d.step_seen_T != Tc) { d.step_seen_T = Tc; d.step_seen_n = 0; d.step_seen_long_n = 0; d.step_seen_chain_n = 0; }
-    int & seen = long_kv ? d.step_seen_long_n : chained ? d.step_seen_chain_n : d.step_seen_n;
+    if (d.step_seen_T != Tc) { d.step_seen_T = Tc; for (auto & g2 : d.step_graphs) g2.seen = 0; }
+    int & seen = sg.seen;
     const bool capture_now = use_graph && !exec && !d.step_capture_failed && ++seen > 64;
     if (capture_now) {
         // first use: run once eagerly (lets the launchers set their function attributes), then capture
@@ -710,8 +704,8 @@ double bench_greedy_step_chain(whisper_context & ctx, int iters) {
     hipEvent_t e0, e1;
     if (!HIP_OK(hipEventCreate(&e0)) || !HIP_OK(hipEventCreate(&e1))) return -1.0;
     const bool long_kv = ((const k::DecStep *) d.step_host)->n_kv > 64 && !ctx.model.quantised;
-    hipGraphExec_t exec = long_kv ? d.step_exec_long : d.step_exec;
-    const int exec_T = long_kv ? d.step_graph_long_T : d.step_graph_T;
+    hipGraphExec_t exec = d.step_graphs[long_kv ? 1 : 0].exec;
+    const int exec_T = d.step_graphs[long_kv ? 1 : 0].T;
     auto once = [&]() { if (exec && exec_T == Tc && g_step_mask == ~0u) (void) hipGraphLaunch(exec, s); else enqueue_greedy_step(ctx, Tc, long_kv); };
     for (int i = 0; i < 4; ++i) once();
     (void) hipStreamSynchronize(s);

@@ -223,12 +223,12 @@ struct DeviceState {
     void   * sample_dev = nullptr; void * sample_host = nullptr;     // k::SampleOut (device / pinned)
     void   * filter_scratch = nullptr;
     uint8_t * ban_dev = nullptr;   uint64_t ban_sig = ~0ull;          // static suppress mask + its parameter signature
-    hipGraph_t step_graph = nullptr; hipGraphExec_t step_exec = nullptr; int step_graph_T = -1;
-    // the same for caches past 64 cells (f16 models: (row, head)-parallel self-attention + plain out projection, device.cpp)
-    hipGraph_t step_graph_long = nullptr; hipGraphExec_t step_exec_long = nullptr; int step_graph_long_T = -1; int step_seen_long_n = 0;
-    // chained form (f16 models, short caches): no embedding launch — the previous step's pick kernel left the token, the position,
-    // the cache head and the next activation row on the device; valid while the host feeds exactly that token at that position
-    hipGraph_t step_graph_chain = nullptr; hipGraphExec_t step_exec_chain = nullptr; int step_graph_chain_T = -1; int step_seen_chain_n = 0;
+    // captured forms of the greedy step, index = (cache longer than 64 cells ? 1 : 0) | (chained ? 2 : 0):
+    //   long    f16 models: (row, head)-parallel self-attention + plain out projection instead of the fused prologue (device.cpp)
+    //   chained no embedding launch — the previous step's pick kernel left the token, the position, the cache head and the next
+    //           activation row on the device; valid while the host feeds exactly that token at that position
+    struct StepGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int T = -1; int seen = 0; };
+    StepGraph step_graphs[4];
     bool chain_valid = false; int32_t chain_token = 0, chain_pos = 0, chain_head = 0;
     int32_t step_seq = 0;                                             // sequence number of the last greedy step launched
     // device-side draws (beam search, t > 0): decode() leaves the logits rows in d.logits, sample_rows_device() draws from them
@@ -236,7 +236,7 @@ struct DeviceState {
     void  * draw_dev = nullptr;  void * draw_host = nullptr;          // DecStep[8] | u[8][8] | SampleOut[8][8] (device / pinned)
     void  * draw_scratch = nullptr;
     bool    step_capture_failed = false;                               // a failed capture is not retried
-    int     step_seen_T = -1, step_seen_n = 0;                        // encoder length of recent steps / how many in a row
+    int     step_seen_T = -1;                                          // encoder length of recent steps (StepGraph::seen counts them)
 };
 
 struct State {
