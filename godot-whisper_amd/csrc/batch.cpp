@@ -267,9 +267,9 @@ static void enqueue_rows_step(whisper_context & ctx, int nb) {
             k::attn_cross_qsplit_partials(b.dx, l.ln2_g, l.ln2_b, hp.eps, l.w_cq, l.b_cq, kq_scale, nb, S, H,
                                           b.kvc_k + (size_t) il * cross_layer, b.kvc_v + (size_t) il * cross_layer, Tc,
                                           b.xattn, &po, &pl, &pm, &ns, s, (int64_t) Tc * S);
-            if (M & 32) k::attn_cross_combine(po, pl, pm, ns, nb, S, H, b.datt, s);
+            // the out projection combines the key-slice partials in its prologue (all row kernels do): no combine launch
             k::GemvArgs g = base(S, S, l.w_co, l.b_co, k::EPI_F32_BIAS_RESID, b.dx, S);
-            g.a16 = b.datt; g.resid = b.dx;
+            g.comb_o = po; g.comb_l = pl; g.comb_m = pm; g.comb_ns = ns; g.resid = b.dx;
             if (M & 64) k::gemv(g, s);
         }
         {

@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
     // f16 activation rows without a LayerNorm in front (out projections, mlp.2): the B fragments of the first pass are requested
     // straight from global memory next to the weights — no LDS copy, no barrier before the first MFMA (the staged copy measured
     // 4 us of a 7.5 us launch at 8 rows x 2048)
-    const bool direct_b = KSPLIT && !a.ln_g && !a.rows;      // (the vocabulary projection always has its LayerNorm: no registers for bf there)
+    const bool direct_b = KSPLIT && !a.ln_g && !a.rows && !a.comb_o;      // (the vocabulary projection always has its LayerNorm: no registers for bf there)
     uint4 bf[MAXF];
     const __half * brow = a.a16 + (size_t) (col < n ? col : 0) * K + kq * 8;
     if (direct_b && tile < ntiles) {
@@ -1121,6 +1121,52 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
         if (n <= 4) ln_rows(std::integral_constant<int, 1>{});
         else if (n <= 8) ln_rows(std::integral_constant<int, 2>{});
         else ln_rows(std::integral_constant<int, 4>{});
+        }
+    } else if (a.comb_o) {
+        // B = the combined cross-attention partials of the rows (k_xattn_combine's arithmetic, f16 like its output): 16-byte pieces
+        // (row, 8 dims of a head) flattened over the workgroup, the ns slices of a piece requested together — one round trip
+        // instead of a combine launch per layer of the lock-step step
+        const int cpr = K >> 3, total = n * cpr, H = K >> 6, ns = a.comb_ns;
+        for (int e0 = 0; e0 < total; e0 += 256) {
+            const int e = e0 + tid;
+            if (e < total) {
+                const int r = e / cpr, c = e - r * cpr, kk = c * 8, h = kk >> 6, dd = kk & 63;
+                const size_t row = (size_t) r * H + h;
+                float o[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; double l = 0.0;
+                if (ns == 8) {
+                    float4 p0[8], p1[8]; float pl[8], pm[8];
+#pragma unroll
+                    for (int s2 = 0; s2 < 8; ++s2) {
+                        p0[s2] = *(const float4 *) (a.comb_o + (row * 8 + s2) * 64 + dd); p1[s2] = *(const float4 *) (a.comb_o + (row * 8 + s2) * 64 + dd + 4);
+                        pl[s2] = a.comb_l[row * 8 + s2]; pm[s2] = a.comb_m ? a.comb_m[row * 8 + s2] : 0.0f;
+                    }
+                    float M = -INFINITY;
+#pragma unroll
+                    for (int s2 = 0; s2 < 8; ++s2) M = fmaxf(M, pm[s2]);
+#pragma unroll
+                    for (int s2 = 0; s2 < 8; ++s2) {
+                        const float w = !a.comb_m ? 1.0f : pm[s2] > -INFINITY ? expf(pm[s2] - M) : 0.0f;
+                        o[0] += p0[s2].x * w; o[1] += p0[s2].y * w; o[2] += p0[s2].z * w; o[3] += p0[s2].w * w;
+                        o[4] += p1[s2].x * w; o[5] += p1[s2].y * w; o[6] += p1[s2].z * w; o[7] += p1[s2].w * w;
+                        l += (double) pl[s2] * (double) w;
+                    }
+                } else {
+                    float M = -INFINITY;
+                    if (a.comb_m) for (int s2 = 0; s2 < ns; ++s2) M = fmaxf(M, a.comb_m[row * ns + s2]);
+                    for (int s2 = 0; s2 < ns; ++s2) {
+                        const float w = comb_weight(a.comb_m, row * ns + s2, M);
+                        const float4 q0 = *(const float4 *) (a.comb_o + (row * ns + s2) * 64 + dd), q1 = *(const float4 *) (a.comb_o + (row * ns + s2) * 64 + dd + 4);
+                        o[0] += q0.x * w; o[1] += q0.y * w; o[2] += q0.z * w; o[3] += q0.w * w;
+                        o[4] += q1.x * w; o[5] += q1.y * w; o[6] += q1.z * w; o[7] += q1.w * w;
+                        l += (double) a.comb_l[row * ns + s2] * (double) w;
+                    }
+                }
+                const float inv = (float) (1.0 / l);
+                __half hv[8];
+#pragma unroll
+                for (int q = 0; q < 8; ++q) hv[q] = f2h(o[q] * inv);
+                *(uint4 *) (act + r * lda + kk) = *(const uint4 *) hv;
+            }
         }
     } else if (!direct_b) {
         // n rows of K / 8 16-byte pieces, flattened over the workgroup; the loads of a group of pieces before their LDS stores
@@ -1308,7 +1354,7 @@ void gemv(const GemvArgs & a, hipStream_t st) {
     // arithmetic is bit-identical to the single-row path: used by the parity tests to pin the control flow)
     static const bool rows_valu_env = getenv("WMI_ROWS_VALU") != nullptr;
     const bool rows_valu = rows_valu_env || g_rows_valu;
-    const bool mfma_ok = a.lanes && a.n >= 2 && a.n <= 16 && !a.sa_q && !a.comb_o && (a.K % 128) == 0 &&
+    const bool mfma_ok = a.lanes && a.n >= 2 && a.n <= 16 && !a.sa_q && (!a.comb_o || a.N < 8192) && (a.K % 128) == 0 &&
                          (a.epi != EPI_QKV_DEC || (a.S % 16) == 0) && (!rows_valu || a.n > 8);
     if (mfma_ok) {
         if (a.N >= 8192) launch_rows_mfma<false>(a, st); else launch_rows_mfma<true>(a, st);
