@@ -219,6 +219,12 @@ def main():
             "sample_ms_per_step": round((t6[5] / 1e3) / args.steps, 4),
             "weight_bcast_ms": round(1e3 * t_bcast, 3), "weight_bcast": "one RCCL broadcast of the packed device arena (no re-parse on the other ranks)",
         }
+        if args.chunks > 1:                          # lock-step calls keep their own timers (last call)
+            t4 = (C.c_int64 * 4)(); ns = C.c_int32(); lib.wmi_get_batch_timings(ctx, t4, C.byref(ns))
+            out["encode_ms"] = round(t4[1] / 1e3, 4); out["mel_ms"] = round(t4[0] / 1e3, 4)
+            out["decode_ms_per_token"] = round(t4[2] / 1e3 / max(ns.value, 1), 4)
+            out["decode_steps_per_call"] = int(ns.value); out["segments_timestamps_ms"] = round(t4[3] / 1e3, 4)
+            out["pcm"] = "device-resident (wmi_full_batch, pcm_on_device = 1)"
         if dev_pcm:
             out["device_pcm"] = dev_pcm
         if uncapped:
