@@ -202,7 +202,19 @@ __global__ __launch_bounds__(MEL_NT) void k_mel_frames(const float * __restrict_
         vmax = fmaxf(vmax, v);
     }
     for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
-    if ((tid & 63) == 0 && vmax > -INFINITY) atomicMax(gmax, enc_ordered(vmax));
+    // one atomic per frame at most, and only when it can raise the maximum: 12 000 atomics on one address (one per wavefront)
+    // serialised at the memory side and were most of this kernel's 76 us
+    __shared__ float s_vmax[MEL_NT / 64];
+    if ((tid & 63) == 0) s_vmax[tid >> 6] = vmax;
+    __syncthreads();
+    if (tid == 0) {
+        float v = s_vmax[0];
+        for (int w = 1; w < MEL_NT / 64; ++w) v = fmaxf(v, s_vmax[w]);
+        if (v > -INFINITY) {
+            const int e = enc_ordered(v);
+            if (e > __hip_atomic_load(gmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(gmax, e);
+        }
+    }
 }
 
 __global__ void k_mel_normalize(float * __restrict__ mel, int n, const int * __restrict__ gmax) {
