@@ -790,7 +790,7 @@ __global__ __launch_bounds__(256) void k_xattn_fused(const float * __restrict__ 
 __device__ __forceinline__ float slice_weight(const float * part_m, size_t base, int ns, int s2, float M) {
     (void) ns;
     const float ms = part_m[base + s2];
-    return ms > -INFINITY ? expf(ms - M) : 0.0f;
+    return ms > -INFINITY ? __expf(ms - M) : 0.0f;
 }
 
 __global__ __launch_bounds__(64) void k_xattn_combine(const float * __restrict__ part_o, const float * __restrict__ part_l,

@@ -72,11 +72,13 @@ __global__ void k_dec_embed_step(const DecStep * __restrict__ host_step, DecStep
 // k_gemv1, the lock-step row kernels — goes through this routine, which keeps them bit-identical to each other.
 // Returns false, with nothing written, when n_kv > 64 (callers then take self_attn_row).
 // weight of a cross-attention slice partial in the combine: 1 when the partials are relative to the row's global maximum
-// (comb_m == null), else exp(m_slice - M) (k_xattn_fused, k_attn.hip)
+// (comb_m == null), else exp(m_slice - M) (k_xattn_fused, k_attn.hip).  v_exp_f32 (__expf, ~1e-6 relative on arguments of a few
+// units) in EVERY consumer of the partials — k_gemv1, k_gemv, k_rows_mfma, k_qrows, k_xattn_combine — so that they stay
+// bit-identical to each other; libm's expf was 16 calls per thread of the out projection's prologue (+0.6 us per launch)
 __device__ __forceinline__ float comb_weight(const float * comb_m, size_t idx, float M) {
     if (!comb_m) return 1.0f;
     const float ms = comb_m[idx];
-    return ms > -INFINITY ? expf(ms - M) : 0.0f;
+    return ms > -INFINITY ? __expf(ms - M) : 0.0f;
 }
 
 template <int NU>
@@ -831,7 +833,7 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
                         for (int s2 = 0; s2 < 8; ++s2) M = fmaxf(M, pm[u][s2]);
 #pragma unroll
                         for (int s2 = 0; s2 < 8; ++s2) {
-                            const float w = !a.comb_m ? 1.0f : pm[u][s2] > -INFINITY ? expf(pm[u][s2] - M) : 0.0f;
+                            const float w = !a.comb_m ? 1.0f : pm[u][s2] > -INFINITY ? __expf(pm[u][s2] - M) : 0.0f;
                             o += po[u][s2] * w; l += (double) pl[u][s2] * (double) w;
                         }
                         if (e0 + u * 256 < K) act[e0 + u * 256] = f2h(o * (float) (1.0 / l));
@@ -1145,7 +1147,7 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
                     for (int s2 = 0; s2 < 8; ++s2) M = fmaxf(M, pm[s2]);
 #pragma unroll
                     for (int s2 = 0; s2 < 8; ++s2) {
-                        const float w = !a.comb_m ? 1.0f : pm[s2] > -INFINITY ? expf(pm[s2] - M) : 0.0f;
+                        const float w = !a.comb_m ? 1.0f : pm[s2] > -INFINITY ? __expf(pm[s2] - M) : 0.0f;
                         o[0] += p0[s2].x * w; o[1] += p0[s2].y * w; o[2] += p0[s2].z * w; o[3] += p0[s2].w * w;
                         o[4] += p1[s2].x * w; o[5] += p1[s2].y * w; o[6] += p1[s2].z * w; o[7] += p1[s2].w * w;
                         l += (double) pl[s2] * (double) w;

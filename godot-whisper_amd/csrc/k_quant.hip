@@ -732,7 +732,7 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
                     for (int s2 = 0; s2 < 8; ++s2) M = fmaxf(M, pm[s2]);
 #pragma unroll
                     for (int s2 = 0; s2 < 8; ++s2) {
-                        const float w = !a.comb_m ? 1.0f : pm[s2] > -INFINITY ? expf(pm[s2] - M) : 0.0f;
+                        const float w = !a.comb_m ? 1.0f : pm[s2] > -INFINITY ? __expf(pm[s2] - M) : 0.0f;
                         o.x += po[s2].x * w; o.y += po[s2].y * w; o.z += po[s2].z * w; o.w += po[s2].w * w; l += (double) pl[s2] * (double) w;
                     }
                 } else {
@@ -740,7 +740,7 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
                     if (a.comb_m) for (int s2 = 0; s2 < ns; ++s2) M = fmaxf(M, a.comb_m[row * ns + s2]);
                     for (int s2 = 0; s2 < ns; ++s2) {
                         const float ms = a.comb_m ? a.comb_m[row * ns + s2] : 0.0f;
-                        const float w = !a.comb_m ? 1.0f : ms > -INFINITY ? expf(ms - M) : 0.0f;
+                        const float w = !a.comb_m ? 1.0f : ms > -INFINITY ? __expf(ms - M) : 0.0f;
                         const float4 t = *(const float4 *) (a.comb_o + (row * ns + s2) * 64 + dd);
                         o.x += t.x * w; o.y += t.y * w; o.z += t.z * w; o.w += t.w * w; l += (double) a.comb_l[row * ns + s2] * (double) w;
                     }
