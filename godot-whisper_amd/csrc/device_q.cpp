@@ -104,10 +104,20 @@ bool decode_layers_q(whisper_context & ctx, int n, int n_kv, int kv_head, int Tc
 
     // y = W . q8(src) with a fused epilogue: <= 32 rows stream the weight tiles once (rows quantised in the kernel's prologue);
     // prompt-sized batches quantise once and go through the tiled GEMM
+    static const bool no_pf = getenv("WMI_NO_PREFETCH") != nullptr;            // A/B knob
+    const k::QMat * pfW = nullptr; int pfN = 0, pfK = 0;                       // the next weight-streaming launch's matrix (k_qrows prefetch)
+    auto next = [&](const k::QMat & W, int N, int K) { pfW = no_pf ? nullptr : &W; pfN = N; pfK = K; };
+    auto set_pf = [&](k::GemvArgs & g) {
+        if (pfW && pfW->tiles && pfN <= 8192) {
+            g.pf_ptr = pfW->tiles; g.pf_group_bytes = (uint32_t) ((size_t) (pfK / 64) * k::q_tile_bytes(pfW->qtype)); g.pf_groups = (uint32_t) ((pfN + 31) / 32);
+        }
+        pfW = nullptr;
+    };
     auto proj = [&](int epi, const Src & src, int K, int N, const k::QMat & W, const float * bias, void * C, int ldc,
                     const float * resid, void * aux, int ldaux, void * aux2, int ldaux2, float scale) {
         if (rows_fit(n, K)) {
             k::GemvArgs g{};
+            set_pf(g);
             g.x32 = src.x32; g.ln_g = src.ln_g; g.ln_b = src.ln_b; g.eps = hp.eps; g.a16 = src.x16; g.n = n; g.K = K; g.N = N;
             g.bias = bias; g.epi = epi; g.C = C; g.ldc = ldc; g.resid = resid; g.ldr = S; g.aux = aux; g.ldaux = ldaux;
             g.aux2 = aux2; g.ldaux2 = ldaux2; g.scale = scale; g.S = S;
@@ -126,11 +136,14 @@ bool decode_layers_q(whisper_context & ctx, int n, int n_kv, int kv_head, int Tc
         const DecLayerW & l = w.dec[il];
         __half * ck = kv.k + ((size_t) il * n_ctx) * S, * cv = kv.v + ((size_t) il * n_ctx) * S;
         Src ln1; ln1.x32 = d.dx; ln1.ln_g = l.ln1_g; ln1.ln_b = l.ln1_b;
+        next(l.q_o, S, S);
         proj(k::EPI_QKV_DEC, ln1, S, 3 * S, l.q_qkv, l.b_qkv, d.dq, S, nullptr, ck + (size_t) kv_head * S, S, cv + (size_t) kv_head * S, S, kq_scale);
         k::attn_decoder(d.dq, n, S, H, ck, cv, n_kv, d.d_mask, n_kv, nullptr, s, nullptr, 0, d.datt32);
         Src att; att.x32 = d.datt32;
+        next(l.q_cq, S, S);
         proj(k::EPI_F32_BIAS_RESID, att, S, S, l.q_o, l.b_o, d.dx, S, d.dx, nullptr, 0, nullptr, 0, 0.f);
         Src ln2; ln2.x32 = d.dx; ln2.ln_g = l.ln2_g; ln2.ln_b = l.ln2_b;
+        next(l.q_co, S, S);
         proj(k::EPI_Q_SCALED, ln2, S, S, l.q_cq, l.b_cq, d.dq, S, nullptr, nullptr, 0, nullptr, 0, kq_scale);
         if (rows_fit(n, S)) {                     // the out projection combines the key-slice partials in its prologue (one launch fewer)
             const float * po = nullptr, * pl = nullptr, * pm = nullptr; int ns = 0;
@@ -138,14 +151,17 @@ bool decode_layers_q(whisper_context & ctx, int n, int n_kv, int kv_head, int Tc
             k::GemvArgs g{};
             g.eps = hp.eps; g.n = n; g.K = S; g.N = S; g.bias = l.b_co; g.epi = k::EPI_F32_BIAS_RESID; g.C = d.dx; g.ldc = S; g.resid = d.dx; g.ldr = S;
             g.S = S; g.comb_o = po; g.comb_l = pl; g.comb_m = pm; g.comb_ns = ns;
+            next(l.q_fc1, 4 * S, S); set_pf(g);
             k::qrows(g, nullptr, l.q_co, s);
         } else {
         k::attn_cross_split(d.dq, n, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, nullptr, s, 0, d.datt32);
         proj(k::EPI_F32_BIAS_RESID, att, S, S, l.q_co, l.b_co, d.dx, S, d.dx, nullptr, 0, nullptr, 0, 0.f);
         }
         Src ln3; ln3.x32 = d.dx; ln3.ln_g = l.ln3_g; ln3.ln_b = l.ln3_b;
+        next(l.q_fc2, S, 4 * S);
         proj(k::EPI_F16_BIAS_GELU, ln3, S, 4 * S, l.q_fc1, l.b_fc1, d.dh, 4 * S, nullptr, nullptr, 0, nullptr, 0, 0.f);
         Src hh; hh.x16 = d.dh;
+        if (il + 1 < Lt) next(w.dec[il + 1].q_qkv, 3 * S, S);
         proj(k::EPI_F32_BIAS_RESID, hh, 4 * S, S, l.q_fc2, l.b_fc2, d.dx, S, d.dx, nullptr, 0, nullptr, 0, 0.f);
     }
 
@@ -178,9 +194,17 @@ void enqueue_greedy_step_q(whisper_context & ctx, int Tc) {
     const k::DecStep * stp = (const k::DecStep *) d.step_dev;
     const float kq_scale = powf((float) S / H, -0.25f);
     k::qdec_embed_step((const k::DecStep *) d.step_host, (k::DecStep *) d.step_dev, S, w.q_te, w.d_pe, d.dx, s);
+    // pfW / pfN / pfK: the matrix of the next weight-streaming launch of the chain, prefetched by this one (k_qrows)
+    static const bool no_pf = getenv("WMI_NO_PREFETCH") != nullptr;            // A/B knob
+    const k::QMat * pfW = nullptr; int pfN = 0, pfK = 0;
+    auto next = [&](const k::QMat & W, int N, int K) { pfW = no_pf ? nullptr : &W; pfN = N; pfK = K; };
     auto rows = [&](int epi, const Src & src, int K, int N, const k::QMat & W, const float * bias, void * C, int ldc, const float * resid,
                     void * aux, void * aux2, float scale, const int32_t * row_off, const float * co = nullptr, const float * cl = nullptr, int cns = 0, const float * cm = nullptr) {
         k::GemvArgs g{};
+        if (pfW && pfW->tiles && pfN <= 8192) {             // (the vocabulary projection is 50 MB: not prefetched)
+            g.pf_ptr = pfW->tiles; g.pf_group_bytes = (uint32_t) ((size_t) (pfK / 64) * k::q_tile_bytes(pfW->qtype)); g.pf_groups = (uint32_t) ((pfN + 31) / 32);
+        }
+        pfW = nullptr;
         g.x32 = src.x32; g.ln_g = src.ln_g; g.ln_b = src.ln_b; g.eps = hp.eps; g.a16 = src.x16; g.n = 1; g.K = K; g.N = N;
         g.bias = bias; g.epi = epi; g.C = C; g.ldc = ldc; g.resid = resid; g.ldr = S; g.aux = aux; g.ldaux = S; g.aux2 = aux2; g.ldaux2 = S;
         g.scale = scale; g.S = S; g.row_off = row_off; g.comb_o = co; g.comb_l = cl; g.comb_ns = cns; g.comb_m = cm;
@@ -190,18 +214,24 @@ void enqueue_greedy_step_q(whisper_context & ctx, int Tc) {
         const DecLayerW & l = w.dec[il];
         __half * ck = kv.k + ((size_t) il * n_ctx) * S, * cv = kv.v + ((size_t) il * n_ctx) * S;
         Src ln1; ln1.x32 = d.dx; ln1.ln_g = l.ln1_g; ln1.ln_b = l.ln1_b;
+        next(l.q_o, S, S);
         rows(k::EPI_QKV_DEC, ln1, S, 3 * S, l.q_qkv, l.b_qkv, d.dq, S, nullptr, ck, cv, kq_scale, &stp->kv_head);
         k::self_attn_rows(d.dq, 1, S, ck, cv, 0, &stp->n_kv, 0, hp.n_text_ctx, nullptr, s, d.datt32);
         Src att; att.x32 = d.datt32;
+        next(l.q_cq, S, S);
         rows(k::EPI_F32_BIAS_RESID, att, S, S, l.q_o, l.b_o, d.dx, S, d.dx, nullptr, nullptr, 0.f, nullptr);
         Src ln2; ln2.x32 = d.dx; ln2.ln_g = l.ln2_g; ln2.ln_b = l.ln2_b;
+        next(l.q_co, S, S);
         rows(k::EPI_Q_SCALED, ln2, S, S, l.q_cq, l.b_cq, d.dq, S, nullptr, nullptr, nullptr, kq_scale, nullptr);
         const float * po = nullptr, * pl = nullptr, * pm = nullptr; int ns = 0;
         k::attn_cross_split_partials(d.dq, 1, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, &po, &pl, &pm, &ns, s);
+        next(l.q_fc1, 4 * S, S);
         rows(k::EPI_F32_BIAS_RESID, Src{}, S, S, l.q_co, l.b_co, d.dx, S, d.dx, nullptr, nullptr, 0.f, nullptr, po, pl, ns, pm);
         Src ln3; ln3.x32 = d.dx; ln3.ln_g = l.ln3_g; ln3.ln_b = l.ln3_b;
+        next(l.q_fc2, S, 4 * S);
         rows(k::EPI_F16_BIAS_GELU, ln3, S, 4 * S, l.q_fc1, l.b_fc1, d.dh, 4 * S, nullptr, nullptr, nullptr, 0.f, nullptr);
         Src hh; hh.x16 = d.dh;
+        if (il + 1 < Lt) next(w.dec[il + 1].q_qkv, 3 * S, S);
         rows(k::EPI_F32_BIAS_RESID, hh, 4 * S, S, l.q_fc2, l.b_fc2, d.dx, S, d.dx, nullptr, nullptr, 0.f, nullptr);
     }
     Src lnf; lnf.x32 = d.dx; lnf.ln_g = w.d_ln_g; lnf.ln_b = w.d_ln_b;
@@ -222,9 +252,16 @@ void enqueue_rows_step_q(whisper_context & ctx, int nb) {
     const int64_t cache_stride = (int64_t) Lt * n_ctx * S;
     const int64_t cross_layer = (int64_t) b.enc_rows * Tc * S;
     k::qdec_embed_step((const k::DecStep *) b.step_host, (k::DecStep *) b.step_dev, S, w.q_te, w.d_pe, b.dx, s, nb);
+    static const bool no_pf = getenv("WMI_NO_PREFETCH") != nullptr;            // A/B knob
+    const k::QMat * pfW = nullptr; int pfN = 0, pfK = 0;                       // the next weight-streaming launch's matrix (k_qrows prefetch)
+    auto next = [&](const k::QMat & W, int N, int K) { pfW = no_pf ? nullptr : &W; pfN = N; pfK = K; };
     auto rows = [&](int epi, const Src & src, int K, int N, const k::QMat & W, const float * bias, void * C, int ldc, const float * resid,
                     void * aux, void * aux2, float scale, const int32_t * row_off) {
         k::GemvArgs g{};
+        if (pfW && pfW->tiles && pfN <= 8192) {
+            g.pf_ptr = pfW->tiles; g.pf_group_bytes = (uint32_t) ((size_t) (pfK / 64) * k::q_tile_bytes(pfW->qtype)); g.pf_groups = (uint32_t) ((pfN + 31) / 32);
+        }
+        pfW = nullptr;
         g.x32 = src.x32; g.ln_g = src.ln_g; g.ln_b = src.ln_b; g.eps = hp.eps; g.a16 = src.x16; g.n = nb; g.K = K; g.N = N;
         g.bias = bias; g.epi = epi; g.C = C; g.ldc = ldc; g.resid = resid; g.ldr = S; g.aux = aux; g.ldaux = S; g.aux2 = aux2; g.ldaux2 = S;
         g.scale = scale; g.S = S; g.row_off = row_off; g.lanes = 1; g.step_stride = step_stride; g.cache_row_stride = cache_stride;
@@ -234,23 +271,29 @@ void enqueue_rows_step_q(whisper_context & ctx, int nb) {
         const DecLayerW & l = w.dec[il];
         __half * ck = b.self_k + (size_t) il * n_ctx * S, * cv = b.self_v + (size_t) il * n_ctx * S;     // chunk 0; + r * cache_stride
         Src ln1; ln1.x32 = b.dx; ln1.ln_g = l.ln1_g; ln1.ln_b = l.ln1_b;
+        next(l.q_o, S, S);
         k::qrows(rows(k::EPI_QKV_DEC, ln1, S, 3 * S, l.q_qkv, l.b_qkv, b.dq, S, nullptr, ck, cv, kq_scale, &stp->kv_head), nullptr, l.q_qkv, s);
         k::self_attn_rows(b.dq, nb, S, ck, cv, cache_stride, &stp->n_kv, step_stride, n_ctx, nullptr, s, b.datt32);
         Src att; att.x32 = b.datt32;
+        next(l.q_cq, S, S);
         k::qrows(rows(k::EPI_F32_BIAS_RESID, att, S, S, l.q_o, l.b_o, b.dx, S, b.dx, nullptr, nullptr, 0.f, nullptr), att.x32, l.q_o, s);
         Src ln2; ln2.x32 = b.dx; ln2.ln_g = l.ln2_g; ln2.ln_b = l.ln2_b;
+        next(l.q_co, S, S);
         k::qrows(rows(k::EPI_Q_SCALED, ln2, S, S, l.q_cq, l.b_cq, b.dq, S, nullptr, nullptr, nullptr, kq_scale, nullptr), nullptr, l.q_cq, s);
         const float * po = nullptr, * pl = nullptr, * pm = nullptr; int ns = 0;
         k::attn_cross_split_partials(b.dq, nb, S, H, b.kvc_k + (size_t) il * cross_layer, b.kvc_v + (size_t) il * cross_layer, Tc,
                                      b.xattn, &po, &pl, &pm, &ns, s, (int64_t) Tc * S);
         {
+            next(l.q_fc1, 4 * S, S);
             k::GemvArgs g = rows(k::EPI_F32_BIAS_RESID, Src{}, S, S, l.q_co, l.b_co, b.dx, S, b.dx, nullptr, nullptr, 0.f, nullptr);
             g.comb_o = po; g.comb_l = pl; g.comb_m = pm; g.comb_ns = ns;
             k::qrows(g, nullptr, l.q_co, s);
         }
         Src ln3; ln3.x32 = b.dx; ln3.ln_g = l.ln3_g; ln3.ln_b = l.ln3_b;
+        next(l.q_fc2, S, 4 * S);
         k::qrows(rows(k::EPI_F16_BIAS_GELU, ln3, S, 4 * S, l.q_fc1, l.b_fc1, b.dh, 4 * S, nullptr, nullptr, nullptr, 0.f, nullptr), nullptr, l.q_fc1, s);
         Src hh; hh.x16 = b.dh;
+        if (il + 1 < Lt) next(w.dec[il + 1].q_qkv, 3 * S, S);
         k::qrows(rows(k::EPI_F32_BIAS_RESID, hh, 4 * S, S, l.q_fc2, l.b_fc2, b.dx, S, b.dx, nullptr, nullptr, 0.f, nullptr), nullptr, l.q_fc2, s);
     }
     Src lnf; lnf.x32 = b.dx; lnf.ln_g = w.d_ln_g; lnf.ln_b = w.d_ln_b;

@@ -569,6 +569,8 @@ void qgemm_epi(int epi, const GemmArgs & a, Q8Rows A, const uint8_t * Wt, hipStr
 // partial sums meet in LDS and are added in wavefront order.
 // SRC: 0 f32 rows, 1 LayerNorm of f32 rows (K <= 1536), 2 f16 rows, 3 the combined partials of the split cross-attention
 // (GemvArgs::comb_*: o / l per head, f32 — what attn_cross_combine writes with out32).
+constexpr int PF_WG = 32;                                   // prefetch workgroups appended to a k_qrows grid (multiple of 8: XCD affinity)
+
 template <int QT, int NR4, int SRC, int NW>
 __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float * __restrict__ a32, const uint8_t * __restrict__ Wt) {
     constexpr int QW = Geo<QT>::QW, HW = Geo<QT>::HW;
@@ -586,6 +588,24 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
     float  * red = ss + (size_t) nb * R8;                    // [NW][32][R8]
 
     const int ngroups = (a.N + 31) >> 5;
+    // The next launch's weights.  A dependent chain of launches pays the HBM first-byte latency (~2 us) in every one of them — a step
+    // streams 846 MB of large-v3 q5_1, nothing stays cached from the previous token.  PF_WG extra workgroups (the grids here are
+    // 40-160 workgroups on 256 CUs: they land on idle CUs) touch one dword per 128-byte line of the next matrix and leave; the
+    // lines are in L2 / Infinity Cache when the next launch asks for them.  Extra workgroup j takes the row groups g = j (mod
+    // PF_WG): with grids that are multiples of 8 it shares its XCD, i.e. its L2, with the workgroup that will stream group g.
+    // (Issued from the streaming workgroups themselves the requests sat in front of the prologue's loads in the in-order
+    // vmcnt queue: +1 us per launch instead of -1.)
+    const int nmain = a.pf_ptr ? (int) gridDim.x - PF_WG : (int) gridDim.x;
+    if ((int) blockIdx.x >= nmain) {
+        const uint8_t * pf = (const uint8_t *) a.pf_ptr;
+        uint32_t acc = 0;
+        for (uint32_t g = blockIdx.x - nmain; g < a.pf_groups; g += PF_WG) {
+            const uint8_t * gp = pf + (size_t) g * a.pf_group_bytes;
+            for (uint32_t off = (uint32_t) tid * 128u; off < a.pf_group_bytes; off += (uint32_t) NT * 128u) acc ^= *(const volatile uint32_t *) (gp + off);
+        }
+        if (acc == 0x9e3779b9u && a.n < 0) ((volatile uint32_t *) a.C)[0] = acc;      // never true: keeps the loads
+        return;
+    }
     int rg = blockIdx.x;
 
     // ---- first weight tiles of this wavefront (independent of the activations)
@@ -603,7 +623,6 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
         }
     };
     if (rg < ngroups) load_tiles(rg, 0);
-
     // ---- prologue: the activation rows as q8 blocks in LDS
     if constexpr (SRC == 1) {
         // LayerNorm needs the statistics of the whole row, the quantiser only a 256-column slice: (row, slice) tasks are spread over
@@ -765,7 +784,7 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
     const int fk = lane >> 5;
     const int8_t * afrag = sq + (size_t) arow * lda + fk * 16;
 
-    for (; rg < ngroups; rg += gridDim.x) {
+    for (; rg < ngroups; rg += nmain) {
         float out[4 * NR4];
 #pragma unroll
         for (int e = 0; e < 4 * NR4; ++e) out[e] = 0.0f;
@@ -815,7 +834,7 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
             }
         }
         // the next row group's first tiles go out before this one is reduced (the vocabulary projection walks ~1.6 groups per workgroup)
-        const int rgn = rg + (int) gridDim.x;
+        const int rgn = rg + nmain;
         const bool more = rgn < ngroups;
         // ---- K-split partials of the wavefronts, added in wavefront order
         if (rg != (int) blockIdx.x) __syncthreads();            // red is reused
@@ -860,6 +879,7 @@ void launch_qrows(const GemvArgs & a, const float * a32, const uint8_t * Wt, hip
     const size_t smem = (((size_t) a.n * (a.K + 16) + 15) & ~(size_t) 15) + (size_t) 2 * nb * R8 * 4 + (size_t) NW * 32 * R8 * 4;
     const int ngroups = (a.N + 31) / 32;
     int blocks = ngroups; if (blocks > 1024) blocks = 1024;
+    if (a.pf_ptr) blocks += PF_WG;                          // the prefetch workgroups (see the kernel)
     static std::atomic<uint64_t> lds_ok{0};
     if (smem > 48 * 1024) allow_full_lds((const void *) k_qrows<QT, NR4, SRC, NW>, lds_ok);
     hipLaunchKernelGGL((k_qrows<QT, NR4, SRC, NW>), dim3(blocks), dim3(NW * 64), smem, st, a, a32, Wt);

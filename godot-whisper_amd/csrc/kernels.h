@@ -144,6 +144,10 @@ struct GemvArgs {
     // chained greedy steps: mirror *step_copy_src (DecStep in pinned host memory) into *step_copy_dst by an extra workgroup
     // (one-row f16 rows x plain projection + residual only: the last mlp.2 of the step)
     const void * step_copy_src; void * step_copy_dst;
+    // weight prefetch for the NEXT launch of a dependent chain (k_qrows): pf_groups row groups of pf_group_bytes each, contiguous at
+    // pf_ptr; workgroup i touches one dword per 128-byte line of the groups g = i (mod grid) — the workgroup of the next launch
+    // that streams group g sits on the same XCD when both grids are multiples of 8
+    const void * pf_ptr; uint32_t pf_group_bytes; uint32_t pf_groups;
 };
 // lock-step chunks: single-token self-attention of n rows, row r against the cache at kc/vc + r * cache_row_stride with
 // n_kv[r * step_stride] cells; same arithmetic as the fused prologue of gemv (GemvArgs::sa_*).  out [n][K] f16
