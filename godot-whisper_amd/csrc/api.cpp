@@ -42,7 +42,13 @@ int64_t time_us() {
     return std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-whisper_context * init_context(const void * buffer, size_t size, int device, bool with_state) {
+bool compute_ready(const whisper_context & ctx, const char * who) {
+    if (ctx.host_only) { WMI_ERR("%s: host-only context has no compute path (this backend has no CPU fallback)\n", who); return false; }
+    if (ctx.weights_pending) { WMI_ERR("%s: the weight arena of this context has not been filled yet (wmi_init_from_header without wmi_arena_commit)\n", who); return false; }
+    return true;
+}
+
+whisper_context * init_context(const void * buffer, size_t size, int device, bool with_state, bool allow_header) {
     const int64_t t0 = time_us();
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0) {
@@ -60,6 +66,11 @@ whisper_context * init_context(const void * buffer, size_t size, int device, boo
         ctx->t_start_us = t0;
         WMI_INFO("%s: loading model from buffer\n", __func__);
         if (!parse_model((const uint8_t *) buffer, size, ctx->model)) { WMI_ERR("%s: failed to load model\n", __func__); delete ctx; return nullptr; }
+        if (ctx->model.directory_only && !allow_header) {
+            WMI_ERR("%s: this buffer is a header image without tensor payloads - load it with wmi_init_from_header and fill the arena\n", __func__);
+            delete ctx; return nullptr;
+        }
+        ctx->weights_pending = ctx->model.directory_only;
         if (!HIP_OK(hipSetDevice(device))) { delete ctx; return nullptr; }
         if (with_state && !init_state(*ctx)) { free_state(*ctx); delete ctx; return nullptr; }
         hipStream_t ls = ctx->state ? ctx->state->dev.stream : nullptr;
@@ -261,6 +272,23 @@ struct whisper_context * wmi_init_from_buffer_on_device(const void * buffer, siz
     if (ctx) ctx->params.use_gpu = true;
     return ctx;
 }
+
+struct whisper_context * wmi_init_from_header(const void * header, size_t header_size, int device) {
+    whisper_context * ctx = init_context(header, header_size, device, true, true);
+    if (ctx && !ctx->model.directory_only) {          // a full model is not a header image: one meaning per entry point
+        WMI_ERR("%s: the buffer holds tensor payloads - use wmi_init_from_buffer_on_device\n", __func__);
+        whisper_free(ctx); return nullptr;
+    }
+    if (ctx) ctx->params.use_gpu = true;
+    return ctx;
+}
+int wmi_arena_commit(struct whisper_context * ctx) {
+    if (!ctx || ctx->host_only || !ctx->w.arena) return -1;
+    if (!HIP_OK(hipSetDevice(ctx->device)) || !HIP_OK(hipDeviceSynchronize())) return -2;     // whatever stream filled the arena has finished
+    ctx->weights_pending = false;
+    return 0;
+}
+int wmi_weights_pending(struct whisper_context * ctx) { return ctx && ctx->weights_pending ? 1 : 0; }
 
 struct whisper_context * wmi_init_host_only(const void * buffer, size_t buffer_size) {
     if (!buffer || buffer_size < 4) return nullptr;

@@ -71,6 +71,9 @@ bool ensure_batch(whisper_context & ctx, int B) {
     dfree(w.mel_t); dfree(w.conv1); dfree(w.x); dfree(w.xn); dfree(w.q); dfree(w.k); dfree(w.att); dfree(w.vt); dfree(w.h);
     dfree(w.enc_out_h); dfree(w.kvc_k); dfree(w.kvc_v); dfree(w.self_k); dfree(w.self_v); dfree(w.dx); dfree(w.dq); dfree(w.datt); dfree(w.dh);
     dfree(w.logits); dfree(w.xattn); dfree(w.aq); dfree(w.ads); dfree(w.att32); dfree(w.datt32);
+    if (w.rows_graph.exec) (void) hipGraphExecDestroy(w.rows_graph.exec);          // the captured step holds the old pointers
+    if (w.rows_graph.graph) (void) hipGraphDestroy(w.rows_graph.graph);
+    w.rows_graph = BatchWork::RowsGraph{};
     if (w.step_dev) (void) hipFree(w.step_dev);
     if (w.sample_dev) (void) hipFree(w.sample_dev);
     if (w.filter_scratch) (void) hipFree(w.filter_scratch);
@@ -296,7 +299,34 @@ bool decode_rows_step(whisper_context & ctx, int nb) {
     BatchWork & b = *ctx.batch;
     const int64_t t0 = time_us();
     hipStream_t s = ctx.state->dev.stream;
-    enqueue_rows_step(ctx, nb);
+    {
+        // every per-step quantity reaches the kernels through the step records in pinned memory, so the launch sequence of a
+        // (rows, encoder length) pair is static: replayed as ONE graph launch instead of 46 host-paced launches (the host needs
+        // ~3 us per launch of this kernarg size, the device 1.6 us between dependent kernels: scratch/lab/chain_lab.hip)
+        static const bool use_graph = getenv("WMI_NO_GRAPH") == nullptr;
+        BatchWork::RowsGraph & rg = b.rows_graph;
+        if (rg.nb != nb || rg.T != b.enc_T || rg.rows != b.enc_rows) {
+            if (rg.exec) (void) hipGraphExecDestroy(rg.exec);
+            if (rg.graph) (void) hipGraphDestroy(rg.graph);
+            rg = BatchWork::RowsGraph{}; rg.nb = nb; rg.T = b.enc_T; rg.rows = b.enc_rows;
+        }
+        if (use_graph && !rg.exec && !rg.failed && ++rg.seen > 24) {
+            if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                enqueue_rows_step(ctx, nb);
+                hipGraph_t g = nullptr;
+                if (hipStreamEndCapture(s, &g) == hipSuccess && g && hipGraphInstantiate(&rg.exec, g, nullptr, nullptr, 0) == hipSuccess) rg.graph = g;
+                else {
+                    WMI_WARN("%s: graph capture failed - staying on eager launches\n", __func__);
+                    if (g) (void) hipGraphDestroy(g);
+                    rg.exec = nullptr; rg.failed = true;
+                    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+                    if (hipStreamIsCapturing(s, &cs) == hipSuccess && cs != hipStreamCaptureStatusNone) { hipGraph_t junk = nullptr; (void) hipStreamEndCapture(s, &junk); if (junk) (void) hipGraphDestroy(junk); }
+                }
+            } else rg.failed = true;
+        }
+        if (use_graph && rg.exec) HIP_TRY(hipGraphLaunch(rg.exec, s));
+        else enqueue_rows_step(ctx, nb);
+    }
     {   // every row's result carries the step's sequence number (set by the caller in the step records)
         const k::DecStep * hs = (const k::DecStep *) b.step_host;
         const k::SampleOut * so = (const k::SampleOut *) b.sample_host;
@@ -328,13 +358,25 @@ double bench_rows_step_chain(whisper_context & ctx, int nb, int iters) {
     hipStream_t s = ctx.state->dev.stream;
     hipEvent_t e0, e1;
     if (!HIP_OK(hipEventCreate(&e0)) || !HIP_OK(hipEventCreate(&e1))) return -1.0;
-    for (int i = 0; i < 3; ++i) enqueue_rows_step(ctx, nb);
+    // replayed from a captured graph like the product's step (eager launches are paced by the host, see bench_greedy_step_chain)
+    static const bool eager = getenv("WMI_CHAIN_EAGER") != nullptr;
+    enqueue_rows_step(ctx, nb);
+    (void) hipStreamSynchronize(s);
+    hipGraph_t pg = nullptr; hipGraphExec_t pexec = nullptr;
+    if (!eager && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        enqueue_rows_step(ctx, nb);
+        if (hipStreamEndCapture(s, &pg) != hipSuccess || !pg || hipGraphInstantiate(&pexec, pg, nullptr, nullptr, 0) != hipSuccess) pexec = nullptr;
+    }
+    auto once = [&]() { if (pexec) (void) hipGraphLaunch(pexec, s); else enqueue_rows_step(ctx, nb); };
+    for (int i = 0; i < 3; ++i) once();
     (void) hipStreamSynchronize(s);
     (void) hipEventRecord(e0, s);
-    for (int i = 0; i < iters; ++i) enqueue_rows_step(ctx, nb);
+    for (int i = 0; i < iters; ++i) once();
     (void) hipEventRecord(e1, s);
     (void) hipEventSynchronize(e1);
     float ms = 0.0f; (void) hipEventElapsedTime(&ms, e0, e1);
+    if (pexec) (void) hipGraphExecDestroy(pexec);
+    if (pg) (void) hipGraphDestroy(pg);
     (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
     g_rows_mask = ~0u;
     return (double) ms * 1000.0 / iters;
@@ -346,6 +388,8 @@ void free_batch(whisper_context & ctx) {
     dfree(w.mel_t); dfree(w.conv1); dfree(w.x); dfree(w.xn); dfree(w.q); dfree(w.k); dfree(w.att); dfree(w.vt); dfree(w.h);
     dfree(w.enc_out_h); dfree(w.kvc_k); dfree(w.kvc_v); dfree(w.self_k); dfree(w.self_v); dfree(w.dx); dfree(w.dq); dfree(w.datt); dfree(w.dh);
     dfree(w.logits); dfree(w.xattn); dfree(w.aq); dfree(w.ads); dfree(w.att32); dfree(w.datt32);
+    if (w.rows_graph.exec) (void) hipGraphExecDestroy(w.rows_graph.exec);
+    if (w.rows_graph.graph) (void) hipGraphDestroy(w.rows_graph.graph);
     if (w.step_dev) (void) hipFree(w.step_dev);
     if (w.sample_dev) (void) hipFree(w.sample_dev);
     if (w.filter_scratch) (void) hipFree(w.filter_scratch);
@@ -358,7 +402,7 @@ void free_batch(whisper_context & ctx) {
 
 int full_batch(whisper_context & ctx, whisper_full_params params, const float * const * pcm, const int * n_samples, int n_chunks,
                bool on_device) {
-    if (ctx.host_only) { WMI_ERR("%s: host-only context has no compute path (this backend has no CPU fallback)\n", __func__); return -2; }
+    if (!compute_ready(ctx, __func__)) return -2;
     if (n_chunks <= 0) return 0;
     const Vocab & v = ctx.model.vocab;
     const HParams & hp = ctx.model.hp;

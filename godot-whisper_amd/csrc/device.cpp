@@ -134,7 +134,7 @@ static bool ensure_mel_capacity(DeviceState & d, size_t n_pad, size_t n_mel_elem
 }
 
 bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, bool samples_on_device, bool sync) {
-    if (ctx.host_only) { WMI_ERR("%s: host-only context has no compute path (this backend has no CPU fallback)\n", __func__); return false; }
+    if (!compute_ready(ctx, __func__)) return false;
     State & st = *ctx.state; DeviceState & d = st.dev;
     const int64_t t0 = time_us();
     const int n_mel = ctx.model.n_filt_mel;
@@ -202,7 +202,7 @@ bool signal_energy_wait(State & st) {
 }
 
 bool set_mel(whisper_context & ctx, const float * data, int n_len, int n_mel) {
-    if (ctx.host_only) { WMI_ERR("%s: host-only context has no compute path (this backend has no CPU fallback)\n", __func__); return false; }
+    if (!compute_ready(ctx, __func__)) return false;
     State & st = *ctx.state; DeviceState & d = st.dev;
     if (!ensure_mel_capacity(d, 0, (size_t) n_len * n_mel)) return false;
     HIP_TRY(hipMemcpyAsync(d.mel, data, (size_t) n_len * n_mel * 4, hipMemcpyHostToDevice, d.stream));
@@ -213,7 +213,7 @@ bool set_mel(whisper_context & ctx, const float * data, int n_len, int n_mel) {
 
 // ------------------------------------------------------------------------------------------------ encoder
 bool encode(whisper_context & ctx, int mel_offset) {
-    if (ctx.host_only) { WMI_ERR("%s: host-only context has no compute path (this backend has no CPU fallback)\n", __func__); return false; }
+    if (!compute_ready(ctx, __func__)) return false;
     State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
     const int64_t t0 = time_us();
     d.chain_valid = false;
@@ -294,7 +294,7 @@ bool encode(whisper_context & ctx, int mel_offset) {
 
 // ------------------------------------------------------------------------------------------------ decoder
 bool decode(whisper_context & ctx, const Batch & batch) {
-    if (ctx.host_only) { WMI_ERR("%s: host-only context has no compute path (this backend has no CPU fallback)\n", __func__); return false; }
+    if (!compute_ready(ctx, __func__)) return false;
     State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
     const int64_t t0 = time_us();
     d.chain_valid = false;                                  // this path overwrites the activation row a chained greedy step would start from
@@ -598,7 +598,7 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = fa
 }
 
 bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const StepFilter & f, whisper_token_data & out) {
-    if (ctx.host_only) { WMI_ERR("%s: host-only context has no compute path\n", __func__); return false; }
+    if (!compute_ready(ctx, __func__)) return false;
     State & st = *ctx.state; DeviceState & d = st.dev; const HParams & hp = ctx.model.hp; const Vocab & v = ctx.model.vocab;
     const int64_t t0 = time_us();
     KVCache & kv = st.kv_self;
@@ -704,9 +704,19 @@ double bench_greedy_step_chain(whisper_context & ctx, int iters) {
     hipEvent_t e0, e1;
     if (!HIP_OK(hipEventCreate(&e0)) || !HIP_OK(hipEventCreate(&e1))) return -1.0;
     const bool long_kv = ((const k::DecStep *) d.step_host)->n_kv > 64 && !ctx.model.quantised;
-    hipGraphExec_t exec = d.step_graphs[long_kv ? 1 : 0].exec;
-    const int exec_T = d.step_graphs[long_kv ? 1 : 0].T;
-    auto once = [&]() { if (exec && exec_T == Tc && g_step_mask == ~0u) (void) hipGraphLaunch(exec, s); else enqueue_greedy_step(ctx, Tc, long_kv); };
+    // The chain is ALWAYS replayed from a captured graph, also for a masked subset of the step's kernels: eager launches are
+    // paced by the host (2.7 us per trivial launch on this stack against 1.63 us for the same chain replayed from a graph,
+    // scratch/lab/chain_lab.hip), which is what round 2's per-kind table had measured for every kernel under ~4 us.
+    // WMI_CHAIN_EAGER=1 keeps the host-paced form for comparison.
+    static const bool eager = getenv("WMI_CHAIN_EAGER") != nullptr;
+    hipGraph_t pg = nullptr; hipGraphExec_t pexec = nullptr;
+    enqueue_greedy_step(ctx, Tc, long_kv);                      // function attributes, lazy allocations: outside the capture
+    (void) hipStreamSynchronize(s);
+    if (!eager && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        enqueue_greedy_step(ctx, Tc, long_kv);
+        if (hipStreamEndCapture(s, &pg) != hipSuccess || !pg || hipGraphInstantiate(&pexec, pg, nullptr, nullptr, 0) != hipSuccess) pexec = nullptr;
+    }
+    auto once = [&]() { if (pexec) (void) hipGraphLaunch(pexec, s); else enqueue_greedy_step(ctx, Tc, long_kv); };
     for (int i = 0; i < 4; ++i) once();
     (void) hipStreamSynchronize(s);
     (void) hipEventRecord(e0, s);
@@ -714,6 +724,8 @@ double bench_greedy_step_chain(whisper_context & ctx, int iters) {
     (void) hipEventRecord(e1, s);
     (void) hipEventSynchronize(e1);
     float ms = 0.0f; (void) hipEventElapsedTime(&ms, e0, e1);
+    if (pexec) (void) hipGraphExecDestroy(pexec);
+    if (pg) (void) hipGraphDestroy(pg);
     (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
     return (double) ms * 1000.0 / iters;
 }

@@ -249,10 +249,20 @@ bool parse_model(const uint8_t * buf, size_t n, ModelFile & mf) {
     }
     if (!rd.eof()) { WMI_ERR("%s: trailing bytes after the last tensor\n", __func__); return false; }
     mf.n_loaded = (int) mf.tensors.size();
+    // geometry limits of the block-quantised kernels (k_quant.hip): output tiles of 128 columns (k_qgemm has no column guard) and
+    // LayerNorm prologues that keep a row of <= 1536 columns in registers (k_qrows, k_q8_rows).  Every published model (384 ..
+    // 1280) is inside; anything else is refused here instead of producing silently wrong numbers
+    if (mf.quantised && mf.n_loaded > 0 && (hp.n_audio_state % 128 != 0 || hp.n_audio_state > 1536)) {
+        WMI_ERR("%s: block-quantised models need n_state %% 128 == 0 and n_state <= 1536 (got %d)\n", __func__, hp.n_audio_state);
+        return false;
+    }
     {
         const int expected = 7 + 15 * hp.n_audio_layer + 4 + 24 * hp.n_text_layer;   // names at W/whisper.cpp:1354-1510
         if (mf.n_loaded == 0) {
             WMI_WARN("%s: WARN no tensors loaded from model file - assuming empty model for testing\n", __func__);
+            // no tensor carries quantised blocks: the zero weights take the f16 path whatever the header's ftype says (the
+            // quantised kernels dispatch on the matrices' block type, which an empty model does not have)
+            mf.quantised = false;
         } else if (mf.n_loaded != expected) {
             WMI_ERR("%s: ERROR not all tensors loaded from model file - expected %d, got %d\n", __func__, expected, mf.n_loaded);
             return false;
@@ -519,6 +529,9 @@ bool upload_weights(const ModelFile & mf, const uint8_t * host_buf, Weights & w,
         if (!build(mf, host_buf, ar, pl2, w) || ar.size != dry.size) { free_weights(w); return false; }
         if (!HIP_OK(hipMemcpyAsync(w.arena, stage.data(), w.arena_bytes, hipMemcpyHostToDevice, st)) ||
             !HIP_OK(hipStreamSynchronize(st))) { free_weights(w); return false; }
+    } else {
+        // header image: the bytes arrive later (RCCL broadcast / peer copy); until then the arena holds zeros, never stale HBM
+        if (!HIP_OK(hipMemsetAsync(w.arena, 0, w.arena_bytes, st)) || !HIP_OK(hipStreamSynchronize(st))) { free_weights(w); return false; }
     }
 
     uint8_t * base = (uint8_t *) w.arena;

@@ -40,7 +40,7 @@ struct wmi_pool * wmi_pool_init(const void * model, size_t model_size, const int
         p->ctx.push_back(c0);
         const std::vector<uint8_t> header = export_header(c0->model, (const uint8_t *) model, c0->w.arena_bytes);
         for (int d = 1; d < n_devices; ++d) {
-            whisper_context * c = init_context(header.data(), header.size(), devices[d], true);     // arena laid out, not filled
+            whisper_context * c = init_context(header.data(), header.size(), devices[d], true, true);     // arena laid out and zeroed, weights pending
             if (!c || c->w.arena_bytes != c0->w.arena_bytes) { WMI_ERR("%s: device %d: arena layout mismatch\n", __func__, devices[d]); if (c) whisper_free(c); wmi_pool_free(p); return nullptr; }
             p->ctx.push_back(c);
             bool ok;
@@ -51,6 +51,7 @@ struct wmi_pool * wmi_pool_init(const void * model, size_t model_size, const int
                 (void) can;
             }
             if (!ok || !HIP_OK(hipDeviceSynchronize())) { wmi_pool_free(p); return nullptr; }
+            c->weights_pending = false;                     // the peer copy has landed
         }
     } catch (const std::exception & e) {
         WMI_ERR("%s: %s\n", __func__, e.what());
@@ -67,6 +68,7 @@ struct whisper_context * wmi_pool_context(struct wmi_pool * p, int i) { return (
 int wmi_pool_full(struct wmi_pool * p, struct whisper_full_params params, const float * const * pcm, const int * n_samples, int n_chunks) {
     if (!p || !pcm || !n_samples || n_chunks < 0) return -1;
     const int N = (int) p->ctx.size();
+    try {
     p->owner.assign(n_chunks, 0); p->index.assign(n_chunks, 0);
     std::vector<std::vector<const float *>> ptrs(N); std::vector<std::vector<int>> lens(N);
     for (int c = 0; c < n_chunks; ++c) {
@@ -76,20 +78,35 @@ int wmi_pool_full(struct wmi_pool * p, struct whisper_full_params params, const 
     }
     params.no_context = true;
     std::vector<int> rets(N, 0);
+    // every entry point of a context serialises on its mutex (wmi_device.h): the workers take it like any other caller, so a
+    // concurrent wmi_batch_select / whisper_full on one of the pool's contexts waits instead of racing; nothing may throw out of a
+    // worker thread (std::terminate) or across the C boundary
     auto work = [&](int d) {
         const int64_t t0 = time_us();
-        if (!ptrs[d].empty()) {
-            (void) hipSetDevice(p->ctx[d]->device);
-            rets[d] = full_batch(*p->ctx[d], params, ptrs[d].data(), lens[d].data(), (int) ptrs[d].size(), false);
-        } else if (p->ctx[d]->batch) { p->ctx[d]->batch->results.clear(); p->ctx[d]->batch->redo.clear(); }
+        try {
+            std::lock_guard<std::recursive_mutex> lk(p->ctx[d]->mu);
+            if (!ptrs[d].empty()) {
+                (void) hipSetDevice(p->ctx[d]->device);
+                rets[d] = full_batch(*p->ctx[d], params, ptrs[d].data(), lens[d].data(), (int) ptrs[d].size(), false);
+            } else if (p->ctx[d]->batch) { p->ctx[d]->batch->results.clear(); p->ctx[d]->batch->redo.clear(); }
+        } catch (const std::exception & e) {
+            WMI_ERR("wmi_pool_full: device %d: %s\n", p->ctx[d]->device, e.what());
+            rets[d] = -9;
+        } catch (...) { rets[d] = -9; }
         p->t_us[d] = time_us() - t0;
     };
-    std::vector<std::thread> th;
-    for (int d = 1; d < N; ++d) th.emplace_back(work, d);
-    work(0);
-    for (auto & t : th) t.join();
+    {
+        std::vector<std::thread> th;
+        struct Joiner { std::vector<std::thread> & t; ~Joiner() { for (auto & x : t) if (x.joinable()) x.join(); } } joiner{th};
+        for (int d = 1; d < N; ++d) th.emplace_back(work, d);
+        work(0);
+    }
     for (int d = 0; d < N; ++d) if (rets[d] != 0) return rets[d];
     return 0;
+    } catch (const std::exception & e) {                    // allocation of the work lists / thread creation
+        WMI_ERR("wmi_pool_full: %s\n", e.what());
+        return -9;
+    }
 }
 
 struct whisper_context * wmi_pool_select(struct wmi_pool * p, int chunk) {

@@ -1,0 +1,56 @@
+// Cross-lane exchanges of a 64-lane wavefront without the LDS crossbar (gfx950).
+//
+// hipcc lowers every __shfl_xor to ds_bpermute_b32 + s_waitcnt lgkmcnt(0): ~100 cycles of dependent latency per step, 18 steps
+// in a LayerNorm + dot-product kernel of the decode step (two 6-step butterflies for mean / variance, one for the dot products)
+// — about a third of that kernel's body (scratch/lab/chain_lab.hip).  The forms below move the same lanes with DPP modifiers and
+// the gfx950 v_permlane{16,32}_swap instructions: plain VALU issue, no LDS, no lgkmcnt wait.
+//
+// xor_lane<M>(x) returns x of lane (L ^ M): exactly __shfl_xor(x, M), so reductions written with it add the same pairs in the
+// same order and give bit-identical results — kernels that must agree bit for bit (the lock-step "exact" mode against the
+// one-row path) can switch independently.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace wmi { namespace k {
+
+#if defined(__HIPCC__)
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf>
+__device__ __forceinline__ int dpp_mov(int old, int x) { return __builtin_amdgcn_update_dpp(old, x, CTRL, ROW_MASK, BANK_MASK, false); }
+
+template <int M> __device__ __forceinline__ int xor_lane_i(int x) {
+    static_assert(M == 1 || M == 2 || M == 4 || M == 8 || M == 16 || M == 32, "xor_lane: power of two below 64");
+    if constexpr (M == 1) return dpp_mov<0xB1>(x, x);                         // quad_perm [1,0,3,2]
+    else if constexpr (M == 2) return dpp_mov<0x4E>(x, x);                    // quad_perm [2,3,0,1]
+    else if constexpr (M == 4) {
+        // banks (4 lanes each) 0 and 2 of a row read 4 lanes up (row_shl:4), banks 1 and 3 read 4 lanes down (row_shr:4)
+        int r = dpp_mov<0x104, 0xf, 0x5>(x, x);
+        return dpp_mov<0x114, 0xf, 0xA>(r, x);
+    }
+    else if constexpr (M == 8) return dpp_mov<0x128>(x, x);                   // row_ror:8: lane i of a row reads lane (i - 8) mod 16 = i ^ 8
+    else if constexpr (M == 16) {
+        // v_permlane16_swap: rows 1 / 3 of the first operand <-> rows 0 / 2 of the second.  Both operands = x:
+        // first = [r0 r0 r2 r2], second = [r1 r1 r3 r3]; lane of an even row wants the odd row's value (second), odd row the first
+        const auto s = __builtin_amdgcn_permlane16_swap((unsigned) x, (unsigned) x, false, false);
+        return (__lane_id() & 16) ? (int) s[0] : (int) s[1];
+    } else {
+        // v_permlane32_swap: lanes 32..63 of the first operand <-> lanes 0..31 of the second.  first = [lo lo], second = [hi hi]
+        const auto s = __builtin_amdgcn_permlane32_swap((unsigned) x, (unsigned) x, false, false);
+        return (__lane_id() & 32) ? (int) s[0] : (int) s[1];
+    }
+}
+template <int M> __device__ __forceinline__ float xor_lane(float x) { return __int_as_float(xor_lane_i<M>(__float_as_int(x))); }
+template <int M> __device__ __forceinline__ int   xor_lane(int x)   { return xor_lane_i<M>(x); }
+
+// 64-lane butterfly sum in the order 32, 16, 8, 4, 2, 1 (the order of `for (o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o)`)
+__device__ __forceinline__ float wave_sum_desc(float v) {
+    v += xor_lane<32>(v); v += xor_lane<16>(v); v += xor_lane<8>(v); v += xor_lane<4>(v); v += xor_lane<2>(v); v += xor_lane<1>(v);
+    return v;
+}
+__device__ __forceinline__ float wave_max_desc(float v) {
+    v = fmaxf(v, xor_lane<32>(v)); v = fmaxf(v, xor_lane<16>(v)); v = fmaxf(v, xor_lane<8>(v));
+    v = fmaxf(v, xor_lane<4>(v)); v = fmaxf(v, xor_lane<2>(v)); v = fmaxf(v, xor_lane<1>(v));
+    return v;
+}
+#endif
+
+}} // namespace wmi::k

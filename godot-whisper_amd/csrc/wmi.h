@@ -277,6 +277,9 @@ struct BatchWork {
     void   * step_dev = nullptr, * step_host = nullptr, * sample_dev = nullptr, * sample_host = nullptr, * filter_scratch = nullptr;
     int      enc_rows = 0, enc_T = 0;                         // chunk rows / encoder length of the last batched encode
     int32_t  step_seq = 0;                                    // sequence number of the last lock-step decode step
+    // the lock-step step as a captured graph, keyed by what its launches depend on (rows, encoder length, chunk rows of the cross
+    // cache); eager until the same key has been decoded for a while (capture + instantiate cost more than a window's steps)
+    struct RowsGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int nb = -1, T = -1, rows = -1, seen = 0; bool failed = false; } rows_graph;
     std::vector<State *> lanes;                               // lanes[0] is the context's own state (not owned)
     std::vector<std::vector<Segment>> results;                // per chunk of the last wmi_full_batch call
     std::vector<int> redo;                                    // per chunk: 1 if it was re-run alone (temperature fallback)
@@ -293,6 +296,9 @@ struct whisper_context {
     wmi::State *   state = nullptr;
     int            device = 0;
     bool           host_only = false;   // vocabulary + host logic only (tests); every compute call fails loudly
+    // loaded from a payload-less header image (wmi_init_from_header): the arena is allocated, zeroed and laid out but its bytes
+    // have not arrived yet — every compute call fails until wmi_arena_commit() says the broadcast / peer copy has landed
+    bool           weights_pending = false;
     wmi::BatchWork * batch = nullptr;   // lazily created by wmi_full_batch
     // the compute code reaches its working set through ctx.state: the *_with_state entry points install the caller's
     // state for the duration of the call under this lock (calls on one context serialise; the GPU runs them in order anyway)
@@ -302,7 +308,11 @@ struct whisper_context {
 namespace wmi {
 
 // parse + upload a ggml model image onto `device`; with_state = false leaves ctx->state null (whisper_init_*_no_state)
-whisper_context * init_context(const void * buffer, size_t size, int device, bool with_state);
+// allow_header: accept the payload-less "wmih" image (only wmi_init_from_header and the in-process pool pass true; every public
+// loader of whisper.h rejects it — such a context would otherwise transcribe from whatever the arena allocation held)
+whisper_context * init_context(const void * buffer, size_t size, int device, bool with_state, bool allow_header = false);
+// false + an error log when the context cannot compute: host-only (tests) or weights still pending (header image not committed)
+bool compute_ready(const whisper_context & ctx, const char * who);
 bool init_state(whisper_context & ctx);
 void free_state(whisper_context & ctx);
 State * create_state(whisper_context & ctx);      // a further state for the same weights (whisper_init_state); null on failure

@@ -48,6 +48,9 @@ DEVICE_API = [
     ("wmi_vad", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_void_p]),
     ("wmi_model_header", C.c_size_t, [C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t]),
     ("wmi_arena_ptr", C.c_void_p, [C.c_void_p]),
+    ("wmi_init_from_header", C.c_void_p, [C.c_void_p, C.c_size_t, C.c_int]),
+    ("wmi_arena_commit", C.c_int, [C.c_void_p]),
+    ("wmi_weights_pending", C.c_int, [C.c_void_p]),
     ("wmi_weights_bytes", C.c_size_t, [C.c_void_p, C.c_int]),
     ("wmi_selftest_quant", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                      C.c_void_p, C.c_void_p, C.c_void_p]),

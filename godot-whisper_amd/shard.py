@@ -75,15 +75,19 @@ def load_replicated(lib, model_bytes: bytes | None, rank: int, world: int, dist,
     if rank != 0:
         hb = h.cpu().numpy().tobytes()
         buf = C.create_string_buffer(hb, len(hb))
-        ctx = lib.wmi_init_from_buffer_on_device(C.cast(buf, C.c_void_p), len(hb), device_index)      # arena laid out, not filled
+        ctx = lib.wmi_init_from_header(C.cast(buf, C.c_void_p), len(hb), device_index)      # arena zeroed and laid out, weights pending
         assert ctx, "header image rejected"
+        assert lib.wmi_weights_pending(ctx) == 1
         assert lib.wmi_weights_bytes(ctx, 0) == n_arena, "arena layout differs between ranks"
     arena = torch.as_tensor(_DevMem(int(lib.wmi_arena_ptr(ctx)), n_arena), device=dev)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     dist.broadcast(arena, src=0)
     torch.cuda.synchronize(dev)
-    return ctx, time.perf_counter() - t0
+    dt = time.perf_counter() - t0
+    if rank != 0:
+        assert lib.wmi_arena_commit(ctx) == 0, "arena commit failed"      # the context refuses to compute before this
+    return ctx, dt
 
 
 def gather_results(local: dict, world: int, dist) -> dict:

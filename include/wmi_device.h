@@ -45,13 +45,20 @@ WHISPER_API struct whisper_context * wmi_init_host_only(const void * buffer, siz
  * every rank, because it is derived from the tensor directory alone:
  *   rank 0:      ctx = wmi_init_from_buffer_on_device(model, n, dev);  h = wmi_model_header(model, n, buf, cap)
  *   every rank:  receives the h bytes of buf (a ~1 MB header image: hyper-parameters, mel filters, vocabulary, tensor directory)
- *   rank != 0:   ctx = wmi_init_from_buffer_on_device(buf, h, dev)     -> arena allocated and laid out, not filled
+ *   rank != 0:   ctx = wmi_init_from_header(buf, h, dev)     -> arena allocated, ZEROED and laid out; the context is "weights
+ *                pending": every compute entry point (mel / encode / decode / whisper_full / wmi_full_batch) fails with an error
  *   every rank:  ncclBroadcast(wmi_arena_ptr(ctx), wmi_weights_bytes(ctx, 0), root 0)   (godot-whisper_amd/shard.py)
+ *   rank != 0:   wmi_arena_commit(ctx)                        -> device synchronised, the context may compute
+ * The header image is accepted by wmi_init_from_header ONLY: whisper_init_from_buffer* and wmi_init_from_buffer_on_device reject it
+ * (a context that "loads fine" and transcribes from an unfilled arena must not exist).
  * wmi_model_header returns the image size (call with out == NULL to size the buffer), 0 for an invalid model.
  * wmi_weights_bytes: which = 0 the whole arena, 1 the matrices only (what a decoded token streams; quantised models: their
  * blocks), 2 the ggml type of the quantised matrices (0: f16). */
 WHISPER_API size_t wmi_model_header(const void * model, size_t model_size, void * out, size_t cap);
 WHISPER_API void * wmi_arena_ptr(struct whisper_context * ctx);
+WHISPER_API struct whisper_context * wmi_init_from_header(const void * header, size_t header_size, int device);
+WHISPER_API int    wmi_arena_commit(struct whisper_context * ctx);      /* 0 ok; < 0: no arena / device error */
+WHISPER_API int    wmi_weights_pending(struct whisper_context * ctx);   /* 1 while a header-image context waits for its arena */
 WHISPER_API size_t wmi_weights_bytes(struct whisper_context * ctx, int which);
 
 /* PCM already in HBM (f32 mono 16 kHz, device pointer on the context's device) -> log-mel in the
