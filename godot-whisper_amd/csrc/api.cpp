@@ -637,6 +637,12 @@ int wmi_selftest_quant(int device, int qtype, int mode, const void * w_blocks, c
     return ok ? 0 : -3;
 }
 
+int wmi_step_stamps(struct whisper_context * ctx, double * out, int cap, int chained) {
+    if (!ctx || !ctx->state || !out) return -1;
+    (void) hipSetDevice(ctx->device);
+    try { return step_stamps(*ctx, out, cap, chained != 0); } catch (...) { return -1; }
+}
+
 double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters) {
     (void) hipSetDevice(ctx->device);
     State & st = *ctx->state; DeviceState & d = st.dev; const HParams & hp = ctx->model.hp; const Weights & w = ctx->w;

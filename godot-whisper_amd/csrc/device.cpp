@@ -712,11 +712,15 @@ double bench_greedy_step_chain(whisper_context & ctx, int iters) {
     hipGraph_t pg = nullptr; hipGraphExec_t pexec = nullptr;
     enqueue_greedy_step(ctx, Tc, long_kv);                      // function attributes, lazy allocations: outside the capture
     (void) hipStreamSynchronize(s);
+    // WMI_CHAIN_REPS = r: r copies of the (masked) step inside ONE graph — a replay of a handful of kernels is bounded by the
+    // replay's own fixed cost, not by the kernels (a per-kind chain of 6 launches is such a graph)
+    const int reps = getenv("WMI_CHAIN_REPS") ? std::max(1, atoi(getenv("WMI_CHAIN_REPS"))) : 1;
     if (!eager && hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-        enqueue_greedy_step(ctx, Tc, long_kv);
+        for (int r = 0; r < reps; ++r) enqueue_greedy_step(ctx, Tc, long_kv);
         if (hipStreamEndCapture(s, &pg) != hipSuccess || !pg || hipGraphInstantiate(&pexec, pg, nullptr, nullptr, 0) != hipSuccess) pexec = nullptr;
     }
     auto once = [&]() { if (pexec) (void) hipGraphLaunch(pexec, s); else enqueue_greedy_step(ctx, Tc, long_kv); };
+    if (reps > 1) iters = (iters + reps - 1) / reps;
     for (int i = 0; i < 4; ++i) once();
     (void) hipStreamSynchronize(s);
     (void) hipEventRecord(e0, s);
@@ -727,7 +731,67 @@ double bench_greedy_step_chain(whisper_context & ctx, int iters) {
     if (pexec) (void) hipGraphExecDestroy(pexec);
     if (pg) (void) hipGraphDestroy(pg);
     (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
-    return (double) ms * 1000.0 / iters;
+    return (double) ms * 1000.0 / (iters * (pexec ? reps : 1));
+}
+
+// probe: body / boundary split of the greedy step's dependent launches from in-kernel time stamps (kernels.h: Stamp).  The step is
+// captured with stamping on, replayed a few times, and the LAST replay's records are reduced per launch:
+// out[6 i + 0..5] = first wavefront start, last wavefront start, last wavefront end (microseconds from the step's first start),
+// number of wavefront records, and two optional mid points (k_gemv1: activation row ready, first row tile reduced; -1 if absent).  Returns the number of launches (<= cap), -1 when there is no step to replay.
+int step_stamps(whisper_context & ctx, double * out, int cap, bool chained) {
+    State & st = *ctx.state; DeviceState & d = st.dev;
+    if (!d.step_dev || ctx.model.quantised || cap <= 0) return -1;
+    const int Tc = st.enc_n_ctx > 0 ? st.enc_n_ctx : ctx.model.hp.n_audio_ctx;
+    hipStream_t s = d.stream;
+    const bool long_kv = ((const k::DecStep *) d.step_host)->n_kv > 64;
+    constexpr int MAXL = 256;
+    const size_t bytes = (size_t) MAXL * k::STAMP_WAVES * 4 * sizeof(unsigned long long);
+    unsigned long long * buf = nullptr;
+    if (!HIP_OK(hipMalloc((void **) &buf, bytes))) return -1;
+    (void) hipMemsetAsync(buf, 0, bytes, s);
+    d.chain_valid = false;
+    enqueue_greedy_step(ctx, Tc, long_kv, false);           // leaves a valid device-side record for the chained form
+    (void) hipStreamSynchronize(s);
+    hipGraph_t g = nullptr; hipGraphExec_t ex = nullptr; int n = 0;
+    k::stamp_enable(buf);
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        enqueue_greedy_step(ctx, Tc, long_kv, chained);
+        n = k::stamp_count();
+        if (hipStreamEndCapture(s, &g) != hipSuccess || !g || hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) ex = nullptr;
+    }
+    k::stamp_enable(nullptr);
+    int ret = -1;
+    if (ex && n > 0 && n <= MAXL) {
+        for (int i = 0; i < 3; ++i) (void) hipGraphLaunch(ex, s);
+        (void) hipStreamSynchronize(s);
+        std::vector<unsigned long long> h((size_t) n * k::STAMP_WAVES * 4);
+        if (HIP_OK(hipMemcpy(h.data(), buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost))) {
+            int khz = 100000; (void) hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx.device);
+            const double tick_us = 1000.0 / (double) (khz > 0 ? khz : 100000);
+            unsigned long long origin = ~0ull;
+            for (size_t i = 0; i < h.size(); i += 4) if (h[i] && h[i] < origin) origin = h[i];
+            ret = std::min(n, cap);
+            for (int l = 0; l < ret; ++l) {
+                unsigned long long mn = ~0ull, mxs = 0, mxe = 0, m1 = 0, m2 = 0; int cnt = 0;
+                for (int w2 = 0; w2 < k::STAMP_WAVES; ++w2) {
+                    const unsigned long long * r = &h[((size_t) l * k::STAMP_WAVES + w2) * 4];
+                    if (!r[0]) continue;
+                    mn = std::min(mn, r[0]); mxs = std::max(mxs, r[0]); mxe = std::max(mxe, r[1]); m1 = std::max(m1, r[2]); m2 = std::max(m2, r[3]); ++cnt;
+                }
+                out[6 * l + 0] = cnt ? (double) (mn - origin) * tick_us : -1.0;
+                out[6 * l + 1] = cnt ? (double) (mxs - origin) * tick_us : -1.0;
+                out[6 * l + 2] = cnt ? (double) (mxe - origin) * tick_us : -1.0;
+                out[6 * l + 3] = (double) cnt;
+                out[6 * l + 4] = m1 ? (double) (m1 - origin) * tick_us : -1.0;      // optional mid points (last wavefront to reach them)
+                out[6 * l + 5] = m2 ? (double) (m2 - origin) * tick_us : -1.0;
+            }
+        }
+    }
+    if (ex) (void) hipGraphExecDestroy(ex);
+    if (g) (void) hipGraphDestroy(g);
+    d.chain_valid = false;                                  // the replays advanced (chained) or reset the device-side record
+    (void) hipFree(buf);
+    return ret;
 }
 
 } // namespace wmi

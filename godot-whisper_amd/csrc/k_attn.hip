@@ -17,6 +17,7 @@
 // (slot (g, j) <-> key 32*ks + 4*g + j for j < 4, + 16 for j >= 4; V^T fragments are gathered to match).
 
 #include "kernels.h"
+#include "wave_ops.h"
 #include <cstdlib>
 
 namespace wmi { namespace k {
@@ -121,8 +122,8 @@ __global__ __launch_bounds__(NW * 64 * KS) void k_attn_enc(const __half * __rest
         }
         __syncthreads();
     }
-    m = fmaxf(m, __shfl_xor(m, 16));
-    m = fmaxf(m, __shfl_xor(m, 32));
+    m = fmaxf(m, WMI_SHX(m, 16));
+    m = fmaxf(m, WMI_SHX(m, 32));
     if (KS == 2) {                                           // exact row max over both key halves
         __shared__ float s_m[2][NW][16];
         if (lane < 16) s_m[half][wave][lane] = m;
@@ -170,8 +171,8 @@ __global__ __launch_bounds__(NW * 64 * KS) void k_attn_enc(const __half * __rest
         }
         __syncthreads();
     }
-    l += __shfl_xor(l, 16);
-    l += __shfl_xor(l, 32);
+    l += WMI_SHX(l, 16);
+    l += WMI_SHX(l, 32);
     if (KS == 2) {                                           // second half hands its partial sums and outputs to the first
         __shared__ float s_o[NW][64][17];
         if (half == 1) {
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(256) void k_attn_dec(const __half * __restrict__ q,
         sc[j] = s;
         lmax = fmaxf(lmax, s);
     }
-    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, WMI_SHX(lmax, o));
     if (lane == 0) red[wave] = lmax;
     __syncthreads();
     const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
@@ -262,7 +263,7 @@ __global__ __launch_bounds__(256) void k_attn_dec(const __half * __restrict__ q,
         sc[j] = e;
         lsum += e;
     }
-    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) lsum += WMI_SHX(lsum, o);
     if (lane == 0) red[wave] = lsum;
     __syncthreads();
     const float inv = (float) (1.0 / ((double) red[0] + (double) red[1] + (double) red[2] + (double) red[3]));
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(256) void k_xattn_scores(const __half * __restrict_
         sc[((size_t) i * H + head) * ld_sc + j] = dot;
         lmax = fmaxf(lmax, dot);
     }
-    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, WMI_SHX(lmax, o));
     if (lane == 0) red[wave] = lmax;
     __syncthreads();
     if (tid == 0) pmax[((size_t) i * H + head) * ns + slice] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
@@ -404,14 +405,14 @@ __global__ __launch_bounds__(256) void k_xattn_qscores(const float * __restrict_
     for (int t = 0; t < NC; ++t)
 #pragma unroll
         for (int e = 0; e < 8; ++e) sum += xv[t][e];
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) sum += WMI_SHX(sum, o);
     const float mean = sum / (float) S;
     float sq = 0.0f;
 #pragma unroll
     for (int t = 0; t < NC; ++t)
 #pragma unroll
         for (int e = 0; e < 8; ++e) { if (on[t]) { xv[t][e] -= mean; sq += xv[t][e] * xv[t][e]; } }
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) sq += WMI_SHX(sq, o);
     const float scl = 1.0f / sqrtf(sq / (float) S + eps);
     float av[NC][8];
 #pragma unroll
@@ -440,27 +441,27 @@ __global__ __launch_bounds__(256) void k_xattn_qscores(const float * __restrict_
     for (int u = 0; u < 8; ++u) {
         const bool hi = lane & 32;
         const float keep = hi ? acc[u + 8] : acc[u], send = hi ? acc[u] : acc[u + 8];
-        acc[u] = keep + __shfl_xor(send, 32);
+        acc[u] = keep + WMI_SHX(send, 32);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         const bool hi = lane & 16;
         const float keep = hi ? acc[u + 4] : acc[u], send = hi ? acc[u] : acc[u + 4];
-        acc[u] = keep + __shfl_xor(send, 16);
+        acc[u] = keep + WMI_SHX(send, 16);
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
         const bool hi = lane & 8;
         const float keep = hi ? acc[u + 2] : acc[u], send = hi ? acc[u] : acc[u + 2];
-        acc[u] = keep + __shfl_xor(send, 8);
+        acc[u] = keep + WMI_SHX(send, 8);
     }
     {
         const bool hi = lane & 4;
         const float keep = hi ? acc[1] : acc[0], send = hi ? acc[0] : acc[1];
-        acc[0] = keep + __shfl_xor(send, 4);
+        acc[0] = keep + WMI_SHX(send, 4);
     }
-    acc[0] += __shfl_xor(acc[0], 2);
-    acc[0] += __shfl_xor(acc[0], 1);
+    acc[0] += WMI_SHX(acc[0], 2);
+    acc[0] += WMI_SHX(acc[0], 1);
     if ((lane & 3) == 0) qs[wave * 16 + ((lane >> 2) & 15)] = round_f16((acc[0] + bias) * qscale);
     __syncthreads();
 
@@ -483,14 +484,14 @@ __global__ __launch_bounds__(256) void k_xattn_qscores(const float * __restrict_
                 dot = fmaf(f.x, qo[2 * e], dot);
                 dot = fmaf(f.y, qo[2 * e + 1], dot);
             }
-            dot += __shfl_xor(dot, 1); dot += __shfl_xor(dot, 2); dot += __shfl_xor(dot, 4);     // the 8 octets of a key
+            dot += WMI_SHX(dot, 1); dot += WMI_SHX(dot, 2); dot += WMI_SHX(dot, 4);     // the 8 octets of a key
             if (ok) {
                 if (o == 0) sc[((size_t) i * H + head) * ld_sc + j] = dot;
                 lmax = fmaxf(lmax, dot);
             }
         }
     }
-    for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, o));
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) lmax = fmaxf(lmax, WMI_SHX(lmax, o));
     if (lane == 0) red[wave] = lmax;
     __syncthreads();
     if (tid == 0) pmax[((size_t) i * H + head) * ns + slice] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
@@ -534,7 +535,7 @@ __global__ __launch_bounds__(256) void k_xattn_pv(const __half * __restrict__ vc
         const float v = exp16(sc[row * ld_sc + j0 + t] - m);
         e[t] = v; lsum += v;
     }
-    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o);
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) lsum += WMI_SHX(lsum, o);
     __syncthreads();
     float acc[8];
 #pragma unroll
@@ -569,7 +570,7 @@ __global__ __launch_bounds__(256) void k_xattn_pv(const __half * __restrict__ vc
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
         float v = acc[d];
-        v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        v += WMI_SHX(v, 8); v += WMI_SHX(v, 16); v += WMI_SHX(v, 32);
         acc[d] = v;
     }
     if (kg == 0) {
@@ -598,12 +599,16 @@ __global__ __launch_bounds__(256) void k_xattn_fused(const float * __restrict__ 
                                                      const __half * __restrict__ q16,
                                                      int S, const __half * __restrict__ kc, const __half * __restrict__ vc, int T, int ks, int ns,
                                                      float * __restrict__ pmax, float * __restrict__ part_o, float * __restrict__ part_l,
-                                                     int64_t kv_row_stride) {
+                                                     int64_t kv_row_stride, int head_major, const Stamp sp) {
     __shared__ float qs[64];
     __shared__ float red[4], lred[4];
     __shared__ float ored[4][64];
+    const unsigned long long ts0 = stamp_t0(sp.base);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int slice = blockIdx.x, head = blockIdx.y, i = blockIdx.z, H = gridDim.y;
+    // head_major: grid (H, ns, n) — workgroup id % 8 = head % 8, so the 8 key slices of a head share one XCD's L2 and that L2
+    // fetches only its head's 64 rows of W_cq (slice-major, every XCD pulled the whole matrix: 2.1x the algorithmic bytes)
+    const int slice = head_major ? blockIdx.y : blockIdx.x, head = head_major ? blockIdx.x : blockIdx.y, i = blockIdx.z;
+    const int H = head_major ? gridDim.x : gridDim.y;
     const size_t row = (size_t) i * H + head;
     kc += (int64_t) i * kv_row_stride; vc += (int64_t) i * kv_row_stride;
     constexpr int KPASS = 6;                                        // 4 wavefronts x 6 passes x 8 keys = 192 >= ks
@@ -661,14 +666,14 @@ __global__ __launch_bounds__(256) void k_xattn_fused(const float * __restrict__ 
         for (int t = 0; t < NC; ++t)
 #pragma unroll
             for (int e = 0; e < 8; ++e) sum += xv[t][e];
-        for (int x = 32; x > 0; x >>= 1) sum += __shfl_xor(sum, x);
+        _Pragma("unroll") for (int x = 32; x > 0; x >>= 1) sum += WMI_SHX(sum, x);
         const float mean = sum / (float) S;
         float sq = 0.0f;
 #pragma unroll
         for (int t = 0; t < NC; ++t)
 #pragma unroll
             for (int e = 0; e < 8; ++e) { if (on[t]) { xv[t][e] -= mean; sq += xv[t][e] * xv[t][e]; } }
-        for (int x = 32; x > 0; x >>= 1) sq += __shfl_xor(sq, x);
+        _Pragma("unroll") for (int x = 32; x > 0; x >>= 1) sq += WMI_SHX(sq, x);
         const float scl = 1.0f / sqrtf(sq / (float) S + eps);
         float av[NC][8];
 #pragma unroll
@@ -696,27 +701,27 @@ __global__ __launch_bounds__(256) void k_xattn_fused(const float * __restrict__ 
         for (int u = 0; u < 8; ++u) {
             const bool hi = lane & 32;
             const float keep = hi ? acc[u + 8] : acc[u], send = hi ? acc[u] : acc[u + 8];
-            acc[u] = keep + __shfl_xor(send, 32);
+            acc[u] = keep + WMI_SHX(send, 32);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const bool hi = lane & 16;
             const float keep = hi ? acc[u + 4] : acc[u], send = hi ? acc[u] : acc[u + 4];
-            acc[u] = keep + __shfl_xor(send, 16);
+            acc[u] = keep + WMI_SHX(send, 16);
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const bool hi = lane & 8;
             const float keep = hi ? acc[u + 2] : acc[u], send = hi ? acc[u] : acc[u + 2];
-            acc[u] = keep + __shfl_xor(send, 8);
+            acc[u] = keep + WMI_SHX(send, 8);
         }
         {
             const bool hi = lane & 4;
             const float keep = hi ? acc[1] : acc[0], send = hi ? acc[0] : acc[1];
-            acc[0] = keep + __shfl_xor(send, 4);
+            acc[0] = keep + WMI_SHX(send, 4);
         }
-        acc[0] += __shfl_xor(acc[0], 2);
-        acc[0] += __shfl_xor(acc[0], 1);
+        acc[0] += WMI_SHX(acc[0], 2);
+        acc[0] += WMI_SHX(acc[0], 1);
         if ((lane & 3) == 0) qs[wave * 16 + ((lane >> 2) & 15)] = round_f16((acc[0] + bias) * qscale);
         if constexpr (NC > 1) {                      // the projection's weights held the registers: V goes out now, behind the scores
 #pragma unroll
@@ -746,11 +751,11 @@ __global__ __launch_bounds__(256) void k_xattn_fused(const float * __restrict__ 
             dot = fmaf(f.x, qo[2 * e], dot);
             dot = fmaf(f.y, qo[2 * e + 1], dot);
         }
-        dot += __shfl_xor(dot, 1); dot += __shfl_xor(dot, 2); dot += __shfl_xor(dot, 4);     // the 8 octets of a key
+        dot += WMI_SHX(dot, 1); dot += WMI_SHX(dot, 2); dot += WMI_SHX(dot, 4);     // the 8 octets of a key
         sv[p] = ok[p] ? dot : -INFINITY;
         lmax = fmaxf(lmax, sv[p]);
     }
-    for (int x = 32; x > 4; x >>= 1) lmax = fmaxf(lmax, __shfl_xor(lmax, x));       // the octet lanes of a key agree already
+    _Pragma("unroll") for (int x = 32; x > 4; x >>= 1) lmax = fmaxf(lmax, WMI_SHX(lmax, x));       // the octet lanes of a key agree already
     if (lane == 0) red[wave] = lmax;
     __syncthreads();
     const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
@@ -769,11 +774,11 @@ __global__ __launch_bounds__(256) void k_xattn_fused(const float * __restrict__ 
             acc[2 * q + 1] = fmaf(e, f.y, acc[2 * q + 1]);
         }
     }
-    for (int x = 32; x > 0; x >>= 1) lsum += __shfl_xor(lsum, x);
+    _Pragma("unroll") for (int x = 32; x > 0; x >>= 1) lsum += WMI_SHX(lsum, x);
 #pragma unroll
     for (int d = 0; d < 8; ++d) {
         float v = acc[d];
-        v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);
+        v += WMI_SHX(v, 8); v += WMI_SHX(v, 16); v += WMI_SHX(v, 32);
         acc[d] = v;
     }
     if (g == 0) {
@@ -784,6 +789,7 @@ __global__ __launch_bounds__(256) void k_xattn_fused(const float * __restrict__ 
     __syncthreads();
     if (tid < 64) part_o[(row * ns + slice) * 64 + tid] = (ored[0][tid] + ored[1][tid]) + (ored[2][tid] + ored[3][tid]);
     if (tid == 0) { part_l[row * ns + slice] = (lred[0] + lred[1]) + (lred[2] + lred[3]); pmax[row * ns + slice] = m; }
+    stamp_end(sp.base, sp.slot, (((int) blockIdx.z * (int) gridDim.y + (int) blockIdx.y) * (int) gridDim.x + (int) blockIdx.x) * 4 + wave, ts0);
 }
 
 // weight of slice s2 when partials are relative to their own slice maximum (part_m != null), else 1
@@ -837,14 +843,16 @@ static XLayout xattn_layout(int n, int H, int T, float * scratch) {
     L.fused = !two_pass && L.ks <= 192;               // one pass keeps a slice's scores in registers: 4 wavefronts x 6 x 8 keys
     return L;
 }
+static bool xattn_head_major() { static const bool off = getenv("WMI_XATTN_SLICE_MAJOR") != nullptr; return !off; }      // A/B knob
+static dim3 xattn_grid(int ns, int H, int n) { return xattn_head_major() ? dim3(H, ns, n) : dim3(ns, H, n); }
 static int g_xattn_probe_skip = 0;        // probe only: bit 0 skips the score kernel, bit 1 the P.V kernel (two-pass form)
 void set_xattn_probe_skip(int mask) { g_xattn_probe_skip = mask; }
 
 static void xattn_run(const XLayout & L, const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int T,
                       hipStream_t st, int64_t kv_row_stride) {
     if (L.fused) {
-        hipLaunchKernelGGL((k_xattn_fused<1, false>), dim3(L.ns, H, n), dim3(256), 0, st, nullptr, nullptr, nullptr, 0.0f, nullptr, nullptr, 0.0f,
-                           q, S, kc, vc, T, L.ks, L.ns, L.pmax, L.part_o, L.part_l, kv_row_stride);
+        hipLaunchKernelGGL((k_xattn_fused<1, false>), xattn_grid(L.ns, H, n), dim3(256), 0, st, nullptr, nullptr, nullptr, 0.0f, nullptr, nullptr, 0.0f,
+                           q, S, kc, vc, T, L.ks, L.ns, L.pmax, L.part_o, L.part_l, kv_row_stride, xattn_head_major() ? 1 : 0, stamp_next());
         return;
     }
     hipLaunchKernelGGL(k_xattn_scores, dim3(L.ns, H, n), dim3(256), 0, st, q, S, kc, T, L.ks, L.ns, L.sc, L.ld_sc, L.pmax, kv_row_stride);
@@ -886,8 +894,8 @@ void attn_cross_qsplit_partials(const float * x32, const float * ln_g, const flo
     if (L.fused) {
         if (g_xattn_probe_skip & 1) return;
         auto kern = S <= 512 ? k_xattn_fused<1, true> : S <= 1024 ? k_xattn_fused<2, true> : k_xattn_fused<3, true>;      // S <= 1536
-        hipLaunchKernelGGL(kern, dim3(L.ns, H, n), dim3(256), 0, st, x32, ln_g, ln_b, eps, wq, bq, qscale, nullptr, S, kc, vc, T, L.ks, L.ns,
-                           L.pmax, L.part_o, L.part_l, kv_row_stride);
+        hipLaunchKernelGGL(kern, xattn_grid(L.ns, H, n), dim3(256), 0, st, x32, ln_g, ln_b, eps, wq, bq, qscale, nullptr, S, kc, vc, T, L.ks, L.ns,
+                           L.pmax, L.part_o, L.part_l, kv_row_stride, xattn_head_major() ? 1 : 0, stamp_next());
         return;
     }
     if (!(g_xattn_probe_skip & 1))

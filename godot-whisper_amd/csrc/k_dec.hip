@@ -13,6 +13,7 @@
 //   * f32 accumulation, 64-lane butterfly reduction, then the same fused epilogues as the big GEMM.
 
 #include "kernels.h"
+#include "wave_ops.h"
 #include <type_traits>
 
 #include <cstdlib>
@@ -43,8 +44,9 @@ __global__ void k_step_mirror(const int32_t * __restrict__ host_step, int32_t * 
 // Graph-replay variant: the step parameters are read straight from pinned HOST memory (one PCIe read, no memcpy
 // node in the graph) and mirrored into device memory for the kernels that follow.
 __global__ void k_dec_embed_step(const DecStep * __restrict__ host_step, DecStep * __restrict__ dev_step, int S,
-                                 const __half * __restrict__ te, const float * __restrict__ pe, float * __restrict__ x) {
+                                 const __half * __restrict__ te, const float * __restrict__ pe, float * __restrict__ x, const Stamp sp) {
     __shared__ DecStep st;
+    const unsigned long long ts0 = stamp_t0(sp.base);
     host_step += blockIdx.x; dev_step += blockIdx.x; x += (size_t) blockIdx.x * S;      // one workgroup per lock-step chunk
     if (threadIdx.x < sizeof(DecStep) / 4) ((int32_t *) &st)[threadIdx.x] = ((const volatile int32_t *) host_step)[threadIdx.x];
     __syncthreads();
@@ -52,6 +54,7 @@ __global__ void k_dec_embed_step(const DecStep * __restrict__ host_step, DecStep
     const __half * t = te + (size_t) st.token * S;
     const float *  p = pe + (size_t) st.pos * S;
     for (int c = threadIdx.x; c < S; c += blockDim.x) x[c] = __half2float(t[c]) + p[c];
+    stamp_end(sp.base, sp.slot, blockIdx.x * 4 + (threadIdx.x >> 6), ts0);
 }
 
 
@@ -142,18 +145,18 @@ __device__ __forceinline__ bool self_attn_wave(const __half * __restrict__ sq, c
                     dot = fmaf(f.x, qf[2 * e], dot);
                     dot = fmaf(f.y, qf[2 * e + 1], dot);
                 }
-                dot += __shfl_xor(dot, 1); dot += __shfl_xor(dot, 2); dot += __shfl_xor(dot, 4);
+                dot += WMI_SHX(dot, 1); dot += WMI_SHX(dot, 2); dot += WMI_SHX(dot, 4);
                 if (8 * t + g < n_kv) { p[u][t] = dot; m = fmaxf(m, dot); }
             }
         }
-        m = fmaxf(m, __shfl_xor(m, 8)); m = fmaxf(m, __shfl_xor(m, 16)); m = fmaxf(m, __shfl_xor(m, 32));
+        m = fmaxf(m, WMI_SHX(m, 8)); m = fmaxf(m, WMI_SHX(m, 16)); m = fmaxf(m, WMI_SHX(m, 32));
         float l = 0.0f;
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
             const float e = (t < n_pass && 8 * t + g < n_kv) ? round_f16(expf(round_f16(p[u][t] - m))) : 0.0f;
             p[u][t] = e; l += e;
         }
-        l += __shfl_xor(l, 8); l += __shfl_xor(l, 16); l += __shfl_xor(l, 32);
+        l += WMI_SHX(l, 8); l += WMI_SHX(l, 16); l += WMI_SHX(l, 32);
         const float inv = (float) (1.0 / (double) l);
 #pragma unroll
         for (int t = 0; t < 8; ++t) p[u][t] = round_f16(p[u][t] * inv);
@@ -180,7 +183,7 @@ __device__ __forceinline__ bool self_attn_wave(const __half * __restrict__ sq, c
             }
         }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { float v = acc[e]; v += __shfl_xor(v, 8); v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); acc[e] = v; }
+        for (int e = 0; e < 8; ++e) { float v = acc[e]; v += WMI_SHX(v, 8); v += WMI_SHX(v, 16); v += WMI_SHX(v, 32); acc[e] = v; }
         if (g == 0 && hs[u] < H) {
             if (out32) {                                  // block-quantised out-projection: the f32 result is quantised as is
                 *(float4 *) (out32 + hs[u] * 64 + o * 8)     = make_float4(acc[0], acc[1], acc[2], acc[3]);
@@ -233,10 +236,10 @@ __device__ __forceinline__ void self_attn_row(const __half * __restrict__ sq, co
         float * row = sc + (size_t) h * cap;
         float m = -INFINITY;
         for (int j = lane; j < n_kv; j += 64) m = fmaxf(m, row[j]);
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, WMI_SHX(m, o));
         float l = 0.0f;
         for (int j = lane; j < n_kv; j += 64) { const float e = round_f16(expf(round_f16(row[j] - m))); row[j] = e; l += e; }
-        for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
+        _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) l += WMI_SHX(l, o);
         const float inv = (float) (1.0 / (double) l);
         for (int j = lane; j < n_kv; j += 64) row[j] = round_f16(row[j] * inv);
     }
@@ -298,10 +301,10 @@ __global__ __launch_bounds__(64) void k_self_attn_rows(const __half * __restrict
     {
         float m = -INFINITY;
         for (int j = lane; j < n_kv; j += 64) m = fmaxf(m, row[j]);
-        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, WMI_SHX(m, o));
         float l = 0.0f;
         for (int j = lane; j < n_kv; j += 64) { const float e = round_f16(expf(round_f16(row[j] - m))); row[j] = e; l += e; }
-        for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
+        _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) l += WMI_SHX(l, o);
         const float inv = (float) (1.0 / (double) l);
         for (int j = lane; j < n_kv; j += 64) row[j] = round_f16(row[j] * inv);
     }
@@ -361,14 +364,14 @@ __global__ __launch_bounds__(256) void k_self_attn_rows_long(const __half * __re
         row[j] = dot;
         m = fmaxf(m, dot);
     }
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, WMI_SHX(m, o));
     if (lane == 0) red[wave] = m;
     __syncthreads();
     m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
     __syncthreads();                                    // red is reused for the sums
     float l = 0.0f;
     for (int j = tid; j < n_kv; j += 256) { const float e = round_f16(expf(round_f16(row[j] - m))); row[j] = e; l += e; }
-    for (int o = 32; o > 0; o >>= 1) l += __shfl_xor(l, o);
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) l += WMI_SHX(l, o);
     if (lane == 0) red[wave] = l;
     __syncthreads();
     const float inv = (float) (1.0 / (double) ((red[0] + red[1]) + (red[2] + red[3])));
@@ -422,7 +425,7 @@ __device__ __forceinline__ void ln_row_compute(float (&xv)[MAXCH][8], const floa
     for (int t = 0; t < MAXCH; ++t)
 #pragma unroll
         for (int e = 0; e < 8; ++e) sum += xv[t][e];
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) sum += WMI_SHX(sum, o);
     const float mean = sum / (float) K;
     float sq = 0.0f;
 #pragma unroll
@@ -431,7 +434,7 @@ __device__ __forceinline__ void ln_row_compute(float (&xv)[MAXCH][8], const floa
 #pragma unroll
         for (int e = 0; e < 8; ++e) if (on) { xv[t][e] -= mean; sq += xv[t][e] * xv[t][e]; }
     }
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) sq += WMI_SHX(sq, o);
     const float sc = 1.0f / sqrtf(sq / (float) K + eps);
 #pragma unroll
     for (int t = 0; t < MAXCH; ++t) {
@@ -455,9 +458,9 @@ __device__ __forceinline__ void ln_rows_compute(float (&xv)[RW][MAXCH][8], const
 #pragma unroll
             for (int e = 0; e < 8; ++e) sum[q] += xv[q][t][e];
     }
-    for (int o = 32; o > 0; o >>= 1) {
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll
-        for (int q = 0; q < RW; ++q) sum[q] += __shfl_xor(sum[q], o);
+        for (int q = 0; q < RW; ++q) sum[q] += WMI_SHX(sum[q], o);
     }
 #pragma unroll
     for (int q = 0; q < RW; ++q) {
@@ -470,9 +473,9 @@ __device__ __forceinline__ void ln_rows_compute(float (&xv)[RW][MAXCH][8], const
             for (int e = 0; e < 8; ++e) if (on) { xv[q][t][e] -= mean; sq[q] += xv[q][t][e] * xv[q][t][e]; }
         }
     }
-    for (int o = 32; o > 0; o >>= 1) {
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) {
 #pragma unroll
-        for (int q = 0; q < RW; ++q) sq[q] += __shfl_xor(sq[q], o);
+        for (int q = 0; q < RW; ++q) sq[q] += WMI_SHX(sq[q], o);
     }
 #pragma unroll
     for (int q = 0; q < RW; ++q) {
@@ -657,7 +660,7 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
 #pragma unroll
             for (int r = 0; r < R; ++r) {
                 float v = acc[u][r];
-                for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+                _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) v += WMI_SHX(v, o);
                 acc[u][r] = v;
             }
         // epilogue: lane (u * R + r) writes element (row r, column o0 + u)
@@ -721,6 +724,7 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     __half * act = (__half *) smem;                         // [K], attention prologues only
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long ts0 = stamp_t0(a.stamps);
     const int K = a.K;
     int nblk = gridDim.x;
     if constexpr (PRO <= 0 && (EPI < 0 || EPI == EPI_F32_BIAS_RESID)) {
@@ -770,12 +774,15 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
     const int src = a.rows ? a.rows[0] : 0;
     if (pro_ln) {
         // same instantiation as k_gemv<R>'s prologue: the lock-step VALU path must stay bit-identical to this kernel
-        float av3[3][8];
-        ln_row_regs<3>(a.x32 + (size_t) src * K, a.ln_g, a.ln_b, K, a.eps, lane, av3);
+        // (ln_row_regs<3> there; with K <= 512 LC the chunks past LC only add exact zeros to the sums: the same bits, a third of the
+        // loads and adds for base.en)
+        constexpr int LC = NCH < 3 ? NCH : 3;
+        float avl[LC][8];
+        ln_row_regs<LC>(a.x32 + (size_t) src * K, a.ln_g, a.ln_b, K, a.eps, lane, avl);
 #pragma unroll
         for (int t = 0; t < NCH; ++t)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) av[t][e] = t < 3 ? av3[t < 3 ? t : 0][e] : 0.0f;
+            for (int e = 0; e < 8; ++e) av[t][e] = t < LC ? avl[t < LC ? t : 0][e] : 0.0f;
     } else {
         const __half * arow = a.a16 + (size_t) src * K;
         if (pro_sa) {
@@ -867,6 +874,8 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
         }
     }
 
+    const unsigned long long tm1 = stamp_t0(a.stamps);     // activation row ready (LayerNorm / attention prologue done)
+    unsigned long long tm2 = 0;
     bool first = have_pre;
     for (int o0 = gw * RIF; o0 < a.N; o0 += nwaves * RIF) {
         uint4 w[NCH][RIF];
@@ -910,20 +919,21 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
         float v;
         if (RIF == 8) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { const bool hi = lane & 32; const float keep = hi ? acc[u + 4] : acc[u], send = hi ? acc[u] : acc[u + 4]; acc[u] = keep + __shfl_xor(send, 32); }
+            for (int u = 0; u < 4; ++u) { const bool hi = lane & 32; const float keep = hi ? acc[u + 4] : acc[u], send = hi ? acc[u] : acc[u + 4]; acc[u] = keep + WMI_SHX(send, 32); }
 #pragma unroll
-            for (int u = 0; u < 2; ++u) { const bool hi = lane & 16; const float keep = hi ? acc[u + 2] : acc[u], send = hi ? acc[u] : acc[u + 2]; acc[u] = keep + __shfl_xor(send, 16); }
-            { const bool hi = lane & 8; const float keep = hi ? acc[1] : acc[0], send = hi ? acc[0] : acc[1]; v = keep + __shfl_xor(send, 8); }
-            v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+            for (int u = 0; u < 2; ++u) { const bool hi = lane & 16; const float keep = hi ? acc[u + 2] : acc[u], send = hi ? acc[u] : acc[u + 2]; acc[u] = keep + WMI_SHX(send, 16); }
+            { const bool hi = lane & 8; const float keep = hi ? acc[1] : acc[0], send = hi ? acc[0] : acc[1]; v = keep + WMI_SHX(send, 8); }
+            v += WMI_SHX(v, 4); v += WMI_SHX(v, 2); v += WMI_SHX(v, 1);
         } else if (RIF == 2) {
-            { const bool hi = lane & 32; const float keep = hi ? acc[RIF - 1] : acc[0], send = hi ? acc[0] : acc[RIF - 1]; v = keep + __shfl_xor(send, 32); }
-            v += __shfl_xor(v, 16); v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+            { const bool hi = lane & 32; const float keep = hi ? acc[RIF - 1] : acc[0], send = hi ? acc[0] : acc[RIF - 1]; v = keep + WMI_SHX(send, 32); }
+            v += WMI_SHX(v, 16); v += WMI_SHX(v, 8); v += WMI_SHX(v, 4); v += WMI_SHX(v, 2); v += WMI_SHX(v, 1);
         } else {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) { const bool hi = lane & 32; const float keep = hi ? acc[u + 2] : acc[u], send = hi ? acc[u] : acc[u + 2]; acc[u] = keep + __shfl_xor(send, 32); }
-            { const bool hi = lane & 16; const float keep = hi ? acc[1] : acc[0], send = hi ? acc[0] : acc[1]; v = keep + __shfl_xor(send, 16); }
-            v += __shfl_xor(v, 8); v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+            for (int u = 0; u < 2; ++u) { const bool hi = lane & 32; const float keep = hi ? acc[u + 2] : acc[u], send = hi ? acc[u] : acc[u + 2]; acc[u] = keep + WMI_SHX(send, 32); }
+            { const bool hi = lane & 16; const float keep = hi ? acc[1] : acc[0], send = hi ? acc[0] : acc[1]; v = keep + WMI_SHX(send, 16); }
+            v += WMI_SHX(v, 8); v += WMI_SHX(v, 4); v += WMI_SHX(v, 2); v += WMI_SHX(v, 1);
         }
+        if (a.stamps && !tm2) { asm volatile("" :: "v"(v)); tm2 = wall_clock64(); }       // first tile reduced
         if (writer) {
             const int n = o0 + wrow;
             if (n < a.N) {
@@ -950,6 +960,7 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
             }
         }
     }
+    stamp_end(a.stamps, a.stamp_slot, gw, ts0, tm1, tm2);
 }
 
 template <int RIF, int NCH, bool NT = false, int PRO = -1, int EPI = -1>
@@ -1333,7 +1344,7 @@ void dec_embed(const int32_t * tokens, const int32_t * pos, int n, int S, const 
 
 void dec_embed_step(const DecStep * host_step, DecStep * dev_step, int S, const __half * te, const float * pe, float * x,
                     hipStream_t st, int n_rows) {
-    hipLaunchKernelGGL(k_dec_embed_step, dim3(n_rows), dim3(256), 0, st, host_step, dev_step, S, te, pe, x);
+    hipLaunchKernelGGL(k_dec_embed_step, dim3(n_rows), dim3(256), 0, st, host_step, dev_step, S, te, pe, x, stamp_next());
 }
 
 void self_attn_rows(const __half * q, int n, int K, const __half * kc, const __half * vc, int64_t cache_row_stride,
@@ -1351,7 +1362,13 @@ static bool g_rows_valu = false;
 void set_rows_valu(bool on) { g_rows_valu = on; }
 bool rows_valu_enabled() { static const bool env = getenv("WMI_ROWS_VALU") != nullptr; return env || g_rows_valu; }
 
+static void gemv_(const GemvArgs & a, hipStream_t st);
 void gemv(const GemvArgs & a, hipStream_t st) {
+    const Stamp sp = stamp_next();
+    if (sp.base) { GemvArgs b = a; b.stamps = sp.base; b.stamp_slot = sp.slot; gemv_(b, st); return; }
+    gemv_(a, st);
+}
+static void gemv_(const GemvArgs & a, hipStream_t st) {
     // lock-step chunk rows go to the matrix cores (WMI_ROWS_VALU=1 keeps them on the VALU kernel, whose per-row
     // arithmetic is bit-identical to the single-row path: used by the parity tests to pin the control flow)
     static const bool rows_valu_env = getenv("WMI_ROWS_VALU") != nullptr;

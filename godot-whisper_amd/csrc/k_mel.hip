@@ -9,6 +9,7 @@
 // and contributes < 1 % of a transcription.
 
 #include "kernels.h"
+#include "wave_ops.h"
 #include <climits>
 #include <cmath>
 #include <mutex>
@@ -201,7 +202,7 @@ __global__ __launch_bounds__(MEL_NT) void k_mel_frames(const float * __restrict_
         mel[(size_t) j * n_len + frame] = v;
         vmax = fmaxf(vmax, v);
     }
-    for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, __shfl_xor(vmax, o));
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) vmax = fmaxf(vmax, WMI_SHX(vmax, o));
     // one atomic per frame at most, and only when it can raise the maximum: 12 000 atomics on one address (one per wavefront)
     // serialised at the memory side and were most of this kernel's 76 us
     __shared__ float s_vmax[MEL_NT / 64];
@@ -268,7 +269,7 @@ __global__ __launch_bounds__(256) void k_signal_energy(const float * __restrict_
         out[i] = v;
     }
     float lo = i < n ? v : INFINITY, hi = i < n ? v : -INFINITY;
-    for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, __shfl_xor(lo, o)); hi = fmaxf(hi, __shfl_xor(hi, o)); }
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) { lo = fminf(lo, WMI_SHX(lo, o)); hi = fmaxf(hi, WMI_SHX(hi, o)); }
     if ((threadIdx.x & 63) == 0) { s_min[threadIdx.x >> 6] = lo; s_max[threadIdx.x >> 6] = hi; }
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -373,6 +374,11 @@ void vad_window(const float * x, int n, int n_last, float alpha, bool filter, fl
 
 __global__ void k_touch(int * p, int nblk) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] += 1; }
 void touch(int * p, int blocks, hipStream_t st) { hipLaunchKernelGGL(k_touch, dim3(blocks), dim3(256), 0, st, p, blocks); }
+
+static Stamp g_stamp{nullptr, 0};
+void  stamp_enable(unsigned long long * base) { g_stamp.base = base; g_stamp.slot = 0; }
+Stamp stamp_next() { if (!g_stamp.base) return Stamp{nullptr, 0}; return Stamp{g_stamp.base, g_stamp.slot++}; }
+int   stamp_count() { return g_stamp.slot; }
 
 void fill_zero(void * p, size_t bytes, hipStream_t st) {
     (void) hipMemsetAsync(p, 0, bytes, st);

@@ -6,6 +6,7 @@
 // HBM-bound: reads 4 B/element, writes 2 (or 6) B/element.
 
 #include "kernels.h"
+#include "wave_ops.h"
 
 namespace wmi { namespace k {
 
@@ -34,7 +35,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float * __restrict__ x,
         if (c < S) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) sum += WMI_SHX(sum, o);
     const float mean = sum / (float) S;
     float sq = 0.0f;
 #pragma unroll
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(256) void k_layernorm(const float * __restrict__ x,
             sq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
         }
     }
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) sq += WMI_SHX(sq, o);
     const float scale = 1.0f / sqrtf(sq / (float) S + eps);
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {

@@ -24,6 +24,7 @@
 //   k_qembed    token embedding gather with dequantisation
 
 #include "kernels.h"
+#include "wave_ops.h"
 
 #include <cstdlib>
 #include <cstring>
@@ -137,12 +138,12 @@ __device__ __forceinline__ void unpack(const uint32_t (&qs)[Geo<QT>::QW], const 
 template <bool F16D>
 __device__ __forceinline__ uint32_t quant4(float y0, float y1, float y2, float y3, float & d_out, float & s_out) {
     float amax = fmaxf(fmaxf(fabsf(y0), fabsf(y1)), fmaxf(fabsf(y2), fabsf(y3)));
-    amax = fmaxf(amax, __shfl_xor(amax, 1)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 4));
+    amax = fmaxf(amax, WMI_SHX(amax, 1)); amax = fmaxf(amax, WMI_SHX(amax, 2)); amax = fmaxf(amax, WMI_SHX(amax, 4));
     const float d  = amax / 127.0f;
     const float id = amax != 0.0f ? 127.0f / amax : 0.0f;
     const int q0 = (int) rintf(y0 * id), q1 = (int) rintf(y1 * id), q2 = (int) rintf(y2 * id), q3 = (int) rintf(y3 * id);
     int sum = (q0 + q1) + (q2 + q3);
-    sum += __shfl_xor(sum, 1); sum += __shfl_xor(sum, 2); sum += __shfl_xor(sum, 4);
+    sum += WMI_SHX(sum, 1); sum += WMI_SHX(sum, 2); sum += WMI_SHX(sum, 4);
     if (F16D) { d_out = round_f16(d); s_out = 0.0f; }
     else      { d_out = d; s_out = d * (float) sum; }
     return (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
@@ -158,7 +159,7 @@ __device__ __forceinline__ void ln_inplace(float4 (&v)[MAXV], const float4 (&gg)
         if (c < S) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) sum += WMI_SHX(sum, o);
     const float mean = sum / (float) S;
     float sq = 0.0f;
 #pragma unroll
@@ -169,7 +170,7 @@ __device__ __forceinline__ void ln_inplace(float4 (&v)[MAXV], const float4 (&gg)
             sq += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
         }
     }
-    for (int o = 32; o > 0; o >>= 1) sq += __shfl_xor(sq, o);
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) sq += WMI_SHX(sq, o);
     const float scale = 1.0f / sqrtf(sq / (float) S + eps);
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
@@ -647,7 +648,7 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
                     const int c = (i * 64 + lane) * 4;
                     if (c < K) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
                 }
-                for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+                _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) sum += WMI_SHX(sum, o);
                 const float mean = sum / (float) K;
                 float sqs = 0.0f;
 #pragma unroll
@@ -658,7 +659,7 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
                         sqs += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
                     }
                 }
-                for (int o = 32; o > 0; o >>= 1) sqs += __shfl_xor(sqs, o);
+                _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) sqs += WMI_SHX(sqs, o);
                 if (lane == 0) { stat[2 * r] = mean; stat[2 * r + 1] = 1.0f / sqrtf(sqs / (float) K + a.eps); }
             }
             __syncthreads();
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
                 if (c < K) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
                 else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
-            for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+            _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) sum += WMI_SHX(sum, o);
             const float mean = sum / (float) K;
             float sqs = 0.0f;
 #pragma unroll
@@ -708,7 +709,7 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
                     sqs += (v[i].x * v[i].x + v[i].y * v[i].y) + (v[i].z * v[i].z + v[i].w * v[i].w);
                 }
             }
-            for (int o = 32; o > 0; o >>= 1) sqs += __shfl_xor(sqs, o);
+            _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) sqs += WMI_SHX(sqs, o);
             const float scale = 1.0f / sqrtf(sqs / (float) K + a.eps);
             float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll

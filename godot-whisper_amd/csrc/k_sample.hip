@@ -14,6 +14,7 @@
 // beam search, t > 0 and logit-filter callbacks.
 
 #include "kernels.h"
+#include "wave_ops.h"
 
 namespace wmi { namespace k {
 
@@ -27,17 +28,18 @@ __device__ __forceinline__ MaxIdx better(MaxIdx a, MaxIdx b) {      // larger va
     return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
 }
 __device__ __forceinline__ MaxIdx wave_max(MaxIdx m) {
-    for (int o = 32; o > 0; o >>= 1) { MaxIdx t; t.v = __shfl_xor(m.v, o); t.i = __shfl_xor(m.i, o); m = better(m, t); }
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) { MaxIdx t; t.v = WMI_SHX(m.v, o); t.i = WMI_SHX(m.i, o); m = better(m, t); }
     return m;
 }
-__device__ __forceinline__ float wave_sum(float v) { for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o); return v; }
+__device__ __forceinline__ float wave_sum(float v) { for (int o = 32; o > 0; o >>= 1) v += WMI_SHX(v, o); return v; }
 
 // per-workgroup partial statistics of the filtered logits: maxima with first-index tie-break (all / text /
 // timestamps) and sums of exp(l - local max) — combined exactly (online soft-max identity) by the second kernel
 struct Partial { MaxIdx all, txt, ts; float sum, sum_ts; float pad[2]; };
 
 __global__ __launch_bounds__(NT) void k_filter_stats(const float * __restrict__ logits, const uint8_t * __restrict__ ban,
-                                                     const DecStep * __restrict__ stp, Partial * __restrict__ part) {
+                                                     const DecStep * __restrict__ stp, Partial * __restrict__ part, const Stamp sp) {
+    const unsigned long long ts0 = stamp_t0(sp.base);
     __shared__ MaxIdx s_all[4], s_txt[4], s_ts[4];
     __shared__ float s_sum[4], s_sum_ts[4];
     __shared__ float b_M;
@@ -103,10 +105,12 @@ __global__ __launch_bounds__(NT) void k_filter_stats(const float * __restrict__ 
         p.pad[0] = p.pad[1] = 0.0f;
         part[blockIdx.x] = p;
     }
+    stamp_end(sp.base, sp.slot, ((int) blockIdx.y * (int) gridDim.x + (int) blockIdx.x) * 4 + wave, ts0);
 }
 
 __global__ __launch_bounds__(64) void k_filter_pick(const Partial * __restrict__ part, const DecStep * __restrict__ stp,
-                                                    SampleOut * __restrict__ out, SampleOut * __restrict__ out_host, const ChainNext chain) {
+                                                    SampleOut * __restrict__ out, SampleOut * __restrict__ out_host, const ChainNext chain, const Stamp sp) {
+    const unsigned long long ts0 = stamp_t0(sp.base);
     const int lane = threadIdx.x;
     part += (size_t) blockIdx.x * NB; stp += blockIdx.x; out += blockIdx.x; if (out_host) out_host += blockIdx.x;
     const Partial p = part[lane];                       // NB == 64: one partial per lane
@@ -158,6 +162,7 @@ __global__ __launch_bounds__(64) void k_filter_pick(const Partial * __restrict__
             chain.step_rw->token = id; chain.step_rw->pos = pos1; chain.step_rw->n_kv = n_kv + 1; chain.step_rw->kv_head = head + 1;
         }
     }
+    stamp_end(sp.base, sp.slot, blockIdx.x, ts0);
 }
 
 // ---- draws (beam search / t > 0).  Same filter predicate as k_filter_stats.
@@ -204,7 +209,7 @@ __global__ __launch_bounds__(NT) void k_prob_blocks(const float * __restrict__ l
     const int per = (NV + NB - 1) / NB, i0 = blockIdx.x * per, i1 = min(NV, i0 + per);
     double acc = 0.0;
     for (int i = i0 + tid; i < i1; i += NT) acc += (double) prob_of(st, rs, logits[i], ban[i], i);
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) acc += WMI_SHX(acc, o);
     if (lane == 0) s_w[wave] = acc;
     __syncthreads();
     if (tid == 0) bsum[(size_t) blockIdx.y * NB + blockIdx.x] = (s_w[0] + s_w[1]) + (s_w[2] + s_w[3]);
@@ -268,7 +273,7 @@ void filter_draw(const float * logits, const uint8_t * static_ban, const DecStep
                  void * scratch, hipStream_t st, int n_rows, int tid_default) {
     Partial * part = (Partial *) scratch;
     double * bsum = (double *) ((char *) scratch + filter_scratch_bytes(n_rows));
-    hipLaunchKernelGGL(k_filter_stats, dim3(NB, n_rows), dim3(NT), 0, st, logits, static_ban, step, part);
+    hipLaunchKernelGGL(k_filter_stats, dim3(NB, n_rows), dim3(NT), 0, st, logits, static_ban, step, part, Stamp{nullptr, 0});
     hipLaunchKernelGGL(k_prob_blocks, dim3(NB, n_rows), dim3(NT), 0, st, logits, static_ban, step, part, bsum);
     hipLaunchKernelGGL(k_draw, dim3(k, n_rows), dim3(64), 0, st, logits, static_ban, step, part, bsum, u, k, tid_default, out);
 }
@@ -277,10 +282,10 @@ size_t filter_draw_scratch_bytes(int n_rows) { return filter_scratch_bytes(n_row
 void filter_argmax(const float * logits, const uint8_t * static_ban, const DecStep * step, SampleOut * out, void * scratch,
                    hipStream_t st, SampleOut * out_host, int n_rows, const ChainNext * chain) {
     Partial * part = (Partial *) scratch;
-    hipLaunchKernelGGL(k_filter_stats, dim3(NB, n_rows), dim3(NT), 0, st, logits, static_ban, step, part);
+    hipLaunchKernelGGL(k_filter_stats, dim3(NB, n_rows), dim3(NT), 0, st, logits, static_ban, step, part, stamp_next());
     ChainNext cn{};                                         // chaining is a one-row affair (the greedy step of device.cpp)
     if (chain && n_rows == 1) cn = *chain;
-    hipLaunchKernelGGL(k_filter_pick, dim3(n_rows), dim3(64), 0, st, part, step, out, out_host, cn);
+    hipLaunchKernelGGL(k_filter_pick, dim3(n_rows), dim3(64), 0, st, part, step, out, out_host, cn, stamp_next());
 }
 size_t filter_scratch_bytes(int n_rows) { return (size_t) n_rows * NB * sizeof(Partial); }
 

@@ -31,6 +31,27 @@ __device__ __forceinline__ float pin_f32(float x) { asm volatile("" : "+v"(x)); 
 __device__ __forceinline__ __half f2h(float x) { return __float2half_rn(pin_f32(x)); }
 #endif
 
+// ---------------------------------------------------------------- in-kernel time stamps (probe: wmi_step_stamps)
+// Body / boundary split of a dependent chain of launches: when stamping is on, lane 0 of every wavefront of a stamped launch
+// writes (s_memrealtime at its first instruction, s_memrealtime behind its last store) to
+// base[(slot * STAMP_WAVES + wave index) * 4] (+ two optional mid points); the host takes min start / max end per launch.  Off (base == null) costs one
+// scalar compare per kernel.  The launchers draw their slot from stamp_next() in launch order (probe runs are single-threaded).
+constexpr int STAMP_WAVES = 4096;                       // wavefront records per launch
+struct Stamp { unsigned long long * base; int slot; };
+void  stamp_enable(unsigned long long * base);          // null = off; resets the slot counter
+Stamp stamp_next();                                     // {base, slot++} or {null, 0}
+int   stamp_count();
+#if defined(__HIPCC__)
+__device__ __forceinline__ unsigned long long stamp_t0(const unsigned long long * base) { return base ? wall_clock64() : 0ull; }
+__device__ __forceinline__ void stamp_end(unsigned long long * base, int slot, int widx, unsigned long long t0,
+                                          unsigned long long tm1 = 0, unsigned long long tm2 = 0) {
+    if (base && (threadIdx.x & 63) == 0 && widx < STAMP_WAVES) {
+        unsigned long long * s = base + ((size_t) slot * STAMP_WAVES + widx) * 4;       // start, two optional mid points, end
+        s[0] = t0; s[1] = wall_clock64(); s[2] = tm1; s[3] = tm2;
+    }
+}
+#endif
+
 // ---------------------------------------------------------------- mel (k_mel.hip)
 // pcm_pad: [200 reflect | n_samples | zeros] ; frames [0, n_fft_frames) get an FFT, the rest up to
 // n_len the constant log10(1e-10).  mel: [n_mel][n_len] f32.  gmax: ordered-int encoded running max.
@@ -148,6 +169,7 @@ struct GemvArgs {
     // pf_ptr; workgroup i touches one dword per 128-byte line of the groups g = i (mod grid) — the workgroup of the next launch
     // that streams group g sits on the same XCD when both grids are multiples of 8
     const void * pf_ptr; uint32_t pf_group_bytes; uint32_t pf_groups;
+    unsigned long long * stamps; int stamp_slot;      // probe (stamp_next()): filled in by gemv() itself
 };
 // lock-step chunks: single-token self-attention of n rows, row r against the cache at kc/vc + r * cache_row_stride with
 // n_kv[r * step_stride] cells; same arithmetic as the fused prologue of gemv (GemvArgs::sa_*).  out [n][K] f16

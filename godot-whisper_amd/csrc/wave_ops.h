@@ -51,6 +51,32 @@ __device__ __forceinline__ float wave_max_desc(float v) {
     v = fmaxf(v, xor_lane<4>(v)); v = fmaxf(v, xor_lane<2>(v)); v = fmaxf(v, xor_lane<1>(v));
     return v;
 }
+
+// xor_lane with the mask as a value: inside a fully unrolled `for (o = 32; o > 0; o >>= 1)` the switch folds to the one DPP form
+// (if the loop is not unrolled the switch stays a scalar branch: still correct).  WMI_NO_DPP keeps __shfl_xor (A/B builds).
+#if defined(WMI_NO_DPP)
+#define WMI_SHX(x, m) __shfl_xor((x), (m))
+#else
+template <typename T> __device__ __forceinline__ T xor_lane_dyn32(T x, int m) {
+    switch (m) {
+        case 1:  return xor_lane<1>(x);
+        case 2:  return xor_lane<2>(x);
+        case 4:  return xor_lane<4>(x);
+        case 8:  return xor_lane<8>(x);
+        case 16: return xor_lane<16>(x);
+        case 32: return xor_lane<32>(x);
+        default: return __shfl_xor(x, m);
+    }
+}
+__device__ __forceinline__ float  xor_lane_dyn(float x, int m) { return xor_lane_dyn32<float>(x, m); }
+__device__ __forceinline__ int    xor_lane_dyn(int x, int m)   { return xor_lane_dyn32<int>(x, m); }
+__device__ __forceinline__ double xor_lane_dyn(double x, int m) {
+    const long long b = __double_as_longlong(x);
+    const int lo = xor_lane_dyn32<int>((int) (b & 0xffffffffll), m), hi = xor_lane_dyn32<int>((int) (b >> 32), m);
+    return __longlong_as_double(((long long) hi << 32) | (long long) (unsigned) lo);
+}
+#define WMI_SHX(x, m) ::wmi::k::xor_lane_dyn((x), (m))
+#endif
 #endif
 
 }} // namespace wmi::k

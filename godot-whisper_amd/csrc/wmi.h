@@ -351,6 +351,7 @@ bool fast_path_enabled();
 void pool_run(int n_tasks, const std::function<void(int)> & fn);
 double bench_greedy_step_chain(whisper_context & ctx, int iters);
 double bench_rows_step_chain(whisper_context & ctx, int nb, int iters);
+int    step_stamps(whisper_context & ctx, double * out, int cap, bool chained);
 // |x| envelope of the last PCM on the GPU; the D2H copy runs on a side stream while the encoder works.
 // sync = false: state.energy is valid only after signal_energy_wait()
 bool signal_energy_device(whisper_context & ctx, int hw, bool sync = true);

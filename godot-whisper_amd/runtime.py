@@ -4,6 +4,7 @@ error, never a silent downgrade."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 import pathlib
 
 import numpy as np
@@ -11,6 +12,9 @@ import numpy as np
 from . import abi
 
 LIB_PATH = pathlib.Path(__file__).resolve().parent / "libwhisper_mi355.so"
+# A/B builds of the same library (scratch/ probes only; the driver and the tests never set this)
+if os.environ.get("WMI_LIB_PATH"):
+    LIB_PATH = pathlib.Path(os.environ["WMI_LIB_PATH"]).resolve()
 
 DEVICE_API = [
     ("wmi_device_count", C.c_int, []),
@@ -37,6 +41,7 @@ DEVICE_API = [
                                     C.POINTER(abi.whisper_token_data)]),
     ("wmi_selftest_proj", C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     ("wmi_bench_kernel", C.c_double, [C.c_void_p, C.c_int, C.c_int]),
+    ("wmi_step_stamps", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int]),
     ("wmi_pool_init", C.c_void_p, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.c_int]),
     ("wmi_pool_free", None, [C.c_void_p]),
     ("wmi_pool_size", C.c_int, [C.c_void_p]),

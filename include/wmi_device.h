@@ -194,6 +194,15 @@ WHISPER_API int wmi_selftest_quant(int device, int qtype, int mode, const void *
  */
 WHISPER_API double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters);
 
+/* Probe: body / boundary split of the last greedy decode step's dependent launches, from time stamps taken INSIDE the kernels
+ * (s_memrealtime at a wavefront's first instruction and behind its last store).  The step is captured as a graph with stamping on
+ * and replayed; per launch i, out[6 i + 0..5] = first wavefront start, last wavefront start, last wavefront end (microseconds
+ * from the step's first start), the number of wavefront records, and two optional mid points (one-row projections: activation
+ * row ready, first row tile reduced; -1 where a kernel has none).  `out` holds 6 * cap doubles.  chained = 1: the form whose first kernel is the q|k|v
+ * projection (the pick kernel of the previous step prepared token, position and activation row on the device).
+ * Returns the number of launches written (<= cap), -1 when no greedy step has run on this context (or the model is quantised). */
+WHISPER_API int wmi_step_stamps(struct whisper_context * ctx, double * out, int cap, int chained);
+
 /* Host worker pool self-test (no device needed): `reps` jobs of `n_tasks` tasks; returns reps * n_tasks * (n_tasks + 1) / 2
  * when every task of every job ran exactly once. */
 WHISPER_API int64_t wmi_selftest_pool(int n_tasks, int reps);
