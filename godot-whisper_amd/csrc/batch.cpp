@@ -330,7 +330,7 @@ bool decode_rows_step(whisper_context & ctx, int nb) {
     {   // every row's result carries the step's sequence number (set by the caller in the step records)
         const k::DecStep * hs = (const k::DecStep *) b.step_host;
         const k::SampleOut * so = (const k::SampleOut *) b.sample_host;
-        for (int r = 0; r < nb; ++r) if (!wait_for_seq(&so[r].seq, hs[r].seq, s)) return false;
+        for (int r = 0; r < nb; ++r) if (!wait_for_sample(&so[r], hs[r].seq, s)) return false;
     }
     b.t_decode_us += time_us() - t0; b.n_steps++;
     return true;

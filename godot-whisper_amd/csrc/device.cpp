@@ -454,18 +454,22 @@ bool upload_static_ban(whisper_context & ctx, const whisper_full_params & params
 // into pinned host memory behind its result (k_filter_pick); the host spins on it (~1 us instead of the 10-20 us of an
 // interrupt-driven hipStreamSynchronize, paid once per token).  Bounded: after ~2 s it falls back to a real
 // synchronisation and reports what the stream says.
-bool wait_for_seq(const volatile int32_t * seq, int32_t want, hipStream_t s) {
+bool wait_for_sample(const k::SampleOut * r, int32_t want, hipStream_t s) {
+    // both halves of the record are written by one 16-byte store each and carry the step's number: a half whose tag matches
+    // is complete (x86 loads are not reordered with each other: tag first, then the fields)
+    const volatile int32_t * t0 = &r->seq0, * t1 = &r->seq;
     static const bool no_spin = getenv("WMI_NO_SPIN") != nullptr;          // debug / A-B
     if (!no_spin) {
-        const int64_t t0 = time_us();
+        const int64_t tb = time_us();
         for (uint32_t it = 1;; ++it) {
-            if (*seq == want) return true;
+            if (*t0 == want && *t1 == want) { asm volatile("" ::: "memory"); return true; }
             __builtin_ia32_pause();
-            if ((it & 0xFFFF) == 0 && time_us() - t0 > 2000000) break;
+            if ((it & 0xFFFF) == 0 && time_us() - tb > 2000000) break;
         }
     }
     if (!HIP_OK(hipStreamSynchronize(s))) return false;
-    return *seq == want;
+    asm volatile("" ::: "memory");
+    return *t0 == want && *t1 == want;
 }
 
 // Draws on the device ("argmax / top-k on GPU so only ~k numbers cross PCIe per step").  The logits rows of the
@@ -677,12 +681,12 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
         enqueue_greedy_step(ctx, Tc, long_kv, chained);
     }
     const k::SampleOut * r = (const k::SampleOut *) d.sample_host;
-    if (!wait_for_seq(&r->seq, d.step_seq, s)) return false;
+    if (!wait_for_sample(r, d.step_seq, s)) return false;
     // what the pick kernel has left on the device for the next step
-    d.chain_valid = !ctx.model.quantised && pos + 1 < hp.n_text_ctx;
+    d.chain_valid = !ctx.model.quantised && pos + 1 < hp.n_text_ctx && hp.n_text_state <= 1536;      // (k_filter_pick prepares rows of <= 3 x 512 columns)
     d.chain_token = r->id; d.chain_pos = pos + 1; d.chain_head = (int32_t) kv.head + 1;
-    if (getenv("WMI_DEBUG_SYNC")) fprintf(stderr, "[wmi] step token=%d pos=%d n_kv=%d head=%d flags=%d floor=%d init=%d -> id=%d tid=%d p=%g plog=%g pt=%g ptsum=%g forced=%d\n",
-        token, pos, hs->n_kv, hs->kv_head, hs->flags, hs->ts_floor_end, hs->ts_initial_start, r->id, r->tid, r->p, r->plog, r->pt, r->ptsum, r->forced_ts);
+    if (getenv("WMI_DEBUG_SYNC")) fprintf(stderr, "[wmi] step token=%d pos=%d n_kv=%d head=%d flags=%d floor=%d init=%d -> id=%d tid=%d p=%g plog=%g pt=%g ptsum=%g\n",
+        token, pos, hs->n_kv, hs->kv_head, hs->flags, hs->ts_floor_end, hs->ts_initial_start, r->id, r->tid, r->p, r->plog, r->pt, r->ptsum);
     out = whisper_token_data{ r->id, r->tid, r->p, r->plog, r->pt, r->ptsum, -1, -1, 0.0f };
     st.t_decode_us += time_us() - t0; st.n_decode++; st.n_sample++;
     return true;
@@ -782,8 +786,19 @@ int step_stamps(whisper_context & ctx, double * out, int cap, bool chained) {
                 out[6 * l + 1] = cnt ? (double) (mxs - origin) * tick_us : -1.0;
                 out[6 * l + 2] = cnt ? (double) (mxe - origin) * tick_us : -1.0;
                 out[6 * l + 3] = (double) cnt;
+                if (m1 >> 63) {
+                    // not wall-clock mid points but the SHADER clock counter at start / end (k_xattn_fused): effective MHz, averaged
+                    double mhz = 0.0; int nm = 0;
+                    for (int w2 = 0; w2 < k::STAMP_WAVES; ++w2) {
+                        const unsigned long long * r = &h[((size_t) l * k::STAMP_WAVES + w2) * 4];
+                        const unsigned long long c0 = r[2] & ~(1ull << 63);
+                        if (r[0] && r[1] > r[0] && r[3] > c0) { mhz += (double) (r[3] - c0) / ((double) (r[1] - r[0]) * tick_us); ++nm; }
+                    }
+                    out[6 * l + 4] = -2.0; out[6 * l + 5] = nm ? mhz / nm : -1.0;
+                } else {
                 out[6 * l + 4] = m1 ? (double) (m1 - origin) * tick_us : -1.0;      // optional mid points (last wavefront to reach them)
                 out[6 * l + 5] = m2 ? (double) (m2 - origin) * tick_us : -1.0;
+                }
             }
         }
     }

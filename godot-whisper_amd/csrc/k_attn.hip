@@ -603,7 +603,7 @@ __global__ __launch_bounds__(256) void k_xattn_fused(const float * __restrict__ 
     __shared__ float qs[64];
     __shared__ float red[4], lred[4];
     __shared__ float ored[4][64];
-    const unsigned long long ts0 = stamp_t0(sp.base);
+    const unsigned long long ts0 = stamp_t0(sp.base), tc0 = sp.base ? clock64() : 0ull;      // (+ shader-clock counter: the probe derives the effective clock)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // head_major: grid (H, ns, n) — workgroup id % 8 = head % 8, so the 8 key slices of a head share one XCD's L2 and that L2
     // fetches only its head's 64 rows of W_cq (slice-major, every XCD pulled the whole matrix: 2.1x the algorithmic bytes)
@@ -627,24 +627,32 @@ __global__ __launch_bounds__(256) void k_xattn_fused(const float * __restrict__ 
         bool on[NC]; int c0[NC];
 #pragma unroll
         for (int t = 0; t < NC; ++t) { on[t] = lane * 8 + 512 * t < S; c0[t] = on[t] ? lane * 8 + 512 * t : 0; }
+        // Load order (vmcnt retires in order): the residual row first — it was written by the previous launch and is in L2, and the
+        // LayerNorm statistics need nothing else — then gain / bias, the 16 query-weight rows, K and V, which come from
+        // Infinity Cache / HBM; the statistics run while those are in flight.  (Weights first: LN waited for all 16 rows.)
+        float xv[NC][8], gv[NC][8], bv[NC][8];
+#pragma unroll
+        for (int t = 0; t < NC; ++t) {
+            const float * xr = x32 + (size_t) i * S + c0[t];
+            const float4 x0 = *(const float4 *) xr, x1 = *(const float4 *) (xr + 4);
+            xv[t][0] = x0.x; xv[t][1] = x0.y; xv[t][2] = x0.z; xv[t][3] = x0.w; xv[t][4] = x1.x; xv[t][5] = x1.y; xv[t][6] = x1.z; xv[t][7] = x1.w;
+        }
+#pragma unroll
+        for (int t = 0; t < NC; ++t) {
+            const float4 g0 = *(const float4 *) (ln_g + c0[t]), g1 = *(const float4 *) (ln_g + c0[t] + 4);
+            const float4 b0 = *(const float4 *) (ln_b + c0[t]), b1 = *(const float4 *) (ln_b + c0[t] + 4);
+            gv[t][0] = g0.x; gv[t][1] = g0.y; gv[t][2] = g0.z; gv[t][3] = g0.w; gv[t][4] = g1.x; gv[t][5] = g1.y; gv[t][6] = g1.z; gv[t][7] = g1.w;
+            bv[t][0] = b0.x; bv[t][1] = b0.y; bv[t][2] = b0.z; bv[t][3] = b0.w; bv[t][4] = b1.x; bv[t][5] = b1.y; bv[t][6] = b1.z; bv[t][7] = b1.w;
+        }
+        __builtin_amdgcn_sched_barrier(0);
         uint4 w[NC][16];
         const __half * wrow0 = wq + (size_t) (head * 64 + wave * 16) * S;
 #pragma unroll
         for (int t = 0; t < NC; ++t)
 #pragma unroll
             for (int u = 0; u < 16; ++u) w[t][u] = *(const uint4 *) (wrow0 + (size_t) u * S + c0[t]);
-        float xv[NC][8], gv[NC][8], bv[NC][8];
-#pragma unroll
-        for (int t = 0; t < NC; ++t) {
-            const float * xr = x32 + (size_t) i * S + c0[t];
-            const float4 x0 = *(const float4 *) xr, x1 = *(const float4 *) (xr + 4);
-            const float4 g0 = *(const float4 *) (ln_g + c0[t]), g1 = *(const float4 *) (ln_g + c0[t] + 4);
-            const float4 b0 = *(const float4 *) (ln_b + c0[t]), b1 = *(const float4 *) (ln_b + c0[t] + 4);
-            xv[t][0] = x0.x; xv[t][1] = x0.y; xv[t][2] = x0.z; xv[t][3] = x0.w; xv[t][4] = x1.x; xv[t][5] = x1.y; xv[t][6] = x1.z; xv[t][7] = x1.w;
-            gv[t][0] = g0.x; gv[t][1] = g0.y; gv[t][2] = g0.z; gv[t][3] = g0.w; gv[t][4] = g1.x; gv[t][5] = g1.y; gv[t][6] = g1.z; gv[t][7] = g1.w;
-            bv[t][0] = b0.x; bv[t][1] = b0.y; bv[t][2] = b0.z; bv[t][3] = b0.w; bv[t][4] = b1.x; bv[t][5] = b1.y; bv[t][6] = b1.z; bv[t][7] = b1.w;
-        }
-        const float bias = bq ? bq[head * 64 + wave * 16 + ((lane >> 2) & 15)] : 0.0f;
+        // (straight-line: an absent bias reads the weights' first bytes and is masked at its use)
+        const float bias_raw = *(bq ? bq + head * 64 + wave * 16 + ((lane >> 2) & 15) : (const float *) wq);
 #pragma unroll
         for (int p = 0; p < KPASS; ++p) kk[p] = *(const uint4 *) (kc + off[p]);
         if constexpr (NC == 1) {
@@ -655,8 +663,6 @@ __global__ __launch_bounds__(256) void k_xattn_fused(const float * __restrict__ 
 #pragma unroll
         for (int t = 0; t < NC; ++t) {
             if (!on[t]) {
-#pragma unroll
-                for (int u = 0; u < 16; ++u) w[t][u] = make_uint4(0u, 0u, 0u, 0u);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) { xv[t][e] = 0.0f; gv[t][e] = 0.0f; bv[t][e] = 0.0f; }
             }
@@ -680,6 +686,14 @@ __global__ __launch_bounds__(256) void k_xattn_fused(const float * __restrict__ 
         for (int t = 0; t < NC; ++t)
 #pragma unroll
             for (int e = 0; e < 8; ++e) av[t][e] = round_f16(__fadd_rn(__fmul_rn(xv[t][e] * scl, gv[t][e]), bv[t][e]));
+        __builtin_amdgcn_sched_barrier(0);          // the LayerNorm before anything that waits for the weight rows
+#pragma unroll
+        for (int t = 0; t < NC; ++t) {               // (columns past S: a select on w is a use of w — it must not sit in front of the LayerNorm)
+            if (!on[t]) {
+#pragma unroll
+                for (int u = 0; u < 16; ++u) w[t][u] = make_uint4(0u, 0u, 0u, 0u);
+            }
+        }
         float acc[16];
 #pragma unroll
         for (int u = 0; u < 16; ++u) {
@@ -722,6 +736,7 @@ __global__ __launch_bounds__(256) void k_xattn_fused(const float * __restrict__ 
         }
         acc[0] += WMI_SHX(acc[0], 2);
         acc[0] += WMI_SHX(acc[0], 1);
+        const float bias = bq ? bias_raw : 0.0f;
         if ((lane & 3) == 0) qs[wave * 16 + ((lane >> 2) & 15)] = round_f16((acc[0] + bias) * qscale);
         if constexpr (NC > 1) {                      // the projection's weights held the registers: V goes out now, behind the scores
 #pragma unroll
@@ -789,7 +804,7 @@ __global__ __launch_bounds__(256) void k_xattn_fused(const float * __restrict__ 
     __syncthreads();
     if (tid < 64) part_o[(row * ns + slice) * 64 + tid] = (ored[0][tid] + ored[1][tid]) + (ored[2][tid] + ored[3][tid]);
     if (tid == 0) { part_l[row * ns + slice] = (lred[0] + lred[1]) + (lred[2] + lred[3]); pmax[row * ns + slice] = m; }
-    stamp_end(sp.base, sp.slot, (((int) blockIdx.z * (int) gridDim.y + (int) blockIdx.y) * (int) gridDim.x + (int) blockIdx.x) * 4 + wave, ts0);
+    stamp_end(sp.base, sp.slot, (((int) blockIdx.z * (int) gridDim.y + (int) blockIdx.y) * (int) gridDim.x + (int) blockIdx.x) * 4 + wave, ts0, tc0 | (1ull << 63), sp.base ? clock64() : 0ull);      // bit 63: a shader-clock pair, not mid points
 }
 
 // weight of slice s2 when partials are relative to their own slice maximum (part_m != null), else 1

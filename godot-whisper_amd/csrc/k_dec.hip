@@ -84,10 +84,15 @@ __device__ __forceinline__ float comb_weight(const float * comb_m, size_t idx, f
     return ms > -INFINITY ? __expf(ms - M) : 0.0f;
 }
 
-template <int NU>
+// after_loads(): called once every load of the routine is issued (the caller's colder loads go there: vmcnt retires in order, so
+// whatever is requested BEFORE the keys delays the attention by its own latency — the out projection's weight rows come from
+// HBM / Infinity Cache, q / K / V of a step from L2).
+struct NoAfterLoads { __device__ __forceinline__ void operator()() const {} };
+template <int NU, typename AfterLoads = NoAfterLoads>
 __device__ __forceinline__ bool self_attn_wave(const __half * __restrict__ sq, const __half * __restrict__ sk,
                                                const __half * __restrict__ sv, const int32_t * __restrict__ n_kv_p, int K, int cap,
-                                               const int (&hs)[NU], int H, int lane, __half * out, float * out32 = nullptr) {
+                                               const int (&hs)[NU], int H, int lane, __half * out, float * out32 = nullptr,
+                                               AfterLoads after_loads = AfterLoads()) {
     const int g = lane >> 3, o = lane & 7;
     int hh[NU];
 #pragma unroll
@@ -109,7 +114,14 @@ __device__ __forceinline__ bool self_attn_wave(const __half * __restrict__ sq, c
             const int j = 8 * t + g;
             vv[u][t] = *(const uint4 *) (sv + (size_t) (j < cap ? j : 0) * K + hh[u] * 64 + o * 8);
         }
-    const int n_kv = *n_kv_p;
+    // n_kv through a lane offset the compiler cannot fold: as a uniform load it became load -> vmcnt(0) -> readfirstlane on the spot,
+    // i.e. a wait for everything issued before it; here the wait sits at the first use and counts only the loads above
+    int zl = 0; asm volatile("" : "+v"(zl));
+    const int n_kv_v = n_kv_p[zl];
+    __builtin_amdgcn_sched_barrier(0);
+    after_loads();
+    __builtin_amdgcn_sched_barrier(0);
+    const int n_kv = __builtin_amdgcn_readfirstlane(n_kv_v);
     if (n_kv > 64) return false;
     if (n_kv > 32) {
 #pragma unroll
@@ -406,14 +418,23 @@ template <int MAXCH>
 __device__ __forceinline__ void ln_row_load(const float * __restrict__ p, int K, int lane, float (&v)[MAXCH][8]) {
 #pragma unroll
     for (int t = 0; t < MAXCH; ++t) {
-        const int c = lane * 8 + 512 * t;
-        if (c < K) {
-            const float4 x0 = *(const float4 *) (p + c), x1 = *(const float4 *) (p + c + 4);
-            v[t][0] = x0.x; v[t][1] = x0.y; v[t][2] = x0.z; v[t][3] = x0.w; v[t][4] = x1.x; v[t][5] = x1.y; v[t][6] = x1.z; v[t][7] = x1.w;
-        } else {
+        // unconditional from a clamped column, masked afterwards: a load inside `if (c < K)` is its own basic block, and the
+        // s_waitcnt pass cannot count loads it is not sure were issued — every wait after such a block became vmcnt(0 or 1),
+        // i.e. "everything", instead of "the row" 
+        // (the mask is ln_row_mask, called where the values are first needed: a select here is a use, i.e. a wait in front of
+        // whatever the caller requests next)
+        const int c = lane * 8 + 512 * t, cc = c < K ? c : 0;
+        const float4 x0 = *(const float4 *) (p + cc), x1 = *(const float4 *) (p + cc + 4);
+        v[t][0] = x0.x; v[t][1] = x0.y; v[t][2] = x0.z; v[t][3] = x0.w; v[t][4] = x1.x; v[t][5] = x1.y; v[t][6] = x1.z; v[t][7] = x1.w;
+    }
+}
+template <int MAXCH>
+__device__ __forceinline__ void ln_row_mask(float (&v)[MAXCH][8], int K, int lane) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[t][e] = 0.0f;
-        }
+    for (int t = 0; t < MAXCH; ++t) {
+        const bool on = lane * 8 + 512 * t < K;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[t][e] = on ? v[t][e] : 0.0f;
     }
 }
 // the arithmetic of ln_row_regs on loaded values (xv is consumed)
@@ -495,6 +516,7 @@ __device__ __forceinline__ void ln_row_regs(const float * __restrict__ xr, const
     ln_row_load<MAXCH>(xr, K, lane, xv);
     ln_row_load<MAXCH>(g, K, lane, gv);
     ln_row_load<MAXCH>(b, K, lane, bv);
+    ln_row_mask<MAXCH>(xv, K, lane); ln_row_mask<MAXCH>(gv, K, lane); ln_row_mask<MAXCH>(bv, K, lane);
     ln_row_compute<MAXCH>(xv, gv, bv, K, eps, lane, av);
 }
 
@@ -715,7 +737,7 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
 // compile time: the decode step's six hot combinations get kernels without the other kinds' code and without the dispatch on
 // kernel arguments (a launch on the step's critical path pays for every instruction and scalar load in front of its first
 // memory request); -1 keeps the run-time dispatch.
-template <int RIF, int NCH, bool NT, int PRO = -1, int EPI = -1>
+template <int RIF, int NCH, bool NT, int PRO = -1, int EPI = -1, int HPW = 0>
 __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
     const bool pro_ln = PRO < 0 ? a.ln_g != nullptr : PRO == 1;
     const bool pro_sa = PRO < 0 ? a.sa_q != nullptr : PRO == 2;
@@ -741,11 +763,29 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
     const int nwaves = nblk * 4;
     const int gw = blockIdx.x * 4 + wave;
 
-    // ALL chunks of the first row tile are requested before anything else (with only the first chunk up front, K > 512 paid a
-    // second round trip after the prologue).  Columns past K read column 0 instead: the activation there is exactly 0.
+    // Load order.  vmcnt retires in order: a wavefront cannot look at a value before everything requested ahead of it has arrived.
+    // The weight rows are the coldest thing this kernel reads (HBM / Infinity Cache, ~1.2 us); the activation row, q / K / V of
+    // the step and the cross-attention partials were written by the previous launch and sit in L2 (~0.4 us).  So the prologue's
+    // own operands go out FIRST, the weight rows (ALL chunks of the first row tile, plus bias / residual / cache head of the
+    // epilogue) right behind them — still before any wait — and the prologue's arithmetic (LayerNorm statistics, the
+    // self-attention, the combine) runs while the weights are in flight.  Weights first (round 2) made every prologue start
+    // at the weights' latency: LN + q|k|v row ready at +1.8 us of a 2.4 us kernel, self-attention + out at +3.7 of 4.3.
+    // Columns past K read column 0 instead: the activation there is exactly 0.
     uint4 wpre[NCH][RIF];
     const bool have_pre = gw * RIF < a.N;
-    if (have_pre) {
+    // after the halving reduction below, row u of a tile ends up on the lanes with (lane / LPR) % RIF == u; lane u * LPR writes it
+    constexpr int LPR = 64 / RIF;                           // 16 (RIF 4) or 8 (RIF 8)
+    const int wrow = lane / LPR;                            // row this lane would write
+    const bool writer = (lane % LPR) == 0;
+    float bias_pre = 0.0f, resid_pre = 0.0f; int ro_pre = 0;
+    int zl = 0; asm volatile("" : "+v"(zl));                // a zero the compiler cannot fold (see self_attn_wave: n_kv)
+    bool w_issued = false;
+    auto issue_weights = [&]() {
+        if (w_issued) return;
+        w_issued = true;
+        __builtin_amdgcn_sched_barrier(0);
+        // straight-line: rows clamped to N - 1 (a wavefront past the matrix re-reads its last row), absent vectors read the
+        // weights' first bytes and are masked — no load sits in a conditional block (see ln_row_load)
 #pragma unroll
         for (int t = 0; t < NCH; ++t) {
             const int c = lane * 8 + 512 * t, cc = c < K ? c : 0;
@@ -755,30 +795,37 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
                 wpre[t][u] = ldw<NT>(a.W + (size_t) o * K + cc);
             }
         }
-    }
-    // after the halving reduction below, row u of a tile ends up on the lanes with (lane / LPR) % RIF == u; lane u * LPR writes it
-    constexpr int LPR = 64 / RIF;                           // 16 (RIF 4) or 8 (RIF 8)
-    const int wrow = lane / LPR;                            // row this lane would write
-    const bool writer = (lane % LPR) == 0;
-    float bias_pre = 0.0f, resid_pre = 0.0f; int ro_pre = 0;
-    {
-        const int n = gw * RIF + wrow;
-        if (writer && n < a.N) {
-            if (a.bias) bias_pre = a.bias[n];
-            if (a.resid) resid_pre = a.resid[n];
+        {
+            int n = gw * RIF + wrow; if (n > a.N - 1) n = a.N - 1;
+            const float * bp = a.bias ? a.bias + n : (const float *) a.W, * rp = a.resid ? a.resid + n : (const float *) a.W;
+            const int32_t * op = a.row_off ? a.row_off : (const int32_t *) a.W;
+            // raw values: "absent" is resolved at the use in the epilogue (a select here is a use, i.e. a wait for the weights);
+            // ro_pre stays a VGPR until then — as a uniform load it became load -> vmcnt(0) -> readfirstlane on the spot
+            bias_pre = *bp; resid_pre = *rp; ro_pre = op[zl];
         }
-        if (a.row_off) ro_pre = *a.row_off;
-    }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+#if defined(WMI_WEIGHTS_FIRST)
+    issue_weights();                                        // A/B build: round 2's order
+#endif
 
     float av[NCH][8];
-    const int src = a.rows ? a.rows[0] : 0;
+    // (the specialised instantiations are only launched without a row gather: a.rows[0] as a vector load put a vmcnt(0) in front of
+    // every later load group through its result register)
+    const int src = PRO >= 0 ? 0 : (a.rows ? a.rows[0] : 0);
     if (pro_ln) {
-        // same instantiation as k_gemv<R>'s prologue: the lock-step VALU path must stay bit-identical to this kernel
+        // same arithmetic as k_gemv<R>'s prologue: the lock-step VALU path must stay bit-identical to this kernel
         // (ln_row_regs<3> there; with K <= 512 LC the chunks past LC only add exact zeros to the sums: the same bits, a third of the
         // loads and adds for base.en)
         constexpr int LC = NCH < 3 ? NCH : 3;
-        float avl[LC][8];
-        ln_row_regs<LC>(a.x32 + (size_t) src * K, a.ln_g, a.ln_b, K, a.eps, lane, avl);
+        float xv[LC][8], gv[LC][8], bv[LC][8], avl[LC][8];
+        const float * xr = a.x32 + (size_t) src * K;
+        ln_row_load<LC>(xr, K, lane, xv);
+        ln_row_load<LC>(a.ln_g, K, lane, gv);
+        ln_row_load<LC>(a.ln_b, K, lane, bv);
+        issue_weights();
+        ln_row_mask<LC>(xv, K, lane); ln_row_mask<LC>(gv, K, lane); ln_row_mask<LC>(bv, K, lane);
+        ln_row_compute<LC>(xv, gv, bv, K, a.eps, lane, avl);
 #pragma unroll
         for (int t = 0; t < NCH; ++t)
 #pragma unroll
@@ -795,21 +842,25 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
             // (only in the self-attention instantiations: 3-5 heads per wavefront need ~400 VGPRs, which must not leak into the
             // generic kernel that also serves the vocabulary projection at two workgroups per CU)
             bool done = true;
-            if (PRO != 2 || H <= 8) {
+            auto al = [&]() { issue_weights(); };
+            if constexpr (PRO == 2) {
+                // HPW heads per wavefront (wave, wave + 4, ...), ONE call, no loop: the weight request rides inside the call, and
+                // a wait behind a block that MAY have issued loads is vmcnt(0) — the s_waitcnt pass counts only loads it is sure
+                // of.  One instantiation per HPW: with all of them in one kernel the code object was 89 KB (instruction cache: 64 KB)
+                static_assert(HPW >= 1 && HPW <= 5, "heads per wavefront");
+                if (wave < H) {
+                    int hs[HPW];
+#pragma unroll
+                    for (int u = 0; u < HPW; ++u) hs[u] = wave + 4 * u;
+                    done = self_attn_wave<HPW>(a.sa_q, a.sa_k, a.sa_v, a.sa_nkv, K, a.sa_cap, hs, H, lane, act, nullptr, al);
+                }
+            } else {
                 for (int h0 = wave; h0 < H; h0 += 8) {
                     const int hs[2] = { h0, h0 + 4 };
-                    done = self_attn_wave<2>(a.sa_q, a.sa_k, a.sa_v, a.sa_nkv, K, a.sa_cap, hs, H, lane, act) && done;
+                    done = self_attn_wave<2>(a.sa_q, a.sa_k, a.sa_v, a.sa_nkv, K, a.sa_cap, hs, H, lane, act, nullptr, al) && done;
                 }
             }
-            else if constexpr (PRO == 2) {
-            if (H <= 12) { const int hs[3] = { wave, wave + 4, wave + 8 };                          done = self_attn_wave<3>(a.sa_q, a.sa_k, a.sa_v, a.sa_nkv, K, a.sa_cap, hs, H, lane, act); }
-            else if (H <= 16) { const int hs[4] = { wave, wave + 4, wave + 8, wave + 12 };               done = self_attn_wave<4>(a.sa_q, a.sa_k, a.sa_v, a.sa_nkv, K, a.sa_cap, hs, H, lane, act); }
-            else if (H <= 20) { const int hs[5] = { wave, wave + 4, wave + 8, wave + 12, wave + 16 };    done = self_attn_wave<5>(a.sa_q, a.sa_k, a.sa_v, a.sa_nkv, K, a.sa_cap, hs, H, lane, act); }
-            else for (int h0 = wave; h0 < H; h0 += 8) {
-                const int hs[2] = { h0, h0 + 4 };
-                done = self_attn_wave<2>(a.sa_q, a.sa_k, a.sa_v, a.sa_nkv, K, a.sa_cap, hs, H, lane, act) && done;
-            }
-            }
+            issue_weights();                                 // (a wavefront without a head)
             if (wave >= H) done = a.sa_nkv[0] <= 64;         // a wavefront without a head (H < 4) still has to agree on the branch
             if (!done) {                                     // wave-uniform and the same in every wavefront: it only depends on n_kv
                 const uint4 kpre[8] = {};
@@ -830,9 +881,10 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
 #pragma unroll
                         for (int s2 = 0; s2 < 8; ++s2) {
                             po[u][s2] = a.comb_o[((size_t) h * 8 + s2) * 64 + dd]; pl[u][s2] = a.comb_l[(size_t) h * 8 + s2];
-                            pm[u][s2] = a.comb_m ? a.comb_m[(size_t) h * 8 + s2] : 0.0f;
+                            pm[u][s2] = (a.comb_m ? a.comb_m : a.comb_l)[(size_t) h * 8 + s2];      // (absent: unused below — no select on a loaded value here)
                         }
                     }
+                    issue_weights();
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         float o = 0.0f, M = -INFINITY; double l = 0.0;
@@ -846,7 +898,9 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
                         if (e0 + u * 256 < K) act[e0 + u * 256] = f2h(o * (float) (1.0 / l));
                     }
                 }
-            } else
+                issue_weights();
+            } else {
+            issue_weights();
             for (int e = tid; e < K; e += 256) {
                 const int h = e >> 6, dd = e & 63;
                 float o = 0.0f, M = -INFINITY; double l = 0.0;
@@ -857,6 +911,7 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
                 }
                 act[e] = f2h(o * (float) (1.0 / l));
             }
+            }
             (void) H;
             __syncthreads();
             arow = act;
@@ -864,6 +919,7 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
         uint4 u4[NCH];                                       // unconditional clamped loads, masked afterwards
 #pragma unroll
         for (int t = 0; t < NCH; ++t) { const int c = lane * 8 + 512 * t; u4[t] = *(const uint4 *) (arow + (c < K ? c : 0)); }
+        issue_weights();                                     // (plain f16 rows: the row first, it is in L2)
 #pragma unroll
         for (int t = 0; t < NCH; ++t) {
             const int c = lane * 8 + 512 * t;
@@ -938,7 +994,7 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
             const int n = o0 + wrow;
             if (n < a.N) {
                 const bool pre = o0 == gw * RIF;
-                const float bias = pre ? bias_pre : (a.bias ? a.bias[n] : 0.0f);
+                const float bias = a.bias ? (pre ? bias_pre : a.bias[n]) : 0.0f;
                 const float resid = a.resid ? (pre ? resid_pre : a.resid[n]) : 0.0f;
                 switch (epi) {
                     case EPI_F16_BIAS:       ((__half *) a.C)[n] = f2h(v + bias); break;
@@ -949,9 +1005,10 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
                         const int seg = __builtin_amdgcn_readfirstlane(o0 / a.S);      // wave-uniform, see DESIGN.md §7
                         const int c = n - seg * a.S;
                         __half * dst; float val;
-                        if (seg == 0)      { dst = (__half *) a.C;                                val = (v + bias) * a.scale; }
-                        else if (seg == 1) { dst = (__half *) a.aux  + (size_t) ro_pre * a.ldaux;  val = v * a.scale; }
-                        else               { dst = (__half *) a.aux2 + (size_t) ro_pre * a.ldaux2; val = v + bias; }
+                        const int ro = a.row_off ? ro_pre : 0;
+                        if (seg == 0)      { dst = (__half *) a.C;                            val = (v + bias) * a.scale; }
+                        else if (seg == 1) { dst = (__half *) a.aux  + (size_t) ro * a.ldaux;  val = v * a.scale; }
+                        else               { dst = (__half *) a.aux2 + (size_t) ro * a.ldaux2; val = v + bias; }
                         dst[c] = f2h(val);
                     } break;
                     case EPI_LOGITS:         ((float *) a.C)[n] = v; break;
@@ -963,7 +1020,7 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
     stamp_end(a.stamps, a.stamp_slot, gw, ts0, tm1, tm2);
 }
 
-template <int RIF, int NCH, bool NT = false, int PRO = -1, int EPI = -1>
+template <int RIF, int NCH, bool NT = false, int PRO = -1, int EPI = -1, int HPW = 0>
 void launch_gemv1(const GemvArgs & a, hipStream_t st, int max_blocks = 512) {
     size_t smem = 0;
     if (a.sa_q)        smem = ((((size_t) a.K * sizeof(__half)) + 15) & ~(size_t) 15) + ((size_t) (a.K / 64) * a.sa_cap + a.K) * sizeof(float);
@@ -971,9 +1028,9 @@ void launch_gemv1(const GemvArgs & a, hipStream_t st, int max_blocks = 512) {
     int blocks = (a.N + 4 * RIF - 1) / (4 * RIF);
     if (blocks > max_blocks) blocks = max_blocks;
     static std::atomic<uint64_t> lds_ok{0};
-    if (smem > 48 * 1024) allow_full_lds((const void *) k_gemv1<RIF, NCH, NT, PRO, EPI>, lds_ok);
+    if (smem > 48 * 1024) allow_full_lds((const void *) k_gemv1<RIF, NCH, NT, PRO, EPI, HPW>, lds_ok);
     if (PRO <= 0 && (EPI < 0 || EPI == EPI_F32_BIAS_RESID) && a.step_copy_src) blocks += 1;       // the step-record mirror (see the kernel)
-    hipLaunchKernelGGL((k_gemv1<RIF, NCH, NT, PRO, EPI>), dim3(blocks), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((k_gemv1<RIF, NCH, NT, PRO, EPI, HPW>), dim3(blocks), dim3(256), smem, st, a);
 }
 
 // the decode step's hot (prologue, epilogue) combinations at one row; false = no specialised kernel for these arguments
@@ -991,11 +1048,16 @@ static bool launch_gemv1_special(const GemvArgs & a, int nch, hipStream_t st) {
     if (nch == 1) {
         if (pro == 1 && a.epi == EPI_QKV_DEC)        { launch_gemv1<4, 1, false, 1, EPI_QKV_DEC>(a, st); return true; }
         if (pro == 1 && a.epi == EPI_F16_BIAS_GELU)  { launch_gemv1<4, 1, false, 1, EPI_F16_BIAS_GELU>(a, st); return true; }
-        if (pro == 2 && a.epi == EPI_F32_BIAS_RESID) { launch_gemv1<4, 1, false, 2, EPI_F32_BIAS_RESID>(a, st); return true; }
     }
-    if (pro == 2 && a.epi == EPI_F32_BIAS_RESID) {           // wider models: all heads of a wavefront in one call need this instantiation
-        if (nch == 2) { launch_gemv1<4, 2, false, 2, EPI_F32_BIAS_RESID>(a, st); return true; }
-        if (nch == 3) { launch_gemv1<4, 3, false, 2, EPI_F32_BIAS_RESID>(a, st); return true; }
+    if (pro == 2 && a.epi == EPI_F32_BIAS_RESID && (a.K % 64) == 0) {
+        // self-attention + out projection: (row chunks, heads per wavefront) — tiny 1/2, base 1/2, small 2/3, medium 2/4, large 3/5
+        const int hpw = (a.K / 64 + 3) / 4;
+        if (nch == 1 && hpw == 1) { launch_gemv1<4, 1, false, 2, EPI_F32_BIAS_RESID, 1>(a, st); return true; }
+        if (nch == 1 && hpw == 2) { launch_gemv1<4, 1, false, 2, EPI_F32_BIAS_RESID, 2>(a, st); return true; }
+        if (nch == 2 && hpw == 3) { launch_gemv1<4, 2, false, 2, EPI_F32_BIAS_RESID, 3>(a, st); return true; }
+        if (nch == 2 && hpw == 4) { launch_gemv1<4, 2, false, 2, EPI_F32_BIAS_RESID, 4>(a, st); return true; }
+        if (nch == 3 && hpw == 5) { launch_gemv1<4, 3, false, 2, EPI_F32_BIAS_RESID, 5>(a, st); return true; }
+        if (nch == 3 && hpw == 4) { launch_gemv1<4, 3, false, 2, EPI_F32_BIAS_RESID, 4>(a, st); return true; }
     }
     if (nch == 1) {
         if (pro == 3 && a.epi == EPI_F32_BIAS_RESID) { launch_gemv1<4, 1, false, 3, EPI_F32_BIAS_RESID>(a, st); return true; }
@@ -1112,6 +1174,9 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
             ln_row_load<3>(a.ln_g, K, lane, gv);
             ln_row_load<3>(a.ln_b, K, lane, bv);
             __builtin_amdgcn_sched_barrier(0);              // keep the loads together: the scheduler sinks each to its first use
+#pragma unroll
+            for (int q = 0; q < RW; ++q) ln_row_mask<3>(xv[q], K, lane);
+            ln_row_mask<3>(gv, K, lane); ln_row_mask<3>(bv, K, lane);
             // K-split launches (one tile per workgroup, a CU to itself): the rows' LayerNorms interleaved
             ln_rows_compute<RW, 3>(xv, gv, bv, K, a.eps, lane);
 #pragma unroll

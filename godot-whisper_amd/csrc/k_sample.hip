@@ -108,27 +108,47 @@ __global__ __launch_bounds__(NT) void k_filter_stats(const float * __restrict__ 
     stamp_end(sp.base, sp.slot, ((int) blockIdx.y * (int) gridDim.x + (int) blockIdx.x) * 4 + wave, ts0);
 }
 
+template <int XU>                                          // chunks of 512 columns of the next step's activation row (S <= 512 XU)
 __global__ __launch_bounds__(64) void k_filter_pick(const Partial * __restrict__ part, const DecStep * __restrict__ stp,
                                                     SampleOut * __restrict__ out, SampleOut * __restrict__ out_host, const ChainNext chain, const Stamp sp) {
     const unsigned long long ts0 = stamp_t0(sp.base);
     const int lane = threadIdx.x;
     part += (size_t) blockIdx.x * NB; stp += blockIdx.x; out += blockIdx.x; if (out_host) out_host += blockIdx.x;
+    // the step record and the partials are requested together (field by field at their first use, the record cost three more
+    // dependent round trips on this one-wavefront kernel)
+    const int4 st0 = *(const int4 *) stp;                  // token, pos, n_kv, kv_head
+    const int beg = stp->beg, seqv = stp->seq;
     const Partial p = part[lane];                       // NB == 64: one partial per lane
     const MaxIdx a = wave_max(p.all), t = wave_max(p.txt), z = wave_max(p.ts);
     const float M = a.v;
     const float w = p.all.v > -INFINITY ? expf(p.all.v - M) : 0.0f;      // rescale the local sums to the global max
     const float sum = wave_sum(p.sum * w), sum_ts = wave_sum(p.sum_ts * w);
-    int id = 0;
+    // every lane evaluates the pick (uniform values): no broadcast between the decision and the next step's gathers
+    const float lse = logf(sum) + M;
+    // timestamp log-mass vs best text token (W/whisper.cpp:4659-4683)
+    const float ts_logprob = sum_ts > 0.0f ? logf(sum_ts) + M - lse : -INFINITY;
+    const float max_text = t.v > -INFINITY ? t.v - lse : -INFINITY;
+    const bool force_ts = ts_logprob > max_text;
+    const MaxIdx pick = force_ts ? z : a;
+    const int id = pick.i;
+    // the next greedy step feeds this pick at the next position (the host checks that before it replays the chained step):
+    // its embedding + positional rows are requested now, the result goes to the host while they are in flight
+    const int pos1 = st0.y + 1;
+    const bool chain_on = chain.step_rw && pos1 < chain.n_pos;
+    // lane L owns columns 512 u + 8 L .. + 8 of the row (XU chunks of 512 columns): one 16-byte and two 16-byte loads per chunk
+    uint4 trv[XU]; float4 prv[XU][2];
+    if (chain_on) {
+        const __half * tr = chain.te + (size_t) id * chain.S;
+        const float * pr = chain.pe + (size_t) pos1 * chain.S;
+#pragma unroll
+        for (int u = 0; u < XU; ++u) {
+            const int c = lane * 8 + 512 * u, cc = c < chain.S ? c : 0;
+            trv[u] = *(const uint4 *) (tr + cc); prv[u][0] = *(const float4 *) (pr + cc); prv[u][1] = *(const float4 *) (pr + cc + 4);
+        }
+    }
     if (lane == 0) {
-        const int beg = stp->beg;
-        const float lse = logf(sum) + M;
-        // timestamp log-mass vs best text token (W/whisper.cpp:4659-4683)
-        const float ts_logprob = sum_ts > 0.0f ? logf(sum_ts) + M - lse : -INFINITY;
-        const float max_text = t.v > -INFINITY ? t.v - lse : -INFINITY;
-        const bool force_ts = ts_logprob > max_text;
-        const MaxIdx pick = force_ts ? z : a;
         SampleOut r;
-        r.id = pick.i; r.plog = pick.v - lse; r.p = expf(r.plog); r.forced_ts = force_ts ? 1 : 0; r.seq = stp->seq;
+        r.id = id; r.plog = pick.v - lse; r.p = expf(r.plog); r.seq0 = seqv; r.seq = seqv;
         // timestamp statistics over the post-filter probabilities (W/whisper.cpp:4793-4809)
         const float p_ts_max = z.v > -INFINITY ? expf(z.v - lse) : 0.0f;
         const double sum_ts_p = (double) sum_ts * (double) expf(M - lse);
@@ -137,30 +157,26 @@ __global__ __launch_bounds__(64) void k_filter_pick(const Partial * __restrict__
         r.ptsum = (float) sum_ts_p;
         if (r.id >= beg) { r.tid = r.id; r.pt = r.p; }
         *out = r;
-        id = r.id;
-        if (out_host) {
-            // result straight into pinned host memory; the sequence number goes last, behind a system-scope fence: the host
-            // spins on it instead of paying a stream synchronisation per token
-            SampleOut body = r; body.seq = out_host->seq;
-            *out_host = body;
-            __threadfence_system();
-            *(volatile int32_t *) &out_host->seq = r.seq;
-            __threadfence_system();
+        if (out_host) {                                      // two 16-byte stores, each carrying the step's sequence number
+            const int4 * h = (const int4 *) &r;
+            ((int4 *) out_host)[0] = h[0];
+            ((int4 *) out_host)[1] = h[1];
         }
     }
     if (chain.step_rw) {
-        // the next greedy step feeds this pick at the next position (the host checks that before it replays the chained step)
-        id = __shfl(id, 0);
-        const int pos1 = stp->pos + 1;
-        if (pos1 < chain.n_pos) {
-            const __half * tr = chain.te + (size_t) id * chain.S;
-            const float * pr = chain.pe + (size_t) pos1 * chain.S;
-            for (int c = lane; c < chain.S; c += 64) chain.x[c] = __half2float(tr[c]) + pr[c];      // k_dec_embed_step's arithmetic
+        if (chain_on) {
+#pragma unroll
+            for (int u = 0; u < XU; ++u) {
+                const int c = lane * 8 + 512 * u;
+                if (c < chain.S) {                           // k_dec_embed_step's arithmetic: f32(te) + pe
+                    const __half2 * h = (const __half2 *) &trv[u];
+                    const float2 f0 = __half22float2(h[0]), f1 = __half22float2(h[1]), f2 = __half22float2(h[2]), f3 = __half22float2(h[3]);
+                    *(float4 *) (chain.x + c)     = make_float4(f0.x + prv[u][0].x, f0.y + prv[u][0].y, f1.x + prv[u][0].z, f1.y + prv[u][0].w);
+                    *(float4 *) (chain.x + c + 4) = make_float4(f2.x + prv[u][1].x, f2.y + prv[u][1].y, f3.x + prv[u][1].z, f3.y + prv[u][1].w);
+                }
+            }
         }
-        if (lane == 0) {
-            const int n_kv = stp->n_kv, head = stp->kv_head;
-            chain.step_rw->token = id; chain.step_rw->pos = pos1; chain.step_rw->n_kv = n_kv + 1; chain.step_rw->kv_head = head + 1;
-        }
+        if (lane == 0) *(int4 *) chain.step_rw = make_int4(id, pos1, st0.z + 1, st0.w + 1);      // token, pos, n_kv, kv_head
     }
     stamp_end(sp.base, sp.slot, blockIdx.x, ts0);
 }
@@ -256,7 +272,7 @@ __global__ __launch_bounds__(64) void k_draw(const float * __restrict__ logits, 
         SampleOut r;
         const float lraw = logits[pick];
         const float l = st.temperature > 0.0f ? lraw / st.temperature : lraw;
-        r.id = pick; r.plog = l - rs.lse; r.p = expf(r.plog); r.forced_ts = rs.force_ts; r.seq = dr;
+        r.id = pick; r.plog = l - rs.lse; r.p = expf(r.plog); r.seq0 = dr; r.seq = dr;
         const float p_ts_max = rs.ts.v > -INFINITY ? expf(rs.ts.v - rs.lse) : 0.0f;
         const double sum_ts_p = (double) rs.sum_ts * (double) expf(rs.M - rs.lse);
         r.tid = p_ts_max > 0.0f ? rs.ts.i : tid_default;      // the reference's initial value: token_beg (top-k) or 0 (single draw)
@@ -285,7 +301,11 @@ void filter_argmax(const float * logits, const uint8_t * static_ban, const DecSt
     hipLaunchKernelGGL(k_filter_stats, dim3(NB, n_rows), dim3(NT), 0, st, logits, static_ban, step, part, stamp_next());
     ChainNext cn{};                                         // chaining is a one-row affair (the greedy step of device.cpp)
     if (chain && n_rows == 1) cn = *chain;
-    hipLaunchKernelGGL(k_filter_pick, dim3(n_rows), dim3(64), 0, st, part, step, out, out_host, cn, stamp_next());
+    if (cn.step_rw && cn.S > 1536) cn = ChainNext{};          // (no such model: the row registers cover 3 chunks; the host then embeds)
+    const int xu = cn.step_rw ? (cn.S + 511) / 512 : 1;
+    if (xu <= 1)      hipLaunchKernelGGL(k_filter_pick<1>, dim3(n_rows), dim3(64), 0, st, part, step, out, out_host, cn, stamp_next());
+    else if (xu == 2) hipLaunchKernelGGL(k_filter_pick<2>, dim3(n_rows), dim3(64), 0, st, part, step, out, out_host, cn, stamp_next());
+    else              hipLaunchKernelGGL(k_filter_pick<3>, dim3(n_rows), dim3(64), 0, st, part, step, out, out_host, cn, stamp_next());
 }
 size_t filter_scratch_bytes(int n_rows) { return (size_t) n_rows * NB * sizeof(Partial); }
 

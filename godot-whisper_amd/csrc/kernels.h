@@ -200,7 +200,10 @@ struct DecStep {
     float   temperature;           // > 0: logits are divided by it before the filters (W/whisper.cpp:4500-4506); 0 = as they are
     int32_t pad[3];
 };
-struct SampleOut { int32_t id, tid; float p, plog, pt, ptsum; int32_t forced_ts; int32_t seq; };
+// Two self-tagged 16-byte halves: the pick kernel writes each half to pinned host memory with ONE 16-byte store, the host accepts
+// a half when its tag (seq0 / seq) is the step it waits for — no fence, no read of host memory by the device (the fenced form,
+// record + __threadfence_system + seq + fence, cost 0.65 us more per step: profiles/r03a_chain_lab_boundary_and_variants.txt)
+struct alignas(16) SampleOut { int32_t id, tid; float p; int32_t seq0; float plog, pt, ptsum; int32_t seq; };
 // logits [n_vocab] -> filtered soft-max statistics and the arg-max token (W/whisper.cpp:4493-4830 at temperature 0)
 // n_rows > 1: lock-step chunks — logits [n_rows][n_vocab], step[n_rows], out[n_rows]
 // chain (one row): the pick kernel also prepares the NEXT greedy step on the device — token = the pick, pos / n_kv / kv_head + 1 in

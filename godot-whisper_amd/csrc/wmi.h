@@ -345,7 +345,7 @@ bool upload_static_ban(whisper_context & ctx, const whisper_full_params & params
 // u [n_rows][k] uniform numbers in [0, 1) from the decoders' generators.  out [n_rows][k].
 bool sample_rows_device(whisper_context & ctx, const StepFilter * f, const int * rows, int n_rows, float temperature, int k,
                         const double * u, int tid_default, whisper_token_data * out);
-bool wait_for_seq(const volatile int32_t * seq, int32_t want, hipStream_t s);   // spin on a pinned sequence number (device.cpp)
+bool wait_for_sample(const k::SampleOut * r, int32_t want, hipStream_t s);   // spin on a pinned, self-tagged result record (device.cpp)
 bool fast_path_enabled();
 // host worker pool (pool.cpp): fn(0..n_tasks-1) on a few persistent threads + the caller; nested calls run inline
 void pool_run(int n_tasks, const std::function<void(int)> & fn);

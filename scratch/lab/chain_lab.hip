@@ -232,7 +232,8 @@ static void launch_gv(int variant, hipStream_t s, const __half * W, const void *
     }
 }
 
-constexpr int S = 512, L = 6, NSTAMP_WAVES = 2048;
+constexpr int S = 512, NSTAMP_WAVES = 2048;
+static int L = 6;                 // decoder layers of the chain: 6 = base.en (44 MB of weights); argv[3] scales the footprint
 static void enqueue_step(int variant, hipStream_t s, const std::vector<Layer> & ly, const Bufs & B, bool stamp, const uint4 * sweep, size_t sweep16, int kind_mask = 63) {
     int li = 0;
     auto st = [&]() -> unsigned long long * { return stamp ? B.stamps + (size_t) (li++) * NSTAMP_WAVES * 3 : nullptr; };
@@ -265,6 +266,9 @@ int main(int argc, char ** argv) {
         printf("xor_lane self-test: mismatch mask 0x%06x (0 = all six exchanges equal __shfl_xor)\n", any);
     }
     const bool quick = argc > 2;
+    if (argc > 3) L = atoi(argv[3]);
+    const bool arena = argc > 4;            // all weights in ONE allocation (the product's arena) instead of one hipMalloc per matrix
+    const int NL = 6 * L;
     // ---- 1. boundaries
     int * dp; CK(hipMalloc(&dp, 4096)); CK(hipMemset(dp, 0, 4096));
     {
@@ -292,8 +296,12 @@ int main(int argc, char ** argv) {
 
     // ---- 2. layer chain
     std::vector<Layer> ly(L);
+    char * arena_base = nullptr; size_t arena_off = 0;
+    if (arena) CK(hipMalloc(&arena_base, (size_t) L * 14 * S * S * 2 + 4096));
     auto walloc = [&](size_t rows, size_t cols) {
-        __half * p; CK(hipMalloc(&p, rows * cols * 2));
+        __half * p;
+        if (arena) { p = (__half *) (arena_base + arena_off); arena_off += rows * cols * 2; }
+        else CK(hipMalloc(&p, rows * cols * 2));
         std::vector<__half> h(rows * cols);
         for (size_t i = 0; i < h.size(); ++i) h[i] = __float2half((float) ((int) ((i * 2654435761u) >> 20 & 255) - 128) / 2048.0f);
         CK(hipMemcpy(p, h.data(), h.size() * 2, hipMemcpyHostToDevice));
@@ -303,7 +311,7 @@ int main(int argc, char ** argv) {
     Bufs B{};
     CK(hipMalloc(&B.x, 8192 * 4)); CK(hipMalloc(&B.q, 4096 * 2)); CK(hipMalloc(&B.c, 4096 * 2)); CK(hipMalloc(&B.h, 4096 * 2));
     CK(hipMalloc(&B.g, S * 4)); CK(hipMalloc(&B.b, S * 4));
-    CK(hipMalloc(&B.stamps, (size_t) 36 * NSTAMP_WAVES * 3 * 8));
+    CK(hipMalloc(&B.stamps, (size_t) NL * NSTAMP_WAVES * 3 * 8));
     {
         std::vector<float> one(S, 1.0f), zero(S, 0.0f), x0(8192);
         for (int i = 0; i < 8192; ++i) x0[i] = (float) ((i * 37) % 101) / 101.0f - 0.5f;
@@ -329,25 +337,25 @@ int main(int argc, char ** argv) {
         hipGraphExec_t exs = capture(s, [&]() { enqueue_step(v, s, ly, B, false, sweep, sweep_bytes / 16); });
         hipGraphExec_t exw = capture(s, [&]() { hipLaunchKernelGGL(k_sweep, dim3(768), dim3(256), 0, s, sweep, sweep_bytes / 16, B.x + 4096); });
         const double us = replay_us(ex, s, reps), uss = replay_us(exs, s, reps), usw = replay_us(exw, s, reps);
-        printf("chain[%d] %-46s: 36 launches %.1f us = %.3f us/launch ; with 53 MB sweep per step %.1f us (sweep alone %.1f) -> %.3f us/launch   (max|dx| vs variant 0: %.2e)\n",
-               v, vname[v], us, us / 36.0, uss, usw, (uss - usw) / 36.0, md);
+        printf("chain[%d] %-46s: %d launches %.1f us = %.3f us/launch ; with 53 MB sweep per step %.1f us (sweep alone %.1f) -> %.3f us/launch   (max|dx| vs variant 0: %.2e)\n",
+               v, vname[v], NL, us, us / NL, uss, usw, (uss - usw) / NL, md);
         // per kernel kind (own chain of 6 launches x 6 kinds is not a dependent chain of that kind alone, but the shares are indicative)
         for (int kind = 0; kind < 6; ++kind) {
             hipGraphExec_t exk = capture(s, [&]() { for (int r = 0; r < 6; ++r) enqueue_step(v, s, ly, B, false, nullptr, 0, 1 << kind); });
-            const double usk = replay_us(exk, s, reps / 2 + 1) / 36.0;
+            const double usk = replay_us(exk, s, reps / 2 + 1) / (6.0 * L);
             static const char * kn[6] = {"LN+qkv 1536x512", "out 512x512+res", "LN+cq 512x512", "co 512x512+res", "LN+fc1 2048x512", "fc2 512x2048+res"};
             printf("    kind %-18s %.3f us/launch\n", kn[kind], usk);
             CK(hipGraphExecDestroy(exk));
         }
         // stamps: one replay of the stamped graph after a warm replay
-        CK(hipMemset(B.stamps, 0, (size_t) 36 * NSTAMP_WAVES * 3 * 8));
+        CK(hipMemset(B.stamps, 0, (size_t) NL * NSTAMP_WAVES * 3 * 8));
         hipGraphExec_t ext = capture(s, [&]() { enqueue_step(v, s, ly, B, true, nullptr, 0); });
         for (int i = 0; i < 5; ++i) CK(hipGraphLaunch(ext, s));
         CK(hipStreamSynchronize(s));
-        std::vector<unsigned long long> st((size_t) 36 * NSTAMP_WAVES * 3);
+        std::vector<unsigned long long> st((size_t) NL * NSTAMP_WAVES * 3);
         CK(hipMemcpy(st.data(), B.stamps, st.size() * 8, hipMemcpyDeviceToHost));
         double body = 0, gap = 0, tox = 0, firstlast = 0; unsigned long long prev_end = 0; int ngap = 0;
-        for (int li = 0; li < 36; ++li) {
+        for (int li = 0; li < NL; ++li) {
             unsigned long long mn = ~0ull, mx = 0, mnx = ~0ull, mxs = 0;
             for (int w = 0; w < NSTAMP_WAVES; ++w) {
                 const unsigned long long * p = &st[((size_t) li * NSTAMP_WAVES + w) * 3];
@@ -361,7 +369,7 @@ int main(int argc, char ** argv) {
         }
         const double tick_us = 1000.0 / (double) wall_khz;
         printf("    stamps: body (first wave start -> last wave end) %.3f us avg ; start -> x arrived %.3f ; first -> last wave start %.3f ; boundary (end -> next start) %.3f us avg\n",
-               body / 36 * tick_us, tox / 36 * tick_us, firstlast / 36 * tick_us, ngap ? gap / ngap * tick_us : 0.0);
+               body / NL * tick_us, tox / NL * tick_us, firstlast / NL * tick_us, ngap ? gap / ngap * tick_us : 0.0);
         CK(hipGraphExecDestroy(ex)); CK(hipGraphExecDestroy(exs)); CK(hipGraphExecDestroy(exw)); CK(hipGraphExecDestroy(ext));
     }
 

@@ -40,8 +40,9 @@ for chained in (1, 0):
         key = nm.split(".")[0] if "." in nm and nm.split(".")[0] in names_layer else nm
         a = agg.setdefault(key, [0.0, 0.0, 0.0, 0, 0.0, 0.0])
         a[0] += e1 - s0; a[1] += gap; a[2] += s1 - s0; a[3] += 1
-        if m1 >= 0: a[4] += m1 - s0
-        if m2 >= 0: a[5] += m2 - s0
+        if m1 == -2.0: a[5] += m2                      # effective shader clock in MHz (k_xattn_fused)
+        elif m1 >= 0: a[4] += m1 - s0
+        if m1 >= 0 and m2 >= 0: a[5] += m2 - s0
         if os.environ.get("VERBOSE"):
             print(f"  {nm:10s} start {s0:8.2f}  body {e1 - s0:5.2f}  wave-start spread {s1 - s0:5.2f}  gap before {gap:5.2f}  waves {cnt}")
         prev_end = e1
