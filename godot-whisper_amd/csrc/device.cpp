@@ -595,10 +595,21 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = fa
         if (M & 64) gv(k::EPI_F32_BIAS_RESID, nullptr, nullptr, d.dh, 4 * S, S, l.w_fc2, l.b_fc2, d.dx, S, d.dx, nullptr, nullptr, 0.f, nullptr);
     }
     chk("layers", Lt);
-    if (M & 128) gv(k::EPI_LOGITS, w.d_ln_g, w.d_ln_b, nullptr, S, NV, w.d_te, nullptr, d.logits, NV, nullptr, nullptr, nullptr, 0.f, nullptr); chk("logits", Lt);
+    // vocabulary projection; when the whole step runs, the logit filters' statistics pass rides in its epilogue (one partial per
+    // workgroup into filter_scratch) and filter_argmax only picks
+    int fused_parts = 0;
+    {
+        k::GemvArgs g{};
+        g.x32 = d.dx; g.ln_g = w.d_ln_g; g.ln_b = w.d_ln_b; g.eps = hp.eps; g.n = 1; g.K = S; g.N = NV; g.W = w.d_te;
+        g.epi = k::EPI_LOGITS; g.C = d.logits; g.ldc = NV; g.ldr = S; g.ldaux = S; g.ldaux2 = S; g.S = S;
+        if ((M & 128) && (M & 256)) { g.fs_ban = d.ban_dev; g.fs_step = stp; g.fs_part = (k::FsPartial *) d.filter_scratch; fused_parts = k::gemv_fused_parts(g); }
+        if (!fused_parts) { g.fs_ban = nullptr; g.fs_step = nullptr; g.fs_part = nullptr; }
+        if (M & 128) k::gemv(g, s);
+        chk("logits", Lt);
+    }
     // the pick also prepares the next step on the device (token = pick, position / cache head + 1, x = te[pick] + pe[pos + 1])
     const k::ChainNext cn{ (k::DecStep *) d.step_dev, w.d_te, w.d_pe, d.dx, S, hp.n_text_ctx };
-    if (M & 256) k::filter_argmax(d.logits, d.ban_dev, stp, (k::SampleOut *) d.sample_dev, d.filter_scratch, s, (k::SampleOut *) d.sample_host, 1, &cn); chk("filter", Lt);
+    if (M & 256) k::filter_argmax(d.logits, d.ban_dev, stp, (k::SampleOut *) d.sample_dev, d.filter_scratch, s, (k::SampleOut *) d.sample_host, 1, &cn, fused_parts); chk("filter", Lt);
 }
 
 bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const StepFilter & f, whisper_token_data & out) {

@@ -464,6 +464,9 @@ __global__ __launch_bounds__(256) void k_xattn_qscores(const float * __restrict_
     acc[0] += WMI_SHX(acc[0], 1);
     if ((lane & 3) == 0) qs[wave * 16 + ((lane >> 2) & 15)] = round_f16((acc[0] + bias) * qscale);
     __syncthreads();
+#if defined(WMI_XA_STAMPS)
+    const unsigned long long xa1 = sp.base ? wall_clock64() : 0ull;
+#endif
 
     float qo[8];
 #pragma unroll
@@ -774,6 +777,9 @@ __global__ __launch_bounds__(256) void k_xattn_fused(const float * __restrict__ 
     if (lane == 0) red[wave] = lmax;
     __syncthreads();
     const float m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+#if defined(WMI_XA_STAMPS)
+    const unsigned long long xa2 = sp.base ? wall_clock64() : 0ull;
+#endif
     float acc[8], lsum = 0.0f;
 #pragma unroll
     for (int d = 0; d < 8; ++d) acc[d] = 0.0f;
@@ -804,7 +810,12 @@ __global__ __launch_bounds__(256) void k_xattn_fused(const float * __restrict__ 
     __syncthreads();
     if (tid < 64) part_o[(row * ns + slice) * 64 + tid] = (ored[0][tid] + ored[1][tid]) + (ored[2][tid] + ored[3][tid]);
     if (tid == 0) { part_l[row * ns + slice] = (lred[0] + lred[1]) + (lred[2] + lred[3]); pmax[row * ns + slice] = m; }
-    stamp_end(sp.base, sp.slot, (((int) blockIdx.z * (int) gridDim.y + (int) blockIdx.y) * (int) gridDim.x + (int) blockIdx.x) * 4 + wave, ts0, tc0 | (1ull << 63), sp.base ? clock64() : 0ull);      // bit 63: a shader-clock pair, not mid points
+    stamp_end(sp.base, sp.slot, (((int) blockIdx.z * (int) gridDim.y + (int) blockIdx.y) * (int) gridDim.x + (int) blockIdx.x) * 4 + wave, ts0,
+#if defined(WMI_XA_STAMPS)
+              xa1, xa2);
+#else
+              tc0 | (1ull << 63), sp.base ? clock64() : 0ull);      // bit 63: a shader-clock pair, not mid points
+#endif
 }
 
 // weight of slice s2 when partials are relative to their own slice maximum (part_m != null), else 1

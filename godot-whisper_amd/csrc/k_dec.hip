@@ -17,12 +17,16 @@
 #include <type_traits>
 
 #include <cstdlib>
+#include <algorithm>
 
 namespace wmi { namespace k {
 
 namespace {
 
 __device__ __forceinline__ float round_f16(float x) { return __half2float(f2h(x)); }
+// floats of the score region behind the f16 rows in the LDS of the projection kernels with a self-attention prologue: [H][cap] for the
+// long-cache routine, and at least the wavefront-private scratch of self_attn_wave (4 wavefronts x 64 x 5 floats)
+__host__ __device__ __forceinline__ size_t sa_score_floats(int K, int cap) { const size_t n = (size_t) (K / 64) * cap; return n < 1280 ? 1280 : n; }
 __device__ __forceinline__ float gelu16(float x) {
     const float xh = round_f16(x);
     const float g  = 0.5f * xh * (1.0f + tanhf(0.79788456080286535587989211986876f * xh * (1.0f + 0.044715f * xh * xh)));
@@ -87,11 +91,185 @@ __device__ __forceinline__ float comb_weight(const float * comb_m, size_t idx, f
 // after_loads(): called once every load of the routine is issued (the caller's colder loads go there: vmcnt retires in order, so
 // whatever is requested BEFORE the keys delays the attention by its own latency — the out projection's weight rows come from
 // HBM / Infinity Cache, q / K / V of a step from L2).
+//
+// Instruction count is what this routine costs (one wavefront per SIMD, every VALU instruction ~4 cycles on the critical path of a
+// launch whose operands are all in L2): round 2's form kept every (head, pass) score on all 8 octet lanes of a key — 8 butterflies of
+// 3 steps, 8 libm expf and 8 x 3 x 3 exchange steps for P.V per head pair, ~1000 instructions, 3.5 us.  Here the octet butterflies
+// and the key-group butterflies are HALVING exchanges (at each step a lane keeps half of its values and receives the partner's
+// partial for those — the same pairs in the same order, bit-identical sums, 7 exchanges instead of 24), after which a lane owns ONE
+// (head, pass) score of its key group: one exponential per lane instead of eight, the soft-max statistics as masked 64-lane
+// reductions, and the probabilities go back to the (key group, octet) layout of P.V through 256 R bytes of wavefront-private LDS
+// (no barrier: one wavefront).  P.V's reduction over the key groups is a halving exchange too (v_permlane16/32_swap: swap + add),
+// leaving each lane one output column.
 struct NoAfterLoads { __device__ __forceinline__ void operator()() const {} };
+#if defined(WMI_SA_STAMPS)
+__shared__ unsigned long long wmi_dbg_t[8];
+#endif
+
+// halving exchange over lane bit M of n values (n even): v[j] <- (bit ? v[j + n/2] : v[j]) + partner's partial of the same
+template <int M, int N>
+__device__ __forceinline__ void halve_sum(float (&v)[N], int n, int lane) {
+    const bool hi = lane & M;
+#pragma unroll
+    for (int j = 0; j < N / 2; ++j) {
+        if (j < n / 2) {
+            const float a = v[j], b = v[j + n / 2];
+            if constexpr (M == 16) {
+                const auto sw = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+                v[j] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            } else if constexpr (M == 32) {
+                const auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+                v[j] = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+            } else {
+                const float keep = hi ? b : a, send = hi ? a : b;
+                v[j] = keep + xor_lane<M>(send);
+            }
+        }
+    }
+}
+
+template <int NU, int NP>
+__device__ __forceinline__ void self_attn_body(const uint4 (&qv)[NU], const uint4 (&kv)[NU][8], const uint4 (&vv)[NU][8], int n_kv,
+                                               const int (&hs)[NU], int H, int lane, __half * out, float * out32, float * wscr) {
+    constexpr int NV = NU * NP, NV8 = (NV + 7) & ~7, R = NV8 / 8;
+    const int g = lane >> 3, o = lane & 7;
+    // ---- scores: value i = u * NP + t is q[u] . K[u][8 t + g] over this lane's octet
+    float d[NV8];
+#pragma unroll
+    for (int i = 0; i < NV8; ++i) {
+        d[i] = 0.0f;
+        if (i < NV) {
+            const int u = i / NP, t = i % NP;
+            const __half2 * qh = (const __half2 *) &qv[u];
+            const __half2 * kh = (const __half2 *) &kv[u][t];
+            float dot = 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float2 q2 = __half22float2(qh[e]), k2 = __half22float2(kh[e]);
+                dot = fmaf(k2.x, q2.x, dot);
+                dot = fmaf(k2.y, q2.y, dot);
+            }
+            d[i] = dot;
+        }
+    }
+    halve_sum<1, NV8>(d, NV8, lane); halve_sum<2, NV8>(d, NV8 / 2, lane); halve_sum<4, NV8>(d, NV8 / 4, lane);
+#if defined(WMI_SA_STAMPS)
+    if (threadIdx.x == 0) wmi_dbg_t[WMI_SA_STAMPS] = wall_clock64();
+#endif
+    // slot r of this lane now holds value i = r + R * code(o) for key group g, summed over the 8 octets in the order 1, 2, 4
+    const int code = ((o >> 2) & 1) + 2 * ((o >> 1) & 1) + 4 * (o & 1);
+    int ui[R]; bool ok[R]; float sc[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const int i = r + R * code, t = i % NP;
+        ui[r] = i / NP;
+        ok[r] = i < NV && 8 * t + g < n_kv;
+        sc[r] = ok[r] ? d[r] : -INFINITY;
+    }
+    // ---- soft-max per head: maximum, e = f16(exp(f16(s - m))), l = sum e, P = f16(e / l)   (SURVEY App. B rules 4, 5)
+    // A head's values sit on the lanes whose high code bits equal its number whenever R divides NP: then ONE butterfly that skips
+    // those octet bits reduces every head at once.  The skipped steps of the general (masked, per head) form only ever add 0 /
+    // compare with -inf, so both forms give the same bits — callers with different NU stay bit-identical to each other.
+    float mr[R], lr[R], er[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) { mr[r] = 0.0f; lr[r] = 1.0f; }
+    constexpr bool FAST = (NP % R) == 0 && NV8 * NP >= 8 * R;      // q = NP / R values of code per head, q in {1, 2, 4, 8}
+    constexpr int QH = FAST ? NP / R : 8;
+    auto reduce_heads = [&](float x, auto op) {
+        // lanes of one head differ in g (xor 8, 16, 32) and in the code bits below QH: code bit weight 1 <-> xor 4, 2 <-> xor 2, 4 <-> xor 1
+        x = op(x, xor_lane<32>(x)); x = op(x, xor_lane<16>(x)); x = op(x, xor_lane<8>(x));
+        if constexpr (QH > 1) x = op(x, xor_lane<4>(x));
+        if constexpr (QH > 2) x = op(x, xor_lane<2>(x));
+        if constexpr (QH > 4) x = op(x, xor_lane<1>(x));
+        return x;
+    };
+    if constexpr (FAST) {
+        float x = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < R; ++r) x = fmaxf(x, sc[r]);
+        x = reduce_heads(x, [](float a, float b) { return fmaxf(a, b); });
+#pragma unroll
+        for (int r = 0; r < R; ++r) mr[r] = x;
+    } else {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            float x = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < R; ++r) x = fmaxf(x, ui[r] == u ? sc[r] : -INFINITY);
+            x = wave_max_desc(x);
+#pragma unroll
+            for (int r = 0; r < R; ++r) if (ui[r] == u) mr[r] = x;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r) er[r] = ok[r] ? round_f16(expf(round_f16(sc[r] - mr[r]))) : 0.0f;
+    if constexpr (FAST) {
+        float x = 0.0f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) x += er[r];
+        x = reduce_heads(x, [](float a, float b) { return a + b; });
+#pragma unroll
+        for (int r = 0; r < R; ++r) lr[r] = x;
+    } else {
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            float x = 0.0f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) x += ui[r] == u ? er[r] : 0.0f;
+            x = wave_sum_desc(x);
+#pragma unroll
+            for (int r = 0; r < R; ++r) if (ui[r] == u) lr[r] = x;
+        }
+    }
+#if defined(WMI_SA_STAMPS)
+    if (threadIdx.x == 0) wmi_dbg_t[WMI_SA_STAMPS + 1] = wall_clock64();
+#endif
+    // ---- probabilities back to the (key group, octet) layout: wscr[g][i], every lane of group g reads the group's NV8 values
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        const float pr = ok[r] ? round_f16(er[r] * (float) (1.0 / (double) lr[r])) : 0.0f;
+        wscr[g * NV8 + r + R * code] = pr;
+    }
+    float pv[NV8];
+#pragma unroll
+    for (int i4 = 0; i4 < NV8; i4 += 4) {
+        const float4 f = *(const float4 *) (wscr + g * NV8 + i4);
+        pv[i4] = f.x; pv[i4 + 1] = f.y; pv[i4 + 2] = f.z; pv[i4 + 3] = f.w;
+    }
+    // ---- P.V: lane (g, o) accumulates the 8 columns of its octet over its keys 8 t + g in pass order, the key groups are summed by
+    // halving exchanges in the order 8, 16, 32 (the old butterflies' pairs); the lane ends with column e = 4 b3 + 2 b4 + b5
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NP; ++t) {
+            if (8 * t + g < n_kv) {                          // (rows past n_kv hold whatever the cache held: never multiplied)
+                const __half2 * vh = (const __half2 *) &vv[u][t];
+                const float w = pv[u * NP + t];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float2 f = __half22float2(vh[e]);
+                    acc[2 * e]     = fmaf(w, f.x, acc[2 * e]);
+                    acc[2 * e + 1] = fmaf(w, f.y, acc[2 * e + 1]);
+                }
+            }
+        }
+        halve_sum<8, 8>(acc, 8, lane); halve_sum<16, 8>(acc, 4, lane); halve_sum<32, 8>(acc, 2, lane);
+        const int col = o * 8 + 4 * ((lane >> 3) & 1) + 2 * ((lane >> 4) & 1) + ((lane >> 5) & 1);
+        if (hs[u] < H) {
+            if (out32) out32[hs[u] * 64 + col] = acc[0];      // block-quantised out-projection: the f32 result is quantised as is
+            else       out[hs[u] * 64 + col] = f2h(acc[0]);
+        }
+    }
+}
+
+// wscr: 64 * ceil(NU * NP / 8) floats of LDS private to this wavefront (NP = 8 passes when n_kv > 32)
 template <int NU, typename AfterLoads = NoAfterLoads>
 __device__ __forceinline__ bool self_attn_wave(const __half * __restrict__ sq, const __half * __restrict__ sk,
                                                const __half * __restrict__ sv, const int32_t * __restrict__ n_kv_p, int K, int cap,
-                                               const int (&hs)[NU], int H, int lane, __half * out, float * out32 = nullptr,
+                                               const int (&hs)[NU], int H, int lane, __half * out, float * out32, float * wscr,
                                                AfterLoads after_loads = AfterLoads()) {
     const int g = lane >> 3, o = lane & 7;
     int hh[NU];
@@ -132,81 +310,9 @@ __device__ __forceinline__ bool self_attn_wave(const __half * __restrict__ sq, c
                 kv[u][t] = *(const uint4 *) (sk + (size_t) jc * K + hh[u] * 64 + o * 8);
                 vv[u][t] = *(const uint4 *) (sv + (size_t) jc * K + hh[u] * 64 + o * 8);
             }
-    }
-    const int n_pass = n_kv > 32 ? 8 : 4;
-
-    float p[NU][8];
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        float qf[8];
-        {
-            const __half2 * qh = (const __half2 *) &qv[u];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const float2 f = __half22float2(qh[e]); qf[2 * e] = f.x; qf[2 * e + 1] = f.y; }
-        }
-        float m = -INFINITY;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            p[u][t] = -INFINITY;
-            if (t < n_pass) {
-                const __half2 * kh = (const __half2 *) &kv[u][t];
-                float dot = 0.0f;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float2 f = __half22float2(kh[e]);
-                    dot = fmaf(f.x, qf[2 * e], dot);
-                    dot = fmaf(f.y, qf[2 * e + 1], dot);
-                }
-                dot += WMI_SHX(dot, 1); dot += WMI_SHX(dot, 2); dot += WMI_SHX(dot, 4);
-                if (8 * t + g < n_kv) { p[u][t] = dot; m = fmaxf(m, dot); }
-            }
-        }
-        m = fmaxf(m, WMI_SHX(m, 8)); m = fmaxf(m, WMI_SHX(m, 16)); m = fmaxf(m, WMI_SHX(m, 32));
-        float l = 0.0f;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            const float e = (t < n_pass && 8 * t + g < n_kv) ? round_f16(expf(round_f16(p[u][t] - m))) : 0.0f;
-            p[u][t] = e; l += e;
-        }
-        l += WMI_SHX(l, 8); l += WMI_SHX(l, 16); l += WMI_SHX(l, 32);
-        const float inv = (float) (1.0 / (double) l);
-#pragma unroll
-        for (int t = 0; t < 8; ++t) p[u][t] = round_f16(p[u][t] * inv);
-    }
-
-    // P.V in the same lane layout: lane (g, o) accumulates the 8 columns of octet o over its keys 8 t + g (pass order), then the
-    // key groups are summed with the butterfly xor 8, 16, 32; lanes of group 0 store the octet.  No broadcast chain, no transpose.
-#pragma unroll
-    for (int u = 0; u < NU; ++u) {
-        float acc[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) acc[e] = 0.0f;
-#pragma unroll
-        for (int t = 0; t < 8; ++t) {
-            if (t < n_pass && 8 * t + g < n_kv) {
-                const __half2 * vh = (const __half2 *) &vv[u][t];
-                const float w = p[u][t];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const float2 f = __half22float2(vh[e]);
-                    acc[2 * e]     = fmaf(w, f.x, acc[2 * e]);
-                    acc[2 * e + 1] = fmaf(w, f.y, acc[2 * e + 1]);
-                }
-            }
-        }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { float v = acc[e]; v += WMI_SHX(v, 8); v += WMI_SHX(v, 16); v += WMI_SHX(v, 32); acc[e] = v; }
-        if (g == 0 && hs[u] < H) {
-            if (out32) {                                  // block-quantised out-projection: the f32 result is quantised as is
-                *(float4 *) (out32 + hs[u] * 64 + o * 8)     = make_float4(acc[0], acc[1], acc[2], acc[3]);
-                *(float4 *) (out32 + hs[u] * 64 + o * 8 + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
-            } else {
-            __half2 h4[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) h4[e] = __halves2half2(f2h(acc[2 * e]), f2h(acc[2 * e + 1]));
-            *(uint4 *) (out + hs[u] * 64 + o * 8) = *(const uint4 *) h4;
-            }
-        }
+        self_attn_body<NU, 8>(qv, kv, vv, n_kv, hs, H, lane, out, out32, wscr);
+    } else {
+        self_attn_body<NU, 4>(qv, kv, vv, n_kv, hs, H, lane, out, out32, wscr);
     }
     return true;
 }
@@ -286,7 +392,7 @@ __global__ __launch_bounds__(64) void k_self_attn_rows(const __half * __restrict
     {   // n_kv <= 64 (the decode loop): the wave-level routine shared with the one-row prologue
         const int hs[1] = { h };
         if (self_attn_wave<1>(q + (size_t) r * K, sk, sv, n_kv_p + r * step_stride, K, cap, hs, K / 64, lane, out + (size_t) r * K,
-                              out32 ? out32 + (size_t) r * K : nullptr)) return;
+                              out32 ? out32 + (size_t) r * K : nullptr, row)) return;       // (row: >= 64 floats, free until the long form)
     }
     const int n_kv = n_kv_p[r * step_stride];
     qf[lane] = __half2float(q[(size_t) r * K + h * 64 + lane]);
@@ -585,7 +691,7 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
         // k_self_attn_rows launch below: R rows recomputed by every workgroup would cost more than the launch.)
         const int H = K / 64;
         float * sc = (float *) (smem + (((size_t) R * K * sizeof(__half) + 15) & ~(size_t) 15));   // [H][sa_cap]
-        float * qf = sc + (size_t) H * a.sa_cap;                                                   // [K]
+        float * qf = sc + sa_score_floats(K, a.sa_cap);                                            // [K]
 #pragma unroll 1
         for (int r = 0; r < R; ++r) {
             const __half * rq = a.sa_q + (size_t) r * K, * rk = a.sa_k + (int64_t) r * a.cache_row_stride, * rv = a.sa_v + (int64_t) r * a.cache_row_stride;
@@ -593,7 +699,7 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
             bool done = true;                               // n_kv <= 64: the wave-level routine of the one-row kernel (bit-identical)
             for (int h0 = tid >> 6; h0 < H; h0 += 8) {
                 const int hs[2] = { h0, h0 + 4 };
-                done = self_attn_wave<2>(rq, rk, rv, rn, K, a.sa_cap, hs, H, tid & 63, act + (size_t) r * K) && done;
+                done = self_attn_wave<2>(rq, rk, rv, rn, K, a.sa_cap, hs, H, tid & 63, act + (size_t) r * K, nullptr, sc + (tid >> 6) * 128) && done;
             }
             if ((tid >> 6) >= H) done = rn[0] <= 64;
             if (!done) {
@@ -737,8 +843,8 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
 // compile time: the decode step's six hot combinations get kernels without the other kinds' code and without the dispatch on
 // kernel arguments (a launch on the step's critical path pays for every instruction and scalar load in front of its first
 // memory request); -1 keeps the run-time dispatch.
-template <int RIF, int NCH, bool NT, int PRO = -1, int EPI = -1, int HPW = 0>
-__global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
+template <int RIF, int NCH, bool NT, int PRO = -1, int EPI = -1, int HPW = 0, int WPB = 4, bool FS = false>
+__global__ __launch_bounds__(64 * WPB) void k_gemv1(const GemvArgs a) {
     const bool pro_ln = PRO < 0 ? a.ln_g != nullptr : PRO == 1;
     const bool pro_sa = PRO < 0 ? a.sa_q != nullptr : PRO == 2;
     const bool pro_comb = PRO < 0 ? a.comb_o != nullptr : PRO == 3;
@@ -760,8 +866,8 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
             }
         }
     }
-    const int nwaves = nblk * 4;
-    const int gw = blockIdx.x * 4 + wave;
+    const int nwaves = nblk * WPB;                          // WPB wavefronts per workgroup (1: plain rows only — no LDS, no barrier)
+    const int gw = blockIdx.x * WPB + wave;
 
     // Load order.  vmcnt retires in order: a wavefront cannot look at a value before everything requested ahead of it has arrived.
     // The weight rows are the coldest thing this kernel reads (HBM / Infinity Cache, ~1.2 us); the activation row, q / K / V of
@@ -778,6 +884,10 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
     const int wrow = lane / LPR;                            // row this lane would write
     const bool writer = (lane % LPR) == 0;
     float bias_pre = 0.0f, resid_pre = 0.0f; int ro_pre = 0;
+    // fused filter statistics (FS): online soft-max partial of the rows this lane writes
+    int4 fs_s1 = make_int4(0, 0, 0, 0), fs_s2 = fs_s1; float fs_temp = 0.0f; unsigned char ban_cur = 0, ban_nxt = 0;
+    float fs_sum = 0.0f, fs_sum_ts = 0.0f;
+    FsMaxIdx fs_all = {-INFINITY, 0x7fffffff}, fs_txt = fs_all, fs_ts = fs_all;
     int zl = 0; asm volatile("" : "+v"(zl));                // a zero the compiler cannot fold (see self_attn_wave: n_kv)
     bool w_issued = false;
     auto issue_weights = [&]() {
@@ -802,6 +912,11 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
             // raw values: "absent" is resolved at the use in the epilogue (a select here is a use, i.e. a wait for the weights);
             // ro_pre stays a VGPR until then — as a uniform load it became load -> vmcnt(0) -> readfirstlane on the spot
             bias_pre = *bp; resid_pre = *rp; ro_pre = op[zl];
+            if constexpr (FS) {                                  // the row's step record (VGPR copies, see ro_pre) and the first tile's ban bytes
+                const int32_t * sp = (const int32_t *) a.fs_step;
+                fs_s1 = *(const int4 *) (sp + 4 + zl); fs_s2 = *(const int4 *) (sp + 8 + zl); fs_temp = __int_as_float(sp[12 + zl]);
+                ban_cur = a.fs_ban[n];
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -835,7 +950,7 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
         if (pro_sa) {
             const int H = K / 64;
             float * sc = (float *) (smem + (((size_t) K * sizeof(__half) + 15) & ~(size_t) 15));   // [H][sa_cap]
-            float * qf = sc + (size_t) H * a.sa_cap;                                             // [K]
+            float * qf = sc + sa_score_floats(K, a.sa_cap);                                      // [K]
             // the decode loop's case (n_kv <= 64): per wavefront, barrier-free — heads wave, wave + 4 (and wave + 8, wave + 12, ...)
             // all heads of a wavefront in ONE call (ceil(H / 4) of them: 2 for base, 3 small, 4 medium, 5 large): a second call
             // would be a second round trip of loads (small, H = 12: 9.6 -> 6.5 us per launch)
@@ -852,12 +967,12 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
                     int hs[HPW];
 #pragma unroll
                     for (int u = 0; u < HPW; ++u) hs[u] = wave + 4 * u;
-                    done = self_attn_wave<HPW>(a.sa_q, a.sa_k, a.sa_v, a.sa_nkv, K, a.sa_cap, hs, H, lane, act, nullptr, al);
+                    done = self_attn_wave<HPW>(a.sa_q, a.sa_k, a.sa_v, a.sa_nkv, K, a.sa_cap, hs, H, lane, act, nullptr, sc + wave * 64 * HPW, al);
                 }
             } else {
                 for (int h0 = wave; h0 < H; h0 += 8) {
                     const int hs[2] = { h0, h0 + 4 };
-                    done = self_attn_wave<2>(a.sa_q, a.sa_k, a.sa_v, a.sa_nkv, K, a.sa_cap, hs, H, lane, act, nullptr, al) && done;
+                    done = self_attn_wave<2>(a.sa_q, a.sa_k, a.sa_v, a.sa_nkv, K, a.sa_cap, hs, H, lane, act, nullptr, sc + wave * 128, al) && done;
                 }
             }
             issue_weights();                                 // (a wavefront without a head)
@@ -930,7 +1045,7 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
         }
     }
 
-    const unsigned long long tm1 = stamp_t0(a.stamps);     // activation row ready (LayerNorm / attention prologue done)
+    unsigned long long tm1 = stamp_t0(a.stamps);     // activation row ready (LayerNorm / attention prologue done)
     unsigned long long tm2 = 0;
     bool first = have_pre;
     for (int o0 = gw * RIF; o0 < a.N; o0 += nwaves * RIF) {
@@ -952,6 +1067,7 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
                         wpre[t][u] = ldw<NT>(a.W + (size_t) o * K + cc);
                     }
                 }
+                if constexpr (FS) { int nn = on + wrow; if (nn > a.N - 1) nn = a.N - 1; ban_nxt = a.fs_ban[nn]; }
             }
         }
         float acc[RIF];
@@ -1014,25 +1130,85 @@ __global__ __launch_bounds__(256) void k_gemv1(const GemvArgs a) {
                     case EPI_LOGITS:         ((float *) a.C)[n] = v; break;
                     default: break;
                 }
+                if constexpr (FS) {
+                    // k_filter_stats' predicate and statistics for vocabulary entry n (W/whisper.cpp:4532-4635), folded into an online
+                    // soft-max relative to the running maximum fs_all.v
+                    const int flags = fs_s1.x, space_id = fs_s1.y, eot = fs_s1.z, beg = fs_s1.w, ts_floor_end = fs_s2.y, ts_initial_start = fs_s2.z;
+                    bool al = !ban_cur;
+                    if ((flags & 1) && (n == eot || n == space_id)) al = false;
+                    if (flags & 2) { if (flags & 4) { if (n >= beg) al = false; } else { if (n < eot) al = false; } }
+                    if (n >= ts_initial_start) al = false;
+                    if (n >= beg && n < ts_floor_end) al = false;
+                    if (al) {
+                        const float lv = fs_temp > 0.0f ? v / fs_temp : v;
+                        const float mo = fs_all.v, mn = fmaxf(mo, lv);
+                        // (v_exp_f32: ~1e-6 relative on the terms that carry weight; two libm expf per row cost the projection 2.6 us)
+                        const float s1 = mo > -INFINITY ? __expf(mo - mn) : 0.0f, e = __expf(lv - mn);
+                        fs_sum = fs_sum * s1 + e; fs_sum_ts = fs_sum_ts * s1 + (n >= beg ? e : 0.0f);
+                        const FsMaxIdx c = {lv, n};
+                        if (c.v > fs_all.v || (c.v == fs_all.v && c.i < fs_all.i)) fs_all = c;
+                        if (n < beg) { if (c.v > fs_txt.v || (c.v == fs_txt.v && c.i < fs_txt.i)) fs_txt = c; }
+                        else         { if (c.v > fs_ts.v  || (c.v == fs_ts.v  && c.i < fs_ts.i))  fs_ts = c; }
+                    }
+                }
             }
         }
+        if constexpr (FS) ban_cur = ban_nxt;
     }
+    if constexpr (FS) {
+        // the wavefront's writer lanes (lane % LPR == 0), then the workgroup's wavefronts, merged pairwise: maxima by value then
+        // index, sums rescaled to the pair's maximum; one FsPartial per workgroup
+        auto merge = [](FsMaxIdx & all, FsMaxIdx & txt, FsMaxIdx & ts, float & sum, float & sum_ts,
+                        FsMaxIdx oall, FsMaxIdx otxt, FsMaxIdx ots, float osum, float osum_ts) {
+            const float mn = fmaxf(all.v, oall.v);
+            const float sa = all.v > -INFINITY ? __expf(all.v - mn) : 0.0f, sb = oall.v > -INFINITY ? __expf(oall.v - mn) : 0.0f;
+            sum = sum * sa + osum * sb; sum_ts = sum_ts * sa + osum_ts * sb;
+            auto bt = [](FsMaxIdx x, FsMaxIdx y) { return (y.v > x.v || (y.v == x.v && y.i < x.i)) ? y : x; };
+            all = bt(all, oall); txt = bt(txt, otxt); ts = bt(ts, ots);
+        };
+        if (!writer) { fs_all = FsMaxIdx{-INFINITY, 0x7fffffff}; fs_txt = fs_all; fs_ts = fs_all; fs_sum = 0.0f; fs_sum_ts = 0.0f; }
+#pragma unroll
+        for (int m = LPR; m < 64; m <<= 1) {
+            FsMaxIdx oa, ot, oz;
+            oa.v = WMI_SHX(fs_all.v, m); oa.i = WMI_SHX(fs_all.i, m); ot.v = WMI_SHX(fs_txt.v, m); ot.i = WMI_SHX(fs_txt.i, m);
+            oz.v = WMI_SHX(fs_ts.v, m);  oz.i = WMI_SHX(fs_ts.i, m);
+            const float os = WMI_SHX(fs_sum, m), ost = WMI_SHX(fs_sum_ts, m);
+            merge(fs_all, fs_txt, fs_ts, fs_sum, fs_sum_ts, oa, ot, oz, os, ost);
+        }
+        __shared__ FsPartial fs_w[WPB];
+        if (lane == 0) { FsPartial pw; pw.all = fs_all; pw.txt = fs_txt; pw.ts = fs_ts; pw.sum = fs_sum; pw.sum_ts = fs_sum_ts; pw.pad[0] = pw.pad[1] = 0.0f; fs_w[wave] = pw; }
+        __syncthreads();
+        if (tid == 0) {
+            FsPartial pw = fs_w[0];
+#pragma unroll
+            for (int w2 = 1; w2 < WPB; ++w2) merge(pw.all, pw.txt, pw.ts, pw.sum, pw.sum_ts, fs_w[w2].all, fs_w[w2].txt, fs_w[w2].ts, fs_w[w2].sum, fs_w[w2].sum_ts);
+            a.fs_part[blockIdx.x] = pw;
+        }
+    }
+#if defined(WMI_SA_STAMPS)
+    if (pro_sa && a.stamps) { tm1 = wmi_dbg_t[WMI_SA_STAMPS]; tm2 = wmi_dbg_t[WMI_SA_STAMPS + 1]; }
+#endif
     stamp_end(a.stamps, a.stamp_slot, gw, ts0, tm1, tm2);
 }
 
-template <int RIF, int NCH, bool NT = false, int PRO = -1, int EPI = -1, int HPW = 0>
+template <int RIF, int NCH, bool NT = false, int PRO = -1, int EPI = -1, int HPW = 0, int WPB = 4, bool FS = false>
 void launch_gemv1(const GemvArgs & a, hipStream_t st, int max_blocks = 512) {
+    static_assert(WPB == 4 || PRO == 0, "one-wavefront workgroups: plain f16 rows only");
     size_t smem = 0;
-    if (a.sa_q)        smem = ((((size_t) a.K * sizeof(__half)) + 15) & ~(size_t) 15) + ((size_t) (a.K / 64) * a.sa_cap + a.K) * sizeof(float);
+    if (a.sa_q)        smem = ((((size_t) a.K * sizeof(__half)) + 15) & ~(size_t) 15) + (sa_score_floats(a.K, a.sa_cap) + a.K) * sizeof(float);
     else if (a.comb_o) smem = (size_t) a.K * sizeof(__half);
-    int blocks = (a.N + 4 * RIF - 1) / (4 * RIF);
+    int blocks = (a.N + WPB * RIF - 1) / (WPB * RIF);
     if (blocks > max_blocks) blocks = max_blocks;
     static std::atomic<uint64_t> lds_ok{0};
-    if (smem > 48 * 1024) allow_full_lds((const void *) k_gemv1<RIF, NCH, NT, PRO, EPI, HPW>, lds_ok);
+    if (smem > 48 * 1024) allow_full_lds((const void *) k_gemv1<RIF, NCH, NT, PRO, EPI, HPW, WPB, FS>, lds_ok);
     if (PRO <= 0 && (EPI < 0 || EPI == EPI_F32_BIAS_RESID) && a.step_copy_src) blocks += 1;       // the step-record mirror (see the kernel)
-    hipLaunchKernelGGL((k_gemv1<RIF, NCH, NT, PRO, EPI, HPW>), dim3(blocks), dim3(256), smem, st, a);
+    hipLaunchKernelGGL((k_gemv1<RIF, NCH, NT, PRO, EPI, HPW, WPB, FS>), dim3(blocks), dim3(64 * WPB), smem, st, a);
 }
 
+static int logits_blocks_cap() {
+    static const int lb = getenv("WMI_LOGITS_BLOCKS") ? std::min(atoi(getenv("WMI_LOGITS_BLOCKS")), FS_MAX_PARTS) : 768;
+    return lb;
+}
 // the decode step's hot (prologue, epilogue) combinations at one row; false = no specialised kernel for these arguments
 static bool launch_gemv1_special(const GemvArgs & a, int nch, hipStream_t st) {
     static const bool off = getenv("WMI_GEMV1_GENERIC") != nullptr;       // debug / A-B
@@ -1041,7 +1217,12 @@ static bool launch_gemv1_special(const GemvArgs & a, int nch, hipStream_t st) {
     if (a.N >= 16384) {                                      // vocabulary projection: its own lean instantiation (the generic kernel carries
         // the attention prologues: 251 VGPRs, 2 workgroups per CU; this one 143).  768 workgroups = 3 per CU: 9.55 us = 5.56 TB/s
         // (512: 10.6, 1024: 10.8, the generic kernel at 512: 11.4)
-        static const int lb = getenv("WMI_LOGITS_BLOCKS") ? atoi(getenv("WMI_LOGITS_BLOCKS")) : 768;
+        const int lb = logits_blocks_cap();
+        if (pro == 1 && a.epi == EPI_LOGITS && a.fs_part) {      // + the logit filters' statistics in the epilogue (greedy step)
+            if (nch == 1) { launch_gemv1<8, 1, false, 1, EPI_LOGITS, 0, 4, true>(a, st, lb); return true; }
+            if (nch == 2) { launch_gemv1<8, 2, false, 1, EPI_LOGITS, 0, 4, true>(a, st, lb); return true; }
+            if (nch == 3) { launch_gemv1<8, 3, false, 1, EPI_LOGITS, 0, 4, true>(a, st, lb); return true; }
+        }
         if (pro == 1 && a.epi == EPI_LOGITS && nch == 1) { launch_gemv1<8, 1, false, 1, EPI_LOGITS>(a, st, lb); return true; }
         return false;
     }
@@ -1064,7 +1245,16 @@ static bool launch_gemv1_special(const GemvArgs & a, int nch, hipStream_t st) {
     }
     if (pro == 0 && a.epi == EPI_F32_BIAS_RESID) {
         if (nch == 3) { launch_gemv1<4, 3, false, 0, EPI_F32_BIAS_RESID>(a, st); return true; }
-        if (nch == 4) { launch_gemv1<4, 4, false, 0, EPI_F32_BIAS_RESID>(a, st); return true; }
+        if (nch == 4) {
+            // mlp.2 of base.en (512 x 2048): 2 MB through 32 four-wavefront workgroups is 64 KB per CU — the CU's own load path is the
+            // limit (~60 GB/s per CU: 1 us from "row ready" to "tile reduced"); one-wavefront workgroups put the same rows on 4x the CUs
+            // (measured body: 256 threads x 4 rows per wavefront 2.93 us, 64 x 4 rows 2.40, 64 x 2 rows 2.22)
+            static const int shape = getenv("WMI_FC2_SHAPE") ? atoi(getenv("WMI_FC2_SHAPE")) : 2;      // A/B knob
+            if (shape == 2) launch_gemv1<2, 4, false, 0, EPI_F32_BIAS_RESID, 0, 1>(a, st, 4096);
+            else if (shape == 1) launch_gemv1<4, 4, false, 0, EPI_F32_BIAS_RESID, 0, 1>(a, st, 4096);
+            else launch_gemv1<4, 4, false, 0, EPI_F32_BIAS_RESID>(a, st);
+            return true;
+        }
         // mlp.2 of the wider models (K = 4 S = 3072 / 4096 / 5120): register budget = activation row + two row tiles of weights
         if (nch == 5 || nch == 6)  { launch_gemv1<4, 6, false, 0, EPI_F32_BIAS_RESID>(a, st); return true; }
         if (nch == 7 || nch == 8)  { launch_gemv1<2, 8, false, 0, EPI_F32_BIAS_RESID>(a, st); return true; }
@@ -1378,7 +1568,7 @@ void launch_rows_mfma(const GemvArgs & a, hipStream_t st) {
 template <int R, int RIF, bool NT = false>
 void launch_gemv_t(const GemvArgs & a, hipStream_t st, int max_blocks = 512) {
     size_t smem = (size_t) R * a.K * sizeof(__half);
-    if (a.sa_q) smem = ((smem + 15) & ~(size_t) 15) + ((size_t) (a.K / 64) * a.sa_cap + a.K) * sizeof(float);
+    if (a.sa_q) smem = ((smem + 15) & ~(size_t) 15) + (sa_score_floats(a.K, a.sa_cap) + a.K) * sizeof(float);
     int blocks = (a.N + 4 * RIF - 1) / (4 * RIF);
     if (blocks > max_blocks) blocks = max_blocks;       // 2 workgroups per CU; longer rows-per-wave loops are software-pipelined
     static std::atomic<uint64_t> lds_ok{0};
@@ -1428,6 +1618,14 @@ void set_rows_valu(bool on) { g_rows_valu = on; }
 bool rows_valu_enabled() { static const bool env = getenv("WMI_ROWS_VALU") != nullptr; return env || g_rows_valu; }
 
 static void gemv_(const GemvArgs & a, hipStream_t st);
+int gemv_fused_parts(const GemvArgs & a) {
+    // mirrors the dispatch below: one row, LayerNorm prologue, EPI_LOGITS, rows of <= 1536 columns, no row gather
+    static const bool off = getenv("WMI_GEMV1_GENERIC") != nullptr || getenv("WMI_GEMV1_OFF") != nullptr || getenv("WMI_GEMV1_MASK") != nullptr ||
+                            getenv("WMI_NO_FUSED_STATS") != nullptr;
+    if (off || !a.fs_part || a.n != 1 || a.lanes || a.rows || !a.ln_g || a.epi != EPI_LOGITS || a.N < 16384 || a.K > 1536 || (a.K % 8) != 0) return 0;
+    const int blocks = (a.N + 31) / 32;
+    return std::min(blocks, logits_blocks_cap());
+}
 void gemv(const GemvArgs & a, hipStream_t st) {
     const Stamp sp = stamp_next();
     if (sp.base) { GemvArgs b = a; b.stamps = sp.base; b.stamp_slot = sp.slot; gemv_(b, st); return; }

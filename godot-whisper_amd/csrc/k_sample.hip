@@ -14,6 +14,7 @@
 // beam search, t > 0 and logit-filter callbacks.
 
 #include "kernels.h"
+#include <algorithm>
 #include "wave_ops.h"
 
 namespace wmi { namespace k {
@@ -23,7 +24,7 @@ namespace {
 constexpr int NB = 64;          // workgroups of the statistics pass
 constexpr int NT = 256;
 
-struct MaxIdx { float v; int i; };
+using MaxIdx = FsMaxIdx;
 __device__ __forceinline__ MaxIdx better(MaxIdx a, MaxIdx b) {      // larger value, then smaller index (first occurrence)
     return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a;
 }
@@ -35,7 +36,7 @@ __device__ __forceinline__ float wave_sum(float v) { for (int o = 32; o > 0; o >
 
 // per-workgroup partial statistics of the filtered logits: maxima with first-index tie-break (all / text /
 // timestamps) and sums of exp(l - local max) — combined exactly (online soft-max identity) by the second kernel
-struct Partial { MaxIdx all, txt, ts; float sum, sum_ts; float pad[2]; };
+using Partial = FsPartial;
 
 __global__ __launch_bounds__(NT) void k_filter_stats(const float * __restrict__ logits, const uint8_t * __restrict__ ban,
                                                      const DecStep * __restrict__ stp, Partial * __restrict__ part, const Stamp sp) {
@@ -108,21 +109,36 @@ __global__ __launch_bounds__(NT) void k_filter_stats(const float * __restrict__ 
     stamp_end(sp.base, sp.slot, ((int) blockIdx.y * (int) gridDim.x + (int) blockIdx.x) * 4 + wave, ts0);
 }
 
-template <int XU>                                          // chunks of 512 columns of the next step's activation row (S <= 512 XU)
-__global__ __launch_bounds__(64) void k_filter_pick(const Partial * __restrict__ part, const DecStep * __restrict__ stp,
+// XU: chunks of 512 columns of the next step's activation row (S <= 512 XU); PPL: partials per lane (1: the 64 of k_filter_stats,
+// 12: up to 768 from the vocabulary projection's fused epilogue — with PPL = 1 the arithmetic is exactly the one-partial form)
+template <int XU, int PPL>
+__global__ __launch_bounds__(64) void k_filter_pick(const Partial * __restrict__ part, int nparts, const DecStep * __restrict__ stp,
                                                     SampleOut * __restrict__ out, SampleOut * __restrict__ out_host, const ChainNext chain, const Stamp sp) {
     const unsigned long long ts0 = stamp_t0(sp.base);
     const int lane = threadIdx.x;
-    part += (size_t) blockIdx.x * NB; stp += blockIdx.x; out += blockIdx.x; if (out_host) out_host += blockIdx.x;
+    part += (size_t) blockIdx.x * nparts; stp += blockIdx.x; out += blockIdx.x; if (out_host) out_host += blockIdx.x;
     // the step record and the partials are requested together (field by field at their first use, the record cost three more
     // dependent round trips on this one-wavefront kernel)
     const int4 st0 = *(const int4 *) stp;                  // token, pos, n_kv, kv_head
     const int beg = stp->beg, seqv = stp->seq;
-    const Partial p = part[lane];                       // NB == 64: one partial per lane
-    const MaxIdx a = wave_max(p.all), t = wave_max(p.txt), z = wave_max(p.ts);
+    Partial pq[PPL];                                     // partials lane, lane + 64, ... (all requested before the first use)
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) { const int idx = lane + 64 * q; pq[q] = part[idx < nparts ? idx : 0]; }
+    MaxIdx la = {-INFINITY, 0x7fffffff}, lt = la, lz = la;
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        if (lane + 64 * q >= nparts) { pq[q].all = MaxIdx{-INFINITY, 0x7fffffff}; pq[q].txt = pq[q].all; pq[q].ts = pq[q].all; pq[q].sum = 0.0f; pq[q].sum_ts = 0.0f; }
+        la = better(la, pq[q].all); lt = better(lt, pq[q].txt); lz = better(lz, pq[q].ts);
+    }
+    const MaxIdx a = wave_max(la), t = wave_max(lt), z = wave_max(lz);
     const float M = a.v;
-    const float w = p.all.v > -INFINITY ? expf(p.all.v - M) : 0.0f;      // rescale the local sums to the global max
-    const float sum = wave_sum(p.sum * w), sum_ts = wave_sum(p.sum_ts * w);
+    float lsum = 0.0f, lsum_ts = 0.0f;
+#pragma unroll
+    for (int q = 0; q < PPL; ++q) {
+        const float w = pq[q].all.v > -INFINITY ? expf(pq[q].all.v - M) : 0.0f;      // rescale the local sums to the global max
+        if (q == 0) { lsum = pq[q].sum * w; lsum_ts = pq[q].sum_ts * w; } else { lsum += pq[q].sum * w; lsum_ts += pq[q].sum_ts * w; }
+    }
+    const float sum = wave_sum(lsum), sum_ts = wave_sum(lsum_ts);
     // every lane evaluates the pick (uniform values): no broadcast between the decision and the next step's gathers
     const float lse = logf(sum) + M;
     // timestamp log-mass vs best text token (W/whisper.cpp:4659-4683)
@@ -296,17 +312,26 @@ void filter_draw(const float * logits, const uint8_t * static_ban, const DecStep
 size_t filter_draw_scratch_bytes(int n_rows) { return filter_scratch_bytes(n_rows) + (size_t) n_rows * NB * sizeof(double); }
 
 void filter_argmax(const float * logits, const uint8_t * static_ban, const DecStep * step, SampleOut * out, void * scratch,
-                   hipStream_t st, SampleOut * out_host, int n_rows, const ChainNext * chain) {
+                   hipStream_t st, SampleOut * out_host, int n_rows, const ChainNext * chain, int fused_parts) {
     Partial * part = (Partial *) scratch;
-    hipLaunchKernelGGL(k_filter_stats, dim3(NB, n_rows), dim3(NT), 0, st, logits, static_ban, step, part, stamp_next());
+    const bool fused = fused_parts > 0 && fused_parts <= FS_MAX_PARTS && n_rows == 1;
+    if (!fused) hipLaunchKernelGGL(k_filter_stats, dim3(NB, n_rows), dim3(NT), 0, st, logits, static_ban, step, part, stamp_next());
     ChainNext cn{};                                         // chaining is a one-row affair (the greedy step of device.cpp)
     if (chain && n_rows == 1) cn = *chain;
     if (cn.step_rw && cn.S > 1536) cn = ChainNext{};          // (no such model: the row registers cover 3 chunks; the host then embeds)
     const int xu = cn.step_rw ? (cn.S + 511) / 512 : 1;
-    if (xu <= 1)      hipLaunchKernelGGL(k_filter_pick<1>, dim3(n_rows), dim3(64), 0, st, part, step, out, out_host, cn, stamp_next());
-    else if (xu == 2) hipLaunchKernelGGL(k_filter_pick<2>, dim3(n_rows), dim3(64), 0, st, part, step, out, out_host, cn, stamp_next());
-    else              hipLaunchKernelGGL(k_filter_pick<3>, dim3(n_rows), dim3(64), 0, st, part, step, out, out_host, cn, stamp_next());
+    const int np = fused ? fused_parts : NB;
+    constexpr int PF = FS_MAX_PARTS / 64;
+    if (fused) {
+        if (xu <= 1)      hipLaunchKernelGGL((k_filter_pick<1, PF>), dim3(1), dim3(64), 0, st, part, np, step, out, out_host, cn, stamp_next());
+        else if (xu == 2) hipLaunchKernelGGL((k_filter_pick<2, PF>), dim3(1), dim3(64), 0, st, part, np, step, out, out_host, cn, stamp_next());
+        else              hipLaunchKernelGGL((k_filter_pick<3, PF>), dim3(1), dim3(64), 0, st, part, np, step, out, out_host, cn, stamp_next());
+        return;
+    }
+    if (xu <= 1)      hipLaunchKernelGGL((k_filter_pick<1, 1>), dim3(n_rows), dim3(64), 0, st, part, np, step, out, out_host, cn, stamp_next());
+    else if (xu == 2) hipLaunchKernelGGL((k_filter_pick<2, 1>), dim3(n_rows), dim3(64), 0, st, part, np, step, out, out_host, cn, stamp_next());
+    else              hipLaunchKernelGGL((k_filter_pick<3, 1>), dim3(n_rows), dim3(64), 0, st, part, np, step, out, out_host, cn, stamp_next());
 }
-size_t filter_scratch_bytes(int n_rows) { return (size_t) n_rows * NB * sizeof(Partial); }
+size_t filter_scratch_bytes(int n_rows) { return (size_t) std::max(n_rows * NB, FS_MAX_PARTS) * sizeof(Partial); }
 
 }} // namespace wmi::k

@@ -140,6 +140,12 @@ size_t attn_cross_scratch_floats(int n, int H, int T);
 // ---------------------------------------------------------------- decoder small-batch (k_dec.hip)
 void dec_embed(const int32_t * tokens, const int32_t * pos, int n, int S, const __half * te, const float * pe,
                float * x, hipStream_t st);
+// per-workgroup partial statistics of a row of filtered logits (k_sample.hip: k_filter_stats writes 64 of them per row; the one-row
+// vocabulary projection writes one per workgroup from its epilogue, GemvArgs::fs_*): maxima with first-index tie-break over all /
+// text / timestamp tokens, and sums of exp(l - all.v) — combined exactly by k_filter_pick (online soft-max identity)
+struct FsMaxIdx { float v; int i; };
+struct FsPartial { FsMaxIdx all, txt, ts; float sum, sum_ts; float pad[2]; };
+constexpr int FS_MAX_PARTS = 768;                 // partials of the fused form (= the vocabulary projection's workgroup cap)
 // rows <= 8 "GEMV" path: out[i][o] = sum_k W[o][k] * a[i][k] with the same epilogues as the GEMM.
 // If ln_g != null the A operand is LayerNorm(x32) computed in the prologue (fused), else a16.
 struct GemvArgs {
@@ -170,7 +176,12 @@ struct GemvArgs {
     // that streams group g sits on the same XCD when both grids are multiples of 8
     const void * pf_ptr; uint32_t pf_group_bytes; uint32_t pf_groups;
     unsigned long long * stamps; int stamp_slot;      // probe (stamp_next()): filled in by gemv() itself
+    // greedy step, EPI_LOGITS at one row: the logit filters' statistics pass folded into the epilogue — fs_part[workgroup] gets the
+    // partial of the rows the workgroup produced (fs_step: DecStep of the row, fs_ban: static ban bytes); gemv_fused_parts() tells
+    // how many partials this launch will write (0: the arguments do not take the fused path — run filter_argmax's own pass)
+    const uint8_t * fs_ban; const void * fs_step; FsPartial * fs_part;
 };
+int gemv_fused_parts(const GemvArgs & a);
 // lock-step chunks: single-token self-attention of n rows, row r against the cache at kc/vc + r * cache_row_stride with
 // n_kv[r * step_stride] cells; same arithmetic as the fused prologue of gemv (GemvArgs::sa_*).  out [n][K] f16
 void self_attn_rows(const __half * q, int n, int K, const __half * kc, const __half * vc, int64_t cache_row_stride,
@@ -209,8 +220,9 @@ struct alignas(16) SampleOut { int32_t id, tid; float p; int32_t seq0; float plo
 // chain (one row): the pick kernel also prepares the NEXT greedy step on the device — token = the pick, pos / n_kv / kv_head + 1 in
 // *step_rw, and the next activation row x = te[pick] + pe[pos + 1] — so that the next step needs no embedding launch
 struct ChainNext { DecStep * step_rw; const __half * te; const float * pe; float * x; int S; int n_pos; };
+// fused_parts > 0 (one row): scratch already holds that many partials (GemvArgs::fs_part): only the pick kernel runs
 void filter_argmax(const float * logits, const uint8_t * static_ban, const DecStep * step, SampleOut * out, void * scratch, hipStream_t st,
-                   SampleOut * out_host = nullptr, int n_rows = 1, const ChainNext * chain = nullptr);
+                   SampleOut * out_host = nullptr, int n_rows = 1, const ChainNext * chain = nullptr, int fused_parts = 0);
 size_t filter_scratch_bytes(int n_rows = 1);
 // Draws from the filtered distribution on the device (beam search candidates, t > 0 sampling: whisper_sample_token(best = false)
 // and whisper_sample_token_topk, W/whisper.cpp:4777-4909).  The reference draws with std::discrete_distribution on the 51 866

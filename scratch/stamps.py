@@ -30,6 +30,8 @@ for chained in (1, 0):
     if not rows:
         print("no stamps (chained=%d)" % chained); continue
     names = ([] if chained else ["embed"]) + [f"{nm}.{l}" for l in range(L) for nm in names_layer] + ["logits", "f.stats", "f.pick"]
+    if len(names) == len(rows) + 1:
+        names.remove("f.stats")                  # statistics pass folded into the vocabulary projection's epilogue
     if len(names) != len(rows):
         names = [f"k{i}" for i in range(len(rows))]
     print(f"--- chained={chained}: {len(rows)} stamped launches; step span {rows[-1][2] - rows[0][0]:.2f} us")

@@ -380,11 +380,14 @@ def test_streaming_node_call_pattern_matches_reference_goldens(product_lib):
 def _assert_same_transcription(got, want, what, strict, ref_last_t1=False):
     g, w = gu.tokens_array(got), gu.tokens_array(want)
     if strict:
-        # same kernels row for row, bit-identical sums: everything equal, probabilities to f32 noise
+        # same kernels row for row, bit-identical logits: ids, timestamps and text equal.  The probabilities come out of two forms of
+        # the same filter statistics (lock-step rows: 64 block partials of k_filter_stats; one row: one online partial per workgroup
+        # of the vocabulary projection's epilogue) — equal up to the f32 order of a 51 864-term sum: a few 1e-7 on p / plog,
+        # amplified in pt = p_ts / sum_ts (measured 1.9e-6)
         assert g.shape == w.shape, (what, g.shape, w.shape)
         assert np.array_equal(g[:, [0, 1, 6, 7, 8]], w[:, [0, 1, 6, 7, 8]]), (what, g[:, [0, 1, 6, 7]], w[:, [0, 1, 6, 7]])
         if len(g):
-            assert np.abs(g[:, 2:6] - w[:, 2:6]).max() <= 1e-6, what
+            assert np.abs(g[:, 2:6] - w[:, 2:6]).max() <= 8e-6, what
         assert bytes(got[0]) == bytes(want[0]), what
         return
     # different f32 summation order somewhere upstream (see the callers): identical up to the first near-tie
