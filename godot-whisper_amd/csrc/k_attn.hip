@@ -464,9 +464,6 @@ __global__ __launch_bounds__(256) void k_xattn_qscores(const float * __restrict_
     acc[0] += WMI_SHX(acc[0], 1);
     if ((lane & 3) == 0) qs[wave * 16 + ((lane >> 2) & 15)] = round_f16((acc[0] + bias) * qscale);
     __syncthreads();
-#if defined(WMI_XA_STAMPS)
-    const unsigned long long xa1 = sp.base ? wall_clock64() : 0ull;
-#endif
 
     float qo[8];
 #pragma unroll
@@ -753,6 +750,9 @@ __global__ __launch_bounds__(256) void k_xattn_fused(const float * __restrict__ 
         for (int p = 0; p < KPASS; ++p) vv[p] = *(const uint4 *) (vc + off[p]);
     }
     __syncthreads();
+#if defined(WMI_XA_STAMPS)
+    const unsigned long long xa1 = sp.base ? wall_clock64() : 0ull;
+#endif
 
     float qo[8];
 #pragma unroll

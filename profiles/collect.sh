@@ -13,6 +13,10 @@ timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o trac
 timeout 400 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT -o pmc_fetch -- python bench.py --steps 2 --warmup 1 --profile > $OUT/bench_pmc_fetch.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT -o pmc_write -- python bench.py --steps 2 --warmup 1 --profile > $OUT/bench_pmc_write.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $OUT -o pmc_mfma -- python bench.py --steps 2 --warmup 1 --profile > $OUT/bench_pmc_mfma.log 2>&1
+# calibration of SQ_VALU_MFMA_BUSY_CYCLES: the MFMA-only loop of scratch/lab/mfma_peak.hip (k_peak: back-to-back MFMAs, ~2.0 PFLOP/s =
+# the pipe's own ceiling) under the same counter group gives busy / gui-active of a ~100 %-busy kernel; summarise.py divides by it
+hipcc -O3 -std=c++17 --offload-arch=gfx950 scratch/lab/mfma_peak.hip -o /tmp/mfma_peak > $OUT/mfma_peak_build.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES --output-format csv -d $OUT -o pmc_mfma_calib -- /tmp/mfma_peak > $OUT/mfma_peak.log 2>&1
 # condense on the box: the raw per-dispatch CSVs are tens of MB per pass and gpurun merges back at most 64 MiB
 python profiles/summarise.py $TAG > $OUT/summary.txt 2>&1
 cp profiles/${TAG}_* $OUT/ 2>/dev/null

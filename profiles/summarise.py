@@ -56,7 +56,20 @@ def main():
     fetch = per_kernel(src / "pmc_fetch_counter_collection.csv", {"FETCH_SIZE"})
     write = per_kernel(src / "pmc_write_counter_collection.csv", {"WRITE_SIZE"})
     mfma = per_kernel(src / "pmc_mfma_counter_collection.csv", {"SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE", "SQ_BUSY_CYCLES"})
+    # normalisation of the MFMA-busy counter, measured rather than assumed: busy / gui-active of the MFMA-only calibration kernel
+    # (scratch/lab/mfma_peak.hip k_peak at 2 workgroups per CU: the matrix pipes issue back to back, busy = 1 by construction).
+    # Round 2 divided by "1024 SIMDs x gui-active / 8", which gave 15.5 % for a kernel whose FLOP rate alone implies 20 %.
+    norm = None
+    calib = src / "pmc_mfma_calib_counter_collection.csv"
+    if calib.exists():
+        c = per_kernel(calib, {"SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"})
+        ratios = [e["SQ_VALU_MFMA_BUSY_CYCLES"] / e["GRBM_GUI_ACTIVE"] for k2, e in c.items() if "k_peak" in k2 and e.get("GRBM_GUI_ACTIVE")]
+        if ratios:
+            norm = max(ratios)                       # the densest variant (16 accumulators, 2 workgroups per CU)
     summary = {}
+    if norm:
+        summary["_mfma_busy_calibration"] = {"launches": 0, "busy_per_gui_active_at_100_percent": norm,
+                                             "source": "scratch/lab/mfma_peak.hip k_peak under the same counter group (profiles/collect.sh)"}
     for k in sorted(set(fetch) | set(write) | set(mfma)):
         e = {"launches": (fetch.get(k) or write.get(k) or mfma.get(k))["launches"]}
         if k in fetch:
@@ -65,8 +78,13 @@ def main():
         if k in write:
             e["write_bytes_raw"] = write[k]["WRITE_SIZE"] * 1024
         if k in mfma and mfma[k].get("GRBM_GUI_ACTIVE"):
-            # SQ_VALU_MFMA_BUSY_CYCLES is summed over the 1024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
-            e["mfma_busy_frac"] = mfma[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / (mfma[k]["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0)
+            # fraction of the calibration kernel's busy / gui-active ratio (the MFMA-only loop = 1.0); without a calibration run the
+            # round-2 guess (summed over 1024 SIMDs, gui-active over 8 XCDs) is kept and flagged
+            r = mfma[k]["SQ_VALU_MFMA_BUSY_CYCLES"] / mfma[k]["GRBM_GUI_ACTIVE"]
+            if norm:
+                e["mfma_busy_frac"] = r / norm
+            else:
+                e["mfma_busy_frac_uncalibrated"] = r / (1024.0 / 8.0)
             e["mfma_busy_cycles"] = mfma[k]["SQ_VALU_MFMA_BUSY_CYCLES"]
             e["gui_active_cycles_sum"] = mfma[k]["GRBM_GUI_ACTIVE"]
         summary[k] = e
