@@ -15,6 +15,7 @@ fraction of f16 roundings):
     token ids, timestamps, text  identical on every greedy case below
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -849,6 +850,32 @@ def test_lockstep_batch_equals_the_compiled_reference(product_lib, checker_lib):
             for c, b in enumerate(pcms):
                 want = ref.transcribe(b, params=pr)
                 _assert_same_transcription(got[c], want, ("batch vs reference", variant, c, node.last_modes[c]), False, ref_last_t1=True)
+    finally:
+        node.close(); ref.close()
+
+
+def test_lockstep_base_en_eight_chunks_equal_the_compiled_reference(product_lib, checker_lib):
+    """BASELINE configs[3]'s per-GPU share at its real size — 8 x 30 s chunks of base.en in one wmi_full_batch call, host
+    parameter set — against the REFERENCE's whisper_full of each chunk (round 2 compared this size only with the product's own
+    one-chunk path).  4 reference threads x 8 chunks ~ 6 s."""
+    if checker_lib is None:
+        pytest.skip("needs the compiled reference")
+    model = synth.make_model("base.en", seed=1234)
+    pcms = [synth.make_pcm(30.0, seed=1234 + i) for i in range(8)]
+    node = host.SpeechToText(product_lib); node.set_language_model(model)
+    ref = host.SpeechToText(checker_lib); ref.set_language_model(model)
+    try:
+        p = node.full_params("", 0); p.temperature_inc = 0.0
+        pr = ref.full_params("", 0); pr.temperature_inc = 0.0; pr.n_threads = max(4, min(32, os.cpu_count() or 4))
+        got = node.transcribe_batch(pcms, params=p)
+        assert node.last_ret == 0 and len(got) == 8 and list(node.last_modes) == [0] * 8
+        n_tok = 0
+        for c, b in enumerate(pcms):
+            want = ref.transcribe(b, params=pr)
+            assert ref.last_ret == 0
+            n_tok += len(want) - 1
+            _assert_same_transcription(got[c], want, ("8 x base.en vs reference", c), False, ref_last_t1=True)
+        assert n_tok >= 8 * 4
     finally:
         node.close(); ref.close()
 
