@@ -108,6 +108,7 @@ void whisper_free(struct whisper_context * ctx) {
     free_batch(*ctx);
     free_state(*ctx);
     free_weights(ctx->w);
+    for (float * t : ctx->d_sinc) if (t) (void) hipFree(t);
     delete ctx;
 }
 
@@ -338,6 +339,71 @@ int wmi_downmix_stereo(struct whisper_context * ctx, const float * frames, int n
     ok = ok && HIP_OK(hipMemcpyAsync(mono_out, d_out, (size_t) n_frames * 4, hipMemcpyDeviceToHost, s)) && HIP_OK(hipStreamSynchronize(s));
     (void) hipFree(d_in); (void) hipFree(d_out);
     return ok ? 0 : -3;
+}
+
+int wmi_resample(struct whisper_context * ctx, const float * src, int n_frames, int src_rate, int dst_rate, int converter, int on_device,
+                 float * dst, int dst_capacity) {
+    if (!ctx || !ctx->state || ctx->host_only || !src || !dst || n_frames < 0 || src_rate <= 0 || dst_rate <= 0 || dst_capacity < 0 ||
+        converter < 0 || converter > 2) return -1;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!HIP_OK(hipSetDevice(ctx->device))) return -2;
+    hipStream_t s = ctx->state->dev.stream;
+    if (src_rate == dst_rate) {                                                                    // src/speech_to_text.cpp:38-42
+        if (n_frames > dst_capacity) return -4;
+        const bool ok = n_frames == 0 || (HIP_OK(hipMemcpyAsync(dst, src, (size_t) n_frames * 4, on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToHost, s)) &&
+                                          HIP_OK(hipStreamSynchronize(s)));
+        return ok ? n_frames : -3;
+    }
+    const double ratio = (double) (uint32_t) dst_rate / (double) (uint32_t) src_rate;              // :25-26
+    const long long out_frames = (int) ((uint32_t) n_frames * ratio);
+    if (out_frames > dst_capacity) return -4;
+    const k::ResamplePlan pl = k::resample_plan(n_frames, out_frames, ratio, converter);
+    if (pl.error) {
+        WMI_ERR("wmi_resample: converter error %d (src_simple would report it through src_strerror)\n", -pl.error);
+        return pl.error == -10 ? -10 : 0;                                                          // the host returns 0 frames on a converter error (:33-36)
+    }
+    if (pl.n_out == 0) return 0;
+    float *& d_tab = ctx->d_sinc[converter];
+    bool ok = true;
+    if (!d_tab) {
+        const float * coeffs; int count, inc;
+        (void) k::sinc_table(converter, &coeffs, &count, &inc);
+        ok = HIP_OK(hipMalloc((void **) &d_tab, (size_t) count * 4)) && HIP_OK(hipMemcpyAsync(d_tab, coeffs, (size_t) count * 4, hipMemcpyHostToDevice, s));
+        if (!ok) { if (d_tab) { (void) hipFree(d_tab); d_tab = nullptr; } return -3; }
+    }
+    float * d_in = nullptr, * d_out = nullptr; int * d_pos = nullptr; double * d_frac = nullptr;
+    const float * in = src; float * out = dst;
+    if (!on_device) {
+        ok = HIP_OK(hipMalloc((void **) &d_in, (size_t) std::max(n_frames, 1) * 4)) && HIP_OK(hipMalloc((void **) &d_out, (size_t) pl.n_out * 4)) &&
+             HIP_OK(hipMemcpyAsync(d_in, src, (size_t) n_frames * 4, hipMemcpyHostToDevice, s));
+        in = d_in; out = d_out;
+    }
+    if (ok && pl.need_table) {                                                                     // positions from the host's recurrence (index bookkeeping)
+        const int * hp; const double * hf;
+        k::resample_table(pl, &hp, &hf);
+        ok = HIP_OK(hipMalloc((void **) &d_pos, (size_t) pl.n_out * 4)) && HIP_OK(hipMalloc((void **) &d_frac, (size_t) pl.n_out * 8)) &&
+             HIP_OK(hipMemcpyAsync(d_pos, hp, (size_t) pl.n_out * 4, hipMemcpyHostToDevice, s)) &&
+             HIP_OK(hipMemcpyAsync(d_frac, hf, (size_t) pl.n_out * 8, hipMemcpyHostToDevice, s));
+    }
+    if (ok) k::resample_launch(pl, in, n_frames, out, d_tab, d_pos, d_frac, s);
+    if (ok && !on_device) ok = HIP_OK(hipMemcpyAsync(dst, d_out, (size_t) pl.n_out * 4, hipMemcpyDeviceToHost, s));
+    ok = ok && HIP_OK(hipStreamSynchronize(s));
+    (void) hipFree(d_in); (void) hipFree(d_out); (void) hipFree(d_pos); (void) hipFree(d_frac);
+    return ok ? (int) pl.n_out : -3;
+}
+
+int wmi_selftest_resample_plan(int n_frames, int src_rate, int dst_rate, int converter, long long * frames_gen, long long * frames_used,
+                               int * closed_form, int n_pos, long long * pos, double * frac) {
+    if (n_frames < 0 || src_rate <= 0 || dst_rate <= 0 || src_rate == dst_rate) return -1;
+    const double ratio = (double) (uint32_t) dst_rate / (double) (uint32_t) src_rate;
+    const long long out_frames = (int) ((uint32_t) n_frames * ratio);
+    const k::ResamplePlan pl = k::resample_plan(n_frames, out_frames, ratio, converter);
+    if (pl.error) return pl.error;
+    if (frames_gen) *frames_gen = pl.n_out;
+    if (frames_used) *frames_used = pl.n_used;
+    if (closed_form) *closed_form = pl.need_table ? 0 : 1;
+    k::resample_positions(pl, std::min<long long>(n_pos, out_frames + 1), pos, frac);
+    return 0;
 }
 
 int wmi_vad(struct whisper_context * ctx, const float * pcm, int n_samples, int on_device, float vad_thold, float freq_thold, float * energies) {

@@ -2,6 +2,8 @@
 // Conventions: activations are token-major ([row][feature], feature contiguous); every matrix
 // operand is K-contiguous; f16 = IEEE half (the reference's rounding points).
 #pragma once
+#include <memory>
+#include <vector>
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <atomic>
@@ -72,6 +74,26 @@ void signal_energy(const float * pcm, int n, int hw, float * out, float * bmin, 
 // (src/speech_to_text.cpp:45-51, 53-104).  res = {no-activity decision, energy_all, energy_last}
 void downmix_stereo(const float * frames, int n_frames, float * out, hipStream_t st);
 void vad_window(const float * x, int n, int n_last, float alpha, bool filter, float vad_thold, float * res, hipStream_t st);
+
+// SINC resampler (k_resample.hip): src_simple(SRC_SINC_FASTEST = 2 | SRC_SINC_MEDIUM_QUALITY = 1, one channel) of libsamplerate as the host
+// calls it (src/speech_to_text.cpp:16-43), bit-identical to the sequential CPU code.  resample_plan replays the converter's index
+// state machine on the host (how many frames come out, whether the position recurrence has a closed form), resample_launch
+// computes every output frame in its own thread.
+struct Stepper;
+struct ResamplePlan {
+    int error = 0;                       // 0, or libsamplerate's error number negated (-6 ratio, -10 converter, -21 length check), -30 ratio unsupported
+    long long n_out = 0, n_used = 0;     // output_frames_gen, input_frames_used
+    int half_len = 0, index_inc = 0, increment = 0;
+    double float_inc = 0.0, out_scale = 0.0;
+    bool need_table = false;             // the (pos, frac) table of resample_table() has to be on the device
+    std::shared_ptr<Stepper> stepper;
+};
+bool sinc_table(int converter, const float ** coeffs, int * count, int * increment);
+ResamplePlan resample_plan(long long n_in, long long out_cap, double ratio, int converter);
+void resample_table(const ResamplePlan & pl, const int ** pos, const double ** frac);       // host arrays, n_out (+1) entries
+void resample_positions(const ResamplePlan & pl, long long n, long long * pos, double * frac);   // first n positions (tests)
+void resample_launch(const ResamplePlan & pl, const float * d_in, long long n_in, float * d_out, const float * d_coeffs,
+                     const int * d_pos, const double * d_frac, hipStream_t st);
 
 // ---------------------------------------------------------------- GEMM (k_gemm.hip)
 enum Epi : int {

@@ -300,6 +300,7 @@ struct whisper_context {
     // have not arrived yet — every compute call fails until wmi_arena_commit() says the broadcast / peer copy has landed
     bool           weights_pending = false;
     wmi::BatchWork * batch = nullptr;   // lazily created by wmi_full_batch
+    float * d_sinc[3] = {nullptr, nullptr, nullptr};   // resampler coefficient tables on the device, by converter (wmi_resample)
     // the compute code reaches its working set through ctx.state: the *_with_state entry points install the caller's
     // state for the duration of the call under this lock (calls on one context serialise; the GPU runs them in order anyway)
     std::recursive_mutex mu;

@@ -139,6 +139,26 @@ class SpeechToText:
             out.append(self.collect())
         return out
 
+    # -- resample (src/speech_to_text.cpp:353-376): stereo capture frames at the mix rate -> mono 16 kHz.  The reference goes through
+    #    libsamplerate on the CPU; here both steps run on the device (wmi_downmix_stereo, wmi_resample).
+    SRC_SINC_BEST_QUALITY, SRC_SINC_MEDIUM_QUALITY, SRC_SINC_FASTEST = 0, 1, 2        # src/speech_to_text.h:151-155
+
+    def resample(self, buffer_xy: np.ndarray, interpolator_type: int = 2, mix_rate: int = 44100) -> np.ndarray:
+        xy = np.ascontiguousarray(buffer_xy, dtype=np.float32).reshape(-1, 2)
+        n = int(xy.shape[0])
+        expected = n * abi.WHISPER_SAMPLE_RATE // int(mix_rate)                        # :356
+        mono = np.empty(n, np.float32)
+        if n and self.lib.wmi_downmix_stereo(self.ctx, xy.ctypes.data_as(C.c_void_p), n, 0, mono.ctypes.data_as(C.c_void_p)) != 0:
+            return np.zeros(0, np.float32)
+        out = np.empty(max(expected, n if mix_rate == abi.WHISPER_SAMPLE_RATE else 0, 1), np.float32)
+        got = self.lib.wmi_resample(self.ctx, mono.ctypes.data_as(C.c_void_p), n, int(mix_rate), abi.WHISPER_SAMPLE_RATE,
+                                    int(interpolator_type), 0, out.ctypes.data_as(C.c_void_p), int(out.size))
+        if got < 0:
+            got = 0
+        if got != expected:                                                            # :368-370
+            self.last_resample_warning = f"size differ exp: {expected} res: {got}"
+        return out[:got].copy()
+
     # -- voice_activity_detection (src/speech_to_text.cpp:53-104, 378-399)
     def voice_activity_detection(self, buffer: np.ndarray) -> bool:
         n_win = abi.WHISPER_SAMPLE_RATE * 3

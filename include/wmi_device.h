@@ -91,7 +91,7 @@ WHISPER_API struct whisper_context * wmi_pool_select(struct wmi_pool * pool, int
 WHISPER_API int64_t wmi_pool_device_time_us(struct wmi_pool * pool, int i);
 
 /* Host-adjacent DSP of the streaming node on the device, so that raw capture frames need not be touched by the
- * CPU.  The 16 kHz resampler between the two (libsamplerate, SRC_SINC_FASTEST) stays with the host: north star "keep".
+ * CPU.
  *   wmi_downmix_stereo   interleaved stereo f32 frames [n_frames][2] -> mono (x + y) / 2
  *                        replaces: _vector2_array_to_float_array, src/speech_to_text.cpp:45-51
  *   wmi_vad              SpeechToText::voice_activity_detection (src/speech_to_text.cpp:53-104, 378-399) on the last 3 s of
@@ -99,6 +99,18 @@ WHISPER_API int64_t wmi_pool_device_time_us(struct wmi_pool * pool, int i);
  *                        energies (optional, 2 floats) receives energy_all, energy_last.
  * `on_device` != 0: the input (and `mono_out`) are device pointers on the context's device, else host pointers. */
 WHISPER_API int wmi_downmix_stereo(struct whisper_context * ctx, const float * frames, int n_frames, int on_device, float * mono_out);
+
+/* The node's 16 kHz resampler on the device.
+ *   replaces: _resample_audio_buffer (src/speech_to_text.cpp:16-43) = libsamplerate's src_simple(&data, interpolator_type, 1)
+ *             (thirdparty/libsamplerate/src/samplerate.c:469-483; SINC converters thirdparty/libsamplerate/src/src_sinc.c:283-427)
+ * converter: the host's InterpolatorType (src/speech_to_text.h:151-155): 2 = SRC_SINC_FASTEST (what capture_stream_to_text.gd:76 asks
+ * for), 1 = SRC_SINC_MEDIUM_QUALITY; 0 = SRC_SINC_BEST_QUALITY answers -10: its coefficient table is a missing blob of the reference
+ * checkout.  Mono f32 frames at src_rate -> dst (room for dst_capacity >= int(n_frames * dst_rate / src_rate) frames) at dst_rate
+ * (the host passes WHISPER_SAMPLE_RATE).  Returns the frames written — the host's result_size; equal rates copy — or 0 where
+ * src_simple reports an error (ratio outside [1/256, 256]); < 0: -1 arguments, -2 / -3 device, -4 dst_capacity too small.
+ * Every output frame equals the sequential CPU code bit for bit (double accumulators, taps in its order). */
+WHISPER_API int wmi_resample(struct whisper_context * ctx, const float * src, int n_frames, int src_rate, int dst_rate, int converter,
+                             int on_device, float * dst, int dst_capacity);
 WHISPER_API int wmi_vad(struct whisper_context * ctx, const float * pcm, int n_samples, int on_device, float vad_thold, float freq_thold,
                         float * energies);
 
@@ -164,6 +176,13 @@ WHISPER_API int wmi_sample_draws(struct whisper_context * ctx, const float * pro
  * MFMA GEMM) on identical random inputs; op: 0 self q|k|v, 1 self out, 2 cross q, 4 mlp.0, 5 mlp.2.
  * Returns the largest absolute difference over all outputs (negative on error). */
 WHISPER_API double wmi_selftest_proj(struct whisper_context * ctx, int op, int n, int layer);
+
+/* Host half of wmi_resample on its own (no device needed; CPU-side tests): the frame counts src_simple reports for n_frames
+ * mono frames at src_rate -> dst_rate (output capacity int(n_frames * ratio) as the host passes it), and the first n_pos output
+ * positions (integer sample, fraction) the kernel would use.  Returns 0, or the converter error as wmi_resample logs it.
+ * closed_form: 1 when the positions come from the exact 128-bit product, 0 when the host ran the double recurrence. */
+WHISPER_API int wmi_selftest_resample_plan(int n_frames, int src_rate, int dst_rate, int converter, long long * frames_gen,
+                                           long long * frames_used, int * closed_form, int n_pos, long long * pos, double * frac);
 
 /* Block-quantised kernels on caller data (parity tests, no context needed): w_blocks = the ggml blocks of an [N][K] matrix of
  * type `qtype` (ggml_type id: 2 q4_0, 3 q4_1, 6 q5_0, 7 q5_1, 8 q8_0; W/ggml-quants.h:10-47) exactly as a model file holds them,

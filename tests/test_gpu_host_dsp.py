@@ -1,14 +1,51 @@
-"""-m gpu: the host-adjacent DSP kernels against the restatement of the host's C++
-(src/speech_to_text.cpp:45-51 stereo -> mono, :53-104 high-pass + energy VAD; godot-whisper_amd/host.py) — bit-exact:
-the filter recurrence and the running f32 energy sums are evaluated in sample order by one lane."""
+"""-m gpu: the host-adjacent DSP kernels against oracle/host_dsp.c, the C restatement of the host's C++
+(src/speech_to_text.cpp:16-51 resample + stereo -> mono, :53-104 high-pass + energy VAD) — bit-exact: the filter recurrence and
+the running f32 energy sums are evaluated in sample order by one lane, every resampled frame by one thread in the converter's
+tap order with double accumulators.  The VAD half of that oracle is pinned to the reference's compiled W/examples/common.cpp,
+the resampler half to libsamplerate's own test programs (tests/test_oracle_host_dsp.py)."""
 import ctypes as C
+import pathlib
+import struct
 
 import numpy as np
 import pytest
 
-from godot_whisper_amd import host, synth
+from godot_whisper_amd import abi, host, synth
 
 pytestmark = pytest.mark.gpu
+
+ROOT = pathlib.Path(__file__).resolve().parent.parent
+
+
+@pytest.fixture(scope="module")
+def dsp():
+    so = ROOT / "oracle" / "liboracle_dsp.so"
+    assert so.exists(), "oracle/liboracle_dsp.so not built (python __graft_entry__.py build)"
+    lib = C.CDLL(str(so))
+    lib.oracle_resample_audio_buffer.restype = C.c_uint32
+    lib.oracle_resample_audio_buffer.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.oracle_vad_simple.restype = C.c_int
+    lib.oracle_vad_simple.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, C.c_void_p]
+    lib.oracle_downmix_stereo.restype = None
+    lib.oracle_downmix_stereo.argtypes = [C.c_uint32, C.c_void_p, C.c_void_p]
+    return lib
+
+
+def _table(name):
+    raw = (ROOT / "godot-whisper_amd" / "csrc" / "data" / name).read_bytes()
+    inc, cnt = struct.unpack("<ii", raw[:8])
+    return inc, np.frombuffer(raw[8:], "<f4", cnt).copy()
+
+
+TABLES = {2: _table("sinc_fastest.bin"), 1: _table("sinc_medium.bin")}
+
+
+def oracle_resample(dsp, x, src_rate, converter):
+    inc, tab = TABLES[converter]
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.zeros(max(int(x.size * 16000.0 / src_rate) + 8, x.size + 8), np.float32)
+    got = dsp.oracle_resample_audio_buffer(x.ctypes.data, x.size, src_rate, 16000, tab.ctypes.data, tab.size, inc, out.ctypes.data)
+    return out[:got]
 
 
 @pytest.fixture(scope="module")
@@ -31,7 +68,7 @@ def test_downmix_is_bit_exact(product_lib, node):
 
 
 @pytest.mark.parametrize("case", ["speech", "gated", "silence", "tiny_noise", "quiet_tail", "no_filter", "short"])
-def test_vad_equals_the_host_arithmetic(product_lib, node, case):
+def test_vad_equals_the_host_arithmetic(product_lib, node, dsp, case):
     sr = 16000
     pcm = synth.make_pcm(5.0, seed=11, gate=(case == "gated"))
     thold, freq = 2.0, 200.0
@@ -51,10 +88,13 @@ def test_vad_equals_the_host_arithmetic(product_lib, node, case):
     if pcm.size < 3 * sr:
         assert got == 0
         return
-    want = host.vad_simple(np.array(pcm[-3 * sr:], np.float32), sr, 500, thold, freq)
-    assert bool(got) == bool(want), (case, got, want, en, host.vad_simple.last_energies)
-    ea, el = host.vad_simple.last_energies
-    assert np.float32(ea).view(np.uint32) == en[0].view(np.uint32) and np.float32(el).view(np.uint32) == en[1].view(np.uint32), (case, en, ea, el)
+    win = np.array(pcm[-3 * sr:], np.float32)
+    en_o = np.zeros(2, np.float32)
+    want = dsp.oracle_vad_simple(win.ctypes.data, win.size, sr, 500, thold, freq, 0, en_o.ctypes.data)       # the host's form
+    assert bool(got) == bool(want), (case, got, want, en, en_o)
+    assert en.tobytes() == en_o.tobytes(), (case, en, en_o)
+    # and the Python mirror of the host node keeps agreeing with both
+    assert bool(host.vad_simple(np.array(pcm[-3 * sr:], np.float32), sr, 500, thold, freq)) == bool(want)
 
 
 def test_vad_on_device_resident_samples(product_lib, node):
@@ -79,3 +119,94 @@ def test_vad_on_device_resident_samples(product_lib, node):
         hip.hipFree(din); hip.hipFree(dout)
     finally:
         hip.hipFree(d)
+
+
+# ------------------------------------------------------------------------------------------------ resampler
+
+def _mic(n, seed):
+    rng = np.random.default_rng(seed)
+    t = np.arange(n)
+    x = 0.4 * np.sin(2 * np.pi * 0.013 * t + 0.2) + 0.2 * np.sin(2 * np.pi * 0.11 * t) + 0.05 * rng.standard_normal(n)
+    return x.astype(np.float32)
+
+
+def _resample(lib, ctx, x, src_rate, converter):
+    x = np.ascontiguousarray(x, np.float32)
+    cap = max(int(x.size * 16000.0 / src_rate) + 8, x.size + 8)
+    out = np.full(cap, np.nan, np.float32)
+    got = lib.wmi_resample(ctx, x.ctypes.data_as(C.c_void_p), int(x.size), src_rate, 16000, converter, 0, out.ctypes.data_as(C.c_void_p), cap)
+    return got, out
+
+
+@pytest.mark.parametrize("src_rate", [48000, 44100, 32000, 22050, 96000, 8000, 11025, 47999])
+@pytest.mark.parametrize("converter", [2, 1])
+def test_resampler_equals_the_sequential_converter_bit_for_bit(product_lib, node, dsp, src_rate, converter):
+    lens = [1, 57, 1000, 14670, 44100, 132301] if converter == 2 else [1000, 44100]
+    for i, n in enumerate(lens):
+        x = _mic(n, seed=100 + i)
+        want = oracle_resample(dsp, x, src_rate, converter)
+        got, out = _resample(product_lib, node.ctx, x, src_rate, converter)
+        assert got == want.size, (src_rate, n, got, want.size)
+        assert out[:got].tobytes() == want.tobytes(), (src_rate, converter, n, float(np.max(np.abs(out[:got] - want))))
+        assert np.all(np.isnan(out[got:]))                                       # nothing written past the frames reported
+
+
+def test_resampler_thirty_seconds_of_capture_frames(product_lib, node, dsp):
+    """The streaming node's own use: 30 s of 44.1 kHz stereo capture frames -> mono -> 16 kHz (capture_stream_to_text.gd:76)."""
+    n = 44100 * 30
+    fr = np.stack([_mic(n, 1), _mic(n, 2)], axis=1)
+    mono = np.zeros(n, np.float32)
+    dsp.oracle_downmix_stereo(n, fr.ctypes.data, mono.ctypes.data)
+    want = oracle_resample(dsp, mono, 44100, 2)
+    got = node.resample(fr, host.SpeechToText.SRC_SINC_FASTEST, mix_rate=44100)
+    # reference quirk, reproduced: the converter is asked for int(n * (16000.0 / 44100.0)) = int(479999.99999999994) = 479 999 frames
+    # (src/speech_to_text.cpp:26-27) while the node expects 1 323 000 * 16000 / 44100 = 480 000 in integer arithmetic (:356) and
+    # prints "size differ" (:368-370).
+    assert got.size == want.size == 479999
+    assert got.tobytes() == want.tobytes()
+    assert node.last_resample_warning == "size differ exp: 480000 res: 479999"
+    # 48 kHz has no such rounding: 30 s -> exactly 480 000 frames, no warning
+    fr48 = np.stack([_mic(48000 * 30, 3), _mic(48000 * 30, 4)], axis=1)
+    del node.last_resample_warning
+    assert node.resample(fr48, host.SpeechToText.SRC_SINC_FASTEST, mix_rate=48000).size == 480000
+    assert not hasattr(node, "last_resample_warning")
+
+
+def test_resampler_edges(product_lib, node, dsp):
+    x = _mic(4800, 5)
+    out = np.zeros(4800, np.float32)
+    # equal rates copy (src/speech_to_text.cpp:38-42)
+    assert product_lib.wmi_resample(node.ctx, x.ctypes.data_as(C.c_void_p), 4800, 16000, 16000, 2, 0, out.ctypes.data_as(C.c_void_p), 4800) == 4800
+    assert out.tobytes() == x.tobytes()
+    # empty input, capacity too small, best-quality table absent, ratio out of libsamplerate's range (the host gets 0 frames)
+    assert product_lib.wmi_resample(node.ctx, x.ctypes.data_as(C.c_void_p), 0, 48000, 16000, 2, 0, out.ctypes.data_as(C.c_void_p), 4800) == 0
+    assert product_lib.wmi_resample(node.ctx, x.ctypes.data_as(C.c_void_p), 4800, 48000, 16000, 2, 0, out.ctypes.data_as(C.c_void_p), 10) == -4
+    assert product_lib.wmi_resample(node.ctx, x.ctypes.data_as(C.c_void_p), 4800, 48000, 16000, 0, 0, out.ctypes.data_as(C.c_void_p), 4800) == -10
+    assert product_lib.wmi_resample(node.ctx, x.ctypes.data_as(C.c_void_p), 4800, 16000 * 300, 16000, 2, 0, out.ctypes.data_as(C.c_void_p), 4800) == 0
+    # upsampling (8 kHz telephone audio)
+    want = oracle_resample(dsp, x, 8000, 2)
+    got, o = _resample(product_lib, node.ctx, x, 8000, 2)
+    assert got == want.size == 9600 and o[:got].tobytes() == want.tobytes()
+
+
+def test_resampler_on_device_pointers_feed_the_transcription(product_lib, node, dsp):
+    """Capture frames never touch the CPU: down-mix, resample and VAD on device pointers; the 16 kHz buffer equals the host path."""
+    hip = C.CDLL("libamdhip64.so")
+    n = 48000 * 4
+    fr = np.stack([_mic(n, 7), _mic(n, 8)], axis=1)
+    d_fr, d_mono, d_16k = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    n16 = n // 3
+    assert hip.hipMalloc(C.byref(d_fr), C.c_size_t(fr.nbytes)) == 0 and hip.hipMalloc(C.byref(d_mono), C.c_size_t(4 * n)) == 0
+    assert hip.hipMalloc(C.byref(d_16k), C.c_size_t(4 * n16)) == 0
+    try:
+        assert hip.hipMemcpy(d_fr, fr.ctypes.data_as(C.c_void_p), C.c_size_t(fr.nbytes), 1) == 0
+        assert product_lib.wmi_downmix_stereo(node.ctx, d_fr, n, 1, d_mono) == 0
+        assert product_lib.wmi_resample(node.ctx, d_mono, n, 48000, 16000, 2, 1, d_16k, n16) == n16
+        out = np.zeros(n16, np.float32)
+        assert hip.hipMemcpy(out.ctypes.data_as(C.c_void_p), d_16k, C.c_size_t(4 * n16), 2) == 0
+        mono = np.zeros(n, np.float32)
+        dsp.oracle_downmix_stereo(n, fr.ctypes.data, mono.ctypes.data)
+        assert out.tobytes() == oracle_resample(dsp, mono, 48000, 2).tobytes()
+        assert product_lib.wmi_vad(node.ctx, d_16k, n16, 1, 2.0, 200.0, None) in (0, 1)
+    finally:
+        hip.hipFree(d_fr); hip.hipFree(d_mono); hip.hipFree(d_16k)
