@@ -19,6 +19,7 @@
 #include "kernels.h"
 #include "wave_ops.h"
 #include <cstdlib>
+#include <atomic>
 
 namespace wmi { namespace k {
 
@@ -159,8 +160,8 @@ __global__ __launch_bounds__(NW * 64 * KS) void k_attn_enc(const __half * __rest
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt) {
                 const int dv = nt * 16 + fr;
-                const int ch = ks * 4 + (fq >> 1);
-                const int hv = ((fq & 1) ^ ((fr >> 3) & 1)) * 8;              // rows 8-15: halves swapped (STORE_V)
+                const int ch = ks * 4 + (fq & 1);                             // V^T key order: vt_pos() (bits 2 and 3 of the key swapped)
+                const int hv = ((fq >> 1) ^ ((fr >> 3) & 1)) * 8;             // rows 8-15: halves swapped (STORE_V)
                 const half4 v0 = *(const half4 *) (sV + lds_off(dv, ch) + hv);
                 const half4 v1 = *(const half4 *) (sV + lds_off(dv, ch + 2) + hv);
                 half8 vf;
@@ -945,8 +946,16 @@ void set_attn_one_group(bool on) { g_attn_one_group = on; }
 
 void attn_encoder(const __half * q, const __half * k, const __half * vt, int T, int Tpad, int S, int H, float scale,
                   __half * out, hipStream_t st, int B, float * out32) {
-    static const int nw = getenv("WMI_ATTN_NW") ? atoi(getenv("WMI_ATTN_NW")) : 4;      // wavefronts per workgroup (A/B knob)
+    // WMI_ATTN_FORM: 2 (default) = 32-row wavefronts, one sweep with a running maximum; 1 = the same kernel with the exact row
+    // maximum found in a first sweep (the reference's soft-max argument); 0 = the round-1/2 kernel (16-row wavefronts, two sweeps)
+    static const int form = getenv("WMI_ATTN_FORM") ? atoi(getenv("WMI_ATTN_FORM")) : 2;
     static const int ksplit = getenv("WMI_ATTN_KSPLIT") ? atoi(getenv("WMI_ATTN_KSPLIT")) : -1;      // A/B knob; default: by grid size
+    if (form >= 1 && scale == 0.125f && (Tpad % 64) == 0) {
+        const bool split = ksplit >= 0 ? ksplit > 1 : (((T + 127) / 128) * H * B < 512 && T >= 512 && !g_attn_one_group);
+        attn_encoder2(q, k, vt, T, Tpad, S, H, out, st, B, out32, form == 2, split);
+        return;
+    }
+    static const int nw = getenv("WMI_ATTN_NW") ? atoi(getenv("WMI_ATTN_NW")) : 4;      // wavefronts per workgroup (A/B knob)
     const int nblk = ((T + 63) / 64) * H * B;
     const bool ks2 = ksplit >= 0 ? ksplit == 2 : (nblk <= 512 && T >= 256 && !g_attn_one_group);
     if (nw == 4 && ks2) hipLaunchKernelGGL((k_attn_enc<4, 2>), dim3((T + 63) / 64, H, B), dim3(512), 0, st, q, k, vt, T, Tpad, S, scale, out, out32);

@@ -242,13 +242,13 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
                             half4 v;
 #pragma unroll
                             for (int r = 0; r < 4; ++r) v[r] = (_Float16) pin_f32(acc[i][j][r] + bias);
-                            *(half4 *) (vt + t0) = v;
+                            *(half4 *) (vt + vt_pos(t0)) = v;
                         } else {
                             for (int r = 0; r < 4; ++r) {
                                 const int m = mrow + r;
                                 if (m >= a.M) continue;
                                 const int cb2 = m / rpc, t = m - cb2 * rpc;
-                                ((__half *) a.aux2)[(size_t) cb2 * a.chunk_stride_aux2 + (size_t) c * a.ldaux2 + t] = f2h(acc[i][j][r] + bias);
+                                ((__half *) a.aux2)[(size_t) cb2 * a.chunk_stride_aux2 + (size_t) c * a.ldaux2 + vt_pos(t)] = f2h(acc[i][j][r] + bias);
                             }
                         }
                         continue;

@@ -266,24 +266,7 @@ __device__ __forceinline__ void q_store(const GemmArgs & a, int m, int n, float 
     }
 }
 
-// LDS-DMA issued from inline assembly: hipcc (ROCm 7.2) tracks a __builtin_amdgcn_global_load_lds as a pending LDS write and puts
-// `s_waitcnt vmcnt(0)` in front of the next ds_read it cannot prove disjoint — here in front of the fragment reads of EVERY K
-// step, i.e. the whole ring was drained right after it had been refilled (ISA dump: vmcnt(0) at the head of the compute block;
-// 56 % of the wave cycles in SQ_WAIT_ANY).  An asm statement is invisible to that bookkeeping; the counted waits below are the
-// only ones.  M0 = LDS byte address of the wavefront's destination (lane L lands at M0 + L * size); saved and restored because
-// the compiler owns M0 (cdna_hip_programming.md §5.7).
-template <int BYTES>
-__device__ __forceinline__ void glds_asm(const void * gsrc, uint32_t lds_dst) {
-    uint32_t keep;
-    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_dst);
-    if constexpr (BYTES == 16)
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
-    else
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
-}
-__device__ __forceinline__ uint32_t lds_addr(const void * p) { return (uint32_t) (uintptr_t) (__attribute__((address_space(3))) const void *) p; }
+// glds_asm / lds_addr (LDS-DMA issued from inline assembly): wave_ops.h
 
 // All operands arrive by global_load_lds into an NST-deep ring (NST - 1 K steps in flight, counted vmcnt waits, one raw
 // s_barrier per K step: an LDS-DMA in flight makes __syncthreads() drain the queue): one wavefront per row group fetches its
@@ -474,13 +457,13 @@ __global__ __launch_bounds__(256, 2) void k_qgemm(const GemmArgs a, const int8_t
                                 half4 v;
 #pragma unroll
                                 for (int r = 0; r < 4; ++r) v[r] = (_Float16) pin_f32(acc[i][j][4 * q + r] + bias);
-                                *(half4 *) (vt + t0) = v;
+                                *(half4 *) (vt + vt_pos(t0)) = v;
                             } else {
                                 for (int r = 0; r < 4; ++r) {
                                     const int m = mrow + r;
                                     if (m >= a.M) continue;
                                     const int cb2 = m / rpc, t = m - cb2 * rpc;
-                                    ((__half *) a.aux2)[(size_t) cb2 * a.chunk_stride_aux2 + (size_t) c * a.ldaux2 + t] = f2h(acc[i][j][4 * q + r] + bias);
+                                    ((__half *) a.aux2)[(size_t) cb2 * a.chunk_stride_aux2 + (size_t) c * a.ldaux2 + vt_pos(t)] = f2h(acc[i][j][4 * q + r] + bias);
                                 }
                             }
                         } else {

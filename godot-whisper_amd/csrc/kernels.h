@@ -31,6 +31,12 @@ inline void allow_full_lds(const void * kernel, std::atomic<uint64_t> & mask) {
 #if defined(__HIPCC__)
 __device__ __forceinline__ float pin_f32(float x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ __half f2h(float x) { return __float2half_rn(pin_f32(x)); }
+// Time index inside an encoder V^T row ([S][Tpad], written by the q|k|v GEMM epilogues, read only by the encoder attention): bits 2
+// and 3 of t are swapped, i.e. within every 16 keys the four-key groups sit in the order 0, 2, 1, 3.  A lane of the 32x32x16 MFMA
+// holds the soft-max numerators of keys 8j + 4g + r (g = lane / 32): with this order the eight V values that pair with them —
+// keys {4g..4g+3} and {8+4g..8+4g+3} of a 16-key slice — are ONE aligned 16-byte piece, so the tile goes global -> LDS by DMA
+// untouched and a fragment is a single ds_read_b128.
+__host__ __device__ __forceinline__ int vt_pos(int t) { return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1); }
 #endif
 
 // ---------------------------------------------------------------- in-kernel time stamps (probe: wmi_step_stamps)
@@ -134,6 +140,9 @@ void layernorm(const float * x, int rows, int S, const float * g, const float * 
 // B > 1: B chunks back to back (q,k,out [B][T][S]; vt [B][S][Tpad]), one grid.z slice each
 // out32 != null: the result is written as f32 to out32 instead (models whose out-projection is block-quantised quantise that
 // f32 tensor directly, as the reference does); same for the decoder kernels below
+// second form (k_attn_enc.hip): 32-row wavefronts; one_sweep = running maximum, else exact maximum first; split = four key groups
+void attn_encoder2(const __half * q, const __half * k, const __half * vt, int T, int Tpad, int S, int H, __half * out, hipStream_t st,
+                   int B, float * out32, bool one_sweep, bool split);
 void attn_encoder(const __half * q, const __half * k, const __half * vt, int T, int Tpad, int S, int H,
                   float scale, __half * out, hipStream_t st, int B = 1, float * out32 = nullptr);
 // decoder: one (token, head) per workgroup.  kc/vc: [n_kv][S] caches (this layer), mask: [n][ld_mask] or null

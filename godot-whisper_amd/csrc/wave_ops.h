@@ -10,6 +10,7 @@
 // one-row path) can switch independently.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdint>
 
 namespace wmi { namespace k {
 
@@ -51,6 +52,25 @@ __device__ __forceinline__ float wave_max_desc(float v) {
     v = fmaxf(v, xor_lane<4>(v)); v = fmaxf(v, xor_lane<2>(v)); v = fmaxf(v, xor_lane<1>(v));
     return v;
 }
+
+// LDS-DMA issued from inline assembly: hipcc (ROCm 7.2) tracks a __builtin_amdgcn_global_load_lds as a pending LDS write and puts
+// `s_waitcnt vmcnt(0)` in front of the next ds_read it cannot prove disjoint — here in front of the fragment reads of EVERY K
+// step, i.e. the whole ring was drained right after it had been refilled (ISA dump: vmcnt(0) at the head of the compute block;
+// 56 % of the wave cycles in SQ_WAIT_ANY).  An asm statement is invisible to that bookkeeping; the counted waits below are the
+// only ones.  M0 = LDS byte address of the wavefront's destination (lane L lands at M0 + L * size); saved and restored because
+// the compiler owns M0 (cdna_hip_programming.md §5.7).
+template <int BYTES>
+__device__ __forceinline__ void glds_asm(const void * gsrc, uint32_t lds_dst) {
+    uint32_t keep;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    if constexpr (BYTES == 16)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void * p) { return (uint32_t) (uintptr_t) (__attribute__((address_space(3))) const void *) p; }
 
 // xor_lane with the mask as a value: inside a fully unrolled `for (o = 32; o > 0; o >>= 1)` the switch folds to the one DPP form
 // (if the loop is not unrolled the switch stays a scalar branch: still correct).  WMI_NO_DPP keeps __shfl_xor (A/B builds).
