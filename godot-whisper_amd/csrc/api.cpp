@@ -2,6 +2,7 @@
 // entry points (include/wmi_device.h).  Nothing throws across the boundary; errors are return codes
 // plus the process-global log callback, as in the reference (W/whisper.cpp:6601-6629).
 
+#include <algorithm>
 #include "wmi.h"
 #include "kernels.h"
 
@@ -793,6 +794,43 @@ double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters) {
         float ms6 = 0.0f; (void) hipEventElapsedTime(&ms6, e0, e1);
         (void) hipEventDestroy(e0); (void) hipEventDestroy(e1); (void) hipFree(pool);
         return (double) ms6 * 1000.0 / iters;
+    }
+    if (which == 7 || which == 8) {
+        // phase probe of one encoder mlp.0 launch (7: the lock-step work buffers, M = chunks * T; 8: one chunk): per workgroup the
+        // wall-clock stamps {entry, first tile landed, K loop done, epilogue done}; prints the averages (us) to stderr
+        const bool batch = which == 7;
+        if (batch && (!ctx->batch || ctx->batch->B < 1)) { (void) hipEventDestroy(e0); (void) hipEventDestroy(e1); return -1.0; }
+        k::GemmArgs a{};
+        if (batch) { const BatchWork & b = *ctx->batch; a.A = b.xn; a.M = b.B * T; a.C = b.h; } else { a.A = d.xn; a.M = T; a.C = d.h; }
+        a.lda = S; a.W = w.enc[0].w_fc1; a.ldw = S; a.N = 4 * S; a.K = S; a.bias = w.enc[0].b_fc1; a.ldc = 4 * S;
+        const int cap = 65536;
+        unsigned long long * dp = nullptr;
+        if (!HIP_OK(hipMalloc((void **) &dp, (size_t) cap * 5 * 8))) { (void) hipEventDestroy(e0); (void) hipEventDestroy(e1); return -1.0; }
+        for (int i = 0; i < 3; ++i) k::gemm(k::EPI_F16_BIAS_GELU, a, s);
+        (void) hipMemsetAsync(dp, 0, (size_t) cap * 5 * 8, s);
+        a.probe = dp;
+        k::gemm(k::EPI_F16_BIAS_GELU, a, s);
+        (void) hipStreamSynchronize(s);
+        std::vector<unsigned long long> h((size_t) cap * 5);
+        (void) hipMemcpy(h.data(), dp, h.size() * 8, hipMemcpyDeviceToHost);
+        (void) hipFree(dp);
+        int n = 0; unsigned long long tmin = ~0ull, tmax = 0;
+        for (int i = 0; i < cap; ++i) if (h[(size_t) i * 5 + 3]) { ++n; tmin = std::min(tmin, h[(size_t) i * 5]); tmax = std::max(tmax, h[(size_t) i * 5 + 3]); }
+        double f = 0, l = 0, e = 0;
+        std::vector<double> starts;
+        for (int i = 0; i < cap; ++i) if (h[(size_t) i * 5 + 3]) {
+            const unsigned long long * q = &h[(size_t) i * 5];
+            f += (double) (q[1] - q[0]); l += (double) (q[2] - q[1]); e += (double) (q[3] - q[2]);
+            starts.push_back((double) (q[0] - tmin) * 0.01);
+        }
+        std::sort(starts.begin(), starts.end());
+        const double tick = 0.01;                                   // wall_clock64: 100 MHz
+        fprintf(stderr, "gemm probe (%s): %d workgroups, span %.2f us; per workgroup: entry -> first tile %.2f us, K loop %.2f us, epilogue %.2f us; "
+                        "entry times: p10 %.2f p50 %.2f p90 %.2f max %.2f us\n", batch ? "M = chunks x T" : "one chunk", n,
+                (double) (tmax - tmin) * tick, f / n * tick, l / n * tick, e / n * tick,
+                starts[starts.size() / 10], starts[starts.size() / 2], starts[starts.size() * 9 / 10], starts.back());
+        (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
+        return (double) (tmax - tmin) * tick;
     }
     if (which == 20) { (void) hipEventDestroy(e0); (void) hipEventDestroy(e1); return bench_greedy_step_chain(*ctx, iters); }
     if (which >= 21 && which <= 36) { (void) hipEventDestroy(e0); (void) hipEventDestroy(e1); return bench_rows_step_chain(*ctx, which - 20, iters); }   // 20 + rows

@@ -38,7 +38,7 @@ __device__ __forceinline__ float max3(float a, float b, float c) { float d; asm(
 //                   cross-attention already makes: e is rounded to f16 relative to the maximum SO FAR);
 //            false: two sweeps, exact row maximum first (the reference's soft-max argument bit for bit).
 //   KS       key groups per workgroup (own tiles, common barriers); partial (m, sum, O^T) combined through LDS at the end.
-template <int QW, int KS, bool ONE>
+template <int QW, int KS, bool ONE, int NST>
 __global__ __launch_bounds__(QW * KS * 64) void k_attn_enc2(const __half * __restrict__ q, const __half * __restrict__ k,
                                                             const __half * __restrict__ vt, int T, int Tpad, int S,
                                                             __half * __restrict__ out, float * __restrict__ out32) {
@@ -58,7 +58,7 @@ __global__ __launch_bounds__(QW * KS * 64) void k_attn_enc2(const __half * __res
         q += zb * (size_t) T * S; k += zb * (size_t) T * S; vt += zb * (size_t) S * Tpad;
         if (out32) out32 += zb * (size_t) T * S; else out += zb * (size_t) T * S;
     }
-    unsigned char * const ring = smem + grp * (2 * STAGE);
+    unsigned char * const ring = smem + grp * (NST * STAGE);
     const uint32_t ring_lds = lds_addr(ring);
 
     half8 qf[4];
@@ -132,20 +132,32 @@ __global__ __launch_bounds__(QW * KS * 64) void k_attn_enc2(const __half * __res
     };
 
     const int nt = ntile_g;
+    // NST-deep ring, one barrier per tile: tiles t + 1 .. t + NST - 2 stay in flight while tile t is multiplied (a tile takes
+    // ~0.4 us of this wavefront's time, a DMA from L2 / Infinity Cache about as long to arrive).  The wait is counted: tile t has
+    // landed when at most (NST - 2) tiles' worth of this wavefront's loads are outstanding; vmcnt retires in order.
+    constexpr int LPT = 2 * PPO;                                   // DMA instructions per wavefront and tile
+    auto ring_fill = [&]() {
+#pragma unroll
+        for (int u = 0; u < NST - 1; ++u) if (u < nt) issue(kbeg + u * 64, u);
+    };
+    auto ring_step = [&](int t) {
+        if (NST > 2 && nt - 1 - t >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * LPT) : "memory");
+        else                                  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                              // tile t is there for everyone; the stage multiplied last step is free
+        asm volatile("" ::: "memory");
+        if (t + NST - 1 < nt) issue(kbeg + (t + NST - 1) * 64, (t + NST - 1) % NST);
+    };
     if constexpr (!ONE) {
         // ---- sweep 1: exact row maximum (K tiles only: the V^T half of each stage is fetched too — same DMA routine — and ignored)
-        issue(kbeg, 0);
+        ring_fill();
         for (int t = 0; t < nt; ++t) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
-            if (t + 1 < nt) issue(kbeg + (t + 1) * 64, (t + 1) & 1);
+            ring_step(t);
             floatx16 s[2];
-            tile_scores(ring + (t & 1) * STAGE, kbeg + t * 64, s);
+            tile_scores(ring + (t % NST) * STAGE, kbeg + t * 64, s);
             m = fmaxf(m, tile_max(s));
         }
         if constexpr (KS > 1) {
-            float * xm = (float *) (smem + KS * 2 * STAGE);        // [KS][QW][32]
+            float * xm = (float *) (smem + KS * NST * STAGE);      // [KS][QW][32]
             __syncthreads();
             if (lane < 32) xm[(grp * QW + qw) * 32 + lane] = m;
             __syncthreads();
@@ -161,13 +173,10 @@ __global__ __launch_bounds__(QW * KS * 64) void k_attn_enc2(const __half * __res
     o[0] = floatx16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     o[1] = o[0];
     const half2v ones = {(_Float16) 1.0f, (_Float16) 1.0f};
-    issue(kbeg, 0);
+    ring_fill();
     for (int t = 0; t < nt; ++t) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (t + 1 < nt) issue(kbeg + (t + 1) * 64, (t + 1) & 1);
-        const unsigned char * st = ring + (t & 1) * STAGE;
+        ring_step(t);
+        const unsigned char * st = ring + (t % NST) * STAGE;
         floatx16 s[2];
         tile_scores(st, kbeg + t * 64, s);
         if constexpr (ONE) {
@@ -287,16 +296,17 @@ __global__ __launch_bounds__(QW * KS * 64) void k_attn_enc2(const __half * __res
     }
 }
 
-template <int QW, int KS, bool ONE>
+template <int QW, int KS, bool ONE, int NST>
 void launch_attn_enc2(const __half * q, const __half * k, const __half * vt, int T, int Tpad, int S, int H, __half * out,
-                             hipStream_t st, int B, float * out32) {
+                      hipStream_t st, int B, float * out32) {
     static std::atomic<uint64_t> lds_ok{0};
-    constexpr size_t ring = (size_t) KS * 2 * 16384;
+    constexpr size_t ring = (size_t) KS * NST * 16384;
     constexpr size_t extra = (!ONE && KS > 1) ? (size_t) KS * QW * 32 * 4 : 0;
     constexpr size_t comb = KS > 1 ? (size_t) (KS - 1) * QW * 64 * 34 * 4 : 0;
     constexpr size_t smem = (ring + extra) > comb ? (ring + extra) : comb;
-    if (smem > 48 * 1024) allow_full_lds((const void *) k_attn_enc2<QW, KS, ONE>, lds_ok);
-    hipLaunchKernelGGL((k_attn_enc2<QW, KS, ONE>), dim3((T + QW * 32 - 1) / (QW * 32), H, B), dim3(QW * KS * 64), smem, st,
+    static_assert(smem <= 160 * 1024, "LDS");
+    if (smem > 48 * 1024) allow_full_lds((const void *) k_attn_enc2<QW, KS, ONE, NST>, lds_ok);
+    hipLaunchKernelGGL((k_attn_enc2<QW, KS, ONE, NST>), dim3((T + QW * 32 - 1) / (QW * 32), H, B), dim3(QW * KS * 64), smem, st,
                        q, k, vt, T, Tpad, S, out, out32);
 }
 
@@ -307,13 +317,23 @@ void attn_encoder2(const __half * q, const __half * k, const __half * vt, int T,
                    int B, float * out32, bool one_sweep, bool split) {
     // one key group wherever the result must not depend on how many chunks share the launch (lock-step "exact" mode) and
     // wherever the grid fills the chip by itself; four key groups of two wavefronts for one or two chunks
-    if (one_sweep) {
-        if (split) launch_attn_enc2<2, 4, true>(q, k, vt, T, Tpad, S, H, out, st, B, out32);
-        else       launch_attn_enc2<4, 1, true>(q, k, vt, T, Tpad, S, H, out, st, B, out32);
-    } else {
-        if (split) launch_attn_enc2<2, 4, false>(q, k, vt, T, Tpad, S, H, out, st, B, out32);
-        else       launch_attn_enc2<4, 1, false>(q, k, vt, T, Tpad, S, H, out, st, B, out32);
+    // WMI_ATTN_CFG = <wavefronts per key group><key groups><ring depth>, e.g. 242 (A/B knob; the defaults are the measured best)
+    static const int cfg_env = getenv("WMI_ATTN_CFG") ? atoi(getenv("WMI_ATTN_CFG")) : 0;
+    const int cfg = cfg_env ? cfg_env : (split ? 242 : 412);
+#define WMI_ATTN_CASE(C, QW, KS, NST) case C: if (one_sweep) launch_attn_enc2<QW, KS, true, NST>(q, k, vt, T, Tpad, S, H, out, st, B, out32); \
+                                              else           launch_attn_enc2<QW, KS, false, NST>(q, k, vt, T, Tpad, S, H, out, st, B, out32); break;
+    switch (cfg) {
+        WMI_ATTN_CASE(242, 2, 4, 2)
+        WMI_ATTN_CASE(223, 2, 2, 3)
+        WMI_ATTN_CASE(224, 2, 2, 4)
+        WMI_ATTN_CASE(423, 4, 2, 3)
+        WMI_ATTN_CASE(413, 4, 1, 3)
+        WMI_ATTN_CASE(414, 4, 1, 4)
+        WMI_ATTN_CASE(213, 2, 1, 3)
+        default:
+        WMI_ATTN_CASE(412, 4, 1, 2)
     }
+#undef WMI_ATTN_CASE
 }
 
 }}  // namespace wmi::k

@@ -69,6 +69,8 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    const unsigned long long pt0 = a.probe ? wall_clock64() : 0ull;
+    unsigned long long pt1 = 0ull, pt2 = 0ull;
 
     // XCD-aware tile order: consecutive workgroup ids land on different XCDs (id % 8), so give each
     // XCD a contiguous run of tiles that share A panels in its private L2.
@@ -121,6 +123,18 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
     };
 
     const int frow = lane & 15, fq = lane >> 4;
+    // Orientation of the accumulator fragments.  mfma(A rows, W rows) leaves a lane with four consecutive ROWS of one output
+    // column: row-major f16 results leave as 64 two-byte stores per lane, and those stores — not the K loop — were the larger part
+    // of a K = 512 tile (per-tile time fitted over K: ~7 us fixed against 0.78 us per K step at M = 12 000).  mfma(W rows, A rows)
+    // computes the same dot products (same operands, same k order) into the transposed fragment: four consecutive COLUMNS of one
+    // row per lane = one 8-byte (f16) or 16-byte (f32) store.  The V^T third of the encoder's q|k|v wants consecutive rows (time
+    // steps) and keeps the first orientation; a tile never straddles the segments (BN | S).
+#ifdef WMI_GEMM_NO_SWAP
+    constexpr bool SWAP = false;
+#else
+    constexpr bool SWAP = EPI != EPI_QKV_DEC;
+#endif
+    const bool swap = SWAP && !(EPI == EPI_QKV_ENC && n0 >= 2 * a.S);
     auto compute = [&](int buf) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
@@ -134,8 +148,10 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
-                for (int j = 0; j < FN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < FN; ++j) {
+                    if (SWAP && swap) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    else              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                }
         }
     };
 
@@ -181,9 +197,11 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
             if (nk - 1 - kt >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * LPT) : "memory");
             else                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __syncthreads();                                  // tile kt landed for everyone; the buffer multiplied last step is free
+            if (a.probe && kt == 0) pt1 = wall_clock64();
             if (kt + NST - 1 < nk) issue(kt + NST - 1, (kt + NST - 1) % NST);
             compute(kt % NST);
         }
+        if (a.probe) { asm volatile("s_nop 0" ::: "memory"); pt2 = wall_clock64(); }
     } else {
         load_tile(0);
         store_tile(0);
@@ -302,8 +320,86 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
             }
         }
     };
-    if (m0 + BM <= a.M && n0 + BN <= a.N && !(a.no_glds & 2)) epilogue(std::false_type{});
-    else                                  epilogue(std::true_type{});
+    // swapped orientation: fragment (i, j) holds row m = mb + i*16 + frow, columns n = nb + j*16 + fq*4 + r (r = 0..3)
+    auto epilogue_sw = [&](auto guard_tag) {
+        constexpr bool GUARD = decltype(guard_tag)::value;
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+            const int n = nb + j * 16 + fq * 4;
+            if (GUARD && n >= a.N) continue;                       // N is a multiple of 4 on every caller of these epilogues
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (a.bias) b4 = *(const float4 *) (a.bias + n);
+            const float bias[4] = {b4.x, b4.y, b4.z, b4.w};
+            float4 rpre[FM];
+            if constexpr (EPI == EPI_F32_BIAS_RESID || EPI == EPI_CONV2) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i) {
+                    const int m = mb + i * 16 + frow;
+                    rpre[i] = *(const float4 *) (a.resid + (size_t) ((GUARD && m >= a.M) ? a.M - 1 : m) * a.ldr + n);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i) {
+                const int m = mb + i * 16 + frow;
+                if (GUARD && m >= a.M) continue;
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
+                auto put16 = [&](__half * dst, const float (&x)[4]) {
+                    half4 h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[r] = (_Float16) pin_f32(x[r]);
+                    *(half4 *) dst = h;
+                };
+                if constexpr (EPI == EPI_F16_BIAS) {
+                    const float x[4] = {v[0] + bias[0], v[1] + bias[1], v[2] + bias[2], v[3] + bias[3]};
+                    put16((__half *) a.C + (size_t) m * a.ldc + n, x);
+                } else if constexpr (EPI == EPI_F16_BIAS_GELU) {
+                    const float x[4] = {gelu16_fast(v[0] + bias[0]), gelu16_fast(v[1] + bias[1]), gelu16_fast(v[2] + bias[2]), gelu16_fast(v[3] + bias[3])};
+                    put16((__half *) a.C + (size_t) m * a.ldc + n, x);
+                } else if constexpr (EPI == EPI_Q_SCALED) {
+                    const float x[4] = {(v[0] + bias[0]) * a.scale, (v[1] + bias[1]) * a.scale, (v[2] + bias[2]) * a.scale, (v[3] + bias[3]) * a.scale};
+                    put16((__half *) a.C + (size_t) m * a.ldc + n, x);
+                } else if constexpr (EPI == EPI_F32_BIAS_RESID) {
+                    float4 o;
+                    o.x = (v[0] + bias[0]) + rpre[i].x; o.y = (v[1] + bias[1]) + rpre[i].y; o.z = (v[2] + bias[2]) + rpre[i].z; o.w = (v[3] + bias[3]) + rpre[i].w;
+                    *(float4 *) ((float *) a.C + (size_t) m * a.ldc + n) = o;
+                } else if constexpr (EPI == EPI_CONV2) {
+                    float4 g, o;
+                    g.x = gelu16_fast(v[0] + bias[0]); g.y = gelu16_fast(v[1] + bias[1]); g.z = gelu16_fast(v[2] + bias[2]); g.w = gelu16_fast(v[3] + bias[3]);
+                    if (a.aux) *(float4 *) ((float *) a.aux + (size_t) m * a.ldaux + n) = g;
+                    o.x = rpre[i].x + g.x; o.y = rpre[i].y + g.y; o.z = rpre[i].z + g.z; o.w = rpre[i].w + g.w;
+                    *(float4 *) ((float *) a.C + (size_t) m * a.ldc + n) = o;
+                } else if constexpr (EPI == EPI_QKV_ENC) {
+                    // q (bias, no scale here: the encoder scales the scores) | k (no bias); the V^T third runs in the first orientation
+                    const int seg = __builtin_amdgcn_readfirstlane(n0 / a.S);       // tile-uniform: BN | S
+                    const int c = n - seg * a.S;
+                    const float x[4] = {v[0] + bias[0], v[1] + bias[1], v[2] + bias[2], v[3] + bias[3]};
+                    if (seg == 0) put16((__half *) a.C + (size_t) m * a.ldc + c, x);
+                    else          put16((__half *) a.aux + (size_t) m * a.ldaux + c, x);
+                } else if constexpr (EPI == EPI_CROSS_KV) {
+                    // columns [il][K: S | V: S]; four consecutive columns never straddle a boundary (4 | S)
+                    const int il = n / (2 * a.S), c = n - il * 2 * a.S;
+                    if (c < a.S) {
+                        const float x[4] = {v[0] * a.scale, v[1] * a.scale, v[2] * a.scale, v[3] * a.scale};
+                        put16((__half *) a.C + il * a.layer_stride + (size_t) m * a.ldc + c, x);
+                    } else {
+                        const float x[4] = {v[0] + bias[0], v[1] + bias[1], v[2] + bias[2], v[3] + bias[3]};
+                        put16((__half *) a.aux + il * a.layer_stride + (size_t) m * a.ldaux + (c - a.S), x);
+                    }
+                }
+            }
+        }
+    };
+    const bool interior = m0 + BM <= a.M && n0 + BN <= a.N && !(a.no_glds & 2);
+    if (SWAP && swap) { if (interior) epilogue_sw(std::false_type{}); else epilogue_sw(std::true_type{}); }
+    else              { if (interior) epilogue(std::false_type{});    else epilogue(std::true_type{}); }
+    if (a.probe && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the probe's "done" includes the stores leaving the wavefront
+        unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
+        unsigned long long * o = a.probe + (size_t) blockIdx.x * 5;
+        o[0] = pt0; o[1] = pt1; o[2] = pt2; o[3] = wall_clock64(); o[4] = hwid;
+    }
 }
 
 template <int BM, int BN, int EPI, int NST>

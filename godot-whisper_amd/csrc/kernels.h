@@ -127,6 +127,7 @@ struct GemmArgs {
     int     rows_per_chunk;         // EPI_QKV_ENC, batched encode: M = chunks * rows_per_chunk (0: one chunk)
     int64_t chunk_stride_aux2;      //   elements between the chunks' V^T images
     int     no_glds;                // debug: keep 128x128 tiles on the register-staged loop
+    unsigned long long * probe;     // probe (wmi_bench_kernel 7): per workgroup {entry, first tile landed, K loop done, epilogue done, SE/CU id}
 };
 void gemm(int epi, const GemmArgs & a, hipStream_t st);
 

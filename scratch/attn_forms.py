@@ -37,6 +37,8 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
 else:
     for form in os.environ.get("FORMS", "0 1 2").split():
         for ks in os.environ.get("KSPLITS", "-1").split():
-            env = dict(os.environ, WMI_ATTN_FORM=form, WMI_ATTN_KSPLIT=ks)
-            print("WMI_ATTN_FORM=%s WMI_ATTN_KSPLIT=%s" % (form, ks), flush=True)
-            subprocess.run([sys.executable, __file__, "child"], env=env)
+            for cfg in os.environ.get("CFGS", "0").split():
+                env = dict(os.environ, WMI_ATTN_FORM=form, WMI_ATTN_KSPLIT=ks)
+                if cfg != "0": env["WMI_ATTN_CFG"] = cfg
+                print("WMI_ATTN_FORM=%s WMI_ATTN_KSPLIT=%s WMI_ATTN_CFG=%s" % (form, ks, cfg), flush=True)
+                subprocess.run([sys.executable, __file__, "child"], env=env)

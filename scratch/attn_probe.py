@@ -16,6 +16,7 @@ assert lib.wmi_full_batch(node.ctx, params, ptrs, lens, nb, 0) == 0
 lib.wmi_bench_kernel.restype = C.c_double
 for which, name, it in ((2, "attention layer, 1 chunk", 100), (5, "attention layer, 8 chunks", 50), (0, "mlp.0 GEMM, 1 chunk", 200), (4, "mlp.0 GEMM, 8 chunks", 100)):
     print("%-28s %8.2f us" % (name, lib.wmi_bench_kernel(node.ctx, which, it)))
+lib.wmi_bench_kernel(node.ctx, 7, 1); lib.wmi_bench_kernel(node.ctx, 8, 1)
 t6 = (C.c_int64 * 6)(); n5 = (C.c_int32 * 5)()
 lib.whisper_reset_timings(node.ctx)
 for _ in range(20): node.transcribe(pcm[0], "", 0)
