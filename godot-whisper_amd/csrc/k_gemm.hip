@@ -17,6 +17,7 @@
 // lda < K makes consecutive A rows overlap, which is exactly im2col for a k=3 convolution.
 
 #include "kernels.h"
+#include "wave_ops.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -53,22 +54,48 @@ __device__ __forceinline__ float gelu16_fast(float x) {
     return round_f16(0.5f * xh * (1.0f + t));
 }
 
+// Two GELUs at once for the transposed epilogue (a lane holds adjacent columns): gelu(x) = x / (1 + exp(-2u)), u = k0 x (1 + k1 x^2),
+// which is 0.5 x (1 + tanh u) without the 1 + tanh cancellation — packed f32 multiplies / FMAs, one v_exp_f32 and one v_rcp_f32 per
+// element: ~8 issue slots against ~18 for gelu16_fast (at M = 12 000 the GELU arithmetic was most of mlp.0's 5 us epilogue, itself
+// 39 % of a workgroup's life: profiles/r03b_gemm_phase_probe.txt).  Input and result rounded to f16 like the reference's table;
+// over all 63 488 finite f16 inputs this form differs from the table on 271 entries (<= 2 ulp, all in the negative tail or at
+// |x| < 0.36), gelu16_fast on 422 (<= 5 ulp) — numpy emulation, hardware exp / rcp add their own 1-2 ulp of f32.
+typedef float    float2v __attribute__((ext_vector_type(2)));
+typedef _Float16 half2v  __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ half2v gelu16_pair(float2v x) {
+    const half2v xh = __builtin_convertvector(x, half2v);
+    const float2v xf = {(float) xh[0], (float) xh[1]};
+    constexpr float C0 = -2.0f * 0.79788456080286535587989211986876f * 1.44269504088896340736f;
+    constexpr float C1 = C0 * 0.044715f;
+    const float2v c0 = {C0, C0}, c1 = {C1, C1}, one = {1.0f, 1.0f};
+    const float2v w = __builtin_elementwise_fma(xf * xf, c1, c0) * xf;          // -2u log2(e)
+    const float2v e = {__builtin_amdgcn_exp2f(w[0]), __builtin_amdgcn_exp2f(w[1])};
+    const float2v d = one + e;
+    const float2v r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    const float2v g = xf * r;
+    return __builtin_convertvector(g, half2v);
+}
+
 __device__ __forceinline__ uint32_t lds_off(int row, int chunk) {      // byte offset inside a [rows][64] f16 tile
     return (uint32_t) (row * 128 + ((chunk ^ (row & 7)) << 4));
 }
 
 // NST = depth of the LDS ring of the global_load_lds path: 2 where several workgroups share a CU and hide each other's loads
 // (the ring costs LDS, i.e. occupancy: mlp.0 at one chunk, 768 tiles, is 20 % slower with 4), 4 where a workgroup is alone
-template <int BM, int BN, int EPI, int NST = 2>
-__global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
-    constexpr int FM = BM / 32, FN = BN / 32;          // fragments per wavefront
-    constexpr int LA = BM / 32, LB = BN / 32;          // 16-byte loads per thread per tile
+// NW wavefronts as a 2 x (NW / 2) grid: 4 (2 x 2, 256 threads) everywhere but the 128 x 256 tile of the big grids (2 x 4, 512 threads:
+// one workgroup per CU with a three-deep 48 KB ring = 96 KB in flight per CU against 2 x 32 KB for two 128 x 128 workgroups, and
+// 25 % fewer operand bytes through L2 -> LDS)
+template <int BM, int BN, int EPI, int NST = 2, int NW = 4>
+__global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
+    constexpr int WN_ = NW / 2;                        // wavefronts along N (2 along M)
+    constexpr int FM = BM / 32, FN = BN / (WN_ * 16);  // fragments per wavefront
+    constexpr int LA = BM / (NW * 8), LB = BN / (NW * 8);   // 16-byte loads per thread per tile (register-staged path)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     auto sA = [&](int buf) -> unsigned char * { return smem + buf * ((BM + BN) * 128); };
     auto sB = [&](int buf) -> unsigned char * { return smem + buf * ((BM + BN) * 128) + BM * 128; };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN_, wn = wave % WN_;
     const unsigned long long pt0 = a.probe ? wall_clock64() : 0ull;
     unsigned long long pt1 = 0ull, pt2 = 0ull;
 
@@ -83,17 +110,17 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
     const int tm = wg / ntn, tn = wg % ntn;
     const int m0 = tm * BM, n0 = tn * BN;
 
-    // per-thread staging coordinates: pass p covers rows p*32 + tid/8, chunk tid%8
+    // per-thread staging coordinates: pass p covers rows p*(NW*8) + tid/8, chunk tid%8
     const int srow = tid >> 3, schunk = tid & 7;
     const __half * gA[LA]; const __half * gB[LB];
 #pragma unroll
     for (int p = 0; p < LA; ++p) {
-        int r = m0 + p * 32 + srow; if (r > a.M - 1) r = a.M - 1;
+        int r = m0 + p * (NW * 8) + srow; if (r > a.M - 1) r = a.M - 1;
         gA[p] = a.A + (size_t) r * a.lda + schunk * 8;
     }
 #pragma unroll
     for (int p = 0; p < LB; ++p) {
-        int r = n0 + p * 32 + srow; if (r > a.N - 1) r = a.N - 1;
+        int r = n0 + p * (NW * 8) + srow; if (r > a.N - 1) r = a.N - 1;
         gB[p] = a.W + (size_t) r * a.ldw + schunk * 8;
     }
 
@@ -117,9 +144,9 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
     };
     auto store_tile = [&](int buf) {
 #pragma unroll
-        for (int p = 0; p < LA; ++p) *(uint4 *) (sA(buf) + lds_off(p * 32 + srow, schunk)) = ra[p];
+        for (int p = 0; p < LA; ++p) *(uint4 *) (sA(buf) + lds_off(p * (NW * 8) + srow, schunk)) = ra[p];
 #pragma unroll
-        for (int p = 0; p < LB; ++p) *(uint4 *) (sB(buf) + lds_off(p * 32 + srow, schunk)) = rb[p];
+        for (int p = 0; p < LB; ++p) *(uint4 *) (sB(buf) + lds_off(p * (NW * 8) + srow, schunk)) = rb[p];
     };
 
     const int frow = lane & 15, fq = lane >> 4;
@@ -144,7 +171,7 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
                 fa[i] = *(const half8 *) (sA(buf) + lds_off(wm * (BM / 2) + i * 16 + frow, kk * 4 + fq));
 #pragma unroll
             for (int j = 0; j < FN; ++j)
-                fb[j] = *(const half8 *) (sB(buf) + lds_off(wn * (BN / 2) + j * 16 + frow, kk * 4 + fq));
+                fb[j] = *(const half8 *) (sB(buf) + lds_off(wn * (BN / WN_) + j * 16 + frow, kk * 4 + fq));
 #pragma unroll
             for (int i = 0; i < FM; ++i)
 #pragma unroll
@@ -163,7 +190,7 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
         // swizzle is applied to each lane's GLOBAL address instead: position p = row*8 + (chunk ^ (row & 7)) of a
         // piece of 8 rows is fetched by lane p.  One barrier per K step: tile kt+1 is in flight while kt is multiplied.
         // (profiles/: +38 % on the M = 12 000 encoder GEMMs over the register-staged loop)
-        constexpr int PA = BM / 32, PB = BN / 32;             // 1 KiB pieces per wavefront per operand
+        constexpr int PA = BM / (NW * 8), PB = BN / (NW * 8); // 1 KiB pieces per wavefront per operand
         const int prow = lane >> 3;
         const __half * qA[PA]; const __half * qB[PB];
 #pragma unroll
@@ -178,13 +205,17 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
             int r = n0 + lrow; if (r > a.N - 1) r = a.N - 1;
             qB[p] = a.W + (size_t) r * a.ldw + pch * 8;
         }
+        // DMA from inline asm + a raw s_barrier: hipcc tracks __builtin_amdgcn_global_load_lds as a memory operation and puts
+        // `s_waitcnt vmcnt(0)` in front of every __syncthreads() — the ring was drained at each K step whatever its depth (ISA dump;
+        // "a 3-deep ring measured the same as 2").  The counted waits below are now the only ones.
+        const uint32_t lds0 = lds_addr(smem);
         auto issue = [&](int kt, int buf) {
 #pragma unroll
             for (int p = 0; p < PA; ++p)
-                __builtin_amdgcn_global_load_lds((const void *) (qA[p] + kt * BK), (__attribute__((address_space(3))) void *) (sA(buf) + (wave * PA + p) * 1024), 16, 0, 0);
+                glds_asm<16>(qA[p] + kt * BK, lds0 + buf * ((BM + BN) * 128) + (wave * PA + p) * 1024);
 #pragma unroll
             for (int p = 0; p < PB; ++p)
-                __builtin_amdgcn_global_load_lds((const void *) (qB[p] + kt * BK), (__attribute__((address_space(3))) void *) (sB(buf) + (wave * PB + p) * 1024), 16, 0, 0);
+                glds_asm<16>(qB[p] + kt * BK, lds0 + buf * ((BM + BN) * 128) + BM * 128 + (wave * PB + p) * 1024);
         };
         // NST-deep ring: NST - 1 tiles are in flight while one is multiplied.  At one chunk a workgroup has its CU (almost) to
         // itself and nothing else hides the ~0.5 us a tile takes to arrive: with a distance of one every K step cost a full
@@ -196,7 +227,8 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
         for (int kt = 0; kt < nk; ++kt) {
             if (nk - 1 - kt >= NST - 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"((NST - 2) * LPT) : "memory");
             else                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();                                  // tile kt landed for everyone; the buffer multiplied last step is free
+            __builtin_amdgcn_s_barrier();                     // tile kt landed for everyone; the buffer multiplied last step is free
+            asm volatile("" ::: "memory");
             if (a.probe && kt == 0) pt1 = wall_clock64();
             if (kt + NST - 1 < nk) issue(kt + NST - 1, (kt + NST - 1) % NST);
             compute(kt % NST);
@@ -220,7 +252,7 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
     // Interior tiles take an instantiation without bounds checks: a per-element `if (m < M)` makes every store its own
     // basic block, and hipcc then waits vmcnt(0) before each one (vmcnt also counts stores on gfx9-family parts), i.e.
     // the 64 stores of a lane complete one after the other (profiles/: -10..30 % kernel time on the M = 12 000 GEMMs).
-    const int mb = m0 + wm * (BM / 2), nb = n0 + wn * (BN / 2);
+    const int mb = m0 + wm * (BM / 2), nb = n0 + wn * (BN / WN_);
     auto epilogue = [&](auto guard_tag) {
         constexpr bool GUARD = decltype(guard_tag)::value;
         float biasv[FN];
@@ -355,8 +387,10 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
                     const float x[4] = {v[0] + bias[0], v[1] + bias[1], v[2] + bias[2], v[3] + bias[3]};
                     put16((__half *) a.C + (size_t) m * a.ldc + n, x);
                 } else if constexpr (EPI == EPI_F16_BIAS_GELU) {
-                    const float x[4] = {gelu16_fast(v[0] + bias[0]), gelu16_fast(v[1] + bias[1]), gelu16_fast(v[2] + bias[2]), gelu16_fast(v[3] + bias[3])};
-                    put16((__half *) a.C + (size_t) m * a.ldc + n, x);
+                    const float2v x0 = {v[0] + bias[0], v[1] + bias[1]}, x1 = {v[2] + bias[2], v[3] + bias[3]};
+                    const half2v g0 = gelu16_pair(x0), g1 = gelu16_pair(x1);
+                    half4 h; h[0] = g0[0]; h[1] = g0[1]; h[2] = g1[0]; h[3] = g1[1];
+                    *(half4 *) ((__half *) a.C + (size_t) m * a.ldc + n) = h;
                 } else if constexpr (EPI == EPI_Q_SCALED) {
                     const float x[4] = {(v[0] + bias[0]) * a.scale, (v[1] + bias[1]) * a.scale, (v[2] + bias[2]) * a.scale, (v[3] + bias[3]) * a.scale};
                     put16((__half *) a.C + (size_t) m * a.ldc + n, x);
@@ -366,7 +400,9 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
                     *(float4 *) ((float *) a.C + (size_t) m * a.ldc + n) = o;
                 } else if constexpr (EPI == EPI_CONV2) {
                     float4 g, o;
-                    g.x = gelu16_fast(v[0] + bias[0]); g.y = gelu16_fast(v[1] + bias[1]); g.z = gelu16_fast(v[2] + bias[2]); g.w = gelu16_fast(v[3] + bias[3]);
+                    const float2v x0 = {v[0] + bias[0], v[1] + bias[1]}, x1 = {v[2] + bias[2], v[3] + bias[3]};
+                    const half2v g0 = gelu16_pair(x0), g1 = gelu16_pair(x1);
+                    g.x = (float) g0[0]; g.y = (float) g0[1]; g.z = (float) g1[0]; g.w = (float) g1[1];
                     if (a.aux) *(float4 *) ((float *) a.aux + (size_t) m * a.ldaux + n) = g;
                     o.x = rpre[i].x + g.x; o.y = rpre[i].y + g.y; o.z = rpre[i].z + g.z; o.w = rpre[i].w + g.w;
                     *(float4 *) ((float *) a.C + (size_t) m * a.ldc + n) = o;
@@ -402,13 +438,13 @@ __global__ __launch_bounds__(256) void k_gemm(const GemmArgs a) {
     }
 }
 
-template <int BM, int BN, int EPI, int NST>
+template <int BM, int BN, int EPI, int NST, int NW = 4>
 void launch_n(const GemmArgs & a, hipStream_t st) {
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
     const size_t smem = NST * (size_t) (BM + BN) * 128;
     static std::atomic<uint64_t> lds_ok{0};
-    allow_full_lds((const void *) k_gemm<BM, BN, EPI, NST>, lds_ok);
-    hipLaunchKernelGGL((k_gemm<BM, BN, EPI, NST>), dim3(ntm * ntn), dim3(256), smem, st, a);
+    allow_full_lds((const void *) k_gemm<BM, BN, EPI, NST, NW>, lds_ok);
+    hipLaunchKernelGGL((k_gemm<BM, BN, EPI, NST, NW>), dim3(ntm * ntn), dim3(NW * 64), smem, st, a);
 }
 template <int BM, int BN, int EPI>
 void launch(const GemmArgs & a, hipStream_t st) {
@@ -425,6 +461,16 @@ void dispatch(const GemmArgs & a, hipStream_t st) {
     const long t128 = (long) ((a.M + 127) / 128) * ((a.N + 127) / 128);
     static const bool no_narrow = getenv("WMI_GEMM_NO_NARROW") != nullptr;  // debug / A-B
     const long t64 = (long) ((a.M + 63) / 64) * ((a.N + 63) / 64);
+    // WMI_GEMM_WIDE=1 (A/B knob, off): 128 x 256 tiles on eight wavefronts with a three-deep ring for the big grids (lock-step encoder,
+    // M = chunks x T).  Measured (profiles/r03b_gemm_wide_tile_and_gelu.txt): mlp.0 x 8 45.8 us against 43.5 us for two co-resident
+    // 128 x 128 workgroups per CU — its K loop takes 7.9 us per 128 x 256 tile against 7.3 us per PAIR of 128 x 128 tiles, so the loop is
+    // not waiting for operands to arrive (twice the bytes in flight changed nothing); it is bound by LDS traffic per MFMA (16 fragment
+    // reads per 32 MFMAs of a wavefront + the DMA writes: ~900 LDS cycles per 1024 MFMA cycles of a SIMD).
+    static const int wide = getenv("WMI_GEMM_WIDE") ? atoi(getenv("WMI_GEMM_WIDE")) : 0;
+    const long t256 = (long) ((a.M + 127) / 128) * (a.N / 256);
+    if constexpr (EPI == EPI_F16_BIAS_GELU || EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV || EPI == EPI_F16_BIAS) {
+        if (wide && (a.N % 256) == 0 && t256 >= 384 && (a.K % BK) == 0 && !(a.no_glds & 1)) { launch_n<128, 256, EPI, 3, 8>(a, st); return; }
+    }
     if (t128 >= 384 || (t128 >= 256 && a.K >= 1024)) launch<128, 128, EPI>(a, st);
     else if constexpr (EPI == EPI_F32_BIAS_RESID) {
         // one chunk, N = S: 64x64 tiles give fewer workgroups than CUs (192 for base.en) and each walks K alone with nothing to
