@@ -1277,7 +1277,10 @@ static bool launch_gemv1_special(const GemvArgs & a, int nch, hipStream_t st) {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float    floatx4 __attribute__((ext_vector_type(4)));
 
-template <bool KSPLIT>
+// EPI_T: the epilogue at compile time (-1: run-time switch).  With it the four features a lane holds leave as ONE 8- or 16-byte store
+// and bias / residual arrive as one 16-byte load each; the run-time form puts every 2-byte store behind its own switch + bounds check,
+// i.e. its own basic block with a vmcnt(0) in front (DESIGN.md toolchain hazard 3).
+template <bool KSPLIT, int EPI_T = -1>
 __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1318,7 +1321,18 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
     // epilogue operands of the first tile (bias, residual): independent of the prologue, requested now
     float bias_pre[4] = {0.f, 0.f, 0.f, 0.f}, resid_pre[4] = {0.f, 0.f, 0.f, 0.f};
     const int tile0 = tile;
+    constexpr bool VEC = EPI_T >= 0;                         // host side guarantees 16 | N, 4 | ldc / ldr, 16-byte aligned operands
     if (tile < ntiles && col < n && (!KSPLIT || wave == 0)) {
+        if constexpr (VEC) {
+            const int nf0_ = tile * 16 + kq * 4;
+            // straight-line loads (an absent operand reads the weights' first bytes and is ignored at its use)
+            const float4 b4 = *(const float4 *) (a.bias ? (const void *) (a.bias + nf0_) : (const void *) a.W);
+            bias_pre[0] = b4.x; bias_pre[1] = b4.y; bias_pre[2] = b4.z; bias_pre[3] = b4.w;
+            if constexpr (EPI_T == EPI_F32_BIAS_RESID) {
+                const float4 r4 = *(const float4 *) (a.resid + (size_t) col * a.ldr + nf0_);
+                resid_pre[0] = r4.x; resid_pre[1] = r4.y; resid_pre[2] = r4.z; resid_pre[3] = r4.w;
+            }
+        } else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int nf_ = tile * 16 + kq * 4 + r;
@@ -1326,6 +1340,7 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
                 if (a.bias) bias_pre[r] = a.bias[nf_];
                 if (a.resid) resid_pre[r] = a.resid[(size_t) col * a.ldr + nf_];
             }
+        }
         }
     }
 
@@ -1521,6 +1536,44 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
         if (col >= n) continue;
         // epilogue: this lane holds C[feature = tile*16 + kq*4 + r][chunk row = col]
         const int seg = __builtin_amdgcn_readfirstlane((tile * 16) / (a.S > 0 ? a.S : 1));   // wave-uniform (16 | S), see DESIGN.md §7
+        if constexpr (VEC) {
+            const int nf0_ = tile * 16 + kq * 4;
+            const bool pre = tile == tile0;
+            float b[4];
+            if (pre) { b[0] = bias_pre[0]; b[1] = bias_pre[1]; b[2] = bias_pre[2]; b[3] = bias_pre[3]; }
+            else if (a.bias) { const float4 b4 = *(const float4 *) (a.bias + nf0_); b[0] = b4.x; b[1] = b4.y; b[2] = b4.z; b[3] = b4.w; }
+            else { b[0] = b[1] = b[2] = b[3] = 0.0f; }
+            if (!a.bias) { b[0] = b[1] = b[2] = b[3] = 0.0f; }
+            typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+            if constexpr (EPI_T == EPI_F32_BIAS_RESID) {
+                float rr[4];
+                if (pre) { rr[0] = resid_pre[0]; rr[1] = resid_pre[1]; rr[2] = resid_pre[2]; rr[3] = resid_pre[3]; }
+                else { const float4 r4 = *(const float4 *) (a.resid + (size_t) col * a.ldr + nf0_); rr[0] = r4.x; rr[1] = r4.y; rr[2] = r4.z; rr[3] = r4.w; }
+                float4 o; o.x = (acc[0] + b[0]) + rr[0]; o.y = (acc[1] + b[1]) + rr[1]; o.z = (acc[2] + b[2]) + rr[2]; o.w = (acc[3] + b[3]) + rr[3];
+                *(float4 *) ((float *) a.C + (size_t) col * a.ldc + nf0_) = o;
+            } else if constexpr (EPI_T == EPI_F16_BIAS_GELU) {
+                half4v h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = (_Float16) __half2float(f2h(gelu16(acc[r] + b[r])));
+                *(half4v *) ((__half *) a.C + (size_t) col * a.ldc + nf0_) = h;
+            } else if constexpr (EPI_T == EPI_LOGITS) {
+                float4 o; o.x = acc[0]; o.y = acc[1]; o.z = acc[2]; o.w = acc[3];
+                *(float4 *) ((float *) a.C + (size_t) col * a.ldc + nf0_) = o;
+            } else if constexpr (EPI_T == EPI_QKV_DEC) {
+                const int c = nf0_ - seg * a.S;
+                const int64_t crow = a.lanes ? (int64_t) col * a.cache_row_stride : 0;
+                const int slot = a.lanes ? ro_pre : col + ro_pre;
+                __half * dst; float val[4];
+                if (seg == 0)      { dst = (__half *) a.C    + (size_t) col * a.ldc;            for (int r = 0; r < 4; ++r) val[r] = (acc[r] + b[r]) * a.scale; }
+                else if (seg == 1) { dst = (__half *) a.aux  + crow + (size_t) slot * a.ldaux;  for (int r = 0; r < 4; ++r) val[r] = acc[r] * a.scale; }
+                else               { dst = (__half *) a.aux2 + crow + (size_t) slot * a.ldaux2; for (int r = 0; r < 4; ++r) val[r] = acc[r] + b[r]; }
+                half4v h;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) h[r] = (_Float16) pin_f32(val[r]);
+                *(half4v *) (dst + c) = h;
+            }
+            continue;
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int nf_ = tile * 16 + kq * 4 + r;
@@ -1550,7 +1603,7 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
     }
 }
 
-template <bool KSPLIT>
+template <bool KSPLIT, int EPI_T = -1>
 void launch_rows_mfma(const GemvArgs & a, hipStream_t st) {
     size_t smem = (((size_t) a.n * (a.K + 8) * sizeof(__half) + 15) & ~(size_t) 15) + (KSPLIT ? 4 * 64 * 4 * sizeof(float) : 0);
     const int ntiles = (a.N + 15) / 16;
@@ -1561,8 +1614,8 @@ void launch_rows_mfma(const GemvArgs & a, hipStream_t st) {
     if (blocks > 1024) blocks = 1024;
     if (!KSPLIT && blocks > cap) blocks = cap;
     static std::atomic<uint64_t> lds_ok{0};
-    if (smem > 48 * 1024) allow_full_lds((const void *) k_rows_mfma<KSPLIT>, lds_ok);
-    hipLaunchKernelGGL((k_rows_mfma<KSPLIT>), dim3(blocks), dim3(256), smem, st, a);
+    if (smem > 48 * 1024) allow_full_lds((const void *) k_rows_mfma<KSPLIT, EPI_T>, lds_ok);
+    hipLaunchKernelGGL((k_rows_mfma<KSPLIT, EPI_T>), dim3(blocks), dim3(256), smem, st, a);
 }
 
 template <int R, int RIF, bool NT = false>
@@ -1639,7 +1692,14 @@ static void gemv_(const GemvArgs & a, hipStream_t st) {
     const bool mfma_ok = a.lanes && a.n >= 2 && a.n <= 16 && !a.sa_q && (!a.comb_o || a.N < 8192) && (a.K % 128) == 0 &&
                          (a.epi != EPI_QKV_DEC || (a.S % 16) == 0) && (!rows_valu || a.n > 8);
     if (mfma_ok) {
-        if (a.N >= 8192) launch_rows_mfma<false>(a, st); else launch_rows_mfma<true>(a, st);
+        static const bool generic = getenv("WMI_ROWS_GENERIC_EPI") != nullptr;       // A/B knob
+        const bool vec = !generic && (a.N % 16) == 0 && (a.ldc % 4) == 0 && (!a.resid || (a.ldr % 4) == 0) &&
+                         (a.epi != EPI_QKV_DEC || ((a.ldaux % 4) == 0 && (a.ldaux2 % 4) == 0));
+        if (a.N >= 8192) { if (vec && a.epi == EPI_LOGITS) launch_rows_mfma<false, EPI_LOGITS>(a, st); else launch_rows_mfma<false>(a, st); }
+        else if (vec && a.epi == EPI_QKV_DEC)        launch_rows_mfma<true, EPI_QKV_DEC>(a, st);
+        else if (vec && a.epi == EPI_F32_BIAS_RESID) launch_rows_mfma<true, EPI_F32_BIAS_RESID>(a, st);
+        else if (vec && a.epi == EPI_F16_BIAS_GELU)  launch_rows_mfma<true, EPI_F16_BIAS_GELU>(a, st);
+        else launch_rows_mfma<true>(a, st);
         return;
     }
     static const bool gemv1_off = getenv("WMI_GEMV1_OFF") != nullptr;       // debug / A-B: LDS-staged one-row path
