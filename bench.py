@@ -28,6 +28,8 @@ import numpy as np
 
 import __graft_entry__ as entry
 
+ROOT = entry.ROOT
+
 SHAPE = "base.en"
 CHUNK_S = 30.0
 # algorithmic work per 30 s chunk: encoder FLOP and decoder bytes per token
@@ -210,6 +212,9 @@ def main():
     stream = None
     if args.stream_seconds > 0 and world == 1:
         stream = stream_config(lib, args.stream_seconds)
+    host_dsp = None
+    if world == 1 and not args.profile and args.chunks == 1:
+        host_dsp = host_dsp_config(lib, ctx, cpu=not args.no_cpu_baseline)
 
     tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
     if world > 1:
@@ -256,6 +261,8 @@ def main():
 
         if stream:
             out["stream_small"] = stream
+        if host_dsp is not None:
+            out["host_dsp"] = host_dsp
         # ---- rooflines, measured live with HIP events on the context's stream (wmi_bench_kernel).
         # `roofline` = the kernel kind with the largest share of GPU time in the headline configuration.  The decode step is a
         # chain of dependent kernels; each kind is timed in its own back-to-back chain (which = 20 + WMI_STEP_MASK, no host in
@@ -371,9 +378,9 @@ def main():
                                                            "avg_us": round(us_g8, 3)}
                 if us_a8 > 0:
                     out["attn_layer_batch8_us"] = round(us_a8, 2)
-                    out["attn_layer_batch8_tflops"] = round(8 * 3 * 2.0 * T * T * hp_S / (us_a8 * 1e-6) / 1e12, 1)
+                    out["attn_layer_batch8_tflops"] = round(8 * 2 * 2.0 * T * T * hp_S / (us_a8 * 1e-6) / 1e12, 1)      # one sweep: QK^T + P.V
             out["attn_layer_us"] = round(us_attn, 2)
-            out["attn_layer_tflops"] = round(3 * 2.0 * T * T * hp_S / (us_attn * 1e-6) / 1e12, 1)
+            out["attn_layer_tflops"] = round(2 * 2.0 * T * T * hp_S / (us_attn * 1e-6) / 1e12, 1)               # (the round-2 kernel computed QK^T twice: 3 x)
             out["encoder_tflops_end_to_end"] = round(ENC_GFLOP / enc_ms, 2)
         except Exception as e:  # pragma: no cover
             out["roofline_error"] = repr(e)
@@ -561,6 +568,57 @@ def stream_config(lib, seconds: float) -> dict:
             "audio_ctx_min_max": [int(min(ctxs)), int(max(ctxs))] if ctxs else None,
             "stream_realtime_factor": round(seconds / dt, 1),
             "retranscribed_audio_s_per_wall_s": round(samples / 16000 / dt, 1)}
+
+
+def host_dsp_config(lib, ctx, cpu: bool = True) -> dict:
+    """the streaming node's DSP in front of transcribe — stereo fold, 16 kHz SINC resampler (SRC_SINC_FASTEST), VAD — on
+    30 s of stereo capture frames resident in HBM (device pointers in, device pointers out), HIP events around 20 repetitions.
+    cpu: the same resampling through oracle/host_dsp.c (libsamplerate's arithmetic restated; one host core) as the CPU figure."""
+    import ctypes as C
+    import torch
+    res = {"workload": "30 s of stereo capture frames in HBM -> mono -> 16 kHz (SRC_SINC_FASTEST) -> VAD, device pointers throughout"}
+    for rate in (48000, 44100):
+        n = rate * 30
+        rng = np.random.default_rng(rate)
+        fr = torch.from_numpy((0.3 * rng.standard_normal((n, 2))).astype(np.float32)).cuda()
+        mono = torch.empty(n, dtype=torch.float32, device="cuda")
+        n16 = int(np.uint32(n) * (16000.0 / rate))
+        out = torch.empty(n16 + 8, dtype=torch.float32, device="cuda")
+        def once():
+            assert lib.wmi_downmix_stereo(ctx, C.c_void_p(fr.data_ptr()), n, 1, C.c_void_p(mono.data_ptr())) == 0
+            got = lib.wmi_resample(ctx, C.c_void_p(mono.data_ptr()), n, rate, 16000, 2, 1, C.c_void_p(out.data_ptr()), n16 + 8)
+            assert got == n16, (got, n16)
+            assert lib.wmi_vad(ctx, C.c_void_p(out.data_ptr()), got, 1, 2.0, 200.0, None) in (0, 1)
+        once(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20): once()
+        torch.cuda.synchronize()
+        ms = 1e3 * (time.perf_counter() - t0) / 20
+        # the resampler alone (the calls above synchronise per call: host-paced)
+        t0 = time.perf_counter()
+        for _ in range(20):
+            lib.wmi_resample(ctx, C.c_void_p(mono.data_ptr()), n, rate, 16000, 2, 1, C.c_void_p(out.data_ptr()), n16 + 8)
+        ms_rs = 1e3 * (time.perf_counter() - t0) / 20
+        res[f"from_{rate}_hz"] = {"ms_per_30s_fold_resample_vad": round(ms, 3), "ms_per_30s_resample_call": round(ms_rs, 3), "frames_out": n16,
+                                  "algorithmic_bytes": int(4 * n + 4 * n16), "resample_gb_per_s": round((4 * n + 4 * n16) / (ms_rs * 1e-3) / 1e9, 1)}
+        if cpu and rate == 48000:
+            so = ROOT / "oracle" / "liboracle_dsp.so"
+            if so.exists():
+                import struct
+                raw = (ROOT / "godot-whisper_amd" / "csrc" / "data" / "sinc_fastest.bin").read_bytes()
+                inc, cnt = struct.unpack("<ii", raw[:8]); tab = np.frombuffer(raw[8:], "<f4", cnt).copy()
+                dsp = C.CDLL(str(so))
+                dsp.oracle_resample_audio_buffer.restype = C.c_uint32
+                dsp.oracle_resample_audio_buffer.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+                x = mono.cpu().numpy(); y = np.zeros(n16 + 8, np.float32)
+                t0 = time.perf_counter()
+                got = dsp.oracle_resample_audio_buffer(x.ctypes.data, n, rate, 16000, tab.ctypes.data, cnt, inc, y.ctypes.data)
+                cpu_ms = 1e3 * (time.perf_counter() - t0)
+                same = bool(got == n16 and np.array_equal(y[:n16], out[:n16].cpu().numpy()))
+                res["cpu_baseline"] = {"value": round(cpu_ms, 1), "unit": "ms per 30 s (resampler only)", "cores": 1, "kind": "port",
+                                       "sample": "one 30 s 48 kHz buffer through oracle/host_dsp.c (libsamplerate src_simple restated, parity unpinned)",
+                                       "device_output_identical": same}
+    return res
 
 
 def pmc_traffic(kernel_key: str):

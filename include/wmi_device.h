@@ -165,7 +165,17 @@ WHISPER_API void wmi_get_timings(struct whisper_context * ctx, int64_t * t6, int
 /* The context's HIP stream (as void*), so a caller can order its own work / events against the hot path. */
 WHISPER_API void * wmi_stream(struct whisper_context * ctx);
 
-/* Host-logic probes used by the parity tests (same decisions as the reference given the same logits). */
+/* Draws of beam search and temperature > 0 (whisper_sample_token / _topk, W/whisper.cpp:4777-4909) run on the device by default: the
+ * host keeps each decoder's mt19937 and ships its uniform numbers, the device searches the cumulative distribution in double over
+ * block sums (k_prob_blocks / k_draw).  CONTRACT: not bit-exact with std::discrete_distribution on the host — the partial sums are
+ * associated differently and exp() is the device's, so a uniform number that falls within ~1e-7 of a cell boundary may select the
+ * neighbouring token, after which that stream diverges like any sampled stream would (tests: test_device_draws_equal_host_draws
+ * pins equality on its fixtures, not in general).  WMI_HOST_DRAWS=1 (environment, read per window) keeps the reference's definition:
+ * logits come back to the host, whisper_process_logits + std::discrete_distribution run there, bit-exact given equal logits.
+ * In device-draw mode the per-step logits stay in HBM: whisper_get_logits() is only defined after whisper_decode() / with
+ * WMI_HOST_DRAWS=1 (greedy whisper_full also keeps them on the device).
+ *
+ * Host-logic probes used by the parity tests (same decisions as the reference given the same logits). */
 WHISPER_API int wmi_process_logits(struct whisper_context * ctx, struct whisper_full_params params, const float * raw_logits,
                                    const whisper_token * hist, int n_hist, int has_ts, int seek_delta, float temperature,
                                    float * out_logits, float * out_logprobs, float * out_probs);
