@@ -56,7 +56,7 @@ def main():
                     help="chunks per GPU per step: 1 = BASELINE configs[1] (headline); 8 = configs[3]'s per-GPU share, lock-step")
     args = ap.parse_args()
     if args.profile:
-        args.no_cpu_baseline = True; args.no_config4 = True
+        args.no_cpu_baseline = True; args.no_config4 = True; args.stream_seconds = 0.0
     IT = 20 if args.profile else 200                 # launches per micro-benchmark chain
 
     import torch
@@ -587,9 +587,10 @@ def host_dsp_config(lib, ctx, cpu: bool = True) -> dict:
         def once():
             assert lib.wmi_downmix_stereo(ctx, C.c_void_p(fr.data_ptr()), n, 1, C.c_void_p(mono.data_ptr())) == 0
             got = lib.wmi_resample(ctx, C.c_void_p(mono.data_ptr()), n, rate, 16000, 2, 1, C.c_void_p(out.data_ptr()), n16 + 8)
-            assert got == n16, (got, n16)
+            assert n16 - 1 <= got <= n16, (got, n16)              # 44.1 kHz: libsamplerate's termination test stops one frame early
             assert lib.wmi_vad(ctx, C.c_void_p(out.data_ptr()), got, 1, 2.0, 200.0, None) in (0, 1)
-        once(); torch.cuda.synchronize()
+            return got
+        n16 = once(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(20): once()
         torch.cuda.synchronize()

@@ -159,9 +159,10 @@ def test_resampler_thirty_seconds_of_capture_frames(product_lib, node, dsp):
     dsp.oracle_downmix_stereo(n, fr.ctypes.data, mono.ctypes.data)
     want = oracle_resample(dsp, mono, 44100, 2)
     got = node.resample(fr, host.SpeechToText.SRC_SINC_FASTEST, mix_rate=44100)
-    # reference quirk, reproduced: the converter is asked for int(n * (16000.0 / 44100.0)) = int(479999.99999999994) = 479 999 frames
-    # (src/speech_to_text.cpp:26-27) while the node expects 1 323 000 * 16000 / 44100 = 480 000 in integer arithmetic (:356) and
-    # prints "size differ" (:368-370).
+    # reference behaviour, reproduced: the converter is asked for int(n * (16000.0 / 44100.0)) = 480 000 frames but stops one early — its
+    # termination test `b_current + input_index + 1 / ratio + 1e-20 > b_real_end` (src_sinc.c:389-393) fires for the last frame because
+    # 1 / fl(16000 / 44100) = 2.7562500000000001 makes 480 000 steps end at 1 323 000.0000000002 > 1 323 000; the node expects
+    # 1 323 000 * 16000 / 44100 = 480 000 (:356) and prints "size differ" (:368-370).
     assert got.size == want.size == 479999
     assert got.tobytes() == want.tobytes()
     assert node.last_resample_warning == "size differ exp: 480000 res: 479999"
