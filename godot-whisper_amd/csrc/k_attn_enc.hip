@@ -327,6 +327,8 @@ void attn_encoder2(const __half * q, const __half * k, const __half * vt, int T,
         WMI_ATTN_CASE(223, 2, 2, 3)
         WMI_ATTN_CASE(224, 2, 2, 4)
         WMI_ATTN_CASE(423, 4, 2, 3)
+        WMI_ATTN_CASE(422, 4, 2, 2)
+        WMI_ATTN_CASE(222, 2, 2, 2)
         WMI_ATTN_CASE(413, 4, 1, 3)
         WMI_ATTN_CASE(414, 4, 1, 4)
         WMI_ATTN_CASE(213, 2, 1, 3)

@@ -73,3 +73,93 @@ def test_two_pass_cross_attention_agrees_within_the_margin(default_run):
             if first:
                 pa, pb = np.array([t[2] for t in a[:first]]), np.array([t[2] for t in b[:first]])
                 assert np.abs(pa - pb).max() <= 1e-2, shape
+
+
+# ------------------------------------------------------------------------------------------------ encoder attention forms
+_ATTN_SCRIPT = r"""
+import json, sys
+sys.path.insert(0, ROOT_PLACEHOLDER); sys.path.insert(0, ROOT_PLACEHOLDER + "/tests")
+import numpy as np
+import __graft_entry__ as entry
+entry.load_package(); entry.load_oracle()
+from godot_whisper_amd import runtime, synth
+from oracle import reflib
+import stage_compare as sc
+lib = runtime.require_gpu(); runtime.silence_logs(lib)
+out = {}
+for shape, actx in (("base.en", 0), ("base.en", 563), ("tiny.en", 0)):      # 563: nine key tiles, the fourth key group of the split form is empty
+    mb = synth.make_model(shape, seed=1234); pcm = synth.make_pcm(30.0, seed=1234)
+    prod = sc.ProductSide(lib, mb)
+    prod.mel(pcm)
+    enc = prod.encode(0, actx)["embd_enc"]
+    rec = {"rms": float(np.sqrt(np.mean(enc.astype(np.float64) ** 2))), "sum": float(enc.astype(np.float64).sum())}
+    if reflib.available():
+        ref = sc.RefSide(reflib.lib(), mb); ref.n_threads = 16
+        ref.mel(pcm)
+        rec["err"] = sc.err_stats(enc, ref.encode(0, actx)["embd_enc"])
+        ref.close()
+    np.save(sys.argv[1] + "_%s_%d.npy" % (shape, actx), enc)
+    out["%s/%d" % (shape, actx)] = rec
+    prod.close()
+print("RESULT" + json.dumps(out))
+""".replace("ROOT_PLACEHOLDER", repr(ROOT))
+
+
+def _run_attn(form, tmp_path):
+    env = dict(os.environ); env["WMI_ATTN_FORM"] = str(form)
+    prefix = str(tmp_path / f"form{form}")
+    r = subprocess.run([sys.executable, "-c", _ATTN_SCRIPT, prefix], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1]
+    return json.loads(line[len("RESULT"):]), prefix
+
+
+def test_encoder_attention_forms_agree_with_the_reference_and_each_other(tmp_path):
+    """WMI_ATTN_FORM: 2 = 32-row wavefronts, one sweep with a running maximum (default); 1 = the same kernel with the exact row
+    maximum found first (the reference's soft-max argument); 0 = the round-2 kernel.  Each against the compiled reference within
+    the encoder bound (rms-rel 2e-3), and the forms against each other (they differ only in f16 rounding positions)."""
+    runs = {f: _run_attn(f, tmp_path) for f in (2, 1, 0)}
+    for f, (res, _) in runs.items():
+        for case, rec in res.items():
+            assert np.isfinite(rec["sum"]) and rec["rms"] > 1e-3, (f, case, rec)
+            if "err" in rec:
+                print(f"WMI_ATTN_FORM={f} {case}: encoder output rms-rel {rec['err']['rms_rel']:.3e} max {rec['err']['max_abs']:.3e}")
+                assert rec["err"]["rms_rel"] <= 2e-3 and rec["err"]["max_abs"] <= 2e-2, (f, case, rec["err"])
+    for case in runs[2][0]:
+        shape, actx = case.split("/")
+        a = np.load(runs[2][1] + f"_{shape}_{actx}.npy").astype(np.float64)
+        for f in (1, 0):
+            b = np.load(runs[f][1] + f"_{shape}_{actx}.npy").astype(np.float64)
+            rel = float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
+            assert rel <= 1e-3, (case, f, rel)
+
+
+# ------------------------------------------------------------------------------------------------ GEMM tile shapes
+_BATCH_SCRIPT = r"""
+import json, sys
+sys.path.insert(0, ROOT_PLACEHOLDER)
+import __graft_entry__ as entry
+entry.load_package()
+from godot_whisper_amd import host, runtime, synth
+lib = runtime.require_gpu(); runtime.silence_logs(lib)
+node = host.SpeechToText(lib); node.set_language_model(synth.make_model("base.en", seed=4242))
+pcms = [synth.make_pcm(30.0, seed=700 + i) for i in range(8)]
+res = node.transcribe_batch(pcms, "", 0)
+out = [[[int(t["id"]), int(t["tid"]), float(t["p"]), float(t["plog"]), int(t["t0"]), int(t["t1"])] for t in r[1:]] for r in res]
+node.close()
+print("RESULT" + json.dumps(out))
+""".replace("ROOT_PLACEHOLDER", repr(ROOT))
+
+
+def test_wide_gemm_tile_is_bit_identical():
+    """WMI_GEMM_WIDE=1 sends the lock-step encoder's big GEMMs through the 128 x 256 eight-wavefront tile (kept as a measured
+    alternative, off by default).  Which wavefront owns an output element changes, its dot product does not (same operands, same k
+    order through the MFMA): eight lock-step chunks must come out bit for bit the same."""
+    def run(env_extra):
+        env = dict(os.environ); env.update(env_extra)
+        r = subprocess.run([sys.executable, "-c", _BATCH_SCRIPT], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1][len("RESULT"):])
+    a, b = run({}), run({"WMI_GEMM_WIDE": "1"})
+    assert len(a) == 8 and all(len(c) > 0 for c in a)
+    assert a == b
