@@ -1323,7 +1323,7 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
     const int tile0 = tile;
     constexpr bool VEC = EPI_T >= 0;                         // host side guarantees 16 | N, 4 | ldc / ldr, 16-byte aligned operands
     if (tile < ntiles && col < n && (!KSPLIT || wave == 0)) {
-        if constexpr (VEC) {
+        if constexpr (VEC && EPI_T != EPI_LOGITS) {
             const int nf0_ = tile * 16 + kq * 4;
             // straight-line loads (an absent operand reads the weights' first bytes and is ignored at its use)
             const float4 b4 = *(const float4 *) (a.bias ? (const void *) (a.bias + nf0_) : (const void *) a.W);
@@ -1352,21 +1352,27 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
             // vocabulary projection: 53 MB streamed by several workgroups per CU — the register budget decides the occupancy, so
             // the rows are normalised one after the other with the loads inside (measured: 19.8 us at 8 rows against 30 us with
             // the all-rows-at-once form below)
-            for (int r = wave; r < n; r += 4) {
-                const int src = a.rows ? a.rows[r] : r;
-                float av[3][8];
-                ln_row_regs<3>(a.x32 + (size_t) src * K, a.ln_g, a.ln_b, K, a.eps, lane, av);
+            auto ln_seq = [&](auto nc_tag) {
+                constexpr int NC = decltype(nc_tag)::value;      // 512-column chunks of a row: registers (and loads) only for the chunks the model has
+                for (int r = wave; r < n; r += 4) {
+                    const int src = a.rows ? a.rows[r] : r;
+                    float av[NC][8];
+                    ln_row_regs<NC>(a.x32 + (size_t) src * K, a.ln_g, a.ln_b, K, a.eps, lane, av);
 #pragma unroll
-                for (int t = 0; t < 3; ++t) {
-                    const int c = lane * 8 + 512 * t;
-                    if (c < K) {
-                        __half2 h[4];
+                    for (int t = 0; t < NC; ++t) {
+                        const int c = lane * 8 + 512 * t;
+                        if (c < K) {
+                            __half2 h[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) h[e] = __floats2half2_rn(av[t][2 * e], av[t][2 * e + 1]);
-                        *(uint4 *) (act + r * lda + c) = *(const uint4 *) h;
+                            for (int e = 0; e < 4; ++e) h[e] = __floats2half2_rn(av[t][2 * e], av[t][2 * e + 1]);
+                            *(uint4 *) (act + r * lda + c) = *(const uint4 *) h;
+                        }
                     }
                 }
-            }
+            };
+            if (K <= 512) ln_seq(std::integral_constant<int, 1>{});
+            else if (K <= 1024) ln_seq(std::integral_constant<int, 2>{});
+            else ln_seq(std::integral_constant<int, 3>{});
         } else {
         auto ln_rows = [&](auto rw_tag) {
             constexpr int RW = decltype(rw_tag)::value;
@@ -1536,7 +1542,7 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
         if (col >= n) continue;
         // epilogue: this lane holds C[feature = tile*16 + kq*4 + r][chunk row = col]
         const int seg = __builtin_amdgcn_readfirstlane((tile * 16) / (a.S > 0 ? a.S : 1));   // wave-uniform (16 | S), see DESIGN.md §7
-        if constexpr (VEC) {
+        if (VEC && (EPI_T != EPI_LOGITS || tile * 16 + 16 <= a.N)) {     // (the vocabulary's last tile is ragged: 51 864 = 16 x 3 241 + 8)
             const int nf0_ = tile * 16 + kq * 4;
             const bool pre = tile == tile0;
             float b[4];
@@ -1695,7 +1701,8 @@ static void gemv_(const GemvArgs & a, hipStream_t st) {
         static const bool generic = getenv("WMI_ROWS_GENERIC_EPI") != nullptr;       // A/B knob
         const bool vec = !generic && (a.N % 16) == 0 && (a.ldc % 4) == 0 && (!a.resid || (a.ldr % 4) == 0) &&
                          (a.epi != EPI_QKV_DEC || ((a.ldaux % 4) == 0 && (a.ldaux2 % 4) == 0));
-        if (a.N >= 8192) { if (vec && a.epi == EPI_LOGITS) launch_rows_mfma<false, EPI_LOGITS>(a, st); else launch_rows_mfma<false>(a, st); }
+        // vocabulary projection: whole tiles leave as one 16-byte store per lane; the ragged last tile keeps the element-wise form
+        if (a.N >= 8192) { if (!generic && a.epi == EPI_LOGITS && (a.ldc % 4) == 0 && !a.bias) launch_rows_mfma<false, EPI_LOGITS>(a, st); else launch_rows_mfma<false>(a, st); }
         else if (vec && a.epi == EPI_QKV_DEC)        launch_rows_mfma<true, EPI_QKV_DEC>(a, st);
         else if (vec && a.epi == EPI_F32_BIAS_RESID) launch_rows_mfma<true, EPI_F32_BIAS_RESID>(a, st);
         else if (vec && a.epi == EPI_F16_BIAS_GELU)  launch_rows_mfma<true, EPI_F16_BIAS_GELU>(a, st);
