@@ -161,8 +161,15 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
 #else
     constexpr bool SWAP = EPI != EPI_QKV_DEC;
 #endif
-    const bool swap = SWAP && !(EPI == EPI_QKV_ENC && n0 >= 2 * a.S);
-    auto compute = [&](int buf) {
+    // Measured per epilogue and grid (profiles/r03b_gemm_orientation_per_kernel.txt, rocprof averages, both orientations on the same
+    // ring code): the transposed form wins at one chunk everywhere (q|k|v 9.9 against 11.0 us, GELU 10.0 / 10.9, cross K/V 25 / 33,
+    // conv 13.1 / 14.3) and at M = 12 000 for GELU (44.9 / 49.6) and cross K/V (142 / 150), but LOSES there for q|k|v (50.3 against
+    // 43.7 us) and the residual epilogues (44.6 / 43.2 on 128 x 128 tiles, 23.9 / 21.6 on 64 x 64): those keep the first orientation
+    // on the big grids.  Workgroup-uniform, both epilogues are compiled.
+    const bool big = a.M >= 4096;
+    const bool swap = SWAP && !(EPI == EPI_QKV_ENC && (n0 >= 2 * a.S || big)) && !(EPI == EPI_F32_BIAS_RESID && big);
+    auto compute = [&](int buf, auto sw_tag) {
+        constexpr bool SWF = decltype(sw_tag)::value;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
             half8 fa[FM], fb[FN];
@@ -176,12 +183,16 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
             for (int i = 0; i < FM; ++i)
 #pragma unroll
                 for (int j = 0; j < FN; ++j) {
-                    if (SWAP && swap) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-                    else              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                    if constexpr (SWF) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
+                    else               acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
                 }
         }
     };
 
+    // The orientation is decided OUTSIDE the K loop (two copies of the loop where it is a run-time choice): with the choice inside,
+    // hipcc kept both MFMA forms and both epilogues' state live through the loop — the residual GEMM at M = 12 000 went from 44 to
+    // 85 us, q|k|v from 44 to 50.
+    auto k_loops = [&](auto sw_tag) {
     // 64x64 tiles take the same path while the grid is small (one chunk: latency-bound, -11..15 % per GEMM); with
     // thousands of small tiles the register-staged loop is the faster one (measured, scratch/lab/gemm_lab.hip)
     if ((BM == 128 || nwg <= 1024) && (a.K % BK) == 0 && !(a.no_glds & 1)) {
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
             asm volatile("" ::: "memory");
             if (a.probe && kt == 0) pt1 = wall_clock64();
             if (kt + NST - 1 < nk) issue(kt + NST - 1, (kt + NST - 1) % NST);
-            compute(kt % NST);
+            compute(kt % NST, sw_tag);
         }
         if (a.probe) { asm volatile("s_nop 0" ::: "memory"); pt2 = wall_clock64(); }
     } else {
@@ -241,11 +252,16 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
         for (int kt = 0; kt < nk; ++kt) {
             const int buf = kt & 1;
             if (kt + 1 < nk) load_tile(kt + 1);
-            compute(buf);
+            compute(buf, sw_tag);
             if (kt + 1 < nk) store_tile(buf ^ 1);
             __syncthreads();
         }
     }
+    };
+    constexpr bool RT_ORIENT = SWAP && (EPI == EPI_QKV_ENC || EPI == EPI_F32_BIAS_RESID);    // epilogues whose orientation depends on the tile / grid
+    if constexpr (!SWAP) k_loops(std::false_type{});
+    else if constexpr (!RT_ORIENT) k_loops(std::true_type{});
+    else { if (swap) k_loops(std::true_type{}); else k_loops(std::false_type{}); }
 
     // ------------------------------------------------------------------ epilogue
     // fragment (i, j): rows m = mb + i*16 + fq*4 + r (r = 0..3), column n = nb + j*16 + frow.
