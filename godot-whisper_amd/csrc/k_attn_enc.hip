@@ -13,7 +13,12 @@ namespace {
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ uint32_t lds_off(int row, int chunk) { return (uint32_t) (row * 128 + ((chunk ^ (row & 7)) << 4)); }
+// Tile rows are 128 B (8 chunks of 16 B); chunk c of row r sits in slot c ^ ((r >> 1) & 7).  A 32-row fragment read (ds_read_b128, lane =
+// row) is served in the hardware's lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (+ 32): 16 rows = 8 even + 8 odd ones, whose 128-byte
+// halves of the 256-byte bank window differ by parity — within a parity the key (r >> 1) & 7 takes all eight values, so a group touches every
+// bank once.  With the key r & 7 of the 16-row kernels rows r and r + 24 (r + 8 within a group's lanes) met on the same banks: PMC
+// SQ_LDS_BANK_CONFLICT = 50 % of SQ_LDS_IDX_ACTIVE (profiles/r03b_pmc_enc8_split.txt).
+__device__ __forceinline__ uint32_t lds_off(int row, int chunk) { return (uint32_t) (row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)); }
 // fmaxf() canonicalises both operands first (v_max_f32 x, x) because they could be signalling NaNs: 3 instructions per maximum.
 // MFMA results are what they are; one v_max3_f32 takes two new values per instruction.
 __device__ __forceinline__ float max3(float a, float b, float c) { float d; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; }
@@ -81,22 +86,24 @@ __global__ __launch_bounds__(QW * KS * 64) void k_attn_enc2(const __half * __res
     // (piece pp * QW + qw: which operand a piece belongs to is known at compile time).  Lane L of a piece lands at L * 16, i.e.
     // (row = L / 8, slot = L % 8), and fetches chunk slot ^ (row & 7) of that row: the XOR swizzle applied to the global address
     constexpr int PPO = 8 / QW;                                    // pieces per wavefront and operand
-    const int prow = lane >> 3, pch = (lane & 7) ^ (prow & 7);     // piece rows are multiples of 8: (8p + prow) & 7 = prow & 7
-    const __half * const kcol = k + head * 64 + pch * 8;
-    const __half * const vrow = vt + (size_t) (head * 64 + prow) * Tpad + pch * 8;
+    const int prow = lane >> 3;                                    // row 8p + prow of the tile: swizzle key (4p + prow / 2) & 7
+    const __half * const kcol = k + head * 64;
+    const __half * const vrow = vt + (size_t) (head * 64 + prow) * Tpad;
     auto issue = [&](int kt0, int stage) {
         const int kv = kt0 > Tpad - 64 ? Tpad - 64 : kt0;
         const uint32_t dst = ring_lds + stage * STAGE;
 #pragma unroll
         for (int pp = 0; pp < PPO; ++pp) {
             const int p = pp * QW + qw;
+            const int pch = (lane & 7) ^ ((4 * p + (prow >> 1)) & 7);
             int r = kt0 + p * 8 + prow; if (r > T - 1) r = T - 1;
-            glds_asm<16>(kcol + (size_t) r * S, dst + p * 1024);
+            glds_asm<16>(kcol + (size_t) r * S + pch * 8, dst + p * 1024);
         }
 #pragma unroll
         for (int pp = 0; pp < PPO; ++pp) {
             const int p = pp * QW + qw;
-            glds_asm<16>(vrow + (size_t) (p * 8) * Tpad + kv, dst + 8192 + p * 1024);
+            const int pch = (lane & 7) ^ ((4 * p + (prow >> 1)) & 7);
+            glds_asm<16>(vrow + (size_t) (p * 8) * Tpad + kv + pch * 8, dst + 8192 + p * 1024);
         }
     };
 
