@@ -349,7 +349,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
                         // (S is a multiple of 16, so a fragment never straddles a segment).  A per-lane
                         // three-way `if` here is miscompiled by hipcc 7.2 for gfx950 (the third arm's
                         // pointer select is dropped by the control-flow structurizer: v lands in the k
-                        // cache) — see DESIGN.md "toolchain hazards"; tests/test_gpu_kernels.py pins it.
+                        // cache) — see DESIGN.md "toolchain hazards"; wmi_selftest_proj / tests/test_gpu_parity.py::test_decoder_projection_paths_agree pins it.
                         const int seg = __builtin_amdgcn_readfirstlane((nb + j * 16) / a.S);
                         const int c = n - seg * a.S;
                         __half * dst; float val;
