@@ -487,7 +487,8 @@ void dispatch(const GemmArgs & a, hipStream_t st) {
     if constexpr (EPI == EPI_F16_BIAS_GELU || EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV || EPI == EPI_F16_BIAS) {
         if (wide && (a.N % 256) == 0 && t256 >= 384 && (a.K % BK) == 0 && !(a.no_glds & 1)) { launch_n<128, 256, EPI, 3, 8>(a, st); return; }
     }
-    if (t128 >= 384 || (t128 >= 256 && a.K >= 1024)) launch<128, 128, EPI>(a, st);
+    static const long t128_min = getenv("WMI_GEMM_T128") ? atol(getenv("WMI_GEMM_T128")) : 320;        // A/B knob; 376 tiles (out projection at M = 12 000): 18.6 us against 23.0 us as 1 504 tiles of 64 x 64
+    if (t128 >= t128_min || (t128 >= 256 && a.K >= 1024)) launch<128, 128, EPI>(a, st);
     else if constexpr (EPI == EPI_F32_BIAS_RESID) {
         // one chunk, N = S: 64x64 tiles give fewer workgroups than CUs (192 for base.en) and each walks K alone with nothing to
         // overlap its loads; 64x32 tiles double the workgroups
