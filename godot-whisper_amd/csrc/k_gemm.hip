@@ -195,7 +195,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
     auto k_loops = [&](auto sw_tag) {
     // 64x64 tiles take the same path while the grid is small (one chunk: latency-bound, -11..15 % per GEMM); with
     // thousands of small tiles the register-staged loop is the faster one (measured, scratch/lab/gemm_lab.hip)
-    if ((BM == 128 || nwg <= 1024) && (a.K % BK) == 0 && !(a.no_glds & 1)) {
+    if ((BM >= 96 || nwg <= 1024) && (a.K % BK) == 0 && !(a.no_glds & 1)) {
         // Large tiles (batched encoder, cross K/V): operands go global -> LDS directly (global_load_lds, 16 B per lane,
         // 1 KiB per wave instruction, no staging VGPRs or ds_write pass).  LDS is written lane-linearly, so the XOR
         // swizzle is applied to each lane's GLOBAL address instead: position p = row*8 + (chunk ^ (row & 7)) of a
@@ -488,7 +488,18 @@ void dispatch(const GemmArgs & a, hipStream_t st) {
         if (wide && (a.N % 256) == 0 && t256 >= 384 && (a.K % BK) == 0 && !(a.no_glds & 1)) { launch_n<128, 256, EPI, 3, 8>(a, st); return; }
     }
     static const long t128_min = getenv("WMI_GEMM_T128") ? atol(getenv("WMI_GEMM_T128")) : 320;        // A/B knob; 376 tiles (out projection at M = 12 000): 18.6 us against 23.0 us as 1 504 tiles of 64 x 64
-    if (t128 >= t128_min || (t128 >= 256 && a.K >= 1024)) launch<128, 128, EPI>(a, st);
+    if (t128 >= t128_min || (t128 >= 256 && a.K >= 1024)) {
+        // Round quantisation on the big grids: two workgroups per CU = 512 resident tiles; q|k|v at M = 12 000 is 1 128 tiles of 128 rows
+        // (2.2 rounds: the third runs 20 % full), the N = S projections 376 (one round, 73 % full).  Tiles of 96 rows make that 1 500 and
+        // 500: whole rounds.  Taken when they fill the rounds better by more than their ~5 % lower operand reuse costs.
+        if constexpr (EPI == EPI_QKV_ENC || EPI == EPI_F32_BIAS_RESID) {
+            static const bool no96 = getenv("WMI_GEMM_NO_96") != nullptr;          // A/B knob
+            const long t96 = (long) ((a.M + 95) / 96) * ((a.N + 127) / 128);
+            auto fill = [](long t) { return (double) t / (double) (((t + 511) / 512) * 512); };
+            if (!no96 && a.M >= 4096 && (a.K % BK) == 0 && fill(t96) > fill(t128) + 0.08) { launch_n<96, 128, EPI, 2>(a, st); return; }
+        }
+        launch<128, 128, EPI>(a, st);
+    }
     else if constexpr (EPI == EPI_F32_BIAS_RESID) {
         // one chunk, N = S: 64x64 tiles give fewer workgroups than CUs (192 for base.en) and each walks K alone with nothing to
         // overlap its loads; 64x32 tiles double the workgroups
