@@ -110,6 +110,8 @@ void whisper_free(struct whisper_context * ctx) {
     free_state(*ctx);
     free_weights(ctx->w);
     for (float * t : ctx->d_sinc) if (t) (void) hipFree(t);
+    if (ctx->vad_res) (void) hipHostFree(ctx->vad_res);
+    if (ctx->dsp_scratch) (void) hipFree(ctx->dsp_scratch);
     delete ctx;
 }
 
@@ -326,6 +328,18 @@ size_t wmi_weights_bytes(struct whisper_context * ctx, int which) {
     return which == 0 ? ctx->w.arena_bytes : which == 1 ? ctx->w.matrix_bytes : which == 2 ? (size_t) ctx->w.qtype : 0;
 }
 
+// grow-only device staging for the host-pointer forms (a hipMalloc / hipFree pair per call costs more than the kernels: the VAD call
+// was 1.7 ms of which the kernel is 0.3)
+static float * dsp_scratch(whisper_context * ctx, size_t bytes) {
+    if (ctx->dsp_scratch_bytes < bytes) {
+        if (ctx->dsp_scratch) (void) hipFree(ctx->dsp_scratch);
+        ctx->dsp_scratch = nullptr; ctx->dsp_scratch_bytes = 0;
+        if (!HIP_OK(hipMalloc((void **) &ctx->dsp_scratch, bytes))) return nullptr;
+        ctx->dsp_scratch_bytes = bytes;
+    }
+    return ctx->dsp_scratch;
+}
+
 int wmi_downmix_stereo(struct whisper_context * ctx, const float * frames, int n_frames, int on_device, float * mono_out) {
     if (!ctx || !ctx->state || ctx->host_only || !frames || !mono_out || n_frames < 0) return -1;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
@@ -333,12 +347,10 @@ int wmi_downmix_stereo(struct whisper_context * ctx, const float * frames, int n
     hipStream_t s = ctx->state->dev.stream;
     if (n_frames == 0) return 0;
     if (on_device) { k::downmix_stereo(frames, n_frames, mono_out, s); return HIP_OK(hipStreamSynchronize(s)) ? 0 : -3; }
-    float * d_in = nullptr, * d_out = nullptr;
-    bool ok = HIP_OK(hipMalloc((void **) &d_in, (size_t) n_frames * 8)) && HIP_OK(hipMalloc((void **) &d_out, (size_t) n_frames * 4));
-    ok = ok && HIP_OK(hipMemcpyAsync(d_in, frames, (size_t) n_frames * 8, hipMemcpyHostToDevice, s));
+    float * d_in = dsp_scratch(ctx, (size_t) n_frames * 12), * d_out = d_in ? d_in + (size_t) n_frames * 2 : nullptr;
+    bool ok = d_in && HIP_OK(hipMemcpyAsync(d_in, frames, (size_t) n_frames * 8, hipMemcpyHostToDevice, s));
     if (ok) k::downmix_stereo(d_in, n_frames, d_out, s);
     ok = ok && HIP_OK(hipMemcpyAsync(mono_out, d_out, (size_t) n_frames * 4, hipMemcpyDeviceToHost, s)) && HIP_OK(hipStreamSynchronize(s));
-    (void) hipFree(d_in); (void) hipFree(d_out);
     return ok ? 0 : -3;
 }
 
@@ -375,8 +387,9 @@ int wmi_resample(struct whisper_context * ctx, const float * src, int n_frames, 
     float * d_in = nullptr, * d_out = nullptr; int * d_pos = nullptr; double * d_frac = nullptr;
     const float * in = src; float * out = dst;
     if (!on_device) {
-        ok = HIP_OK(hipMalloc((void **) &d_in, (size_t) std::max(n_frames, 1) * 4)) && HIP_OK(hipMalloc((void **) &d_out, (size_t) pl.n_out * 4)) &&
-             HIP_OK(hipMemcpyAsync(d_in, src, (size_t) n_frames * 4, hipMemcpyHostToDevice, s));
+        d_in = dsp_scratch(ctx, ((size_t) std::max(n_frames, 1) + (size_t) pl.n_out) * 4);
+        d_out = d_in ? d_in + std::max(n_frames, 1) : nullptr;
+        ok = d_in && HIP_OK(hipMemcpyAsync(d_in, src, (size_t) n_frames * 4, hipMemcpyHostToDevice, s));
         in = d_in; out = d_out;
     }
     if (ok && pl.need_table) {                                                                     // positions from the host's recurrence (index bookkeeping)
@@ -389,7 +402,7 @@ int wmi_resample(struct whisper_context * ctx, const float * src, int n_frames, 
     if (ok) k::resample_launch(pl, in, n_frames, out, d_tab, d_pos, d_frac, s);
     if (ok && !on_device) ok = HIP_OK(hipMemcpyAsync(dst, d_out, (size_t) pl.n_out * 4, hipMemcpyDeviceToHost, s));
     ok = ok && HIP_OK(hipStreamSynchronize(s));
-    (void) hipFree(d_in); (void) hipFree(d_out); (void) hipFree(d_pos); (void) hipFree(d_frac);
+    (void) hipFree(d_pos); (void) hipFree(d_frac);
     return ok ? (int) pl.n_out : -3;
 }
 
@@ -418,17 +431,17 @@ int wmi_vad(struct whisper_context * ctx, const float * pcm, int n_samples, int 
     const float rc = (float) (1.0f / (2.0f * 3.14159265358979323846 * freq_thold));
     const float dt = 1.0f / (float) WHISPER_SAMPLE_RATE;
     const float alpha = dt / (rc + dt);
-    float * d_win = nullptr, * d_res = nullptr;
-    bool ok = HIP_OK(hipMalloc((void **) &d_res, 16));
+    if (!ctx->vad_res && !HIP_OK(hipHostMalloc((void **) &ctx->vad_res, 16, hipHostMallocDefault))) return -3;
+    bool ok = true;
     const float * win = pcm + (n_samples - n_win);
-    if (ok && !on_device) {
-        ok = HIP_OK(hipMalloc((void **) &d_win, (size_t) n_win * 4)) && HIP_OK(hipMemcpyAsync(d_win, win, (size_t) n_win * 4, hipMemcpyHostToDevice, s));
+    if (!on_device) {
+        float * d_win = dsp_scratch(ctx, (size_t) n_win * 4);
+        ok = d_win && HIP_OK(hipMemcpyAsync(d_win, win, (size_t) n_win * 4, hipMemcpyHostToDevice, s));
         win = d_win;
     }
-    float res[3] = {0.f, 0.f, 0.f};
-    if (ok) k::vad_window(win, n_win, n_last, alpha, freq_thold > 0.0f, vad_thold, d_res, s);
-    ok = ok && HIP_OK(hipMemcpyAsync(res, d_res, 12, hipMemcpyDeviceToHost, s)) && HIP_OK(hipStreamSynchronize(s));
-    (void) hipFree(d_win); (void) hipFree(d_res);
+    volatile float * res = ctx->vad_res;                              // the kernel stores its three results straight into pinned host memory
+    if (ok) k::vad_window(win, n_win, n_last, alpha, freq_thold > 0.0f, vad_thold, ctx->vad_res, s);
+    ok = ok && HIP_OK(hipStreamSynchronize(s));
     if (!ok) return -3;
     if (energies) { energies[0] = res[1]; energies[1] = res[2]; }
     return res[0] != 0.0f ? 1 : 0;

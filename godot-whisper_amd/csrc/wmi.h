@@ -301,6 +301,8 @@ struct whisper_context {
     bool           weights_pending = false;
     wmi::BatchWork * batch = nullptr;   // lazily created by wmi_full_batch
     float * d_sinc[3] = {nullptr, nullptr, nullptr};   // resampler coefficient tables on the device, by converter (wmi_resample)
+    float * vad_res = nullptr;          // pinned host memory the VAD kernel writes {decision, energy_all, energy_last} into (wmi_vad)
+    float * dsp_scratch = nullptr; size_t dsp_scratch_bytes = 0;   // grow-only device staging of the host-pointer forms of wmi_vad / wmi_downmix_stereo / wmi_resample
     // the compute code reaches its working set through ctx.state: the *_with_state entry points install the caller's
     // state for the duration of the call under this lock (calls on one context serialise; the GPU runs them in order anyway)
     std::recursive_mutex mu;
