@@ -199,9 +199,12 @@ __global__ __launch_bounds__(QW * KS * 64) void k_attn_enc2(const __half * __res
         }
         const float negm = m == -INFINITY ? 0.0f : -m;             // a key group without a valid key: s = -inf everywhere, e = 0
         const float2v nm2 = {negm, negm}, sc2 = {0.125f, 0.125f};
-        half8 pf[2][2];
+        // per 32-key block: numerators, then that block's P.V MFMAs — the matrix pipe works on block 0 while the VALU forms the numerators
+        // of block 1 (in program order "all numerators, then all P.V" a wavefront's own MFMAs and VALU work never overlapped)
+        const unsigned char * sv = st + 8192;
 #pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
+        for (int blk = 0; blk < 2; ++blk) {
+            half8 pf[2];
 #pragma unroll
             for (int pr = 0; pr < 8; ++pr) {
                 const float2v s2 = {s[blk][2 * pr], s[blk][2 * pr + 1]};
@@ -214,19 +217,17 @@ __global__ __launch_bounds__(QW * KS * 64) void k_attn_enc2(const __half * __res
                 const float2v e2 = {__builtin_amdgcn_exp2f(x0), __builtin_amdgcn_exp2f(x1)};
                 const half2v eh = __builtin_convertvector(e2, half2v);           // ... and its f16 entry
                 l = __builtin_amdgcn_fdot2(eh, ones, l, false);
-                pf[blk][pr >> 2][2 * (pr & 3)] = eh[0];
-                pf[blk][pr >> 2][2 * (pr & 3) + 1] = eh[1];
+                pf[pr >> 2][2 * (pr & 3)] = eh[0];
+                pf[pr >> 2][2 * (pr & 3) + 1] = eh[1];
             }
-        const unsigned char * sv = st + 8192;
-#pragma unroll
-        for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
                     const half8 vf = *(const half8 *) (sv + lds_off(mt * 32 + i, blk * 4 + u * 2 + g));
-                    o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[blk][u], o[mt], 0, 0, 0);
+                    o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u], o[mt], 0, 0, 0);
                 }
+        }
     }
     l += xor_lane<32>(l);                                          // the two lanes of a query row saw disjoint keys
 
