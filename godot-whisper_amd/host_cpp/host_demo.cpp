@@ -1,6 +1,7 @@
 // Command-line driver of the C++ host mirror (tests/test_host_cpp.py):
 //   wmi_host_demo <model.ggml> <pcm.f32> <mode> [language] [initial_prompt] [audio_ctx]
-// mode: transcribe | vad | stream | batch (pcm file = several buffers, see below)
+// mode: transcribe | vad | stream | batch (pcm file = several buffers, see below) | resample (pcm file = interleaved stereo frames;
+//       language = mix rate, prompt = interpolator type: prints the frame count, an FNV-1a hash of the frames' bits and the error string)
 // Prints one JSON document on stdout.  pcm.f32: raw little-endian float32 mono 16 kHz; for `batch` the file starts with
 // int32 n, then n x int32 lengths, then the buffers back to back.
 #include "speech_to_text.h"
@@ -74,6 +75,16 @@ int main(int argc, char ** argv) {
     node.set_language(language);
     node.set_language_model(model.data(), model.size());
     if (!node.context()) { printf("{\"ok\": false, \"error\": \"no context\"}\n"); return 1; }
+    if (mode == "resample") {
+        std::vector<float> xy((const float *) raw.data(), (const float *) raw.data() + raw.size() / 4);
+        const auto out = node.resample(xy, (SpeechToText::InterpolatorType) atoi(prompt.c_str()), language);
+        uint64_t hsh = 1469598103934665603ull;
+        for (float v : out) { uint32_t b; memcpy(&b, &v, 4); for (int k = 0; k < 4; ++k) { hsh ^= (b >> (8 * k)) & 0xff; hsh *= 1099511628211ull; } }
+        printf("{\"frames\": %zu, \"fnv1a\": \"%016llx\", \"error\": ", out.size(), (unsigned long long) hsh);
+        json_string(node.last_resample_error);
+        printf("}\n");
+        return 0;
+    }
     if (mode == "batch") {
         const int32_t * h = (const int32_t *) raw.data();
         const int n = h[0];

@@ -1,5 +1,6 @@
 // see speech_to_text.h.  Reference lines are cited per function.
 #include "speech_to_text.h"
+#include <algorithm>
 
 #include <cmath>
 #include <cstdio>
@@ -27,6 +28,23 @@ void SpeechToText::set_language_model(const uint8_t * data, size_t size) {   // 
     if (data == nullptr || size == 0) return;
     const whisper_context_params context_params{ settings.use_gpu };
     context_instance = whisper_init_from_buffer_with_params((void *) data, size, context_params);
+}
+
+std::vector<float> SpeechToText::resample(const std::vector<float> & interleaved_xy, InterpolatorType interpolator_type, int mix_rate) {   // src/speech_to_text.cpp:353-376
+    last_resample_error.clear();
+    const int64_t buffer_len = (int64_t) (interleaved_xy.size() / 2);
+    const uint32_t expected_size = (uint32_t) (buffer_len * WHISPER_SAMPLE_RATE / mix_rate);
+    if (!context_instance || buffer_len == 0) return {};
+    std::vector<float> buffer_float((size_t) buffer_len);
+    if (wmi_downmix_stereo(context_instance, interleaved_xy.data(), (int) buffer_len, 0, buffer_float.data()) != 0) return {};   // _vector2_array_to_float_array
+    std::vector<float> resampled_float((size_t) std::max<int64_t>(expected_size, mix_rate == WHISPER_SAMPLE_RATE ? buffer_len : 0) + 1);
+    int result_size = wmi_resample(context_instance, buffer_float.data(), (int) buffer_len, mix_rate, WHISPER_SAMPLE_RATE, (int) interpolator_type, 0,
+                                   resampled_float.data(), (int) resampled_float.size());                                        // _resample_audio_buffer
+    if (result_size < 0) result_size = 0;                                                                                      // converter error: 0 frames
+    if ((uint32_t) result_size != expected_size)
+        last_resample_error = "size differ exp: " + std::to_string(expected_size) + " res: " + std::to_string(result_size);
+    resampled_float.resize((size_t) result_size);
+    return resampled_float;
 }
 
 bool SpeechToText::voice_activity_detection(const std::vector<float> & buffer) const {     // src/speech_to_text.cpp:378-399

@@ -56,6 +56,13 @@ public:
     // set_language_model(Ref<WhisperResource>) + _load_model(): the resource's bytes (src/resource_whisper.h)
     void set_language_model(const uint8_t * data, size_t size);
 
+    // src/speech_to_text.h:151-155, :162 — resample(PackedVector2Array buffer, InterpolatorType): stereo capture frames at the mix rate
+    // -> mono 16 kHz.  The reference folds on the CPU and calls libsamplerate's src_simple; here both steps run on the device
+    // (wmi_downmix_stereo, wmi_resample: the same arithmetic frame for frame).  `mix_rate` stands in for AudioServer::get_mix_rate().
+    enum InterpolatorType { SRC_SINC_BEST_QUALITY = 0, SRC_SINC_MEDIUM_QUALITY = 1, SRC_SINC_FASTEST = 2 };
+    std::vector<float> resample(const std::vector<float> & interleaved_xy, InterpolatorType interpolator_type, int mix_rate);
+    std::string last_resample_error;      // what the reference ERR_PRINTs ("size differ exp: ... res: ...")
+
     bool voice_activity_detection(const std::vector<float> & buffer) const;
     Transcription transcribe(const std::vector<float> & buffer, const std::string & initial_prompt, int audio_ctx);
     // not in the reference: several buffers in lock-step on one GPU (include/wmi_device.h: wmi_full_batch); element c is
@@ -84,8 +91,7 @@ public:
 };
 std::string remove_special_characters(std::string message);          // addon/audio_stream_to_text.gd:64-88
 
-// addon/capture_stream_to_text.gd: the streaming loop over a pre-recorded 16 kHz buffer (resampling stays with
-// libsamplerate in the real host)
+// addon/capture_stream_to_text.gd: the streaming loop over a pre-recorded 16 kHz buffer (capture frames go through resample() first)
 class CaptureStreamToText : public SpeechToText {
 public:
     using SpeechToText::SpeechToText;
