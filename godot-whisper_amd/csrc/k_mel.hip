@@ -9,6 +9,7 @@
 // and contributes < 1 % of a transcription.
 
 #include "kernels.h"
+#include <type_traits>
 #include "wave_ops.h"
 #include <climits>
 #include <cmath>
@@ -290,28 +291,61 @@ __global__ void k_downmix(const float2 * __restrict__ frames, int n, float * __r
 // _high_pass_filter + _vad_simple (src/speech_to_text.cpp:53-104), operation for operation.  The filter runs IN PLACE, so its
 // "previous input" data[i - 1] is the previous OUTPUT: y_i = alpha * ((y_{i-1} + x_i) - y_{i-1}) — a recurrence through f32
 // rounding only, but a recurrence: it and the two running f32 energy sums are evaluated by ONE lane in sample order (48 000
-// samples x ~15 dependent cycles = 0.3 ms against a 300 ms cadence); the other lanes stage the samples through LDS.
+// samples x ~45 cycles of dependent single-lane VALU issue = 0.9 ms per call against a 300 ms cadence); the other lanes stage the samples through LDS.
 // res: {decision (1.0 = "no activity"), energy_all, energy_last}
 __global__ __launch_bounds__(256) void k_vad(const float * __restrict__ x, int n, int n_last, float alpha, int filter, float vad_thold,
                                              float * __restrict__ res) {
     constexpr int CHUNK = 8192;
-    __shared__ float buf[CHUNK];
+    __shared__ __attribute__((aligned(16))) float buf[CHUNK];
     float y = 0.0f, e_all = 0.0f, e_last = 0.0f;
+    const int first_last = n - n_last;                      // samples from here on also count towards energy_last
     for (int c0 = 0; c0 < n; c0 += CHUNK) {
         const int m = min(CHUNK, n - c0);
         for (int i = threadIdx.x; i < m; i += 256) buf[i] = x[c0 + i];
         __syncthreads();
         if (threadIdx.x == 0) {
-            for (int i = 0; i < m; ++i) {
-                const int gi = c0 + i;
-                float v = buf[i];
-                if (filter) {
-                    if (gi == 0) y = v;
-                    else { y = __fmul_rn(alpha, __fsub_rn(__fadd_rn(y, v), y)); v = y; }
+            // eight samples per trip come out of LDS with two 16-byte reads BEFORE the dependent chain touches them (one ds_read_b32 per
+            // sample inside the chain was a ~100-cycle LDS round trip per sample: 1.8 ms per 3 s window); the special cases (very first
+            // sample, start of the energy_last tail) split the range instead of sitting in the loop body.  The arithmetic and its order
+            // are unchanged: y = alpha * ((y + v) - y), e_all += |y|, e_last += |y| over the tail.
+            auto run = [&](int i0, int i1, auto tail_tag) {
+                constexpr bool TAIL = decltype(tail_tag)::value;
+                int i = i0;
+                for (; i < i1 && (i & 3); ++i) {                   // up to the next 16-byte boundary
+                    float v = buf[i];
+                    if (filter) { y = __fmul_rn(alpha, __fsub_rn(__fadd_rn(y, v), y)); v = y; }
+                    e_all = __fadd_rn(e_all, fabsf(v));
+                    if (TAIL) e_last = __fadd_rn(e_last, fabsf(v));
                 }
+                for (; i + 8 <= i1; i += 8) {
+                    const float4 a4 = *(const float4 *) (buf + i), b4 = *(const float4 *) (buf + i + 4);
+                    const float v8[8] = {a4.x, a4.y, a4.z, a4.w, b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        float v = v8[u];
+                        if (filter) { y = __fmul_rn(alpha, __fsub_rn(__fadd_rn(y, v), y)); v = y; }
+                        e_all = __fadd_rn(e_all, fabsf(v));
+                        if (TAIL) e_last = __fadd_rn(e_last, fabsf(v));
+                    }
+                }
+                for (; i < i1; ++i) {
+                    float v = buf[i];
+                    if (filter) { y = __fmul_rn(alpha, __fsub_rn(__fadd_rn(y, v), y)); v = y; }
+                    e_all = __fadd_rn(e_all, fabsf(v));
+                    if (TAIL) e_last = __fadd_rn(e_last, fabsf(v));
+                }
+            };
+            int i0 = 0;
+            if (c0 == 0) {                                         // the filter starts from the first sample itself (y = data[0])
+                const float v = buf[0];
+                if (filter) y = v;
                 e_all = __fadd_rn(e_all, fabsf(v));
-                if (gi >= n - n_last) e_last = __fadd_rn(e_last, fabsf(v));
+                if (first_last <= 0) e_last = __fadd_rn(e_last, fabsf(v));
+                i0 = 1;
             }
+            const int split = min(max(first_last - c0, i0), m);    // [i0, split): body, [split, m): also energy_last
+            run(i0, split, std::false_type{});
+            run(split, m, std::true_type{});
         }
         __syncthreads();
     }
