@@ -592,6 +592,19 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
     }
     int rg = blockIdx.x;
 
+    // ---- epilogue operands of this workgroup's first row group (bias, residual, cache slot): they depend on nothing this launch
+    // computes, so they are requested before everything else — loaded inside the epilogue they were one more dependent round trip
+    // (~1 us of a ~5 us launch, 8 launches per decoder layer of the one-row step)
+    float bias_pre = 0.0f, resid_pre = 0.0f; int ro_pre = 0;
+    {
+        const int nl = tid & 31, r = tid >> 5, nf = rg * 32 + nl;
+        if (tid < 32 * R8 && r < n && nf < a.N && rg < ngroups) {
+            if (a.bias) bias_pre = a.bias[nf];
+            if (a.epi == EPI_F32_BIAS_RESID) resid_pre = a.resid[(size_t) r * a.ldr + nf];
+            if (a.row_off) ro_pre = a.lanes ? a.row_off[r * a.step_stride] : *a.row_off;
+        }
+    }
+
     // ---- first weight tiles of this wavefront (independent of the activations)
     uint32_t wq[CH][QW], wh[CH][HW];
     auto load_tiles = [&](int g, int c0) {
@@ -834,15 +847,16 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
             float v = red[(size_t) nl * R8 + r];
 #pragma unroll
             for (int w = 1; w < NW; ++w) v += red[(size_t) (w * 32 + nl) * R8 + r];
-            const float bias = a.bias ? a.bias[nf] : 0.0f;
+            const bool pre = rg == (int) blockIdx.x && e == tid;          // this thread's prefetched element
+            const float bias = pre ? bias_pre : (a.bias ? a.bias[nf] : 0.0f);
             switch (a.epi) {
                 case EPI_F16_BIAS:       ((__half *) a.C)[(size_t) r * a.ldc + nf] = f2h(v + bias); break;
                 case EPI_F16_BIAS_GELU:  ((__half *) a.C)[(size_t) r * a.ldc + nf] = f2h(gelu16(v + bias)); break;
-                case EPI_F32_BIAS_RESID: ((float *) a.C)[(size_t) r * a.ldc + nf] = (v + bias) + a.resid[(size_t) r * a.ldr + nf]; break;
+                case EPI_F32_BIAS_RESID: ((float *) a.C)[(size_t) r * a.ldc + nf] = (v + bias) + (pre ? resid_pre : a.resid[(size_t) r * a.ldr + nf]); break;
                 case EPI_Q_SCALED:       ((__half *) a.C)[(size_t) r * a.ldc + nf] = f2h((v + bias) * a.scale); break;
                 case EPI_QKV_DEC: {
                     const int seg = nf / a.S, c = nf - seg * a.S;
-                    const int ro = a.row_off ? (a.lanes ? a.row_off[r * a.step_stride] : *a.row_off) : 0;
+                    const int ro = pre ? ro_pre : (a.row_off ? (a.lanes ? a.row_off[r * a.step_stride] : *a.row_off) : 0);
                     const int64_t crow = a.lanes ? (int64_t) r * a.cache_row_stride : 0;
                     const int slot = a.lanes ? ro : r + ro;
                     if (seg == 0)      ((__half *) a.C)[(size_t) r * a.ldc + c] = f2h((v + bias) * a.scale);
