@@ -35,8 +35,31 @@ def run():
     prod.close(); chk.close()
     node = host.AudioStreamToText(lib); node.set_language_model(model)
     text = node.get_text(pcm)
+    dsp = _resampler_check(lib, node)
     node.close()
-    print("smoke ok: micro.en 4 s chunk, logits within 6e-2 of the oracle, greedy tokens identical; text =", repr(text[:40]))
+    print("smoke ok: micro.en 4 s chunk, logits within 6e-2 of the oracle, greedy tokens identical; text =", repr(text[:40]) + dsp)
+
+
+def _resampler_check(lib, node) -> str:
+    """0.5 s of 44.1 kHz capture frames through the node's device resampler against oracle/host_dsp.c (bit for bit), when that checker is built."""
+    import ctypes as C, pathlib, struct
+    root = pathlib.Path(__file__).resolve().parent.parent
+    so = root / "oracle" / "liboracle_dsp.so"
+    if not so.exists():
+        return ""
+    raw = (root / "godot-whisper_amd" / "csrc" / "data" / "sinc_fastest.bin").read_bytes()
+    inc, cnt = struct.unpack("<ii", raw[:8]); tab = np.frombuffer(raw[8:], "<f4", cnt).copy()
+    dsp = C.CDLL(str(so))
+    dsp.oracle_resample_audio_buffer.restype = C.c_uint32
+    dsp.oracle_resample_audio_buffer.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    n = 22050
+    x = (0.3 * np.random.default_rng(5).standard_normal(n)).astype(np.float32)
+    want = np.zeros(n, np.float32)
+    nw = dsp.oracle_resample_audio_buffer(x.ctypes.data, n, 44100, 16000, tab.ctypes.data, cnt, inc, want.ctypes.data)
+    got = np.zeros(n, np.float32)
+    ng = lib.wmi_resample(node.ctx, x.ctypes.data_as(C.c_void_p), n, 44100, 16000, 2, 0, got.ctypes.data_as(C.c_void_p), n)
+    assert ng == nw and got[:ng].tobytes() == want[:nw].tobytes(), (ng, nw)
+    return f"; resampler 44.1 -> 16 kHz: {ng} frames identical to the sequential converter"
 
 
 def _quiet(lib):
