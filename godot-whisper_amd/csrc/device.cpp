@@ -755,7 +755,8 @@ double bench_greedy_step_chain(whisper_context & ctx, int iters) {
 // number of wavefront records, and two optional mid points (k_gemv1: activation row ready, first row tile reduced; -1 if absent).  Returns the number of launches (<= cap), -1 when there is no step to replay.
 int step_stamps(whisper_context & ctx, double * out, int cap, bool chained) {
     State & st = *ctx.state; DeviceState & d = st.dev;
-    if (!d.step_dev || ctx.model.quantised || cap <= 0) return -1;
+    if (!d.step_dev || cap <= 0) return -1;
+    if (ctx.model.quantised) chained = false;               // (the block-quantised step has one form)
     const int Tc = st.enc_n_ctx > 0 ? st.enc_n_ctx : ctx.model.hp.n_audio_ctx;
     hipStream_t s = d.stream;
     const bool long_kv = ((const k::DecStep *) d.step_host)->n_kv > 64;

@@ -563,6 +563,8 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
     constexpr int CH = NW == 16 ? 5 : NW == 8 ? 3 : 5;      // weight tiles in flight per wavefront (K = 5120 / 1280: everything at once)
     constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const unsigned long long ts0 = stamp_t0(a.stamps);     // probe (wmi_step_stamps): entry, activation rows quantised, tiles multiplied, end
+    unsigned long long tm1 = 0, tm2 = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int K = a.K, n = a.n, nb = K >> 5, np = K >> 6;
     const int lda = K + 16;                                  // bytes per quantised row in LDS (+16: the fragment reads of 16 rows spread over the banks)
@@ -776,6 +778,7 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
     // scale slots of absent rows: finite zeros (they are multiplied, never stored)
     if (n < R8) for (int e = tid; e < nb * R8; e += NT) { if ((e % R8) >= n) { sd[e] = 0.0f; ss[e] = 0.0f; } }
     __syncthreads();
+    if (a.stamps) tm1 = wall_clock64();
 
     const int arow = (lane & 31) < n ? (lane & 31) : 0;     // activation row this lane feeds the MFMA with
     const int fk = lane >> 5;
@@ -830,6 +833,7 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
                 }
             }
         }
+        if (a.stamps && !tm2) { asm volatile("" :: "v"(out[0])); tm2 = wall_clock64(); }
         // the next row group's first tiles go out before this one is reduced (the vocabulary projection walks ~1.6 groups per workgroup)
         const int rgn = rg + nmain;
         const bool more = rgn < ngroups;
@@ -869,6 +873,7 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
         }
         (void) more;
     }
+    stamp_end(a.stamps, a.stamp_slot, (int) blockIdx.x * NW + wave, ts0, tm1, tm2);
 }
 
 template <int QT, int NR4, int SRC, int NW>
@@ -978,7 +983,9 @@ void qgemm(int epi, const GemmArgs & a, Q8Rows A, QMat W, hipStream_t st) {
     }
 }
 
-void qrows(const GemvArgs & a, const float * a32, QMat W, hipStream_t st) {
+void qrows(const GemvArgs & a_in, const float * a32, QMat W, hipStream_t st) {
+    GemvArgs a = a_in;
+    { const Stamp sp = stamp_next(); a.stamps = sp.base; a.stamp_slot = sp.slot; }
     switch (W.qtype) {
         case QT_Q4_0: qrows_t<QT_Q4_0>(a, a32, W.tiles, st); break;
         case QT_Q4_1: qrows_t<QT_Q4_1>(a, a32, W.tiles, st); break;
