@@ -666,17 +666,20 @@ int wmi_selftest_quant(int device, int qtype, int mode, const void * w_blocks, c
                        int M, int N, int K, float * out, int8_t * out_qs, float * out_ds) {
     const k::QGeom g = k::q_geom(qtype);
     if (!g.qb || M < 1 || N < 1 || K < 64 || (K % 64) != 0 || !w_blocks || !out) return -1;
-    if ((mode == 0 && M > 32) || (mode == 1 && (N % 128) != 0) || mode < 0 || mode > 2 || (mode == 2 ? !tokens : !x)) return -1;
+    // mode 0: <= 32 rows through k_qrows; 1: the block-dot GEMM; 2: embedding gather; 3: the f16 form of the GEMM (k_qdequant + k_gemm)
+    if ((mode == 0 && M > 32) || ((mode == 1 || mode == 3) && (N % 128) != 0) || mode < 0 || mode > 3 || (mode == 2 ? !tokens : !x)) return -1;
     if (!HIP_OK(hipSetDevice(device))) return -2;
     const int nb = K / 32;
     std::vector<uint8_t> tiles(k::q_matrix_bytes(qtype, N, K));
     k::q_repack_host(qtype, (const uint8_t *) w_blocks, N, K, tiles.data());
     uint8_t * d_t = nullptr; float * d_x = nullptr, * d_o = nullptr, * d_z = nullptr; int8_t * d_qs = nullptr; float * d_ds = nullptr; int32_t * d_tok = nullptr;
+    __half * d_a16 = nullptr, * d_w16 = nullptr;
     const size_t n_out = (size_t) M * (mode == 2 ? K : N);
     bool ok = HIP_OK(hipMalloc((void **) &d_t, tiles.size() + 4096)) && HIP_OK(hipMalloc((void **) &d_x, (size_t) M * K * 4)) &&
               HIP_OK(hipMalloc((void **) &d_o, n_out * 4)) && HIP_OK(hipMalloc((void **) &d_z, n_out * 4)) &&
               HIP_OK(hipMalloc((void **) &d_qs, (size_t) M * K)) && HIP_OK(hipMalloc((void **) &d_ds, (size_t) M * nb * 8)) &&
               HIP_OK(hipMalloc((void **) &d_tok, (size_t) M * 4 * 2));
+    if (mode == 3) ok = ok && HIP_OK(hipMalloc((void **) &d_a16, (size_t) M * K * 2)) && HIP_OK(hipMalloc((void **) &d_w16, (size_t) N * K * 2));
     hipStream_t st = nullptr;
     ok = ok && HIP_OK(hipStreamCreate(&st));
     if (ok) {
@@ -689,7 +692,8 @@ int wmi_selftest_quant(int device, int qtype, int mode, const void * w_blocks, c
             ok = HIP_OK(hipMemcpy(d_tok, tp.data(), tp.size() * 4, hipMemcpyHostToDevice));
             k::qdec_embed(d_tok, d_tok + M, M, K, W, d_z, d_o, st);           // "positional embedding" = zeros
         } else if (ok) {
-            const k::Q8Rows A{d_qs, d_ds, d_ds + (size_t) nb * M, M};
+            k::Q8Rows A{d_qs, d_ds, d_ds + (size_t) nb * M, M};
+            if (mode == 3) { A.deq = d_a16; A.wdeq = d_w16; A.wdeq_elems = (size_t) N * K; }
             k::quantize_rows(d_x, nullptr, M, K, nullptr, nullptr, 0.f, qtype, A, nullptr, nullptr, st);
             if (mode == 0) {
                 k::GemvArgs ga{};
@@ -698,7 +702,8 @@ int wmi_selftest_quant(int device, int qtype, int mode, const void * w_blocks, c
             } else {
                 k::GemmArgs a{};
                 a.M = M; a.N = N; a.K = K; a.C = d_o; a.ldc = N; a.resid = d_z; a.ldr = N;
-                k::qgemm(k::EPI_F32_BIAS_RESID, a, A, W, st);
+                if (mode == 3) { k::qdequant(W, 0, N, K, d_w16, st); a.A = d_a16; a.lda = K; a.W = d_w16; a.ldw = K; k::gemm(k::EPI_F32_BIAS_RESID, a, st); }
+                else k::qgemm(k::EPI_F32_BIAS_RESID, a, A, W, st);
             }
         }
         ok = ok && HIP_OK(hipStreamSynchronize(st)) && HIP_OK(hipGetLastError());
@@ -714,6 +719,7 @@ int wmi_selftest_quant(int device, int qtype, int mode, const void * w_blocks, c
     }
     if (st) (void) hipStreamDestroy(st);
     (void) hipFree(d_t); (void) hipFree(d_x); (void) hipFree(d_o); (void) hipFree(d_z); (void) hipFree(d_qs); (void) hipFree(d_ds); (void) hipFree(d_tok);
+    (void) hipFree(d_a16); (void) hipFree(d_w16);
     return ok ? 0 : -3;
 }
 

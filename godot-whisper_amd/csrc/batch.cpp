@@ -70,7 +70,7 @@ bool ensure_batch(whisper_context & ctx, int B) {
     (void) hipStreamSynchronize(s);
     dfree(w.mel_t); dfree(w.conv1); dfree(w.x); dfree(w.xn); dfree(w.q); dfree(w.k); dfree(w.att); dfree(w.vt); dfree(w.h);
     dfree(w.enc_out_h); dfree(w.kvc_k); dfree(w.kvc_v); dfree(w.self_k); dfree(w.self_v); dfree(w.dx); dfree(w.dq); dfree(w.datt); dfree(w.dh);
-    dfree(w.logits); dfree(w.xattn); dfree(w.aq); dfree(w.ads); dfree(w.att32); dfree(w.datt32);
+    dfree(w.logits); dfree(w.xattn); dfree(w.aq); dfree(w.ads); dfree(w.aq16); dfree(w.wq16); dfree(w.att32); dfree(w.datt32);
     if (w.rows_graph.exec) (void) hipGraphExecDestroy(w.rows_graph.exec);          // the captured step holds the old pointers
     if (w.rows_graph.graph) (void) hipGraphDestroy(w.rows_graph.graph);
     w.rows_graph = BatchWork::RowsGraph{};
@@ -96,6 +96,8 @@ bool ensure_batch(whisper_context & ctx, int B) {
     if (ctx.model.quantised) {                               // q8 activation rows of all chunks + f32 attention outputs (device_q.cpp)
         w.aq_rows = (int) (nb * T);
         ok = ok && dalloc(w.aq, nb * T * 4 * S) && dalloc(w.ads, 2 * nb * T * (4 * S / 32)) && dalloc(w.att32, nb * T * S) && dalloc(w.datt32, nb * S);
+        w.wq16_elems = 8 * S * S;
+        ok = ok && dalloc(w.aq16, nb * T * 4 * S) && dalloc(w.wq16, w.wq16_elems);
     }
     ok = ok && HIP_OK(hipMalloc(&w.step_dev, nb * sizeof(k::DecStep))) && HIP_OK(hipMalloc(&w.sample_dev, nb * sizeof(k::SampleOut)))
             && HIP_OK(hipMalloc(&w.filter_scratch, k::filter_scratch_bytes(B)))
@@ -159,8 +161,7 @@ bool encode_rows(whisper_context & ctx, const std::vector<int> & rows, const std
         EncBufsQ e{};
         e.T = T; e.nb = nb; e.Tpad = b.Tpad; e.x = b.x; e.q = b.q; e.k = b.k; e.vt = b.vt; e.h = b.h; e.att32 = b.att32;
         e.enc_out = nullptr; e.enc_out_h = b.enc_out_h; e.kvc_k = b.kvc_k; e.kvc_v = b.kvc_v;
-        e.A = k::Q8Rows{b.aq, b.ads, b.ads + (size_t) (S / 32) * b.aq_rows, b.aq_rows};
-        e.A4 = k::Q8Rows{b.aq, b.ads, b.ads + (size_t) (4 * S / 32) * b.aq_rows, b.aq_rows};
+        e.A = q8_rows(b, S); e.A4 = q8_rows(b, 4 * S);
         if (!encode_layers_q_on(ctx, e, s)) return false;
         HIP_TRY(hipStreamSynchronize(s));
         if (!HIP_OK(hipGetLastError())) return false;
@@ -387,7 +388,7 @@ void free_batch(whisper_context & ctx) {
     BatchWork & w = *ctx.batch;
     dfree(w.mel_t); dfree(w.conv1); dfree(w.x); dfree(w.xn); dfree(w.q); dfree(w.k); dfree(w.att); dfree(w.vt); dfree(w.h);
     dfree(w.enc_out_h); dfree(w.kvc_k); dfree(w.kvc_v); dfree(w.self_k); dfree(w.self_v); dfree(w.dx); dfree(w.dq); dfree(w.datt); dfree(w.dh);
-    dfree(w.logits); dfree(w.xattn); dfree(w.aq); dfree(w.ads); dfree(w.att32); dfree(w.datt32);
+    dfree(w.logits); dfree(w.xattn); dfree(w.aq); dfree(w.ads); dfree(w.aq16); dfree(w.wq16); dfree(w.att32); dfree(w.datt32);
     if (w.rows_graph.exec) (void) hipGraphExecDestroy(w.rows_graph.exec);
     if (w.rows_graph.graph) (void) hipGraphDestroy(w.rows_graph.graph);
     if (w.step_dev) (void) hipFree(w.step_dev);

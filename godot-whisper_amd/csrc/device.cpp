@@ -57,6 +57,8 @@ bool init_state(whisper_context & ctx) {
         const size_t rows = std::max<size_t>(T, n);
         d.aq_rows = (int) rows;
         ok = ok && dalloc(d.aq, rows * 4 * S) && dalloc(d.ads, 2 * rows * (4 * S / 32)) && dalloc(d.att32, T * S) && dalloc(d.datt32, n * S);
+        d.wq16_elems = 8 * S * S;                           // mlp (4 S^2), q|k|v (3 S^2), four layers of cross K | V at a time
+        ok = ok && dalloc(d.aq16, rows * 4 * S) && dalloc(d.wq16, d.wq16_elems);
     }
     d.logits_rows_cap = 8;
     ok = ok && dalloc(d.d_tokens, n) && dalloc(d.d_pos, n) && dalloc(d.d_mask, n * n_self) && dalloc(d.d_rows, n)
@@ -111,7 +113,7 @@ void destroy_state(State * st) {
     dfree(d.xn); dfree(d.q); dfree(d.k); dfree(d.vt); dfree(d.att); dfree(d.h); dfree(d.rowmax); dfree(d.enc_out);
     dfree(d.enc_out_h); dfree(d.d_tokens); dfree(d.d_pos); dfree(d.d_mask); dfree(d.d_rows); dfree(d.dx); dfree(d.dxn);
     dfree(d.dq); dfree(d.datt); dfree(d.dh); dfree(d.logits); dfree(d.xattn); dfree(d.ban_dev);
-    dfree(d.aq); dfree(d.ads); dfree(d.att32); dfree(d.datt32);
+    dfree(d.aq); dfree(d.ads); dfree(d.aq16); dfree(d.wq16); dfree(d.att32); dfree(d.datt32);
     for (auto & sg : d.step_graphs) { if (sg.exec) (void) hipGraphExecDestroy(sg.exec); if (sg.graph) (void) hipGraphDestroy(sg.graph); sg = DeviceState::StepGraph{}; }
     if (d.step_dev) (void) hipFree(d.step_dev);
     if (d.sample_dev) (void) hipFree(d.sample_dev);

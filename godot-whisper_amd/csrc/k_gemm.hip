@@ -487,6 +487,18 @@ void dispatch(const GemmArgs & a, hipStream_t st) {
     if constexpr (EPI == EPI_F16_BIAS_GELU || EPI == EPI_QKV_ENC || EPI == EPI_CROSS_KV || EPI == EPI_F16_BIAS) {
         if (wide && (a.N % 256) == 0 && t256 >= 384 && (a.K % BK) == 0 && !(a.no_glds & 1)) { launch_n<128, 256, EPI, 3, 8>(a, st); return; }
     }
+    // WMI_GEMM_TALL (A/B knob, off): wave tiles of 128 x 64 instead of 64 x 64 on the big grids.  Per k the fragment reads of a wavefront are
+    // (TM + TN) x 2 bytes for 2 TM TN flops: 64 x 64 wave tiles read 1 KB of LDS per 16-cycle MFMA quartet, which together with the DMA writes
+    // is ~1.5x the LDS cycles of the MFMA cycles they feed; 128 x 64 cuts the reads per flop by a quarter.
+    //   1: 256 x 128 tiles, four wavefronts, two-deep ring (96 KB)   2: the same, three-deep (144 KB)   3: 256 x 256, eight wavefronts (128 KB)
+    static const int tall = getenv("WMI_GEMM_TALL") ? atoi(getenv("WMI_GEMM_TALL")) : 0;
+    if constexpr (EPI == EPI_F16_BIAS_GELU) {
+        if (tall && a.M >= 4096 && (a.K % BK) == 0 && (a.N % 256) == 0 && !(a.no_glds & 1)) {
+            if (tall == 1) { launch_n<256, 128, EPI, 2, 4>(a, st); return; }
+            if (tall == 2) { launch_n<256, 128, EPI, 3, 4>(a, st); return; }
+            if (tall == 3) { launch_n<256, 256, EPI, 2, 8>(a, st); return; }
+        }
+    }
     static const long t128_min = getenv("WMI_GEMM_T128") ? atol(getenv("WMI_GEMM_T128")) : 320;        // A/B knob; 376 tiles (out projection at M = 12 000): 18.6 us against 23.0 us as 1 504 tiles of 64 x 64
     if (t128 >= t128_min || (t128 >= 256 && a.K >= 1024)) {
         // Round quantisation on the big grids: two workgroups per CU = 512 resident tiles; q|k|v at M = 12 000 is 1 128 tiles of 128 rows

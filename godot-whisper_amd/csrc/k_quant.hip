@@ -26,6 +26,7 @@
 #include "kernels.h"
 #include "wave_ops.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 #include <type_traits>
@@ -149,6 +150,16 @@ __device__ __forceinline__ uint32_t quant4(float y0, float y1, float y2, float y
     return (uint32_t) (q0 & 0xFF) | ((uint32_t) (q1 & 0xFF) << 8) | ((uint32_t) (q2 & 0xFF) << 16) | ((uint32_t) (q3 & 0xFF) << 24);
 }
 
+// four quants of a block back as f16(d * q): the A operand of the f16 form of the GEMM (qgemm below).  One f32 product, pinned, one
+// rounding: the value does not depend on which slot of an unrolled group computed it
+__device__ __forceinline__ void put_deq(__half * dst, uint32_t q, float d) {
+    const float x0 = (float) (int) (int8_t) (q & 0xFF) * d, x1 = (float) (int) (int8_t) ((q >> 8) & 0xFF) * d;
+    const float x2 = (float) (int) (int8_t) ((q >> 16) & 0xFF) * d, x3 = (float) (int) (int8_t) (q >> 24) * d;
+    const __half2 h01 = __floats2half2_rn(pin_f32(x0), pin_f32(x1)), h23 = __floats2half2_rn(pin_f32(x2), pin_f32(x3));
+    uint2 pk; pk.x = *(const uint32_t *) &h01; pk.y = *(const uint32_t *) &h23;
+    *(uint2 *) dst = pk;
+}
+
 // LayerNorm of a row held as MAXV float4 per lane (columns (i * 64 + lane) * 4), k_norm.hip's arithmetic
 template <int MAXV>
 __device__ __forceinline__ void ln_inplace(float4 (&v)[MAXV], const float4 (&gg)[MAXV], const float4 (&bb)[MAXV], int S, float eps, int lane) {
@@ -189,7 +200,7 @@ template <int MAXV, int SRC, bool F16D>
 __global__ __launch_bounds__(256) void k_q8_rows(const float * __restrict__ x32, const __half * __restrict__ x16, int M, int K,
                                                  const float * __restrict__ g, const float * __restrict__ b, float eps,
                                                  int8_t * __restrict__ qs, float * __restrict__ dT, float * __restrict__ sT, int ldm,
-                                                 float * __restrict__ out32, __half * __restrict__ out16) {
+                                                 float * __restrict__ out32, __half * __restrict__ out16, __half * __restrict__ deq) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
@@ -210,6 +221,7 @@ __global__ __launch_bounds__(256) void k_q8_rows(const float * __restrict__ x32,
             if (c < K) {
                 *(uint32_t *) (qs + (size_t) row * K + c) = q;
                 if ((lane & 7) == 0) { dT[(size_t) (c >> 5) * ldm + row] = d; sT[(size_t) (c >> 5) * ldm + row] = s; }
+                if (deq) put_deq(deq + (size_t) row * K + c, q, d);
                 if (out32) *(float4 *) (out32 + (size_t) row * K + c) = v[i];
                 if (out16) {
                     __half2 h01 = __floats2half2_rn(pin_f32(v[i].x), pin_f32(v[i].y)), h23 = __floats2half2_rn(pin_f32(v[i].z), pin_f32(v[i].w));
@@ -240,6 +252,7 @@ __global__ __launch_bounds__(256) void k_q8_rows(const float * __restrict__ x32,
                 if (c < K) {
                     *(uint32_t *) (qs + (size_t) row * K + c) = q;
                     if ((lane & 7) == 0) { dT[(size_t) (c >> 5) * ldm + row] = d; sT[(size_t) (c >> 5) * ldm + row] = s; }
+                    if (deq) put_deq(deq + (size_t) row * K + c, q, d);
                 }
             }
         }
@@ -955,6 +968,62 @@ __global__ void k_qembed(const int32_t * __restrict__ tokens, const int32_t * __
     }
 }
 
+// ------------------------------------------------------------------------------------------------ f16 form of the GEMM
+// From ~256 activation rows on, the block dots above are VALU-bound (48 scale / convert instructions per 32-cycle MFMA).
+// The large-M projections therefore run as f16 x f16 -> f32 products on k_gemm's tiles: the activation rows are the SAME q8 quants and
+// scales the reference computes, handed over as f16(d_a * q_a) (k_q8_rows, `deq`), the weight blocks as f16(d_w * q_w + m_w) in a scratch
+// image written by k_qdequant right before the GEMM (the weights stay in their blocks in HBM; the image holds one matrix at a time).
+// sum_k (d_w q_w + m_w)(d_a q_a) is the reference's sum_blocks (d_w d_a) isum + m_w s_a with the two factors of every term rounded to f16
+// (2^-11 relative each) before the f32 accumulation — the operand rounding the f16 models have, an order of magnitude below what the
+// reference's own outputs move by when a quant flips (tests/test_gpu_parity.py, the yardstick of the quantised models).
+//
+// k_qdequant: one wavefront per 32 x 64 tile (lane = (row, block of the pair): 32 values = 64 bytes), four K-consecutive tiles per
+// workgroup, turned through LDS so that a row's 512 bytes leave as one run.
+template <int QT>
+__global__ __launch_bounds__(256) void k_qdequant(const uint8_t * __restrict__ Wt, int np, int K, __half * __restrict__ out) {
+    constexpr int QW = Geo<QT>::QW, HW = Geo<QT>::HW, ROWB = 528;
+    __shared__ __attribute__((aligned(16))) unsigned char sm[32 * ROWB];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tp = blockIdx.x * 4 + wave, tn = blockIdx.y;
+    if (tp < np) {
+        const uint8_t * t = Wt + ((size_t) tn * np + tp) * tile_bytes<QT>();
+        uint32_t rq[QW], rh[HW];
+        { const uint4 u = *(const uint4 *) (t + (size_t) lane * QW * 4); rq[0] = u.x; rq[1] = u.y; rq[2] = u.z; rq[3] = u.w; }
+        if constexpr (QW == 8) { const uint4 u = *(const uint4 *) (t + (size_t) lane * 32 + 16); rq[4] = u.x; rq[5] = u.y; rq[6] = u.z; rq[7] = u.w; }
+#pragma unroll
+        for (int h = 0; h < HW; ++h) rh[h] = *(const uint32_t *) (t + 64 * QW * 4 + lane * HW * 4 + h * 4);
+        uint32_t lo[4], hi[4]; float d, m;
+        unpack<QT>(rq, rh, lo, hi, d, m);
+        unsigned char * dst = sm + (lane & 31) * ROWB + wave * 128 + (lane >> 5) * 64;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t w = i < 2 ? lo[2 * i] : hi[2 * (i - 2)], w2 = i < 2 ? lo[2 * i + 1] : hi[2 * (i - 2) + 1];
+            uint32_t pk[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const uint32_t src = e < 2 ? w : w2; const int sh = (e & 1) * 16;
+                const float x0 = (float) (int) (int8_t) ((src >> sh) & 0xFF) * d + m, x1 = (float) (int) (int8_t) ((src >> (sh + 8)) & 0xFF) * d + m;
+                const __half2 h = __floats2half2_rn(pin_f32(x0), pin_f32(x1));
+                pk[e] = *(const uint32_t *) &h;
+            }
+            *(uint4 *) (dst + i * 16) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+        }
+    }
+    __syncthreads();
+    const int k0 = blockIdx.x * 256;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = i * 256 + tid, row = idx >> 5, ch = idx & 31;
+        if (k0 + ch * 8 < K) *(uint4 *) (out + ((size_t) tn * 32 + row) * K + k0 + ch * 8) = *(const uint4 *) (sm + row * ROWB + ch * 16);
+    }
+}
+
+template <int QT> static void qdequant_launch(const uint8_t * Wt, int64_t row0, int64_t rows, int K, __half * out, hipStream_t st) {
+    const int np = K / 64;
+    hipLaunchKernelGGL((k_qdequant<QT>), dim3((np + 3) / 4, (unsigned) ((rows + 31) / 32)), dim3(256), 0, st,
+                       Wt + (size_t) (row0 / 32) * np * tile_bytes<QT>(), np, K, out);
+}
+
 } // namespace
 
 void quantize_rows(const float * x32, const __half * x16, int M, int K, const float * ln_g, const float * ln_b, float eps,
@@ -962,8 +1031,8 @@ void quantize_rows(const float * x32, const __half * x16, int M, int K, const fl
     if (M <= 0) return;
     const dim3 grid((M + 3) / 4), block(256);
     const bool f16d = !q_geom(qtype).has_m;
-#define WMI_Q8(MAXV, SRC) do { if (f16d) hipLaunchKernelGGL((k_q8_rows<MAXV, SRC, true>), grid, block, 0, st, x32, x16, M, K, ln_g, ln_b, eps, out.qs, out.d, out.s, out.ldm, out32, out16); \
-                               else      hipLaunchKernelGGL((k_q8_rows<MAXV, SRC, false>), grid, block, 0, st, x32, x16, M, K, ln_g, ln_b, eps, out.qs, out.d, out.s, out.ldm, out32, out16); } while (0)
+#define WMI_Q8(MAXV, SRC) do { if (f16d) hipLaunchKernelGGL((k_q8_rows<MAXV, SRC, true>), grid, block, 0, st, x32, x16, M, K, ln_g, ln_b, eps, out.qs, out.d, out.s, out.ldm, out32, out16, out.deq); \
+                               else      hipLaunchKernelGGL((k_q8_rows<MAXV, SRC, false>), grid, block, 0, st, x32, x16, M, K, ln_g, ln_b, eps, out.qs, out.d, out.s, out.ldm, out32, out16, out.deq); } while (0)
     if (ln_g) {
         const int nv = (K + 255) / 256;
         if (nv <= 2) WMI_Q8(2, 1); else if (nv <= 4) WMI_Q8(4, 1); else WMI_Q8(6, 1);
@@ -972,7 +1041,41 @@ void quantize_rows(const float * x32, const __half * x16, int M, int K, const fl
 #undef WMI_Q8
 }
 
+void qdequant(QMat W, int64_t row0, int64_t rows, int K, __half * out, hipStream_t st) {
+    switch (W.qtype) {
+        case QT_Q4_0: qdequant_launch<QT_Q4_0>(W.tiles, row0, rows, K, out, st); break;
+        case QT_Q4_1: qdequant_launch<QT_Q4_1>(W.tiles, row0, rows, K, out, st); break;
+        case QT_Q5_0: qdequant_launch<QT_Q5_0>(W.tiles, row0, rows, K, out, st); break;
+        case QT_Q5_1: qdequant_launch<QT_Q5_1>(W.tiles, row0, rows, K, out, st); break;
+        case QT_Q8_0: qdequant_launch<QT_Q8_0>(W.tiles, row0, rows, K, out, st); break;
+        default: break;
+    }
+}
+
 void qgemm(int epi, const GemmArgs & a, Q8Rows A, QMat W, hipStream_t st) {
+    // f16 form (see k_qdequant) from WMI_QGEMM_F16_ROWS activation rows on (0 = never: the block-dot kernel for every M)
+    static const int f16_rows = getenv("WMI_QGEMM_F16_ROWS") ? atoi(getenv("WMI_QGEMM_F16_ROWS")) : 256;
+    if (f16_rows > 0 && a.M >= f16_rows && A.deq && A.wdeq && (a.K % 64) == 0 && (a.N % 32) == 0) {
+        const int64_t cap = (int64_t) (A.wdeq_elems / (size_t) a.K) / 32 * 32;               // weight rows the image holds
+        GemmArgs g = a; g.A = A.deq; g.lda = a.K; g.W = A.wdeq; g.ldw = a.K;
+        if (epi == EPI_CROSS_KV && cap >= 2 * a.S) {
+            // the decoder layers' K | V projections, as many layers at a time as the image holds
+            const int layers = a.N / (2 * a.S), per = (int) std::min<int64_t>(layers, cap / (2 * a.S));
+            for (int l0 = 0; l0 < layers; l0 += per) {
+                const int nl = std::min(per, layers - l0);
+                qdequant(W, (int64_t) l0 * 2 * a.S, (int64_t) nl * 2 * a.S, a.K, A.wdeq, st);
+                g.N = nl * 2 * a.S; g.bias = a.bias ? a.bias + (size_t) l0 * 2 * a.S : nullptr;
+                g.C = (__half *) a.C + (size_t) l0 * a.layer_stride; g.aux = (__half *) a.aux + (size_t) l0 * a.layer_stride;
+                gemm(epi, g, st);
+            }
+            return;
+        }
+        if (epi != EPI_CROSS_KV && a.N <= cap) {
+            qdequant(W, 0, a.N, a.K, A.wdeq, st);
+            gemm(epi, g, st);
+            return;
+        }
+    }
     switch (W.qtype) {
         case QT_Q4_0: qgemm_epi<QT_Q4_0>(epi, a, A, W.tiles, st); break;
         case QT_Q4_1: qgemm_epi<QT_Q4_1>(epi, a, A, W.tiles, st); break;

@@ -294,7 +294,9 @@ struct QMat { const uint8_t * tiles = nullptr; int qtype = QT_NONE; };
 // activation rows as q8 blocks in global memory (the GEMM's A operand): qs [M][K] int8; scales block-major d [K / 32][ldm],
 // s [K / 32][ldm] (the GEMM fetches the scales of 64 / 128 consecutive rows of one block with one load per wavefront);
 // s = d * sum(q) for the q8_1 kinds; for the q8_0 kinds d is rounded to f16 as the reference stores it and s = 0
-struct Q8Rows { int8_t * qs; float * d; float * s; int ldm; };
+// deq (optional): the same rows as f16(d * q) [M][K] — the A operand of the f16 form of qgemm; wdeq / wdeq_elems: scratch image for one
+// dequantised weight matrix (or a group of cross K | V layers) [rows][K] f16
+struct Q8Rows { int8_t * qs; float * d; float * s; int ldm; __half * deq = nullptr; __half * wdeq = nullptr; size_t wdeq_elems = 0; };
 // rows -> q8.  Exactly one source: x32 (+ optional LayerNorm gain/bias: y = LN(x) * g + b in f32, the reference quantises that
 // f32 tensor) or x16 (an f16 tensor, e.g. the GELU output, widened exactly).  out32 / out16: optional copy of the LN result.
 void quantize_rows(const float * x32, const __half * x16, int M, int K, const float * ln_g, const float * ln_b, float eps,
@@ -303,6 +305,8 @@ void quantize_rows(const float * x32, const __half * x16, int M, int K, const fl
 // C[M][N] = A_q8[M][K] . W_q[N][K]^T with the GEMM's epilogues (Epi above; GemmArgs fields A / W / lda / ldw unused).
 // N % 128 == 0, K % 64 == 0.
 void qgemm(int epi, const GemmArgs & a, Q8Rows A, QMat W, hipStream_t st);
+// rows [row0, row0 + rows) of a quantised matrix (row0 % 32 == 0) as f16(d * q + m) [rows][K]
+void qdequant(QMat W, int64_t row0, int64_t rows, int K, __half * out, hipStream_t st);
 
 // <= 32 activation rows against a quantised matrix: the weight tiles are streamed once, the rows are quantised in the
 // prologue of every workgroup (LayerNorm of x32 if ln_g, plain f32 rows a32, or f16 rows a16) — GemvArgs as for gemv();

@@ -203,6 +203,7 @@ struct DeviceState {
     float  * rowmax = nullptr;                                // [H][T] f32 (attention pass A)
     // block-quantised models only: activation rows as q8 blocks (the quantised GEMMs' A operand) and f32 attention outputs
     int8_t * aq = nullptr;  float * ads = nullptr;  int aq_rows = 0;   // [rows][4S] int8; scales d [K / 32][rows] | s [K / 32][rows], rows = max(T, n_text_ctx)
+    __half * aq16 = nullptr, * wq16 = nullptr; size_t wq16_elems = 0;  // f16 form of the large-M projections (k_quant.hip, k_qdequant): rows as f16(d q) [rows][4S]; one dequantised weight matrix
     float  * att32 = nullptr;                                 // [T][S] f32
     float  * datt32 = nullptr;                                // [n_text_ctx][S] f32
     float  * enc_out = nullptr;                               // [T][S] f32  (embd_enc)
@@ -274,6 +275,7 @@ struct BatchWork {
     float  * dx = nullptr; __half * dq = nullptr, * datt = nullptr, * dh = nullptr; float * logits = nullptr, * xattn = nullptr;
     // block-quantised models: q8 activation rows [B*T][4S] + block scales, f32 attention outputs (device_q.cpp)
     int8_t * aq = nullptr; float * ads = nullptr; int aq_rows = 0; float * att32 = nullptr, * datt32 = nullptr;
+    __half * aq16 = nullptr, * wq16 = nullptr; size_t wq16_elems = 0;  // as DeviceState's
     void   * step_dev = nullptr, * step_host = nullptr, * sample_dev = nullptr, * sample_host = nullptr, * filter_scratch = nullptr;
     int      enc_rows = 0, enc_T = 0;                         // chunk rows / encoder length of the last batched encode
     int32_t  step_seq = 0;                                    // sequence number of the last lock-step decode step
@@ -327,7 +329,9 @@ bool set_mel(whisper_context & ctx, const float * data, int n_len, int n_mel);
 bool encode(whisper_context & ctx, int mel_offset);
 bool decode(whisper_context & ctx, const Batch & batch);
 // block-quantised models (device_q.cpp): the layer loops of encode() / decode() with the quantised kernels
-inline k::Q8Rows q8_rows(const DeviceState & d, int K) { return k::Q8Rows{d.aq, d.ads, d.ads + (size_t) (K / 32) * d.aq_rows, d.aq_rows}; }
+template <typename BUFS> inline k::Q8Rows q8_rows(const BUFS & d, int K) {
+    return k::Q8Rows{d.aq, d.ads, d.ads + (size_t) (K / 32) * d.aq_rows, d.aq_rows, d.aq16, d.wq16, d.wq16_elems};
+}
 bool encode_layers_q(whisper_context & ctx, int T);
 // the same layer loop over caller-supplied buffers: nb chunks stacked along M (lock-step, batch.cpp) — activations [nb*T][S],
 // V^T [nb][S][Tpad], cross cache [L][nb*T][S]

@@ -200,6 +200,8 @@ WHISPER_API int wmi_selftest_resample_plan(int n_frames, int src_rate, int dst_r
  * (W/ggml-quants.c:837-870) and multiplied with the integer-dot kernels:
  *   mode 0  weight-streaming row kernel (M <= 32)        mode 1  tiled GEMM (N % 128 == 0)
  *   mode 2  x ignored; M token ids in `tokens`: out[M][K] = dequantised rows `tokens[i]` of the matrix (get_rows)
+ *   mode 3  the large-M form of mode 1 (N % 128 == 0): the same q8 rows as f16(d_a q_a) against the blocks as f16(d_w q_w + m_w) on the
+ *           f16 MFMA GEMM, f32 accumulation (what encode uses from 256 activation rows on; WMI_QGEMM_F16_ROWS=0 keeps mode 1's kernel)
  * out [M][N] f32 (mode 2: [M][K]); out_qs [M][K] int8 and out_ds [M][K/32][2] {d, s} receive the quantised rows when non-NULL.
  * Returns 0, or a negative value on a bad argument / device error. */
 WHISPER_API int wmi_selftest_quant(int device, int qtype, int mode, const void * w_blocks, const float * x, const int32_t * tokens,

@@ -19,5 +19,5 @@ assert lib.whisper_pcm_to_mel(node.ctx, pcm.ctypes.data_as(C.POINTER(C.c_float))
 lib.whisper_encode(node.ctx, 0, 4)
 t0 = time.perf_counter(); n = 5
 for _ in range(n): lib.whisper_encode(node.ctx, 0, 4)
-print(os.environ.get("WMI_QGEMM_BM"), os.environ.get("WMI_QGEMM_NST"), "encode ms", round((time.perf_counter() - t0) / n * 1e3, 2), "fc1 us", round(lib.wmi_bench_kernel(node.ctx, 0, 50), 1), flush=True)
+print("BM", os.environ.get("WMI_QGEMM_BM"), "NST", os.environ.get("WMI_QGEMM_NST"), "F16_ROWS", os.environ.get("WMI_QGEMM_F16_ROWS"), "encode ms", round((time.perf_counter() - t0) / n * 1e3, 2), "fc1 us", round(lib.wmi_bench_kernel(node.ctx, 0, 50), 1), flush=True)
 node.close()

@@ -87,6 +87,32 @@ def test_quantised_matmul_against_the_oracle(product_lib, qtype, mode, M, N, K):
 
 
 @pytest.mark.parametrize("qtype", list(QT))
+@pytest.mark.parametrize("M,N,K", [(300, 256, 128), (77, 128, 384), (1500, 384, 1280), (260, 128, 5120)])
+def test_quantised_matmul_f16_form_against_the_oracle(product_lib, qtype, M, N, K):
+    """The large-M form of the quantised projections (k_qdequant + the f16 GEMM): the activation rows are the reference's own
+    q8 quants and scales (bit-identical, as above); the product rounds each factor of each term — f16(d_w q_w + m_w), f16(d_a q_a) — to
+    f16 before the f32 accumulation, so |out - reference| <= (2^-11 + 2^-11 + f32 slack) * sum_k |w_k||x_k| element by element, and
+    ~2^-11 in the rms (independent roundings)."""
+    gtype, bb, has_s, w, wq, x = _inputs(qtype, M, N, K, seed=3000 + M + N + K)
+    pl = _port()
+    qs_o, d_o, s_o, out_o = _oracle(pl, gtype, bb, has_s, wq, x)
+    out = np.zeros((M, N), np.float32); qs = np.zeros((M, K), np.int8); ds = np.zeros((M, K // 32, 2), np.float32)
+    assert product_lib.wmi_selftest_quant(0, gtype, 3, _p(wq), _p(x), None, M, N, K, _p(out), _p(qs), _p(ds)) == 0
+    assert np.array_equal(qs, qs_o), "q8 quants differ"
+    assert np.array_equal(ds[:, :, 0].copy().view(np.uint32), d_o.view(np.uint32)), "q8 scales differ"
+    wd = np.zeros((N, K), np.float32)
+    for i in range(N):
+        pl.port_dequantize_row(gtype, _p(wq[i]), _p(wd[i]), K)
+    xq = (qs_o.reshape(M, K // 32, 32).astype(np.float64) * d_o[:, :, None].astype(np.float64)).reshape(M, K)
+    mag = np.abs(xq) @ np.abs(wd).astype(np.float64).T
+    err = np.abs(out.astype(np.float64) - out_o.astype(np.float64))
+    assert np.all(err <= 1.0e-3 * mag + 1e-30), (float((err / (mag + 1e-30)).max()), float(err.max()))
+    rms = np.sqrt((err ** 2).mean()) / np.sqrt((out_o.astype(np.float64) ** 2).mean())
+    print(f"{qtype} f16 form {M}x{N}x{K}: rms-rel {rms:.2e}, worst |err| / sum|w||x| {float((err / (mag + 1e-30)).max()):.2e}")
+    assert rms <= 6e-4
+
+
+@pytest.mark.parametrize("qtype", list(QT))
 def test_quantised_embedding_gather_is_bit_exact(product_lib, qtype):
     gtype, bb, has_s = QT[qtype]
     N, K = 300, 384
