@@ -197,12 +197,12 @@ __device__ __forceinline__ void ln_inplace(float4 (&v)[MAXV], const float4 (&gg)
 
 // SRC: 0 = f32 rows, 1 = LayerNorm of f32 rows (K <= 256 * MAXV), 2 = f16 rows
 template <int MAXV, int SRC, bool F16D>
-__global__ __launch_bounds__(256) void k_q8_rows(const float * __restrict__ x32, const __half * __restrict__ x16, int M, int K,
-                                                 const float * __restrict__ g, const float * __restrict__ b, float eps,
-                                                 int8_t * __restrict__ qs, float * __restrict__ dT, float * __restrict__ sT, int ldm,
-                                                 float * __restrict__ out32, __half * __restrict__ out16, __half * __restrict__ deq) {
+__device__ __forceinline__ void q8_rows_body(int blk, const float * __restrict__ x32, const __half * __restrict__ x16, int M, int K,
+                                             const float * __restrict__ g, const float * __restrict__ b, float eps,
+                                             int8_t * __restrict__ qs, float * __restrict__ dT, float * __restrict__ sT, int ldm,
+                                             float * __restrict__ out32, __half * __restrict__ out16, __half * __restrict__ deq) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blk * 4 + (threadIdx.x >> 6);
     if (row >= M) return;
     if constexpr (SRC == 1) {
         const float * xr = x32 + (size_t) row * K;
@@ -257,6 +257,14 @@ __global__ __launch_bounds__(256) void k_q8_rows(const float * __restrict__ x32,
             }
         }
     }
+}
+
+template <int MAXV, int SRC, bool F16D>
+__global__ __launch_bounds__(256) void k_q8_rows(const float * __restrict__ x32, const __half * __restrict__ x16, int M, int K,
+                                                 const float * __restrict__ g, const float * __restrict__ b, float eps,
+                                                 int8_t * __restrict__ qs, float * __restrict__ dT, float * __restrict__ sT, int ldm,
+                                                 float * __restrict__ out32, __half * __restrict__ out16, __half * __restrict__ deq) {
+    q8_rows_body<MAXV, SRC, F16D>((int) blockIdx.x, x32, x16, M, K, g, b, eps, qs, dT, sT, ldm, out32, out16, deq);
 }
 
 // ------------------------------------------------------------------------------------------------ GEMM
@@ -566,7 +574,7 @@ void qgemm_epi(int epi, const GemmArgs & a, Q8Rows A, const uint8_t * Wt, hipStr
 // partial sums meet in LDS and are added in wavefront order.
 // SRC: 0 f32 rows, 1 LayerNorm of f32 rows (K <= 1536), 2 f16 rows, 3 the combined partials of the split cross-attention
 // (GemvArgs::comb_*: o / l per head, f32 — what attn_cross_combine writes with out32).
-constexpr int PF_WG = 32;                                   // prefetch workgroups appended to a k_qrows grid (multiple of 8: XCD affinity)
+constexpr int PF_WG = 64;                                   // prefetch workgroups appended to a k_qrows grid (multiple of 8: XCD affinity)
 
 template <int QT, int NR4, int SRC, int NW>
 __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float * __restrict__ a32, const uint8_t * __restrict__ Wt) {
@@ -596,13 +604,17 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
     // vmcnt queue: +1 us per launch instead of -1.)
     const int nmain = a.pf_ptr ? (int) gridDim.x - PF_WG : (int) gridDim.x;
     if ((int) blockIdx.x >= nmain) {
+        // every line of this workgroup's share is requested before the first one is waited for: as `acc ^= load` in a loop hipcc waited
+        // vmcnt(0) per iteration (ISA dump), i.e. one HBM round trip per line and thread — the five groups per workgroup of an N = 4 S
+        // matrix took ~10 us, twice the launch that was supposed to hide them.  The destination register is never read.
         const uint8_t * pf = (const uint8_t *) a.pf_ptr;
-        uint32_t acc = 0;
+        uint32_t junk = 0;
         for (uint32_t g = blockIdx.x - nmain; g < a.pf_groups; g += PF_WG) {
             const uint8_t * gp = pf + (size_t) g * a.pf_group_bytes;
-            for (uint32_t off = (uint32_t) tid * 128u; off < a.pf_group_bytes; off += (uint32_t) NT * 128u) acc ^= *(const volatile uint32_t *) (gp + off);
+            for (uint32_t off = (uint32_t) tid * 128u; off < a.pf_group_bytes; off += (uint32_t) NT * 128u)
+                asm volatile("global_load_dword %0, %1, off" : "+v"(junk) : "v"(gp + off) : "memory");
         }
-        if (acc == 0x9e3779b9u && a.n < 0) ((volatile uint32_t *) a.C)[0] = acc;      // never true: keeps the loads
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(junk) :: "memory");
         return;
     }
     int rg = blockIdx.x;
@@ -692,16 +704,10 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
                     if ((lane & 7) == 0) { sd[(cs >> 5) * R8 + r] = d; ss[(cs >> 5) * R8 + r] = sv; }
                 }
             }
-        } else                                               // (stat is read before the barrier that ends the prologue; red is written after it)
-        for (int task = wave; task < n * nsl; task += NW) {
-            const int r = task / nsl, sl = task - r * nsl;
-            const int src = a.rows ? a.rows[r] : r;
-            const float * xr = a.x32 + (size_t) src * K;
-            float4 v[MAXV];
-#pragma unroll
-            for (int i = 0; i < MAXV; ++i) { const int c = (i * 64 + lane) * 4; v[i] = *(const float4 *) (xr + (c < K ? c : 0)); }
-            const int cs = (sl * 64 + lane) * 4, ccs = cs < K ? cs : 0;
-            const float4 gg = *(const float4 *) (a.ln_g + ccs), bb = *(const float4 *) (a.ln_b + ccs);
+        } else {                                             // (stat is read before the barrier that ends the prologue; red is written after it)
+        // one task: the row's statistics from all of its columns, then this task's 256-column slice normalised and quantised
+        auto ln_task = [&](int r, int sl, float4 (&v)[MAXV], const float4 gg, const float4 bb) {
+            const int cs = (sl * 64 + lane) * 4;
             float sum = 0.0f;
 #pragma unroll
             for (int i = 0; i < MAXV; ++i) {
@@ -734,6 +740,18 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
                 *(uint32_t *) (sq + (size_t) r * lda + cs) = q;
                 if ((lane & 7) == 0) { sd[(cs >> 5) * R8 + r] = d; ss[(cs >> 5) * R8 + r] = sv; }
             }
+        };
+        for (int task = wave; task < n * nsl; task += NW) {
+            const int r = task / nsl, sl = task - r * nsl;
+            const int src = a.rows ? a.rows[r] : r;
+            const float * xr = a.x32 + (size_t) src * K;
+            float4 v[MAXV];
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) { const int c = (i * 64 + lane) * 4; v[i] = *(const float4 *) (xr + (c < K ? c : 0)); }
+            const int cs = (sl * 64 + lane) * 4, ccs = cs < K ? cs : 0;
+            const float4 gg = *(const float4 *) (a.ln_g + ccs), bb = *(const float4 *) (a.ln_b + ccs);
+            ln_task(r, sl, v, gg, bb);
+        }
         }
     } else {
         // blocks quantise independently: (row, 256-column slice) pairs spread over all wavefronts
@@ -802,7 +820,7 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
 #pragma unroll
         for (int e = 0; e < 4 * NR4; ++e) out[e] = 0.0f;
         for (int c0 = 0; wave + NW * c0 < np; c0 += CH) {
-            if (!(rg == (int) blockIdx.x && c0 == 0)) load_tiles(rg, c0);
+            if (c0 != 0) load_tiles(rg, c0);                 // (the first tiles of a group: requested before the prologue, resp. before the previous group's reduction)
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
                 const int tp = wave + NW * (c0 + u);
@@ -850,6 +868,7 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
         // the next row group's first tiles go out before this one is reduced (the vocabulary projection walks ~1.6 groups per workgroup)
         const int rgn = rg + nmain;
         const bool more = rgn < ngroups;
+        if (more) load_tiles(rgn, 0);
         // ---- K-split partials of the wavefronts, added in wavefront order
         if (rg != (int) blockIdx.x) __syncthreads();            // red is reused
 #pragma unroll
@@ -884,7 +903,6 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
                 default: break;
             }
         }
-        (void) more;
     }
     stamp_end(a.stamps, a.stamp_slot, (int) blockIdx.x * NW + wave, ts0, tm1, tm2);
 }
@@ -894,7 +912,12 @@ void launch_qrows(const GemvArgs & a, const float * a32, const uint8_t * Wt, hip
     const int nb = a.K / 32, R8 = NR4 * 8;
     const size_t smem = (((size_t) a.n * (a.K + 16) + 15) & ~(size_t) 15) + (size_t) 2 * nb * R8 * 4 + (size_t) NW * 32 * R8 * 4;
     const int ngroups = (a.N + 31) / 32;
-    int blocks = ngroups; if (blocks > 1024) blocks = 1024;
+    // The vocabulary projection (1 621 row groups): as many workgroups as are resident at once (124 VGPRs x 8 wavefronts: two per CU; 164 x 4:
+    // three), each walking its groups with the next group's tiles in flight — with 1 024 workgroups the second round paid the prologue
+    // (LayerNorm + quantiser, ~4 us) again behind the first.
+    static const int cap_env = getenv("WMI_QROWS_BLOCKS") ? atoi(getenv("WMI_QROWS_BLOCKS")) : 0;      // A/B knob
+    const int cap = cap_env > 0 ? cap_env : NW == 4 ? 768 : NW == 8 ? 512 : 256;
+    int blocks = ngroups; if (blocks > cap) blocks = cap;
     if (a.pf_ptr) blocks += PF_WG;                          // the prefetch workgroups (see the kernel)
     static std::atomic<uint64_t> lds_ok{0};
     if (smem > 48 * 1024) allow_full_lds((const void *) k_qrows<QT, NR4, SRC, NW>, lds_ok);
@@ -980,11 +1003,11 @@ __global__ void k_qembed(const int32_t * __restrict__ tokens, const int32_t * __
 // k_qdequant: one wavefront per 32 x 64 tile (lane = (row, block of the pair): 32 values = 64 bytes), four K-consecutive tiles per
 // workgroup, turned through LDS so that a row's 512 bytes leave as one run.
 template <int QT>
-__global__ __launch_bounds__(256) void k_qdequant(const uint8_t * __restrict__ Wt, int np, int K, __half * __restrict__ out) {
+__device__ __forceinline__ void qdequant_body(int bx, int by, const uint8_t * __restrict__ Wt, int np, int K, __half * __restrict__ out) {
     constexpr int QW = Geo<QT>::QW, HW = Geo<QT>::HW, ROWB = 528;
     __shared__ __attribute__((aligned(16))) unsigned char sm[32 * ROWB];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int tp = blockIdx.x * 4 + wave, tn = blockIdx.y;
+    const int tp = bx * 4 + wave, tn = by;
     if (tp < np) {
         const uint8_t * t = Wt + ((size_t) tn * np + tp) * tile_bytes<QT>();
         uint32_t rq[QW], rh[HW];
@@ -1010,12 +1033,29 @@ __global__ __launch_bounds__(256) void k_qdequant(const uint8_t * __restrict__ W
         }
     }
     __syncthreads();
-    const int k0 = blockIdx.x * 256;
+    const int k0 = bx * 256;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int idx = i * 256 + tid, row = idx >> 5, ch = idx & 31;
         if (k0 + ch * 8 < K) *(uint4 *) (out + ((size_t) tn * 32 + row) * K + k0 + ch * 8) = *(const uint4 *) (sm + row * ROWB + ch * 16);
     }
+}
+template <int QT>
+__global__ __launch_bounds__(256) void k_qdequant(const uint8_t * __restrict__ Wt, int np, int K, __half * __restrict__ out) {
+    qdequant_body<QT>((int) blockIdx.x, (int) blockIdx.y, Wt, np, K, out);
+}
+// The row quantiser of a projection and the dequantisation of that projection's weights in ONE launch (they are independent, both are
+// short streaming jobs, and as two launches each paid its own boundary and ramp): workgroups [0, nrb) quantise four rows each, the
+// others are k_qdequant's (bx, by) = ((blockIdx.x - nrb) % nbx, (blockIdx.x - nrb) / nbx).
+template <int MAXV, int SRC, int QT>
+__global__ __launch_bounds__(256) void k_q8_rows_wdeq(const float * __restrict__ x32, const __half * __restrict__ x16, int M, int K,
+                                                      const float * __restrict__ g, const float * __restrict__ b, float eps,
+                                                      int8_t * __restrict__ qs, float * __restrict__ dT, float * __restrict__ sT, int ldm,
+                                                      float * __restrict__ out32, __half * __restrict__ out16, __half * __restrict__ deq,
+                                                      int nrb, const uint8_t * __restrict__ Wt, int np, int Kw, int nbx, __half * __restrict__ wout) {
+    if ((int) blockIdx.x < nrb) { q8_rows_body<MAXV, SRC, !Geo<QT>::M>((int) blockIdx.x, x32, x16, M, K, g, b, eps, qs, dT, sT, ldm, out32, out16, deq); return; }
+    const int e = (int) blockIdx.x - nrb;
+    qdequant_body<QT>(e % nbx, e / nbx, Wt, np, Kw, wout);
 }
 
 template <int QT> static void qdequant_launch(const uint8_t * Wt, int64_t row0, int64_t rows, int K, __half * out, hipStream_t st) {
@@ -1026,9 +1066,44 @@ template <int QT> static void qdequant_launch(const uint8_t * Wt, int64_t row0, 
 
 } // namespace
 
-void quantize_rows(const float * x32, const __half * x16, int M, int K, const float * ln_g, const float * ln_b, float eps,
-                   int qtype, Q8Rows out, float * out32, __half * out16, hipStream_t st) {
-    if (M <= 0) return;
+static int qgemm_f16_rows() {
+    // f16 form (see k_qdequant) from WMI_QGEMM_F16_ROWS activation rows on (0 = never: the block-dot kernel for every M)
+    static const int v = getenv("WMI_QGEMM_F16_ROWS") ? atoi(getenv("WMI_QGEMM_F16_ROWS")) : 256;
+    return v;
+}
+
+template <int QT>
+static void q8_rows_wdeq_launch(const float * x32, const __half * x16, int M, int K, const float * ln_g, const float * ln_b, float eps,
+                                Q8Rows out, float * out32, __half * out16, const uint8_t * Wt, int Nw, int Kw, hipStream_t st) {
+    const int nrb = (M + 3) / 4, np = Kw / 64, nbx = (np + 3) / 4, nby = (Nw + 31) / 32;
+    const dim3 grid(nrb + nbx * nby), block(256);
+#define WMI_Q8W(MAXV, SRC) hipLaunchKernelGGL((k_q8_rows_wdeq<MAXV, SRC, QT>), grid, block, 0, st, x32, x16, M, K, ln_g, ln_b, eps, out.qs, out.d, out.s, out.ldm, \
+                                              out32, out16, out.deq, nrb, Wt, np, Kw, nbx, out.wdeq)
+    if (ln_g) {
+        const int nv = (K + 255) / 256;
+        if (nv <= 2) WMI_Q8W(2, 1); else if (nv <= 4) WMI_Q8W(4, 1); else WMI_Q8W(6, 1);
+    } else if (x32) WMI_Q8W(4, 0);
+    else            WMI_Q8W(4, 2);
+#undef WMI_Q8W
+}
+
+bool quantize_rows(const float * x32, const __half * x16, int M, int K, const float * ln_g, const float * ln_b, float eps,
+                   int qtype, Q8Rows out, float * out32, __half * out16, hipStream_t st, const QMat * W_next, int N_next) {
+    if (M <= 0) return false;
+    static const bool fuse = getenv("WMI_QGEMM_NO_FUSED_DEQ") == nullptr;    // A/B knob
+    if (fuse && W_next && W_next->tiles && W_next->qtype == qtype && out.deq && out.wdeq && qgemm_f16_rows() > 0 && M >= qgemm_f16_rows() &&
+        (K % 64) == 0 && (N_next % 32) == 0 && (size_t) N_next * K <= out.wdeq_elems) {
+        // the projection that follows takes the f16 form: its weight image is written by this launch (qgemm is told through Q8Rows::wdeq_ready)
+        switch (qtype) {
+            case QT_Q4_0: q8_rows_wdeq_launch<QT_Q4_0>(x32, x16, M, K, ln_g, ln_b, eps, out, out32, out16, W_next->tiles, N_next, K, st); break;
+            case QT_Q4_1: q8_rows_wdeq_launch<QT_Q4_1>(x32, x16, M, K, ln_g, ln_b, eps, out, out32, out16, W_next->tiles, N_next, K, st); break;
+            case QT_Q5_0: q8_rows_wdeq_launch<QT_Q5_0>(x32, x16, M, K, ln_g, ln_b, eps, out, out32, out16, W_next->tiles, N_next, K, st); break;
+            case QT_Q5_1: q8_rows_wdeq_launch<QT_Q5_1>(x32, x16, M, K, ln_g, ln_b, eps, out, out32, out16, W_next->tiles, N_next, K, st); break;
+            case QT_Q8_0: q8_rows_wdeq_launch<QT_Q8_0>(x32, x16, M, K, ln_g, ln_b, eps, out, out32, out16, W_next->tiles, N_next, K, st); break;
+            default: return false;
+        }
+        return true;
+    }
     const dim3 grid((M + 3) / 4), block(256);
     const bool f16d = !q_geom(qtype).has_m;
 #define WMI_Q8(MAXV, SRC) do { if (f16d) hipLaunchKernelGGL((k_q8_rows<MAXV, SRC, true>), grid, block, 0, st, x32, x16, M, K, ln_g, ln_b, eps, out.qs, out.d, out.s, out.ldm, out32, out16, out.deq); \
@@ -1039,6 +1114,7 @@ void quantize_rows(const float * x32, const __half * x16, int M, int K, const fl
     } else if (x32) WMI_Q8(4, 0);
     else            WMI_Q8(4, 2);
 #undef WMI_Q8
+    return false;
 }
 
 void qdequant(QMat W, int64_t row0, int64_t rows, int K, __half * out, hipStream_t st) {
@@ -1053,8 +1129,7 @@ void qdequant(QMat W, int64_t row0, int64_t rows, int K, __half * out, hipStream
 }
 
 void qgemm(int epi, const GemmArgs & a, Q8Rows A, QMat W, hipStream_t st) {
-    // f16 form (see k_qdequant) from WMI_QGEMM_F16_ROWS activation rows on (0 = never: the block-dot kernel for every M)
-    static const int f16_rows = getenv("WMI_QGEMM_F16_ROWS") ? atoi(getenv("WMI_QGEMM_F16_ROWS")) : 256;
+    const int f16_rows = qgemm_f16_rows();
     if (f16_rows > 0 && a.M >= f16_rows && A.deq && A.wdeq && (a.K % 64) == 0 && (a.N % 32) == 0) {
         const int64_t cap = (int64_t) (A.wdeq_elems / (size_t) a.K) / 32 * 32;               // weight rows the image holds
         GemmArgs g = a; g.A = A.deq; g.lda = a.K; g.W = A.wdeq; g.ldw = a.K;
@@ -1071,7 +1146,7 @@ void qgemm(int epi, const GemmArgs & a, Q8Rows A, QMat W, hipStream_t st) {
             return;
         }
         if (epi != EPI_CROSS_KV && a.N <= cap) {
-            qdequant(W, 0, a.N, a.K, A.wdeq, st);
+            if (!A.wdeq_ready) qdequant(W, 0, a.N, a.K, A.wdeq, st);
             gemm(epi, g, st);
             return;
         }

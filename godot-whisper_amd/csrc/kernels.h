@@ -296,11 +296,14 @@ struct QMat { const uint8_t * tiles = nullptr; int qtype = QT_NONE; };
 // s = d * sum(q) for the q8_1 kinds; for the q8_0 kinds d is rounded to f16 as the reference stores it and s = 0
 // deq (optional): the same rows as f16(d * q) [M][K] — the A operand of the f16 form of qgemm; wdeq / wdeq_elems: scratch image for one
 // dequantised weight matrix (or a group of cross K | V layers) [rows][K] f16
-struct Q8Rows { int8_t * qs; float * d; float * s; int ldm; __half * deq = nullptr; __half * wdeq = nullptr; size_t wdeq_elems = 0; };
+// wdeq_ready: the image already holds the matrix the next qgemm multiplies with (written by quantize_rows' fused launch)
+struct Q8Rows { int8_t * qs; float * d; float * s; int ldm; __half * deq = nullptr; __half * wdeq = nullptr; size_t wdeq_elems = 0; bool wdeq_ready = false; };
 // rows -> q8.  Exactly one source: x32 (+ optional LayerNorm gain/bias: y = LN(x) * g + b in f32, the reference quantises that
 // f32 tensor) or x16 (an f16 tensor, e.g. the GELU output, widened exactly).  out32 / out16: optional copy of the LN result.
-void quantize_rows(const float * x32, const __half * x16, int M, int K, const float * ln_g, const float * ln_b, float eps,
-                   int qtype, Q8Rows out, float * out32, __half * out16, hipStream_t st);
+// W_next / N_next (optional): the [N_next][K] matrix of the projection these rows feed.  When that projection will take the f16 form
+// (qgemm), its weight image is written by the same launch; returns true then (the caller sets Q8Rows::wdeq_ready for that qgemm).
+bool quantize_rows(const float * x32, const __half * x16, int M, int K, const float * ln_g, const float * ln_b, float eps,
+                   int qtype, Q8Rows out, float * out32, __half * out16, hipStream_t st, const QMat * W_next = nullptr, int N_next = 0);
 
 // C[M][N] = A_q8[M][K] . W_q[N][K]^T with the GEMM's epilogues (Epi above; GemmArgs fields A / W / lda / ldw unused).
 // N % 128 == 0, K % 64 == 0.

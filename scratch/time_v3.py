@@ -41,5 +41,5 @@ if os.environ.get("BATCH"):
     t0 = time.perf_counter(); r = node.transcribe_batch(pcms, params=p); dt = time.perf_counter() - t0
     t4 = (C.c_int64 * 4)(); ns = C.c_int32(); lib.wmi_get_batch_timings(node.ctx, t4, C.byref(ns))
     print(f"lock-step {nb} chunks: {dt*1e3:.1f} ms per call ({nb*30/dt:.0f}x) modes {list(node.last_modes)} | mel {t4[0]/1e3:.2f} enc {t4[1]/1e3:.2f} dec {t4[2]/1e3:.2f} ({ns.value} steps) emit {t4[3]/1e3:.2f}", flush=True)
-print('greedy step chain on the GPU, us per step:', lib.wmi_bench_kernel(node.ctx, 20, 20), flush=True)
+print('greedy step chain on the GPU, us per step:', lib.wmi_bench_kernel(node.ctx, 20, 20), '| vocabulary projection (rotating copies), us:', lib.wmi_bench_kernel(node.ctx, 6, 100), flush=True)
 node.close()
