@@ -577,7 +577,8 @@ void qgemm_epi(int epi, const GemmArgs & a, Q8Rows A, const uint8_t * Wt, hipStr
 constexpr int PF_WG = 64;                                   // prefetch workgroups appended to a k_qrows grid (multiple of 8: XCD affinity)
 
 template <int QT, int NR4, int SRC, int NW>
-__global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float * __restrict__ a32, const uint8_t * __restrict__ Wt) {
+// (8 wavefronts, <= 8 rows: held to 128 VGPRs = two workgroups per CU — the vocabulary projection's grid is sized for that)
+__global__ __launch_bounds__(NW * 64, (NW == 8 && NR4 == 1) ? 4 : 1) void k_qrows(const GemvArgs a, const float * __restrict__ a32, const uint8_t * __restrict__ Wt) {
     constexpr int QW = Geo<QT>::QW, HW = Geo<QT>::HW;
     constexpr bool HAS_M = Geo<QT>::M, F16D = Geo<QT>::F16D;
     constexpr int R8 = NR4 * 8;                             // row slots
@@ -704,10 +705,16 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
                     if ((lane & 7) == 0) { sd[(cs >> 5) * R8 + r] = d; ss[(cs >> 5) * R8 + r] = sv; }
                 }
             }
-        } else {                                             // (stat is read before the barrier that ends the prologue; red is written after it)
-        // one task: the row's statistics from all of its columns, then this task's 256-column slice normalised and quantised
-        auto ln_task = [&](int r, int sl, float4 (&v)[MAXV], const float4 gg, const float4 bb) {
-            const int cs = (sl * 64 + lane) * 4;
+        } else                                               // (stat is read before the barrier that ends the prologue; red is written after it)
+        for (int task = wave; task < n * nsl; task += NW) {
+            const int r = task / nsl, sl = task - r * nsl;
+            const int src = a.rows ? a.rows[r] : r;
+            const float * xr = a.x32 + (size_t) src * K;
+            float4 v[MAXV];
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) { const int c = (i * 64 + lane) * 4; v[i] = *(const float4 *) (xr + (c < K ? c : 0)); }
+            const int cs = (sl * 64 + lane) * 4, ccs = cs < K ? cs : 0;
+            const float4 gg = *(const float4 *) (a.ln_g + ccs), bb = *(const float4 *) (a.ln_b + ccs);
             float sum = 0.0f;
 #pragma unroll
             for (int i = 0; i < MAXV; ++i) {
@@ -740,18 +747,6 @@ __global__ __launch_bounds__(NW * 64) void k_qrows(const GemvArgs a, const float
                 *(uint32_t *) (sq + (size_t) r * lda + cs) = q;
                 if ((lane & 7) == 0) { sd[(cs >> 5) * R8 + r] = d; ss[(cs >> 5) * R8 + r] = sv; }
             }
-        };
-        for (int task = wave; task < n * nsl; task += NW) {
-            const int r = task / nsl, sl = task - r * nsl;
-            const int src = a.rows ? a.rows[r] : r;
-            const float * xr = a.x32 + (size_t) src * K;
-            float4 v[MAXV];
-#pragma unroll
-            for (int i = 0; i < MAXV; ++i) { const int c = (i * 64 + lane) * 4; v[i] = *(const float4 *) (xr + (c < K ? c : 0)); }
-            const int cs = (sl * 64 + lane) * 4, ccs = cs < K ? cs : 0;
-            const float4 gg = *(const float4 *) (a.ln_g + ccs), bb = *(const float4 *) (a.ln_b + ccs);
-            ln_task(r, sl, v, gg, bb);
-        }
         }
     } else {
         // blocks quantise independently: (row, 256-column slice) pairs spread over all wavefronts
