@@ -15,5 +15,5 @@ for _ in range(3):
     assert lib.wmi_full_batch(node.ctx, params, ptrs, lens, nb, 0) == 0
 t4 = (C.c_int64 * 4)(); ns = C.c_int32(); lib.wmi_get_batch_timings(node.ctx, t4, C.byref(ns))
 us = [lib.wmi_bench_kernel(node.ctx, 4, 200) for _ in range(3)]
-print("TALL", os.environ.get("WMI_GEMM_TALL"), "mlp.0 x 8 us", [round(u, 2) for u in us], "TFLOP/s", round(2 * 12000 * 2048 * 512 / min(us) / 1e6, 1), "batch encode ms (3 calls)", round(t4[1] / 1e3, 3), flush=True)
+print("TALL", os.environ.get("WMI_GEMM_TALL"), "STAGGER", os.environ.get("WMI_GEMM_STAGGER"), "mlp.0 x 8 us", [round(u, 2) for u in us], "TFLOP/s", round(2 * 12000 * 2048 * 512 / min(us) / 1e6, 1), "batch encode ms (3 calls)", round(t4[1] / 1e3, 3), flush=True)
 node.close()
