@@ -666,8 +666,9 @@ int wmi_selftest_quant(int device, int qtype, int mode, const void * w_blocks, c
                        int M, int N, int K, float * out, int8_t * out_qs, float * out_ds) {
     const k::QGeom g = k::q_geom(qtype);
     if (!g.qb || M < 1 || N < 1 || K < 64 || (K % 64) != 0 || !w_blocks || !out) return -1;
-    // mode 0: <= 32 rows through k_qrows; 1: the block-dot GEMM; 2: embedding gather; 3: the f16 form of the GEMM (k_qdequant + k_gemm)
-    if ((mode == 0 && M > 32) || ((mode == 1 || mode == 3) && (N % 128) != 0) || mode < 0 || mode > 3 || (mode == 2 ? !tokens : !x)) return -1;
+    // mode 0: <= 32 rows through k_qrows; 1: the block-dot GEMM; 2: embedding gather; 3: the f16 form of the GEMM (k_qdequant + k_gemm);
+    // 4: the same through the product's route (quantize_rows with the weight expansion in its launch, then qgemm: needs M >= 256)
+    if ((mode == 0 && M > 32) || ((mode == 1 || mode == 3 || mode == 4) && (N % 128) != 0) || mode < 0 || mode > 4 || (mode == 2 ? !tokens : !x)) return -1;
     if (!HIP_OK(hipSetDevice(device))) return -2;
     const int nb = K / 32;
     std::vector<uint8_t> tiles(k::q_matrix_bytes(qtype, N, K));
@@ -679,7 +680,7 @@ int wmi_selftest_quant(int device, int qtype, int mode, const void * w_blocks, c
               HIP_OK(hipMalloc((void **) &d_o, n_out * 4)) && HIP_OK(hipMalloc((void **) &d_z, n_out * 4)) &&
               HIP_OK(hipMalloc((void **) &d_qs, (size_t) M * K)) && HIP_OK(hipMalloc((void **) &d_ds, (size_t) M * nb * 8)) &&
               HIP_OK(hipMalloc((void **) &d_tok, (size_t) M * 4 * 2));
-    if (mode == 3) ok = ok && HIP_OK(hipMalloc((void **) &d_a16, (size_t) M * K * 2)) && HIP_OK(hipMalloc((void **) &d_w16, (size_t) N * K * 2));
+    if (mode == 3 || mode == 4) ok = ok && HIP_OK(hipMalloc((void **) &d_a16, (size_t) M * K * 2)) && HIP_OK(hipMalloc((void **) &d_w16, (size_t) N * K * 2));
     hipStream_t st = nullptr;
     ok = ok && HIP_OK(hipStreamCreate(&st));
     if (ok) {
@@ -693,8 +694,9 @@ int wmi_selftest_quant(int device, int qtype, int mode, const void * w_blocks, c
             k::qdec_embed(d_tok, d_tok + M, M, K, W, d_z, d_o, st);           // "positional embedding" = zeros
         } else if (ok) {
             k::Q8Rows A{d_qs, d_ds, d_ds + (size_t) nb * M, M};
-            if (mode == 3) { A.deq = d_a16; A.wdeq = d_w16; A.wdeq_elems = (size_t) N * K; }
-            k::quantize_rows(d_x, nullptr, M, K, nullptr, nullptr, 0.f, qtype, A, nullptr, nullptr, st);
+            if (mode == 3 || mode == 4) { A.deq = d_a16; A.wdeq = d_w16; A.wdeq_elems = (size_t) N * K; }
+            if (mode == 4) { A.wdeq_ready = k::quantize_rows(d_x, nullptr, M, K, nullptr, nullptr, 0.f, qtype, A, nullptr, nullptr, st, &W, N); if (!A.wdeq_ready) ok = false; }
+            else k::quantize_rows(d_x, nullptr, M, K, nullptr, nullptr, 0.f, qtype, A, nullptr, nullptr, st);
             if (mode == 0) {
                 k::GemvArgs ga{};
                 ga.n = M; ga.K = K; ga.N = N; ga.epi = k::EPI_LOGITS; ga.C = d_o; ga.ldc = N;

@@ -202,6 +202,8 @@ WHISPER_API int wmi_selftest_resample_plan(int n_frames, int src_rate, int dst_r
  *   mode 2  x ignored; M token ids in `tokens`: out[M][K] = dequantised rows `tokens[i]` of the matrix (get_rows)
  *   mode 3  the large-M form of mode 1 (N % 128 == 0): the same q8 rows as f16(d_a q_a) against the blocks as f16(d_w q_w + m_w) on the
  *           f16 MFMA GEMM, f32 accumulation (what encode uses from 256 activation rows on; WMI_QGEMM_F16_ROWS=0 keeps mode 1's kernel)
+ *   mode 4  mode 3 through the product's own route: the row quantiser's launch also expands the weight blocks, then the projection
+ *           (M >= 256; fails with -3 when that route is not taken)
  * out [M][N] f32 (mode 2: [M][K]); out_qs [M][K] int8 and out_ds [M][K/32][2] {d, s} receive the quantised rows when non-NULL.
  * Returns 0, or a negative value on a bad argument / device error. */
 WHISPER_API int wmi_selftest_quant(int device, int qtype, int mode, const void * w_blocks, const float * x, const int32_t * tokens,

@@ -110,6 +110,11 @@ def test_quantised_matmul_f16_form_against_the_oracle(product_lib, qtype, M, N, 
     rms = np.sqrt((err ** 2).mean()) / np.sqrt((out_o.astype(np.float64) ** 2).mean())
     print(f"{qtype} f16 form {M}x{N}x{K}: rms-rel {rms:.2e}, worst |err| / sum|w||x| {float((err / (mag + 1e-30)).max()):.2e}")
     assert rms <= 6e-4
+    if M >= 256:
+        # the product's route (weight expansion inside the row quantiser's launch, then qgemm's dispatch): same bits
+        out4 = np.zeros((M, N), np.float32); qs4 = np.zeros((M, K), np.int8)
+        assert product_lib.wmi_selftest_quant(0, gtype, 4, _p(wq), _p(x), None, M, N, K, _p(out4), _p(qs4), None) == 0
+        assert np.array_equal(qs4, qs_o) and np.array_equal(out4.view(np.uint32), out.view(np.uint32))
 
 
 @pytest.mark.parametrize("qtype", list(QT))
