@@ -513,6 +513,14 @@ void dispatch(const GemmArgs & a, hipStream_t st) {
         launch<128, 128, EPI>(a, st);
     }
     else if constexpr (EPI == EPI_F32_BIAS_RESID) {
+        // The N = S projections of the widest models at one chunk (large-v3: 1500 x 1280, K = 1280 / 5120): 240 tiles of 64 x 128 on a four-deep ring
+        // instead of 480 of 64 x 64 — a quarter fewer LDS fragment reads per flop.  Measured on the large-v3 q5_1 encoder (64 of these GEMMs):
+        // 6.85 -> 6.70 ms; 128 x 64 tiles 6.83, 64 x 128 on a two-deep ring 6.99 (profiles/r03c_gemm_ns_tile.txt).  WMI_GEMM_NS_TILE=0: off.
+        static const int ns_tile = getenv("WMI_GEMM_NS_TILE") ? atoi(getenv("WMI_GEMM_NS_TILE")) : 1;
+        if (ns_tile && a.K >= 1024 && (a.N % 128) == 0 && (a.K % BK) == 0 && t64 >= 400 && !(a.no_glds & 1)) {
+            if (ns_tile == 2) { launch_n<128, 64, EPI, 4>(a, st); return; }
+            launch_n<64, 128, EPI, 4>(a, st); return;
+        }
         // one chunk, N = S: 64x64 tiles give fewer workgroups than CUs (192 for base.en) and each walks K alone with nothing to
         // overlap its loads; 64x32 tiles double the workgroups
         if (t64 < 256 && !no_narrow) launch<64, 32, EPI>(a, st); else launch<64, 64, EPI>(a, st);
