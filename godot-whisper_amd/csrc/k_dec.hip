@@ -1354,6 +1354,39 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
             // the all-rows-at-once form below)
             auto ln_seq = [&](auto nc_tag) {
                 constexpr int NC = decltype(nc_tag)::value;      // 512-column chunks of a row: registers (and loads) only for the chunks the model has
+                if constexpr (NC <= 2) {
+                    // two rows at a time (rows r and r + 4 of this wavefront): both rows' loads go out together — row after row each LayerNorm
+                    // waited its own ~2 us round trip for a row the previous launch wrote on another XCD (2 round trips at 8 rows, 4 at 16).
+                    // 16 * NC more registers than one row: still two workgroups per CU.  Per row the arithmetic is ln_row_compute's.
+                    for (int r0 = wave; r0 < n; r0 += 8) {
+                        const int r1 = r0 + 4 < n ? r0 + 4 : r0;
+                        const int s0 = a.rows ? a.rows[r0] : r0, s1 = a.rows ? a.rows[r1] : r1;
+                        float xv[2][NC][8], gv[NC][8], bv[NC][8];
+                        ln_row_load<NC>(a.x32 + (size_t) s0 * K, K, lane, xv[0]);
+                        ln_row_load<NC>(a.x32 + (size_t) s1 * K, K, lane, xv[1]);
+                        ln_row_load<NC>(a.ln_g, K, lane, gv);
+                        ln_row_load<NC>(a.ln_b, K, lane, bv);
+                        __builtin_amdgcn_sched_barrier(0);
+                        ln_row_mask<NC>(xv[0], K, lane); ln_row_mask<NC>(xv[1], K, lane); ln_row_mask<NC>(gv, K, lane); ln_row_mask<NC>(bv, K, lane);
+                        ln_rows_compute<2, NC>(xv, gv, bv, K, a.eps, lane);
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            const int r = q == 0 ? r0 : r0 + 4;
+                            if (r < n) {
+#pragma unroll
+                                for (int t = 0; t < NC; ++t) {
+                                    const int c = lane * 8 + 512 * t;
+                                    if (c < K) {
+                                        __half2 h[4];
+#pragma unroll
+                                        for (int e = 0; e < 4; ++e) h[e] = __floats2half2_rn(xv[q][t][2 * e], xv[q][t][2 * e + 1]);
+                                        *(uint4 *) (act + r * lda + c) = *(const uint4 *) h;
+                                    }
+                                }
+                            }
+                        }
+                    }
+                } else
                 for (int r = wave; r < n; r += 4) {
                     const int src = a.rows ? a.rows[r] : r;
                     float av[NC][8];
