@@ -725,6 +725,15 @@ int wmi_selftest_quant(int device, int qtype, int mode, const void * w_blocks, c
     return ok ? 0 : -3;
 }
 
+int wmi_selftest_seqsum(const float * x, int n, float * out_blocked, float * out_plain) {
+    if (!x || n < 0 || !out_blocked || !out_plain) return -1;
+    volatile float acc = 0.0f;                              // the definition: one f32 addition after the other
+    for (int i = 0; i < n; ++i) acc = acc + x[i];
+    *out_plain = acc;
+    *out_blocked = seq_sum_f32(x, n);
+    return 0;
+}
+
 int wmi_step_stamps(struct whisper_context * ctx, double * out, int cap, int chained) {
     if (!ctx || !ctx->state || !out) return -1;
     (void) hipSetDevice(ctx->device);

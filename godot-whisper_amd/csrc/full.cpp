@@ -525,6 +525,55 @@ std::vector<float> signal_energy(const float * signal, int n_samples, int hw) {
     return out;
 }
 
+// The value of   s = 0; for (i < n) s += p[i];   (f32, left to right — the reference's window sums, W/whisper.cpp:6506-6515), without its
+// 4-cycle dependency per element.  While the accumulator stays inside one binade [2^E, 2^(E+1)) it is a multiple of ulp = 2^(E-23), and
+// adding x rounds the exact sum to a multiple of that ulp: acc += ulp * rne(x / ulp), an INTEGER addition — unless x / ulp ends in exactly
+// .5 (the tie goes to the even neighbour of the running sum, which depends on the sum) or the sum leaves the binade.  So blocks of 64
+// elements are converted and added as integers with AVX2 (x / ulp is an exact power-of-two scaling, the conversion rounds to nearest
+// even like the adder); a block that contains a tie, a negative or huge element, or that could cross the binade is added the plain way.
+// The envelope is non-negative, so the sum is monotone and crosses at most ~30 binades per window.  Bit-identical to the loop
+// (tests/test_abi.py::test_sequential_sum_is_exact, random / tie-heavy / denormal / crossing inputs).
+float seq_sum_f32(const float * p, int n) {
+    float acc = 0.0f;
+    int i = 0;
+    constexpr int B = 64;
+    while (i < n) {
+        uint32_t bits; memcpy(&bits, &acc, 4);
+        const int E = (int) ((bits >> 23) & 0xFF) - 127;                        // acc in [2^E, 2^(E+1)) when normal and positive
+        if (i + B <= n && (bits >> 31) == 0 && E >= -100 && E <= 100) {
+            const uint32_t units = (bits & 0x7FFFFFu) | 0x800000u;               // acc / ulp, in [2^23, 2^24)
+            uint32_t sb = (uint32_t) (127 + 23 - E) << 23; float scale; memcpy(&scale, &sb, 4);       // 2^(23 - E) = 1 / ulp
+            const __m256 vs = _mm256_set1_ps(scale), half = _mm256_set1_ps(0.5f), big = _mm256_set1_ps(8388608.0f);
+            const __m256 absmask = _mm256_castsi256_ps(_mm256_set1_epi32(0x7FFFFFFF));
+            __m256i isum = _mm256_setzero_si256();
+            __m256 bad = _mm256_setzero_ps();
+            for (int k = 0; k < B; k += 8) {
+                const __m256 t = _mm256_mul_ps(_mm256_loadu_ps(p + i + k), vs);
+                const __m256i q = _mm256_cvtps_epi32(t);                         // round to nearest even (MXCSR default)
+                const __m256 d = _mm256_and_ps(_mm256_sub_ps(t, _mm256_cvtepi32_ps(q)), absmask);
+                bad = _mm256_or_ps(bad, _mm256_cmp_ps(d, half, _CMP_EQ_OQ));     // tie: decided by the parity of the running sum
+                bad = _mm256_or_ps(bad, _mm256_cmp_ps(t, big, _CMP_NLT_UQ));     // >= 2^23 units (leaves the binade) or NaN
+                bad = _mm256_or_ps(bad, _mm256_cmp_ps(t, _mm256_setzero_ps(), _CMP_LT_OQ));      // negative: the sum could drop a binade
+                isum = _mm256_add_epi32(isum, q);
+            }
+            if (_mm256_movemask_ps(bad) == 0) {
+                __m128i s4 = _mm_add_epi32(_mm256_castsi256_si128(isum), _mm256_extracti128_si256(isum, 1));
+                s4 = _mm_add_epi32(s4, _mm_shuffle_epi32(s4, 0x4E)); s4 = _mm_add_epi32(s4, _mm_shuffle_epi32(s4, 0xB1));
+                const uint64_t total = (uint64_t) units + (uint32_t) _mm_cvtsi128_si32(s4);
+                if (total < 0x1000000u) {                                        // every prefix stayed below 2^24 units: same ulp throughout
+                    const uint32_t nb = ((uint32_t) (E + 127) << 23) | ((uint32_t) total & 0x7FFFFFu);
+                    memcpy(&acc, &nb, 4);
+                    i += B;
+                    continue;
+                }
+            }
+        }
+        const int e = std::min(n, i + B);
+        for (; i < e; ++i) acc += p[i];
+    }
+    return acc;
+}
+
 void token_level_timestamps(whisper_context & ctx, State & st, int i_segment, float thold_pt, float thold_ptsum) {
     const Vocab & v = ctx.model.vocab;
     Segment & seg = st.result_all[i_segment];
@@ -593,30 +642,49 @@ void token_level_timestamps(whisper_context & ctx, State & st, int i_segment, fl
     // whole block is decided by one comparison (all above th <=> block min > th, all below <=> block max < th); the
     // sample the walk stops on is the same as for the reference's one-by-one loop.
     const float * bmin = st.energy_bmin, * bmax = st.energy_bmax;
+    // (whole blocks are skipped on the block extrema alone: stepping block by block through `en` touched one cache line per KB of
+    //  envelope — 1 875 misses for a walk to the end of a 30 s signal; the 1 875 extrema are 7.5 KB)
     auto walk_down_while_above = [&](int k, float th) {      // while (k > 0 && en[k] > th) --k;
         while (k > 0 && en[k] > th) {
-            if ((k & 255) == 255 && bmin && bmin[k >> 8] > th) { if (k < 256) return 0; k -= 256; continue; }
+            if ((k & 255) == 255 && bmin && bmin[k >> 8] > th) {
+                int b = k >> 8;
+                while (b >= 0 && bmin[b] > th) --b;
+                if (b < 0) return 0;
+                k = (b << 8) + 255; continue;
+            }
             --k;
         }
         return k;
     };
     auto walk_up_while_above = [&](int k, float th, int last) {   // while (k < last && en[k] > th) ++k;
         while (k < last && en[k] > th) {
-            if ((k & 255) == 0 && k + 256 <= last && bmin && bmin[k >> 8] > th) { k += 256; continue; }
+            if ((k & 255) == 0 && k + 256 <= last && bmin && bmin[k >> 8] > th) {
+                int b = k >> 8;
+                while (((b + 1) << 8) <= last && bmin[b] > th) ++b;
+                k = b << 8; continue;
+            }
             ++k;
         }
         return k;
     };
     auto walk_up_while_below = [&](int k, float th, int last) {   // while (en[k] < th && k < last) ++k;
         while (en[k] < th && k < last) {
-            if ((k & 255) == 0 && k + 256 <= last && bmax && bmax[k >> 8] < th) { k += 256; continue; }
+            if ((k & 255) == 0 && k + 256 <= last && bmax && bmax[k >> 8] < th) {
+                int b = k >> 8;
+                while (((b + 1) << 8) <= last && bmax[b] < th) ++b;
+                k = b << 8; continue;
+            }
             ++k;
         }
         return k;
     };
     auto walk_down_while_below = [&](int k, float th, int first) { // while (en[k] < th && k > first) --k;
         while (en[k] < th && k > first) {
-            if ((k & 255) == 255 && k - 256 >= first && bmax && bmax[k >> 8] < th) { k -= 256; continue; }
+            if ((k & 255) == 255 && k - 256 >= first && bmax && bmax[k >> 8] < th) {
+                int b = k >> 8;
+                while ((b << 8) + 255 - 256 >= first && bmax[b] < th) --b;
+                k = (b << 8) + 255; continue;
+            }
             --k;
         }
         return k;
@@ -631,37 +699,15 @@ void token_level_timestamps(whisper_context & ctx, State & st, int i_segment, fl
     {
         std::vector<int> idx;
         for (int j = 0; j < n; ++j) if (tokens[j].id < v.eot) idx.push_back(j);
-        // groups of up to 8 tokens; with more than one group the groups go to the worker pool (6 tokens per group then: a 30 s
-        // chunk's 17 tokens become three tasks instead of 8 + 8 + 1 one after the other)
-        const size_t gsz = idx.size() > 8 ? 6 : 8;
-        const int n_groups = (int) ((idx.size() + gsz - 1) / gsz);
-        auto sum_group = [&](int gi) {
-            const size_t g0 = (size_t) gi * gsz;
-            const int ng = (int) std::min<size_t>(gsz, idx.size() - g0);
-            const float * base[8]; int len[8]; float acc[8];
-            int common = INT32_MAX;
-            for (int t = 0; t < 8; ++t) {
-                const int j = idx[g0 + std::min(t, ng - 1)];                 // pad the group with its last token
-                const int a0 = std::max(ts_to_sample(tokens[j].t0, n_samples) - hw, 0);
-                const int a1 = std::min(ts_to_sample(tokens[j].t1, n_samples) + hw, n_samples);
-                base[t] = en + a0; len[t] = std::max(a1 - a0, 0); acc[t] = 0.0f;
-                common = std::min(common, len[t]);
-            }
-            for (int i = 0; i < common; ++i) {
-                acc[0] += base[0][i]; acc[1] += base[1][i]; acc[2] += base[2][i]; acc[3] += base[3][i];
-                acc[4] += base[4][i]; acc[5] += base[5][i]; acc[6] += base[6][i]; acc[7] += base[7][i];
-            }
-            // the rest in lock-step too, windows that have ended add +0.0f (the envelope is non-negative, so the
-            // accumulators are never -0.0 and x + 0.0f == x exactly): eight chains stay in flight to the longest window
-            int longest = 0;
-            for (int t = 0; t < 8; ++t) longest = std::max(longest, len[t]);
-            for (int i = common; i < longest; ++i) {
-#pragma GCC unroll 8
-                for (int t = 0; t < 8; ++t) acc[t] += i < len[t] ? base[t][i] : 0.0f;
-            }
-            for (int t = 0; t < ng; ++t) win_sum[idx[g0 + t]] = acc[t];
+        // one task per token on the worker pool (up to 8 threads), each an exact blocked sum (seq_sum_f32: ~10x the plain loop).
+        // Before: eight chains side by side per task, 90 us for the 17 tokens of a 30 s chunk; the longest window set the time.
+        auto sum_one = [&](int t) {
+            const int j = idx[t];
+            const int a0 = std::max(ts_to_sample(tokens[j].t0, n_samples) - hw, 0);
+            const int a1 = std::min(ts_to_sample(tokens[j].t1, n_samples) + hw, n_samples);
+            win_sum[j] = a1 > a0 ? seq_sum_f32(en + a0, a1 - a0) : 0.0f;
         };
-        pool_run(n_groups, sum_group);
+        pool_run((int) idx.size(), sum_one);
     }
     const int64_t ts1 = time_us();
     struct TsReport { bool on; int64_t a, b; ~TsReport() { if (on) fprintf(stderr, "[wmi] token timestamps: window sums %lld us, walks %lld us\n", (long long) (b - a), (long long) (time_us() - b)); } } ts_report{dbg_ts, ts0, ts1};

@@ -383,6 +383,7 @@ void emit_window(whisper_context & ctx, State & st, const whisper_full_params & 
                  size_t n_prompt_init, const Decoder & best);
 std::vector<float> signal_energy(const float * signal, int n_samples, int hw);
 void token_level_timestamps(whisper_context & ctx, State & st, int i_segment, float thold_pt, float thold_ptsum);
+float seq_sum_f32(const float * p, int n);            // the left-to-right f32 sum of p[0..n), bit for bit, in blocks (full.cpp)
 int  wrap_segment(whisper_context & ctx, State & st, int max_len, bool split_on_word);
 
 int         lang_id(const char * lang);

@@ -236,6 +236,11 @@ WHISPER_API double wmi_bench_kernel(struct whisper_context * ctx, int which, int
  * Returns the number of launches written (<= cap), -1 when no greedy step has run on this context (or the model is quantised). */
 WHISPER_API int wmi_step_stamps(struct whisper_context * ctx, double * out, int cap, int chained);
 
+/* Host arithmetic self-test (no device needed): the window sums of the token timestamps are the reference's left-to-right f32 sums
+ * (W/whisper.cpp:6506-6515), evaluated in blocks as integer additions wherever that is exact (csrc/full.cpp: seq_sum_f32).
+ * out_blocked = that routine's result for x[0..n), out_plain = the plain loop's; they must have the same bits.  Returns 0. */
+WHISPER_API int wmi_selftest_seqsum(const float * x, int n, float * out_blocked, float * out_plain);
+
 /* Host worker pool self-test (no device needed): `reps` jobs of `n_tasks` tasks; returns reps * n_tasks * (n_tasks + 1) / 2
  * when every task of every job ran exactly once. */
 WHISPER_API int64_t wmi_selftest_pool(int n_tasks, int reps);

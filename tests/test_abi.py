@@ -183,6 +183,36 @@ def test_host_worker_pool_runs_every_task_exactly_once():
         assert lib.wmi_selftest_pool(n, reps) == reps * n * (n + 1) // 2, (n, reps)
 
 
+def test_sequential_sum_is_exact():
+    """csrc/full.cpp: seq_sum_f32 — the token timestamps' window sums are the reference's left-to-right f32 sums
+    (W/whisper.cpp:6506-6515); the blocked evaluation (integer additions inside a binade, plain additions around ties and binade
+    crossings) must give the same BITS as the one-by-one loop on anything it is handed."""
+    lib = runtime.load_library()
+    rng = np.random.default_rng(11)
+    cases = []
+    for n in (0, 1, 7, 63, 64, 65, 127, 128, 1000, 4001, 36000, 100003):
+        cases.append(np.abs(rng.standard_normal(n)).astype(np.float32) * np.float32(0.05))             # envelope-like
+    cases.append((rng.integers(0, 1 << 12, 50000) / np.float32(1 << 16)).astype(np.float32))           # coarse grid: ties by the thousand
+    cases.append((rng.integers(0, 4, 70000) * np.float32(2.0 ** -20)).astype(np.float32))               # tiny steps, long runs of zeros
+    cases.append(np.full(40000, 2.0 ** -13, np.float32))                                                # exact half-ulps once the sum passes 1024
+    cases.append(np.concatenate([np.full(300, 1e-42, np.float32), np.abs(rng.standard_normal(5000)).astype(np.float32)]))   # denormal start
+    cases.append((np.abs(rng.standard_normal(30000)) * 10.0 ** rng.uniform(-8, 6, 30000)).astype(np.float32))       # 14 decades: crossings everywhere
+    cases.append(rng.standard_normal(20000).astype(np.float32))                                         # negatives: plain path
+    x = np.abs(rng.standard_normal(9000)).astype(np.float32); x[4000] = np.float32(3e38); x[4500] = np.float32(3e38)
+    cases.append(x)                                                                                     # overflow to inf
+    x = np.abs(rng.standard_normal(3000)).astype(np.float32); x[1234] = np.nan
+    cases.append(x)
+    for k, x in enumerate(cases):
+        for off in (0, 1, 3):                                                                           # unaligned starts
+            xs = np.ascontiguousarray(x[off:]) if x.size > off else x
+            a, b = C.c_float(), C.c_float()
+            assert lib.wmi_selftest_seqsum(xs.ctypes.data_as(C.POINTER(C.c_float)), xs.size, C.byref(a), C.byref(b)) == 0
+            ab = np.array([a.value, b.value], np.float32).view(np.uint32)
+            assert ab[0] == ab[1] or (np.isnan(a.value) and np.isnan(b.value)), (k, off, a.value, b.value)
+            if k < 12 and xs.size:                                                                      # and the loop is what numpy's cumulative sum is
+                assert np.float32(b.value) == np.cumsum(xs, dtype=np.float32)[-1]
+
+
 def test_malformed_model_files_are_rejected_not_trusted():
     """The model buffer is untrusted input (the reference rejects all of these with a load error, W/whisper.cpp:1113-1600):
     truncated payloads, zero / negative / absurd hyper-parameters (a zero head count was a division by zero), lengths that
