@@ -528,7 +528,7 @@ std::vector<float> signal_energy(const float * signal, int n_samples, int hw) {
 // The value of   s = 0; for (i < n) s += p[i];   (f32, left to right — the reference's window sums, W/whisper.cpp:6506-6515), without its
 // 4-cycle dependency per element.  While the accumulator stays inside one binade [2^E, 2^(E+1)) it is a multiple of ulp = 2^(E-23), and
 // adding x rounds the exact sum to a multiple of that ulp: acc += ulp * rne(x / ulp), an INTEGER addition — unless x / ulp ends in exactly
-// .5 (the tie goes to the even neighbour of the running sum, which depends on the sum) or the sum leaves the binade.  So blocks of 64
+// .5 (the tie goes to the even neighbour of the running sum, which depends on the sum) or the sum leaves the binade.  So blocks of 128
 // elements are converted and added as integers with AVX2 (x / ulp is an exact power-of-two scaling, the conversion rounds to nearest
 // even like the adder); a block that contains a tie, a negative or huge element, or that could cross the binade is added the plain way.
 // The envelope is non-negative, so the sum is monotone and crosses at most ~30 binades per window.  Bit-identical to the loop
@@ -536,7 +536,7 @@ std::vector<float> signal_energy(const float * signal, int n_samples, int hw) {
 float seq_sum_f32(const float * p, int n) {
     float acc = 0.0f;
     int i = 0;
-    constexpr int B = 64;
+    constexpr int B = 128;                                  // (per lane 16 additions of < 2^23: no 32-bit overflow; 64: 12.2, 128: 10.5, 256: 10.5 us per 36 000 elements)
     while (i < n) {
         uint32_t bits; memcpy(&bits, &acc, 4);
         const int E = (int) ((bits >> 23) & 0xFF) - 127;                        // acc in [2^E, 2^(E+1)) when normal and positive
