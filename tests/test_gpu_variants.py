@@ -163,3 +163,45 @@ def test_wide_gemm_tile_is_bit_identical():
     a, b = run({}), run({"WMI_GEMM_WIDE": "1"})
     assert len(a) == 8 and all(len(c) > 0 for c in a)
     assert a == b
+
+
+# ------------------------------------------------------------------------------------------------ quantised projections: the two forms
+_QFORM_SCRIPT = r"""
+import sys
+import numpy as np
+sys.path.insert(0, ROOT_PLACEHOLDER); sys.path.insert(0, ROOT_PLACEHOLDER + "/tests")
+import __graft_entry__ as entry
+entry.load_package()
+from godot_whisper_amd import runtime, synth
+import stage_compare as sc
+lib = runtime.require_gpu(); runtime.silence_logs(lib)
+model = synth.quantize_model(synth.make_model("tiny.en", seed=77), sys.argv[2])
+side = sc.ProductSide(lib, model)
+side.mel(synth.make_pcm(30.0, seed=78))
+out = side.encode(0, 0)
+np.save(sys.argv[1], np.concatenate([out["embd_enc"].ravel(), out["cross_k"].ravel(), out["cross_v"].ravel()]))
+side.close()
+""".replace("ROOT_PLACEHOLDER", repr(ROOT))
+
+
+@pytest.mark.parametrize("qtype", ["q5_1", "q8_0"])
+def test_quantised_encoder_forms_agree(tmp_path, qtype):
+    """The encoder projections of a block-quantised model run as f16 operands on the MFMA GEMM from 256 activation rows on (default);
+    WMI_QGEMM_F16_ROWS=0 keeps the block-dot kernel (exact i8 dots, f32 scale per block) for every M.  Both start from the same q8
+    quants and the same blocks; they differ by two f16 operand roundings per term, which the 8-bit quantiser in front of the next
+    projection turns into the occasional flipped quant — the same mechanism, and the same size, as the reference's own response to a
+    1e-6 perturbation (tests/test_gpu_parity.py): the two forms must agree within that yardstick's cap, and the default must not depend
+    on where the weight image was expanded (own launch or inside the row quantiser's)."""
+    outs = {}
+    for name, extra in (("f16", {}), ("blockdot", {"WMI_QGEMM_F16_ROWS": "0"}), ("unfused", {"WMI_QGEMM_NO_FUSED_DEQ": "1"})):
+        env = dict(os.environ); env.update(extra)
+        path = str(tmp_path / f"{name}.npy")
+        r = subprocess.run([sys.executable, "-c", _QFORM_SCRIPT, path, qtype], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = np.load(path).astype(np.float64)
+    assert np.array_equal(outs["f16"], outs["unfused"])
+    a, b = outs["f16"], outs["blockdot"]
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    rel = float(np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(b ** 2)))
+    print(f"{qtype}: f16 form vs block-dot form, encoder output + cross K/V rms-rel {rel:.3e}")
+    assert rel <= 3e-2
