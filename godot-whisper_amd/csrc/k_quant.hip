@@ -657,9 +657,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && NR4 == 1) ? 4 : 1) void k_qrow
         constexpr int MAXV = 6;                              // K <= 1536
         const int nsl = (K + 255) >> 8;
         if (n * nsl > 2 * NW) {
-            // many rows (lock-step chunks, beams): the statistics once per row (wavefront w: rows w, w + NW, ...), parked in the
-            // reduction scratch, then the (row, slice) tasks only load their own 256 columns — same arithmetic, same order
-            float * stat = red;                              // [n][2]: mean, 1 / sqrt(var + eps)  (red is not in use yet)
+            // many rows (lock-step chunks, beams): a row per wavefront (rows w, w + NW, ...), statistics AND all of its slices from the one
+            // copy of the row in registers; the gain / bias vectors arrive two slices at a time.  (Before: statistics per row, a barrier,
+            // then (row, slice) tasks that loaded their 256 columns of x, gain and bias again — five dependent L2 round trips per wavefront
+            // at 8 rows x 1280 columns, ~1.5 us of every LayerNorm launch of a lock-step / beam step.)  Same arithmetic, same order.
             for (int r = wave; r < n; r += NW) {
                 const int src = a.rows ? a.rows[r] : r;
                 const float * xr = a.x32 + (size_t) src * K;
@@ -684,28 +685,36 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && NR4 == 1) ? 4 : 1) void k_qrow
                     }
                 }
                 _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) sqs += WMI_SHX(sqs, o);
-                if (lane == 0) { stat[2 * r] = mean; stat[2 * r + 1] = 1.0f / sqrtf(sqs / (float) K + a.eps); }
-            }
-            __syncthreads();
-            for (int task = wave; task < n * nsl; task += NW) {
-                const int r = task / nsl, sl = task - r * nsl;
-                const int src = a.rows ? a.rows[r] : r;
-                const int cs = (sl * 64 + lane) * 4, ccs = cs < K ? cs : 0;
-                float4 y = *(const float4 *) (a.x32 + (size_t) src * K + ccs);
-                const float4 gg = *(const float4 *) (a.ln_g + ccs), bb = *(const float4 *) (a.ln_b + ccs);
-                const float mean = stat[2 * r], scale = stat[2 * r + 1];
-                y.x -= mean; y.y -= mean; y.z -= mean; y.w -= mean;
-                y.x = __fadd_rn(__fmul_rn(y.x * scale, gg.x), bb.x); y.y = __fadd_rn(__fmul_rn(y.y * scale, gg.y), bb.y);
-                y.z = __fadd_rn(__fmul_rn(y.z * scale, gg.z), bb.z); y.w = __fadd_rn(__fmul_rn(y.w * scale, gg.w), bb.w);
-                if (cs >= K) y = make_float4(0.f, 0.f, 0.f, 0.f);
-                float d, sv;
-                const uint32_t q = quant4<F16D>(y.x, y.y, y.z, y.w, d, sv);
-                if (cs < K) {
-                    *(uint32_t *) (sq + (size_t) r * lda + cs) = q;
-                    if ((lane & 7) == 0) { sd[(cs >> 5) * R8 + r] = d; ss[(cs >> 5) * R8 + r] = sv; }
+                const float scale = 1.0f / sqrtf(sqs / (float) K + a.eps);
+#pragma unroll
+                for (int i0 = 0; i0 < MAXV; i0 += 2) {
+                    if (i0 < nsl) {                              // wave-uniform
+                        float4 gg[2], bb[2];
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            const int cs = ((i0 + u) * 64 + lane) * 4, ccs = cs < K ? cs : 0;
+                            gg[u] = *(const float4 *) (a.ln_g + ccs); bb[u] = *(const float4 *) (a.ln_b + ccs);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 2; ++u) {
+                            if (i0 + u < nsl) {                  // wave-uniform
+                                const int cs = ((i0 + u) * 64 + lane) * 4;
+                                float4 y = v[i0 + u];
+                                y.x = __fadd_rn(__fmul_rn(y.x * scale, gg[u].x), bb[u].x); y.y = __fadd_rn(__fmul_rn(y.y * scale, gg[u].y), bb[u].y);
+                                y.z = __fadd_rn(__fmul_rn(y.z * scale, gg[u].z), bb[u].z); y.w = __fadd_rn(__fmul_rn(y.w * scale, gg[u].w), bb[u].w);
+                                if (cs >= K) y = make_float4(0.f, 0.f, 0.f, 0.f);
+                                float d, sv;
+                                const uint32_t q = quant4<F16D>(y.x, y.y, y.z, y.w, d, sv);
+                                if (cs < K) {
+                                    *(uint32_t *) (sq + (size_t) r * lda + cs) = q;
+                                    if ((lane & 7) == 0) { sd[(cs >> 5) * R8 + r] = d; ss[(cs >> 5) * R8 + r] = sv; }
+                                }
+                            }
+                        }
+                    }
                 }
             }
-        } else                                               // (stat is read before the barrier that ends the prologue; red is written after it)
+        } else                                               // few rows: a (row, slice) task per wavefront, the row's statistics recomputed by each
         for (int task = wave; task < n * nsl; task += NW) {
             const int r = task / nsl, sl = task - r * nsl;
             const int src = a.rows ? a.rows[r] : r;
