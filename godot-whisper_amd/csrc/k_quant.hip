@@ -44,6 +44,21 @@ QGeom q_geom(int qtype) {
     }
 }
 
+// The fifth bits of a q5 block in the order the unpacker wants them: the file keeps bit e for element e; the tiles keep the bit of element
+// 4 i + j (i, j < 4: the low-nibble half, dword i / byte j of the unpacked block) at position 8 j + i and that of element 16 + 4 i + j at
+// 8 j + 4 + i, so that "bit 4 of the four bytes of dword i" is one shift and one mask on the device ((w << (4 - i)) & 0x10101010,
+// (w >> i) & 0x10101010) instead of shift, mask, multiply, mask, shift per dword — the unpack is what bounds the row kernels' tile phase
+// (VALU issue).  Same 32 bits, same bytes in HBM.
+static uint32_t q5_bits_tile_order(const uint8_t * qh_file) {
+    uint32_t q; memcpy(&q, qh_file, 4);
+    uint32_t out = 0;
+    for (int e = 0; e < 32; ++e) {
+        const int half = e >> 4, i = (e & 15) >> 2, j = e & 3;
+        out |= ((q >> e) & 1u) << (8 * j + 4 * half + i);
+    }
+    return out;
+}
+
 void q_repack_host(int qtype, const uint8_t * src, int64_t N, int64_t K, uint8_t * dst) {
     const QGeom g = q_geom(qtype);
     const int64_t nb = K / 32, np = K / 64, ntn = (N + 31) / 32;
@@ -59,8 +74,8 @@ void q_repack_host(int qtype, const uint8_t * src, int64_t N, int64_t K, uint8_t
             switch (qtype) {
                 case QT_Q4_0: memcpy(hd, s, 2);                         memcpy(qs, s + 2, 16); break;
                 case QT_Q4_1: memcpy(hd, s, 4);                         memcpy(qs, s + 4, 16); break;
-                case QT_Q5_0: memcpy(hd, s, 2); memcpy(hd + 4, s + 2, 4); memcpy(qs, s + 6, 16); break;
-                case QT_Q5_1: memcpy(hd, s, 8);                         memcpy(qs, s + 8, 16); break;
+                case QT_Q5_0: memcpy(hd, s, 2); { const uint32_t p5 = q5_bits_tile_order(s + 2); memcpy(hd + 4, &p5, 4); } memcpy(qs, s + 6, 16); break;
+                case QT_Q5_1: memcpy(hd, s, 4); { const uint32_t p5 = q5_bits_tile_order(s + 4); memcpy(hd + 4, &p5, 4); } memcpy(qs, s + 8, 16); break;
                 case QT_Q8_0: memcpy(hd, s, 2);                         memcpy(qs, s + 2, 32); break;
                 default: break;
             }
@@ -97,8 +112,6 @@ template <> struct Geo<QT_Q5_1> { static constexpr int QW = 4, HW = 2; static co
 template <> struct Geo<QT_Q8_0> { static constexpr int QW = 8, HW = 1; static constexpr bool M = false, F16D = true;  };
 template <int QT> constexpr int tile_bytes() { return 64 * 4 * (Geo<QT>::QW + Geo<QT>::HW); }
 
-// bits 0..3 of x -> bit 4 of bytes 0..3 (the fifth bit of four q5 quants)
-__device__ __forceinline__ uint32_t spread4(uint32_t x) { return ((__umul24(x & 0xFu, 0x00204081u)) & 0x01010101u) << 4; }
 
 // one block -> 32 signed 8-bit integers: lo = elements 0..15, hi = elements 16..31 (four per dword, element order);
 // d, m as f32 (m = 0 for the symmetric kinds)
@@ -115,8 +128,8 @@ __device__ __forceinline__ void unpack(const uint32_t (&qs)[Geo<QT>::QW], const 
         for (int i = 0; i < 4; ++i) {
             uint32_t l = qs[i] & 0x0F0F0F0Fu, h = (qs[i] >> 4) & 0x0F0F0F0Fu;
             if constexpr (QT == QT_Q5_0 || QT == QT_Q5_1) {
-                const uint32_t qh = hd[1];
-                l |= spread4(qh >> (4 * i)); h |= spread4(qh >> (16 + 4 * i));
+                const uint32_t qh = hd[1];                   // fifth bits in tile order (q5_bits_tile_order): element 4 i + j at bit 8 j + i, 16 + 4 i + j at 8 j + 4 + i
+                l |= (qh << (4 - i)) & 0x10101010u; h |= (qh >> i) & 0x10101010u;
             }
             if constexpr (QT == QT_Q4_0) {           // x - 8: flip bit 3 (offset binary -> two's complement), sign-extend the nibble
                 l ^= 0x08080808u; h ^= 0x08080808u;
