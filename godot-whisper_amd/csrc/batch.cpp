@@ -71,9 +71,12 @@ bool ensure_batch(whisper_context & ctx, int B) {
     dfree(w.mel_t); dfree(w.conv1); dfree(w.x); dfree(w.xn); dfree(w.q); dfree(w.k); dfree(w.att); dfree(w.vt); dfree(w.h);
     dfree(w.enc_out_h); dfree(w.kvc_k); dfree(w.kvc_v); dfree(w.self_k); dfree(w.self_v); dfree(w.dx); dfree(w.dq); dfree(w.datt); dfree(w.dh);
     dfree(w.logits); dfree(w.xattn); dfree(w.aq); dfree(w.ads); dfree(w.aq16); dfree(w.wq16); dfree(w.att32); dfree(w.datt32);
-    if (w.rows_graph.exec) (void) hipGraphExecDestroy(w.rows_graph.exec);          // the captured step holds the old pointers
-    if (w.rows_graph.graph) (void) hipGraphDestroy(w.rows_graph.graph);
-    w.rows_graph = BatchWork::RowsGraph{};
+    for (auto & rg : w.rows_graph) {                                               // the captured steps hold the old pointers
+        if (rg.exec) (void) hipGraphExecDestroy(rg.exec);
+        if (rg.graph) (void) hipGraphDestroy(rg.graph);
+        rg = BatchWork::RowsGraph{};
+    }
+    w.chain_valid = false;
     if (w.step_dev) (void) hipFree(w.step_dev);
     if (w.sample_dev) (void) hipFree(w.sample_dev);
     if (w.filter_scratch) (void) hipFree(w.filter_scratch);
@@ -222,7 +225,9 @@ bool encode_rows(whisper_context & ctx, const std::vector<int> & rows, const std
 // 3 out, 4 cross scores + P.V, 5 combine, 6 cross out, 7 mlp.0, 8 mlp.2, 9 logits, 10 filters
 static unsigned g_rows_mask = ~0u;
 
-static void enqueue_rows_step(whisper_context & ctx, int nb) {
+// chained: the step starts from what the previous step's pick kernel left on the device (see BatchWork::chain_*): no embedding
+// launch; the rest of the host's step records reaches the filters through extra workgroups of the last layer's self-attention launch
+static void enqueue_rows_step(whisper_context & ctx, int nb, bool chained = false) {
     if (ctx.model.quantised) { enqueue_rows_step_q(ctx, nb); return; }
     BatchWork & b = *ctx.batch; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
     const unsigned M = g_rows_mask;
@@ -235,7 +240,16 @@ static void enqueue_rows_step(whisper_context & ctx, int nb) {
     const int64_t cache_stride = (int64_t) Lt * n_ctx * S;             // between the chunks' self caches
     const int64_t cross_layer = (int64_t) b.enc_rows * Tc * S;
 
-    if (M & 1) k::dec_embed_step((const k::DecStep *) b.step_host, (k::DecStep *) b.step_dev, S, w.d_te, w.d_pe, b.dx, s, nb);
+    // where the chained form mirrors the rest of the host's records: beside the vocabulary projection when that launch is the
+    // matrix-core rows kernel, else beside the last layer's self-attention
+    k::GemvArgs glog{};
+    {
+        glog.n = nb; glog.K = S; glog.N = NV; glog.W = w.d_te; glog.epi = k::EPI_LOGITS; glog.C = b.logits; glog.ldc = NV; glog.ldr = S; glog.S = S;
+        glog.eps = hp.eps; glog.lanes = 1; glog.step_stride = step_stride; glog.cache_row_stride = cache_stride;
+        glog.x32 = b.dx; glog.ln_g = w.d_ln_g; glog.ln_b = w.d_ln_b;
+    }
+    const bool mirror_in_logits = chained && (M & 512) && k::gemv_rows_carries_mirror(glog);
+    if ((M & 1) && !chained) k::dec_embed_step((const k::DecStep *) b.step_host, (k::DecStep *) b.step_dev, S, w.d_te, w.d_pe, b.dx, s, nb);
     auto base = [&](int K, int N, const __half * W, const float * bias, int epi, void * C, int ldc) {
         k::GemvArgs g{};
         g.n = nb; g.K = K; g.N = N; g.W = W; g.bias = bias; g.epi = epi; g.C = C; g.ldc = ldc; g.ldr = S; g.S = S; g.eps = hp.eps;
@@ -253,7 +267,9 @@ static void enqueue_rows_step(whisper_context & ctx, int nb) {
         }
         {   // self-attention, one workgroup per chunk row (same arithmetic as the single-row fused prologue), then
             // out projection + residual
-            if (M & 4) k::self_attn_rows(b.dq, nb, S, ck, cv, cache_stride, &stp->n_kv, step_stride, n_ctx, b.datt, s);
+            const bool mirror = chained && il == Lt - 1 && !mirror_in_logits;
+            if (M & 4) k::self_attn_rows(b.dq, nb, S, ck, cv, cache_stride, &stp->n_kv, step_stride, n_ctx, b.datt, s, nullptr, false,
+                                         mirror ? b.step_host : nullptr, mirror ? b.step_dev : nullptr);
             k::GemvArgs g = base(S, S, l.w_o, l.b_o, k::EPI_F32_BIAS_RESID, b.dx, S);
             g.a16 = b.datt; g.resid = b.dx;
             if (M & 8) k::gemv(g, s);
@@ -288,12 +304,14 @@ static void enqueue_rows_step(whisper_context & ctx, int nb) {
         }
     }
     {
-        k::GemvArgs g = base(S, NV, w.d_te, nullptr, k::EPI_LOGITS, b.logits, NV);
-        g.x32 = b.dx; g.ln_g = w.d_ln_g; g.ln_b = w.d_ln_b;
+        k::GemvArgs g = glog;
+        if (mirror_in_logits) { g.rows_mirror_src = b.step_host; g.rows_mirror_dst = b.step_dev; }
         if (M & 512) k::gemv(g, s);
     }
+    // the picks also prepare the next step on the device (row r: token = pick, position / cache head + 1, x[r] = te[pick] + pe[pos + 1])
+    const k::ChainNext cn{ (k::DecStep *) b.step_dev, w.d_te, w.d_pe, b.dx, S, n_ctx };
     if (M & 1024) k::filter_argmax(b.logits, ctx.state->dev.ban_dev, stp, (k::SampleOut *) b.sample_dev, b.filter_scratch, s,
-                                   (k::SampleOut *) b.sample_host, nb);
+                                   (k::SampleOut *) b.sample_host, nb, S <= 1536 ? &cn : nullptr);
 }
 
 bool decode_rows_step(whisper_context & ctx, int nb) {
@@ -305,7 +323,14 @@ bool decode_rows_step(whisper_context & ctx, int nb) {
         // (rows, encoder length) pair is static: replayed as ONE graph launch instead of 46 host-paced launches (the host needs
         // ~3 us per launch of this kernarg size, the device 1.6 us between dependent kernels: scratch/lab/chain_lab.hip)
         static const bool use_graph = getenv("WMI_NO_GRAPH") == nullptr;
-        BatchWork::RowsGraph & rg = b.rows_graph;
+        static const bool no_chain = getenv("WMI_NO_CHAIN") != nullptr;         // debug / A-B
+        const k::DecStep * hs = (const k::DecStep *) b.step_host;
+        bool chained = !no_chain && b.chain_valid && b.chain_nb == nb && !ctx.model.quantised;
+        for (int r = 0; chained && r < nb; ++r)
+            chained = b.chain_row_ok[r] && hs[r].token == b.chain_token[r] && hs[r].pos == b.chain_pos[r] && hs[r].kv_head == b.chain_pos[r] &&
+                      hs[r].n_kv == b.chain_pos[r] + 1;
+        b.chain_valid = false; b.n_chained += chained ? 1 : 0;
+        BatchWork::RowsGraph & rg = b.rows_graph[chained ? 1 : 0];
         if (rg.nb != nb || rg.T != b.enc_T || rg.rows != b.enc_rows) {
             if (rg.exec) (void) hipGraphExecDestroy(rg.exec);
             if (rg.graph) (void) hipGraphDestroy(rg.graph);
@@ -313,7 +338,7 @@ bool decode_rows_step(whisper_context & ctx, int nb) {
         }
         if (use_graph && !rg.exec && !rg.failed && ++rg.seen > 24) {
             if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                enqueue_rows_step(ctx, nb);
+                enqueue_rows_step(ctx, nb, chained);
                 hipGraph_t g = nullptr;
                 if (hipStreamEndCapture(s, &g) == hipSuccess && g && hipGraphInstantiate(&rg.exec, g, nullptr, nullptr, 0) == hipSuccess) rg.graph = g;
                 else {
@@ -326,12 +351,19 @@ bool decode_rows_step(whisper_context & ctx, int nb) {
             } else rg.failed = true;
         }
         if (use_graph && rg.exec) HIP_TRY(hipGraphLaunch(rg.exec, s));
-        else enqueue_rows_step(ctx, nb);
+        else enqueue_rows_step(ctx, nb, chained);
     }
     {   // every row's result carries the step's sequence number (set by the caller in the step records)
         const k::DecStep * hs = (const k::DecStep *) b.step_host;
         const k::SampleOut * so = (const k::SampleOut *) b.sample_host;
         for (int r = 0; r < nb; ++r) if (!wait_for_sample(&so[r], hs[r].seq, s)) return false;
+        // what the pick kernel has left on the device for the next step (k_filter_pick prepares rows of <= 3 x 512 columns)
+        const HParams & hp = ctx.model.hp;
+        b.chain_valid = !ctx.model.quantised && hp.n_text_state <= 1536 && nb <= 16; b.chain_nb = nb;
+        for (int r = 0; b.chain_valid && r < nb; ++r) {
+            b.chain_token[r] = so[r].id; b.chain_pos[r] = hs[r].pos + 1;
+            b.chain_row_ok[r] = hs[r].pos + 1 < hp.n_text_ctx && hs[r].n_kv == hs[r].pos + 1 && hs[r].kv_head == hs[r].pos;
+        }
     }
     b.t_decode_us += time_us() - t0; b.n_steps++;
     return true;
@@ -356,6 +388,7 @@ double bench_rows_step_chain(whisper_context & ctx, int nb, int iters) {
     if (!ctx.batch || ctx.batch->B < nb || !ctx.batch->step_dev || iters <= 0) return -1.0;
     const char * mask_env = getenv("WMI_STEP_MASK");
     g_rows_mask = mask_env ? (unsigned) strtoul(mask_env, nullptr, 0) : ~0u;
+    ctx.batch->chain_valid = false;                         // the replays below rewrite the device-side records and activation rows
     hipStream_t s = ctx.state->dev.stream;
     hipEvent_t e0, e1;
     if (!HIP_OK(hipEventCreate(&e0)) || !HIP_OK(hipEventCreate(&e1))) return -1.0;
@@ -389,8 +422,11 @@ void free_batch(whisper_context & ctx) {
     dfree(w.mel_t); dfree(w.conv1); dfree(w.x); dfree(w.xn); dfree(w.q); dfree(w.k); dfree(w.att); dfree(w.vt); dfree(w.h);
     dfree(w.enc_out_h); dfree(w.kvc_k); dfree(w.kvc_v); dfree(w.self_k); dfree(w.self_v); dfree(w.dx); dfree(w.dq); dfree(w.datt); dfree(w.dh);
     dfree(w.logits); dfree(w.xattn); dfree(w.aq); dfree(w.ads); dfree(w.aq16); dfree(w.wq16); dfree(w.att32); dfree(w.datt32);
-    if (w.rows_graph.exec) (void) hipGraphExecDestroy(w.rows_graph.exec);
-    if (w.rows_graph.graph) (void) hipGraphDestroy(w.rows_graph.graph);
+    for (auto & rg : w.rows_graph) {
+        if (rg.exec) (void) hipGraphExecDestroy(rg.exec);
+        if (rg.graph) (void) hipGraphDestroy(rg.graph);
+        rg = BatchWork::RowsGraph{};
+    }
     if (w.step_dev) (void) hipFree(w.step_dev);
     if (w.sample_dev) (void) hipFree(w.sample_dev);
     if (w.filter_scratch) (void) hipFree(w.filter_scratch);
@@ -411,7 +447,7 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
     if (!ctx.batch) ctx.batch = new BatchWork();
     ctx.batch->results.assign(n_chunks, {});
     ctx.batch->redo.assign(n_chunks, 0);
-    ctx.batch->t_mel_us = ctx.batch->t_encode_us = ctx.batch->t_decode_us = ctx.batch->t_emit_us = 0; ctx.batch->n_steps = 0;
+    ctx.batch->t_mel_us = ctx.batch->t_encode_us = ctx.batch->t_decode_us = ctx.batch->t_emit_us = 0; ctx.batch->n_steps = 0; ctx.batch->n_chained = 0;
 
     auto run_alone = [&](int c) -> int {                          // the general driver, one chunk at a time
         // as on a fresh whisper_state (what every whisper_full_parallel worker gets, W/whisper.cpp:5837-5843): the
@@ -522,6 +558,7 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
                 std::vector<int> lanes(nb), seeks(nb);
                 for (int r = 0; r < nb; ++r) { lanes[r] = rows[act[r]].lane; seeks[r] = rows[act[r]].seek; }
                 if (!encode_rows(ctx, lanes, seeks, params.audio_ctx)) { WMI_ERR("%s: failed to encode\n", __func__); return -6; }
+                b.chain_valid = false;                             // new windows, possibly other chunks in the rows: every row restarts at cell 0
             }
             for (int r = 0; r < nb; ++r) {
                 Row & row = rows[act[r]]; State & ls = *b.lanes[row.lane];
@@ -554,7 +591,14 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
                     st.seq = b.step_seq + 1;
                     st.space_id = space_id; st.eot = v.eot; st.beg = v.beg; st.n_vocab = v.n_vocab;
                     st.ts_floor_end = v.beg; st.ts_initial_start = v.n_vocab;
-                    if (row.done) { st.token = v.eot; st.pos = 0; st.n_kv = 1; st.kv_head = 0; continue; }   // idle row
+                    if (row.done) {                                                                            // idle row: result discarded
+                        // it keeps following its own picks while the device-side chain allows, so that the other rows' step stays
+                        // chained (rows are independent: own caches, own activation row); otherwise it restarts at cell 0
+                        if (b.chain_valid && b.chain_nb == nb && b.chain_row_ok[r] && b.chain_pos[r] + 1 < hp.n_text_ctx) {
+                            st.token = b.chain_token[r]; st.pos = b.chain_pos[r]; st.n_kv = st.pos + 1; st.kv_head = st.pos;
+                        } else { st.token = v.eot; st.pos = 0; st.n_kv = 1; st.kv_head = 0; }
+                        continue;
+                    }
                     any = true;
                     const int np = (int) row.prompt.size();
                     if (row.n_fed < np) { st.token = row.prompt[row.n_fed]; st.pos = row.n_fed; }
@@ -655,8 +699,8 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
         }
     }
     static const bool dbg_t = getenv("WMI_DEBUG_TIMING") != nullptr;
-    if (dbg_t) fprintf(stderr, "[wmi] full_batch: %d chunks | mel+envelope %.3f ms | encode %.3f | decode %.3f (%d steps) | segments+timestamps %.3f\n",
-                       n_chunks, b.t_mel_us / 1e3, b.t_encode_us / 1e3, b.t_decode_us / 1e3, b.n_steps, b.t_emit_us / 1e3);
+    if (dbg_t) fprintf(stderr, "[wmi] full_batch: %d chunks | mel+envelope %.3f ms | encode %.3f | decode %.3f (%d steps, %d chained) | segments+timestamps %.3f\n",
+                       n_chunks, b.t_mel_us / 1e3, b.t_encode_us / 1e3, b.t_decode_us / 1e3, b.n_steps, b.n_chained, b.t_emit_us / 1e3);
     return 0;
 }
 

@@ -383,11 +383,20 @@ __device__ __forceinline__ void self_attn_row(const __half * __restrict__ sq, co
 __global__ __launch_bounds__(64) void k_self_attn_rows(const __half * __restrict__ q, const __half * __restrict__ kc,
                                                        const __half * __restrict__ vc, int64_t cache_row_stride,
                                                        const int32_t * __restrict__ n_kv_p, int step_stride, int K, int cap,
-                                                       __half * __restrict__ out, float * __restrict__ out32) {
+                                                       __half * __restrict__ out, float * __restrict__ out32,
+                                                       const int32_t * __restrict__ mirror_src, int32_t * __restrict__ mirror_dst) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     float * row = (float *) smem;                       // [cap] scores -> probabilities of this head
     float * qf  = row + cap;                            // [64]
     const int r = blockIdx.x, h = blockIdx.y, lane = threadIdx.x;
+    if (h == K / 64) {
+        // chained lock-step steps (batch.cpp): one extra workgroup per row mirrors the host's step record — filter flags, sequence
+        // number, temperature: words 4.. of DecStep — into the device-side record; token / position / cache head (words 0..3) are
+        // what the previous step's pick kernel left there.  The PCIe read rides beside the attention instead of in front of the step.
+        constexpr int W = (int) (sizeof(DecStep) / 4);
+        if (lane >= 4 && lane < W) mirror_dst[r * W + lane] = ((const volatile int32_t *) mirror_src)[r * W + lane];
+        return;
+    }
     const __half * sk = kc + (int64_t) r * cache_row_stride, * sv = vc + (int64_t) r * cache_row_stride;
     {   // n_kv <= 64 (the decode loop): the wave-level routine shared with the one-row prologue
         const int hs[1] = { h };
@@ -1293,8 +1302,23 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
 
     const int kbeg = KSPLIT ? wave * (K >> 2) : 0;
     const int kend = KSPLIT ? kbeg + (K >> 2) : K;
+    int nblk = (int) gridDim.x;
+    if constexpr (!KSPLIT) {
+        // chained lock-step steps (batch.cpp): one extra workgroup of the vocabulary projection mirrors words 4.. of the rows' step
+        // records (filter flags, sequence number, temperature) from pinned host memory into the device records the filter kernels
+        // read next — the PCIe round trip (~5 us) rides beside the longest launch of the step instead of in front of it
+        if (a.rows_mirror_src) {
+            nblk -= 1;
+            if ((int) blockIdx.x == nblk) {
+                constexpr int W = (int) (sizeof(DecStep) / 4);
+                for (int i = tid; i < n * W; i += 256)
+                    if ((i % W) >= 4) ((int32_t *) a.rows_mirror_dst)[i] = ((const volatile int32_t *) a.rows_mirror_src)[i];
+                return;
+            }
+        }
+    }
     int tile = KSPLIT ? (int) blockIdx.x : (int) (blockIdx.x * 4 + wave);
-    const int tstride = KSPLIT ? (int) gridDim.x : (int) (gridDim.x * 4);
+    const int tstride = KSPLIT ? nblk : nblk * 4;
 
     // ---- weight prefetch of the first pass (independent of the activations)
     uint4 wf[MAXF];
@@ -1654,6 +1678,7 @@ void launch_rows_mfma(const GemvArgs & a, hipStream_t st) {
     if (!KSPLIT && blocks > cap) blocks = cap;
     static std::atomic<uint64_t> lds_ok{0};
     if (smem > 48 * 1024) allow_full_lds((const void *) k_rows_mfma<KSPLIT, EPI_T>, lds_ok);
+    if (!KSPLIT && a.rows_mirror_src) blocks += 1;           // the step-record mirror (see the kernel)
     hipLaunchKernelGGL((k_rows_mfma<KSPLIT, EPI_T>), dim3(blocks), dim3(256), smem, st, a);
 }
 
@@ -1695,14 +1720,16 @@ void dec_embed_step(const DecStep * host_step, DecStep * dev_step, int S, const 
 }
 
 void self_attn_rows(const __half * q, int n, int K, const __half * kc, const __half * vc, int64_t cache_row_stride,
-                    const int32_t * n_kv, int step_stride, int cap, __half * out, hipStream_t st, float * out32, bool long_cache) {
+                    const int32_t * n_kv, int step_stride, int cap, __half * out, hipStream_t st, float * out32, bool long_cache,
+                    const void * mirror_src, void * mirror_dst) {
     if (long_cache) {
         const size_t smem = ((size_t) cap + 64 + 256 + 4) * sizeof(float);
         hipLaunchKernelGGL(k_self_attn_rows_long, dim3(n, K / 64), dim3(256), smem, st, q, kc, vc, cache_row_stride, n_kv, step_stride, K, cap, out, out32);
         return;
     }
     const size_t smem = ((size_t) cap + 64) * sizeof(float);
-    hipLaunchKernelGGL(k_self_attn_rows, dim3(n, K / 64), dim3(64), smem, st, q, kc, vc, cache_row_stride, n_kv, step_stride, K, cap, out, out32);
+    hipLaunchKernelGGL(k_self_attn_rows, dim3(n, K / 64 + (mirror_src ? 1 : 0)), dim3(64), smem, st, q, kc, vc, cache_row_stride, n_kv, step_stride, K, cap, out, out32,
+                       (const int32_t *) mirror_src, (int32_t *) mirror_dst);
 }
 
 static bool g_rows_valu = false;
@@ -1723,13 +1750,17 @@ void gemv(const GemvArgs & a, hipStream_t st) {
     if (sp.base) { GemvArgs b = a; b.stamps = sp.base; b.stamp_slot = sp.slot; gemv_(b, st); return; }
     gemv_(a, st);
 }
+static bool rows_on_mfma(const GemvArgs & a) {
+    static const bool rows_valu_env = getenv("WMI_ROWS_VALU") != nullptr;
+    const bool rows_valu = rows_valu_env || g_rows_valu;
+    return a.lanes && a.n >= 2 && a.n <= 16 && !a.sa_q && (!a.comb_o || a.N < 8192) && (a.K % 128) == 0 &&
+           (a.epi != EPI_QKV_DEC || (a.S % 16) == 0) && (!rows_valu || a.n > 8);
+}
+bool gemv_rows_carries_mirror(const GemvArgs & a) { return rows_on_mfma(a) && a.N >= 8192; }
 static void gemv_(const GemvArgs & a, hipStream_t st) {
     // lock-step chunk rows go to the matrix cores (WMI_ROWS_VALU=1 keeps them on the VALU kernel, whose per-row
     // arithmetic is bit-identical to the single-row path: used by the parity tests to pin the control flow)
-    static const bool rows_valu_env = getenv("WMI_ROWS_VALU") != nullptr;
-    const bool rows_valu = rows_valu_env || g_rows_valu;
-    const bool mfma_ok = a.lanes && a.n >= 2 && a.n <= 16 && !a.sa_q && (!a.comb_o || a.N < 8192) && (a.K % 128) == 0 &&
-                         (a.epi != EPI_QKV_DEC || (a.S % 16) == 0) && (!rows_valu || a.n > 8);
+    const bool mfma_ok = rows_on_mfma(a);
     if (mfma_ok) {
         static const bool generic = getenv("WMI_ROWS_GENERIC_EPI") != nullptr;       // A/B knob
         const bool vec = !generic && (a.N % 16) == 0 && (a.ldc % 4) == 0 && (!a.resid || (a.ldr % 4) == 0) &&

@@ -117,6 +117,8 @@ __global__ __launch_bounds__(64) void k_filter_pick(const Partial * __restrict__
     const unsigned long long ts0 = stamp_t0(sp.base);
     const int lane = threadIdx.x;
     part += (size_t) blockIdx.x * nparts; stp += blockIdx.x; out += blockIdx.x; if (out_host) out_host += blockIdx.x;
+    DecStep * const step_rw = chain.step_rw ? chain.step_rw + blockIdx.x : nullptr;      // lock-step rows: a record and an activation row per chunk
+    float * const chain_x = chain.x + (size_t) blockIdx.x * chain.S;
     // the step record and the partials are requested together (field by field at their first use, the record cost three more
     // dependent round trips on this one-wavefront kernel)
     const int4 st0 = *(const int4 *) stp;                  // token, pos, n_kv, kv_head
@@ -150,7 +152,7 @@ __global__ __launch_bounds__(64) void k_filter_pick(const Partial * __restrict__
     // the next greedy step feeds this pick at the next position (the host checks that before it replays the chained step):
     // its embedding + positional rows are requested now, the result goes to the host while they are in flight
     const int pos1 = st0.y + 1;
-    const bool chain_on = chain.step_rw && pos1 < chain.n_pos;
+    const bool chain_on = step_rw && pos1 < chain.n_pos;
     // lane L owns columns 512 u + 8 L .. + 8 of the row (XU chunks of 512 columns): one 16-byte and two 16-byte loads per chunk
     uint4 trv[XU]; float4 prv[XU][2];
     if (chain_on) {
@@ -179,7 +181,7 @@ __global__ __launch_bounds__(64) void k_filter_pick(const Partial * __restrict__
             ((int4 *) out_host)[1] = h[1];
         }
     }
-    if (chain.step_rw) {
+    if (step_rw) {
         if (chain_on) {
 #pragma unroll
             for (int u = 0; u < XU; ++u) {
@@ -187,12 +189,12 @@ __global__ __launch_bounds__(64) void k_filter_pick(const Partial * __restrict__
                 if (c < chain.S) {                           // k_dec_embed_step's arithmetic: f32(te) + pe
                     const __half2 * h = (const __half2 *) &trv[u];
                     const float2 f0 = __half22float2(h[0]), f1 = __half22float2(h[1]), f2 = __half22float2(h[2]), f3 = __half22float2(h[3]);
-                    *(float4 *) (chain.x + c)     = make_float4(f0.x + prv[u][0].x, f0.y + prv[u][0].y, f1.x + prv[u][0].z, f1.y + prv[u][0].w);
-                    *(float4 *) (chain.x + c + 4) = make_float4(f2.x + prv[u][1].x, f2.y + prv[u][1].y, f3.x + prv[u][1].z, f3.y + prv[u][1].w);
+                    *(float4 *) (chain_x + c)     = make_float4(f0.x + prv[u][0].x, f0.y + prv[u][0].y, f1.x + prv[u][0].z, f1.y + prv[u][0].w);
+                    *(float4 *) (chain_x + c + 4) = make_float4(f2.x + prv[u][1].x, f2.y + prv[u][1].y, f3.x + prv[u][1].z, f3.y + prv[u][1].w);
                 }
             }
         }
-        if (lane == 0) *(int4 *) chain.step_rw = make_int4(id, pos1, st0.z + 1, st0.w + 1);      // token, pos, n_kv, kv_head
+        if (lane == 0) *(int4 *) step_rw = make_int4(id, pos1, st0.z + 1, st0.w + 1);      // token, pos, n_kv, kv_head
     }
     stamp_end(sp.base, sp.slot, blockIdx.x, ts0);
 }
@@ -316,8 +318,8 @@ void filter_argmax(const float * logits, const uint8_t * static_ban, const DecSt
     Partial * part = (Partial *) scratch;
     const bool fused = fused_parts > 0 && fused_parts <= FS_MAX_PARTS && n_rows == 1;
     if (!fused) hipLaunchKernelGGL(k_filter_stats, dim3(NB, n_rows), dim3(NT), 0, st, logits, static_ban, step, part, stamp_next());
-    ChainNext cn{};                                         // chaining is a one-row affair (the greedy step of device.cpp)
-    if (chain && n_rows == 1) cn = *chain;
+    ChainNext cn{};                                         // one row: the greedy step of device.cpp; rows: the lock-step step of batch.cpp
+    if (chain) cn = *chain;
     if (cn.step_rw && cn.S > 1536) cn = ChainNext{};          // (no such model: the row registers cover 3 chunks; the host then embeds)
     const int xu = cn.step_rw ? (cn.S + 511) / 512 : 1;
     const int np = fused ? fused_parts : NB;

@@ -203,6 +203,9 @@ struct GemvArgs {
     // chained greedy steps: mirror *step_copy_src (DecStep in pinned host memory) into *step_copy_dst by an extra workgroup
     // (one-row f16 rows x plain projection + residual only: the last mlp.2 of the step)
     const void * step_copy_src; void * step_copy_dst;
+    // chained lock-step steps: the rows' records (words 4.. of each DecStep) mirrored by an extra workgroup of the vocabulary
+    // projection on the matrix cores (k_rows_mfma); ask gemv_rows_carries_mirror() first, the other row kernels ignore these
+    const void * rows_mirror_src; void * rows_mirror_dst;
     // weight prefetch for the NEXT launch of a dependent chain (k_qrows): pf_groups row groups of pf_group_bytes each, contiguous at
     // pf_ptr; workgroup i touches one dword per 128-byte line of the groups g = i (mod grid) — the workgroup of the next launch
     // that streams group g sits on the same XCD when both grids are multiples of 8
@@ -214,11 +217,14 @@ struct GemvArgs {
     const uint8_t * fs_ban; const void * fs_step; FsPartial * fs_part;
 };
 int gemv_fused_parts(const GemvArgs & a);
+bool gemv_rows_carries_mirror(const GemvArgs & a);
 // lock-step chunks: single-token self-attention of n rows, row r against the cache at kc/vc + r * cache_row_stride with
 // n_kv[r * step_stride] cells; same arithmetic as the fused prologue of gemv (GemvArgs::sa_*).  out [n][K] f16
 void self_attn_rows(const __half * q, int n, int K, const __half * kc, const __half * vc, int64_t cache_row_stride,
                     const int32_t * n_kv, int step_stride, int cap, __half * out, hipStream_t st, float * out32 = nullptr,
-                    bool long_cache = false);   // long_cache: the host knows a row has > 64 cells: four wavefronts per (row, head)
+                    bool long_cache = false,    // long_cache: the host knows a row has > 64 cells: four wavefronts per (row, head)
+                    const void * mirror_src = nullptr, void * mirror_dst = nullptr);   // chained lock-step steps: + one workgroup per row copying
+                                                // words 4.. of the row's DecStep from pinned host memory to the device record (short-cache form only)
 // split cross-attention partials -> out [n][S] f16 (the separate form of GemvArgs::comb_*)
 void set_xattn_probe_skip(int mask);      // probe only
 void attn_cross_partials_layout(int n, int H, int T, float * scratch, const float ** po, const float ** pl, const float ** pm, int * pns);

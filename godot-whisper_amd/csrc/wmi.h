@@ -281,11 +281,15 @@ struct BatchWork {
     int32_t  step_seq = 0;                                    // sequence number of the last lock-step decode step
     // the lock-step step as a captured graph, keyed by what its launches depend on (rows, encoder length, chunk rows of the cross
     // cache); eager until the same key has been decoded for a while (capture + instantiate cost more than a window's steps)
-    struct RowsGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int nb = -1, T = -1, rows = -1, seen = 0; bool failed = false; } rows_graph;
+    struct RowsGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int nb = -1, T = -1, rows = -1, seen = 0; bool failed = false; } rows_graph[2];   // [chained]
+    // chained steps: the pick kernel of a step leaves every row's next token, position and cache head in step_dev and the next
+    // activation row in dx (as the one-row greedy step does, DeviceState::chain_*); a step whose host records say the same for
+    // every row starts without the embedding launch (which reads the records over PCIe in front of everything else)
+    bool chain_valid = false; int chain_nb = 0; int32_t chain_token[16] = {}, chain_pos[16] = {}; bool chain_row_ok[16] = {};
     std::vector<State *> lanes;                               // lanes[0] is the context's own state (not owned)
     std::vector<std::vector<Segment>> results;                // per chunk of the last wmi_full_batch call
     std::vector<int> redo;                                    // per chunk: 1 if it was re-run alone (temperature fallback)
-    int64_t t_mel_us = 0, t_encode_us = 0, t_decode_us = 0, t_emit_us = 0; int n_steps = 0;
+    int64_t t_mel_us = 0, t_encode_us = 0, t_decode_us = 0, t_emit_us = 0; int n_steps = 0, n_chained = 0;
 };
 
 } // namespace wmi
