@@ -1675,10 +1675,11 @@ void launch_rows_mfma(const GemvArgs & a, hipStream_t st) {
     // weights in flight (811 workgroups, one tile per wavefront: 19.9 us at 8 rows; 512: 15.9; 576 and more: 20.5)
     static const int cap = getenv("WMI_ROWS_BLOCKS") ? atoi(getenv("WMI_ROWS_BLOCKS")) : 512;        // A/B knob
     if (blocks > 1024) blocks = 1024;
-    if (!KSPLIT && blocks > cap) blocks = cap;
+    const bool mirror = !KSPLIT && a.rows_mirror_src;        // the step-record mirror (see the kernel): one more workgroup, inside the resident-sized grid
+    if (!KSPLIT && blocks > cap - (mirror ? 1 : 0)) blocks = cap - (mirror ? 1 : 0);
     static std::atomic<uint64_t> lds_ok{0};
     if (smem > 48 * 1024) allow_full_lds((const void *) k_rows_mfma<KSPLIT, EPI_T>, lds_ok);
-    if (!KSPLIT && a.rows_mirror_src) blocks += 1;           // the step-record mirror (see the kernel)
+    if (mirror) blocks += 1;
     hipLaunchKernelGGL((k_rows_mfma<KSPLIT, EPI_T>), dim3(blocks), dim3(256), smem, st, a);
 }
 

@@ -165,6 +165,47 @@ def test_wide_gemm_tile_is_bit_identical():
     assert a == b
 
 
+_RAGGED_BATCH_SCRIPT = r"""
+import json, sys
+sys.path.insert(0, ROOT_PLACEHOLDER)
+import __graft_entry__ as entry
+entry.load_package()
+from godot_whisper_amd import host, runtime, synth
+lib = runtime.require_gpu(); runtime.silence_logs(lib)
+out = {}
+for shape in ("base.en", "micro"):
+    node = host.SpeechToText(lib); node.set_language_model(synth.make_model(shape, seed=4242))
+    if shape == "micro": node.language = "de"
+    secs = [30.0, 11.0, 4.0, 47.0, 30.0, 22.5, 30.0, 8.0, 30.0, 15.0]
+    pcms = [synth.make_pcm(s, seed=640 + i, gate=(i % 3 == 1)) for i, s in enumerate(secs)]
+    runs = []
+    for rep in range(4):                               # the chained form of the step is captured during the second call, then replayed
+        p = node.full_params("", 0); p.temperature_inc = 0.0
+        if shape == "micro": p.max_tokens = 0          # long windows: rows finish many steps apart, caches pass 64 cells
+        res = node.transcribe_batch(pcms, params=p)
+        runs.append([[[int(t["id"]), int(t["tid"]), float(t["p"]), float(t["plog"]), int(t["t0"]), int(t["t1"])] for t in r[1:]] for r in res])
+    out[shape] = runs
+    node.close()
+print("RESULT" + json.dumps(out))
+""".replace("ROOT_PLACEHOLDER", repr(ROOT))
+
+
+def test_chained_lockstep_steps_are_bit_identical():
+    """Lock-step steps start from what the previous step's pick kernel left on the device (token, position, cache head, activation
+    row; finished rows keep following their own picks) or, with WMI_NO_CHAIN=1, from an embedding launch that reads every row's
+    record from the host.  Ragged chunk lengths (rows finish at different steps, two windows for one chunk, more chunks than rows):
+    ids, probabilities and token times must be the same bit for bit (first calls eager, later ones replayed from the captured graphs)."""
+    def run(env_extra):
+        env = dict(os.environ); env.update(env_extra)
+        r = subprocess.run([sys.executable, "-c", _RAGGED_BATCH_SCRIPT], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1][len("RESULT"):])
+    a, b = run({}), run({"WMI_NO_CHAIN": "1"})
+    for shape in a:
+        assert sum(len(c) > 0 for c in a[shape][0]) >= 6, shape
+        assert a[shape] == b[shape], shape
+
+
 # ------------------------------------------------------------------------------------------------ quantised projections: the two forms
 _QFORM_SCRIPT = r"""
 import sys
