@@ -277,7 +277,8 @@ def main():
             step_bytes = (DEC_MB_PER_TOKEN - 18.4) * 1e6 + min(args.chunks, 16) * 18.4e6      # weights once, cross K/V per chunk
             out["roofline"] = {"kernel": "lock-step decode step (k_rows_mfma projections, per-row attention, filters): %d rows" % min(args.chunks, 16),
                                "bound": "hbm", "achieved": round(step_bytes / (us_step * 1e-6) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
-                               "frac": round(step_bytes / (us_step * 1e-6) / 1e9 / 8000.0, 4), "traffic": None, "algorithmic_bytes": int(step_bytes), "avg_us": round(us_step, 2)}
+                               "frac": round(step_bytes / (us_step * 1e-6) / 1e9 / 8000.0, 4), "traffic": None, "algorithmic_bytes": int(step_bytes), "avg_us": round(us_step, 2),
+                               "note": "the probe replays the step with its embedding launch; inside a call every step after a window's first is chained on the device (no embedding launch), see decode_ms_per_token"}
           else:
             step(0)                                          # the step record / caches of a headline transcription (17 cells)
             hp_S = lib.whisper_model_n_audio_state(ctx); T = lib.whisper_model_n_audio_ctx(ctx); NV = lib.whisper_n_vocab(ctx)
