@@ -336,7 +336,10 @@ bool decode_rows_step(whisper_context & ctx, int nb) {
             if (rg.graph) (void) hipGraphDestroy(rg.graph);
             rg = BatchWork::RowsGraph{}; rg.nb = nb; rg.T = b.enc_T; rg.rows = b.enc_rows;
         }
-        if (use_graph && !rg.exec && !rg.failed && ++rg.seen > 24) {
+        ++rg.seen;                                                // (counted over both forms: the embedding form runs once per window)
+        const BatchWork::RowsGraph & og = b.rows_graph[chained ? 0 : 1];
+        const int seen_other = (og.nb == nb && og.T == b.enc_T && og.rows == b.enc_rows) ? og.seen : 0;
+        if (use_graph && !rg.exec && !rg.failed && rg.seen + seen_other > 24) {
             if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                 enqueue_rows_step(ctx, nb, chained);
                 hipGraph_t g = nullptr;

@@ -661,8 +661,11 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
     // launches go out eagerly (the host then pays ~4 us per launch: equal to the replay for the 40-launch short-cache step,
     // twice the replay's time for the long-cache form)
     if (d.step_seen_T != Tc) { d.step_seen_T = Tc; for (auto & g2 : d.step_graphs) g2.seen = 0; }
-    int & seen = sg.seen;
-    const bool capture_now = use_graph && !exec && !d.step_capture_failed && ++seen > 64;
+    // (the count is shared by the forms: the embedding form runs once per window, the chained form for every other step — counted
+    // alone it would be captured, at tens of milliseconds, only after 65 windows)
+    ++sg.seen;
+    int seen_all = 0; for (const auto & g2 : d.step_graphs) seen_all += g2.seen;
+    const bool capture_now = use_graph && !exec && !d.step_capture_failed && seen_all > 64;
     if (capture_now) {
         // first use: run once eagerly (lets the launchers set their function attributes), then capture
         // (not for the chained form: a step's pick kernel advances the device-side record, so the step must not run twice — and its
