@@ -73,6 +73,7 @@ def main():
         local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    comm_backend = "none (1 rank)" if world == 1 else ("gloo (rehearsal, staged through the host)" if rehearsal else "nccl (RCCL over xGMI)")
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -248,7 +249,10 @@ def main():
             "decode_ms_per_token": round((t6[2] / 1e3) / dec_calls, 4),
             "mel_ms": round((t6[0] / 1e3) / args.steps, 4),
             "sample_ms_per_step": round((t6[5] / 1e3) / args.steps, 4),
-            "weight_bcast_ms": round(1e3 * t_bcast, 3), "weight_bcast": "one RCCL broadcast of the packed device arena (no re-parse on the other ranks)",
+            "comm_backend": comm_backend,
+            "weight_bcast_ms": round(1e3 * t_bcast, 3),
+            "weight_bcast": ("none (one rank: the file is parsed in place)" if world == 1 else
+                             f"one {comm_backend} broadcast of the packed device arena (no re-parse on the other ranks)"),
         }
         if args.chunks > 1:                          # lock-step calls keep their own timers (last call)
             t4 = (C.c_int64 * 4)(); ns = C.c_int32(); lib.wmi_get_batch_timings(ctx, t4, C.byref(ns))

@@ -331,14 +331,17 @@ bool decode_rows_step(whisper_context & ctx, int nb) {
                       hs[r].n_kv == b.chain_pos[r] + 1;
         b.chain_valid = false; b.n_chained += chained ? 1 : 0;
         BatchWork::RowsGraph & rg = b.rows_graph[chained ? 1 : 0];
-        if (rg.nb != nb || rg.T != b.enc_T || rg.rows != b.enc_rows) {
+        // the key includes the epoch of the run-time kernel switches (wmi_set_lockstep_exact: VALU rows / one-group attention):
+        // a step captured under the other mode would keep replaying that mode's kernels
+        const int epoch = k::mode_epoch();
+        if (rg.nb != nb || rg.T != b.enc_T || rg.rows != b.enc_rows || rg.epoch != epoch) {
             if (rg.exec) (void) hipGraphExecDestroy(rg.exec);
             if (rg.graph) (void) hipGraphDestroy(rg.graph);
-            rg = BatchWork::RowsGraph{}; rg.nb = nb; rg.T = b.enc_T; rg.rows = b.enc_rows;
+            rg = BatchWork::RowsGraph{}; rg.nb = nb; rg.T = b.enc_T; rg.rows = b.enc_rows; rg.epoch = epoch;
         }
         ++rg.seen;                                                // (counted over both forms: the embedding form runs once per window)
         const BatchWork::RowsGraph & og = b.rows_graph[chained ? 0 : 1];
-        const int seen_other = (og.nb == nb && og.T == b.enc_T && og.rows == b.enc_rows) ? og.seen : 0;
+        const int seen_other = (og.nb == nb && og.T == b.enc_T && og.rows == b.enc_rows && og.epoch == epoch) ? og.seen : 0;
         if (use_graph && !rg.exec && !rg.failed && rg.seen + seen_other > 24) {
             if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                 enqueue_rows_step(ctx, nb, chained);

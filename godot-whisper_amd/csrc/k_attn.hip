@@ -942,7 +942,7 @@ size_t attn_cross_scratch_floats(int n, int H, int T) {
 }
 
 static bool g_attn_one_group = false;
-void set_attn_one_group(bool on) { g_attn_one_group = on; }
+void set_attn_one_group(bool on) { if (on != g_attn_one_group) bump_mode_epoch(); g_attn_one_group = on; }
 
 void attn_encoder(const __half * q, const __half * k, const __half * vt, int T, int Tpad, int S, int H, float scale,
                   __half * out, hipStream_t st, int B, float * out32) {

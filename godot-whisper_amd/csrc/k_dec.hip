@@ -12,6 +12,7 @@
 //     prologue produces them straight from the f32 residual stream (saves one launch per sub-block);
 //   * f32 accumulation, 64-lane butterfly reduction, then the same fused epilogues as the big GEMM.
 
+#include <atomic>
 #include "kernels.h"
 #include "wave_ops.h"
 #include <type_traits>
@@ -1734,7 +1735,10 @@ void self_attn_rows(const __half * q, int n, int K, const __half * kc, const __h
 }
 
 static bool g_rows_valu = false;
-void set_rows_valu(bool on) { g_rows_valu = on; }
+static std::atomic<int> g_mode_epoch{0};
+int  mode_epoch() { return g_mode_epoch.load(std::memory_order_relaxed); }
+void bump_mode_epoch() { g_mode_epoch.fetch_add(1, std::memory_order_relaxed); }
+void set_rows_valu(bool on) { if (on != g_rows_valu) bump_mode_epoch(); g_rows_valu = on; }
 bool rows_valu_enabled() { static const bool env = getenv("WMI_ROWS_VALU") != nullptr; return env || g_rows_valu; }
 
 static void gemv_(const GemvArgs & a, hipStream_t st);

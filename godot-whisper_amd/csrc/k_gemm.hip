@@ -18,6 +18,7 @@
 
 #include "kernels.h"
 #include "wave_ops.h"
+#include "gemm_epi.h"
 
 #include <cstdlib>
 #include <type_traits>
@@ -26,55 +27,9 @@ namespace wmi { namespace k {
 
 namespace {
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-typedef float    floatx4 __attribute__((ext_vector_type(4)));
+using namespace gemm_detail;
 
 constexpr int BK = 64;                 // K extent of one LDS tile (two MFMA k-steps)
-
-__device__ __forceinline__ float round_f16(float x) { return __half2float(f2h(x)); }
-
-// GELU exactly as the reference evaluates it: input rounded to f16, tanh form in f32, result rounded
-// to f16 (its 65536-entry table is this function tabulated; W/ggml.c:1400-1423, 2229-2231)
-__device__ __forceinline__ float gelu16(float x) {
-    const float xh = round_f16(x);
-    const float g  = 0.5f * xh * (1.0f + tanhf(0.79788456080286535587989211986876f * xh * (1.0f + 0.044715f * xh * xh)));
-    return round_f16(g);
-}
-
-// Epilogue variant for the encoder GEMMs (24.6 M evaluations per batched mlp.0 launch): tanh through the hardware
-// exponential, tanh(u) = 1 - 2 / (exp(2u) + 1) — ~10 VALU instructions instead of libm's tanhf (which, like a
-// 65 536-entry table gather, costs as much as the whole GEMM: 39 -> 72 us measured).  v_exp_f32 is good to ~2 ulp
-// of f32; after the two f16 roundings the result equals gelu16's except for a 1-ulp(f16) flip on a few per mille of
-// the inputs (same trade as exp16_fast in the encoder attention).  The decoder's one-row kernels keep tanhf.
-__device__ __forceinline__ float gelu16_fast(float x) {
-    const float xh = round_f16(x);
-    const float u  = 0.79788456080286535587989211986876f * xh * (1.0f + 0.044715f * xh * xh);
-    const float t  = 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * u) + 1.0f);      // v_rcp_f32: 1 ulp, no division sequence
-    return round_f16(0.5f * xh * (1.0f + t));
-}
-
-// Two GELUs at once for the transposed epilogue (a lane holds adjacent columns): gelu(x) = x / (1 + exp(-2u)), u = k0 x (1 + k1 x^2),
-// which is 0.5 x (1 + tanh u) without the 1 + tanh cancellation — packed f32 multiplies / FMAs, one v_exp_f32 and one v_rcp_f32 per
-// element: ~8 issue slots against ~18 for gelu16_fast (at M = 12 000 the GELU arithmetic was most of mlp.0's 5 us epilogue, itself
-// 39 % of a workgroup's life: profiles/r03b_gemm_phase_probe.txt).  Input and result rounded to f16 like the reference's table;
-// over all 63 488 finite f16 inputs this form differs from the table on 271 entries (<= 2 ulp, all in the negative tail or at
-// |x| < 0.36), gelu16_fast on 422 (<= 5 ulp) — numpy emulation, hardware exp / rcp add their own 1-2 ulp of f32.
-typedef float    float2v __attribute__((ext_vector_type(2)));
-typedef _Float16 half2v  __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ half2v gelu16_pair(float2v x) {
-    const half2v xh = __builtin_convertvector(x, half2v);
-    const float2v xf = {(float) xh[0], (float) xh[1]};
-    constexpr float C0 = -2.0f * 0.79788456080286535587989211986876f * 1.44269504088896340736f;
-    constexpr float C1 = C0 * 0.044715f;
-    const float2v c0 = {C0, C0}, c1 = {C1, C1}, one = {1.0f, 1.0f};
-    const float2v w = __builtin_elementwise_fma(xf * xf, c1, c0) * xf;          // -2u log2(e)
-    const float2v e = {__builtin_amdgcn_exp2f(w[0]), __builtin_amdgcn_exp2f(w[1])};
-    const float2v d = one + e;
-    const float2v r = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
-    const float2v g = xf * r;
-    return __builtin_convertvector(g, half2v);
-}
 
 __device__ __forceinline__ uint32_t lds_off(int row, int chunk) {      // byte offset inside a [rows][64] f16 tile
     return (uint32_t) (row * 128 + ((chunk ^ (row & 7)) << 4));
@@ -263,189 +218,11 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
     else if constexpr (!RT_ORIENT) k_loops(std::true_type{});
     else { if (swap) k_loops(std::true_type{}); else k_loops(std::false_type{}); }
 
-    // ------------------------------------------------------------------ epilogue
-    // fragment (i, j): rows m = mb + i*16 + fq*4 + r (r = 0..3), column n = nb + j*16 + frow.
-    // Interior tiles take an instantiation without bounds checks: a per-element `if (m < M)` makes every store its own
-    // basic block, and hipcc then waits vmcnt(0) before each one (vmcnt also counts stores on gfx9-family parts), i.e.
-    // the 64 stores of a lane complete one after the other (profiles/: -10..30 % kernel time on the M = 12 000 GEMMs).
+    // ------------------------------------------------------------------ epilogue (gemm_epi.h)
     const int mb = m0 + wm * (BM / 2), nb = n0 + wn * (BN / WN_);
-    auto epilogue = [&](auto guard_tag) {
-        constexpr bool GUARD = decltype(guard_tag)::value;
-        float biasv[FN];
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int n = nb + j * 16 + frow;
-            biasv[j] = (a.bias && (!GUARD || n < a.N)) ? a.bias[n] : 0.0f;
-        }
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int n = nb + j * 16 + frow;
-            if (GUARD && n >= a.N) continue;
-            const float bias = biasv[j];
-            // residual / positional operand of this fragment column: all FM x 4 values requested before the first store (the output
-            // is updated in place, so element by element every load had to wait for the previous store: one round trip per element)
-            float rpre[FM][4];
-            if constexpr (EPI == EPI_F32_BIAS_RESID || EPI == EPI_CONV2) {
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = mb + i * 16 + fq * 4 + r;
-                        rpre[i][r] = a.resid[(size_t) ((GUARD && m >= a.M) ? a.M - 1 : m) * a.ldr + n];
-                    }
-            }
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int mrow = mb + i * 16 + fq * 4;
-                if constexpr (EPI == EPI_QKV_ENC) {
-                    const int seg = n / a.S, c = n - seg * a.S;
-                    if (seg == 2) {            // V^T: four consecutive time steps per lane -> one 8-byte store
-                        // batched encode: row m = chunk * rows_per_chunk + t, V^T is [chunk][S][Tpad]
-                        const int rpc = a.rows_per_chunk > 0 ? a.rows_per_chunk : a.M;
-                        const int cb = mrow / rpc, t0 = mrow - cb * rpc;
-                        __half * vt = (__half *) a.aux2 + (size_t) cb * a.chunk_stride_aux2 + (size_t) c * a.ldaux2;
-                        if ((!GUARD || mrow + 3 < a.M) && t0 + 3 < rpc && ((t0 & 3) == 0)) {
-                            half4 v;
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = (_Float16) pin_f32(acc[i][j][r] + bias);
-                            *(half4 *) (vt + vt_pos(t0)) = v;
-                        } else {
-                            for (int r = 0; r < 4; ++r) {
-                                const int m = mrow + r;
-                                if (m >= a.M) continue;
-                                const int cb2 = m / rpc, t = m - cb2 * rpc;
-                                ((__half *) a.aux2)[(size_t) cb2 * a.chunk_stride_aux2 + (size_t) c * a.ldaux2 + vt_pos(t)] = f2h(acc[i][j][r] + bias);
-                            }
-                        }
-                        continue;
-                    }
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = mrow + r;
-                        if (GUARD && m >= a.M) continue;
-                        const float v = acc[i][j][r] + bias;
-                        if (seg == 0) ((__half *) a.C)[(size_t) m * a.ldc + c] = f2h(v);
-                        else          ((__half *) a.aux)[(size_t) m * a.ldaux + c] = f2h(v);
-                    }
-                    continue;
-                }
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const int m = mrow + r;
-                    if (GUARD && m >= a.M) continue;
-                    const float v = acc[i][j][r];
-                    if constexpr (EPI == EPI_F16_BIAS) {
-                        ((__half *) a.C)[(size_t) m * a.ldc + n] = f2h(v + bias);
-                    } else if constexpr (EPI == EPI_F16_BIAS_GELU) {
-                        ((__half *) a.C)[(size_t) m * a.ldc + n] = f2h(gelu16_fast(v + bias));
-                    } else if constexpr (EPI == EPI_F32_BIAS_RESID) {
-                        ((float *) a.C)[(size_t) m * a.ldc + n] = (v + bias) + rpre[i][r];
-                    } else if constexpr (EPI == EPI_CONV2) {
-                        const float g = gelu16_fast(v + bias);
-                        if (a.aux) ((float *) a.aux)[(size_t) m * a.ldaux + n] = g;
-                        ((float *) a.C)[(size_t) m * a.ldc + n] = rpre[i][r] + g;
-                    } else if constexpr (EPI == EPI_QKV_DEC) {
-                        // The q | k | v segment is decided per 16-column fragment on a WAVE-UNIFORM value
-                        // (S is a multiple of 16, so a fragment never straddles a segment).  A per-lane
-                        // three-way `if` here is miscompiled by hipcc 7.2 for gfx950 (the third arm's
-                        // pointer select is dropped by the control-flow structurizer: v lands in the k
-                        // cache) — see DESIGN.md "toolchain hazards"; wmi_selftest_proj / tests/test_gpu_parity.py::test_decoder_projection_paths_agree pins it.
-                        const int seg = __builtin_amdgcn_readfirstlane((nb + j * 16) / a.S);
-                        const int c = n - seg * a.S;
-                        __half * dst; float val;
-                        if (seg == 0)      { dst = (__half *) a.C    + (size_t) m * a.ldc;    val = (v + bias) * a.scale; }
-                        else if (seg == 1) { dst = (__half *) a.aux  + (size_t) m * a.ldaux;  val = v * a.scale; }
-                        else               { dst = (__half *) a.aux2 + (size_t) m * a.ldaux2; val = v + bias; }
-                        dst[c] = f2h(val);
-                    } else if constexpr (EPI == EPI_CROSS_KV) {
-                        const int il = n / (2 * a.S), c = n - il * 2 * a.S;
-                        if (c < a.S) ((__half *) a.C)[il * a.layer_stride + (size_t) m * a.ldc + c] = f2h(v * a.scale);
-                        else         ((__half *) a.aux)[il * a.layer_stride + (size_t) m * a.ldaux + (c - a.S)] = f2h(v + bias);
-                    } else if constexpr (EPI == EPI_Q_SCALED) {
-                        ((__half *) a.C)[(size_t) m * a.ldc + n] = f2h((v + bias) * a.scale);
-                    }
-                }
-            }
-        }
-    };
-    // swapped orientation: fragment (i, j) holds row m = mb + i*16 + frow, columns n = nb + j*16 + fq*4 + r (r = 0..3)
-    auto epilogue_sw = [&](auto guard_tag) {
-        constexpr bool GUARD = decltype(guard_tag)::value;
-#pragma unroll
-        for (int j = 0; j < FN; ++j) {
-            const int n = nb + j * 16 + fq * 4;
-            if (GUARD && n >= a.N) continue;                       // N is a multiple of 4 on every caller of these epilogues
-            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (a.bias) b4 = *(const float4 *) (a.bias + n);
-            const float bias[4] = {b4.x, b4.y, b4.z, b4.w};
-            float4 rpre[FM];
-            if constexpr (EPI == EPI_F32_BIAS_RESID || EPI == EPI_CONV2) {
-#pragma unroll
-                for (int i = 0; i < FM; ++i) {
-                    const int m = mb + i * 16 + frow;
-                    rpre[i] = *(const float4 *) (a.resid + (size_t) ((GUARD && m >= a.M) ? a.M - 1 : m) * a.ldr + n);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < FM; ++i) {
-                const int m = mb + i * 16 + frow;
-                if (GUARD && m >= a.M) continue;
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = acc[i][j][r];
-                auto put16 = [&](__half * dst, const float (&x)[4]) {
-                    half4 h;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) h[r] = (_Float16) pin_f32(x[r]);
-                    *(half4 *) dst = h;
-                };
-                if constexpr (EPI == EPI_F16_BIAS) {
-                    const float x[4] = {v[0] + bias[0], v[1] + bias[1], v[2] + bias[2], v[3] + bias[3]};
-                    put16((__half *) a.C + (size_t) m * a.ldc + n, x);
-                } else if constexpr (EPI == EPI_F16_BIAS_GELU) {
-                    const float2v x0 = {v[0] + bias[0], v[1] + bias[1]}, x1 = {v[2] + bias[2], v[3] + bias[3]};
-                    const half2v g0 = gelu16_pair(x0), g1 = gelu16_pair(x1);
-                    half4 h; h[0] = g0[0]; h[1] = g0[1]; h[2] = g1[0]; h[3] = g1[1];
-                    *(half4 *) ((__half *) a.C + (size_t) m * a.ldc + n) = h;
-                } else if constexpr (EPI == EPI_Q_SCALED) {
-                    const float x[4] = {(v[0] + bias[0]) * a.scale, (v[1] + bias[1]) * a.scale, (v[2] + bias[2]) * a.scale, (v[3] + bias[3]) * a.scale};
-                    put16((__half *) a.C + (size_t) m * a.ldc + n, x);
-                } else if constexpr (EPI == EPI_F32_BIAS_RESID) {
-                    float4 o;
-                    o.x = (v[0] + bias[0]) + rpre[i].x; o.y = (v[1] + bias[1]) + rpre[i].y; o.z = (v[2] + bias[2]) + rpre[i].z; o.w = (v[3] + bias[3]) + rpre[i].w;
-                    *(float4 *) ((float *) a.C + (size_t) m * a.ldc + n) = o;
-                } else if constexpr (EPI == EPI_CONV2) {
-                    float4 g, o;
-                    const float2v x0 = {v[0] + bias[0], v[1] + bias[1]}, x1 = {v[2] + bias[2], v[3] + bias[3]};
-                    const half2v g0 = gelu16_pair(x0), g1 = gelu16_pair(x1);
-                    g.x = (float) g0[0]; g.y = (float) g0[1]; g.z = (float) g1[0]; g.w = (float) g1[1];
-                    if (a.aux) *(float4 *) ((float *) a.aux + (size_t) m * a.ldaux + n) = g;
-                    o.x = rpre[i].x + g.x; o.y = rpre[i].y + g.y; o.z = rpre[i].z + g.z; o.w = rpre[i].w + g.w;
-                    *(float4 *) ((float *) a.C + (size_t) m * a.ldc + n) = o;
-                } else if constexpr (EPI == EPI_QKV_ENC) {
-                    // q (bias, no scale here: the encoder scales the scores) | k (no bias); the V^T third runs in the first orientation
-                    const int seg = __builtin_amdgcn_readfirstlane(n0 / a.S);       // tile-uniform: BN | S
-                    const int c = n - seg * a.S;
-                    const float x[4] = {v[0] + bias[0], v[1] + bias[1], v[2] + bias[2], v[3] + bias[3]};
-                    if (seg == 0) put16((__half *) a.C + (size_t) m * a.ldc + c, x);
-                    else          put16((__half *) a.aux + (size_t) m * a.ldaux + c, x);
-                } else if constexpr (EPI == EPI_CROSS_KV) {
-                    // columns [il][K: S | V: S]; four consecutive columns never straddle a boundary (4 | S)
-                    const int il = n / (2 * a.S), c = n - il * 2 * a.S;
-                    if (c < a.S) {
-                        const float x[4] = {v[0] * a.scale, v[1] * a.scale, v[2] * a.scale, v[3] * a.scale};
-                        put16((__half *) a.C + il * a.layer_stride + (size_t) m * a.ldc + c, x);
-                    } else {
-                        const float x[4] = {v[0] + bias[0], v[1] + bias[1], v[2] + bias[2], v[3] + bias[3]};
-                        put16((__half *) a.aux + il * a.layer_stride + (size_t) m * a.ldaux + (c - a.S), x);
-                    }
-                }
-            }
-        }
-    };
     const bool interior = m0 + BM <= a.M && n0 + BN <= a.N && !(a.no_glds & 2);
-    if (SWAP && swap) { if (interior) epilogue_sw(std::false_type{}); else epilogue_sw(std::true_type{}); }
-    else              { if (interior) epilogue(std::false_type{});    else epilogue(std::true_type{}); }
+    if (SWAP && swap) { if (interior) epilogue_cols<EPI, FM, FN, false>(a, acc, mb, nb, n0, lane); else epilogue_cols<EPI, FM, FN, true>(a, acc, mb, nb, n0, lane); }
+    else              { if (interior) epilogue_rows<EPI, FM, FN, false>(a, acc, mb, nb, lane);     else epilogue_rows<EPI, FM, FN, true>(a, acc, mb, nb, lane); }
     if (a.probe && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the probe's "done" includes the stores leaving the wavefront
         unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));

@@ -235,6 +235,8 @@ void gemv(const GemvArgs & a, hipStream_t st);
 void set_attn_one_group(bool on);              // encoder attention: never split the keys over two wave groups (bit-identical for any batch)
 bool rows_valu_enabled();
 void set_rows_valu(bool on);                  // lock-step rows: true = VALU kernel (bit-identical to the one-row path), false = MFMA
+int  mode_epoch();                             // bumped by every run-time switch that changes which kernels a step launches: a captured
+void bump_mode_epoch();                        // step graph is replayed only under the epoch it was captured in
 
 // ---------------------------------------------------------------- device-side logit filters + greedy pick (k_sample.hip)
 // One decode step's dynamic inputs; lives in device memory, refreshed by a 64-byte H2D copy per step so that

@@ -281,7 +281,7 @@ struct BatchWork {
     int32_t  step_seq = 0;                                    // sequence number of the last lock-step decode step
     // the lock-step step as a captured graph, keyed by what its launches depend on (rows, encoder length, chunk rows of the cross
     // cache); eager until the same key has been decoded for a while (capture + instantiate cost more than a window's steps)
-    struct RowsGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int nb = -1, T = -1, rows = -1, seen = 0; bool failed = false; } rows_graph[2];   // [chained]
+    struct RowsGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int nb = -1, T = -1, rows = -1, epoch = -1, seen = 0; bool failed = false; } rows_graph[2];   // [chained]
     // chained steps: the pick kernel of a step leaves every row's next token, position and cache head in step_dev and the next
     // activation row in dx (as the one-row greedy step does, DeviceState::chain_*); a step whose host records say the same for
     // every row starts without the embedding launch (which reads the records over PCIe in front of everything else)

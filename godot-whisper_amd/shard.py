@@ -40,17 +40,20 @@ class _DevMem:
         self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (ptr, False), "version": 2}
 
 
-def load_replicated(lib, model_bytes: bytes | None, rank: int, world: int, dist, device_index: int, torch_device=None):
+def load_replicated(lib, model_bytes: bytes | None, rank: int, world: int, dist, device_index: int, torch_device=None,
+                    force_collectives: bool = False):
     """Every rank ends up with a context holding the same weights; rank 0 is the only one that parses payloads.
     Collectives: the header image (~1 MB: hyper-parameters, mel filters, vocabulary, tensor directory) and ONE broadcast of
     the packed device arena straight into every rank's arena allocation (RCCL over xGMI: base.en 148 MB, large-v3 q5_1 1.18 GB)
-    — no D2H, no re-parse, no re-quantisation on the other ranks.  Returns (ctx, seconds spent in the arena broadcast)."""
+    — no D2H, no re-parse, no re-quantisation on the other ranks.  Returns (ctx, seconds spent in the arena broadcast).
+    force_collectives: issue the collectives at world size 1 too (tests: the RCCL calls on the non-torch arena allocation can
+    be executed on a one-GPU box, where RCCL admits one rank per device)."""
     import ctypes as C
     import time
 
     import numpy as np
     import torch
-    if world == 1:
+    if world == 1 and not force_collectives:
         buf = C.create_string_buffer(model_bytes, len(model_bytes))
         ctx = lib.wmi_init_from_buffer_on_device(C.cast(buf, C.c_void_p), len(model_bytes), device_index)
         assert ctx, "model load failed"
@@ -90,9 +93,9 @@ def load_replicated(lib, model_bytes: bytes | None, rank: int, world: int, dist,
     return ctx, dt
 
 
-def gather_results(local: dict, world: int, dist) -> dict:
+def gather_results(local: dict, world: int, dist, force_collectives: bool = False) -> dict:
     """local: {chunk_id: result}; returns the merged {chunk_id: result} on every rank (host-side gather)."""
-    if world == 1:
+    if world == 1 and not force_collectives:
         return dict(local)
     parts = [None] * world
     dist.all_gather_object(parts, local)
