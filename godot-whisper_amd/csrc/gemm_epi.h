@@ -3,6 +3,7 @@
 // applied to the accumulator fragments of v_mfma_f32_16x16x32_f16, in both fragment orientations.
 #pragma once
 #include "kernels.h"
+#include "wave_ops.h"
 
 namespace wmi { namespace k { namespace gemm_detail {
 
@@ -235,6 +236,139 @@ __device__ __forceinline__ void epilogue_cols(const GemmArgs & a, floatx4 (&acc)
                 }
             }
         }
+    }
+}
+
+// ---- transposed orientation with FULL-LINE stores.  The plain form above stores 8 bytes per lane: a wave instruction covers 16 rows x 32
+// bytes, i.e. 16 partial-line requests for 512 bytes, and the epilogue of a big tile is bound by exactly that request count (measured on
+// mlp.0 at M = 12 000, 192 x 256 tiles: 4.5 us of epilogue per tile with a bias-add-and-store epilogue, the same with every store aimed at
+// one L2-resident patch — not HBM bandwidth, not the GELU arithmetic: scratch/lab/gemm8_lab.hip).  Here the fragments of one 16-row band
+// are exchanged between lanes until a lane holds 16 consecutive bytes and a wave instruction covers 8 rows x 128 bytes (f16: two
+// v_permlane16_swap per fragment pair put columns fq*4 .. of fragments j, j + 1 next to each other; then the lane halves frow < 8 / >= 8
+// of every 16-lane row trade one 16-byte register through DPP row_ror:8): a quarter of the requests, pure data movement — every stored
+// value is the plain form's.  Needs an even number of fragment columns in the wave tile (FN = 2, 4) and, for the segmented epilogues,
+// segments that are multiples of the wave tile's 16 FN columns.
+__device__ __forceinline__ uint4 ror8_u4(uint4 t) {
+    t.x = (uint32_t) xor_lane<8>((int) t.x); t.y = (uint32_t) xor_lane<8>((int) t.y);
+    t.z = (uint32_t) xor_lane<8>((int) t.z); t.w = (uint32_t) xor_lane<8>((int) t.w);
+    return t;
+}
+// P, Q: this lane's 16-byte pieces of two column blocks of row frow.  Afterwards P belongs to row (frow & 7), Q to row (frow & 7) + 8,
+// both in column block (frow >> 3): lanes frow < 8 keep P and get the partner's P, lanes frow >= 8 keep Q and get the partner's Q.
+__device__ __forceinline__ void trade_rows8(uint4 & P, uint4 & Q, const bool lo) {
+    uint4 t = lo ? Q : P;
+    t = ror8_u4(t);
+    if (lo) Q = t; else P = t;
+}
+
+template <int EPI, int FM, int FN, bool GUARD>
+__device__ __forceinline__ void epilogue_cols_wide(const GemmArgs & a, floatx4 (&acc)[FM][FN], const int mb, const int nb, const int n0, const int lane) {
+    static_assert(FN % 2 == 0, "wide stores pair fragment columns");
+    static_assert(EPI == EPI_F16_BIAS || EPI == EPI_F16_BIAS_GELU || EPI == EPI_Q_SCALED || EPI == EPI_F32_BIAS_RESID || EPI == EPI_CROSS_KV || EPI == EPI_QKV_ENC, "epilogue");
+    if constexpr (GUARD) {                                 // a wave tile that crosses the right edge of the matrix takes the plain form (wave-uniform)
+        if (nb + 16 * FN > a.N) { epilogue_cols<EPI, FM, FN, true>(a, acc, mb, nb, n0, lane); return; }
+    }
+    const int frow = lane & 15, fq = lane >> 4;
+    const bool lo = frow < 8;
+    const int r8 = frow & 7, hb = frow >> 3;
+    float bias[FN][4];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias) b4 = *(const float4 *) (a.bias + nb + j * 16 + fq * 4);
+        bias[j][0] = b4.x; bias[j][1] = b4.y; bias[j][2] = b4.z; bias[j][3] = b4.w;
+    }
+    if constexpr (EPI == EPI_F32_BIAS_RESID) {
+        // f32 rows: a lane already holds 16 bytes (4 columns); fragments j, j + 1 are 128 consecutive bytes of a row
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+            const int m = mb + i * 16 + frow;
+            float4 rp[FN];
+#pragma unroll
+            for (int j = 0; j < FN; ++j) rp[j] = *(const float4 *) (a.resid + (size_t) ((GUARD && m >= a.M) ? a.M - 1 : m) * a.ldr + nb + j * 16 + fq * 4);
+#pragma unroll
+            for (int j = 0; j < FN; j += 2) {
+                uint4 P, Q;
+                {
+                    float4 o;
+                    o.x = (acc[i][j][0] + bias[j][0]) + rp[j].x; o.y = (acc[i][j][1] + bias[j][1]) + rp[j].y;
+                    o.z = (acc[i][j][2] + bias[j][2]) + rp[j].z; o.w = (acc[i][j][3] + bias[j][3]) + rp[j].w;
+                    P = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w));
+                    o.x = (acc[i][j + 1][0] + bias[j + 1][0]) + rp[j + 1].x; o.y = (acc[i][j + 1][1] + bias[j + 1][1]) + rp[j + 1].y;
+                    o.z = (acc[i][j + 1][2] + bias[j + 1][2]) + rp[j + 1].z; o.w = (acc[i][j + 1][3] + bias[j + 1][3]) + rp[j + 1].w;
+                    Q = make_uint4(__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w));
+                }
+                trade_rows8(P, Q, lo);
+                const int mr = mb + i * 16 + r8, n = nb + (j + hb) * 16 + fq * 4;
+                if (!GUARD || mr < a.M)     *(uint4 *) ((float *) a.C + (size_t) mr * a.ldc + n) = P;
+                if (!GUARD || mr + 8 < a.M) *(uint4 *) ((float *) a.C + (size_t) (mr + 8) * a.ldc + n) = Q;
+            }
+        }
+        return;
+    } else {
+    // f16 rows.  Destination of the wave tile's 16 FN columns: one segment (wave-uniform)
+    __half * dst; int ldd; int c0; float scale = 1.0f; bool use_bias = true;
+    if constexpr (EPI == EPI_QKV_ENC) {
+        const int seg = __builtin_amdgcn_readfirstlane(nb / a.S);
+        c0 = nb - seg * a.S;
+        dst = seg == 0 ? (__half *) a.C : (__half *) a.aux; ldd = seg == 0 ? a.ldc : a.ldaux;
+    } else if constexpr (EPI == EPI_CROSS_KV) {
+        const int il = __builtin_amdgcn_readfirstlane(nb / (2 * a.S)), c = nb - il * 2 * a.S;
+        const bool isk = c < a.S;
+        dst = (isk ? (__half *) a.C : (__half *) a.aux) + il * a.layer_stride; ldd = isk ? a.ldc : a.ldaux; c0 = isk ? c : c - a.S;
+        scale = isk ? a.scale : 1.0f; use_bias = !isk;
+    } else {
+        dst = (__half *) a.C; ldd = a.ldc; c0 = nb;
+        if constexpr (EPI == EPI_Q_SCALED) scale = a.scale;
+    }
+    const int cb = ((fq & 1) << 4) | ((fq >> 1) << 3);         // this lane's 8 columns inside a 32-column fragment pair after the swaps
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        uint4 blk[FN / 2];
+#pragma unroll
+        for (int j = 0; j < FN; j += 2) {
+            uint32_t w[2][2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const floatx4 v = acc[i][j + jj];
+                half4 h;
+                if constexpr (EPI == EPI_F16_BIAS_GELU) {
+                    const float2v x0 = {v[0] + bias[j + jj][0], v[1] + bias[j + jj][1]}, x1 = {v[2] + bias[j + jj][2], v[3] + bias[j + jj][3]};
+                    const half2v g0 = gelu16_pair(x0), g1 = gelu16_pair(x1);
+                    h[0] = g0[0]; h[1] = g0[1]; h[2] = g1[0]; h[3] = g1[1];
+                } else if constexpr (EPI == EPI_CROSS_KV) {
+                    // K: acc * scale (no bias) | V: acc + bias — the plain form's two expressions, chosen per wave
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[r] = (_Float16) pin_f32(use_bias ? v[r] + bias[j + jj][r] : v[r] * scale);
+                } else if constexpr (EPI == EPI_Q_SCALED) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[r] = (_Float16) pin_f32((v[r] + bias[j + jj][r]) * scale);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[r] = (_Float16) pin_f32(v[r] + bias[j + jj][r]);
+                }
+                const uint2 u = *(const uint2 *) &h;
+                w[jj][0] = u.x; w[jj][1] = u.y;
+            }
+            // rows (16 lanes) 1 / 3 of fragment j <-> rows 0 / 2 of fragment j + 1
+            const auto s0 = __builtin_amdgcn_permlane16_swap(w[0][0], w[1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(w[0][1], w[1][1], false, false);
+            blk[j / 2] = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        }
+#pragma unroll
+        for (int b = 0; b < FN / 2; b += 2) {
+            if constexpr (FN / 2 >= 2) {
+                uint4 P = blk[b], Q = blk[b + 1];
+                trade_rows8(P, Q, lo);
+                const int mr = mb + i * 16 + r8, c = c0 + (b + hb) * 32 + cb;
+                if (!GUARD || mr < a.M)     *(uint4 *) (dst + (size_t) mr * ldd + c) = P;
+                if (!GUARD || mr + 8 < a.M) *(uint4 *) (dst + (size_t) (mr + 8) * ldd + c) = Q;
+            } else {
+                const int m = mb + i * 16 + frow, c = c0 + b * 32 + cb;
+                if (!GUARD || m < a.M) *(uint4 *) (dst + (size_t) m * ldd + c) = blk[b];
+            }
+        }
+    }
     }
 }
 

@@ -221,7 +221,21 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
     // ------------------------------------------------------------------ epilogue (gemm_epi.h)
     const int mb = m0 + wm * (BM / 2), nb = n0 + wn * (BN / WN_);
     const bool interior = m0 + BM <= a.M && n0 + BN <= a.N && !(a.no_glds & 2);
-    if (SWAP && swap) { if (interior) epilogue_cols<EPI, FM, FN, false>(a, acc, mb, nb, n0, lane); else epilogue_cols<EPI, FM, FN, true>(a, acc, mb, nb, n0, lane); }
+    // full-line stores (gemm_epi.h: epilogue_cols_wide) wherever the wave tile has an even number of fragment columns and the epilogue is one
+    // of the row-major ones; a.no_glds bit 2 (WMI_GEMM_NARROW_STORES, A/B) keeps the 8-byte form
+    constexpr bool WIDE_OK = FN % 2 == 0 && (EPI == EPI_F16_BIAS || EPI == EPI_F16_BIAS_GELU || EPI == EPI_Q_SCALED || EPI == EPI_F32_BIAS_RESID ||
+                                             EPI == EPI_CROSS_KV || EPI == EPI_QKV_ENC);
+    if (SWAP && swap) {
+        if constexpr (WIDE_OK) {
+            if (!(a.no_glds & 4)) {
+                if (interior) epilogue_cols_wide<EPI, FM, FN, false>(a, acc, mb, nb, n0, lane); else epilogue_cols_wide<EPI, FM, FN, true>(a, acc, mb, nb, n0, lane);
+            } else {
+                if (interior) epilogue_cols<EPI, FM, FN, false>(a, acc, mb, nb, n0, lane); else epilogue_cols<EPI, FM, FN, true>(a, acc, mb, nb, n0, lane);
+            }
+        } else {
+            if (interior) epilogue_cols<EPI, FM, FN, false>(a, acc, mb, nb, n0, lane); else epilogue_cols<EPI, FM, FN, true>(a, acc, mb, nb, n0, lane);
+        }
+    }
     else              { if (interior) epilogue_rows<EPI, FM, FN, false>(a, acc, mb, nb, lane);     else epilogue_rows<EPI, FM, FN, true>(a, acc, mb, nb, lane); }
     if (a.probe && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // the probe's "done" includes the stores leaving the wavefront
@@ -310,7 +324,8 @@ void dispatch(const GemmArgs & a, hipStream_t st) {
 void gemm(int epi, const GemmArgs & a_in, hipStream_t st) {
     static const bool no_glds = getenv("WMI_GEMM_NO_GLDS") != nullptr;       // debug / A-B: register-staged loop for every tile size
     static const bool guard_all = getenv("WMI_GEMM_GUARD_ALL") != nullptr;   // debug / A-B: bounds-checked epilogue for every tile
-    GemmArgs a = a_in; a.no_glds = (no_glds ? 1 : 0) | (guard_all ? 2 : 0);
+    static const bool narrow = getenv("WMI_GEMM_NARROW_STORES") != nullptr;  // debug / A-B: 8-byte epilogue stores
+    GemmArgs a = a_in; a.no_glds = (no_glds ? 1 : 0) | (guard_all ? 2 : 0) | (narrow ? 4 : 0);
     switch (epi) {
         case EPI_F16_BIAS:       dispatch<EPI_F16_BIAS>(a, st); break;
         case EPI_F16_BIAS_GELU:  dispatch<EPI_F16_BIAS_GELU>(a, st); break;

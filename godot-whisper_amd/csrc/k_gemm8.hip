@@ -43,34 +43,54 @@ __device__ __forceinline__ uint32_t lds_off8(int row, int chunk) {     // byte o
     return (uint32_t) (row * 128 + ((chunk ^ (row & 7)) << 4));
 }
 
-template <int BM, int EPI, int NST, bool SWAPPED>
+// Ring depths NSA (A image) / NSW (W image) and who requests what:
+//   3 / 3  both groups request their share of step t + 2 behind their own fragment reads (BM <= 160: the ring fits 160 KB three deep)
+//   2 / 3  BM = 192: three whole stages are 8 KB too many, so the smaller image gets two — group 0 requests A of step t + 1 at the START
+//          of its LOAD slot (the stage was freed by the barrier in front of it: two slots of flight), group 1 requests W of step t + 2
+//          behind its reads (four slots)
+//   2 / 2  BM = 256: group 0 requests both images of step t + 1 at the start of its LOAD slot
+template <int BM, int EPI, int NSA, int NSW, bool SWAPPED, int KS>
 __global__ __launch_bounds__(512) void k_gemm8(const GemmArgs a) {
     constexpr int BN = 256, FM = BM / 32, FN = 4;
-    constexpr int STAGE = (BM + BN) * 128;                 // bytes of one ring slot: A image, then W image
-    constexpr int NA = BM / 8;                             // 1 KiB DMA pieces (8 rows) of the A image; the W image has 32
-    constexpr int PA1 = NA / 8, PA0 = (NA - 4 * PA1) / 4;  // A pieces per wave of group 1 / group 0 (BM = 96: 1 / 2)
-    static_assert(BM % 32 == 0 && 4 * PA0 + 4 * PA1 == NA, "tile height");
+    constexpr int SZA = BM * 128, SZW = BN * 128;          // bytes of one stage of each ring
+    constexpr int RING_W = NSA * SZA;                      // the W ring starts behind the A ring
+    constexpr int NA = BM / 8, NW = BN / 8;                // 1 KiB DMA pieces (8 rows) per image
+    constexpr bool DEEP = NSA == 3 && NSW == 3;
+    // pieces per wave of group 0 / group 1
+    constexpr int PA1 = DEEP ? NA / 8 : (NSA == 3 ? NA / 4 : 0), PA0 = DEEP ? (NA - 4 * PA1) / 4 : (NSA == 3 ? 0 : NA / 4);
+    constexpr int PW1 = DEEP ? NW / 8 : (NSW == 3 ? NW / 4 : 0), PW0 = DEEP ? NW / 8 : (NSW == 3 ? 0 : NW / 4);
+    static_assert(BM % 32 == 0 && 4 * PA0 + 4 * PA1 == NA && 4 * PW0 + 4 * PW1 == NW, "tile");
+    static_assert((NSA == 2 || NSA == 3) && (NSW == 2 || NSW == 3) && !(NSA == 3 && NSW == 2), "ring depths");
+    constexpr int NKK = KS / 32;                           // MFMA k-steps per slot; 64 / KS slots per K step
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef WMI_G8_LAB                                           // scratch/lab/gemm8_lab.hip: ablations
+    const int lab = a.no_glds;
+#else
+    constexpr int lab = 0;
+#endif
     const int grp = wave >> 2, wn = wave & 3;
     const unsigned long long pt0 = a.probe ? wall_clock64() : 0ull;
-    unsigned long long pt1 = 0ull, pt2 = 0ull;
+    unsigned long long pt1 = 0ull, pt2 = 0ull, pte = 0ull;
 
-    // tile order: every XCD (workgroup id % 8) gets a contiguous run of the list; the list walks column groups of <= 8 tiles, inside
-    // a group row by row: the 32 workgroups an XCD runs at a time share 4 A panels and <= 8 W panels (<= 2 MB + 4 x BM x K x 2 B in its 4 MB L2)
-    const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN, nwg = ntm * ntn;
-    int wg = blockIdx.x;
-    {
-        const int q = nwg / 8, r = nwg % 8, xcd = wg % 8, idx = wg / 8;
-        wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    // Persistent workgroups (one per CU): the tile list walks column groups of <= 8 tiles, inside a group row by row; XCD x
+    // (workgroup id % 8) owns the contiguous run [x * per, (x + 1) * per) of it and its workgroups take the run's entries in turn, so the
+    // 32 tiles an XCD works on at a time share 4 A panels and <= 8 W panels (<= 2 MB + 4 x BM x K x 2 B in its 4 MB L2).
+    const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN, ntiles = ntm * ntn;
+    const int nx = (int) gridDim.x >> 3;                    // workgroups per XCD (grid is a multiple of 8)
+    const int xcd = (int) blockIdx.x & 7, jx = (int) blockIdx.x >> 3;
+    const int per = (ntiles + 7) >> 3;
+    const int run = ntiles - xcd * per < per ? ntiles - xcd * per : per;     // entries of this XCD's run (may be <= 0)
+    const int n_my = run > jx ? (run - jx + nx - 1) / nx : 0;
     constexpr int GN = 8;
-    const int ng = wg / (ntm * GN), rem = wg - ng * (ntm * GN);
-    const int gcur = ntn - ng * GN < GN ? ntn - ng * GN : GN;
-    const int tm = rem / gcur, tn = ng * GN + rem % gcur;
-    const int m0 = tm * BM, n0 = tn * BN;
+    auto tile_origin = [&](int i, int & m0, int & n0) {
+        const int idx = xcd * per + jx + i * nx;
+        const int ng = idx / (ntm * GN), rem = idx - ng * (ntm * GN);
+        const int gcur = ntn - ng * GN < GN ? ntn - ng * GN : GN;
+        m0 = (rem / gcur) * BM; n0 = (ng * GN + rem % gcur) * BN;
+    };
 
     floatx4 acc[FM][FN];
 #pragma unroll
@@ -79,147 +99,240 @@ __global__ __launch_bounds__(512) void k_gemm8(const GemmArgs a) {
         for (int j = 0; j < FN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
 
     const int nk = a.K / 64;
+    const int total = n_my * nk;                           // K steps of this workgroup, over all of its tiles
     const uint32_t lds0 = lds_addr(smem);
     const int frow = lane & 15, fq = lane >> 4;
-    // fragment addresses inside a ring slot (kk = 0; kk = 1 flips chunk bit 2: + or - 64 bytes, resolved per row below)
+    // fragment addresses inside a stage for k-step 0; k-step q flips bit 2 of the chunk index: chunk = (4 q + fq) ^ (row & 7)
     uint32_t offA[FM], offB[FN];
 #pragma unroll
     for (int i = 0; i < FM; ++i) offA[i] = lds_off8(grp * (BM / 2) + i * 16 + frow, fq);
 #pragma unroll
-    for (int j = 0; j < FN; ++j) offB[j] = BM * 128 + lds_off8(wn * 64 + j * 16 + frow, fq);
+    for (int j = 0; j < FN; ++j) offB[j] = RING_W + lds_off8(wn * 64 + j * 16 + frow, fq);
 
     auto body = [&](auto grp_tag) {
         constexpr int G = decltype(grp_tag)::value;
-        constexpr int PA = G ? PA1 : PA0;
-        constexpr int LPT = PA + 4;                       // DMA instructions per wave and tile
-        const __half * qA[PA > 0 ? PA : 1]; const __half * qB[4];
-        uint32_t dA[PA > 0 ? PA : 1], dB[4];
+        // Who requests what.  A DMA instruction holds its wave for ~110 cycles wherever it is issued (the CU's vector memory path accepts
+        // 1 KiB per ~27 cycles: ~38 B/clk), so requests belong in LOAD slots, where the wave has nothing else to do — between the MFMAs of
+        // an MFMA slot each one cost the matrix pipe 115-130 cycles (measured: profiles/r04_gemm8_lab.txt).
+        //   3 / 3  both groups request their share of step t + 2
+        //   2 / 3  group 0 requests A of step t + 1 (its LOAD slot starts behind the barrier that freed the stage: two slots of flight),
+        //          group 1 requests W of step t + 2
+        //   2 / 2  group 0 requests both images of step t + 1
+        constexpr int PA = G ? PA1 : PA0, PW = G ? PW1 : PW0;
+        constexpr int LATE = (NSA == 3 ? PA : 0) + (NSW == 3 ? PW : 0);      // this wave's DMA instructions per step that run TWO steps ahead
         const int prow = lane >> 3;
+        struct Stream { int i = 0, k = 0, n = 0; const __half * base = nullptr; };
+        Stream sa, sw;
+        uint32_t vA[PA > 0 ? PA : 1], vW[PW > 0 ? PW : 1];
+        const int pa0 = DEEP ? (G ? 4 * PA0 + wn * PA1 : wn * PA0) : wn * PA;     // this wave's first piece of each image
+        const int pw0 = DEEP ? wave * PW : wn * PW;
 #pragma unroll
-        for (int p = 0; p < PA; ++p) {
-            const int piece = G ? 4 * PA0 + wn * PA1 + p : wn * PA0 + p;
-            const int lrow = piece * 8 + prow, pch = (lane & 7) ^ (lrow & 7);
-            int r = m0 + lrow; if (r > a.M - 1) r = a.M - 1;
-            qA[p] = a.A + (size_t) r * a.lda + pch * 8;
-            dA[p] = (uint32_t) piece * 1024u;
+        for (int p = 0; p < PW; ++p) {                    // W rows never leave the matrix (N is a multiple of 256): offsets fixed for the launch
+            const int lrow = (pw0 + p) * 8 + prow, pch = (lane & 7) ^ (lrow & 7);
+            vW[p] = (uint32_t) (lrow * a.ldw + pch * 8) * 2u;
         }
+        auto adv = [&](Stream & t) { ++t.n; if (++t.k == nk) { t.k = 0; ++t.i; } };
+        auto request_a = [&]() {
+            if constexpr (PA > 0) {
+                if (sa.k == 0) {                               // first step of a tile: source rows (clamped at the bottom edge of the matrix)
+                    int m0, n0; tile_origin(sa.i, m0, n0);
+                    sa.base = a.A + (size_t) m0 * a.lda;
+                    const int rmax = a.M - 1 - m0;
 #pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            const int piece = wave * 4 + p;
-            const int lrow = piece * 8 + prow, pch = (lane & 7) ^ (lrow & 7);
-            int r = n0 + lrow; if (r > a.N - 1) r = a.N - 1;
-            qB[p] = a.W + (size_t) r * a.ldw + pch * 8;
-            dB[p] = (uint32_t) (BM * 128) + (uint32_t) piece * 1024u;
-        }
-        auto issue = [&](int kt) {
-            const uint32_t base = lds0 + (uint32_t) (kt % NST) * STAGE;
-#pragma unroll
-            for (int p = 0; p < PA; ++p) glds_asm<16>(qA[p] + kt * 64, base + dA[p]);
-#pragma unroll
-            for (int p = 0; p < 4; ++p) glds_asm<16>(qB[p] + kt * 64, base + dB[p]);
-        };
-        // this wave's pieces of tile kt have landed when at most the tiles issued after it are outstanding
-        auto wait_tile = [&](int kt) {
-            int later = kt + NST - 2 < nk - 1 ? NST - 2 : nk - 1 - kt;      // tiles issued behind kt so far (issue point: start of K step kt - 1)
-            if (later < 0) later = 0;
-            if constexpr (NST >= 3) {
-                if (later >= 1) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPT) : "memory"); return; }
+                    for (int p = 0; p < PA; ++p) {
+                        int lrow = (pa0 + p) * 8 + prow; const int pch = (lane & 7) ^ (lrow & 7);
+                        if (lrow > rmax) lrow = rmax;
+                        vA[p] = (uint32_t) (lrow * a.lda + pch * 8) * 2u;
+                    }
+                }
+                glds_run<PA>(vA, sa.base + sa.k * 64, lds0 + (uint32_t) (sa.n % NSA) * SZA + (uint32_t) pa0 * 1024u);
             }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            adv(sa);
+        };
+        auto request_w = [&]() {
+            if constexpr (PW > 0) {
+                if (sw.k == 0) { int m0, n0; tile_origin(sw.i, m0, n0); sw.base = a.W + (size_t) n0 * a.ldw; }
+                glds_run<PW>(vW, sw.base + sw.k * 64, lds0 + RING_W + (uint32_t) (sw.n % NSW) * SZW + (uint32_t) pw0 * 1024u);
+            }
+            adv(sw);
+        };
+        // this wave's pieces of step gs have landed when at most its two-steps-ahead requests for step gs + 1 are outstanding
+        auto wait_step = [&](int gs) {
+            if constexpr (PA + PW > 0) {
+                if constexpr (LATE > 0) {
+                    const int n_late = NSW == 3 ? sw.n : sa.n;           // (the deep streams advance together)
+                    if (n_late > gs + 1) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LATE) : "memory"); return; }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
         };
 
+        // prologue: NSx - 1 steps of each image
 #pragma unroll
-        for (int s0 = 0; s0 < NST - 1; ++s0) if (s0 < nk) issue(s0);
-        // tile 0: outstanding behind it are the other prologue tiles
-        if constexpr (NST >= 3) { if (nk >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPT) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (int s0 = 0; s0 < NSA - 1; ++s0) if (sa.n < total) request_a();
+#pragma unroll
+        for (int s0 = 0; s0 < NSW - 1; ++s0) if (sw.n < total) request_w();
+        if (total > 0) wait_step(0);
         __builtin_amdgcn_s_barrier();
         if (a.probe) pt1 = wall_clock64();
         if constexpr (G == 1) __builtin_amdgcn_s_barrier();        // group 1 runs one slot behind
 
-        for (int kt = 0; kt < nk; ++kt) {
-            if (kt + NST - 1 < nk) issue(kt + NST - 1);
-            const unsigned char * st = smem + (size_t) (kt % NST) * STAGE;
+#ifdef WMI_G8_LAB
+        long long tc[5] = {0, 0, 0, 0, 0}, tprev = 0;     // cycles: LOAD work, barrier behind LOAD, MFMA work, vmcnt wait, barrier behind MFMA
+        const bool stampit = (lab & 2048) != 0;
+#define G8_STAMP(i) do { if (stampit) { const long long t_ = clock64(); tc[i] += t_ - tprev; tprev = t_; } } while (0)
+        if (stampit) tprev = clock64();
+#else
+#define G8_STAMP(i) do { } while (0)
+#endif
+        int gs = 0;
+        for (int ti = 0; ti < n_my; ++ti) {
+            for (int kt = 0; kt < nk; ++kt, ++gs) {
+                const unsigned char * stA = smem + (size_t) (gs % NSA) * SZA;
+                const unsigned char * stW = smem + (size_t) (gs % NSW) * SZW;
 #pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                // ---- LOAD slot
-                half8 fa[FM], fb[FN];
+                for (int sl = 0; sl < 64 / KS; ++sl) {
+                    // ---- LOAD slot: the fragments of NKK k-steps, then this wave's requests (one or two steps ahead: every target stage was
+                    // freed by the barrier in front of this slot and is not the one being read)
+                    half8 fa[NKK][FM], fb[NKK][FN];
+                    if (!(lab & 32) || gs == 0) {
 #pragma unroll
-                for (int j = 0; j < FN; ++j) fb[j] = *(const half8 *) (st + (offB[j] ^ (uint32_t) (kk << 6)));
+                        for (int q = 0; q < NKK; ++q) {
+                            const uint32_t kx = (uint32_t) ((sl * NKK + q) << 6);
 #pragma unroll
-                for (int i = 0; i < FM; ++i) fa[i] = *(const half8 *) (st + (offA[i] ^ (uint32_t) (kk << 6)));
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if constexpr (G == 1) { if (kk == 1 && kt + 1 < nk) wait_tile(kt + 1); }
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- MFMA slot
-                __builtin_amdgcn_s_setprio(1);
+                            for (int j = 0; j < FN; ++j) fb[q][j] = *(const half8 *) (stW + (offB[j] ^ kx));
+#pragma unroll
+                            for (int i = 0; i < FM; ++i) fa[q][i] = *(const half8 *) (stA + (offA[i] ^ kx));
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    // the requests go out while the fragment reads are in flight: a DMA instruction holds the wave for ~85 cycles (the CU's
+                    // vector memory path takes 1 KiB per ~16-20 cycles from four waves at once), which is as long as the reads take to return —
+                    // behind the lgkmcnt wait the two added up to a LOAD slot of 1100-1270 cycles against 875 of MFMA (slot accounting, lab)
+                    if (sl == 0 && !(lab & 8)) {
+                        if (sa.n < total) request_a();
+                        if (sw.n < total) request_w();
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    G8_STAMP(0);
+                    if constexpr (G == 1) { if (sl == 64 / KS - 1 && gs + 1 < total) wait_step(gs + 1); }
+                    G8_STAMP(3);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    G8_STAMP(1);
+                    // ---- MFMA slot
+                    __builtin_amdgcn_s_setprio(1);
+                    if (!(lab & 16))
+#pragma unroll
+                    for (int q = 0; q < NKK; ++q)
+#pragma unroll
+                        for (int i = 0; i < FM; ++i)
+#pragma unroll
+                            for (int j = 0; j < FN; ++j) {
+                                if constexpr (SWAPPED) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[q][j], fa[q][i], acc[i][j], 0, 0, 0);
+                                else                   acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[q][i], fb[q][j], acc[i][j], 0, 0, 0);
+                            }
+                    __builtin_amdgcn_s_setprio(0);
+                    G8_STAMP(2);
+                    if constexpr (G == 0) { if (sl == 64 / KS - 1 && gs + 1 < total) wait_step(gs + 1); }
+                    G8_STAMP(3);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    G8_STAMP(4);
+                }
+            }
+            // ---- epilogue of tile ti (gemm_epi.h); the requests for the next tile's first steps are in flight.
+            // Both groups run it in the SAME slot (group 0 sits out group 1's last MFMA slot, group 1 takes its extra barrier behind the
+            // epilogue): one slot behind each other, each group's epilogue had the partner waiting at the next barrier for all of it.
+            if constexpr (G == 0) __builtin_amdgcn_s_barrier();
+            if (a.probe && ti == 0) pt2 = wall_clock64();
+            int m0, n0; tile_origin(ti, m0, n0);
+            if (lab & 512) { m0 = 0; n0 = 0; }              // (lab) every workgroup stores to the same patch: no HBM write traffic
+            const int mb = m0 + grp * (BM / 2), nb = n0 + wn * 64;
+            const bool interior = m0 + BM <= a.M;          // N is a multiple of 256 here
+            if (lab & 4) {                                  // (lab) no epilogue: keep the accumulators alive, store nothing
 #pragma unroll
                 for (int i = 0; i < FM; ++i)
 #pragma unroll
-                    for (int j = 0; j < FN; ++j) {
-                        if constexpr (SWAPPED) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[j], fa[i], acc[i][j], 0, 0, 0);
-                        else                   acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-                    }
-                __builtin_amdgcn_s_setprio(0);
-                if constexpr (G == 0) { if (kk == 1 && kt + 1 < nk) wait_tile(kt + 1); }
-                __builtin_amdgcn_sched_barrier(0);
-                __builtin_amdgcn_s_barrier();
-                __builtin_amdgcn_sched_barrier(0);
+                    for (int j = 0; j < FN; ++j) asm volatile("" :: "v"(acc[i][j]));
+            } else
+            if constexpr (SWAPPED) {
+                if (lab & 1024) { if (interior) epilogue_cols<EPI, FM, FN, false>(a, acc, mb, nb, n0, lane); else epilogue_cols<EPI, FM, FN, true>(a, acc, mb, nb, n0, lane); }
+                else            { if (interior) epilogue_cols_wide<EPI, FM, FN, false>(a, acc, mb, nb, n0, lane); else epilogue_cols_wide<EPI, FM, FN, true>(a, acc, mb, nb, n0, lane); }
             }
+            else                   { if (interior) epilogue_rows<EPI, FM, FN, false>(a, acc, mb, nb, lane);     else epilogue_rows<EPI, FM, FN, true>(a, acc, mb, nb, lane); }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+            if (a.probe && ti == 0) pte = wall_clock64();
+            if constexpr (G == 1) __builtin_amdgcn_s_barrier();
+#ifdef WMI_G8_LAB
+            if (stampit) tprev = clock64();                // (the epilogue is not part of the slot accounting)
+#endif
         }
+#ifdef WMI_G8_LAB
+        if (stampit && a.probe && lane == 0) {
+            unsigned long long * o = a.probe + (size_t) gridDim.x * 5 + ((size_t) blockIdx.x * 8 + wave) * 5;
+            for (int i = 0; i < 5; ++i) o[i] = (unsigned long long) tc[i];
+        }
+#endif
+#undef G8_STAMP
         if constexpr (G == 0) __builtin_amdgcn_s_barrier();        // the barrier group 1 spent idle at the start
     };
     if (grp == 0) body(std::integral_constant<int, 0>{}); else body(std::integral_constant<int, 1>{});
-    if (a.probe) { asm volatile("s_nop 0" ::: "memory"); pt2 = wall_clock64(); }
-
-    // ------------------------------------------------------------------ epilogue (gemm_epi.h)
-    const int mb = m0 + grp * (BM / 2), nb = n0 + wn * 64;
-    const bool interior = m0 + BM <= a.M;                  // N is a multiple of 256 here
-    if constexpr (SWAPPED) { if (interior) epilogue_cols<EPI, FM, FN, false>(a, acc, mb, nb, n0, lane); else epilogue_cols<EPI, FM, FN, true>(a, acc, mb, nb, n0, lane); }
-    else                   { if (interior) epilogue_rows<EPI, FM, FN, false>(a, acc, mb, nb, lane);     else epilogue_rows<EPI, FM, FN, true>(a, acc, mb, nb, lane); }
     if (a.probe && tid == 0) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned hwid; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hwid));
         unsigned long long * o = a.probe + (size_t) blockIdx.x * 5;
-        o[0] = pt0; o[1] = pt1; o[2] = pt2; o[3] = wall_clock64(); o[4] = hwid;
+        o[0] = pt0; o[1] = pt1; o[2] = pt2; o[3] = wall_clock64(); o[4] = pte;      // entry, first tile landed, first tile's K loop done, all done, first epilogue done
     }
 }
 
-template <int BM, int EPI, int NST, bool SWAPPED>
+template <int BM, int EPI, int NSA, int NSW, bool SWAPPED, int KS>
 void launch8(const GemmArgs & a, hipStream_t st) {
     const int ntm = (a.M + BM - 1) / BM, ntn = a.N / 256;
-    const size_t smem = NST * (size_t) (BM + 256) * 128;
+    const size_t smem = (size_t) NSA * BM * 128 + (size_t) NSW * 256 * 128;
     static std::atomic<uint64_t> lds_ok{0};
-    allow_full_lds((const void *) k_gemm8<BM, EPI, NST, SWAPPED>, lds_ok);
-    hipLaunchKernelGGL((k_gemm8<BM, EPI, NST, SWAPPED>), dim3(ntm * ntn), dim3(512), smem, st, a);
+    allow_full_lds((const void *) k_gemm8<BM, EPI, NSA, NSW, SWAPPED, KS>, lds_ok);
+    static const int n_cu = [] { int dev = 0, n = 256; (void) hipGetDevice(&dev); (void) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 8 ? n & ~7 : 8; }();
+    const int tiles = ntm * ntn;
+    const int grid = tiles < n_cu ? (tiles + 7) & ~7 : n_cu;
+    hipLaunchKernelGGL((k_gemm8<BM, EPI, NSA, NSW, SWAPPED, KS>), dim3(grid), dim3(512), smem, st, a);
 }
 
 } // namespace
 
-// bm: 96 / 128 / 192 / 256 rows per tile.  false = this epilogue / shape is not served here (the caller keeps k_gemm).
-bool gemm8(int epi, int bm, bool swapped, const GemmArgs & a, hipStream_t st) {
-    if ((a.N % 256) != 0 || (a.K % 64) != 0 || a.M < 1) return false;
+// bm: 96 / 128 / 160 / 192 / 256 rows per tile; ks: k extent of a slot (32 or 64).  false = this epilogue / shape is not served here.
+bool gemm8(int epi, int bm, bool swapped, const GemmArgs & a, hipStream_t st, int ks) {
+    if ((a.N % 256) != 0 || (a.K % 64) != 0 || a.M < 1 || (ks != 32 && ks != 64)) return false;
+#define WMI_G8B(E, SW, KSV)                                                                             \
+            if (bm == 96) launch8<96, E, 3, 3, SW, KSV>(a, st); else if (bm == 128) launch8<128, E, 3, 3, SW, KSV>(a, st);  \
+            else if (bm == 160) launch8<160, E, 3, 3, SW, KSV>(a, st);                                  \
+            else if (bm == 192) launch8<192, E, 2, 3, SW, KSV>(a, st); else if (bm == 256) launch8<256, E, 2, 2, SW, KSV>(a, st); else return false;
 #define WMI_G8(E)                                                                                       \
     case E:                                                                                             \
-        if (swapped) {                                                                                  \
-            if (bm == 96) launch8<96, E, 3, true>(a, st); else if (bm == 128) launch8<128, E, 3, true>(a, st);  \
-            else if (bm == 192) launch8<192, E, 2, true>(a, st); else if (bm == 256) launch8<256, E, 2, true>(a, st); else return false; \
-        } else {                                                                                        \
-            if (bm == 96) launch8<96, E, 3, false>(a, st); else if (bm == 128) launch8<128, E, 3, false>(a, st); \
-            else if (bm == 192) launch8<192, E, 2, false>(a, st); else if (bm == 256) launch8<256, E, 2, false>(a, st); else return false; \
-        }                                                                                               \
+        if (swapped) { if (ks == 64) { WMI_G8B(E, true, 64) } else { WMI_G8B(E, true, 32) } }           \
+        else         { if (ks == 64) { WMI_G8B(E, false, 64) } else { WMI_G8B(E, false, 32) } }         \
         return true;
     switch (epi) {
+#ifdef WMI_G8_LAB
+        WMI_G8(EPI_F16_BIAS)
+        WMI_G8(EPI_F16_BIAS_GELU)
+        WMI_G8(EPI_F32_BIAS_RESID)
+        WMI_G8(EPI_CROSS_KV)
+#else
         WMI_G8(EPI_F16_BIAS)
         WMI_G8(EPI_F16_BIAS_GELU)
         WMI_G8(EPI_F32_BIAS_RESID)
         WMI_G8(EPI_CROSS_KV)
         WMI_G8(EPI_QKV_ENC)
+#endif
         default: return false;
     }
 #undef WMI_G8
+#undef WMI_G8B
 }
 
 }} // namespace wmi::k

@@ -70,6 +70,41 @@ __device__ __forceinline__ void glds_asm(const void * gsrc, uint32_t lds_dst) {
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
 }
+
+// A run of N consecutive 1 KiB pieces by LDS-DMA from ONE asm statement: source = a wave-uniform 64-bit base (SGPR pair) + a 32-bit
+// byte offset per lane and piece, destination = lds_dst, lds_dst + 1 KiB, ...  Against N x glds_asm: no 64-bit VALU address add per
+// piece, M0 saved / restored once, three instructions per piece (the DMA, s_add_u32 m0, s_nop) — the issue cost of a tile's pieces
+// sits on the LOAD side's critical path in k_gemm8.  N in {1, 2, 3, 4, 6, 8}.  (s_add_u32 writes SCC: declared, or a compare of the surrounding loop is lost.)
+#define WMI_GL_(i) "global_load_lds_dwordx4 %[v" #i "], %[b]\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+#define WMI_GL_HEAD "s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_nop 0\n\t"
+#define WMI_GL_TAIL "s_mov_b32 m0, %[k]"
+template <int N>
+__device__ __forceinline__ void glds_run(const uint32_t (&v)[N], const void * sbase, uint32_t lds_dst) {
+    static_assert(N == 1 || N == 2 || N == 3 || N == 4 || N == 6 || N == 8, "glds_run: piece count");
+    uint32_t keep;
+    const uint32_t d = __builtin_amdgcn_readfirstlane(lds_dst);
+    const uint64_t b64 = (uint64_t) (uintptr_t) sbase;
+    const uint64_t b = ((uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (b64 >> 32)) << 32) | (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) b64);
+    if constexpr (N == 1)
+        asm volatile(WMI_GL_HEAD WMI_GL_(0) WMI_GL_TAIL : [k] "=&s"(keep) : [v0] "v"(v[0]), [d] "s"(d), [b] "s"(b) : "memory", "scc");
+    else if constexpr (N == 2)
+        asm volatile(WMI_GL_HEAD WMI_GL_(0) WMI_GL_(1) WMI_GL_TAIL : [k] "=&s"(keep) : [v0] "v"(v[0]), [v1] "v"(v[1]), [d] "s"(d), [b] "s"(b) : "memory", "scc");
+    else if constexpr (N == 3)
+        asm volatile(WMI_GL_HEAD WMI_GL_(0) WMI_GL_(1) WMI_GL_(2) WMI_GL_TAIL : [k] "=&s"(keep) : [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [d] "s"(d), [b] "s"(b) : "memory", "scc");
+    else if constexpr (N == 4)
+        asm volatile(WMI_GL_HEAD WMI_GL_(0) WMI_GL_(1) WMI_GL_(2) WMI_GL_(3) WMI_GL_TAIL : [k] "=&s"(keep)
+                     : [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [d] "s"(d), [b] "s"(b) : "memory", "scc");
+    else if constexpr (N == 6)
+        asm volatile(WMI_GL_HEAD WMI_GL_(0) WMI_GL_(1) WMI_GL_(2) WMI_GL_(3) WMI_GL_(4) WMI_GL_(5) WMI_GL_TAIL : [k] "=&s"(keep)
+                     : [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [v4] "v"(v[4]), [v5] "v"(v[5]), [d] "s"(d), [b] "s"(b) : "memory", "scc");
+    else
+        asm volatile(WMI_GL_HEAD WMI_GL_(0) WMI_GL_(1) WMI_GL_(2) WMI_GL_(3) WMI_GL_(4) WMI_GL_(5) WMI_GL_(6) WMI_GL_(7) WMI_GL_TAIL : [k] "=&s"(keep)
+                     : [v0] "v"(v[0]), [v1] "v"(v[1]), [v2] "v"(v[2]), [v3] "v"(v[3]), [v4] "v"(v[4]), [v5] "v"(v[5]), [v6] "v"(v[6]), [v7] "v"(v[7]),
+                       [d] "s"(d), [b] "s"(b) : "memory", "scc");
+}
+#undef WMI_GL_
+#undef WMI_GL_HEAD
+#undef WMI_GL_TAIL
 __device__ __forceinline__ uint32_t lds_addr(const void * p) { return (uint32_t) (uintptr_t) (__attribute__((address_space(3))) const void *) p; }
 
 // xor_lane with the mask as a value: inside a fully unrolled `for (o = 32; o > 0; o >>= 1)` the switch folds to the one DPP form

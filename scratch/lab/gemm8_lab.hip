@@ -1,6 +1,7 @@
 // GEMM lab, round 4: the eight-wavefront ping-pong kernel (csrc/k_gemm8.hip) against the shipping k_gemm on the lock-step encoder's
 // shapes — bit-identity of every output element and microseconds per launch.
 // build: hipcc -O3 -std=c++17 -ffp-contract=off --offload-arch=gfx950 -I../../godot-whisper_amd/csrc gemm8_lab.hip -o gemm8_lab
+#define WMI_G8_LAB 1
 #include "../../godot-whisper_amd/csrc/k_gemm.hip"
 #include "../../godot-whisper_amd/csrc/k_gemm8.hip"
 #include <cstdio>
@@ -20,9 +21,10 @@ int main(int argc, char ** argv) {
         {12000,  512, 2048, EPI_F32_BIAS_RESID, "mlp.2 x8 (resid)"},
         {12000,  512,  512, EPI_F32_BIAS_RESID, "out   x8 (resid)"},
         {12000, 6144,  512, EPI_CROSS_KV,       "cross x8"},
-        {12000, 1536,  512, EPI_F16_BIAS,       "qkv-shaped x8 (f16+bias)"},
+        {12000, 1536,  512, EPI_F16_BIAS_GELU,  "qkv-shaped x8 (GELU epilogue)"},
         { 1500, 2048,  512, EPI_F16_BIAS_GELU,  "mlp.0 x1 (GELU)"},
         {24000, 2048,  512, EPI_F16_BIAS_GELU,  "mlp.0 x16 (GELU)"},
+        {12000, 2048,  512, EPI_F16_BIAS,       "mlp.0-shaped x8, f16 + bias only"},
     };
     const int only = argc > 1 ? atoi(argv[1]) : -1;
     hipStream_t st; CK(hipStreamCreate(&st));
@@ -69,21 +71,54 @@ int main(int argc, char ** argv) {
         printf("%-26s M=%5d N=%5d K=%5d | shipping k_gemm %8.2f us %7.1f TF/s\n", s.what, s.M, s.N, s.K, t0, flop / t0 / 1e6);
         std::vector<unsigned char> c0(csz), x0(csz), c1(csz), x1(csz);
         CK(hipMemcpy(c0.data(), dC0, csz, hipMemcpyDeviceToHost)); CK(hipMemcpy(x0.data(), dX0, csz, hipMemcpyDeviceToHost));
-        for (int bm : {96, 128, 192, 256}) for (int sw = 1; sw >= 0; --sw) {
+        for (int bm : {96, 128, 160, 192, 256}) for (int ks : {64, 32}) for (int sw = 1; sw >= 1; --sw) {
             if (getenv("LAB_BM") && atoi(getenv("LAB_BM")) != bm) continue;
-            if (getenv("LAB_SW") && atoi(getenv("LAB_SW")) != sw) continue;
+            if (getenv("LAB_KS") && atoi(getenv("LAB_KS")) != ks) continue;
             CK(hipMemset(dC1, 0, csz)); CK(hipMemset(dX1, 0, csz));
             const GemmArgs a1 = args(dC1, dX1);
-            if (!gemm8(s.epi, bm, sw != 0, a1, st)) { printf("    gemm8 bm=%3d sw=%d: not served\n", bm, sw); continue; }
+            if (!gemm8(s.epi, bm, sw != 0, a1, st, ks)) { printf("    gemm8 bm=%3d ks=%d: not served\n", bm, ks); continue; }
             CK(hipStreamSynchronize(st)); CK(hipGetLastError());
             CK(hipMemcpy(c1.data(), dC1, csz, hipMemcpyDeviceToHost)); CK(hipMemcpy(x1.data(), dX1, csz, hipMemcpyDeviceToHost));
             const bool same = memcmp(c0.data(), c1.data(), csz) == 0 && memcmp(x0.data(), x1.data(), csz) == 0;
             size_t nbad = 0; if (!same) for (size_t i = 0; i < csz; ++i) nbad += c0[i] != c1[i] || x0[i] != x1[i];
-            const double t1 = time_it([&]() { gemm8(s.epi, bm, sw != 0, a1, st); }, iters);
+            const double t1 = time_it([&]() { gemm8(s.epi, bm, sw != 0, a1, st, ks); }, iters);
             const int tiles = ((s.M + bm - 1) / bm) * (s.N / 256);
-            printf("    gemm8 bm=%3d sw=%d %5d tiles (%.2f rounds) %8.2f us %7.1f TF/s  %s", bm, sw, tiles, tiles / 256.0, t1, flop / t1 / 1e6,
+            printf("    gemm8 bm=%3d ks=%d %5d tiles (%.2f rounds) %8.2f us %7.1f TF/s  %s", bm, ks, tiles, tiles / 256.0, t1, flop / t1 / 1e6,
                    same ? "bit-identical\n" : "DIFFERS\n");
             if (!same) printf("        %zu differing bytes\n", nbad);
+            if (getenv("LAB_PROBE")) {
+                // per-workgroup stamps of one launch (wave 0): entry, first tile landed, K loop done, stores left; and the ablations
+                const int cap = tiles < 256 ? ((tiles + 7) & ~7) : 256;
+                unsigned long long * dp; CK(hipMalloc(&dp, (size_t) cap * 5 * 8)); CK(hipMemset(dp, 0, (size_t) cap * 5 * 8));
+                GemmArgs ap = a1; ap.probe = dp;
+                gemm8(s.epi, bm, sw != 0, ap, st, ks); CK(hipStreamSynchronize(st));
+                std::vector<unsigned long long> h((size_t) cap * 5); CK(hipMemcpy(h.data(), dp, h.size() * 8, hipMemcpyDeviceToHost)); hipFree(dp);
+                unsigned long long tmin = ~0ull, tmax = 0; double f = 0, l = 0, e = 0; std::vector<double> starts;
+                for (int i = 0; i < cap; ++i) { const unsigned long long * q = &h[(size_t) i * 5]; tmin = std::min(tmin, q[0]); tmax = std::max(tmax, q[3]); }
+                double tot = 0;
+                for (int i = 0; i < cap; ++i) { const unsigned long long * q = &h[(size_t) i * 5]; f += q[1] - q[0]; l += q[2] - q[1]; e += q[4] - q[2]; tot += q[3] - q[0]; starts.push_back((q[0] - tmin) * 0.01); }
+                std::sort(starts.begin(), starts.end());
+                printf("        probe (wave 0): span %.2f us; per workgroup: entry -> first tile %.2f, first tile's K loop %.2f, its epilogue %.2f, whole life %.2f us; starts p50 %.2f max %.2f\n",
+                       (tmax - tmin) * 0.01, f / cap * 0.01, l / cap * 0.01, e / cap * 0.01, tot / cap * 0.01, starts[cap / 2], starts.back());
+                {   // slot accounting: cycles per wave in LOAD work / barrier behind LOAD / MFMA work / vmcnt wait / barrier behind MFMA
+                    unsigned long long * dq; const size_t nq = (size_t) cap * 5 + (size_t) cap * 8 * 5;
+                    CK(hipMalloc(&dq, nq * 8)); CK(hipMemset(dq, 0, nq * 8));
+                    GemmArgs aq = a1; aq.probe = dq; aq.no_glds = 2048;
+                    gemm8(s.epi, bm, sw != 0, aq, st, ks); CK(hipStreamSynchronize(st));
+                    std::vector<unsigned long long> hq(nq); CK(hipMemcpy(hq.data(), dq, nq * 8, hipMemcpyDeviceToHost)); hipFree(dq);
+                    double sum[2][5] = {{0}}; 
+                    for (int w = 0; w < cap; ++w) for (int v = 0; v < 8; ++v) for (int i = 0; i < 5; ++i) sum[v >> 2][i] += (double) hq[(size_t) cap * 5 + ((size_t) w * 8 + v) * 5 + i];
+                    const double nsteps = (double) s.K / 64 * tiles / cap;      // K steps per workgroup (average)
+                    for (int g = 0; g < 2; ++g)
+                        printf("        slots, group %d (cycles per K step and wave): LOAD work %.0f, barrier behind LOAD %.0f, MFMA work %.0f, vmcnt wait %.0f, barrier behind MFMA %.0f\n", g,
+                               sum[g][0] / (cap * 4) / nsteps, sum[g][1] / (cap * 4) / nsteps, sum[g][2] / (cap * 4) / nsteps, sum[g][3] / (cap * 4) / nsteps, sum[g][4] / (cap * 4) / nsteps);
+                }
+                for (int flags : {4, 4 | 8, 4 | 16, 4 | 8 | 16, 4 | 8 | 32, 4 | 8 | 16 | 32}) {
+                    GemmArgs af = a1; af.no_glds = flags;
+                    const double tf = time_it([&]() { gemm8(s.epi, bm, sw != 0, af, st, ks); }, iters);
+                    printf("        ablation%s%s%s%s%s%s: %8.2f us\n", flags & 4 ? " -epilogue" : "", flags & 8 ? " -dma" : "", flags & 16 ? " -mfma" : "", flags & 32 ? " -ldsreads" : "", flags & 64 ? " (no setprio on MFMA)" : "", "", tf);
+                }
+            }
         }
         hipFree(dA); hipFree(dW); hipFree(db); hipFree(dC0); hipFree(dC1); hipFree(dX0); hipFree(dX1); hipFree(dR);
     }
