@@ -326,6 +326,16 @@ void gemm(int epi, const GemmArgs & a_in, hipStream_t st) {
     static const bool guard_all = getenv("WMI_GEMM_GUARD_ALL") != nullptr;   // debug / A-B: bounds-checked epilogue for every tile
     static const bool narrow = getenv("WMI_GEMM_NARROW_STORES") != nullptr;  // debug / A-B: 8-byte epilogue stores
     GemmArgs a = a_in; a.no_glds = (no_glds ? 1 : 0) | (guard_all ? 2 : 0) | (narrow ? 4 : 0);
+    // The big grids (lock-step encoder: M = chunks x 1500) whose output is wide enough for several 192 x 256 tiles per CU go to the
+    // persistent ping-pong kernel (k_gemm8.hip): mlp.0 (N = 4 S) and the cross K / V of all decoder layers (N = 2 L S).  Measured at
+    // M = 12 000 (profiles/r04a_gemm8_lab_*): mlp.0 41 -> 35.7 us, cross K/V 132 -> 105 us, every output element identical.  The N = S
+    // projections (one or two column tiles) and q|k|v (its V^T third wants the other fragment orientation) stay here.
+    static const int g8 = getenv("WMI_GEMM8") ? atoi(getenv("WMI_GEMM8")) : 1;         // A/B knob: 0 = off
+    if (g8 && !no_glds && (epi == EPI_F16_BIAS_GELU || epi == EPI_CROSS_KV) && a.M >= 4096 && a.N >= 1024 && (a.N % 256) == 0 && (a.K % 64) == 0 &&
+        (epi != EPI_CROSS_KV || (a.S % 64) == 0)) {
+        const long t192 = (long) ((a.M + 191) / 192) * (a.N / 256);
+        if (t192 >= 384) { GemmArgs b = a; b.no_glds = 0; if (gemm8(epi, 192, true, b, st)) return; }
+    }
     switch (epi) {
         case EPI_F16_BIAS:       dispatch<EPI_F16_BIAS>(a, st); break;
         case EPI_F16_BIAS_GELU:  dispatch<EPI_F16_BIAS_GELU>(a, st); break;

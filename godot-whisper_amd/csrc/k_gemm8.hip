@@ -304,9 +304,12 @@ void launch8(const GemmArgs & a, hipStream_t st) {
 
 } // namespace
 
-// bm: 96 / 128 / 160 / 192 / 256 rows per tile; ks: k extent of a slot (32 or 64).  false = this epilogue / shape is not served here.
+// bm: rows per tile; ks: k extent of a slot (32 or 64).  false = this epilogue / shape / tile is not served here (the caller keeps gemm()).
+// The library instantiates what its dispatch uses (k_gemm.hip: gemm()): the transposed orientation on 192-row tiles (128 as the fallback
+// for narrower outputs) for the GELU and cross K/V epilogues; the lab (scratch/lab/gemm8_lab.hip) builds the whole grid of variants.
 bool gemm8(int epi, int bm, bool swapped, const GemmArgs & a, hipStream_t st, int ks) {
     if ((a.N % 256) != 0 || (a.K % 64) != 0 || a.M < 1 || (ks != 32 && ks != 64)) return false;
+#ifdef WMI_G8_LAB
 #define WMI_G8B(E, SW, KSV)                                                                             \
             if (bm == 96) launch8<96, E, 3, 3, SW, KSV>(a, st); else if (bm == 128) launch8<128, E, 3, 3, SW, KSV>(a, st);  \
             else if (bm == 160) launch8<160, E, 3, 3, SW, KSV>(a, st);                                  \
@@ -317,22 +320,27 @@ bool gemm8(int epi, int bm, bool swapped, const GemmArgs & a, hipStream_t st, in
         else         { if (ks == 64) { WMI_G8B(E, false, 64) } else { WMI_G8B(E, false, 32) } }         \
         return true;
     switch (epi) {
-#ifdef WMI_G8_LAB
         WMI_G8(EPI_F16_BIAS)
         WMI_G8(EPI_F16_BIAS_GELU)
         WMI_G8(EPI_F32_BIAS_RESID)
         WMI_G8(EPI_CROSS_KV)
-#else
-        WMI_G8(EPI_F16_BIAS)
-        WMI_G8(EPI_F16_BIAS_GELU)
-        WMI_G8(EPI_F32_BIAS_RESID)
-        WMI_G8(EPI_CROSS_KV)
-        WMI_G8(EPI_QKV_ENC)
-#endif
         default: return false;
     }
 #undef WMI_G8
 #undef WMI_G8B
+#else
+    if (!swapped || ks != 64) return false;
+#define WMI_G8(E)                                                                                       \
+    case E:                                                                                             \
+        if (bm == 192) launch8<192, E, 2, 3, true, 64>(a, st); else if (bm == 128) launch8<128, E, 3, 3, true, 64>(a, st); else return false;   \
+        return true;
+    switch (epi) {
+        WMI_G8(EPI_F16_BIAS_GELU)
+        WMI_G8(EPI_CROSS_KV)
+        default: return false;
+    }
+#undef WMI_G8
+#endif
 }
 
 }} // namespace wmi::k

@@ -130,6 +130,10 @@ struct GemmArgs {
     unsigned long long * probe;     // probe (wmi_bench_kernel 7): per workgroup {entry, first tile landed, K loop done, epilogue done, SE/CU id}
 };
 void gemm(int epi, const GemmArgs & a, hipStream_t st);
+// k_gemm8.hip: the eight-wavefront ping-pong form for the big grids (M = chunks x 1500): BM x 256 tiles, bm in {96, 128, 160, 192, 256},
+// swapped = transposed accumulator fragments (row-major f16 / f32 epilogues), ks = k extent of a slot.  Bit-identical to gemm().
+// false = not served (N % 256, K % 64, epilogue): the caller keeps gemm().
+bool gemm8(int epi, int bm, bool swapped, const GemmArgs & a, hipStream_t st, int ks = 64);
 
 // ---------------------------------------------------------------- LayerNorm (k_norm.hip)
 // y = (x - mean) / sqrt(var + eps) * g + b ; one wave per row. out16 and/or out32 may be null.

@@ -83,6 +83,8 @@ class SpeechToText:
         p.max_tokens = int(self.settings["audio/input/transcribe/max_tokens"])
         p.entropy_thold = float(self.settings["audio/input/transcribe/entropy_treshold"])
         p.initial_prompt = prompt
+        if getattr(self, "n_threads", 0):            # tests: the CPU reference behind this mirror (results do not depend on the thread count)
+            p.n_threads = int(self.n_threads)
         return p
 
     def transcribe(self, buffer: np.ndarray, initial_prompt: str = "", audio_ctx: int = 0, params=None) -> list:

@@ -926,24 +926,37 @@ def test_ten_minute_stream_small_shape(product_lib, checker_lib):
         node.close()
     if checker_lib is None:
         return
-    # the first calls against the compiled reference (same call pattern, reference library behind the same host mirror)
+    # the first 64 calls against the compiled reference (same call pattern, reference library behind the same host mirror; the buffer
+    # grows through two sentence boundaries, audio_ctx from 178 to ~900: ~0.3-1 s of reference time per call at 32 threads)
     ref = host.CaptureStreamToText(checker_lib, transcribe_interval=0.3); ref.language = "de"; ref.set_language_model(model)
+    ref.n_threads = max(4, min(32, os.cpu_count() or 4))
     try:
-        n_cmp = 0; near_ties = 0
-        for (fin, text, n_used, actx, toks), mine in zip(ref.stream(pcm[: 16000 * 12], max_calls=12), calls):
-            assert (n_used, actx) == (mine[1], mine[2])
+        n_cmp = 0; near_ties = []; n_tok = 0; n_full = 0
+        for (fin, text, n_used, actx, toks), mine in zip(ref.stream(pcm[: 16000 * 24], max_calls=64), calls):
+            if (fin, n_used, actx) != (mine[0], mine[1], mine[2]):
+                # the two loops only part ways when a near-tie changed a token count or the last character the sentence rule looks at
+                assert near_ties, (n_cmp, fin, n_used, actx, mine[:3])
+                print(f"configs[2]: the call patterns part ways at call {n_cmp} (behind the near-tie at call {near_ties[-1][0]})")
+                break
             w = gu.tokens_array([b""] + toks); g = mine[3]
             n = min(len(g), len(w)); same = g[:n, 0] == w[:n, 0]
             first = n if same.all() else int(np.argmin(same))
-            # margin-aware like every token comparison here: a disagreement in the first tokens is admitted only as a near-tie (the
-            # two picks' probabilities within 1e-2: e.g. call 9, token 1: 0.1462 against 0.1464), and at most once in the calls compared
-            if first < min(n, 3):
+            # margin-aware like every token comparison here: a first disagreement is admitted only as a near-tie (the two picks'
+            # probabilities within 1e-2: e.g. call 9, token 1: 0.1462 against 0.1464); they are counted and reported, not capped at one
+            if first < n:
                 assert abs(g[first, 2] - w[first, 2]) <= 1e-2, (n_cmp, first, g[:, 0], w[:, 0], g[:, 2], w[:, 2])
-                near_ties += 1
+                near_ties.append((n_cmp, first))
+            else:
+                assert len(g) == len(w), (n_cmp, len(g), len(w))
+                n_full += 1
             if first:
                 assert np.abs(g[:first, 2] - w[:first, 2]).max() <= 1e-2
+                assert np.array_equal(g[:first, 6], w[:first, 6])                 # token start times of the common prefix
+            n_tok += first
             n_cmp += 1
-        assert n_cmp >= 8 and near_ties <= 1, (n_cmp, near_ties)
+        print(f"configs[2]: {n_cmp} calls compared with the reference, {n_full} identical token streams, {n_tok} common tokens, "
+              f"{len(near_ties)} near-ties (call, token): {near_ties}")
+        assert n_cmp >= 40 and len(near_ties) <= max(2, n_cmp // 8), (n_cmp, near_ties)
     finally:
         ref.close()
 
