@@ -302,14 +302,278 @@ void launch8(const GemmArgs & a, hipStream_t st) {
     hipLaunchKernelGGL((k_gemm8<BM, EPI, NSA, NSW, SWAPPED, KS>), dim3(grid), dim3(512), smem, st, a);
 }
 
+#ifdef WMI_G8_LAB
+// ---------------------------------------------------------------------------------------------------------------------------------
+// (lab only — measured, NOT kept: profiles/r04a_gemm8_lab_loader_waves_not_kept.txt.  mlp.0 at M = 12 000: 36.7 us on 128 x 256 tiles with
+// 32-deep slots / 38.2 us on 96 x 256 with 64-deep slots against 35.6 us for k_gemm8 on 192 x 256; cross K/V 108 against 104 us.  Twelve
+// wavefronts leave 168 VGPRs each — the 192-row tile spills — and a barrier among twelve waves every 450 cycles costs what the freed
+// LOAD slots gain: the skeleton alone (no DMA, reads or MFMA) is 10.7 us of the 36.  Two of the variants also showed a few thousand
+// differing bytes on the cross K/V shape: an unresolved hazard between the loaders' run-ahead and a tile boundary.)
+// k_gemm8l: the same ping-pong, with the DMA taken off the MFMA wavefronts.  Slot accounting of k_gemm8 (profiles/r04a_gemm8_lab_slots_and_
+// ablations.txt): a LOAD slot is 1000-1220 cycles — ~300 of fragment reads and 110 cycles PER DMA INSTRUCTION (the CU's vector memory path
+// takes 1 KiB per ~27 cycles, ~38 B/clk, and holds the issuing wave meanwhile) — against 875 cycles of MFMA slot: the K step is paced by
+// the DMA issue of the waves that should be feeding the matrix pipe.  Here four more wavefronts (8..11, one per SIMD) do nothing but issue
+// the tile requests, a few per slot, and meet the others at every barrier; the eight MFMA wavefronts read fragments and multiply.  Three
+// wavefronts per SIMD leave 168 VGPRs each: 128 x 256 tiles with 64-deep slots, or 192 x 256 with 32-deep ones.
+//
+//   loader schedule, K step t (slots numbered by group 0): first the image that runs one step ahead (two-deep ring: its stage was freed by
+//   the barrier that ended step t - 1), then the two-steps-ahead image; before the barrier that ends step t the loader waits until only the
+//   two-steps-ahead requests of this step are outstanding — everything step t + 1 reads has then landed.
+template <int BM, int EPI, int NSA, int NSW, int KS>
+__global__ __launch_bounds__(768) void k_gemm8l(const GemmArgs a) {
+    constexpr int BN = 256, FM = BM / 32, FN = 4;
+    constexpr int SZA = BM * 128, SZW = BN * 128, RING_W = NSA * SZA;
+    constexpr int NA = BM / 8, NW = BN / 8;
+    constexpr int PA = NA / 4, PW = NW / 4;                 // pieces per loader wavefront and step
+    constexpr int NSL = 2 * (64 / KS);                      // slots (= barriers) per K step
+    constexpr int NKK = KS / 32;
+    static_assert(BM % 32 == 0 && NA % 4 == 0 && (NSA == 2 || NSA == 3) && (NSW == 2 || NSW == 3), "tile / rings");
+    static_assert(KS == 64 ? (PA == 1 || PA == 2 || PA == 3 || PA == 4 || PA == 6 || PA == 8) : (PA % 2 == 0 && PA / 2 <= 4), "loader chunking");
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef WMI_G8_LAB
+    const int lab = a.no_glds;
+#else
+    constexpr int lab = 0;
+#endif
+    const unsigned long long pt0 = a.probe ? wall_clock64() : 0ull;
+    unsigned long long pt1 = 0ull, pt2 = 0ull, pte = 0ull;
+
+    const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN, ntiles = ntm * ntn;
+    const int nx = (int) gridDim.x >> 3;
+    const int xcd = (int) blockIdx.x & 7, jx = (int) blockIdx.x >> 3;
+    const int per = (ntiles + 7) >> 3;
+    const int run = ntiles - xcd * per < per ? ntiles - xcd * per : per;
+    const int n_my = run > jx ? (run - jx + nx - 1) / nx : 0;
+    constexpr int GN = 8;
+    auto tile_origin = [&](int i, int & m0, int & n0) {
+        const int idx = xcd * per + jx + i * nx;
+        const int ng = idx / (ntm * GN), rem = idx - ng * (ntm * GN);
+        const int gcur = ntn - ng * GN < GN ? ntn - ng * GN : GN;
+        m0 = (rem / gcur) * BM; n0 = (ng * GN + rem % gcur) * BN;
+    };
+    const int nk = a.K / 64;
+    const int total = n_my * nk;
+    const uint32_t lds0 = lds_addr(smem);
+
+    if (wave >= 8) {
+        // ------------------------------------------------------------------------------------------------ loader wavefronts
+        const int ld = wave - 8, prow = lane >> 3;
+        struct Stream { int i = 0, k = 0, n = 0; const __half * base = nullptr; };
+        Stream sa, sw;
+        uint32_t vA[PA], vW[PW];
+        const int pa0 = ld * PA, pw0 = ld * PW;
+#pragma unroll
+        for (int p = 0; p < PW; ++p) {
+            const int lrow = (pw0 + p) * 8 + prow, pch = (lane & 7) ^ (lrow & 7);
+            vW[p] = (uint32_t) (lrow * a.ldw + pch * 8) * 2u;
+        }
+        auto adv = [&](Stream & t) { ++t.n; if (++t.k == nk) { t.k = 0; ++t.i; } };
+        auto prep_a = [&]() {
+            if (sa.k == 0) {
+                int m0, n0; tile_origin(sa.i, m0, n0);
+                sa.base = a.A + (size_t) m0 * a.lda;
+                const int rmax = a.M - 1 - m0;
+#pragma unroll
+                for (int p = 0; p < PA; ++p) {
+                    int lrow = (pa0 + p) * 8 + prow; const int pch = (lane & 7) ^ (lrow & 7);
+                    if (lrow > rmax) lrow = rmax;
+                    vA[p] = (uint32_t) (lrow * a.lda + pch * 8) * 2u;
+                }
+            }
+        };
+        auto prep_w = [&]() { if (sw.k == 0) { int m0, n0; tile_origin(sw.i, m0, n0); sw.base = a.W + (size_t) n0 * a.ldw; } };
+        // part h of H of this step's requests for an image (H = 1: the whole image in one slot; H = 2: half per slot)
+        auto req_a = [&](auto h_tag, auto H_tag) {
+            constexpr int h = decltype(h_tag)::value, Hn = decltype(H_tag)::value, N = PA / Hn;
+            if (h == 0) prep_a();
+            uint32_t v[N];
+#pragma unroll
+            for (int p = 0; p < N; ++p) v[p] = vA[h * N + p];
+            glds_run<N>(v, sa.base + sa.k * 64, lds0 + (uint32_t) (sa.n % NSA) * SZA + (uint32_t) (pa0 + h * N) * 1024u);
+            if (h == Hn - 1) adv(sa);
+        };
+        auto req_w = [&](auto h_tag, auto H_tag) {
+            constexpr int h = decltype(h_tag)::value, Hn = decltype(H_tag)::value, N = PW / Hn;
+            if (h == 0) prep_w();
+            uint32_t v[N];
+#pragma unroll
+            for (int p = 0; p < N; ++p) v[p] = vW[h * N + p];
+            glds_run<N>(v, sw.base + sw.k * 64, lds0 + RING_W + (uint32_t) (sw.n % NSW) * SZW + (uint32_t) (pw0 + h * N) * 1024u);
+            if (h == Hn - 1) adv(sw);
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        // everything step gs reads has landed when only this loader's two-steps-ahead requests issued behind it are outstanding
+        auto wait_step = [&](int gs) {
+            const bool a_late = NSA == 3 && sa.n > gs + 1, w_late = NSW == 3 && sw.n > gs + 1;
+            if (a_late && w_late) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PA + PW) : "memory");
+            else if (w_late)      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PW) : "memory");
+            else if (a_late)      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PA) : "memory");
+            else                  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        };
+        // prologue (one-step-ahead image first: wait_step counts on that order)
+        if constexpr (NSA == 2) { if (sa.n < total) req_a(I0{}, I1{}); }
+        if constexpr (NSW == 2) { if (sw.n < total) req_w(I0{}, I1{}); }
+        if constexpr (NSA == 3) { for (int s0 = 0; s0 < 2; ++s0) if (sa.n < total) req_a(I0{}, I1{}); }
+        if constexpr (NSW == 3) { for (int s0 = 0; s0 < 2; ++s0) if (sw.n < total) req_w(I0{}, I1{}); }
+        // (three-deep images issued step 0 and step 1 back to back: step 1's pieces are the "late" ones of the first wait)
+        if (total > 0) wait_step(0);
+        __builtin_amdgcn_s_barrier();                                   // B0
+        int gs = 0;
+        for (int ti = 0; ti < n_my; ++ti) {
+            for (int kt = 0; kt < nk; ++kt, ++gs) {
+                // requests of this step: image(s) one step ahead in the first slot(s), two steps ahead behind them
+                const bool more_a = sa.n < total && !(lab & 8), more_w = sw.n < total && !(lab & 8);
+                if constexpr (NSL == 2) {
+                    if constexpr (NSA == 2) { if (more_a) req_a(I0{}, I1{}); if constexpr (NSW == 2) { if (more_w) req_w(I0{}, I1{}); } }
+                    else { if (more_a) req_a(I0{}, I1{}); }
+                    __builtin_amdgcn_s_barrier();
+                    if constexpr (!(NSA == 2 && NSW == 2)) { if (more_w) req_w(I0{}, I1{}); }
+                    if (gs + 1 < total) wait_step(gs + 1);
+                    __builtin_amdgcn_s_barrier();
+                } else {
+                    if (more_a) req_a(I0{}, I2{});
+                    __builtin_amdgcn_s_barrier();
+                    if (more_a) req_a(I1{}, I2{});
+                    __builtin_amdgcn_s_barrier();
+                    if (more_w) req_w(I0{}, I2{});
+                    __builtin_amdgcn_s_barrier();
+                    if (more_w) req_w(I1{}, I2{});
+                    if (gs + 1 < total) wait_step(gs + 1);
+                    __builtin_amdgcn_s_barrier();
+                }
+            }
+            __builtin_amdgcn_s_barrier();                               // the tile's epilogue slot
+        }
+        __builtin_amdgcn_s_barrier();                                   // group 1's lag
+        return;
+    }
+
+    // ------------------------------------------------------------------------------------------------ MFMA wavefronts
+    const int grp = wave >> 2, wn = wave & 3;
+    floatx4 acc[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int frow = lane & 15, fq = lane >> 4;
+    uint32_t offA[FM], offB[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) offA[i] = lds_off8(grp * (BM / 2) + i * 16 + frow, fq);
+#pragma unroll
+    for (int j = 0; j < FN; ++j) offB[j] = RING_W + lds_off8(wn * 64 + j * 16 + frow, fq);
+
+    auto body = [&](auto grp_tag) {
+        constexpr int G = decltype(grp_tag)::value;
+        __builtin_amdgcn_s_barrier();                                   // B0: the loaders' first step has landed
+        if (a.probe) pt1 = wall_clock64();
+        if constexpr (G == 1) __builtin_amdgcn_s_barrier();            // group 1 runs one slot behind
+        int gs = 0;
+        for (int ti = 0; ti < n_my; ++ti) {
+            for (int kt = 0; kt < nk; ++kt, ++gs) {
+                const unsigned char * stA = smem + (size_t) (gs % NSA) * SZA;
+                const unsigned char * stW = smem + (size_t) (gs % NSW) * SZW;
+#pragma unroll
+                for (int sl = 0; sl < 64 / KS; ++sl) {
+                    half8 fa[NKK][FM], fb[NKK][FN];
+                    if (!(lab & 32) || gs == 0) {
+#pragma unroll
+                        for (int q = 0; q < NKK; ++q) {
+                            const uint32_t kx = (uint32_t) ((sl * NKK + q) << 6);
+#pragma unroll
+                            for (int j = 0; j < FN; ++j) fb[q][j] = *(const half8 *) (stW + (offB[j] ^ kx));
+#pragma unroll
+                            for (int i = 0; i < FM; ++i) fa[q][i] = *(const half8 *) (stA + (offA[i] ^ kx));
+                        }
+                    }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_setprio(1);
+                    if (!(lab & 16))
+#pragma unroll
+                    for (int q = 0; q < NKK; ++q)
+#pragma unroll
+                        for (int i = 0; i < FM; ++i)
+#pragma unroll
+                            for (int j = 0; j < FN; ++j)
+                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[q][j], fa[q][i], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_s_setprio(0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            if constexpr (G == 0) __builtin_amdgcn_s_barrier();        // both groups run the epilogue in the same slot (see k_gemm8)
+            if (a.probe && ti == 0) pt2 = wall_clock64();
+            int m0, n0; tile_origin(ti, m0, n0);
+            const int mb = m0 + grp * (BM / 2), nb = n0 + wn * 64;
+            const bool interior = m0 + BM <= a.M;
+            if (lab & 4) {
+#pragma unroll
+                for (int i = 0; i < FM; ++i)
+#pragma unroll
+                    for (int j = 0; j < FN; ++j) asm volatile("" :: "v"(acc[i][j]));
+            } else {
+                if (interior) epilogue_cols_wide<EPI, FM, FN, false>(a, acc, mb, nb, n0, lane); else epilogue_cols_wide<EPI, FM, FN, true>(a, acc, mb, nb, n0, lane);
+            }
+#pragma unroll
+            for (int i = 0; i < FM; ++i)
+#pragma unroll
+                for (int j = 0; j < FN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
+            if (a.probe && ti == 0) pte = wall_clock64();
+            if constexpr (G == 1) __builtin_amdgcn_s_barrier();
+        }
+        if constexpr (G == 0) __builtin_amdgcn_s_barrier();
+    };
+    if (grp == 0) body(std::integral_constant<int, 0>{}); else body(std::integral_constant<int, 1>{});
+    if (a.probe && tid == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        unsigned long long * o = a.probe + (size_t) blockIdx.x * 5;
+        o[0] = pt0; o[1] = pt1; o[2] = pt2; o[3] = wall_clock64(); o[4] = pte;
+    }
+}
+
+template <int BM, int EPI, int NSA, int NSW, int KS>
+void launch8l(const GemmArgs & a, hipStream_t st) {
+    const int ntm = (a.M + BM - 1) / BM, ntn = a.N / 256;
+    const size_t smem = (size_t) NSA * BM * 128 + (size_t) NSW * 256 * 128;
+    static std::atomic<uint64_t> lds_ok{0};
+    allow_full_lds((const void *) k_gemm8l<BM, EPI, NSA, NSW, KS>, lds_ok);
+    static const int n_cu = [] { int dev = 0, n = 256; (void) hipGetDevice(&dev); (void) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 8 ? n & ~7 : 8; }();
+    const int tiles = ntm * ntn;
+    const int grid = tiles < n_cu ? (tiles + 7) & ~7 : n_cu;
+    hipLaunchKernelGGL((k_gemm8l<BM, EPI, NSA, NSW, KS>), dim3(grid), dim3(768), smem, st, a);
+}
+#endif  // WMI_G8_LAB
+
 } // namespace
 
 // bm: rows per tile; ks: k extent of a slot (32 or 64).  false = this epilogue / shape / tile is not served here (the caller keeps gemm()).
 // The library instantiates what its dispatch uses (k_gemm.hip: gemm()): the transposed orientation on 192-row tiles (128 as the fallback
 // for narrower outputs) for the GELU and cross K/V epilogues; the lab (scratch/lab/gemm8_lab.hip) builds the whole grid of variants.
 bool gemm8(int epi, int bm, bool swapped, const GemmArgs & a, hipStream_t st, int ks) {
-    if ((a.N % 256) != 0 || (a.K % 64) != 0 || a.M < 1 || (ks != 32 && ks != 64)) return false;
+    if ((a.N % 256) != 0 || (a.K % 64) != 0 || a.M < 1) return false;
 #ifdef WMI_G8_LAB
+    if (ks == 164 || ks == 132) {                          // (lab) the loader-wave kernel: 64- / 32-deep slots
+        if (!swapped) return false;
+#define WMI_G8L(E)                                                                                      \
+    case E:                                                                                             \
+        if (ks == 164) { if (bm == 128) launch8l<128, E, 3, 3, 64>(a, st); else if (bm == 96) launch8l<96, E, 3, 3, 64>(a, st); else return false; }    \
+        else { if (bm == 192) launch8l<192, E, 2, 3, 32>(a, st); else if (bm == 128) launch8l<128, E, 3, 3, 32>(a, st); else if (bm == 256) launch8l<256, E, 2, 2, 32>(a, st); else return false; } \
+        return true;
+        switch (epi) {
+            WMI_G8L(EPI_F16_BIAS_GELU)
+            WMI_G8L(EPI_F32_BIAS_RESID)
+            WMI_G8L(EPI_CROSS_KV)
+            default: return false;
+        }
+#undef WMI_G8L
+    }
+    if (ks != 32 && ks != 64) return false;
 #define WMI_G8B(E, SW, KSV)                                                                             \
             if (bm == 96) launch8<96, E, 3, 3, SW, KSV>(a, st); else if (bm == 128) launch8<128, E, 3, 3, SW, KSV>(a, st);  \
             else if (bm == 160) launch8<160, E, 3, 3, SW, KSV>(a, st);                                  \

@@ -71,7 +71,7 @@ int main(int argc, char ** argv) {
         printf("%-26s M=%5d N=%5d K=%5d | shipping k_gemm %8.2f us %7.1f TF/s\n", s.what, s.M, s.N, s.K, t0, flop / t0 / 1e6);
         std::vector<unsigned char> c0(csz), x0(csz), c1(csz), x1(csz);
         CK(hipMemcpy(c0.data(), dC0, csz, hipMemcpyDeviceToHost)); CK(hipMemcpy(x0.data(), dX0, csz, hipMemcpyDeviceToHost));
-        for (int bm : {96, 128, 160, 192, 256}) for (int ks : {64, 32}) for (int sw = 1; sw >= 1; --sw) {
+        for (int bm : {96, 128, 160, 192, 256}) for (int ks : {64, 32, 164, 132}) for (int sw = 1; sw >= 1; --sw) {
             if (getenv("LAB_BM") && atoi(getenv("LAB_BM")) != bm) continue;
             if (getenv("LAB_KS") && atoi(getenv("LAB_KS")) != ks) continue;
             CK(hipMemset(dC1, 0, csz)); CK(hipMemset(dX1, 0, csz));
