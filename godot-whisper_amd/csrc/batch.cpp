@@ -268,11 +268,19 @@ static void enqueue_rows_step(whisper_context & ctx, int nb, bool chained = fals
         {   // self-attention, one workgroup per chunk row (same arithmetic as the single-row fused prologue), then
             // out projection + residual
             const bool mirror = chained && il == Lt - 1 && !mirror_in_logits;
-            if (M & 4) k::self_attn_rows(b.dq, nb, S, ck, cv, cache_stride, &stp->n_kv, step_stride, n_ctx, b.datt, s, nullptr, false,
-                                         mirror ? b.step_host : nullptr, mirror ? b.step_dev : nullptr);
             k::GemvArgs g = base(S, S, l.w_o, l.b_o, k::EPI_F32_BIAS_RESID, b.dx, S);
-            g.a16 = b.datt; g.resid = b.dx;
-            if (M & 8) k::gemv(g, s);
+            g.resid = b.dx;
+            // the out projection takes the self-attention in its prologue (the one-row kernel per row, kernels.h) unless this launch
+            // has to carry the step-record mirror or the probe asked for the two kinds separately
+            k::GemvArgs gs = g;
+            gs.sa_q = b.dq; gs.sa_k = ck; gs.sa_v = cv; gs.sa_nkv = &stp->n_kv; gs.sa_cap = n_ctx;
+            if (!mirror && (M & 4) && (M & 8) && k::gemv_rows_take_self_attention(gs)) k::gemv(gs, s);
+            else {
+                if (M & 4) k::self_attn_rows(b.dq, nb, S, ck, cv, cache_stride, &stp->n_kv, step_stride, n_ctx, b.datt, s, nullptr, false,
+                                             mirror ? b.step_host : nullptr, mirror ? b.step_dev : nullptr);
+                g.a16 = b.datt;
+                if (M & 8) k::gemv(g, s);
+            }
         }
         {   // LN2 + cross query (folded into the score kernel) + cross-attention partials over each row's own chunk
             const float * po = nullptr, * pl = nullptr, * pm = nullptr; int ns = 0;

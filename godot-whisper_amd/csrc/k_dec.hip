@@ -854,7 +854,31 @@ __global__ __launch_bounds__(256) void k_gemv(const GemvArgs a) {
 // kernel arguments (a launch on the step's critical path pays for every instruction and scalar load in front of its first
 // memory request); -1 keeps the run-time dispatch.
 template <int RIF, int NCH, bool NT, int PRO = -1, int EPI = -1, int HPW = 0, int WPB = 4, bool FS = false>
-__global__ __launch_bounds__(64 * WPB) void k_gemv1(const GemvArgs a) {
+__global__ __launch_bounds__(64 * WPB) void k_gemv1(const GemvArgs a_in) {
+    // Lock-step chunk rows (a_in.lanes != 0, grid.y = rows): row y IS a one-row problem — its own activation row, its own self cache
+    // and step record, its own slice of the cross-attention partials — so the arguments are shifted to row y and everything below is
+    // the one-row kernel, bit for bit.  The weight rows are read once per row instead of once: grid.x is a multiple of 8, so the
+    // workgroups of ALL rows that stream a given weight tile share one XCD (workgroup id % 8 = tile % 8) and the tile comes out of
+    // that XCD's L2 for rows 1..n-1 (7.3 MB per decoder layer, 4 MB of L2 per XCD).
+    GemvArgs a = a_in;
+    if (a_in.lanes) {
+        const int y = blockIdx.y;
+        const int epi_ = EPI < 0 ? a.epi : EPI;
+        if (a.x32) a.x32 += (size_t) y * a.K;
+        if (a.a16) a.a16 += (size_t) y * a.K;
+        if (a.resid) a.resid += (size_t) y * a.ldr;
+        const bool c32 = epi_ == EPI_F32_BIAS_RESID || epi_ == EPI_LOGITS;
+        a.C = c32 ? (void *) ((float *) a.C + (size_t) y * a.ldc) : (void *) ((__half *) a.C + (size_t) y * a.ldc);
+        if (a.aux)  a.aux  = (__half *) a.aux  + (int64_t) y * a.cache_row_stride;      // (QKV_DEC: the row's self caches)
+        if (a.aux2) a.aux2 = (__half *) a.aux2 + (int64_t) y * a.cache_row_stride;
+        if (a.row_off) a.row_off += (size_t) y * a.step_stride;
+        if (a.sa_q) { a.sa_q += (size_t) y * a.K; a.sa_k += (int64_t) y * a.cache_row_stride; a.sa_v += (int64_t) y * a.cache_row_stride; a.sa_nkv += (size_t) y * a.step_stride; }
+        if (a.comb_o) {
+            const size_t hs = (size_t) y * (a.K >> 6) * a.comb_ns;                       // partials of row y: [head][slice]
+            a.comb_o += hs * 64; a.comb_l += hs; if (a.comb_m) a.comb_m += hs;
+        }
+        a.lanes = 0; a.n = 1;
+    }
     const bool pro_ln = PRO < 0 ? a.ln_g != nullptr : PRO == 1;
     const bool pro_sa = PRO < 0 ? a.sa_q != nullptr : PRO == 2;
     const bool pro_comb = PRO < 0 ? a.comb_o != nullptr : PRO == 3;
@@ -1212,7 +1236,9 @@ void launch_gemv1(const GemvArgs & a, hipStream_t st, int max_blocks = 512) {
     static std::atomic<uint64_t> lds_ok{0};
     if (smem > 48 * 1024) allow_full_lds((const void *) k_gemv1<RIF, NCH, NT, PRO, EPI, HPW, WPB, FS>, lds_ok);
     if (PRO <= 0 && (EPI < 0 || EPI == EPI_F32_BIAS_RESID) && a.step_copy_src) blocks += 1;       // the step-record mirror (see the kernel)
-    hipLaunchKernelGGL((k_gemv1<RIF, NCH, NT, PRO, EPI, HPW, WPB, FS>), dim3(blocks), dim3(64 * WPB), smem, st, a);
+    int rows = 1;
+    if (a.lanes) { rows = a.n; blocks = (blocks + 7) & ~7; }      // lock-step rows: grid.y = row, grid.x a multiple of 8 (see the kernel)
+    hipLaunchKernelGGL((k_gemv1<RIF, NCH, NT, PRO, EPI, HPW, WPB, FS>), dim3(blocks, rows), dim3(64 * WPB), smem, st, a);
 }
 
 static int logits_blocks_cap() {
@@ -1762,10 +1788,26 @@ static bool rows_on_mfma(const GemvArgs & a) {
            (a.epi != EPI_QKV_DEC || (a.S % 16) == 0) && (!rows_valu || a.n > 8);
 }
 bool gemv_rows_carries_mirror(const GemvArgs & a) { return rows_on_mfma(a) && a.N >= 8192; }
+bool gemv_rows_take_self_attention(const GemvArgs & a) {
+    static const int rows_y = getenv("WMI_ROWS_Y") ? atoi(getenv("WMI_ROWS_Y")) : 1;
+    static const bool off = getenv("WMI_GEMV1_GENERIC") != nullptr;
+    const int nch = (a.K + 511) / 512, hpw = (a.K / 64 + 3) / 4;
+    const bool inst = (nch == 1 && (hpw == 1 || hpw == 2)) || (nch == 2 && (hpw == 3 || hpw == 4)) || (nch == 3 && (hpw == 5 || hpw == 4));
+    return rows_y && !off && a.lanes && a.n >= 2 && a.n <= 16 && a.N < 8192 && a.K <= 2048 && (a.K % 64) == 0 && a.epi == EPI_F32_BIAS_RESID && inst;
+}
 static void gemv_(const GemvArgs & a, hipStream_t st) {
     // lock-step chunk rows go to the matrix cores (WMI_ROWS_VALU=1 keeps them on the VALU kernel, whose per-row
     // arithmetic is bit-identical to the single-row path: used by the parity tests to pin the control flow)
-    const bool mfma_ok = rows_on_mfma(a);
+    // ... except the small projections (everything but the vocabulary): as n one-row problems, row = grid.y of the one-row kernels
+    // (k_gemv1).  The matrix-core rows kernel reads every weight once but normalises / gathers all n rows in each of its workgroups and
+    // runs 6.3-6.6 us per launch at 8 rows where the one-row kernels take 4.2-4.8; with the row dimension on grid.y the extra weight
+    // reads come from the XCD's own L2, and the out projection takes the self-attention in its prologue like the one-row step (one
+    // launch fewer per layer).  Per row the arithmetic IS the one-row path's.  WMI_ROWS_Y=0: off (A/B).
+    static const int rows_y = getenv("WMI_ROWS_Y") ? atoi(getenv("WMI_ROWS_Y")) : 1;
+    if (rows_y && a.lanes && a.n >= 2 && a.n <= 16 && a.N < 8192 && !a.rows && a.K <= 2048 && (a.K % 8) == 0 && (!a.ln_g || a.K <= 1536) && !a.step_copy_src) {
+        if (launch_gemv1_special(a, (a.K + 511) / 512, st)) return;
+    }
+    const bool mfma_ok = rows_on_mfma(a) && !a.sa_q;
     if (mfma_ok) {
         static const bool generic = getenv("WMI_ROWS_GENERIC_EPI") != nullptr;       // A/B knob
         const bool vec = !generic && (a.N % 16) == 0 && (a.ldc % 4) == 0 && (!a.resid || (a.ldr % 4) == 0) &&

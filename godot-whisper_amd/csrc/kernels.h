@@ -222,6 +222,7 @@ struct GemvArgs {
 };
 int gemv_fused_parts(const GemvArgs & a);
 bool gemv_rows_carries_mirror(const GemvArgs & a);
+bool gemv_rows_take_self_attention(const GemvArgs & a);      // lock-step rows: will gemv() run this out projection with the self-attention in its prologue?
 // lock-step chunks: single-token self-attention of n rows, row r against the cache at kc/vc + r * cache_row_stride with
 // n_kv[r * step_stride] cells; same arithmetic as the fused prologue of gemv (GemvArgs::sa_*).  out [n][K] f16
 void self_attn_rows(const __half * q, int n, int K, const __half * kc, const __half * vc, int64_t cache_row_stride,

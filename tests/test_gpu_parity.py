@@ -931,7 +931,7 @@ def test_ten_minute_stream_small_shape(product_lib, checker_lib):
     ref = host.CaptureStreamToText(checker_lib, transcribe_interval=0.3); ref.language = "de"; ref.set_language_model(model)
     ref.n_threads = max(4, min(32, os.cpu_count() or 4))
     try:
-        n_cmp = 0; near_ties = []; n_tok = 0; n_full = 0
+        n_cmp = 0; near_ties = []; n_tok = 0; n_full = 0; worst_p = 0.0
         for (fin, text, n_used, actx, toks), mine in zip(ref.stream(pcm[: 16000 * 24], max_calls=64), calls):
             if (fin, n_used, actx) != (mine[0], mine[1], mine[2]):
                 # the two loops only part ways when a near-tie changed a token count or the last character the sentence rule looks at
@@ -950,12 +950,15 @@ def test_ten_minute_stream_small_shape(product_lib, checker_lib):
                 assert len(g) == len(w), (n_cmp, len(g), len(w))
                 n_full += 1
             if first:
-                assert np.abs(g[:first, 2] - w[:first, 2]).max() <= 1e-2
+                # p = soft-max probability of the picked token: a logit difference d moves it by p (1 - p) d, i.e. by up to 0.25 x the logit
+                # bound (LOGIT_ABS = 6e-2, + 20 % for the log-sum-exp) where the distribution is flat (p ~ 0.3-0.5 on these weights); 1e-2 holds where p > 0.9
+                dp = np.abs(g[:first, 2] - w[:first, 2]); worst_p = max(worst_p, float(dp.max()))
+                assert np.all(dp <= np.maximum(1e-2, 1.2 * LOGIT_ABS * w[:first, 2] * (1 - w[:first, 2]) + 2e-3)), (n_cmp, dp, w[:first, 2])
                 assert np.array_equal(g[:first, 6], w[:first, 6])                 # token start times of the common prefix
             n_tok += first
             n_cmp += 1
         print(f"configs[2]: {n_cmp} calls compared with the reference, {n_full} identical token streams, {n_tok} common tokens, "
-              f"{len(near_ties)} near-ties (call, token): {near_ties}")
+              f"{len(near_ties)} near-ties (call, token): {near_ties}; largest |p difference| on common tokens {worst_p:.3e}")
         assert n_cmp >= 40 and len(near_ties) <= max(2, n_cmp // 8), (n_cmp, near_ties)
     finally:
         ref.close()
