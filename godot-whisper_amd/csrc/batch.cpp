@@ -522,6 +522,8 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
     for (int g0 = 0; g0 < n_chunks; g0 += group) {
         const int ng = std::min(group, n_chunks - g0);
         std::vector<Row> rows(ng);
+        static const int env_when_ = getenv("WMI_ENVELOPE_WHEN") ? atoi(getenv("WMI_ENVELOPE_WHEN")) : 0;
+        const bool env_interleaved = env_when_ == 0;            // default: each chunk's envelope right behind its mel kernels
         // ---- per chunk: PCM -> mel, envelope, window bounds (the head of full())
         for (int r = 0; r < ng; ++r) {
             Row & row = rows[r]; row.chunk = g0 + r; row.lane = r;
@@ -538,10 +540,27 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
             }
             if (params.token_timestamps) {
                 ls.t_beg = 0; ls.t_last = 0; ls.tid_last = 0;
-                if (n_samples[row.chunk] > 0 && !signal_energy_device(ctx, 32, false)) { WMI_ERR("%s: failed to compute the signal envelope\n", __func__); return -2; }
+                if (env_interleaved && n_samples[row.chunk] > 0 && !signal_energy_device(ctx, 32, false)) { WMI_ERR("%s: failed to compute the signal envelope\n", __func__); return -2; }
             }
             b.t_mel_us += time_us() - tm0;
         }
+        // The |x| envelopes (token timestamps): 1875 workgroups per chunk whose waves sit on stores into pinned host memory (1.9 MB per
+        // chunk over PCIe).  WMI_ENVELOPE_WHEN (A/B): 0 = behind each chunk's mel kernels (default), 1 = behind the mel kernels of all
+        // chunks (beside the encoder), 2 = behind the first window's encoder (beside the decode steps).  Measured (profiles/
+        // r04b_envelope_placement.txt): they cost 0.3-0.4 ms of the 8-chunk call WHEREVER they run — mel phase 0.60 -> 0.24 ms with 1 or 2,
+        // and the encoder (its persistent GEMMs want every CU at once) or the decode steps (their 32-byte results queue behind 15 MB of
+        // bulk writes) give the same time back; the copy-engine form (WMI_ENVELOPE_DMA) is a blit kernel on this stack (rocprof:
+        // __amd_rocclr_copyBuffer, no SDMA), a thin grid (WMI_ENVELOPE_GRID) starves the kernel's 65-deep f64 chains.
+        static const bool env_dma = getenv("WMI_ENVELOPE_DMA") != nullptr;
+        auto envelopes = [&]() -> bool {
+            if (!params.token_timestamps) return true;
+            for (int r = 0; r < ng; ++r) {
+                State & ls = *b.lanes[r];
+                StateSwap sw(ctx, &ls);
+                if (n_samples[g0 + r] > 0 && !signal_energy_device(ctx, 32, false, env_dma)) { WMI_ERR("%s: failed to compute the signal envelope\n", __func__); return false; }
+            }
+            return true;
+        };
         // one synchronisation for the mel kernels of all chunks (keeps the mel / encoder time buckets separate); the
         // envelopes are written to the host by the chunks' side streams and are awaited at emission time
         {
@@ -554,6 +573,8 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
             if (!HIP_OK(hipStreamSynchronize(primary->dev.stream))) return -2;
             b.t_mel_us += time_us() - tm0;
         }
+        bool env_done = env_interleaved || !params.token_timestamps;
+        if (!env_done && env_when_ == 1) { if (!envelopes()) return -2; env_done = true; }
         for (int r = 0; r < ng; ++r) {
             Row & row = rows[r]; State & ls = *b.lanes[r];
             row.seek_start = params.offset_ms / 10;
@@ -563,6 +584,8 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
         }
 
         // ---- windows in lock-step
+        // (chunks too short for a window never reach the encoder: their envelopes are not needed either — emission only reads them for
+        //  decoded tokens)
         while (true) {
             std::vector<int> act;                              // row r of the kernels <-> rows[act[r]]
             for (int r = 0; r < ng; ++r) if (rows[r].live && !rows[r].redo && rows[r].seek + 100 < rows[r].seek_end) act.push_back(r);
@@ -572,6 +595,7 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
                 std::vector<int> lanes(nb), seeks(nb);
                 for (int r = 0; r < nb; ++r) { lanes[r] = rows[act[r]].lane; seeks[r] = rows[act[r]].seek; }
                 if (!encode_rows(ctx, lanes, seeks, params.audio_ctx)) { WMI_ERR("%s: failed to encode\n", __func__); return -6; }
+                if (!env_done) { if (!envelopes()) return -2; env_done = true; }
                 b.chain_valid = false;                             // new windows, possibly other chunks in the rows: every row restarts at cell 0
             }
             for (int r = 0; r < nb; ++r) {

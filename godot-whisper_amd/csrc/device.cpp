@@ -164,12 +164,15 @@ bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, boo
     return true;
 }
 
-bool signal_energy_device(whisper_context & ctx, int hw, bool sync) {
+bool signal_energy_device(whisper_context & ctx, int hw, bool sync, bool via_dma) {
     State & st = *ctx.state; DeviceState & d = st.dev;
     const int n = d.last_pcm_n;
     if (!d.last_pcm || n <= 0) return false;
     if (!d.copy_stream) {
-        HIP_TRY(hipStreamCreateWithFlags(&d.copy_stream, hipStreamNonBlocking));
+        // lowest priority: the envelope is needed at emission time only, whatever shares the chip with it goes first
+        int prio_lo = 0, prio_hi = 0;
+        (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        if (!HIP_OK(hipStreamCreateWithPriority(&d.copy_stream, hipStreamNonBlocking, prio_lo))) HIP_TRY(hipStreamCreateWithFlags(&d.copy_stream, hipStreamNonBlocking));
         HIP_TRY(hipEventCreateWithFlags(&d.energy_ev, hipEventDisableTiming));
     }
     if (d.energy_pending) { HIP_TRY(hipStreamSynchronize(d.copy_stream)); d.energy_pending = false; }   // previous envelope still being written
@@ -187,6 +190,16 @@ bool signal_energy_device(whisper_context & ctx, int hw, bool sync) {
     HIP_TRY(hipStreamWaitEvent(d.copy_stream, d.energy_ev, 0));
     {
         const size_t nb = (size_t) n / 256 + 2;
+        // via_dma (several chunks per call): the kernel writes a device buffer (~10 us) and the copy engine moves it to the pinned image —
+        // as stores from the kernel, 8 x 1875 workgroups sat on PCIe writes in the CUs' wave slots for 0.25-0.35 ms beside the mel kernels
+        // or the encoder, whichever they were queued next to.  One chunk: the direct stores (no copy call on the host's critical path).
+        const size_t need = d.energy_cap + 2 * nb;
+        if (via_dma && d.energy_dev_cap < need) { dfree(d.energy); d.energy_dev_cap = 0; if (dalloc(d.energy, need)) d.energy_dev_cap = need; else via_dma = false; }
+        if (via_dma) {
+            k::signal_energy(d.last_pcm, n, hw, d.energy, d.energy + d.energy_cap, d.energy + d.energy_cap + nb, d.copy_stream);
+            HIP_TRY(hipMemcpyAsync(d.energy_host, d.energy, (size_t) n * 4, hipMemcpyDeviceToHost, d.copy_stream));
+            HIP_TRY(hipMemcpyAsync(d.energy_host + d.energy_cap, d.energy + d.energy_cap, 2 * nb * 4, hipMemcpyDeviceToHost, d.copy_stream));
+        } else
         k::signal_energy(d.last_pcm, n, hw, d.energy_host, d.energy_host + d.energy_cap, d.energy_host + d.energy_cap + nb, d.copy_stream);
     }
     d.energy_pending = true;

@@ -258,7 +258,12 @@ __global__ void k_mel_slice(const float * __restrict__ mel, int n_len, int n_mel
 __global__ __launch_bounds__(256) void k_signal_energy(const float * __restrict__ x, int n, int hw, float * __restrict__ out,
                                                        float * __restrict__ bmin, float * __restrict__ bmax) {
     __shared__ float s_min[4], s_max[4];
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // block-stride loop: the grid may be thinner than one workgroup per 256 samples (WMI_ENVELOPE_GRID, A/B: the kernel is bound by its
+    // stores into pinned host memory and its stalled waves hold slots beside whatever runs next to it — but 64 workgroups starve the
+    // 65-deep f64 chains: the lock-step call 6.0 -> 6.5 ms; the one-chunk call within noise)
+    for (int blk = blockIdx.x; blk * 256 < n; blk += gridDim.x) {
+    if (blk != (int) blockIdx.x) __syncthreads();          // s_min / s_max are reused
+    const int i = blk * blockDim.x + threadIdx.x;
     float v = 0.0f;
     if (i < n) {
         float sum = 0.0f;
@@ -274,8 +279,9 @@ __global__ __launch_bounds__(256) void k_signal_energy(const float * __restrict_
     if ((threadIdx.x & 63) == 0) { s_min[threadIdx.x >> 6] = lo; s_max[threadIdx.x >> 6] = hi; }
     __syncthreads();
     if (threadIdx.x == 0) {
-        bmin[blockIdx.x] = fminf(fminf(s_min[0], s_min[1]), fminf(s_min[2], s_min[3]));
-        bmax[blockIdx.x] = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+        bmin[blk] = fminf(fminf(s_min[0], s_min[1]), fminf(s_min[2], s_min[3]));
+        bmax[blk] = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
+    }
     }
 }
 
@@ -396,7 +402,9 @@ void mel_slice(const float * mel, int n_len, int n_mel, int offset, int n_frames
 }
 
 void signal_energy(const float * pcm, int n, int hw, float * out, float * bmin, float * bmax, hipStream_t st) {
-    hipLaunchKernelGGL(k_signal_energy, dim3((n + 255) / 256), dim3(256), 0, st, pcm, n, hw, out, bmin, bmax);
+    static const int thin = getenv("WMI_ENVELOPE_GRID") ? atoi(getenv("WMI_ENVELOPE_GRID")) : 0;      // A/B knob; 0 = one workgroup per block
+    const int nblk = (n + 255) / 256;
+    hipLaunchKernelGGL(k_signal_energy, dim3(thin > 0 && thin < nblk ? thin : nblk), dim3(256), 0, st, pcm, n, hw, out, bmin, bmax);
 }
 
 void downmix_stereo(const float * frames, int n_frames, float * out, hipStream_t st) {

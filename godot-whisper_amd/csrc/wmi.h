@@ -187,6 +187,7 @@ struct DeviceState {
     const float * last_pcm = nullptr; int last_pcm_n = 0;     // device copy of the samples of the last pcm_to_mel
     float * energy = nullptr;   size_t energy_cap = 0;        // |x| envelope (device)
     float * energy_host = nullptr;                            // pinned mirror
+    size_t  energy_dev_cap = 0;                               // floats allocated at `energy` (envelope + block extrema; the copy-engine form)
     hipStream_t copy_stream = nullptr; hipEvent_t energy_ev = nullptr;   // envelope D2H overlaps the encoder
     hipStream_t mel_stream = nullptr;  hipEvent_t mel_ev = nullptr;      // lock-step chunks: the mel kernels of the chunks overlap
     bool    energy_pending = false;                            // copy in flight: signal_energy_wait() before reading state.energy
@@ -365,7 +366,7 @@ double bench_rows_step_chain(whisper_context & ctx, int nb, int iters);
 int    step_stamps(whisper_context & ctx, double * out, int cap, bool chained);
 // |x| envelope of the last PCM on the GPU; the D2H copy runs on a side stream while the encoder works.
 // sync = false: state.energy is valid only after signal_energy_wait()
-bool signal_energy_device(whisper_context & ctx, int hw, bool sync = true);
+bool signal_energy_device(whisper_context & ctx, int hw, bool sync = true, bool via_dma = false);   // via_dma: kernel -> device buffer -> copy engine (lock-step chunks)
 bool signal_energy_wait(State & st);
 
 // host logic (logits filters, sampling, driver)
