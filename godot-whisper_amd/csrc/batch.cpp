@@ -89,7 +89,7 @@ bool ensure_batch(whisper_context & ctx, int B) {
     w.Tpad = (int) ((T + 63) / 64 * 64);
     w.mel_rows = 2 * T + 8;
     const size_t nb = (size_t) B;
-    bool ok = dalloc(w.mel_t, nb * w.mel_rows * hp.n_mels + 1024) && dalloc(w.conv1, nb * (2 * T + 4) * S)
+    bool ok = dalloc(w.mel_t, nb * w.mel_rows * hp.n_mels + 1024) && dalloc(w.conv1, nb * (2 * T + 8) * S + 4 * S)
            && dalloc(w.x, nb * T * S) && dalloc(w.xn, nb * T * S) && dalloc(w.q, nb * T * S) && dalloc(w.k, nb * T * S)
            && dalloc(w.att, nb * T * S) && dalloc(w.vt, nb * S * w.Tpad) && dalloc(w.h, nb * T * 4 * S) && dalloc(w.enc_out_h, nb * T * S)
            && dalloc(w.kvc_k, Lt * nb * T * S) && dalloc(w.kvc_v, Lt * nb * T * S)
@@ -110,7 +110,7 @@ bool ensure_batch(whisper_context & ctx, int B) {
     memset(w.sample_host, 0, nb * sizeof(k::SampleOut));
     w.step_seq = 0;
     k::fill_zero(w.vt, nb * S * w.Tpad * sizeof(__half), s);
-    k::fill_zero(w.conv1, nb * (2 * T + 4) * S * sizeof(__half), s);
+    k::fill_zero(w.conv1, (nb * (2 * T + 8) * S + 4 * S) * sizeof(__half), s);
     k::fill_zero(w.mel_t, (nb * w.mel_rows * hp.n_mels + 1024) * sizeof(__half), s);
     k::fill_zero(w.self_k, nb * Lt * n_ctx * S * sizeof(__half), s);
     k::fill_zero(w.self_v, nb * Lt * n_ctx * S * sizeof(__half), s);
@@ -138,13 +138,42 @@ bool encode_rows(whisper_context & ctx, const std::vector<int> & rows, const std
     hipStream_t s = ctx.state->dev.stream;
     const int M = nb * T;
 
-    // conv front-end, per chunk (the overlapping-row implicit GEMM needs each chunk's zero guard rows)
+    // conv front-end.  The overlapping-row implicit GEMM needs each chunk's zero guard rows, so the chunks are STACKED with a period of
+    // R = 2 T + 8 rows in both images — mel slice rows c R .. (row 0 and the rows behind the 2 T frames are zero) and conv1 rows c R ..
+    // (row c R = the chunk's leading guard) — and each convolution is ONE launch over all of them: conv1 row m + 1 from mel rows m .. m + 2,
+    // conv2 output t of chunk c from conv1 rows c R + 2 t .. + 2 (EPI_CONV2 with rows_per_chunk = R / 2 stores rows t < T at c T + t).
+    // The rows conv1 computes across a chunk boundary (c R + 2 T + 1 .. (c + 1) R) are zeroed again before conv2 reads them.
+    // Per element the arithmetic is the one-chunk launch's (same operands, same k order).  8 chunks: 32 launches -> 4.
+    // WMI_CONV_PER_CHUNK=1 (A/B): one chunk at a time as before.
+    static const bool conv_per_chunk = getenv("WMI_CONV_PER_CHUNK") != nullptr;
     const int rows_mel = 2 * T + 6;
     for (int r = 0; r < nb; ++r) {
         State & ls = *b.lanes[rows[r]];
         if (ls.mel.n_mel != nm || ls.dev.mel == nullptr) { WMI_ERR("%s: chunk row %d has no mel spectrogram\n", __func__, r); return false; }
+    }
+    if (!conv_per_chunk && nb >= 2 && nb <= 16) {
+        const int R = 2 * T + 8;
+        k::MelSliceBatch mb{};
+        for (int r = 0; r < nb; ++r) { State & ls = *b.lanes[rows[r]]; mb.mel[r] = ls.dev.mel; mb.n_len[r] = ls.mel.n_len; mb.offset[r] = seek[r]; }
+        k::mel_slice_batch(mb, nb, nm, 2 * T, b.mel_t, nm, R, s);
+        {
+            k::GemmArgs a{};
+            a.A = b.mel_t; a.lda = nm; a.W = w.conv1_w; a.ldw = w.conv1_k; a.M = nb * R - 1; a.N = S; a.K = w.conv1_k;
+            a.bias = w.conv1_b; a.C = b.conv1 + S; a.ldc = S;
+            k::gemm(k::EPI_F16_BIAS_GELU, a, s);
+        }
+        k::fill_zero_strided(b.conv1 + (size_t) (2 * T + 1) * S, (size_t) 8 * S * sizeof(__half), (size_t) R * S * sizeof(__half), nb, s);
+        {
+            k::GemmArgs a{};
+            a.A = b.conv1; a.lda = 2 * S; a.W = w.conv2_w; a.ldw = w.conv2_k; a.M = nb * (R / 2) - 1; a.N = S; a.K = w.conv2_k;
+            a.bias = w.conv2_b; a.C = b.x; a.ldc = S; a.resid = w.e_pe; a.ldr = S; a.rows_per_chunk = R / 2;
+            k::gemm(k::EPI_CONV2, a, s);
+        }
+    } else
+    for (int r = 0; r < nb; ++r) {
+        State & ls = *b.lanes[rows[r]];
         __half * mel_t = b.mel_t + (size_t) r * b.mel_rows * nm;
-        __half * conv1 = b.conv1 + (size_t) r * (2 * hp.n_audio_ctx + 4) * S;
+        __half * conv1 = b.conv1 + (size_t) r * (2 * hp.n_audio_ctx + 8) * S;
         k::mel_slice(ls.dev.mel, ls.mel.n_len, nm, seek[r], 2 * T, mel_t, nm, rows_mel, s);
         {
             k::GemmArgs a{};

@@ -56,6 +56,16 @@ __device__ __forceinline__ half2v gelu16_pair(float2v x) {
     return __builtin_convertvector(g, half2v);
 }
 
+// EPI_CONV2 over several lock-step chunks in one launch (GemmArgs::rows_per_chunk = P > 0): the implicit-GEMM rows of chunk c are
+// c P .. c P + P - 1 (P = T + 4: the chunk's T output frames and the rows that straddle its guard rows), output row c T + t, positional
+// row t; rows t >= T are not stored.  P = 0: one chunk, row m is both.
+struct Conv2Row { int out, pe; bool valid; };
+__device__ __forceinline__ Conv2Row conv2_row(const GemmArgs & a, int m) {
+    if (a.rows_per_chunk <= 0) return Conv2Row{m, m, true};
+    const int P = a.rows_per_chunk, c = m / P, t = m - c * P;
+    return Conv2Row{c * (P - 4) + t, t < P - 4 ? t : 0, t < P - 4};
+}
+
 // first orientation, mfma(A rows, W rows): fragment (i, j) holds rows m = mb + i*16 + fq*4 + r (r = 0..3) of column n = nb + j*16 + frow.
 // Interior tiles take the instantiation without bounds checks: a per-element `if (m < M)` makes every store its own basic block, and
 // hipcc then waits vmcnt(0) before each one (vmcnt also counts stores on gfx9-family parts), i.e. the 64 stores of a lane complete one
@@ -83,7 +93,8 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs & a, floatx4 (&acc)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int m = mb + i * 16 + fq * 4 + r;
-                    rpre[i][r] = a.resid[(size_t) ((GUARD && m >= a.M) ? a.M - 1 : m) * a.ldr + n];
+                    const int mc = (GUARD && m >= a.M) ? a.M - 1 : m;
+                    rpre[i][r] = a.resid[(size_t) (EPI == EPI_CONV2 ? conv2_row(a, mc).pe : mc) * a.ldr + n];
                 }
         }
 #pragma unroll
@@ -134,8 +145,11 @@ __device__ __forceinline__ void epilogue_rows(const GemmArgs & a, floatx4 (&acc)
                     ((float *) a.C)[(size_t) m * a.ldc + n] = (v + bias) + rpre[i][r];
                 } else if constexpr (EPI == EPI_CONV2) {
                     const float g = gelu16_fast(v + bias);
-                    if (a.aux) ((float *) a.aux)[(size_t) m * a.ldaux + n] = g;
-                    ((float *) a.C)[(size_t) m * a.ldc + n] = rpre[i][r] + g;
+                    const Conv2Row cr = conv2_row(a, m);
+                    if (cr.valid) {
+                        if (a.aux) ((float *) a.aux)[(size_t) cr.out * a.ldaux + n] = g;
+                        ((float *) a.C)[(size_t) cr.out * a.ldc + n] = rpre[i][r] + g;
+                    }
                 } else if constexpr (EPI == EPI_QKV_DEC) {
                     // The q | k | v segment is decided per 16-column fragment on a WAVE-UNIFORM value
                     // (S is a multiple of 16, so a fragment never straddles a segment).  A per-lane
@@ -178,7 +192,8 @@ __device__ __forceinline__ void epilogue_cols(const GemmArgs & a, floatx4 (&acc)
 #pragma unroll
             for (int i = 0; i < FM; ++i) {
                 const int m = mb + i * 16 + frow;
-                rpre[i] = *(const float4 *) (a.resid + (size_t) ((GUARD && m >= a.M) ? a.M - 1 : m) * a.ldr + n);
+                const int mc = (GUARD && m >= a.M) ? a.M - 1 : m;
+                rpre[i] = *(const float4 *) (a.resid + (size_t) (EPI == EPI_CONV2 ? conv2_row(a, mc).pe : mc) * a.ldr + n);
             }
         }
 #pragma unroll
@@ -214,9 +229,12 @@ __device__ __forceinline__ void epilogue_cols(const GemmArgs & a, floatx4 (&acc)
                 const float2v x0 = {v[0] + bias[0], v[1] + bias[1]}, x1 = {v[2] + bias[2], v[3] + bias[3]};
                 const half2v g0 = gelu16_pair(x0), g1 = gelu16_pair(x1);
                 g.x = (float) g0[0]; g.y = (float) g0[1]; g.z = (float) g1[0]; g.w = (float) g1[1];
-                if (a.aux) *(float4 *) ((float *) a.aux + (size_t) m * a.ldaux + n) = g;
-                o.x = rpre[i].x + g.x; o.y = rpre[i].y + g.y; o.z = rpre[i].z + g.z; o.w = rpre[i].w + g.w;
-                *(float4 *) ((float *) a.C + (size_t) m * a.ldc + n) = o;
+                const Conv2Row cr = conv2_row(a, m);
+                if (cr.valid) {
+                    if (a.aux) *(float4 *) ((float *) a.aux + (size_t) cr.out * a.ldaux + n) = g;
+                    o.x = rpre[i].x + g.x; o.y = rpre[i].y + g.y; o.z = rpre[i].z + g.z; o.w = rpre[i].w + g.w;
+                    *(float4 *) ((float *) a.C + (size_t) cr.out * a.ldc + n) = o;
+                }
             } else if constexpr (EPI == EPI_QKV_ENC) {
                 // q (bias, no scale here: the encoder scales the scores) | k (no bias); the V^T third runs in the first orientation
                 const int seg = __builtin_amdgcn_readfirstlane(n0 / a.S);       // tile-uniform: BN | S

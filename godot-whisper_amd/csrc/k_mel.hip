@@ -248,6 +248,33 @@ __global__ void k_mel_slice(const float * __restrict__ mel, int n_len, int n_mel
     }
 }
 
+// the same for up to 16 lock-step chunks in one launch (grid.z = chunk): chunk c's rows are c * rows_total .. (c + 1) * rows_total - 1 of `out`
+__global__ void k_mel_slice_batch(const MelSliceBatch mb, int n_mel, int n_frames, __half * __restrict__ out, int ld, int rows_total) {
+    __shared__ float tile[32][33];
+    const int ch = blockIdx.z;
+    const float * __restrict__ mel = mb.mel[ch]; const int n_len = mb.n_len[ch], offset = mb.offset[ch];
+    out += (size_t) ch * rows_total * ld;
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int j = ty; j < 32; j += 8) {
+        const int c = c0 + j, r = r0 + tx;
+        const int fr = offset + r - 1;
+        float v = 0.0f;
+        if (c < n_mel && r >= 1 && r <= n_frames && fr < n_len && fr >= 0) v = mel[(size_t) c * n_len + fr];
+        tile[j][tx] = v;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int r = r0 + j, c = c0 + tx;
+        if (r < rows_total && c < ld) out[(size_t) r * ld + c] = f2h(c < n_mel ? tile[tx][j] : 0.0f);
+    }
+}
+// `count` runs of `words` 32-bit zeros, `stride_words` apart (the guard rows between the stacked chunks of the batched conv front-end)
+__global__ void k_fill_zero_strided(uint32_t * p, size_t words, size_t stride_words, int count) {
+    const size_t i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < words && (int) blockIdx.y < count) p[(size_t) blockIdx.y * stride_words + i] = 0u;
+}
+
 // mean |x| over a (2 hw + 1)-sample window, summed left to right with the reference's exact arithmetic
 // (float accumulator, each step rounded through a double add: `sum += fabs(x)`, W/whisper.cpp:6352-6366),
 // so the host-side timestamp heuristics see bit-identical thresholds.
@@ -399,6 +426,15 @@ void mel_slice(const float * mel, int n_len, int n_mel, int offset, int n_frames
                hipStream_t st) {
     dim3 grid((rows_total + 31) / 32, (ld + 31) / 32);
     hipLaunchKernelGGL(k_mel_slice, grid, dim3(256), 0, st, mel, n_len, n_mel, offset, n_frames, out, ld, rows_total);
+}
+
+void mel_slice_batch(const MelSliceBatch & mb, int nb, int n_mel, int n_frames, __half * out, int ld, int rows_total, hipStream_t st) {
+    dim3 grid((rows_total + 31) / 32, (ld + 31) / 32, nb);
+    hipLaunchKernelGGL(k_mel_slice_batch, grid, dim3(256), 0, st, mb, n_mel, n_frames, out, ld, rows_total);
+}
+void fill_zero_strided(void * p, size_t bytes, size_t stride_bytes, int count, hipStream_t st) {
+    if (count <= 0 || bytes == 0) return;
+    hipLaunchKernelGGL(k_fill_zero_strided, dim3((unsigned) ((bytes / 4 + 255) / 256), count), dim3(256), 0, st, (uint32_t *) p, bytes / 4, stride_bytes / 4, count);
 }
 
 void signal_energy(const float * pcm, int n, int hw, float * out, float * bmin, float * bmax, hipStream_t st) {

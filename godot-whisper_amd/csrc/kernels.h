@@ -69,6 +69,10 @@ void mel_frames(const float * pcm_pad, int n_valid, int n_fft_frames, int n_len,
 void mel_normalize(float * mel, int n, const int * gmax, hipStream_t st);
 // token-major f16 slice for the conv front-end: out[r][c], r in [0, rows_total), row r holds frame
 // (offset + r - 1); rows outside [1, n_frames] and frames >= n_len are zero.
+// lock-step chunks: the slices of up to 16 chunks in one launch (chunk c -> rows c * rows_total ..), and the guard rows between stacked chunks
+struct MelSliceBatch { const float * mel[16]; int n_len[16]; int offset[16]; };
+void mel_slice_batch(const MelSliceBatch & mb, int nb, int n_mel, int n_frames, __half * out, int ld, int rows_total, hipStream_t st);
+void fill_zero_strided(void * p, size_t bytes, size_t stride_bytes, int count, hipStream_t st);
 void mel_slice(const float * mel, int n_len, int n_mel, int offset, int n_frames, __half * out, int ld,
                int rows_total, hipStream_t st);
 
