@@ -370,6 +370,7 @@ int wmi_resample(struct whisper_context * ctx, const float * src, int n_frames, 
     const double ratio = (double) (uint32_t) dst_rate / (double) (uint32_t) src_rate;              // :25-26
     const long long out_frames = (int) ((uint32_t) n_frames * ratio);
     if (out_frames > dst_capacity) return -4;
+    try {                                                                                          // (the plan allocates: nothing throws across the C ABI)
     const k::ResamplePlan pl = k::resample_plan(n_frames, out_frames, ratio, converter);
     if (pl.error) {
         WMI_ERR("wmi_resample: converter error %d (src_simple would report it through src_strerror)\n", -pl.error);
@@ -404,20 +405,23 @@ int wmi_resample(struct whisper_context * ctx, const float * src, int n_frames, 
     ok = ok && HIP_OK(hipStreamSynchronize(s));
     (void) hipFree(d_pos); (void) hipFree(d_frac);
     return ok ? (int) pl.n_out : -3;
+    } catch (...) { WMI_ERR("wmi_resample: out of memory\n"); return -3; }
 }
 
 int wmi_selftest_resample_plan(int n_frames, int src_rate, int dst_rate, int converter, long long * frames_gen, long long * frames_used,
                                int * closed_form, int n_pos, long long * pos, double * frac) {
-    if (n_frames < 0 || src_rate <= 0 || dst_rate <= 0 || src_rate == dst_rate) return -1;
+    if (n_frames < 0 || src_rate <= 0 || dst_rate <= 0 || src_rate == dst_rate || n_pos < 0 || (n_pos > 0 && (!pos || !frac))) return -1;
     const double ratio = (double) (uint32_t) dst_rate / (double) (uint32_t) src_rate;
     const long long out_frames = (int) ((uint32_t) n_frames * ratio);
-    const k::ResamplePlan pl = k::resample_plan(n_frames, out_frames, ratio, converter);
-    if (pl.error) return pl.error;
-    if (frames_gen) *frames_gen = pl.n_out;
-    if (frames_used) *frames_used = pl.n_used;
-    if (closed_form) *closed_form = pl.need_table ? 0 : 1;
-    k::resample_positions(pl, std::min<long long>(n_pos, out_frames + 1), pos, frac);
-    return 0;
+    try {
+        const k::ResamplePlan pl = k::resample_plan(n_frames, out_frames, ratio, converter);
+        if (pl.error) return pl.error;
+        if (frames_gen) *frames_gen = pl.n_out;
+        if (frames_used) *frames_used = pl.n_used;
+        if (closed_form) *closed_form = pl.need_table ? 0 : 1;
+        if (n_pos > 0) k::resample_positions(pl, std::min<long long>(n_pos, out_frames + 1), pos, frac);
+        return 0;
+    } catch (...) { return -3; }
 }
 
 int wmi_vad(struct whisper_context * ctx, const float * pcm, int n_samples, int on_device, float vad_thold, float freq_thold, float * energies) {
@@ -695,7 +699,7 @@ int wmi_selftest_quant(int device, int qtype, int mode, const void * w_blocks, c
         } else if (ok) {
             k::Q8Rows A{d_qs, d_ds, d_ds + (size_t) nb * M, M};
             if (mode == 3 || mode == 4) { A.deq = d_a16; A.wdeq = d_w16; A.wdeq_elems = (size_t) N * K; }
-            if (mode == 4) { A.wdeq_ready = k::quantize_rows(d_x, nullptr, M, K, nullptr, nullptr, 0.f, qtype, A, nullptr, nullptr, st, &W, N); if (!A.wdeq_ready) ok = false; }
+            if (mode == 4) { A.wdeq_ready = k::quantize_rows(d_x, nullptr, M, K, nullptr, nullptr, 0.f, qtype, A, nullptr, nullptr, st, &W, N); A.wdeq_of = W.tiles; if (!A.wdeq_ready) ok = false; }
             else k::quantize_rows(d_x, nullptr, M, K, nullptr, nullptr, 0.f, qtype, A, nullptr, nullptr, st);
             if (mode == 0) {
                 k::GemvArgs ga{};
@@ -736,6 +740,7 @@ int wmi_selftest_seqsum(const float * x, int n, float * out_blocked, float * out
 
 int wmi_step_stamps(struct whisper_context * ctx, double * out, int cap, int chained) {
     if (!ctx || !ctx->state || !out) return -1;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);      // the probe replays the context's step: not beside a transcription
     (void) hipSetDevice(ctx->device);
     try { return step_stamps(*ctx, out, cap, chained != 0); } catch (...) { return -1; }
 }

@@ -477,7 +477,12 @@ bool wait_for_sample(const k::SampleOut * r, int32_t want, hipStream_t s) {
     if (!no_spin) {
         const int64_t tb = time_us();
         for (uint32_t it = 1;; ++it) {
-            if (*t0 == want && *t1 == want) { asm volatile("" ::: "memory"); return true; }
+            if (*t0 == want && *t1 == want) {
+                // the device writes each 16-byte half with one store that carries the tag; the caller reads the fields behind this
+                // return — re-read the tags behind a compiler barrier so that "tag, fields, tag" brackets what the caller copies
+                asm volatile("" ::: "memory");
+                if (*t0 == want && *t1 == want) return true;
+            }
             __builtin_ia32_pause();
             if ((it & 0xFFFF) == 0 && time_us() - tb > 2000000) break;
         }
@@ -775,6 +780,8 @@ int step_stamps(whisper_context & ctx, double * out, int cap, bool chained) {
     State & st = *ctx.state; DeviceState & d = st.dev;
     if (!d.step_dev || cap <= 0) return -1;
     if (ctx.model.quantised) chained = false;               // (the block-quantised step has one form)
+    // the chained replays advance the device-side record (cache head / n_kv + 1 per replay: four below): refuse near the end of the cache
+    if (chained && (int) ((const k::DecStep *) d.step_host)->kv_head + 6 >= (int) st.kv_self.size) return -1;
     const int Tc = st.enc_n_ctx > 0 ? st.enc_n_ctx : ctx.model.hp.n_audio_ctx;
     hipStream_t s = d.stream;
     const bool long_kv = ((const k::DecStep *) d.step_host)->n_kv > 64;

@@ -54,7 +54,7 @@ bool encode_layers_q_on(whisper_context & ctx, const EncBufsQ & e, hipStream_t s
         const EncLayerW & l = w.enc[il];
         // (each quantiser launch also writes the f16 image of the weights its projection multiplies with, see k::quantize_rows)
         k::Q8Rows Aq = A;
-        Aq.wdeq_ready = k::quantize_rows(e.x, nullptr, M, S, l.ln1_g, l.ln1_b, hp.eps, qt, A, nullptr, nullptr, s, &l.q_qkv, 3 * S);
+        Aq.wdeq_ready = k::quantize_rows(e.x, nullptr, M, S, l.ln1_g, l.ln1_b, hp.eps, qt, A, nullptr, nullptr, s, &l.q_qkv, 3 * S); Aq.wdeq_of = l.q_qkv.tiles;
         {
             k::GemmArgs a{};
             a.M = M; a.N = 3 * S; a.K = S; a.bias = l.b_qkv;
@@ -63,20 +63,20 @@ bool encode_layers_q_on(whisper_context & ctx, const EncBufsQ & e, hipStream_t s
             k::qgemm(k::EPI_QKV_ENC, a, Aq, l.q_qkv, s);
         }
         k::attn_encoder(e.q, e.k, e.vt, T, e.Tpad, S, H, kq_scale, nullptr, s, e.nb, e.att32);
-        Aq.wdeq_ready = k::quantize_rows(e.att32, nullptr, M, S, nullptr, nullptr, 0.f, qt, A, nullptr, nullptr, s, &l.q_o, S);
+        Aq.wdeq_ready = k::quantize_rows(e.att32, nullptr, M, S, nullptr, nullptr, 0.f, qt, A, nullptr, nullptr, s, &l.q_o, S); Aq.wdeq_of = l.q_o.tiles;
         {
             k::GemmArgs a{};
             a.M = M; a.N = S; a.K = S; a.bias = l.b_o; a.C = e.x; a.ldc = S; a.resid = e.x; a.ldr = S;
             k::qgemm(k::EPI_F32_BIAS_RESID, a, Aq, l.q_o, s);
         }
-        Aq.wdeq_ready = k::quantize_rows(e.x, nullptr, M, S, l.ln2_g, l.ln2_b, hp.eps, qt, A, nullptr, nullptr, s, &l.q_fc1, 4 * S);
+        Aq.wdeq_ready = k::quantize_rows(e.x, nullptr, M, S, l.ln2_g, l.ln2_b, hp.eps, qt, A, nullptr, nullptr, s, &l.q_fc1, 4 * S); Aq.wdeq_of = l.q_fc1.tiles;
         {
             k::GemmArgs a{};
             a.M = M; a.N = 4 * S; a.K = S; a.bias = l.b_fc1; a.C = e.h; a.ldc = 4 * S;
             k::qgemm(k::EPI_F16_BIAS_GELU, a, Aq, l.q_fc1, s);
         }
         k::Q8Rows A4q = A4;
-        A4q.wdeq_ready = k::quantize_rows(nullptr, e.h, M, 4 * S, nullptr, nullptr, 0.f, qt, A4, nullptr, nullptr, s, &l.q_fc2, S);
+        A4q.wdeq_ready = k::quantize_rows(nullptr, e.h, M, 4 * S, nullptr, nullptr, 0.f, qt, A4, nullptr, nullptr, s, &l.q_fc2, S); A4q.wdeq_of = l.q_fc2.tiles;
         {
             k::GemmArgs a{};
             a.M = M; a.N = S; a.K = 4 * S; a.bias = l.b_fc2; a.C = e.x; a.ldc = S; a.resid = e.x; a.ldr = S;

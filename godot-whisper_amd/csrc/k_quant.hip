@@ -1163,7 +1163,7 @@ void qgemm(int epi, const GemmArgs & a, Q8Rows A, QMat W, hipStream_t st) {
             return;
         }
         if (epi != EPI_CROSS_KV && a.N <= cap) {
-            if (!A.wdeq_ready) qdequant(W, 0, a.N, a.K, A.wdeq, st);
+            if (!(A.wdeq_ready && A.wdeq_of == (const void *) W.tiles)) qdequant(W, 0, a.N, a.K, A.wdeq, st);      // (a stale image of another matrix is never trusted)
             gemm(epi, g, st);
             return;
         }

@@ -314,7 +314,8 @@ struct QMat { const uint8_t * tiles = nullptr; int qtype = QT_NONE; };
 // deq (optional): the same rows as f16(d * q) [M][K] — the A operand of the f16 form of qgemm; wdeq / wdeq_elems: scratch image for one
 // dequantised weight matrix (or a group of cross K | V layers) [rows][K] f16
 // wdeq_ready: the image already holds the matrix the next qgemm multiplies with (written by quantize_rows' fused launch)
-struct Q8Rows { int8_t * qs; float * d; float * s; int ldm; __half * deq = nullptr; __half * wdeq = nullptr; size_t wdeq_elems = 0; bool wdeq_ready = false; };
+struct Q8Rows { int8_t * qs; float * d; float * s; int ldm; __half * deq = nullptr; __half * wdeq = nullptr; size_t wdeq_elems = 0; bool wdeq_ready = false;
+                const void * wdeq_of = nullptr; };     // wdeq_of: the matrix (QMat::tiles) whose f16 image wdeq holds when wdeq_ready — qgemm checks it
 // rows -> q8.  Exactly one source: x32 (+ optional LayerNorm gain/bias: y = LN(x) * g + b in f32, the reference quantises that
 // f32 tensor) or x16 (an f16 tensor, e.g. the GELU output, widened exactly).  out32 / out16: optional copy of the LN result.
 // W_next / N_next (optional): the [N_next][K] matrix of the projection these rows feed.  When that projection will take the f16 form
