@@ -284,7 +284,7 @@ def main():
             Lt = lib.whisper_model_n_text_layer(ctx)
             us_step = lib.wmi_bench_kernel(ctx, 20 + min(args.chunks, 16), 100)
             step_bytes = (DEC_MB_PER_TOKEN - 18.4) * 1e6 + min(args.chunks, 16) * 18.4e6      # weights once, cross K/V per chunk
-            out["roofline"] = {"kernel": "lock-step decode step (k_rows_mfma projections, per-row attention, filters): %d rows" % min(args.chunks, 16),
+            out["roofline"] = {"kernel": "lock-step decode step (one-row kernels with the row on grid.y for the layer projections, k_rows_mfma vocabulary projection, per-row attention, filters): %d rows" % min(args.chunks, 16),
                                "bound": "hbm", "achieved": round(step_bytes / (us_step * 1e-6) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
                                "frac": round(step_bytes / (us_step * 1e-6) / 1e9 / 8000.0, 4), "traffic": None, "algorithmic_bytes": int(step_bytes), "avg_us": round(us_step, 2),
                                "note": "the probe replays the step with its embedding launch; inside a call every step after a window's first is chained on the device (no embedding launch), see decode_ms_per_token"}
@@ -382,10 +382,17 @@ def main():
                 us_g8 = lib.wmi_bench_kernel(ctx, 4, 100); us_a8 = lib.wmi_bench_kernel(ctx, 5, 30)
                 if us_g8 > 0:
                     tf8 = 8 * flops / (us_g8 * 1e-6) / 1e12
-                    out["roofline_encoder_gemm_batch8"] = {"kernel": "k_gemm<128,128,EPI_F16_BIAS_GELU> encoder mlp.0 [12000x2048x512] f16 MFMA, global_load_lds staging",
+                    out["roofline_encoder_gemm_batch8"] = {"kernel": "k_gemm8<192,EPI_F16_BIAS_GELU> encoder mlp.0 [12000x2048x512] f16 MFMA: persistent 8-wave ping-pong, 192x256 tiles, LDS-DMA rings",
                                                            "bound": "mfma", "achieved": round(tf8, 2), "peak": 2500.0, "unit": "TFLOP/s",
-                                                           "frac": round(tf8 / 2500.0, 4), "traffic": pmc_traffic("k_gemm<128, 128, 1,* grid=385024"),
+                                                           "frac": round(tf8 / 2500.0, 4), "traffic": pmc_traffic("k_gemm8<192, 1,*"),
                                                            "avg_us": round(us_g8, 3)}
+                us_c8 = lib.wmi_bench_kernel(ctx, 9, 60)
+                if us_c8 > 0:
+                    fl_c8 = 2.0 * 8 * T * (2 * Lt * hp_S) * hp_S
+                    out["roofline_encoder_cross_kv_batch8"] = {"kernel": "k_gemm8<192,EPI_CROSS_KV> cross K/V of all decoder layers [12000x6144x512] f16 MFMA",
+                                                               "bound": "mfma", "achieved": round(fl_c8 / (us_c8 * 1e-6) / 1e12, 2), "peak": 2500.0, "unit": "TFLOP/s",
+                                                               "frac": round(fl_c8 / (us_c8 * 1e-6) / 1e12 / 2500.0, 4), "traffic": pmc_traffic("k_gemm8<192, 6,*"),
+                                                               "avg_us": round(us_c8, 3)}
                 if us_a8 > 0:
                     out["attn_layer_batch8_us"] = round(us_a8, 2)
                     out["attn_layer_batch8_tflops"] = round(8 * 2 * 2.0 * T * T * hp_S / (us_a8 * 1e-6) / 1e12, 1)      # one sweep: QK^T + P.V

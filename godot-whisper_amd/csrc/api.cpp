@@ -781,6 +781,15 @@ double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters) {
                 a.C = b.h; a.ldc = 4 * S;
                 k::gemm(k::EPI_F16_BIAS_GELU, a, s);
             } break;
+            case 9: {                                  // cross K / V of every decoder layer over the lock-step work buffers (M = chunks * T)
+                const BatchWork & b = *ctx->batch;
+                const int Lt = hp.n_text_layer, M = b.B * T;
+                k::GemmArgs a{};
+                a.A = b.enc_out_h; a.lda = S; a.W = w.w_ckv; a.ldw = S; a.M = M; a.N = Lt * 2 * S; a.K = S; a.bias = w.b_ckv;
+                a.C = b.kvc_k; a.ldc = S; a.aux = b.kvc_v; a.ldaux = S; a.S = S; a.layer_stride = (int64_t) M * S;
+                a.scale = powf((float) S / H, -0.25f);
+                k::gemm(k::EPI_CROSS_KV, a, s);
+            } break;
             case 5: {                                  // encoder attention of all lock-step chunks
                 const BatchWork & b = *ctx->batch;
                 k::attn_encoder(b.q, b.k, b.vt, T, b.Tpad, S, H, 0.125f, b.att, s, b.B);
@@ -788,7 +797,7 @@ double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters) {
             default: break;
         }
     };
-    if ((which == 4 || which == 5) && (!ctx->batch || ctx->batch->B < 1)) { (void) hipEventDestroy(e0); (void) hipEventDestroy(e1); return -1.0; }
+    if ((which == 4 || which == 5 || which == 9) && (!ctx->batch || ctx->batch->B < 1)) { (void) hipEventDestroy(e0); (void) hipEventDestroy(e1); return -1.0; }
     if (which >= 10 && which <= 12) {                                   // launch-floor probes: chains of trivial dependent kernels
         const int blocks = which == 10 ? 1 : which == 11 ? 32 : 256;
         int * p = (int *) d.mel_max;
