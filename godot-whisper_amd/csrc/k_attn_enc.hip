@@ -43,7 +43,7 @@ __device__ __forceinline__ float max3(float a, float b, float c) { float d; asm(
 //                   cross-attention already makes: e is rounded to f16 relative to the maximum SO FAR);
 //            false: two sweeps, exact row maximum first (the reference's soft-max argument bit for bit).
 //   KS       key groups per workgroup (own tiles, common barriers); partial (m, sum, O^T) combined through LDS at the end.
-template <int QW, int KS, bool ONE, int NST>
+template <int QW, int KS, bool ONE, int NST, bool WIDE_OUT = true>
 __global__ __launch_bounds__(QW * KS * 64) void k_attn_enc2(const __half * __restrict__ q, const __half * __restrict__ k,
                                                             const __half * __restrict__ vt, int T, int Tpad, int S,
                                                             __half * __restrict__ out, float * __restrict__ out32) {
@@ -52,6 +52,10 @@ __global__ __launch_bounds__(QW * KS * 64) void k_attn_enc2(const __half * __res
     typedef float float2v __attribute__((ext_vector_type(2)));
     typedef _Float16 half2v __attribute__((ext_vector_type(2)));
     constexpr int STAGE = 16384;                                   // K tile 8 KB + V^T tile 8 KB
+    // the output images of the query wavefronts sit behind everything else the kernel keeps in LDS (ring, maxima, combine area)
+    constexpr size_t RING_B = (size_t) KS * NST * STAGE, EXTRA_B = (!ONE && KS > 1) ? (size_t) KS * QW * 32 * 4 : 0;
+    constexpr size_t COMB_B = KS > 1 ? (size_t) (KS - 1) * QW * 64 * 34 * 4 : 0;
+    constexpr size_t TB_OFF = (RING_B + EXTRA_B) > COMB_B ? (RING_B + EXTRA_B) : COMB_B;
     constexpr float LOG2E = 1.44269504088896340736f;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: scalar branches
     const int grp = KS == 1 ? 0 : wave / QW, qw = wave - grp * QW;
@@ -282,6 +286,33 @@ __global__ __launch_bounds__(QW * KS * 64) void k_attn_enc2(const __half * __res
 
     // O^T: lane = query row q0 + i, value columns 32 mt + 8 j + 4 g + r
     const int qg = q0 + i;
+    if constexpr (WIDE_OUT) {
+        if (!out32) {
+            // f16 output through a wavefront-private 4 KB LDS image (32 rows x 128 B, 16-byte chunks XOR-swizzled by the row): as 8-byte
+            // stores a wave instruction covered 32 rows x 16 B = 32 partial-line requests and the eight of them per wavefront were
+            // request-bound like the GEMM epilogues' (gemm_epi.h); read back 16 B per lane an instruction covers 8 rows x 128 B.
+            // Wavefront-private: no barrier, only the wave's own lgkmcnt wait.  The stored values are the plain form's.
+            unsigned char * tb = smem + TB_OFF + qw * 4096;
+            const float inv = (float) (1.0 / (double) l);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    half4 w;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) w[r] = (_Float16) pin_f32(o[mt][4 * j + r] * inv);
+                    *(half4 *) (tb + i * 128 + (((4 * mt + j) ^ (i & 7)) << 4) + g * 8) = w;
+                }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int row = p * 8 + (lane >> 3), ch = lane & 7;
+                const uint4 v = *(const uint4 *) (tb + row * 128 + ((ch ^ (row & 7)) << 4));
+                if (q0 + row < T) *(uint4 *) (out + (size_t) (q0 + row) * S + head * 64 + ch * 8) = v;
+            }
+            return;
+        }
+    }
     if (qg < T) {
         const float inv = (float) (1.0 / (double) l);
 #pragma unroll
@@ -311,10 +342,20 @@ void launch_attn_enc2(const __half * q, const __half * k, const __half * vt, int
     constexpr size_t ring = (size_t) KS * NST * 16384;
     constexpr size_t extra = (!ONE && KS > 1) ? (size_t) KS * QW * 32 * 4 : 0;
     constexpr size_t comb = KS > 1 ? (size_t) (KS - 1) * QW * 64 * 34 * 4 : 0;
-    constexpr size_t smem = (ring + extra) > comb ? (ring + extra) : comb;
+    constexpr size_t smem0 = (ring + extra) > comb ? (ring + extra) : comb;
+    static const bool narrow = getenv("WMI_ATTN_NARROW_STORES") != nullptr;       // A/B knob: 8-byte output stores
+    if (narrow) {
+        static_assert(smem0 <= 160 * 1024, "LDS");
+        if (smem0 > 48 * 1024) allow_full_lds((const void *) k_attn_enc2<QW, KS, ONE, NST, false>, lds_ok);
+        hipLaunchKernelGGL((k_attn_enc2<QW, KS, ONE, NST, false>), dim3((T + QW * 32 - 1) / (QW * 32), H, B), dim3(QW * KS * 64), smem0, st,
+                           q, k, vt, T, Tpad, S, out, out32);
+        return;
+    }
+    constexpr size_t smem = smem0 + (size_t) QW * 4096;                          // + the query wavefronts' output images
     static_assert(smem <= 160 * 1024, "LDS");
-    if (smem > 48 * 1024) allow_full_lds((const void *) k_attn_enc2<QW, KS, ONE, NST>, lds_ok);
-    hipLaunchKernelGGL((k_attn_enc2<QW, KS, ONE, NST>), dim3((T + QW * 32 - 1) / (QW * 32), H, B), dim3(QW * KS * 64), smem, st,
+    static std::atomic<uint64_t> lds_ok_w{0};
+    if (smem > 48 * 1024) allow_full_lds((const void *) k_attn_enc2<QW, KS, ONE, NST, true>, lds_ok_w);
+    hipLaunchKernelGGL((k_attn_enc2<QW, KS, ONE, NST, true>), dim3((T + QW * 32 - 1) / (QW * 32), H, B), dim3(QW * KS * 64), smem, st,
                        q, k, vt, T, Tpad, S, out, out32);
 }
 
