@@ -46,7 +46,7 @@ __device__ __forceinline__ float max3(float a, float b, float c) { float d; asm(
 template <int QW, int KS, bool ONE, int NST, bool WIDE_OUT = true>
 __global__ __launch_bounds__(QW * KS * 64) void k_attn_enc2(const __half * __restrict__ q, const __half * __restrict__ k,
                                                             const __half * __restrict__ vt, int T, int Tpad, int S,
-                                                            __half * __restrict__ out, float * __restrict__ out32) {
+                                                            __half * __restrict__ out, float * __restrict__ out32, int xcd_order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef float floatx16 __attribute__((ext_vector_type(16)));
     typedef float float2v __attribute__((ext_vector_type(2)));
@@ -60,10 +60,20 @@ __global__ __launch_bounds__(QW * KS * 64) void k_attn_enc2(const __half * __res
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: scalar branches
     const int grp = KS == 1 ? 0 : wave / QW, qw = wave - grp * QW;
     const int i = lane & 31, g = lane >> 5;
-    const int head = blockIdx.y;
-    const int q0 = blockIdx.x * (QW * 32) + qw * 32;
+    // XCD-aware order: workgroup ids go round-robin over the 8 XCDs, so the query blocks of one (chunk, head) — which stream the same
+    // K / V^T — would sit on eight different L2s and fetch them eight times (PMC: 213 MB per launch at 8 chunks for 37 MB of operands).
+    // The launch id is mapped so that every XCD owns a contiguous run of (chunk, head, query block) triples.
+    int bx = blockIdx.x, head = blockIdx.y, bz = blockIdx.z;
+    if (xcd_order) {
+        const int nwg = gridDim.x * gridDim.y * gridDim.z;
+        int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+        const int q8 = nwg / 8, r8 = nwg % 8, xcd = wg % 8, idx = wg / 8;
+        wg = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + idx;
+        bx = wg % gridDim.x; wg /= gridDim.x; head = wg % gridDim.y; bz = wg / gridDim.y;
+    }
+    const int q0 = bx * (QW * 32) + qw * 32;
     {
-        const size_t zb = blockIdx.z;
+        const size_t zb = bz;
         q += zb * (size_t) T * S; k += zb * (size_t) T * S; vt += zb * (size_t) S * Tpad;
         if (out32) out32 += zb * (size_t) T * S; else out += zb * (size_t) T * S;
     }
@@ -344,11 +354,15 @@ void launch_attn_enc2(const __half * q, const __half * k, const __half * vt, int
     constexpr size_t comb = KS > 1 ? (size_t) (KS - 1) * QW * 64 * 34 * 4 : 0;
     constexpr size_t smem0 = (ring + extra) > comb ? (ring + extra) : comb;
     static const bool narrow = getenv("WMI_ATTN_NARROW_STORES") != nullptr;       // A/B knob: 8-byte output stores
+    // A/B knob: 0 = launch order, 1 = XCD runs.  Default: XCD runs for several chunks (operand fetches 213 -> ~40 MB per launch at 8 chunks;
+    // time unchanged within the noise: the Infinity Cache was serving the re-fetches), launch order for one chunk (14.3 against 15.0 us)
+    static const int xcd_env = getenv("WMI_ATTN_XCD") ? atoi(getenv("WMI_ATTN_XCD")) : -1;
+    const int xcd_order = xcd_env >= 0 ? xcd_env : (B > 1);
     if (narrow) {
         static_assert(smem0 <= 160 * 1024, "LDS");
         if (smem0 > 48 * 1024) allow_full_lds((const void *) k_attn_enc2<QW, KS, ONE, NST, false>, lds_ok);
         hipLaunchKernelGGL((k_attn_enc2<QW, KS, ONE, NST, false>), dim3((T + QW * 32 - 1) / (QW * 32), H, B), dim3(QW * KS * 64), smem0, st,
-                           q, k, vt, T, Tpad, S, out, out32);
+                           q, k, vt, T, Tpad, S, out, out32, xcd_order);
         return;
     }
     constexpr size_t smem = smem0 + (size_t) QW * 4096;                          // + the query wavefronts' output images
@@ -356,7 +370,7 @@ void launch_attn_enc2(const __half * q, const __half * k, const __half * vt, int
     static std::atomic<uint64_t> lds_ok_w{0};
     if (smem > 48 * 1024) allow_full_lds((const void *) k_attn_enc2<QW, KS, ONE, NST, true>, lds_ok_w);
     hipLaunchKernelGGL((k_attn_enc2<QW, KS, ONE, NST, true>), dim3((T + QW * 32 - 1) / (QW * 32), H, B), dim3(QW * KS * 64), smem, st,
-                       q, k, vt, T, Tpad, S, out, out32);
+                       q, k, vt, T, Tpad, S, out, out32, xcd_order);
 }
 
 }  // namespace
