@@ -473,6 +473,7 @@ def config4(lib, cpu: bool = True, rank: int = 0, world: int = 1, dist=None, loc
            "model_file_mb": round(file_mb, 1), "weights_in_hbm_mb": round(arena / 1e6, 1), "model_synthesis_s": round(t_model, 1),
            "weight_bcast_ms": round(1e3 * t_bcast, 3)}
     q = node.full_params("", 0)
+    ps = {}
     for name, strat, bs in (("beam5", abi.WHISPER_SAMPLING_BEAM_SEARCH, 5), ("greedy", abi.WHISPER_SAMPLING_GREEDY, 1)):
         p = lib.whisper_full_default_params(strat)
         for f in ("language", "audio_ctx", "split_on_word", "token_timestamps", "suppress_non_speech_tokens", "single_segment",
@@ -480,6 +481,7 @@ def config4(lib, cpu: bool = True, rank: int = 0, world: int = 1, dist=None, loc
             setattr(p, f, getattr(q, f))
         if strat == abi.WHISPER_SAMPLING_BEAM_SEARCH:
             p.beam_search.beam_size = bs
+        ps[name] = p
         node.transcribe(pcm, params=p); node.transcribe(pcm, params=p)
         lib.whisper_reset_timings(ctx)
         if world > 1:
@@ -514,6 +516,18 @@ def config4(lib, cpu: bool = True, rank: int = 0, world: int = 1, dist=None, loc
                                    "encode_ms": round(t4[1] / 1e3, 2), "decode_ms": round(t4[2] / 1e3, 2), "decode_steps": int(ns.value),
                                    "chunks_run_alone": int(sum(node.last_modes)),
                                    "encoder_tflops_equivalent": round(nb8 * 2588.3 / (t4[1] / 1e3), 1)}
+        # the same 8 chunks with beam search: not lock-step — whisper_full per chunk on 1 + 3 replica contexts of this GPU (own state
+        # and stream, shared weight arena: include/wmi_device.h wmi_set_batch_replicas), against one chunk at a time
+        pb = ps["beam5"]; pb.temperature_inc = 0.0
+        for label, n_rep in (("beam5_8chunks_one_at_a_time", 0), ("beam5_8chunks_replicas", -1)):
+            lib.wmi_set_batch_replicas(ctx, n_rep)
+            node.transcribe_batch(pcms, params=pb)
+            t1 = time.perf_counter(); repsb = 2
+            for _ in range(repsb):
+                node.transcribe_batch(pcms, params=pb)
+            dtb = (time.perf_counter() - t1) / repsb
+            res[label] = {"value": round(nb8 * CHUNK_S / dtb, 1), "unit": "x realtime", "ms_per_call": round(dtb * 1e3, 2),
+                          "ms_per_chunk": round(dtb * 1e3 / nb8, 2), "contexts": 1 if n_rep == 0 else 4}
         node.transcribe(pcm, params=q)                      # back to the one-chunk state for the probes below
     except Exception as e:  # pragma: no cover
         res["lockstep8_error"] = repr(e)

@@ -554,6 +554,17 @@ int wmi_batch_chunk_mode(struct whisper_context * ctx, int chunk) {
     return ctx->batch->redo[chunk];
 }
 
+int wmi_set_batch_replicas(struct whisper_context * ctx, int n) {
+    if (!ctx) return -1;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    try {
+        if (!ctx->batch) ctx->batch = new BatchWork();
+    } catch (const std::exception &) { return -1; }
+    const int prev = ctx->batch->replicas_wanted;
+    ctx->batch->replicas_wanted = n < 0 ? -1 : (n > 15 ? 15 : n);
+    return prev;
+}
+
 void * wmi_stream(struct whisper_context * ctx) { return (void *) ctx->state->dev.stream; }
 
 int wmi_process_logits(struct whisper_context * ctx, struct whisper_full_params params, const float * raw_logits,

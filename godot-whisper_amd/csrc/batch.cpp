@@ -459,6 +459,31 @@ double bench_rows_step_chain(whisper_context & ctx, int nb, int iters) {
     return (double) ms * 1000.0 / iters;
 }
 
+// A replica context: the model directory and the device view of the weights copied, the arena itself borrowed (read-only for every
+// kernel), a state of its own (caches, activations, stream, graphs).  The reference's precedent is whisper_full_parallel's one
+// whisper_state per worker over one shared model (W/whisper.cpp:5837-5858).
+static whisper_context * new_replica(whisper_context & ctx) {
+    whisper_context * r = nullptr;
+    try {
+        r = new whisper_context();
+        r->params = ctx.params; r->model = ctx.model; r->device = ctx.device;
+        r->w = ctx.w; r->w.arena_borrowed = true;
+        if (!init_state(*r)) { free_state(*r); delete r; return nullptr; }
+    } catch (const std::exception & e) {
+        WMI_ERR("%s: %s\n", __func__, e.what());
+        if (r) { free_state(*r); delete r; }
+        return nullptr;
+    }
+    return r;
+}
+static void free_replica(whisper_context * r) {
+    if (!r) return;
+    free_batch(*r);
+    free_state(*r);
+    free_weights(r->w);                                        // borrowed: forgets the pointer
+    delete r;
+}
+
 void free_batch(whisper_context & ctx) {
     if (!ctx.batch) return;
     BatchWork & w = *ctx.batch;
@@ -476,6 +501,7 @@ void free_batch(whisper_context & ctx) {
     if (w.step_host) (void) hipHostFree(w.step_host);
     if (w.sample_host) (void) hipHostFree(w.sample_host);
     for (size_t i = 1; i < w.lanes.size(); ++i) free_lane_state(w.lanes[i]);
+    for (whisper_context * r : w.replicas) free_replica(r);
     delete ctx.batch;
     ctx.batch = nullptr;
 }
@@ -511,7 +537,58 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
                           !params.progress_callback && !params.encoder_begin_callback && !params.abort_callback &&
                           ctx.model.n_loaded > 0 && n_chunks > 1;
     if (!lockstep) {
-        for (int c = 0; c < n_chunks; ++c) { const int rc = run_alone(c); if (rc != 0) return rc; ctx.batch->redo[c] = 1; }
+        // Chunks the lock-step rows cannot carry (beam search, t > 0, callbacks ...): the general driver, chunk by chunk — and, where
+        // nothing observable depends on the order, on several REPLICA contexts at once: worker w takes the chunks c = w (mod workers),
+        // each on its own state and stream, so the short launches of one chunk's decode steps (40-160 workgroups on 256 CUs) run
+        // beside another chunk's.  Every chunk is still one whisper_full on a fresh state: results are identical to the sequential
+        // loop by construction.  Measured (scratch/pool_beam.py): beam 5, 8 chunks, base.en 9.8 -> 5.1 ms per chunk, large-v3 q5_1
+        // 47.1 -> 27.3 ms per chunk with four contexts.  Not with user callbacks (they would run concurrently, on contexts the
+        // caller never saw) or the print options.
+        static const int rep_env = getenv("WMI_BATCH_REPLICAS") ? atoi(getenv("WMI_BATCH_REPLICAS")) : 3;
+        const int rep_want = ctx.batch->replicas_wanted >= 0 ? ctx.batch->replicas_wanted : rep_env;
+        const bool observers = params.logits_filter_callback || params.new_segment_callback || params.progress_callback ||
+                               params.encoder_begin_callback || params.abort_callback || params.print_realtime || params.print_progress;
+        int n_rep = (!force_seq && !observers && ctx.model.n_loaded > 0) ? std::min(rep_want, n_chunks - 1) : 0;
+        if (n_rep < 0) n_rep = 0;
+        while ((int) ctx.batch->replicas.size() < n_rep) {
+            whisper_context * r = new_replica(ctx);
+            if (!r) { n_rep = (int) ctx.batch->replicas.size(); break; }         // out of memory: fewer workers
+            ctx.batch->replicas.push_back(r);
+        }
+        if (n_rep == 0) {
+            for (int c = 0; c < n_chunks; ++c) { const int rc = run_alone(c); if (rc != 0) return rc; ctx.batch->redo[c] = 1; }
+            return 0;
+        }
+        const int workers = n_rep + 1;
+        std::vector<int> rets(workers, 0);
+        auto work = [&](int w) {
+            try {
+                whisper_context & wc = w == 0 ? ctx : *ctx.batch->replicas[w - 1];
+                (void) hipSetDevice(ctx.device);
+                for (int c = w; c < n_chunks; c += workers) {
+                    int rc;
+                    if (w == 0) rc = run_alone(c);
+                    else {
+                        for (auto & dec : wc.state->decoders) dec.rng = std::mt19937(0);
+                        rc = full(wc, params, on_device ? nullptr : pcm[c], on_device ? pcm[c] : nullptr, n_samples[c]);
+                        if (rc == 0) ctx.batch->results[c] = std::move(wc.state->result_all);
+                        wc.state->result_all.clear();
+                    }
+                    if (rc != 0) { rets[w] = rc; return; }
+                    ctx.batch->redo[c] = 1;
+                }
+            } catch (const std::exception & e) {
+                WMI_ERR("wmi_full_batch: worker %d: %s\n", w, e.what());
+                rets[w] = -9;
+            } catch (...) { rets[w] = -9; }
+        };
+        {
+            std::vector<std::thread> th;
+            struct Joiner { std::vector<std::thread> & t; ~Joiner() { for (auto & x : t) if (x.joinable()) x.join(); } } joiner{th};
+            for (int w = 1; w < workers; ++w) th.emplace_back(work, w);
+            work(0);
+        }
+        for (int w = 0; w < workers; ++w) if (rets[w] != 0) return rets[w];
         return 0;
     }
     if (params.audio_ctx > hp.n_audio_ctx) {

@@ -572,8 +572,8 @@ bool upload_weights(const ModelFile & mf, const uint8_t * host_buf, Weights & w,
 }
 
 void free_weights(Weights & w) {
-    if (w.arena) (void) hipFree(w.arena);
-    w.arena = nullptr; w.arena_bytes = 0;
+    if (w.arena && !w.arena_borrowed) (void) hipFree(w.arena);
+    w.arena = nullptr; w.arena_bytes = 0; w.arena_borrowed = false;
 }
 
 } // namespace wmi

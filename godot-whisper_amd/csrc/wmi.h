@@ -103,6 +103,7 @@ struct DecLayerW {
 };
 struct Weights {
     void *  arena = nullptr;  size_t arena_bytes = 0;
+    bool    arena_borrowed = false;     // a replica context of wmi_full_batch: the arena belongs to the context it was made from
     // conv front-end, weights re-laid as [oc][k][ic] (+ zero pad to a multiple of 32) for the
     // overlapped-row implicit GEMM
     const __half *conv1_w; const float *conv1_b; int conv1_k = 0;     // K (padded)
@@ -290,6 +291,9 @@ struct BatchWork {
     std::vector<State *> lanes;                               // lanes[0] is the context's own state (not owned)
     std::vector<std::vector<Segment>> results;                // per chunk of the last wmi_full_batch call
     std::vector<int> redo;                                    // per chunk: 1 if it was re-run alone (temperature fallback)
+    // chunks that cannot advance in lock-step (beam search, t > 0, quantised beams ...) run through the general driver on replica
+    // contexts: own state and stream, the weight arena borrowed from this context — see full_batch
+    std::vector<whisper_context *> replicas; int replicas_wanted = -1;      // -1: default (WMI_BATCH_REPLICAS, 3)
     int64_t t_mel_us = 0, t_encode_us = 0, t_decode_us = 0, t_emit_us = 0; int n_steps = 0, n_chained = 0;
 };
 

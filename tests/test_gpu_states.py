@@ -292,3 +292,50 @@ def test_in_process_device_pool_equals_one_context(product_lib):
         assert product_lib.wmi_pool_device_time_us(pool, 0) > 0
     finally:
         one.close(); product_lib.wmi_pool_free(pool)
+
+
+@pytest.mark.parametrize("kind", ["beam5", "best_of_t04", "q5_1_beam3"])
+def test_full_batch_runs_unlockable_chunks_on_replica_contexts(product_lib, kind):
+    """wmi_full_batch with a strategy the lock-step rows cannot carry (beam search, t > 0): the chunks go through the whisper_full
+    driver on replica contexts (own state and stream, the weight arena shared) — the worker threads of whisper_full_parallel
+    (W/whisper.cpp:5837-5913).  Every chunk must come back exactly as whisper_full returns it on a fresh context, whatever the
+    number of replicas (0 = one at a time, 1, default 3), in every field."""
+    model = synth.make_model("micro.en", seed=1234)
+    if kind == "q5_1_beam3":
+        model = synth.quantize_model(model, "q5_1")
+    pcms = [synth.make_pcm(6.0 + 1.5 * i, seed=2100 + i) for i in range(7)]
+
+    def params(lib):
+        if kind == "best_of_t04":
+            p = lib.whisper_full_default_params(abi.WHISPER_SAMPLING_GREEDY)
+            p.temperature = 0.4; p.greedy.best_of = 4
+        else:
+            p = lib.whisper_full_default_params(abi.WHISPER_SAMPLING_BEAM_SEARCH)
+            p.beam_search.beam_size = 5 if kind == "beam5" else 3
+        p.language = b"en"; p.temperature_inc = 0.0; p.print_progress = False; p.token_timestamps = True; p.max_tokens = 24
+        return p
+
+    want = []
+    for pcm in pcms:                                               # whisper_full on a fresh context per chunk
+        one = host.SpeechToText(product_lib); one.set_language_model(model)
+        assert product_lib.whisper_full(one.ctx, params(product_lib), _fp(pcm), pcm.size) == 0
+        want.append(_ctx_segments(product_lib, one.ctx))
+        one.close()
+    assert sum(len(s[3]) for w in want for s in w) >= 20 and len({tuple(t[0] for s in w for t in s[3]) for w in want}) >= 4
+    node = host.SpeechToText(product_lib); node.set_language_model(model)
+    try:
+        ptrs = (C.c_void_p * len(pcms))(*[b.ctypes.data for b in pcms]); lens = (C.c_int * len(pcms))(*[b.size for b in pcms])
+        assert product_lib.wmi_set_batch_replicas(node.ctx, 0) == -1
+        for n_rep in (0, 1, -1):
+            product_lib.wmi_set_batch_replicas(node.ctx, n_rep)
+            assert product_lib.wmi_full_batch(node.ctx, params(product_lib), ptrs, lens, len(pcms), 0) == 0
+            for c in range(len(pcms)):
+                assert product_lib.wmi_batch_chunk_mode(node.ctx, c) == 1
+                assert product_lib.wmi_batch_select(node.ctx, c) == len(want[c])
+                assert _ctx_segments(product_lib, node.ctx) == want[c], (kind, n_rep, c)
+        # a lock-step call on the same context afterwards still works (replicas stay parked)
+        g = _params(product_lib)
+        assert product_lib.wmi_full_batch(node.ctx, g, ptrs, lens, len(pcms), 0) == 0
+        assert product_lib.wmi_batch_chunk_mode(node.ctx, 0) == 0
+    finally:
+        node.close()
