@@ -543,11 +543,11 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
         // beside another chunk's.  Every chunk is still one whisper_full on a fresh state: results are identical to the sequential
         // loop by construction.  Measured (scratch/pool_beam.py): beam 5, 8 chunks, base.en 9.8 -> 5.1 ms per chunk, large-v3 q5_1
         // 47.1 -> 27.3 ms per chunk with four contexts.  Not with user callbacks (they would run concurrently, on contexts the
-        // caller never saw) or the print options.
+        // caller never saw) or print_realtime (its stdout text would interleave).
         static const int rep_env = getenv("WMI_BATCH_REPLICAS") ? atoi(getenv("WMI_BATCH_REPLICAS")) : 3;
         const int rep_want = ctx.batch->replicas_wanted >= 0 ? ctx.batch->replicas_wanted : rep_env;
         const bool observers = params.logits_filter_callback || params.new_segment_callback || params.progress_callback ||
-                               params.encoder_begin_callback || params.abort_callback || params.print_realtime || params.print_progress;
+                               params.encoder_begin_callback || params.abort_callback || params.print_realtime;      // (print_progress only writes percent lines to stderr)
         int n_rep = (!force_seq && !observers && ctx.model.n_loaded > 0) ? std::min(rep_want, n_chunks - 1) : 0;
         if (n_rep < 0) n_rep = 0;
         while ((int) ctx.batch->replicas.size() < n_rep) {

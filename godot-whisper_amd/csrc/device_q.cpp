@@ -32,6 +32,14 @@ bool rows_fit(int n, int K) {
     return smem <= 150 * 1024;
 }
 
+// mlp.2 of the decoder with K split over two workgroups per row group (kernels.h GemvArgs::ksplit; WMI_Q_KSPLIT=0: off, A/B)
+bool fc2_ksplit(k::GemvArgs & g, float * kpart) {
+    static const bool off = getenv("WMI_Q_KSPLIT") && atoi(getenv("WMI_Q_KSPLIT")) == 0;
+    if (off || !kpart || !k::qrows_ksplit_ok(g, 2)) return false;
+    g.ksplit = 2; g.kpart = kpart;
+    return true;
+}
+
 } // namespace
 
 bool encode_layers_q(whisper_context & ctx, int T) {
@@ -116,14 +124,20 @@ bool decode_layers_q(whisper_context & ctx, int n, int n_kv, int kv_head, int Tc
         }
         pfW = nullptr;
     };
+    // pend: the upper-K-half sums of the last mlp.2 that the residual stream d.dx still lacks (GemvArgs::ksplit): taken by the launches
+    // that read d.dx until the next out projection has written the row whole again
+    const float * pend = nullptr;
     auto proj = [&](int epi, const Src & src, int K, int N, const k::QMat & W, const float * bias, void * C, int ldc,
-                    const float * resid, void * aux, int ldaux, void * aux2, int ldaux2, float scale) {
+                    const float * resid, void * aux, int ldaux, void * aux2, int ldaux2, float scale, bool is_fc2 = false) {
         if (rows_fit(n, K)) {
             k::GemvArgs g{};
             set_pf(g);
             g.x32 = src.x32; g.ln_g = src.ln_g; g.ln_b = src.ln_b; g.eps = hp.eps; g.a16 = src.x16; g.n = n; g.K = K; g.N = N;
             g.bias = bias; g.epi = epi; g.C = C; g.ldc = ldc; g.resid = resid; g.ldr = S; g.aux = aux; g.ldaux = ldaux;
             g.aux2 = aux2; g.ldaux2 = ldaux2; g.scale = scale; g.S = S;
+            if (pend && (src.ln_g || resid)) g.pend = pend;
+            if (resid) pend = nullptr;
+            if (is_fc2 && fc2_ksplit(g, d.xattn)) pend = d.xattn;
             k::qrows(g, src.ln_g ? nullptr : src.x32, W, s);
         } else {
             const k::Q8Rows A = q8_rows(d, K);
@@ -165,7 +179,7 @@ bool decode_layers_q(whisper_context & ctx, int n, int n_kv, int kv_head, int Tc
         proj(k::EPI_F16_BIAS_GELU, ln3, S, 4 * S, l.q_fc1, l.b_fc1, d.dh, 4 * S, nullptr, nullptr, 0, nullptr, 0, 0.f);
         Src hh; hh.x16 = d.dh;
         if (il + 1 < Lt) next(w.dec[il + 1].q_qkv, 3 * S, S);
-        proj(k::EPI_F32_BIAS_RESID, hh, 4 * S, S, l.q_fc2, l.b_fc2, d.dx, S, d.dx, nullptr, 0, nullptr, 0, 0.f);
+        proj(k::EPI_F32_BIAS_RESID, hh, 4 * S, S, l.q_fc2, l.b_fc2, d.dx, S, d.dx, nullptr, 0, nullptr, 0, 0.f, true);
     }
 
     // final LN + logits for the flagged rows
@@ -174,7 +188,7 @@ bool decode_layers_q(whisper_context & ctx, int n, int n_kv, int kv_head, int Tc
         const int nr = (int) std::min<size_t>(8, rows.size() - r0);
         k::GemvArgs g{};
         g.x32 = d.dx; g.ln_g = w.d_ln_g; g.ln_b = w.d_ln_b; g.eps = hp.eps; g.n = nr; g.K = S; g.N = NV;
-        g.epi = k::EPI_LOGITS; g.C = d.logits; g.ldc = NV; g.rows = d.d_rows + r0;
+        g.epi = k::EPI_LOGITS; g.C = d.logits; g.ldc = NV; g.rows = d.d_rows + r0; g.pend = pend;
         k::qrows(g, nullptr, w.q_te, s);
         if (d.keep_logits_on_device && rows.size() <= 8) continue;
         HIP_TRY(hipMemcpyAsync(d.pinned, d.logits, (size_t) nr * NV * 4, hipMemcpyDeviceToHost, s));
@@ -201,6 +215,7 @@ void enqueue_greedy_step_q(whisper_context & ctx, int Tc) {
     static const bool no_pf = getenv("WMI_NO_PREFETCH") != nullptr;            // A/B knob
     const k::QMat * pfW = nullptr; int pfN = 0, pfK = 0;
     auto next = [&](const k::QMat & W, int N, int K) { pfW = no_pf ? nullptr : &W; pfN = N; pfK = K; };
+    const float * pend = nullptr;                             // see decode_layers_q
     auto rows = [&](int epi, const Src & src, int K, int N, const k::QMat & W, const float * bias, void * C, int ldc, const float * resid,
                     void * aux, void * aux2, float scale, const int32_t * row_off, const float * co = nullptr, const float * cl = nullptr, int cns = 0, const float * cm = nullptr) {
         k::GemvArgs g{};
@@ -211,6 +226,9 @@ void enqueue_greedy_step_q(whisper_context & ctx, int Tc) {
         g.x32 = src.x32; g.ln_g = src.ln_g; g.ln_b = src.ln_b; g.eps = hp.eps; g.a16 = src.x16; g.n = 1; g.K = K; g.N = N;
         g.bias = bias; g.epi = epi; g.C = C; g.ldc = ldc; g.resid = resid; g.ldr = S; g.aux = aux; g.ldaux = S; g.aux2 = aux2; g.ldaux2 = S;
         g.scale = scale; g.S = S; g.row_off = row_off; g.comb_o = co; g.comb_l = cl; g.comb_ns = cns; g.comb_m = cm;
+        if (pend && (src.ln_g || (resid && !co))) g.pend = pend;
+        if (resid && !co && !src.x16) pend = nullptr;                        // the self-attention's out projection writes the row whole again
+        if (src.x16 && epi == k::EPI_F32_BIAS_RESID && fc2_ksplit(g, d.xattn)) pend = d.xattn;      // mlp.2
         k::qrows(g, src.ln_g ? nullptr : src.x32, W, s);
     };
     for (int il = 0; il < Lt; ++il) {
@@ -258,6 +276,7 @@ void enqueue_rows_step_q(whisper_context & ctx, int nb) {
     static const bool no_pf = getenv("WMI_NO_PREFETCH") != nullptr;            // A/B knob
     const k::QMat * pfW = nullptr; int pfN = 0, pfK = 0;                       // the next weight-streaming launch's matrix (k_qrows prefetch)
     auto next = [&](const k::QMat & W, int N, int K) { pfW = no_pf ? nullptr : &W; pfN = N; pfK = K; };
+    const float * pend = nullptr;                             // see decode_layers_q
     auto rows = [&](int epi, const Src & src, int K, int N, const k::QMat & W, const float * bias, void * C, int ldc, const float * resid,
                     void * aux, void * aux2, float scale, const int32_t * row_off) {
         k::GemvArgs g{};
@@ -268,6 +287,9 @@ void enqueue_rows_step_q(whisper_context & ctx, int nb) {
         g.x32 = src.x32; g.ln_g = src.ln_g; g.ln_b = src.ln_b; g.eps = hp.eps; g.a16 = src.x16; g.n = nb; g.K = K; g.N = N;
         g.bias = bias; g.epi = epi; g.C = C; g.ldc = ldc; g.resid = resid; g.ldr = S; g.aux = aux; g.ldaux = S; g.aux2 = aux2; g.ldaux2 = S;
         g.scale = scale; g.S = S; g.row_off = row_off; g.lanes = 1; g.step_stride = step_stride; g.cache_row_stride = cache_stride;
+        if (pend && (src.ln_g || resid)) g.pend = pend;       // (the cross-attention's out projection runs behind the self-attention's: pend is null by then)
+        if (resid && !src.x16) pend = nullptr;
+        if (src.x16 && epi == k::EPI_F32_BIAS_RESID && fc2_ksplit(g, b.xattn)) pend = b.xattn;      // mlp.2; the cross-attention scratch is idle until the next layer's cross-attention
         return g;
     };
     for (int il = 0; il < Lt; ++il) {

@@ -589,13 +589,13 @@ void qgemm_epi(int epi, const GemmArgs & a, Q8Rows A, const uint8_t * Wt, hipStr
 // (GemvArgs::comb_*: o / l per head, f32 — what attn_cross_combine writes with out32).
 constexpr int PF_WG = 64;                                   // prefetch workgroups appended to a k_qrows grid (multiple of 8: XCD affinity)
 
-template <int QT, int NR4, int SRC, int NW>
+template <int QT, int NR4, int SRC, int NW, int CHX = 0>
 // (8 wavefronts, <= 8 rows: held to 128 VGPRs = two workgroups per CU — the vocabulary projection's grid is sized for that)
 __global__ __launch_bounds__(NW * 64, (NW == 8 && NR4 == 1) ? 4 : 1) void k_qrows(const GemvArgs a, const float * __restrict__ a32, const uint8_t * __restrict__ Wt) {
     constexpr int QW = Geo<QT>::QW, HW = Geo<QT>::HW;
     constexpr bool HAS_M = Geo<QT>::M, F16D = Geo<QT>::F16D;
     constexpr int R8 = NR4 * 8;                             // row slots
-    constexpr int CH = NW == 16 ? 5 : NW == 8 ? 3 : 5;      // weight tiles in flight per wavefront (K = 5120 / 1280: everything at once)
+    constexpr int CH = CHX ? CHX : NW == 16 ? 5 : NW == 8 ? 3 : 5;      // weight tiles in flight per wavefront (K = 5120 / 1280: everything at once; CHX: a K part of 40 tiles on 16 wavefronts)
     constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const unsigned long long ts0 = stamp_t0(a.stamps);     // probe (wmi_step_stamps): entry, activation rows quantised, tiles multiplied, end
@@ -617,6 +617,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && NR4 == 1) ? 4 : 1) void k_qrow
     // (Issued from the streaming workgroups themselves the requests sat in front of the prologue's loads in the in-order
     // vmcnt queue: +1 us per launch instead of -1.)
     const int nmain = a.pf_ptr ? (int) gridDim.x - PF_WG : (int) gridDim.x;
+    // K split over workgroups (GemvArgs::ksplit): workgroup = (row group, K part); tiles [tp0, tp0 + npq) of every row group
+    const int ks = a.ksplit > 1 ? a.ksplit : 1, kq = ks > 1 ? (int) blockIdx.x % ks : 0;
+    const int npq = np / ks, tp0 = kq * npq, rstride = nmain / ks;
     if ((int) blockIdx.x >= nmain) {
         // every line of this workgroup's share is requested before the first one is waited for: as `acc ^= load` in a loop hipcc waited
         // vmcnt(0) per iteration (ISA dump), i.e. one HBM round trip per line and thread — the five groups per workgroup of an N = 4 S
@@ -631,7 +634,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && NR4 == 1) ? 4 : 1) void k_qrow
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(junk) :: "memory");
         return;
     }
-    int rg = blockIdx.x;
+    int rg = (int) blockIdx.x / ks;
+    const int rg_first = rg;
 
     // ---- epilogue operands of this workgroup's first row group (bias, residual, cache slot): they depend on nothing this launch
     // computes, so they are requested before everything else — loaded inside the epilogue they were one more dependent round trip
@@ -639,9 +643,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && NR4 == 1) ? 4 : 1) void k_qrow
     float bias_pre = 0.0f, resid_pre = 0.0f; int ro_pre = 0;
     {
         const int nl = tid & 31, r = tid >> 5, nf = rg * 32 + nl;
-        if (tid < 32 * R8 && r < n && nf < a.N && rg < ngroups) {
+        if (tid < 32 * R8 && r < n && nf < a.N && rg < ngroups && kq == 0) {
             if (a.bias) bias_pre = a.bias[nf];
-            if (a.epi == EPI_F32_BIAS_RESID) resid_pre = a.resid[(size_t) r * a.ldr + nf];
+            if (a.epi == EPI_F32_BIAS_RESID) {
+                // (straight-line: the pending partial is read from a valid address either way and selected afterwards)
+                const float rv = a.resid[(size_t) r * a.ldr + nf];
+                const float pv = (a.pend ? a.pend : a.resid)[(size_t) r * a.ldr + nf];
+                resid_pre = a.pend ? rv + pv : rv;
+            }
             if (a.row_off) ro_pre = a.lanes ? a.row_off[r * a.step_stride] : *a.row_off;
         }
     }
@@ -651,7 +660,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && NR4 == 1) ? 4 : 1) void k_qrow
     auto load_tiles = [&](int g, int c0) {
 #pragma unroll
         for (int u = 0; u < CH; ++u) {
-            int tp = wave + NW * (c0 + u); if (tp > np - 1) tp = np - 1;
+            int tp = wave + NW * (c0 + u); if (tp > npq - 1) tp = npq - 1;
+            tp += tp0;
             const uint8_t * t = Wt + ((size_t) g * np + tp) * tile_bytes<QT>();
             if constexpr (QW == 4) { const uint4 v = *(const uint4 *) (t + lane * 16); wq[u][0] = v.x; wq[u][1] = v.y; wq[u][2] = v.z; wq[u][3] = v.w; }
             else { const uint4 v = *(const uint4 *) (t + lane * 32), w = *(const uint4 *) (t + lane * 32 + 16);
@@ -680,6 +690,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && NR4 == 1) ? 4 : 1) void k_qrow
                 float4 v[MAXV];
 #pragma unroll
                 for (int i = 0; i < MAXV; ++i) { const int c = (i * 64 + lane) * 4; v[i] = *(const float4 *) (xr + (c < K ? c : 0)); }
+                {   // pending K-split partial of the row (GemvArgs::pend): x = x + p, all loads in flight together
+                    const float * pr = (a.pend ? a.pend : a.x32) + (size_t) src * K;
+                    float4 pv[MAXV];
+#pragma unroll
+                    for (int i = 0; i < MAXV; ++i) { const int c = (i * 64 + lane) * 4; pv[i] = *(const float4 *) (pr + (c < K ? c : 0)); }
+                    if (a.pend) {
+#pragma unroll
+                        for (int i = 0; i < MAXV; ++i) { v[i].x += pv[i].x; v[i].y += pv[i].y; v[i].z += pv[i].z; v[i].w += pv[i].w; }
+                    }
+                }
                 float sum = 0.0f;
 #pragma unroll
                 for (int i = 0; i < MAXV; ++i) {
@@ -735,8 +755,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && NR4 == 1) ? 4 : 1) void k_qrow
             float4 v[MAXV];
 #pragma unroll
             for (int i = 0; i < MAXV; ++i) { const int c = (i * 64 + lane) * 4; v[i] = *(const float4 *) (xr + (c < K ? c : 0)); }
+            const float * pr = (a.pend ? a.pend : a.x32) + (size_t) src * K;       // pending K-split partial of the row (GemvArgs::pend)
+            float4 pv[MAXV];
+#pragma unroll
+            for (int i = 0; i < MAXV; ++i) { const int c = (i * 64 + lane) * 4; pv[i] = *(const float4 *) (pr + (c < K ? c : 0)); }
             const int cs = (sl * 64 + lane) * 4, ccs = cs < K ? cs : 0;
             const float4 gg = *(const float4 *) (a.ln_g + ccs), bb = *(const float4 *) (a.ln_b + ccs);
+            if (a.pend) {
+#pragma unroll
+                for (int i = 0; i < MAXV; ++i) { v[i].x += pv[i].x; v[i].y += pv[i].y; v[i].z += pv[i].z; v[i].w += pv[i].w; }
+            }
             float sum = 0.0f;
 #pragma unroll
             for (int i = 0; i < MAXV; ++i) {
@@ -772,9 +800,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && NR4 == 1) ? 4 : 1) void k_qrow
         }
     } else {
         // blocks quantise independently: (row, 256-column slice) pairs spread over all wavefronts
-        const int nsl = (K + 255) >> 8;
+        const int nsl = ((K + 255) >> 8) / ks, sl0 = kq * nsl;      // (a K part quantises its own slices only)
         for (int sl = wave; sl < n * nsl; sl += NW) {
-            const int r = sl / nsl, c = (sl - r * nsl) * 256 + lane * 4, cc = c < K ? c : 0;
+            const int r = sl / nsl, c = (sl0 + sl - r * nsl) * 256 + lane * 4, cc = c < K ? c : 0;
             const int src = a.rows ? a.rows[r] : r;
             float4 v;
             if constexpr (SRC == 0) v = *(const float4 *) (a32 + (size_t) src * K + cc);
@@ -832,16 +860,16 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && NR4 == 1) ? 4 : 1) void k_qrow
     const int fk = lane >> 5;
     const int8_t * afrag = sq + (size_t) arow * lda + fk * 16;
 
-    for (; rg < ngroups; rg += nmain) {
+    for (; rg < ngroups; rg += rstride) {
         float out[4 * NR4];
 #pragma unroll
         for (int e = 0; e < 4 * NR4; ++e) out[e] = 0.0f;
-        for (int c0 = 0; wave + NW * c0 < np; c0 += CH) {
+        for (int c0 = 0; wave + NW * c0 < npq; c0 += CH) {
             if (c0 != 0) load_tiles(rg, c0);                 // (the first tiles of a group: requested before the prologue, resp. before the previous group's reduction)
 #pragma unroll
             for (int u = 0; u < CH; ++u) {
-                const int tp = wave + NW * (c0 + u);
-                if (tp < np) {                               // wave-uniform
+                const int tpl = wave + NW * (c0 + u), tp = tp0 + tpl;
+                if (tpl < npq) {                             // wave-uniform
                     uint32_t lo[4], hi[4]; float d, m;
                     unpack<QT>(wq[u], wh[u], lo, hi, d, m);
                     // lane (n, g) unpacked block 2 tp + g; the MFMA of block 2 tp wants elements 0..15 of it on lanes < 32 and 16..31 on
@@ -883,11 +911,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && NR4 == 1) ? 4 : 1) void k_qrow
         }
         if (a.stamps && !tm2) { asm volatile("" :: "v"(out[0])); tm2 = wall_clock64(); }
         // the next row group's first tiles go out before this one is reduced (the vocabulary projection walks ~1.6 groups per workgroup)
-        const int rgn = rg + nmain;
+        const int rgn = rg + rstride;
         const bool more = rgn < ngroups;
         if (more) load_tiles(rgn, 0);
         // ---- K-split partials of the wavefronts, added in wavefront order
-        if (rg != (int) blockIdx.x) __syncthreads();            // red is reused
+        if (rg != rg_first) __syncthreads();                    // red is reused
 #pragma unroll
         for (int q = 0; q < NR4; ++q)
             *(float4 *) (red + ((size_t) (wave * 32 + (lane & 31)) * R8 + 8 * q + 4 * fk)) = make_float4(out[4 * q], out[4 * q + 1], out[4 * q + 2], out[4 * q + 3]);
@@ -900,12 +928,13 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && NR4 == 1) ? 4 : 1) void k_qrow
             float v = red[(size_t) nl * R8 + r];
 #pragma unroll
             for (int w = 1; w < NW; ++w) v += red[(size_t) (w * 32 + nl) * R8 + r];
-            const bool pre = rg == (int) blockIdx.x && e == tid;          // this thread's prefetched element
+            if (kq > 0) { a.kpart[(size_t) r * a.N + nf] = v; continue; }         // upper K part: the raw sums (GemvArgs::ksplit)
+            const bool pre = rg == rg_first && e == tid;                  // this thread's prefetched element
             const float bias = pre ? bias_pre : (a.bias ? a.bias[nf] : 0.0f);
             switch (a.epi) {
                 case EPI_F16_BIAS:       ((__half *) a.C)[(size_t) r * a.ldc + nf] = f2h(v + bias); break;
                 case EPI_F16_BIAS_GELU:  ((__half *) a.C)[(size_t) r * a.ldc + nf] = f2h(gelu16(v + bias)); break;
-                case EPI_F32_BIAS_RESID: ((float *) a.C)[(size_t) r * a.ldc + nf] = (v + bias) + (pre ? resid_pre : a.resid[(size_t) r * a.ldr + nf]); break;
+                case EPI_F32_BIAS_RESID: ((float *) a.C)[(size_t) r * a.ldc + nf] = (v + bias) + (pre ? resid_pre : a.pend ? a.resid[(size_t) r * a.ldr + nf] + a.pend[(size_t) r * a.ldr + nf] : a.resid[(size_t) r * a.ldr + nf]); break;
                 case EPI_Q_SCALED:       ((__half *) a.C)[(size_t) r * a.ldc + nf] = f2h((v + bias) * a.scale); break;
                 case EPI_QKV_DEC: {
                     const int seg = nf / a.S, c = nf - seg * a.S;
@@ -924,7 +953,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && NR4 == 1) ? 4 : 1) void k_qrow
     stamp_end(a.stamps, a.stamp_slot, (int) blockIdx.x * NW + wave, ts0, tm1, tm2);
 }
 
-template <int QT, int NR4, int SRC, int NW>
+template <int QT, int NR4, int SRC, int NW, int CHX = 0>
 void launch_qrows(const GemvArgs & a, const float * a32, const uint8_t * Wt, hipStream_t st) {
     const int nb = a.K / 32, R8 = NR4 * 8;
     const size_t smem = (((size_t) a.n * (a.K + 16) + 15) & ~(size_t) 15) + (size_t) 2 * nb * R8 * 4 + (size_t) NW * 32 * R8 * 4;
@@ -935,21 +964,27 @@ void launch_qrows(const GemvArgs & a, const float * a32, const uint8_t * Wt, hip
     static const int cap_env = getenv("WMI_QROWS_BLOCKS") ? atoi(getenv("WMI_QROWS_BLOCKS")) : 0;      // A/B knob
     const int cap = cap_env > 0 ? cap_env : NW == 4 ? 768 : NW == 8 ? 512 : 256;
     int blocks = ngroups; if (blocks > cap) blocks = cap;
+    if (a.ksplit > 1) blocks = ngroups * a.ksplit;            // (qrows() grants the split only where every (row group, part) gets its own workgroup)
     if (a.pf_ptr) blocks += PF_WG;                          // the prefetch workgroups (see the kernel)
     static std::atomic<uint64_t> lds_ok{0};
-    if (smem > 48 * 1024) allow_full_lds((const void *) k_qrows<QT, NR4, SRC, NW>, lds_ok);
-    hipLaunchKernelGGL((k_qrows<QT, NR4, SRC, NW>), dim3(blocks), dim3(NW * 64), smem, st, a, a32, Wt);
+    if (smem > 48 * 1024) allow_full_lds((const void *) k_qrows<QT, NR4, SRC, NW, CHX>, lds_ok);
+    hipLaunchKernelGGL((k_qrows<QT, NR4, SRC, NW, CHX>), dim3(blocks), dim3(NW * 64), smem, st, a, a32, Wt);
 }
 
 template <int QT, int NR4, int SRC>
 void qrows_nw(const GemvArgs & a, const float * a32, const uint8_t * Wt, hipStream_t st) {
     // K split: every wavefront should find all of its tiles in one round of loads (<= 5, resp. 3 with 8 wavefronts)
-    const int np = a.K / 64;
+    const int np = a.K / 64 / (a.ksplit > 1 ? a.ksplit : 1);
     if constexpr (SRC == 1) { if (np <= 8) launch_qrows<QT, NR4, SRC, 4>(a, a32, Wt, st); else launch_qrows<QT, NR4, SRC, 8>(a, a32, Wt, st); }
     else {
         if (np <= 8)       launch_qrows<QT, NR4, SRC, 4>(a, a32, Wt, st);
         else if (np <= 24) launch_qrows<QT, NR4, SRC, 8>(a, a32, Wt, st);
-        else               launch_qrows<QT, NR4, SRC, 16>(a, a32, Wt, st);
+        else {
+            // a K part of <= 48 tiles on 16 wavefronts: three tiles per wavefront in flight — 18 tile registers instead of 30, no spills
+            // under the 128 VGPRs of a 16-wavefront workgroup (the five-deep form spills 21 registers at <= 8 rows)
+            if constexpr (SRC == 2) { if (a.ksplit > 1 && np <= 48) { launch_qrows<QT, NR4, SRC, 16, 3>(a, a32, Wt, st); return; } }
+            launch_qrows<QT, NR4, SRC, 16>(a, a32, Wt, st);
+        }
     }
 }
 
@@ -1178,8 +1213,15 @@ void qgemm(int epi, const GemmArgs & a, Q8Rows A, QMat W, hipStream_t st) {
     }
 }
 
+bool qrows_ksplit_ok(const GemvArgs & a, int parts) {
+    // a16 rows (mlp.2), whole 256-column slices and tile pairs per part, one workgroup per (row group, part)
+    return parts == 2 && a.a16 && !a.ln_g && !a.comb_o && !a.rows && a.epi == EPI_F32_BIAS_RESID && a.n <= 32 &&
+           (a.K % (256 * parts)) == 0 && ((a.N + 31) / 32) * parts <= 256;
+}
+
 void qrows(const GemvArgs & a_in, const float * a32, QMat W, hipStream_t st) {
     GemvArgs a = a_in;
+    if (a.ksplit > 1 && (!a.kpart || a32 || !qrows_ksplit_ok(a, a.ksplit))) { a.ksplit = 0; a.kpart = nullptr; }
     { const Stamp sp = stamp_next(); a.stamps = sp.base; a.stamp_slot = sp.slot; }
     switch (W.qtype) {
         case QT_Q4_0: qrows_t<QT_Q4_0>(a, a32, W.tiles, st); break;

@@ -223,6 +223,13 @@ struct GemvArgs {
     // partial of the rows the workgroup produced (fs_step: DecStep of the row, fs_ban: static ban bytes); gemv_fused_parts() tells
     // how many partials this launch will write (0: the arguments do not take the fused path — run filter_argmax's own pass)
     const uint8_t * fs_ban; const void * fs_step; FsPartial * fs_part;
+    // k_qrows, K split over workgroups (ksplit = 2: mlp.2 of the wide models — N = S is only S / 32 row groups, K = 4 S is 4 S / 64 tiles
+    // each): workgroup (row group, half) multiplies its half of K; the lower half runs the epilogue as usual (bias, residual, in
+    // place), the upper half leaves its sums in kpart [n][N] f32.  The launches that read that row next take them as `pend` and add
+    // them — x = C + kpart, one f32 addition per element, the same in every consumer: the LayerNorm prologue of the next projection /
+    // of the vocabulary projection (x32 + pend) and the residual of the next out projection (resid + pend), which writes the row whole again.
+    int ksplit; float * kpart;
+    const float * pend;
 };
 int gemv_fused_parts(const GemvArgs & a);
 bool gemv_rows_carries_mirror(const GemvArgs & a);
@@ -333,6 +340,7 @@ void qdequant(QMat W, int64_t row0, int64_t rows, int K, __half * out, hipStream
 // prologue of every workgroup (LayerNorm of x32 if ln_g, plain f32 rows a32, or f16 rows a16) — GemvArgs as for gemv();
 // the fused attention prologues (sa_*, comb_*) are not available here.
 void qrows(const GemvArgs & a, const float * a32, QMat W, hipStream_t st);
+bool qrows_ksplit_ok(const GemvArgs & a, int parts);        // may this launch split K over `parts` workgroups per row group (GemvArgs::ksplit)?
 
 // token embedding gather from a quantised matrix: x[i] = dequant(te[token[i]]) + pe[pos[i]]   (W/ggml.c get_rows, dequantize_row_*)
 void qdec_embed(const int32_t * tokens, const int32_t * pos, int n, int S, QMat te, const float * pe, float * x, hipStream_t st);
