@@ -629,7 +629,7 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
         const int ng = std::min(group, n_chunks - g0);
         std::vector<Row> rows(ng);
         static const int env_when_ = getenv("WMI_ENVELOPE_WHEN") ? atoi(getenv("WMI_ENVELOPE_WHEN")) : 0;
-        const bool env_interleaved = env_when_ == 0;            // default: each chunk's envelope right behind its mel kernels
+        const bool env_interleaved = env_when_ == 0 || env_when_ == 3;   // each chunk's envelope kernel right behind its mel kernels (3: into HBM, copied out beside the decode steps)
         // ---- per chunk: PCM -> mel, envelope, window bounds (the head of full())
         for (int r = 0; r < ng; ++r) {
             Row & row = rows[r]; row.chunk = g0 + r; row.lane = r;
@@ -646,7 +646,7 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
             }
             if (params.token_timestamps) {
                 ls.t_beg = 0; ls.t_last = 0; ls.tid_last = 0;
-                if (env_interleaved && n_samples[row.chunk] > 0 && !signal_energy_device(ctx, 32, false)) { WMI_ERR("%s: failed to compute the signal envelope\n", __func__); return -2; }
+                if (env_interleaved && n_samples[row.chunk] > 0 && !signal_energy_device(ctx, 32, false, env_when_ == 3 ? 2 : 0)) { WMI_ERR("%s: failed to compute the signal envelope\n", __func__); return -2; }
             }
             b.t_mel_us += time_us() - tm0;
         }
@@ -657,7 +657,7 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
         // and the encoder (its persistent GEMMs want every CU at once) or the decode steps (their 32-byte results queue behind 15 MB of
         // bulk writes) give the same time back; the copy-engine form (WMI_ENVELOPE_DMA) is a blit kernel on this stack (rocprof:
         // __amd_rocclr_copyBuffer, no SDMA), a thin grid (WMI_ENVELOPE_GRID) starves the kernel's 65-deep f64 chains.
-        static const bool env_dma = getenv("WMI_ENVELOPE_DMA") != nullptr;
+        static const int env_dma = getenv("WMI_ENVELOPE_DMA") ? std::max(1, atoi(getenv("WMI_ENVELOPE_DMA"))) : 0;
         auto envelopes = [&]() -> bool {
             if (!params.token_timestamps) return true;
             for (int r = 0; r < ng; ++r) {
@@ -679,7 +679,7 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
             if (!HIP_OK(hipStreamSynchronize(primary->dev.stream))) return -2;
             b.t_mel_us += time_us() - tm0;
         }
-        bool env_done = env_interleaved || !params.token_timestamps;
+        bool env_done = env_interleaved || !params.token_timestamps, env_flushed = false;
         if (!env_done && env_when_ == 1) { if (!envelopes()) return -2; env_done = true; }
         for (int r = 0; r < ng; ++r) {
             Row & row = rows[r]; State & ls = *b.lanes[r];
@@ -702,6 +702,10 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
                 for (int r = 0; r < nb; ++r) { lanes[r] = rows[act[r]].lane; seeks[r] = rows[act[r]].seek; }
                 if (!encode_rows(ctx, lanes, seeks, params.audio_ctx)) { WMI_ERR("%s: failed to encode\n", __func__); return -6; }
                 if (!env_done) { if (!envelopes()) return -2; env_done = true; }
+                if (env_when_ == 3 && !env_flushed) {            // the thin copies start now: beside the decode steps, done long before emission
+                    for (int r = 0; r < ng; ++r) if (!signal_energy_flush(*b.lanes[r])) return -2;
+                    env_flushed = true;
+                }
                 b.chain_valid = false;                             // new windows, possibly other chunks in the rows: every row restarts at cell 0
             }
             for (int r = 0; r < nb; ++r) {

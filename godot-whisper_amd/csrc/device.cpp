@@ -164,7 +164,7 @@ bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, boo
     return true;
 }
 
-bool signal_energy_device(whisper_context & ctx, int hw, bool sync, bool via_dma) {
+bool signal_energy_device(whisper_context & ctx, int hw, bool sync, int via_dma) {
     State & st = *ctx.state; DeviceState & d = st.dev;
     const int n = d.last_pcm_n;
     if (!d.last_pcm || n <= 0) return false;
@@ -194,7 +194,12 @@ bool signal_energy_device(whisper_context & ctx, int hw, bool sync, bool via_dma
         // as stores from the kernel, 8 x 1875 workgroups sat on PCIe writes in the CUs' wave slots for 0.25-0.35 ms beside the mel kernels
         // or the encoder, whichever they were queued next to.  One chunk: the direct stores (no copy call on the host's critical path).
         const size_t need = d.energy_cap + 2 * nb;
-        if (via_dma && d.energy_dev_cap < need) { dfree(d.energy); d.energy_dev_cap = 0; if (dalloc(d.energy, need)) d.energy_dev_cap = need; else via_dma = false; }
+        if (via_dma && d.energy_dev_cap < need) { dfree(d.energy); d.energy_dev_cap = 0; if (dalloc(d.energy, need)) d.energy_dev_cap = need; else via_dma = 0; }
+        if (via_dma == 2) {
+            // the kernel runs now, into HBM (~10 us); the copy to the pinned image is signal_energy_flush()'s thin kernel, later
+            k::signal_energy(d.last_pcm, n, hw, d.energy, d.energy + d.energy_cap, d.energy + d.energy_cap + nb, d.copy_stream);
+            d.energy_unflushed = true;
+        } else
         if (via_dma) {
             k::signal_energy(d.last_pcm, n, hw, d.energy, d.energy + d.energy_cap, d.energy + d.energy_cap + nb, d.copy_stream);
             HIP_TRY(hipMemcpyAsync(d.energy_host, d.energy, (size_t) n * 4, hipMemcpyDeviceToHost, d.copy_stream));
@@ -206,9 +211,22 @@ bool signal_energy_device(whisper_context & ctx, int hw, bool sync, bool via_dma
     return sync ? signal_energy_wait(st) : true;
 }
 
+bool signal_energy_flush(State & st) {
+    DeviceState & d = st.dev;
+    if (!d.energy_pending || !d.energy_unflushed) return true;
+    static const int wgs = getenv("WMI_ENVELOPE_COPY_WGS") ? atoi(getenv("WMI_ENVELOPE_COPY_WGS")) : 2;
+    const size_t nb = (size_t) d.last_pcm_n / 256 + 2;
+    // envelope [n] and the block extrema behind energy_cap: the pinned image has the device buffer's layout
+    k::copy_thin(d.energy, d.energy_host, (size_t) d.last_pcm_n * 4, wgs, d.copy_stream);
+    k::copy_thin(d.energy + d.energy_cap, d.energy_host + d.energy_cap, 2 * nb * 4, 1, d.copy_stream);
+    d.energy_unflushed = false;
+    return hipGetLastError() == hipSuccess;
+}
+
 bool signal_energy_wait(State & st) {
     DeviceState & d = st.dev;
     if (!d.energy_pending) return true;
+    if (d.energy_unflushed && !signal_energy_flush(st)) return false;
     HIP_TRY(hipStreamSynchronize(d.copy_stream));
     st.energy = d.energy_host; st.energy_n = d.last_pcm_n;
     st.energy_bmin = d.energy_host + d.energy_cap; st.energy_bmax = st.energy_bmin + ((size_t) d.last_pcm_n / 256 + 2);

@@ -443,6 +443,28 @@ void signal_energy(const float * pcm, int n, int hw, float * out, float * bmin, 
     hipLaunchKernelGGL(k_signal_energy, dim3(thin > 0 && thin < nblk ? thin : nblk), dim3(256), 0, st, pcm, n, hw, out, bmin, bmax);
 }
 
+// A copy by a handful of workgroups: 16 bytes per lane and trip, four trips in flight.  Used for the |x| envelopes of a lock-step call
+// (15 MB to pinned host memory for 8 chunks): as stores of the full-grid envelope kernel — or of the runtime's blit kernel — thousands
+// of wavefronts queue megabytes of PCIe writes at once, and the 32-byte results of the decode steps running beside them wait behind
+// that queue; a few wavefronts keep it a few KB deep and take as long as the decode phase lets them.
+__global__ __launch_bounds__(256) void k_copy_thin(const uint4 * __restrict__ src, uint4 * __restrict__ dst, size_t n16, const unsigned char * __restrict__ tsrc,
+                                                   unsigned char * __restrict__ tdst, int tail) {
+    const size_t stride = (size_t) gridDim.x * 256;
+    size_t i = (size_t) blockIdx.x * 256 + threadIdx.x;
+    for (; i + 3 * stride < n16; i += 4 * stride) {
+        const uint4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+        dst[i] = a; dst[i + stride] = b; dst[i + 2 * stride] = c; dst[i + 3 * stride] = d;
+    }
+    for (; i < n16; i += stride) dst[i] = src[i];
+    if (blockIdx.x == 0 && (int) threadIdx.x < tail) tdst[threadIdx.x] = tsrc[threadIdx.x];
+}
+void copy_thin(const void * src, void * dst, size_t bytes, int wgs, hipStream_t st) {
+    if (!bytes) return;
+    const size_t n16 = bytes / 16; const int tail = (int) (bytes - n16 * 16);
+    hipLaunchKernelGGL(k_copy_thin, dim3(wgs < 1 ? 1 : wgs), dim3(256), 0, st, (const uint4 *) src, (uint4 *) dst, n16,
+                       (const unsigned char *) src + n16 * 16, (unsigned char *) dst + n16 * 16, tail);
+}
+
 void downmix_stereo(const float * frames, int n_frames, float * out, hipStream_t st) {
     if (n_frames > 0) hipLaunchKernelGGL(k_downmix, dim3((n_frames + 255) / 256), dim3(256), 0, st, (const float2 *) frames, n_frames, out);
 }

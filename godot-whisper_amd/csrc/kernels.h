@@ -79,6 +79,8 @@ void mel_slice(const float * mel, int n_len, int n_mel, int offset, int n_frames
 // |x| envelope for the token-level timestamp heuristics (W/whisper.cpp:6352-6366), bit-identical to the CPU loop
 // out[n] plus the minimum / maximum of each 256-sample block of out (bmin, bmax: ceil(n / 256) entries)
 void signal_energy(const float * pcm, int n, int hw, float * out, float * bmin, float * bmax, hipStream_t st);
+// device -> pinned host (or anywhere) by `wgs` workgroups only: a deliberately slow copy that keeps the PCIe write queue short
+void copy_thin(const void * src, void * dst, size_t bytes, int wgs, hipStream_t st);
 
 // host-adjacent DSP of the streaming node: stereo -> mono and the energy VAD, bit-identical to the host's C++
 // (src/speech_to_text.cpp:45-51, 53-104).  res = {no-activity decision, energy_all, energy_last}

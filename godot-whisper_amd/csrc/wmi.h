@@ -192,6 +192,7 @@ struct DeviceState {
     hipStream_t copy_stream = nullptr; hipEvent_t energy_ev = nullptr;   // envelope D2H overlaps the encoder
     hipStream_t mel_stream = nullptr;  hipEvent_t mel_ev = nullptr;      // lock-step chunks: the mel kernels of the chunks overlap
     bool    energy_pending = false;                            // copy in flight: signal_energy_wait() before reading state.energy
+    bool    energy_unflushed = false;                          // the envelope sits in the device buffer `energy`: signal_energy_flush() starts its copy to the pinned image
     // encoder activations, token-major
     __half * mel_t = nullptr;                                 // [2T+2+pad][n_mel_pad] f16, rows -1 and 2T are zero
     __half * conv1 = nullptr;                                 // [2T+2][S] f16 (row 0 and 2T+1 zero)
@@ -370,7 +371,8 @@ double bench_rows_step_chain(whisper_context & ctx, int nb, int iters);
 int    step_stamps(whisper_context & ctx, double * out, int cap, bool chained);
 // |x| envelope of the last PCM on the GPU; the D2H copy runs on a side stream while the encoder works.
 // sync = false: state.energy is valid only after signal_energy_wait()
-bool signal_energy_device(whisper_context & ctx, int hw, bool sync = true, bool via_dma = false);   // via_dma: kernel -> device buffer -> copy engine (lock-step chunks)
+bool signal_energy_device(whisper_context & ctx, int hw, bool sync = true, int via_dma = 0);   // via_dma 1: kernel -> device buffer -> hipMemcpyAsync; 2: kernel -> device buffer now, signal_energy_flush() later
+bool signal_energy_flush(State & st);             // via_dma 2: a THIN copy kernel moves the envelope to the pinned image (lock-step calls: beside the decode steps)
 bool signal_energy_wait(State & st);
 
 // host logic (logits filters, sampling, driver)
