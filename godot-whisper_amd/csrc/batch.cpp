@@ -629,7 +629,7 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
         const int ng = std::min(group, n_chunks - g0);
         std::vector<Row> rows(ng);
         static const int env_when_ = getenv("WMI_ENVELOPE_WHEN") ? atoi(getenv("WMI_ENVELOPE_WHEN")) : 0;
-        const bool env_interleaved = env_when_ == 0 || env_when_ == 3;   // each chunk's envelope kernel right behind its mel kernels (3: into HBM, copied out beside the decode steps)
+        const bool env_interleaved = env_when_ == 0 || env_when_ >= 3;   // each chunk's envelope kernel right behind its mel kernels (3: into HBM, copied out beside the decode steps)
         // ---- per chunk: PCM -> mel, envelope, window bounds (the head of full())
         for (int r = 0; r < ng; ++r) {
             Row & row = rows[r]; row.chunk = g0 + r; row.lane = r;
@@ -646,7 +646,7 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
             }
             if (params.token_timestamps) {
                 ls.t_beg = 0; ls.t_last = 0; ls.tid_last = 0;
-                if (env_interleaved && n_samples[row.chunk] > 0 && !signal_energy_device(ctx, 32, false, env_when_ == 3 ? 2 : 0)) { WMI_ERR("%s: failed to compute the signal envelope\n", __func__); return -2; }
+                if (env_interleaved && n_samples[row.chunk] > 0 && !signal_energy_device(ctx, 32, false, env_when_ >= 3 ? 2 : 0)) { WMI_ERR("%s: failed to compute the signal envelope\n", __func__); return -2; }
             }
             b.t_mel_us += time_us() - tm0;
         }
@@ -680,6 +680,10 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
             b.t_mel_us += time_us() - tm0;
         }
         bool env_done = env_interleaved || !params.token_timestamps, env_flushed = false;
+        if (env_when_ == 4 && params.token_timestamps) {        // thin copies beside the encoder
+            for (int r = 0; r < ng; ++r) if (!signal_energy_flush(*b.lanes[r])) return -2;
+            env_flushed = true;
+        }
         if (!env_done && env_when_ == 1) { if (!envelopes()) return -2; env_done = true; }
         for (int r = 0; r < ng; ++r) {
             Row & row = rows[r]; State & ls = *b.lanes[r];
