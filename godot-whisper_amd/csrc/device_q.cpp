@@ -35,9 +35,13 @@ bool rows_fit(int n, int K) {
 // mlp.2 of the decoder with K split over two workgroups per row group (kernels.h GemvArgs::ksplit; WMI_Q_KSPLIT=0: off, A/B)
 bool fc2_ksplit(k::GemvArgs & g, float * kpart) {
     static const bool off = getenv("WMI_Q_KSPLIT") && atoi(getenv("WMI_Q_KSPLIT")) == 0;
-    if (off || !kpart || !k::qrows_ksplit_ok(g, 2)) return false;
+    static const bool dbg = getenv("WMI_DEBUG_KSPLIT") != nullptr;
+    const bool ok = !off && kpart && k::qrows_ksplit_ok(g, 2);
+    if (dbg) fprintf(stderr, "[wmi] mlp.2 K split: %s (n %d K %d N %d a16 %p epi %d)\n", ok ? "yes" : "no", g.n, g.K, g.N, (const void *) g.a16, g.epi);
+    if (!ok) return false;
     g.ksplit = 2; g.kpart = kpart;
-    return true;
+    static const bool drop = getenv("WMI_DEBUG_KSPLIT_DROP") != nullptr;      // debug: the consumers ignore the pending half (results must change)
+    return !drop;
 }
 
 } // namespace
