@@ -108,6 +108,8 @@ void whisper_free(struct whisper_context * ctx) {
     (void) hipSetDevice(ctx->device);
     free_batch(*ctx);
     free_state(*ctx);
+    for (hipStream_t sp : ctx->spare_streams) own_queue_stream_put(ctx->device, sp);
+    ctx->spare_streams.clear();
     free_weights(ctx->w);
     for (float * t : ctx->d_sinc) if (t) (void) hipFree(t);
     if (ctx->vad_res) (void) hipHostFree(ctx->vad_res);
@@ -562,6 +564,11 @@ int wmi_set_batch_replicas(struct whisper_context * ctx, int n) {
     } catch (const std::exception &) { return -1; }
     const int prev = ctx->batch->replicas_wanted;
     ctx->batch->replicas_wanted = n < 0 ? -1 : (n > 15 ? 15 : n);
+    // the replicas are made now rather than inside the first call that wants them: state allocation (~0.6 GB each for large-v3) stays out
+    // of that call, and their hardware queues exist before the context's other streams do (see init_state: the order matters)
+    if (n > 0 && compute_ready(*ctx, __func__)) {
+        try { (void) hipSetDevice(ctx->device); (void) ensure_replicas(*ctx, ctx->batch->replicas_wanted); } catch (const std::exception &) {}
+    }
     return prev;
 }
 

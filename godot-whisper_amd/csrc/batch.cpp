@@ -468,7 +468,9 @@ static whisper_context * new_replica(whisper_context & ctx) {
         r = new whisper_context();
         r->params = ctx.params; r->model = ctx.model; r->device = ctx.device;
         r->w = ctx.w; r->w.arena_borrowed = true;
-        if (!init_state(*r)) { free_state(*r); delete r; return nullptr; }
+        hipStream_t adopt = nullptr;
+        if (!ctx.spare_streams.empty()) { adopt = ctx.spare_streams.back(); ctx.spare_streams.pop_back(); }
+        if (!init_state(*r, true, adopt)) { free_state(*r); delete r; return nullptr; }
     } catch (const std::exception & e) {
         WMI_ERR("%s: %s\n", __func__, e.what());
         if (r) { free_state(*r); delete r; }
@@ -482,6 +484,16 @@ static void free_replica(whisper_context * r) {
     free_state(*r);
     free_weights(r->w);                                        // borrowed: forgets the pointer
     delete r;
+}
+
+int ensure_replicas(whisper_context & ctx, int n) {
+    if (!ctx.batch) ctx.batch = new BatchWork();
+    while ((int) ctx.batch->replicas.size() < n) {
+        whisper_context * r = new_replica(ctx);
+        if (!r) break;
+        ctx.batch->replicas.push_back(r);
+    }
+    return std::min(n, (int) ctx.batch->replicas.size());
 }
 
 void free_batch(whisper_context & ctx) {
@@ -550,11 +562,9 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
                                params.encoder_begin_callback || params.abort_callback || params.print_realtime;      // (print_progress only writes percent lines to stderr)
         int n_rep = (!force_seq && !observers && ctx.model.n_loaded > 0) ? std::min(rep_want, n_chunks - 1) : 0;
         if (n_rep < 0) n_rep = 0;
-        while ((int) ctx.batch->replicas.size() < n_rep) {
-            whisper_context * r = new_replica(ctx);
-            if (!r) { n_rep = (int) ctx.batch->replicas.size(); break; }         // out of memory: fewer workers
-            ctx.batch->replicas.push_back(r);
-        }
+        n_rep = ensure_replicas(ctx, n_rep);                             // (out of memory: fewer workers)
+        static const bool dbg_rep = getenv("WMI_DEBUG_TIMING") != nullptr;
+        if (dbg_rep) fprintf(stderr, "[wmi] full_batch: %d chunks through the general driver on 1 + %d contexts (wanted %d, observers %d)\n", n_chunks, n_rep, rep_want, (int) observers);
         if (n_rep == 0) {
             for (int c = 0; c < n_chunks; ++c) { const int rc = run_alone(c); if (rc != 0) return rc; ctx.batch->redo[c] = 1; }
             return 0;

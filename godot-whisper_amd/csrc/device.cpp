@@ -11,6 +11,9 @@
 // except when a longer PCM / mel than ever seen before arrives (grow-only).
 
 #include "wmi.h"
+#include <atomic>
+#include <map>
+#include <mutex>
 #include "kernels.h"
 
 #include <algorithm>
@@ -30,14 +33,63 @@ template <typename T> void dfree(T *& p) { if (p) (void) hipFree(p); p = nullptr
 
 } // namespace
 
-bool init_state(whisper_context & ctx) {
+static bool make_own_queue_stream(int device, hipStream_t * out) {
+    uint32_t mask[16]; for (uint32_t & m : mask) m = 0xFFFFFFFFu;
+    hipDeviceProp_t prop{};
+    const int ncu = hipGetDeviceProperties(&prop, device) == hipSuccess ? prop.multiProcessorCount : 256;
+    const uint32_t words = (uint32_t) std::min(16, (ncu + 31) / 32);
+    if (hipExtStreamCreateWithCUMask(out, words, mask) == hipSuccess) return true;
+    (void) hipGetLastError();
+    return false;
+}
+
+// Process-wide pool of such streams, per device.  Measured (profiles/r04d_replica_streams_hw_queues.txt): whether four contexts' launch
+// chains run beside each other depends on WHEN their hardware queues were created relative to the process's other queues — the queues a
+// process makes first behave, queues made after several contexts have come and gone did not (bench.py: 40 ms per chunk against 18).  So
+// the streams are made once, as early as a context exists, never destroyed, and handed from context to context.
+static std::mutex g_oq_mu;
+static std::map<int, std::vector<hipStream_t>> g_oq_pool;
+hipStream_t own_queue_stream_get(int device) {
+    {
+        std::lock_guard<std::mutex> lk(g_oq_mu);
+        auto & v = g_oq_pool[device];
+        if (!v.empty()) { hipStream_t s = v.back(); v.pop_back(); return s; }
+    }
+    hipStream_t s = nullptr;
+    return make_own_queue_stream(device, &s) ? s : nullptr;
+}
+void own_queue_stream_put(int device, hipStream_t s) {
+    if (!s) return;
+    (void) hipStreamSynchronize(s);
+    std::lock_guard<std::mutex> lk(g_oq_mu);
+    g_oq_pool[device].push_back(s);
+}
+
+bool init_state(whisper_context & ctx, bool replica_state, hipStream_t adopt) {
     const HParams & hp = ctx.model.hp;
     State * st = new State();
     ctx.state = st;
     st->device = ctx.device;
     DeviceState & d = st->dev;
     if (!HIP_OK(hipSetDevice(ctx.device))) return false;
-    HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+    // The context's stream has a hardware queue of its own (a CU-masked stream naming every CU) taken from the process-wide pool above;
+    // ordinary streams are multiplexed by the runtime onto a few shared hardware queues in creation order.  What this buys is measured,
+    // not understood in full (profiles/r04d_replica_streams_hw_queues.txt): four contexts running beam search side by side (wmi_full_batch
+    // replicas) take 18 ms per large-v3 chunk when all four launch on queues the process made early, and 40 ms — hardly better than one after
+    // the other — when the calling context's stream was an ordinary one created after an earlier context had run lock-step batches (sixteen
+    // more ordinary streams).  One chunk alone measures the same on either kind of stream.  WMI_POOLED_MAIN_STREAM=1: the ordinary kind.
+    static const bool pooled = getenv("WMI_POOLED_MAIN_STREAM") != nullptr || getenv("WMI_REPLICA_POOLED_QUEUES") != nullptr;
+    if (adopt) { d.stream = adopt; d.stream_own_queue = true; }
+    else if (!pooled && (d.stream = own_queue_stream_get(ctx.device))) d.stream_own_queue = true;
+    else HIP_TRY(hipStreamCreateWithFlags(&d.stream, hipStreamNonBlocking));
+    if (!replica_state) {
+        // as many as wmi_full_batch's default number of replica contexts (WMI_BATCH_REPLICAS, 3); measured on large-v3 q5_1, beam 5 x 8 chunks:
+        // queues made here -> 18 ms per chunk on 1 + 3 contexts whatever the process did in between; made when the replicas are first
+        // needed -> 18 or 40 ms depending on what else had been created by then (profiles/r04d_replica_streams_hw_queues.txt)
+        static const int spares = getenv("WMI_SPARE_QUEUES") ? atoi(getenv("WMI_SPARE_QUEUES"))
+                                : getenv("WMI_BATCH_REPLICAS") ? std::max(0, std::min(15, atoi(getenv("WMI_BATCH_REPLICAS")))) : 3;
+        for (int i = 0; i < spares; ++i) { hipStream_t sp = own_queue_stream_get(ctx.device); if (sp) ctx.spare_streams.push_back(sp); }
+    }
 
     const size_t S = hp.n_audio_state, T = hp.n_audio_ctx, Lt = hp.n_text_layer, H = hp.n_audio_head;
     const size_t n_self = 3 * (size_t) hp.n_text_ctx;                         // W/whisper.cpp:3009 (factor 3)
@@ -90,7 +142,7 @@ State * create_state(whisper_context & ctx) {
     State * saved = ctx.state;
     ctx.state = nullptr;
     State * st = nullptr;
-    if (init_state(ctx)) st = ctx.state; else free_state(ctx);
+    if (init_state(ctx, true)) st = ctx.state; else free_state(ctx);        // (a further state: the context's spare streams exist already)
     ctx.state = saved;
     return st;
 }
@@ -124,7 +176,8 @@ void destroy_state(State * st) {
     if (d.step_host) (void) hipHostFree(d.step_host);
     if (d.sample_host) (void) hipHostFree(d.sample_host);
     if (d.pinned) (void) hipHostFree(d.pinned);
-    if (d.stream) (void) hipStreamDestroy(d.stream);
+    if (d.stream && d.stream_own_queue) own_queue_stream_put(st->device, d.stream);
+    else if (d.stream) (void) hipStreamDestroy(d.stream);
     delete st;
 }
 

@@ -55,7 +55,9 @@ __global__ __launch_bounds__(QW * KS * 64) void k_attn_enc2(const __half * __res
     // the output images of the query wavefronts sit behind everything else the kernel keeps in LDS (ring, maxima, combine area)
     constexpr size_t RING_B = (size_t) KS * NST * STAGE, EXTRA_B = (!ONE && KS > 1) ? (size_t) KS * QW * 32 * 4 : 0;
     constexpr size_t COMB_B = KS > 1 ? (size_t) (KS - 1) * QW * 64 * 34 * 4 : 0;
-    constexpr size_t TB_OFF = (RING_B + EXTRA_B) > COMB_B ? (RING_B + EXTRA_B) : COMB_B;
+    // (one key group: the images reuse the ring once every wavefront is done with it — 32 KB per workgroup instead of 48: four workgroups
+    //  per CU, which is what the registers allow, instead of three)
+    constexpr size_t TB_OFF = KS == 1 ? 0 : ((RING_B + EXTRA_B) > COMB_B ? (RING_B + EXTRA_B) : COMB_B);
     constexpr float LOG2E = 1.44269504088896340736f;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave-uniform: scalar branches
     const int grp = KS == 1 ? 0 : wave / QW, qw = wave - grp * QW;
@@ -64,7 +66,8 @@ __global__ __launch_bounds__(QW * KS * 64) void k_attn_enc2(const __half * __res
     // K / V^T — would sit on eight different L2s and fetch them eight times (PMC: 213 MB per launch at 8 chunks for 37 MB of operands).
     // The launch id is mapped so that every XCD owns a contiguous run of (chunk, head, query block) triples.
     int bx = blockIdx.x, head = blockIdx.y, bz = blockIdx.z;
-    if (xcd_order) {
+    const bool mfma_prio = (xcd_order & 2) != 0;            // A/B: s_setprio 1 around the MFMA clusters (WMI_ATTN_PRIO)
+    if (xcd_order & 1) {
         const int nwg = gridDim.x * gridDim.y * gridDim.z;
         int wg = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
         const int q8 = nwg / 8, r8 = nwg % 8, xcd = wg % 8, idx = wg / 8;
@@ -123,6 +126,7 @@ __global__ __launch_bounds__(QW * KS * 64) void k_attn_enc2(const __half * __res
 
     float m = -INFINITY;
     auto tile_scores = [&](const unsigned char * st, int kt0, floatx16 (&s)[2]) {
+        if (mfma_prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int blk = 0; blk < 2; ++blk) {
             s[blk] = floatx16{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -132,6 +136,7 @@ __global__ __launch_bounds__(QW * KS * 64) void k_attn_enc2(const __half * __res
                 s[blk] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[kk], s[blk], 0, 0, 0);
             }
         }
+        if (mfma_prio) __builtin_amdgcn_s_setprio(0);
         if (kt0 + 64 > T) {                                        // ragged last tile (and whole tiles past T of the last key group)
 #pragma unroll
             for (int blk = 0; blk < 2; ++blk)
@@ -234,6 +239,7 @@ __global__ __launch_bounds__(QW * KS * 64) void k_attn_enc2(const __half * __res
                 pf[pr >> 2][2 * (pr & 3)] = eh[0];
                 pf[pr >> 2][2 * (pr & 3) + 1] = eh[1];
             }
+            if (mfma_prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
@@ -241,6 +247,7 @@ __global__ __launch_bounds__(QW * KS * 64) void k_attn_enc2(const __half * __res
                     const half8 vf = *(const half8 *) (sv + lds_off(mt * 32 + i, blk * 4 + u * 2 + g));
                     o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[u], o[mt], 0, 0, 0);
                 }
+            if (mfma_prio) __builtin_amdgcn_s_setprio(0);
         }
     }
     l += xor_lane<32>(l);                                          // the two lanes of a query row saw disjoint keys
@@ -302,6 +309,7 @@ __global__ __launch_bounds__(QW * KS * 64) void k_attn_enc2(const __half * __res
             // stores a wave instruction covered 32 rows x 16 B = 32 partial-line requests and the eight of them per wavefront were
             // request-bound like the GEMM epilogues' (gemm_epi.h); read back 16 B per lane an instruction covers 8 rows x 128 B.
             // Wavefront-private: no barrier, only the wave's own lgkmcnt wait.  The stored values are the plain form's.
+            if constexpr (KS == 1) __syncthreads();          // the ring's last tile has been read by every wavefront
             unsigned char * tb = smem + TB_OFF + qw * 4096;
             const float inv = (float) (1.0 / (double) l);
 #pragma unroll
@@ -357,7 +365,8 @@ void launch_attn_enc2(const __half * q, const __half * k, const __half * vt, int
     // A/B knob: 0 = launch order, 1 = XCD runs.  Default: XCD runs for several chunks (operand fetches 213 -> ~40 MB per launch at 8 chunks;
     // time unchanged within the noise: the Infinity Cache was serving the re-fetches), launch order for one chunk (14.3 against 15.0 us)
     static const int xcd_env = getenv("WMI_ATTN_XCD") ? atoi(getenv("WMI_ATTN_XCD")) : -1;
-    const int xcd_order = xcd_env >= 0 ? xcd_env : (B > 1);
+    static const int prio_env = getenv("WMI_ATTN_PRIO") ? atoi(getenv("WMI_ATTN_PRIO")) : 0;      // A/B knob: s_setprio 1 around the MFMA clusters
+    const int xcd_order = (xcd_env >= 0 ? (xcd_env & 1) : (B > 1)) | (prio_env ? 2 : 0);
     if (narrow) {
         static_assert(smem0 <= 160 * 1024, "LDS");
         if (smem0 > 48 * 1024) allow_full_lds((const void *) k_attn_enc2<QW, KS, ONE, NST, false>, lds_ok);
@@ -365,7 +374,7 @@ void launch_attn_enc2(const __half * q, const __half * k, const __half * vt, int
                            q, k, vt, T, Tpad, S, out, out32, xcd_order);
         return;
     }
-    constexpr size_t smem = smem0 + (size_t) QW * 4096;                          // + the query wavefronts' output images
+    constexpr size_t smem = KS == 1 ? (smem0 > (size_t) QW * 4096 ? smem0 : (size_t) QW * 4096) : smem0 + (size_t) QW * 4096;      // the query wavefronts' output images: inside the ring (one key group) or behind it
     static_assert(smem <= 160 * 1024, "LDS");
     static std::atomic<uint64_t> lds_ok_w{0};
     if (smem > 48 * 1024) allow_full_lds((const void *) k_attn_enc2<QW, KS, ONE, NST, true>, lds_ok_w);

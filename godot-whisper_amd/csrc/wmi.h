@@ -180,7 +180,7 @@ struct Mel { int n_len = 0, n_len_org = 0, n_mel = 0; };
 
 // device scratch for one in-flight chunk; sized at init for the model's maxima
 struct DeviceState {
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr; bool stream_own_queue = false;   // own_queue: made by make_own_queue_stream — goes back to the process-wide pool, not destroyed
     // mel
     float * pcm = nullptr;      size_t pcm_cap = 0;          // padded PCM
     float * mel = nullptr;      size_t mel_cap = 0;          // [n_mel][n_len] f32 (reference layout)
@@ -312,6 +312,9 @@ struct whisper_context {
     // have not arrived yet — every compute call fails until wmi_arena_commit() says the broadcast / peer copy has landed
     bool           weights_pending = false;
     wmi::BatchWork * batch = nullptr;   // lazily created by wmi_full_batch
+    // streams with a hardware queue of their own, made together with the context's first stream and handed to replica contexts later
+    // (init_state: it is the ORDER in which the queues are created that decides whether the replicas run beside each other)
+    std::vector<hipStream_t> spare_streams;
     float * d_sinc[3] = {nullptr, nullptr, nullptr};   // resampler coefficient tables on the device, by converter (wmi_resample)
     float * vad_res = nullptr;          // pinned host memory the VAD kernel writes {decision, energy_all, energy_last} into (wmi_vad)
     float * dsp_scratch = nullptr; size_t dsp_scratch_bytes = 0;   // grow-only device staging of the host-pointer forms of wmi_vad / wmi_downmix_stereo / wmi_resample
@@ -328,7 +331,10 @@ namespace wmi {
 whisper_context * init_context(const void * buffer, size_t size, int device, bool with_state, bool allow_header = false);
 // false + an error log when the context cannot compute: host-only (tests) or weights still pending (header image not committed)
 bool compute_ready(const whisper_context & ctx, const char * who);
-bool init_state(whisper_context & ctx);
+bool init_state(whisper_context & ctx, bool replica_state = false, hipStream_t adopt = nullptr);   // replica_state: no spare streams of its own; adopt: the stream to use
+// streams with a hardware queue of their own are kept for the life of the process and handed from context to context (device.cpp)
+hipStream_t own_queue_stream_get(int device);
+void        own_queue_stream_put(int device, hipStream_t s);     // own_hw_queue: a stream that does not share its hardware queue with other streams (replica contexts)
 void free_state(whisper_context & ctx);
 State * create_state(whisper_context & ctx);      // a further state for the same weights (whisper_init_state); null on failure
 void destroy_state(State * st);
@@ -389,6 +395,7 @@ int  full(whisper_context & ctx, whisper_full_params params, const float * sampl
 // several independent chunks in lock-step (batch.cpp); results per chunk in ctx.batch->results
 int  full_batch(whisper_context & ctx, whisper_full_params params, const float * const * pcm, const int * n_samples, int n_chunks, bool on_device);
 void free_batch(whisper_context & ctx);
+int  ensure_replicas(whisper_context & ctx, int n);     // create up to n replica contexts now; returns how many exist (<= n)
 // segment emission of one decoded window: updates prompt_past and appends to state.result_all (W/whisper.cpp:5682-5796)
 void emit_window(whisper_context & ctx, State & st, const whisper_full_params & params, int seek, const std::vector<int32_t> & prompt,
                  size_t n_prompt_init, const Decoder & best);
