@@ -553,8 +553,8 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
         // nothing observable depends on the order, on several REPLICA contexts at once: worker w takes the chunks c = w (mod workers),
         // each on its own state and stream, so the short launches of one chunk's decode steps (40-160 workgroups on 256 CUs) run
         // beside another chunk's.  Every chunk is still one whisper_full on a fresh state: results are identical to the sequential
-        // loop by construction.  Measured (scratch/pool_beam.py): beam 5, 8 chunks, base.en 9.8 -> 5.1 ms per chunk, large-v3 q5_1
-        // 47.1 -> 27.3 ms per chunk with four contexts.  Not with user callbacks (they would run concurrently, on contexts the
+        // loop by construction.  Measured (profiles/r04d_replica_streams_hw_queues.txt): beam 5, 8 chunks, base.en 9.3 -> 3.3 ms per chunk,
+        // large-v3 q5_1 46 -> 18 ms per chunk with four contexts.  Not with user callbacks (they would run concurrently, on contexts the
         // caller never saw) or print_realtime (its stdout text would interleave).
         static const int rep_env = getenv("WMI_BATCH_REPLICAS") ? atoi(getenv("WMI_BATCH_REPLICAS")) : 3;
         const int rep_want = ctx.batch->replicas_wanted >= 0 ? ctx.batch->replicas_wanted : rep_env;
