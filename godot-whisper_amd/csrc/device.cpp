@@ -113,7 +113,11 @@ bool init_state(whisper_context & ctx, bool replica_state, hipStream_t adopt) {
         ok = ok && dalloc(d.aq16, rows * 4 * S) && dalloc(d.wq16, d.wq16_elems);
     }
     d.logits_rows_cap = 8;
-    ok = ok && dalloc(d.d_tokens, n) && dalloc(d.d_pos, n) && dalloc(d.d_mask, n * n_self) && dalloc(d.d_rows, n)
+    // tokens | positions | rows wanting logits | mask: ONE allocation in the order of the pinned staging block, one copy per decode() call
+    // (four separate copies cost ~20 us of every batched step)
+    ok = ok && dalloc(d.d_tokens, 3 * n + n * n_self);
+    if (ok) { d.d_pos = d.d_tokens + n; d.d_rows = d.d_pos + n; d.d_mask = (float *) (d.d_rows + n); }
+    ok = ok
             && dalloc(d.dx, n * S) && dalloc(d.dxn, n * S) && dalloc(d.dq, n * S) && dalloc(d.datt, n * S)
             && dalloc(d.dh, n * 4 * S) && dalloc(d.logits, (size_t) d.logits_rows_cap * hp.n_vocab)
             && dalloc(d.xattn, k::attn_cross_scratch_floats((int) n, (int) H, (int) T));
@@ -163,7 +167,7 @@ void destroy_state(State * st) {
     dfree(d.energy); if (d.energy_host) (void) hipHostFree(d.energy_host);
     dfree(d.pcm); dfree(d.mel); dfree(d.mel_max); dfree(d.mel_t); dfree(d.conv1); dfree(d.x); dfree(d.embd_conv);
     dfree(d.xn); dfree(d.q); dfree(d.k); dfree(d.vt); dfree(d.att); dfree(d.h); dfree(d.rowmax); dfree(d.enc_out);
-    dfree(d.enc_out_h); dfree(d.d_tokens); dfree(d.d_pos); dfree(d.d_mask); dfree(d.d_rows); dfree(d.dx); dfree(d.dxn);
+    dfree(d.enc_out_h); dfree(d.d_tokens); d.d_pos = nullptr; d.d_mask = nullptr; d.d_rows = nullptr; dfree(d.dx); dfree(d.dxn);
     dfree(d.dq); dfree(d.datt); dfree(d.dh); dfree(d.logits); dfree(d.xattn); dfree(d.ban_dev);
     dfree(d.aq); dfree(d.ads); dfree(d.aq16); dfree(d.wq16); dfree(d.att32); dfree(d.datt32);
     for (auto & sg : d.step_graphs) { if (sg.exec) (void) hipGraphExecDestroy(sg.exec); if (sg.graph) (void) hipGraphDestroy(sg.graph); sg = DeviceState::StepGraph{}; }
@@ -407,10 +411,9 @@ bool decode(whisper_context & ctx, const Batch & batch) {
         for (int i = 0; i < n_kv; ++i)
             p_mask[(size_t) j * n_kv + i] = (!kv.cells[i].has(seq) || kv.cells[i].pos > pos) ? -INFINITY : 0.0f;
     }
-    HIP_TRY(hipMemcpyAsync(d.d_tokens, p_tok, (size_t) n * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d.d_pos, p_pos, (size_t) n * 4, hipMemcpyHostToDevice, s));
-    if (!rows.empty()) HIP_TRY(hipMemcpyAsync(d.d_rows, p_rows, rows.size() * 4, hipMemcpyHostToDevice, s));
-    HIP_TRY(hipMemcpyAsync(d.d_mask, p_mask, (size_t) n * n_kv * 4, hipMemcpyHostToDevice, s));
+    // (the device block has the pinned block's layout for THIS n: tokens | positions | rows | mask, packed)
+    d.d_pos = d.d_tokens + n; d.d_rows = d.d_pos + n; d.d_mask = (float *) (d.d_rows + n);
+    HIP_TRY(hipMemcpyAsync(d.d_tokens, p_tok, ((size_t) 3 * n + (size_t) n * n_kv) * 4, hipMemcpyHostToDevice, s));
 
     if (ctx.model.quantised) {
         if (!decode_layers_q(ctx, n, n_kv, kv_head, Tc, rows)) return false;
@@ -588,9 +591,13 @@ bool sample_rows_device(whisper_context & ctx, const StepFilter * f, const int *
         hs[r].temperature = temperature > 0.0f ? temperature : 0.0f;
         for (int c = 0; c < k; ++c) hu[r * k + c] = u[r * k + c];
     }
-    HIP_TRY(hipMemcpyAsync(d.draw_dev, d.draw_host, OFF_OUT, hipMemcpyHostToDevice, s));
-    const k::DecStep * ds = (const k::DecStep *) d.draw_dev; const double * du = (const double *) ((char *) d.draw_dev + OFF_U);
-    k::SampleOut * dout = (k::SampleOut *) ((char *) d.draw_dev + OFF_OUT);
+    // The kernels read the step records and the uniform numbers straight from the pinned block and write their results into it: two small
+    // copies fewer per sampled step (WMI_DRAW_STAGED=1: through the device block, as before)
+    static const bool staged = getenv("WMI_DRAW_STAGED") != nullptr;
+    if (staged) HIP_TRY(hipMemcpyAsync(d.draw_dev, d.draw_host, OFF_OUT, hipMemcpyHostToDevice, s));
+    void * const blk = staged ? d.draw_dev : d.draw_host;
+    const k::DecStep * ds = (const k::DecStep *) blk; const double * du = (const double *) ((char *) blk + OFF_U);
+    k::SampleOut * dout = (k::SampleOut *) ((char *) blk + OFF_OUT);
     // rows that sit next to each other in d.logits go in one launch; the first step of a window draws every decoder from row 0
     bool contiguous = true;
     for (int r = 0; r < n_rows; ++r) contiguous = contiguous && rows[r] == rows[0] + r;
@@ -598,7 +605,7 @@ bool sample_rows_device(whisper_context & ctx, const StepFilter * f, const int *
     else for (int r = 0; r < n_rows; ++r)
         k::filter_draw(d.logits + (size_t) rows[r] * NV, d.ban_dev, ds + r, du + r * k, k, dout + r * k, d.draw_scratch, s, 1, tid_default);
     k::SampleOut * hout = (k::SampleOut *) ((char *) d.draw_host + OFF_OUT);
-    HIP_TRY(hipMemcpyAsync(hout, dout, (size_t) n_rows * k * sizeof(k::SampleOut), hipMemcpyDeviceToHost, s));
+    if (staged) HIP_TRY(hipMemcpyAsync(hout, dout, (size_t) n_rows * k * sizeof(k::SampleOut), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
     for (int i = 0; i < n_rows * k; ++i)
         out[i] = whisper_token_data{ hout[i].id, hout[i].tid, hout[i].p, hout[i].plog, hout[i].pt, hout[i].ptsum, -1, -1, 0.0f };
