@@ -275,7 +275,15 @@ __global__ __launch_bounds__(256) void k_attn_dec(const __half * __restrict__ q,
     // P.V: lane <-> value column, wavefront <-> key residue class
     float acc = 0.0f;
     const __half * vp = vc + head * 64 + lane;
-    for (int j = wave; j < n_kv; j += 4) acc = fmaf(sc[j], __half2float(vp[(size_t) j * S]), acc);
+    // eight value rows requested together (a row per trip was one dependent L2 round trip per key: ~25 in a row for the 100 cells of a
+    // five-beam step); accumulated in the same key order
+    for (int j0 = wave; j0 < n_kv; j0 += 32) {
+        __half vv[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { const int jj = j0 + 4 * t; vv[t] = vp[(size_t) (jj < n_kv ? jj : j0) * S]; }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { const int jj = j0 + 4 * t; if (jj < n_kv) acc = fmaf(sc[jj], __half2float(vv[t]), acc); }
+    }
     red[wave * 64 + lane] = acc;
     __syncthreads();
     if (tid < 64) {
