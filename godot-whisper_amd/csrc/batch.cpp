@@ -58,6 +58,7 @@ void free_lane_state(State * st) {
     if (d.mel_ev) (void) hipEventDestroy(d.mel_ev);
     dfree(d.pcm); dfree(d.mel); dfree(d.mel_max); dfree(d.energy);
     if (d.energy_host) (void) hipHostFree(d.energy_host);
+    if (d.ts_host) (void) hipHostFree(d.ts_host);
     delete st;
 }
 
@@ -639,6 +640,12 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
         const int ng = std::min(group, n_chunks - g0);
         std::vector<Row> rows(ng);
         static const int env_when_ = getenv("WMI_ENVELOPE_WHEN") ? atoi(getenv("WMI_ENVELOPE_WHEN")) : 0;
+        // WMI_TS_DEVICE=1 (not the default): the envelopes of a lock-step call stay in HBM and the window sums + walks of the token timestamps
+        // run there (device.cpp ts_refine_device, k_ts_refine: one wavefront per token, exact like the host's).  Measured: the mel phase
+        // loses the PCIe side of the envelopes (0.74 -> 0.57 ms) but the refinement kernel is bound by its longest token — a sequential
+        // f32 sum over up to 480 000 samples on ONE wavefront, 250 us on average — where eight host threads finish all chunks in 170-220 us:
+        // 6.32 against 6.14 ms per 8-chunk call (profiles/r04f_token_timestamps_on_device_not_default.txt)
+        static const bool ts_device = getenv("WMI_TS_DEVICE") && atoi(getenv("WMI_TS_DEVICE")) != 0;
         const bool env_interleaved = env_when_ == 0 || env_when_ >= 3;   // each chunk's envelope kernel right behind its mel kernels (3: into HBM, copied out beside the decode steps)
         // ---- per chunk: PCM -> mel, envelope, window bounds (the head of full())
         for (int r = 0; r < ng; ++r) {
@@ -656,7 +663,7 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
             }
             if (params.token_timestamps) {
                 ls.t_beg = 0; ls.t_last = 0; ls.tid_last = 0;
-                if (env_interleaved && n_samples[row.chunk] > 0 && !signal_energy_device(ctx, 32, false, env_when_ >= 3 ? 2 : 0)) { WMI_ERR("%s: failed to compute the signal envelope\n", __func__); return -2; }
+                if (env_interleaved && n_samples[row.chunk] > 0 && !signal_energy_device(ctx, 32, false, (ts_device && env_when_ == 0) ? 3 : env_when_ >= 3 ? 2 : 0)) { WMI_ERR("%s: failed to compute the signal envelope\n", __func__); return -2; }
             }
             b.t_mel_us += time_us() - tm0;
         }

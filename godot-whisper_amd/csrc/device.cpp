@@ -165,6 +165,7 @@ void destroy_state(State * st) {
     if (d.copy_stream) { (void) hipStreamSynchronize(d.copy_stream); (void) hipStreamDestroy(d.copy_stream); }
     if (d.energy_ev) (void) hipEventDestroy(d.energy_ev);
     dfree(d.energy); if (d.energy_host) (void) hipHostFree(d.energy_host);
+    if (d.ts_host) (void) hipHostFree(d.ts_host);
     dfree(d.pcm); dfree(d.mel); dfree(d.mel_max); dfree(d.mel_t); dfree(d.conv1); dfree(d.x); dfree(d.embd_conv);
     dfree(d.xn); dfree(d.q); dfree(d.k); dfree(d.vt); dfree(d.att); dfree(d.h); dfree(d.rowmax); dfree(d.enc_out);
     dfree(d.enc_out_h); dfree(d.d_tokens); d.d_pos = nullptr; d.d_mask = nullptr; d.d_rows = nullptr; dfree(d.dx); dfree(d.dxn);
@@ -233,6 +234,7 @@ bool signal_energy_device(whisper_context & ctx, int hw, bool sync, int via_dma)
         HIP_TRY(hipEventCreateWithFlags(&d.energy_ev, hipEventDisableTiming));
     }
     if (d.energy_pending) { HIP_TRY(hipStreamSynchronize(d.copy_stream)); d.energy_pending = false; }   // previous envelope still being written
+    d.energy_device_only = false;
     if ((size_t) n > d.energy_cap) {
         st.energy = nullptr; st.energy_n = 0; st.energy_bmin = st.energy_bmax = nullptr;
         if (d.energy_host) (void) hipHostFree(d.energy_host);
@@ -252,6 +254,10 @@ bool signal_energy_device(whisper_context & ctx, int hw, bool sync, int via_dma)
         // or the encoder, whichever they were queued next to.  One chunk: the direct stores (no copy call on the host's critical path).
         const size_t need = d.energy_cap + 2 * nb;
         if (via_dma && d.energy_dev_cap < need) { dfree(d.energy); d.energy_dev_cap = 0; if (dalloc(d.energy, need)) d.energy_dev_cap = need; else via_dma = 0; }
+        if (via_dma == 3) {
+            k::signal_energy(d.last_pcm, n, hw, d.energy, d.energy + d.energy_cap, d.energy + d.energy_cap + nb, d.copy_stream);
+            d.energy_device_only = true; d.energy_unflushed = false;
+        } else
         if (via_dma == 2) {
             // the kernel runs now, into HBM (~10 us); the copy to the pinned image is signal_energy_flush()'s thin kernel, later
             k::signal_energy(d.last_pcm, n, hw, d.energy, d.energy + d.energy_cap, d.energy + d.energy_cap + nb, d.copy_stream);
@@ -280,9 +286,32 @@ bool signal_energy_flush(State & st) {
     return hipGetLastError() == hipSuccess;
 }
 
+bool ts_refine_device(State & st, const k::TsTok * in, int n, k::TsOut * out) {
+    DeviceState & d = st.dev;
+    constexpr int CAP = 448;
+    if (n <= 0) return true;
+    if (n > CAP || !d.energy || !d.copy_stream) return false;
+    if (!d.ts_host && !HIP_OK(hipHostMalloc(&d.ts_host, CAP * (sizeof(k::TsTok) + sizeof(k::TsOut)), hipHostMallocDefault))) return false;
+    k::TsTok * hin = (k::TsTok *) d.ts_host; k::TsOut * hout = (k::TsOut *) (hin + CAP);
+    memcpy(hin, in, (size_t) n * sizeof(k::TsTok));
+    const size_t nb = (size_t) d.last_pcm_n / 256 + 2;
+    // the kernel reads its records from, and writes its results to, the pinned block; on the envelope's own stream (behind the envelope kernel)
+    k::ts_refine(d.energy, d.energy + d.energy_cap, d.energy + d.energy_cap + nb, d.last_pcm_n, hin, hout, n, d.copy_stream);
+    HIP_TRY(hipStreamSynchronize(d.copy_stream));
+    memcpy(out, hout, (size_t) n * sizeof(k::TsOut));
+    return true;
+}
+
 bool signal_energy_wait(State & st) {
     DeviceState & d = st.dev;
     if (!d.energy_pending) return true;
+    if (d.energy_device_only) {
+        HIP_TRY(hipStreamSynchronize(d.copy_stream));
+        st.energy = nullptr; st.energy_bmin = st.energy_bmax = nullptr; st.energy_n = d.last_pcm_n; st.energy_on_device = true;
+        d.energy_pending = false;
+        return true;
+    }
+    st.energy_on_device = false;
     if (d.energy_unflushed && !signal_energy_flush(st)) return false;
     HIP_TRY(hipStreamSynchronize(d.copy_stream));
     st.energy = d.energy_host; st.energy_n = d.last_pcm_n;

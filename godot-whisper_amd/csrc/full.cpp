@@ -474,6 +474,11 @@ void emit_window(whisper_context & ctx, State & st, const whisper_full_params & 
     if (prompt.front() == v.prev) prompt_past.insert(prompt_past.end(), prompt.begin() + 1, prompt.end() - n_prompt_init);
     for (int i = 0; i < result_len; ++i) prompt_past.push_back(toks[i].id);
 
+    // envelope in HBM (lock-step calls): the segments' envelope-side refinement is ONE device call per window instead of one per segment
+    // (nothing between the segments reads the refined times: no callback, no max_len re-wrap)
+    st.ts_defer = params.token_timestamps && params.max_len <= 0 && !params.new_segment_callback && !params.print_realtime;
+    st.ts_pending.clear();
+    struct Flush { whisper_context & c; State & s; ~Flush() { flush_token_timestamps(c, s); s.ts_defer = false; } } flush_guard{ctx, st};
     if (!toks.empty() && ctx.model.n_loaded > 0) {
         int i0 = 0;
         int64_t t0 = seek + 2 * (toks.front().tid - v.beg);
@@ -574,6 +579,65 @@ float seq_sum_f32(const float * p, int n) {
     return acc;
 }
 
+// The envelope stayed in HBM (lock-step calls): the window sums and the four walks a token may take are computed there, one wavefront per
+// token (k_ts_refine) — every token's sum and walks depend only on its own t0 / t1 as they stand after the first half of
+// token_level_timestamps.  What remains is the reference's sequential pass over a segment's tokens (clamps against the neighbours),
+// replayed here on those results:
+//   walk_down_while_above(s0)         -> w_down_above_s0                walk_up_while_below(s0, last = s1) -> w_up_below_s0
+//   walk_up_while_above(s1, n - 1)    -> w_up_above_s1
+//   walk_down_while_below(s1, first)  -> s1 <= first ? s1 : max(first, w_down_below_s1)      (the device walk has first = 0)
+// All pending segments of a window go in ONE device call.
+void flush_token_timestamps(whisper_context & ctx, State & st) {
+    if (st.ts_pending.empty()) return;
+    const Vocab & v = ctx.model.vocab;
+    const int n_samples = st.energy_n;
+    const int hw = WHISPER_SAMPLE_RATE / 8;
+    struct Ref { int seg, j; };
+    std::vector<k::TsTok> in; std::vector<Ref> ref;
+    for (int si : st.ts_pending) {
+        auto & tokens = st.result_all[si].tokens;
+        for (int j = 0; j < (int) tokens.size(); ++j) {
+            if (tokens[j].id >= v.eot) continue;
+            const int s0 = ts_to_sample(tokens[j].t0, n_samples), s1 = ts_to_sample(tokens[j].t1, n_samples);
+            in.push_back(k::TsTok{ s0, s1, std::max(s0 - hw, 0), std::min(s1 + hw, n_samples) });
+            ref.push_back(Ref{ si, j });
+        }
+    }
+    st.ts_pending.clear();
+    std::vector<k::TsOut> res(in.size());
+    for (size_t q0 = 0; q0 < in.size(); q0 += 448) {            // (the pinned block holds 448 records)
+        const int cnt = (int) std::min<size_t>(448, in.size() - q0);
+        if (!ts_refine_device(st, in.data() + q0, cnt, res.data() + q0)) { WMI_ERR("%s: timestamp refinement on the device failed\n", __func__); return; }
+    }
+    for (size_t q = 0; q < ref.size(); ++q) {                    // segments in order, tokens in order: the reference's loop
+        auto & tokens = st.result_all[ref[q].seg].tokens;
+        const int n = (int) tokens.size(), j = ref[q].j;
+        const k::TsOut & r = res[q];
+        int s0 = in[q].s0, s1 = in[q].s1;
+        const int ns = in[q].a1 - in[q].a0;
+        if (r.e0 && j > 0) {
+            const int k2 = r.w_down_above_s0;
+            tokens[j].t0 = sample_to_ts(k2);
+            if (tokens[j].t0 < tokens[j - 1].t1) tokens[j].t0 = tokens[j - 1].t1; else s0 = k2;
+        } else {
+            const int k2 = r.w_up_below_s0;
+            s0 = k2;
+            tokens[j].t0 = sample_to_ts(k2);
+        }
+        if (r.e1) {
+            const int k2 = r.w_up_above_s1;
+            tokens[j].t1 = sample_to_ts(k2);
+            // (`j < ns - 1`: the reference's test against the window length, see the host loop below)
+            if (j < ns - 1 && j + 1 < n && tokens[j].t1 > tokens[j + 1].t0) tokens[j].t1 = tokens[j + 1].t0; else s1 = k2;
+        } else {
+            const int k2 = s1 <= s0 ? s1 : std::max(s0, r.w_down_below_s1);
+            s1 = k2;
+            tokens[j].t1 = sample_to_ts(k2);
+        }
+        (void) s1;
+    }
+}
+
 void token_level_timestamps(whisper_context & ctx, State & st, int i_segment, float thold_pt, float thold_ptsum) {
     const Vocab & v = ctx.model.vocab;
     Segment & seg = st.result_all[i_segment];
@@ -633,6 +697,8 @@ void token_level_timestamps(whisper_context & ctx, State & st, int i_segment, fl
 
     // expand / contract by voice activity
     const int hw = WHISPER_SAMPLE_RATE / 8;
+    if (st.energy_on_device && st.ts_defer) { st.ts_pending.push_back(i_segment); return; }
+    if (st.energy_on_device) { st.ts_pending.assign(1, i_segment); flush_token_timestamps(ctx, st); return; }
     const float * en = st.energy;                    // pinned host memory the GPU wrote (device.cpp: signal_energy_device)
     // The walks below ("move left/right while the envelope stays above/below the threshold") run to the end of
     // the signal on stationary audio — millions of scalar steps per call in the reference.  They are pure

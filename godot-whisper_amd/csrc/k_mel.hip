@@ -443,6 +443,119 @@ void signal_energy(const float * pcm, int n, int hw, float * out, float * bmin, 
     hipLaunchKernelGGL(k_signal_energy, dim3(thin > 0 && thin < nblk ? thin : nblk), dim3(256), 0, st, pcm, n, hw, out, bmin, bmax);
 }
 
+// ---------------------------------------------------------------- token timestamps: window sums + walks over the envelope (kernels.h TsTok / TsOut)
+// walk: the first position p in k, k + dir, k + 2 dir, ... with p == bound or NOT cont(en[p]), cont(x) = above ? x > th : x < th — the
+// reference's `while (cont(en[k]) && k != bound) k += dir` — 64 samples per trip, whole 256-sample blocks skipped on the block extrema
+// (all above th <=> block minimum > th, all below <=> block maximum < th) as the host walks do.  A NaN threshold stops at once, as there.
+__device__ __forceinline__ int ts_walk(const float * __restrict__ en, const float * __restrict__ bext, int k, int bound, float th, int dir, bool above, int lane) {
+    for (;;) {
+        const int dist = dir > 0 ? bound - k : k - bound;
+        if (dist <= 0) return k;
+        const bool edge = dir > 0 ? (k & 255) == 0 : (k & 255) == 255;
+        if (edge) {
+            const int b = (k >> 8) + dir * lane;
+            const bool inside = dir > 0 ? ((b + 1) << 8) <= bound : (b >= 0 && (b << 8) > bound);
+            bool cont = false;
+            if (inside) { const float e = bext[b]; cont = above ? e > th : e < th; }
+            const unsigned long long m = __ballot(cont);
+            const int nskip = m == ~0ull ? 64 : __builtin_ctzll(~m);
+            if (nskip > 0) { k += dir * 256 * nskip; continue; }
+        }
+        const int to_edge = dir > 0 ? 256 - (k & 255) : (k & 255) + 1;
+        int cnt = dist + 1; if (cnt > 64) cnt = 64; if (cnt > to_edge) cnt = to_edge;
+        const int p = k + dir * lane;
+        bool stop = false;
+        if (lane < cnt) { const float x = en[p]; stop = p == bound || !(above ? x > th : x < th); }
+        const unsigned long long m = __ballot(stop);
+        if (m) return k + dir * __builtin_ctzll(m);
+        k += dir * cnt;
+    }
+}
+
+__global__ __launch_bounds__(64) void k_ts_refine(const float * __restrict__ en, const float * __restrict__ bmin, const float * __restrict__ bmax,
+                                                  int n_samples, const TsTok * __restrict__ in, TsOut * __restrict__ out) {
+    const int lane = threadIdx.x;
+    const TsTok t = in[blockIdx.x];
+    // ---- sum of en[a0 .. a1) = the loop `s = 0; for (i) s += en[i]` in f32, left to right.  As on the host (full.cpp seq_sum_f32, pinned by
+    // tests/test_abi.py::test_sequential_sum_is_exact): while the accumulator stays in one binade it is a multiple of ulp = 2^(E-23) and adding x
+    // adds rne(x / ulp) units — an integer sum, order-free — unless x / ulp is a tie (.5 exactly), negative, NaN or >= 2^23 units, or the total
+    // leaves the binade; such a block of 256 elements is added the plain way, one f32 addition per element in index order.
+    float acc = 0.0f;
+    {
+        const float * p = en + t.a0;
+        const int n = t.a1 - t.a0;
+        // 1 024 samples per trip (16 per lane, element e of a trip = 256 sub + 64 k + lane), the next trip's loads in flight while this one is
+        // added: a trip without prefetch was one L2 round trip per 256 samples — 1.9 ms for a 30 s window
+        constexpr int R = 16;
+        float cur[R], nxt[R];
+        auto fetch = [&](float (&dst)[R], int base) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) { const int e = base + r * 64 + lane; dst[r] = e < n ? p[e] : 0.0f; }
+        };
+        fetch(cur, 0);
+        for (int i = 0; i < n; i += 1024) {
+            fetch(nxt, i + 1024);
+#pragma unroll
+            for (int sub = 0; sub < 4; ++sub) {
+                const int b0 = i + sub * 256;
+                if (b0 >= n) break;
+                const uint32_t bits = __float_as_uint(acc);
+                const int E = (int) ((bits >> 23) & 0xFF) - 127;
+                bool done = false;
+                if (b0 + 256 <= n && (bits >> 31) == 0 && E >= -100 && E <= 100) {
+                    const uint32_t units = (bits & 0x7FFFFFu) | 0x800000u;
+                    const float scale = __uint_as_float((uint32_t) (127 + 23 - E) << 23);
+                    bool bad = false; uint32_t isum = 0;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float tt = cur[sub * 4 + k] * scale;
+                        const int q = __float2int_rn(tt);
+                        const float d = fabsf(tt - (float) q);
+                        bad = bad || d == 0.5f || !(tt < 8388608.0f) || tt < 0.0f;
+                        isum += (uint32_t) q;
+                    }
+                    if (__ballot(bad) == 0) {
+                        _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) isum += (uint32_t) __shfl_xor((int) isum, o);
+                        const unsigned long long total = (unsigned long long) units + isum;
+                        if (total < 0x1000000ull) { acc = __uint_as_float(((uint32_t) (E + 127) << 23) | ((uint32_t) total & 0x7FFFFFu)); done = true; }
+                    }
+                }
+                if (!done) {                                     // the plain way: one f32 addition per element, in index order
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const int c0 = b0 + k * 64;
+                        const int cnt = n - c0 < 64 ? n - c0 : 64;
+                        const float v = cur[sub * 4 + k];
+                        if (cnt >= 64) {
+#pragma unroll
+                            for (int l = 0; l < 64; ++l) acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+                        } else {
+                            for (int l = 0; l < cnt; ++l) acc = acc + __shfl(v, l);
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < R; ++r) cur[r] = nxt[r];
+        }
+    }
+    const int ns = t.a1 - t.a0;
+    const float th = (float) (0.5 * (double) acc / (double) ns);            // `const float thold = 0.5 * sum / ns;`
+    const float x0 = en[t.s0], x1 = en[t.s1];
+    const int wa = ts_walk(en, bmin, t.s0, 0, th, -1, true, lane);
+    const int wb = ts_walk(en, bmax, t.s0, t.s1, th, +1, false, lane);
+    const int wc = ts_walk(en, bmin, t.s1, n_samples - 1, th, +1, true, lane);
+    const int wd = ts_walk(en, bmax, t.s1, 0, th, -1, false, lane);
+    if (lane == 0) {
+        TsOut o; o.sum = acc; o.thold = th; o.e0 = x0 > th ? 1 : 0; o.e1 = x1 > th ? 1 : 0;
+        o.w_down_above_s0 = wa; o.w_up_below_s0 = wb; o.w_up_above_s1 = wc; o.w_down_below_s1 = wd;
+        out[blockIdx.x] = o;
+    }
+}
+void ts_refine(const float * en, const float * bmin, const float * bmax, int n_samples, const TsTok * in, TsOut * out, int n_tok, hipStream_t st) {
+    if (n_tok > 0) hipLaunchKernelGGL(k_ts_refine, dim3(n_tok), dim3(64), 0, st, en, bmin, bmax, n_samples, in, out);
+}
+
 // A copy by a handful of workgroups: 16 bytes per lane and trip, four trips in flight.  Used for the |x| envelopes of a lock-step call
 // (15 MB to pinned host memory for 8 chunks): as stores of the full-grid envelope kernel — or of the runtime's blit kernel — thousands
 // of wavefronts queue megabytes of PCIe writes at once, and the 32-byte results of the decode steps running beside them wait behind

@@ -192,6 +192,8 @@ struct DeviceState {
     hipStream_t copy_stream = nullptr; hipEvent_t energy_ev = nullptr;   // envelope D2H overlaps the encoder
     hipStream_t mel_stream = nullptr;  hipEvent_t mel_ev = nullptr;      // lock-step chunks: the mel kernels of the chunks overlap
     bool    energy_pending = false;                            // copy in flight: signal_energy_wait() before reading state.energy
+    bool    energy_device_only = false;                        // the envelope stays in HBM: the timestamp walks run there too (ts_refine_device), nothing crosses PCIe
+    void *  ts_host = nullptr;                                 // pinned block: TsTok[448] | TsOut[448] (ts_refine_device)
     bool    energy_unflushed = false;                          // the envelope sits in the device buffer `energy`: signal_energy_flush() starts its copy to the pinned image
     // encoder activations, token-major
     __half * mel_t = nullptr;                                 // [2T+2+pad][n_mel_pad] f16, rows -1 and 2T are zero
@@ -258,6 +260,8 @@ struct State {
     int64_t t_beg = 0, t_last = 0; int32_t tid_last = 0;
     const float * energy = nullptr; int energy_n = 0;   // |x| envelope of the last PCM (view of dev.energy_host)
     const float * energy_bmin = nullptr, * energy_bmax = nullptr;   // its per-256-sample block extrema
+    bool energy_on_device = false;
+    bool ts_defer = false; std::vector<int> ts_pending;     // emit_window: segments whose envelope-side refinement runs as ONE device call at the end of the window                      // energy == nullptr: the envelope lives in dev.energy, use ts_refine_device()
     int32_t exp_n_audio_ctx = 0;
     int     enc_n_ctx = 0;                        // n_ctx of the last encode (cross cache extent)
     DeviceState dev;
@@ -378,6 +382,10 @@ int    step_stamps(whisper_context & ctx, double * out, int cap, bool chained);
 // |x| envelope of the last PCM on the GPU; the D2H copy runs on a side stream while the encoder works.
 // sync = false: state.energy is valid only after signal_energy_wait()
 bool signal_energy_device(whisper_context & ctx, int hw, bool sync = true, int via_dma = 0);   // via_dma 1: kernel -> device buffer -> hipMemcpyAsync; 2: kernel -> device buffer now, signal_energy_flush() later
+// via_dma 3: the envelope is computed into HBM and STAYS there (lock-step calls): token_level_timestamps() asks ts_refine_device() for the
+// window sums and walks instead of reading it (15 MB of PCIe writes per 8-chunk call, ~0.3 ms of whatever runs beside them, are not made)
+bool ts_refine_device(State & st, const k::TsTok * in, int n, k::TsOut * out);
+void flush_token_timestamps(whisper_context & ctx, State & st);      // full.cpp: the pending segments' envelope-side refinement, one device call
 bool signal_energy_flush(State & st);             // via_dma 2: a THIN copy kernel moves the envelope to the pinned image (lock-step calls: beside the decode steps)
 bool signal_energy_wait(State & st);
 
