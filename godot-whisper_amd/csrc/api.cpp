@@ -410,6 +410,51 @@ int wmi_resample(struct whisper_context * ctx, const float * src, int n_frames, 
     } catch (...) { WMI_ERR("wmi_resample: out of memory\n"); return -3; }
 }
 
+int wmi_selftest_ts_refine(struct whisper_context * ctx, const float * envelope, int n, const int * s0s1, int n_tok, float * sums, float * thold, int * walks) {
+    if (!ctx || !envelope || n <= 0 || !s0s1 || n_tok <= 0 || n_tok > 4096 || !sums || !thold || !walks) return -1;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    if (!compute_ready(*ctx, __func__)) return -2;
+    try {
+        (void) hipSetDevice(ctx->device);
+        const size_t nb = (size_t) n / 256 + 2;
+        std::vector<float> ext(2 * nb, 0.0f);                     // block minima | maxima, as k_signal_energy writes them
+        for (size_t b = 0; b * 256 < (size_t) n; ++b) {
+            float lo = INFINITY, hi = -INFINITY;
+            for (size_t i = b * 256; i < std::min<size_t>((b + 1) * 256, (size_t) n); ++i) { lo = std::min(lo, envelope[i]); hi = std::max(hi, envelope[i]); }
+            ext[b] = lo; ext[nb + b] = hi;
+        }
+        std::vector<k::TsTok> in(n_tok);
+        for (int t = 0; t < n_tok; ++t) {
+            const int s0 = s0s1[2 * t], s1 = s0s1[2 * t + 1];
+            if (s0 < 0 || s0 >= n || s1 < 0 || s1 >= n) return -1;
+            in[t] = k::TsTok{ s0, s1, std::max(s0 - 2000, 0), std::min(s1 + 2000, n) };
+        }
+        float * d_en = nullptr, * d_ext = nullptr; k::TsTok * d_in = nullptr; k::TsOut * d_out = nullptr;
+        hipStream_t s = ctx->state->dev.stream;
+        bool ok = HIP_OK(hipMalloc((void **) &d_en, (size_t) n * 4)) && HIP_OK(hipMalloc((void **) &d_ext, 2 * nb * 4)) &&
+                  HIP_OK(hipMalloc((void **) &d_in, (size_t) n_tok * sizeof(k::TsTok))) && HIP_OK(hipMalloc((void **) &d_out, (size_t) n_tok * sizeof(k::TsOut)));
+        std::vector<k::TsOut> out(n_tok);
+        if (ok) {
+            ok = HIP_OK(hipMemcpyAsync(d_en, envelope, (size_t) n * 4, hipMemcpyHostToDevice, s)) &&
+                 HIP_OK(hipMemcpyAsync(d_ext, ext.data(), 2 * nb * 4, hipMemcpyHostToDevice, s)) &&
+                 HIP_OK(hipMemcpyAsync(d_in, in.data(), (size_t) n_tok * sizeof(k::TsTok), hipMemcpyHostToDevice, s));
+            if (ok) k::ts_refine(d_en, d_ext, d_ext + nb, n, d_in, d_out, n_tok, s);
+            ok = ok && HIP_OK(hipMemcpyAsync(out.data(), d_out, (size_t) n_tok * sizeof(k::TsOut), hipMemcpyDeviceToHost, s)) && HIP_OK(hipStreamSynchronize(s));
+        }
+        if (d_en) (void) hipFree(d_en); if (d_ext) (void) hipFree(d_ext); if (d_in) (void) hipFree(d_in); if (d_out) (void) hipFree(d_out);
+        if (!ok) return -3;
+        for (int t = 0; t < n_tok; ++t) {
+            sums[t] = out[t].sum; thold[t] = out[t].thold;
+            int * w = walks + 6 * t;
+            w[0] = out[t].e0; w[1] = out[t].e1; w[2] = out[t].w_down_above_s0; w[3] = out[t].w_up_below_s0; w[4] = out[t].w_up_above_s1; w[5] = out[t].w_down_below_s1;
+        }
+        return 0;
+    } catch (const std::exception & e) {
+        WMI_ERR("%s: %s\n", __func__, e.what());
+        return -9;
+    }
+}
+
 int wmi_selftest_resample_plan(int n_frames, int src_rate, int dst_rate, int converter, long long * frames_gen, long long * frames_used,
                                int * closed_form, int n_pos, long long * pos, double * frac) {
     if (n_frames < 0 || src_rate <= 0 || dst_rate <= 0 || src_rate == dst_rate || n_pos < 0 || (n_pos > 0 && (!pos || !frac))) return -1;

@@ -198,6 +198,13 @@ WHISPER_API double wmi_selftest_proj(struct whisper_context * ctx, int op, int n
  * mono frames at src_rate -> dst_rate (output capacity int(n_frames * ratio) as the host passes it), and the first n_pos output
  * positions (integer sample, fraction) the kernel would use.  Returns 0, or the converter error as wmi_resample logs it.
  * closed_form: 1 when the positions come from the exact 128-bit product, 0 when the host ran the double recurrence. */
+/* Test hook for the device form of the token timestamps' envelope side (csrc/k_mel.hip k_ts_refine; opt-in, WMI_TS_DEVICE=1):
+ * `envelope` [n] is a host array standing in for the |x| envelope; for each of the n_tok tokens, s0s1[2 t] / s0s1[2 t + 1] are its start / end
+ * sample.  Writes per token sums[t] = the sequential f32 sum of envelope[max(s0 - 2000, 0) .. min(s1 + 2000, n)), thold[t], and
+ * walks[6 t ..] = { en[s0] > thold, en[s1] > thold, walk_down_while_above(s0), walk_up_while_below(s0, s1), walk_up_while_above(s1, n - 1),
+ * walk_down_while_below(s1, 0) } — the loops of W/whisper.cpp:6540-6590.  Returns 0, or < 0 on argument / device errors. */
+WHISPER_API int wmi_selftest_ts_refine(struct whisper_context * ctx, const float * envelope, int n, const int * s0s1, int n_tok,
+                                       float * sums, float * thold, int * walks);
 WHISPER_API int wmi_selftest_resample_plan(int n_frames, int src_rate, int dst_rate, int converter, long long * frames_gen,
                                            long long * frames_used, int * closed_form, int n_pos, long long * pos, double * frac);
 

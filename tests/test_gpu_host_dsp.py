@@ -211,3 +211,60 @@ def test_resampler_on_device_pointers_feed_the_transcription(product_lib, node, 
         assert product_lib.wmi_vad(node.ctx, d_16k, n16, 1, 2.0, 200.0, None) in (0, 1)
     finally:
         hip.hipFree(d_fr); hip.hipFree(d_mono); hip.hipFree(d_16k)
+
+
+# ------------------------------------------------------------------------------------------------ token timestamps, envelope side on the device
+def _ts_reference(en, s0, s1, hw=2000):
+    """The loops of W/whisper.cpp:6500-6590 for one token on a host envelope (numpy.cumsum in float32 is the sequential left-to-right sum)."""
+    n = en.size
+    a0, a1 = max(s0 - hw, 0), min(s1 + hw, n)
+    total = np.float32(0.0) if a1 <= a0 else np.cumsum(en[a0:a1], dtype=np.float32)[-1]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        th = np.float32(0.5 * np.float64(total) / np.float64(a1 - a0))
+    def walk(k, bound, d, above):
+        cont = (lambda x: x > th) if above else (lambda x: x < th)
+        while k != bound and (d > 0) == (k < bound) and cont(en[k]):
+            k += d
+        return k
+    return total, th, [int(en[s0] > th), int(en[s1] > th), walk(s0, 0, -1, True), walk(s0, s1, +1, False), walk(s1, n - 1, +1, True), walk(s1, 0, -1, False)]
+
+
+@pytest.mark.parametrize("kind", ["noise", "ties", "steps", "crossing", "silence", "tiny"])
+def test_token_timestamp_sums_and_walks_on_the_device_equal_the_sequential_loops(product_lib, kind):
+    """csrc/k_mel.hip k_ts_refine (the opt-in device form of token_level_timestamps' envelope side, WMI_TS_DEVICE=1): per token the
+    sequential f32 window sum — taken as order-free integer sums while the running sum stays in one binade, the plain way across ties
+    and binade crossings —, the threshold, and the four walks with their block skips.  Every value must equal the plain loops on
+    envelopes built to hit those cases: noise, values that are exact half-ulps of the running sum, long constant runs (whole blocks
+    skipped on the extrema), sums crossing many binades, all-zero stretches, denormal-sized values."""
+    rng = np.random.default_rng({"noise": 1, "ties": 2, "steps": 3, "crossing": 4, "silence": 5, "tiny": 6}[kind])
+    n = 200_000
+    if kind == "noise":
+        en = np.abs(rng.standard_normal(n)).astype(np.float32) * 0.05
+    elif kind == "ties":                                   # multiples of 2^-k: sums hit exact ties again and again
+        en = (rng.integers(0, 8, n).astype(np.float32) * np.float32(2.0 ** -9)) + np.float32(2.0 ** -13) * rng.integers(0, 2, n).astype(np.float32)
+    elif kind == "steps":
+        en = np.repeat(np.abs(rng.standard_normal(n // 1000)).astype(np.float32), 1000) * 0.1
+    elif kind == "crossing":
+        en = (np.float32(1e-6) * np.exp(np.linspace(0, 14, n)).astype(np.float32) * (1 + 0.1 * rng.random(n).astype(np.float32))).astype(np.float32)
+    elif kind == "silence":
+        en = np.zeros(n, np.float32); en[50_000:50_300] = 0.2; en[120_000:150_000] = np.abs(rng.standard_normal(30_000)).astype(np.float32) * 0.01
+    else:
+        en = (rng.random(n).astype(np.float32) * np.float32(1e-38)).astype(np.float32)
+    toks = []
+    for _ in range(24):
+        a = int(rng.integers(0, n - 2)); b = int(min(n - 1, a + rng.integers(1, 60_000)))
+        toks.append((a, b))
+    toks += [(0, n - 1), (n - 1, n - 1), (0, 0), (255, 256), (256, 511), (70_000, 69_000)]       # whole signal, degenerate and reversed tokens
+    s0s1 = np.array(toks, np.int32)
+    node = host.SpeechToText(product_lib); node.set_language_model(synth.make_model("micro.en", seed=1234))
+    try:
+        sums = np.zeros(len(toks), np.float32); th = np.zeros(len(toks), np.float32); walks = np.zeros((len(toks), 6), np.int32)
+        rc = product_lib.wmi_selftest_ts_refine(node.ctx, en.ctypes.data, n, s0s1.ctypes.data, len(toks), sums.ctypes.data, th.ctypes.data, walks.ctypes.data)
+        assert rc == 0
+    finally:
+        node.close()
+    for t, (a, b) in enumerate(toks):
+        want_sum, want_th, want_walks = _ts_reference(en, a, b)
+        assert sums[t].tobytes() == np.float32(want_sum).tobytes(), (kind, t, a, b, sums[t], want_sum)
+        assert th[t].tobytes() == np.float32(want_th).tobytes() or (np.isnan(th[t]) and np.isnan(want_th)), (kind, t, th[t], want_th)
+        assert walks[t].tolist() == want_walks, (kind, t, a, b, walks[t].tolist(), want_walks)
