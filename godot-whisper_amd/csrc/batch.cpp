@@ -640,12 +640,12 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
         const int ng = std::min(group, n_chunks - g0);
         std::vector<Row> rows(ng);
         static const int env_when_ = getenv("WMI_ENVELOPE_WHEN") ? atoi(getenv("WMI_ENVELOPE_WHEN")) : 0;
-        // WMI_TS_DEVICE=1 (not the default): the envelopes of a lock-step call stay in HBM and the window sums + walks of the token timestamps
-        // run there (device.cpp ts_refine_device, k_ts_refine: one wavefront per token, exact like the host's).  Measured: the mel phase
-        // loses the PCIe side of the envelopes (0.74 -> 0.57 ms) but the refinement kernel is bound by its longest token — a sequential
-        // f32 sum over up to 480 000 samples on ONE wavefront, 250 us on average — where eight host threads finish all chunks in 170-220 us:
-        // 6.32 against 6.14 ms per 8-chunk call (profiles/r04f_token_timestamps_on_device_not_default.txt)
-        static const bool ts_device = getenv("WMI_TS_DEVICE") && atoi(getenv("WMI_TS_DEVICE")) != 0;
+        // The envelopes of a lock-step call stay in HBM and the window sums + walks of the token timestamps run there (device.cpp
+        // ts_refine_device, k_ts_refine: one workgroup per token, the window sum as order-free integer sums per binade over eight wavefronts —
+        // every value equals the host loop's, tests/test_gpu_host_dsp.py).  15 MB of PCIe writes per 8-chunk call are not made: mel phase
+        // 0.74 -> 0.54 ms, segments + timestamps 0.20 -> 0.31 ms (one device call per window and chunk), 5.99 -> 5.84 ms per call
+        // (profiles/r04g_token_timestamps_on_device.txt).  WMI_TS_DEVICE=0: envelopes to pinned host memory, sums and walks on the host.
+        static const bool ts_device = !(getenv("WMI_TS_DEVICE") && atoi(getenv("WMI_TS_DEVICE")) == 0);
         const bool env_interleaved = env_when_ == 0 || env_when_ >= 3;   // each chunk's envelope kernel right behind its mel kernels (3: into HBM, copied out beside the decode steps)
         // ---- per chunk: PCM -> mel, envelope, window bounds (the head of full())
         for (int r = 0; r < ng; ++r) {

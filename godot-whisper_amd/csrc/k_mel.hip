@@ -472,73 +472,135 @@ __device__ __forceinline__ int ts_walk(const float * __restrict__ en, const floa
     }
 }
 
-__global__ __launch_bounds__(64) void k_ts_refine(const float * __restrict__ en, const float * __restrict__ bmin, const float * __restrict__ bmax,
-                                                  int n_samples, const TsTok * __restrict__ in, TsOut * __restrict__ out) {
-    const int lane = threadIdx.x;
+// One trip of <= 1 024 samples starting at p (n_left of them exist), added to acc by ONE wavefront: per 256-element block the integer form where
+// it is exact (see k_ts_refine), else one f32 addition per element in index order.  x[r] = element 64 r + lane of the trip (0 past the end).
+__device__ __forceinline__ float ts_trip_exact(float acc, const float (&x)[16], int n_left, int lane) {
+#pragma unroll
+    for (int sub = 0; sub < 4; ++sub) {
+        const int b0 = sub * 256;
+        if (b0 >= n_left) break;
+        const uint32_t bits = __float_as_uint(acc);
+        const int E = (int) ((bits >> 23) & 0xFF) - 127;
+        bool done = false;
+        if (b0 + 256 <= n_left && (bits >> 31) == 0 && E >= -100 && E <= 100) {
+            const uint32_t units = (bits & 0x7FFFFFu) | 0x800000u;
+            const float scale = __uint_as_float((uint32_t) (127 + 23 - E) << 23);
+            bool bad = false; uint32_t isum = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float tt = x[sub * 4 + k] * scale;
+                const int q = __float2int_rn(tt);
+                const float d = fabsf(tt - (float) q);
+                bad = bad || d == 0.5f || !(tt < 8388608.0f) || tt < 0.0f;
+                isum += (uint32_t) q;
+            }
+            if (__ballot(bad) == 0) {
+                _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) isum += (uint32_t) __shfl_xor((int) isum, o);
+                const unsigned long long total = (unsigned long long) units + isum;
+                if (total < 0x1000000ull) { acc = __uint_as_float(((uint32_t) (E + 127) << 23) | ((uint32_t) total & 0x7FFFFFu)); done = true; }
+            }
+        }
+        if (!done) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int c0 = b0 + k * 64;
+                const int cnt = n_left - c0 < 64 ? n_left - c0 : 64;
+                const float v = x[sub * 4 + k];
+                if (cnt >= 64) {
+#pragma unroll
+                    for (int l = 0; l < 64; ++l) acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+                } else {
+                    for (int l = 0; l < cnt; ++l) acc = acc + __shfl(v, l);
+                }
+            }
+        }
+    }
+    return acc;
+}
+
+// One workgroup of TS_W wavefronts per token.
+//  * window sum = the loop `s = 0; for (i) s += en[i]` in f32, left to right.  As on the host (full.cpp seq_sum_f32, pinned by
+//    tests/test_abi.py::test_sequential_sum_is_exact): while the accumulator stays in one binade [2^E, 2^(E+1)) it is a multiple of
+//    ulp = 2^(E-23) and adding x adds rne(x / ulp) units — an integer sum, ORDER-FREE — unless x / ulp is a tie (.5 exactly), negative, NaN
+//    or >= 2^23 units, or the total leaves the binade.  So the wavefronts take the next TS_W trips of 1 024 samples side by side, all with
+//    the exponent the sum has NOW; the trips are then accepted in order while the running total stays below 2^24 units and no trip saw an
+//    exception; the first trip that is not accepted (a binade crossing — ~20 per window, the envelope is non-negative —, a tie, the tail) is
+//    added by wavefront 0 the careful way (ts_trip_exact), and the rest start again from there with the new exponent.
+//  * threshold and the four walks: wavefront 0.
+constexpr int TS_W = 8;
+__global__ __launch_bounds__(TS_W * 64) void k_ts_refine(const float * __restrict__ en, const float * __restrict__ bmin, const float * __restrict__ bmax,
+                                                         int n_samples, const TsTok * __restrict__ in, TsOut * __restrict__ out) {
+    __shared__ uint32_t s_sum[TS_W]; __shared__ int s_bad[TS_W]; __shared__ float s_acc;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const TsTok t = in[blockIdx.x];
-    // ---- sum of en[a0 .. a1) = the loop `s = 0; for (i) s += en[i]` in f32, left to right.  As on the host (full.cpp seq_sum_f32, pinned by
-    // tests/test_abi.py::test_sequential_sum_is_exact): while the accumulator stays in one binade it is a multiple of ulp = 2^(E-23) and adding x
-    // adds rne(x / ulp) units — an integer sum, order-free — unless x / ulp is a tie (.5 exactly), negative, NaN or >= 2^23 units, or the total
-    // leaves the binade; such a block of 256 elements is added the plain way, one f32 addition per element in index order.
     float acc = 0.0f;
     {
         const float * p = en + t.a0;
         const int n = t.a1 - t.a0;
-        // 1 024 samples per trip (16 per lane, element e of a trip = 256 sub + 64 k + lane), the next trip's loads in flight while this one is
-        // added: a trip without prefetch was one L2 round trip per 256 samples — 1.9 ms for a 30 s window
-        constexpr int R = 16;
-        float cur[R], nxt[R];
-        auto fetch = [&](float (&dst)[R], int base) {
+        auto fetch = [&](float (&dst)[16], int base) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) { const int e = base + r * 64 + lane; dst[r] = e < n ? p[e] : 0.0f; }
+            for (int r = 0; r < 16; ++r) { const int e = base + r * 64 + lane; dst[r] = (e >= 0 && e < n) ? p[e] : 0.0f; }
         };
-        fetch(cur, 0);
-        for (int i = 0; i < n; i += 1024) {
-            fetch(nxt, i + 1024);
+        float x[16], nx[16]; int nx_base = -1;
+        int i = 0;
+        while (i < n) {
+            const int base = i + wave * 1024;
+            if (nx_base == base) {
 #pragma unroll
-            for (int sub = 0; sub < 4; ++sub) {
-                const int b0 = i + sub * 256;
-                if (b0 >= n) break;
-                const uint32_t bits = __float_as_uint(acc);
-                const int E = (int) ((bits >> 23) & 0xFF) - 127;
-                bool done = false;
-                if (b0 + 256 <= n && (bits >> 31) == 0 && E >= -100 && E <= 100) {
-                    const uint32_t units = (bits & 0x7FFFFFu) | 0x800000u;
-                    const float scale = __uint_as_float((uint32_t) (127 + 23 - E) << 23);
-                    bool bad = false; uint32_t isum = 0;
+                for (int r = 0; r < 16; ++r) x[r] = nx[r];
+            } else fetch(x, base);
+            nx_base = base + TS_W * 1024;
+            if (nx_base < n) fetch(nx, nx_base); else nx_base = -1;          // the next round's trip of this wavefront, if this round is accepted whole
+            const uint32_t bits = __float_as_uint(acc);
+            const int E = (int) ((bits >> 23) & 0xFF) - 127;
+            const bool fast = (bits >> 31) == 0 && E >= -100 && E <= 100;
+            bool bad = !fast || base + 1024 > n;
+            uint32_t isum = 0;
+            if (!bad) {
+                const float scale = __uint_as_float((uint32_t) (127 + 23 - E) << 23);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const float tt = cur[sub * 4 + k] * scale;
-                        const int q = __float2int_rn(tt);
-                        const float d = fabsf(tt - (float) q);
-                        bad = bad || d == 0.5f || !(tt < 8388608.0f) || tt < 0.0f;
-                        isum += (uint32_t) q;
-                    }
-                    if (__ballot(bad) == 0) {
-                        _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) isum += (uint32_t) __shfl_xor((int) isum, o);
-                        const unsigned long long total = (unsigned long long) units + isum;
-                        if (total < 0x1000000ull) { acc = __uint_as_float(((uint32_t) (E + 127) << 23) | ((uint32_t) total & 0x7FFFFFu)); done = true; }
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const float tt = x[r] * scale;
+                    const int q = __float2int_rn(tt);
+                    const float d = fabsf(tt - (float) q);
+                    bad = bad || d == 0.5f || !(tt < 8388608.0f) || tt < 0.0f;
+                    isum += (uint32_t) q;                                    // <= 16 x 2^23
                 }
-                if (!done) {                                     // the plain way: one f32 addition per element, in index order
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) {
-                        const int c0 = b0 + k * 64;
-                        const int cnt = n - c0 < 64 ? n - c0 : 64;
-                        const float v = cur[sub * 4 + k];
-                        if (cnt >= 64) {
-#pragma unroll
-                            for (int l = 0; l < 64; ++l) acc = acc + __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
-                        } else {
-                            for (int l = 0; l < cnt; ++l) acc = acc + __shfl(v, l);
-                        }
-                    }
-                }
+                bad = bad || isum >= 0x1000000u;                             // (then the wave total below cannot wrap: 64 x < 2^24)
+                bad = __ballot(bad) != 0;
+                if (!bad) { _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) isum += (uint32_t) __shfl_xor((int) isum, o); }
             }
+            if (lane == 0) { s_sum[wave] = isum; s_bad[wave] = bad ? 1 : 0; }
+            __syncthreads();
+            int k = 0;
+            if (fast) {
+                uint32_t running = (bits & 0x7FFFFFu) | 0x800000u;
+                for (; k < TS_W; ++k) {
+                    if (s_bad[k] || (unsigned long long) running + s_sum[k] >= 0x1000000ull) break;
+                    running += s_sum[k];
+                }
+                if (k > 0) acc = __uint_as_float(((uint32_t) (E + 127) << 23) | (running & 0x7FFFFFu));
+            }
+            i += k * 1024;
+            const bool slow = k < TS_W && i < n;                              // uniform over the workgroup
+            if (slow) {
+                if (wave == 0) {
+                    float y[16];
+                    if (k == 0) {
 #pragma unroll
-            for (int r = 0; r < R; ++r) cur[r] = nxt[r];
+                        for (int r = 0; r < 16; ++r) y[r] = x[r];                // wavefront 0's own trip is the one that failed
+                    } else fetch(y, i);
+                    const float a2 = ts_trip_exact(acc, y, n - i, lane);
+                    if (lane == 0) s_acc = a2;
+                }
+                __syncthreads();
+                acc = s_acc;
+                i += n - i < 1024 ? n - i : 1024;
+            }
+            __syncthreads();                                                  // s_sum / s_bad / s_acc are rewritten next round
         }
     }
+    if (wave != 0) return;
     const int ns = t.a1 - t.a0;
     const float th = (float) (0.5 * (double) acc / (double) ns);            // `const float thold = 0.5 * sum / ns;`
     const float x0 = en[t.s0], x1 = en[t.s1];
@@ -553,7 +615,7 @@ __global__ __launch_bounds__(64) void k_ts_refine(const float * __restrict__ en,
     }
 }
 void ts_refine(const float * en, const float * bmin, const float * bmax, int n_samples, const TsTok * in, TsOut * out, int n_tok, hipStream_t st) {
-    if (n_tok > 0) hipLaunchKernelGGL(k_ts_refine, dim3(n_tok), dim3(64), 0, st, en, bmin, bmax, n_samples, in, out);
+    if (n_tok > 0) hipLaunchKernelGGL(k_ts_refine, dim3(n_tok), dim3(TS_W * 64), 0, st, en, bmin, bmax, n_samples, in, out);
 }
 
 // A copy by a handful of workgroups: 16 bytes per lane and trip, four trips in flight.  Used for the |x| envelopes of a lock-step call
