@@ -427,7 +427,7 @@ int wmi_selftest_ts_refine(struct whisper_context * ctx, const float * envelope,
         for (int t = 0; t < n_tok; ++t) {
             const int s0 = s0s1[2 * t], s1 = s0s1[2 * t + 1];
             if (s0 < 0 || s0 >= n || s1 < 0 || s1 >= n) return -1;
-            in[t] = k::TsTok{ s0, s1, std::max(s0 - 2000, 0), std::min(s1 + 2000, n) };
+            in[t] = k::TsTok{ s0, s1, std::max(s0 - 2000, 0), std::min(s1 + 2000, n), nullptr, 0, 0 };
         }
         float * d_en = nullptr, * d_ext = nullptr; k::TsTok * d_in = nullptr; k::TsOut * d_out = nullptr;
         hipStream_t s = ctx->state->dev.stream;

@@ -643,7 +643,7 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
         // The envelopes of a lock-step call stay in HBM and the window sums + walks of the token timestamps run there (device.cpp
         // ts_refine_device, k_ts_refine: one workgroup per token, the window sum as order-free integer sums per binade over eight wavefronts —
         // every value equals the host loop's, tests/test_gpu_host_dsp.py).  15 MB of PCIe writes per 8-chunk call are not made: mel phase
-        // 0.74 -> 0.54 ms, segments + timestamps 0.20 -> 0.31 ms (one device call per window and chunk), 5.99 -> 5.84 ms per call
+        // 0.74 -> 0.57 ms, segments + timestamps unchanged at ~0.25 ms (one device call per window for all chunks), 6.14 -> 5.92 ms per call
         // (profiles/r04g_token_timestamps_on_device.txt).  WMI_TS_DEVICE=0: envelopes to pinned host memory, sums and walks on the host.
         static const bool ts_device = !(getenv("WMI_TS_DEVICE") && atoi(getenv("WMI_TS_DEVICE")) == 0);
         const bool env_interleaved = env_when_ == 0 || env_when_ >= 3;   // each chunk's envelope kernel right behind its mel kernels (3: into HBM, copied out beside the decode steps)
@@ -845,11 +845,17 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
                     emit_window(ctx, ls, params, row.seek, row.prompt, prompt_init.size(), ls.decoders[0]);
                     row.seek += ls.decoders[0].seek_delta;
                 };
+                // token times refined on the device (envelopes in HBM): the chunks' pending segments go in ONE launch behind the per-chunk work
+                // (eight threads each launching and synchronising their own small kernel took as long as eight launches in a row)
+                std::vector<State *> held;
+                if (params.token_timestamps && ts_device) for (int ri : emit) { State * ls = b.lanes[rows[ri].lane]; ls->ts_hold = true; held.push_back(ls); }
                 if (params.token_timestamps && !params.print_realtime && emit.size() > 1) {
                     pool_run((int) emit.size(), [&](int e) { emit_row(emit[e]); });       // persistent workers (pool.cpp)
                 } else {
                     for (int ri : emit) emit_row(ri);
                 }
+                for (State * ls : held) ls->ts_hold = false;
+                if (!held.empty()) flush_token_timestamps_of(ctx, held);
                 b.t_emit_us += time_us() - te0;
             }
         }

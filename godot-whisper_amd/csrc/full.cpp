@@ -587,30 +587,25 @@ float seq_sum_f32(const float * p, int n) {
 //   walk_up_while_above(s1, n - 1)    -> w_up_above_s1
 //   walk_down_while_below(s1, first)  -> s1 <= first ? s1 : max(first, w_down_below_s1)      (the device walk has first = 0)
 // All pending segments of a window go in ONE device call.
-void flush_token_timestamps(whisper_context & ctx, State & st) {
-    if (st.ts_pending.empty()) return;
+void ts_collect(whisper_context & ctx, State & st, std::vector<k::TsTok> & in, std::vector<TsRef> & ref) {
     const Vocab & v = ctx.model.vocab;
     const int n_samples = st.energy_n;
     const int hw = WHISPER_SAMPLE_RATE / 8;
-    struct Ref { int seg, j; };
-    std::vector<k::TsTok> in; std::vector<Ref> ref;
     for (int si : st.ts_pending) {
         auto & tokens = st.result_all[si].tokens;
         for (int j = 0; j < (int) tokens.size(); ++j) {
             if (tokens[j].id >= v.eot) continue;
             const int s0 = ts_to_sample(tokens[j].t0, n_samples), s1 = ts_to_sample(tokens[j].t1, n_samples);
-            in.push_back(k::TsTok{ s0, s1, std::max(s0 - hw, 0), std::min(s1 + hw, n_samples) });
-            ref.push_back(Ref{ si, j });
+            in.push_back(k::TsTok{ s0, s1, std::max(s0 - hw, 0), std::min(s1 + hw, n_samples), st.dev.energy, n_samples, (int32_t) st.dev.energy_cap });
+            ref.push_back(TsRef{ &st, si, j });
         }
     }
     st.ts_pending.clear();
-    std::vector<k::TsOut> res(in.size());
-    for (size_t q0 = 0; q0 < in.size(); q0 += 448) {            // (the pinned block holds 448 records)
-        const int cnt = (int) std::min<size_t>(448, in.size() - q0);
-        if (!ts_refine_device(st, in.data() + q0, cnt, res.data() + q0)) { WMI_ERR("%s: timestamp refinement on the device failed\n", __func__); return; }
-    }
-    for (size_t q = 0; q < ref.size(); ++q) {                    // segments in order, tokens in order: the reference's loop
-        auto & tokens = st.result_all[ref[q].seg].tokens;
+}
+
+void ts_apply(const std::vector<k::TsTok> & in, const std::vector<TsRef> & ref, const std::vector<k::TsOut> & res) {
+    for (size_t q = 0; q < ref.size(); ++q) {                    // per state: segments in order, tokens in order — the reference's loop
+        auto & tokens = ref[q].st->result_all[ref[q].seg].tokens;
         const int n = (int) tokens.size(), j = ref[q].j;
         const k::TsOut & r = res[q];
         int s0 = in[q].s0, s1 = in[q].s1;
@@ -636,6 +631,25 @@ void flush_token_timestamps(whisper_context & ctx, State & st) {
         }
         (void) s1;
     }
+}
+
+// the pending segments of ONE state, or (lock-step calls) of all chunks at once: one launch, one synchronisation
+void flush_token_timestamps(whisper_context & ctx, State & st) {
+    if (st.ts_pending.empty() || st.ts_hold) return;
+    std::vector<State *> one{ &st };
+    flush_token_timestamps_of(ctx, one);
+}
+void flush_token_timestamps_of(whisper_context & ctx, const std::vector<State *> & states) {
+    std::vector<k::TsTok> in; std::vector<TsRef> ref;
+    State * first = nullptr;
+    for (State * s : states) if (s && !s->ts_pending.empty()) { if (!first) first = s; ts_collect(ctx, *s, in, ref); }
+    if (!first || in.empty()) return;
+    std::vector<k::TsOut> res(in.size());
+    for (size_t q0 = 0; q0 < in.size(); q0 += 448) {            // (the pinned block holds 448 records)
+        const int cnt = (int) std::min<size_t>(448, in.size() - q0);
+        if (!ts_refine_device(*first, in.data() + q0, cnt, res.data() + q0)) { WMI_ERR("%s: timestamp refinement on the device failed\n", __func__); return; }
+    }
+    ts_apply(in, ref, res);
 }
 
 void token_level_timestamps(whisper_context & ctx, State & st, int i_segment, float thold_pt, float thold_ptsum) {
@@ -698,7 +712,12 @@ void token_level_timestamps(whisper_context & ctx, State & st, int i_segment, fl
     // expand / contract by voice activity
     const int hw = WHISPER_SAMPLE_RATE / 8;
     if (st.energy_on_device && st.ts_defer) { st.ts_pending.push_back(i_segment); return; }
-    if (st.energy_on_device) { st.ts_pending.assign(1, i_segment); flush_token_timestamps(ctx, st); return; }
+    if (st.energy_on_device) {                               // something reads the refined times right away (max_len re-wrap, a callback): now
+        st.ts_pending.assign(1, i_segment);
+        std::vector<State *> one{ &st };
+        flush_token_timestamps_of(ctx, one);
+        return;
+    }
     const float * en = st.energy;                    // pinned host memory the GPU wrote (device.cpp: signal_energy_device)
     // The walks below ("move left/right while the envelope stays above/below the threshold") run to the end of
     // the signal on stationary audio — millions of scalar steps per call in the reference.  They are pure

@@ -528,11 +528,16 @@ __device__ __forceinline__ float ts_trip_exact(float acc, const float (&x)[16], 
 //    added by wavefront 0 the careful way (ts_trip_exact), and the rest start again from there with the new exponent.
 //  * threshold and the four walks: wavefront 0.
 constexpr int TS_W = 8;
-__global__ __launch_bounds__(TS_W * 64) void k_ts_refine(const float * __restrict__ en, const float * __restrict__ bmin, const float * __restrict__ bmax,
-                                                         int n_samples, const TsTok * __restrict__ in, TsOut * __restrict__ out) {
+__global__ __launch_bounds__(TS_W * 64) void k_ts_refine(const float * __restrict__ en_, const float * __restrict__ bmin_, const float * __restrict__ bmax_,
+                                                         int n_samples_, const TsTok * __restrict__ in, TsOut * __restrict__ out) {
     __shared__ uint32_t s_sum[TS_W]; __shared__ int s_bad[TS_W]; __shared__ float s_acc;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const TsTok t = in[blockIdx.x];
+    // (tokens of several chunks in one launch carry their own envelope)
+    const float * __restrict__ en = t.en ? t.en : en_;
+    const int n_samples = t.en ? t.n_samples : n_samples_;
+    const float * __restrict__ bmin = t.en ? t.en + t.ext_off : bmin_;
+    const float * __restrict__ bmax = t.en ? bmin + ((size_t) t.n_samples / 256 + 2) : bmax_;
     float acc = 0.0f;
     {
         const float * p = en + t.a0;

@@ -82,7 +82,8 @@ void signal_energy(const float * pcm, int n, int hw, float * out, float * bmin, 
 // Token-level timestamps, the envelope side (W/whisper.cpp:6500-6590, csrc/full.cpp token_level_timestamps): per token the sequential f32 sum of
 // the envelope over its window, the threshold, and the four walks the reference may take from the token's start / end sample.  One
 // wavefront per token; every result equals the host loop's (sequential sum in index order; walks stop on the same sample).
-struct TsTok { int32_t s0, s1, a0, a1; };                   // start / end sample of the token, window [a0, a1) of the sum
+struct TsTok { int32_t s0, s1, a0, a1;                      // start / end sample of the token, window [a0, a1) of the sum
+               const float * en; int32_t n_samples, ext_off; };   // optional (en != null): this token's own envelope, its length, and the offset of its block minima (maxima: + n_samples / 256 + 2) — tokens of several chunks in one launch
 struct TsOut { float sum, thold; int32_t e0, e1;            // e0 = en[s0] > thold, e1 = en[s1] > thold
                int32_t w_down_above_s0, w_up_below_s0, w_up_above_s1, w_down_below_s1; };   // walk results (bounds: 0, s1, n - 1, 0)
 void ts_refine(const float * en, const float * bmin, const float * bmax, int n_samples, const TsTok * in, TsOut * out, int n_tok, hipStream_t st);

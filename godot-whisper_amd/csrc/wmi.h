@@ -261,6 +261,7 @@ struct State {
     const float * energy = nullptr; int energy_n = 0;   // |x| envelope of the last PCM (view of dev.energy_host)
     const float * energy_bmin = nullptr, * energy_bmax = nullptr;   // its per-256-sample block extrema
     bool energy_on_device = false;
+    bool ts_hold = false;                               // lock-step: emit_window leaves the pending list to the caller (flush_token_timestamps_of)
     bool ts_defer = false; std::vector<int> ts_pending;     // emit_window: segments whose envelope-side refinement runs as ONE device call at the end of the window                      // energy == nullptr: the envelope lives in dev.energy, use ts_refine_device()
     int32_t exp_n_audio_ctx = 0;
     int     enc_n_ctx = 0;                        // n_ctx of the last encode (cross cache extent)
@@ -385,7 +386,9 @@ bool signal_energy_device(whisper_context & ctx, int hw, bool sync = true, int v
 // via_dma 3: the envelope is computed into HBM and STAYS there (lock-step calls): token_level_timestamps() asks ts_refine_device() for the
 // window sums and walks instead of reading it (15 MB of PCIe writes per 8-chunk call, ~0.3 ms of whatever runs beside them, are not made)
 bool ts_refine_device(State & st, const k::TsTok * in, int n, k::TsOut * out);
+struct TsRef { State * st; int seg, j; };
 void flush_token_timestamps(whisper_context & ctx, State & st);      // full.cpp: the pending segments' envelope-side refinement, one device call
+void flush_token_timestamps_of(whisper_context & ctx, const std::vector<State *> & states);    // ... of several states (lock-step chunks) in ONE device call
 bool signal_energy_flush(State & st);             // via_dma 2: a THIN copy kernel moves the envelope to the pinned image (lock-step calls: beside the decode steps)
 bool signal_energy_wait(State & st);
 
