@@ -292,6 +292,24 @@ __global__ __launch_bounds__(256) void k_signal_energy(const float * __restrict_
     if (blk != (int) blockIdx.x) __syncthreads();          // s_min / s_max are reused
     const int i = blk * blockDim.x + threadIdx.x;
     float v = 0.0f;
+    // The reference adds in double and stores the sum as float every step: (float) ((double) sum + fabs((double) x)).  That IS the f32 addition
+    // sum + |x| — the double sum of two floats rounded to float equals the correctly rounded float sum (53 >= 2 x 24 + 2 bits: the first
+    // rounding cannot move the second) — so the 65-step chain runs on f32 adds.  The 256 + 2 hw samples of a block come through LDS once
+    // (each is read by up to 65 threads).
+    if (hw <= 64) {
+        __shared__ float tile[256 + 128];
+        const int base = blk * 256 - hw;
+        for (int t = threadIdx.x; t < 256 + 2 * hw; t += 256) { const int k = base + t; tile[t] = (k >= 0 && k < n) ? fabsf(x[k]) : 0.0f; }
+        __syncthreads();
+        if (i < n) {
+            float sum = 0.0f;
+            // samples outside [0, n) are skipped by the reference: adding their 0.0f placeholders is the same sum (x + 0.0f == x for x >= 0)
+            for (int j = 0; j <= 2 * hw; ++j) sum = sum + tile[threadIdx.x + j];
+            v = sum / (float) (2 * hw + 1);
+            out[i] = v;
+        }
+        __syncthreads();                                    // (tile is refilled by the next block of the stride loop)
+    } else
     if (i < n) {
         float sum = 0.0f;
         for (int j = -hw; j <= hw; ++j) {
