@@ -396,6 +396,20 @@ def main():
                 if us_a8 > 0:
                     out["attn_layer_batch8_us"] = round(us_a8, 2)
                     out["attn_layer_batch8_tflops"] = round(8 * 2 * 2.0 * T * T * hp_S / (us_a8 * 1e-6) / 1e12, 1)      # one sweep: QK^T + P.V
+            # north_star's number: aggregate MFMA utilisation over ALL encoder GEMMs (one chunk, and the 8 lock-step chunks), in situ.
+            # Denominators: the vendor's dense f16 peak (2.5 PFLOP/s) and the MFMA-only loop measured on this pool's boxes
+            # (scratch/lab/mfma_peak.hip: 2.03 PFLOP/s, profiles/README.md)
+            try:
+                step(0)                                         # the one-chunk mel of a headline transcription
+                u1 = encoder_gemm_utilisation(lib, ctx, 1, 2030.0)
+                if u1: out["encoder_gemm_mfma_utilisation"] = u1
+                if batch8:
+                    ptrs8, lens8 = batch_args(0, 8)
+                    assert lib.wmi_full_batch(ctx, params, ptrs8, lens8, 8, 1) == 0
+                    u8 = encoder_gemm_utilisation(lib, ctx, 8, 2030.0)
+                    if u8: out["encoder_gemm_mfma_utilisation_batch8"] = u8
+            except Exception as e:  # pragma: no cover
+                out["encoder_gemm_mfma_utilisation_error"] = repr(e)
             out["attn_layer_us"] = round(us_attn, 2)
             out["attn_layer_tflops"] = round(2 * 2.0 * T * T * hp_S / (us_attn * 1e-6) / 1e12, 1)               # (the round-2 kernel computed QK^T twice: 3 x)
             out["encoder_tflops_end_to_end"] = round(ENC_GFLOP / enc_ms, 2)
@@ -651,6 +665,58 @@ def host_dsp_config(lib, ctx, cpu: bool = True) -> dict:
                                        "sample": "one 30 s 48 kHz buffer through oracle/host_dsp.c (libsamplerate src_simple restated, parity unpinned)",
                                        "device_output_identical": same}
     return res
+
+
+def encoder_gemm_utilisation(lib, ctx, chunks: int, measured_peak_tflops: float | None = None) -> dict | None:
+    """`MFMA utilisation` on the encoder GEMMs = (conv + projection + MLP + cross K/V FLOP) / (time in those kernels x
+    peak).  Times are IN SITU: one encoder pass with a probe slice on every gemm() launch (wmi_encoder_gemm_stamps: first workgroup
+    entered -> last workgroup done, taken by the kernels themselves), not back-to-back loops of one warm shape.  FLOP = 2 M N K of each
+    launch as launched (the stacked-chunk conv launches include their guard rows: < 0.4 %)."""
+    cap = 128
+    buf = (C.c_double * (6 * cap))()
+    n = lib.wmi_encoder_gemm_stamps(ctx, chunks, buf, cap)
+    if n <= 0:
+        return None
+    names = {(1, "conv1"): "conv1 (implicit GEMM, k3 s1, + GELU)", (3, None): "conv2 (implicit GEMM, k3 s2, + GELU + positional)",
+             (4, None): "q|k|v^T", (2, "out"): "attention out + residual", (1, "mlp0"): "mlp.0 + GELU", (2, "mlp2"): "mlp.2 + residual",
+             (6, None): "cross K/V, all decoder layers"}
+    shapes = {}
+    order = []
+    seen_conv2 = False                                  # the launches in front of the first conv2 are conv1 (same epilogue id as mlp.0)
+    for i in range(n):
+        epi, M, N, K, us, wgs = (buf[6 * i + j] for j in range(6))
+        epi, M, N, K = int(epi), int(M), int(N), int(K)
+        if us <= 0:
+            continue
+        seen_conv2 = seen_conv2 or epi == 3
+        if epi == 1:
+            key = (1, "mlp0") if seen_conv2 else (1, "conv1")
+        elif epi == 2:
+            key = (2, "out") if K == N else (2, "mlp2")
+        else:
+            key = (epi, None)
+        e = shapes.setdefault(key, {"shape": names.get(key, str(key)), "M": M, "N": N, "K": K, "launches": 0, "us_sum": 0.0, "gflop_sum": 0.0,
+                                    "workgroups": int(wgs)})
+        if key not in order:
+            order.append(key)
+        e["launches"] += 1; e["us_sum"] += us; e["gflop_sum"] += 2.0 * M * N * K / 1e9
+    tot_us = sum(e["us_sum"] for e in shapes.values()); tot_gf = sum(e["gflop_sum"] for e in shapes.values())
+    per = []
+    for key in order:
+        e = shapes[key]
+        tf = e["gflop_sum"] / (e["us_sum"] * 1e-6) / 1e3
+        kern = "k_gemm8 (persistent 8-wave ping-pong)" if (e["workgroups"] <= 256 and e["M"] >= 4096) else "k_gemm"
+        per.append({"shape": e["shape"], "M": e["M"], "N": e["N"], "K": e["K"], "launches": e["launches"], "avg_us": round(e["us_sum"] / e["launches"], 2),
+                    "tflops": round(tf, 1), "frac": round(tf / 2500.0, 4), "share_of_gemm_time": round(e["us_sum"] / tot_us, 3),
+                    "kernel": kern, "workgroups": e["workgroups"]})
+    agg = tot_gf / (tot_us * 1e-6) / 1e3
+    out = {"definition": "sum over the encoder's GEMM launches of 2 M N K / sum of their in-situ durations / dense f16 MFMA peak (SURVEY 8(d); north_star's '>= 40 % on encoder GEMMs')",
+           "chunks": chunks, "gemm_gflop": round(tot_gf, 2), "gemm_us": round(tot_us, 1), "achieved": round(agg, 1), "unit": "TFLOP/s",
+           "peak": 2500.0, "frac": round(agg / 2500.0, 4), "per_shape": per,
+           "timing": "in-kernel wall-clock stamps (100 MHz) of one stamped encoder pass: first workgroup entry -> last workgroup done"}
+    if measured_peak_tflops:
+        out["measured_peak"] = measured_peak_tflops; out["frac_of_measured_peak"] = round(agg / measured_peak_tflops, 4)
+    return out
 
 
 def pmc_traffic(kernel_key: str):

@@ -809,6 +809,8 @@ int wmi_step_stamps(struct whisper_context * ctx, double * out, int cap, int cha
 }
 
 double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters) {
+    if (!ctx || !ctx->state || iters < 1) return -1.0;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);      // the probes replay the context's kernels on its buffers: not beside a transcription
     (void) hipSetDevice(ctx->device);
     State & st = *ctx->state; DeviceState & d = st.dev; const HParams & hp = ctx->model.hp; const Weights & w = ctx->w;
     const int S = hp.n_audio_state, T = hp.n_audio_ctx, H = hp.n_audio_head;
@@ -960,6 +962,56 @@ double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters) {
     (void) hipEventElapsedTime(&ms, e0, e1);
     (void) hipEventDestroy(e0); (void) hipEventDestroy(e1);
     return (double) ms * 1000.0 / iters;
+}
+
+// One encoder pass (the last single-chunk mel: chunks = 1; the rows of the last wmi_full_batch call: chunks > 1) with a probe slice on
+// every gemm() launch: out[6 i + 0..5] = {epilogue id, M, N, K, in-situ microseconds (last workgroup done - first workgroup entered),
+// workgroups that reported}.  Returns the number of launches written, -1 when there is nothing to replay.
+int wmi_encoder_gemm_stamps(struct whisper_context * ctx, int chunks, double * out, int cap) {
+    if (!ctx || !ctx->state || !out || cap < 1 || ctx->model.quantised) return -1;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    (void) hipSetDevice(ctx->device);
+    State & st = *ctx->state; DeviceState & d = st.dev;
+    std::vector<int> rows, seek;
+    if (chunks > 1) {
+        if (!ctx->batch || ctx->batch->enc_rows < 2) return -1;
+        for (int r = 0; r < ctx->batch->enc_rows; ++r) { rows.push_back(r); seek.push_back(0); }
+    } else if (d.mel == nullptr) return -1;
+    const int saved = st.exp_n_audio_ctx;
+    auto pass = [&]() { return chunks > 1 ? encode_rows(*ctx, rows, seek, ctx->batch->enc_T) : encode(*ctx, 0); };
+    k::GemmLog log;
+    log.cap_words = (size_t) 4 << 20;
+    if (!HIP_OK(hipMalloc((void **) &log.buf, log.cap_words * 8))) return -1;
+    int ret = -1;
+    try {
+        if (pass()) {                                                   // warm-up, unstamped
+            (void) hipMemsetAsync(log.buf, 0, log.cap_words * 8, d.stream);
+            k::gemm_log_install(&log);
+            const bool ok = pass();                                     // (both forms synchronise the stream before they return)
+            k::gemm_log_install(nullptr);
+            std::vector<unsigned long long> h(log.used);
+            if (ok && log.used && HIP_OK(hipMemcpy(h.data(), log.buf, log.used * 8, hipMemcpyDeviceToHost))) {
+                int khz = 100000; (void) hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx->device);
+                const double tick_us = 1000.0 / (double) (khz > 0 ? khz : 100000);
+                ret = 0;
+                for (const k::GemmLogEntry & e : log.entries) {
+                    if (ret >= cap) break;
+                    unsigned long long t0 = ~0ull, t1 = 0; int n = 0;
+                    for (int g = 0; g < e.cap; ++g) {
+                        const unsigned long long * q = &h[e.off + (size_t) g * 5];
+                        if (!q[3]) continue;
+                        t0 = std::min(t0, q[0]); t1 = std::max(t1, q[3]); ++n;
+                    }
+                    double * o = out + (size_t) 6 * ret++;
+                    o[0] = e.epi; o[1] = e.M; o[2] = e.N; o[3] = e.K; o[4] = n ? (double) (t1 - t0) * tick_us : -1.0; o[5] = n;
+                }
+            }
+        }
+    } catch (...) { ret = -1; }
+    k::gemm_log_install(nullptr);
+    st.exp_n_audio_ctx = saved;
+    (void) hipFree(log.buf);
+    return ret;
 }
 
 } // extern "C"

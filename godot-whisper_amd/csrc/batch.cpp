@@ -128,8 +128,10 @@ bool ensure_batch(whisper_context & ctx, int B) {
     return true;
 }
 
+} // namespace
+
 // ---------------------------------------------------------------------------------------------- batched encoder
-// rows[r] = lane whose mel feeds chunk row r; seek[r] = its mel frame offset
+// rows[r] = lane whose mel feeds chunk row r; seek[r] = its mel frame offset  (declared in wmi.h: the in-situ GEMM probe replays it)
 bool encode_rows(whisper_context & ctx, const std::vector<int> & rows, const std::vector<int> & seek, int audio_ctx) {
     BatchWork & b = *ctx.batch; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
     const int64_t t0 = time_us();
@@ -248,6 +250,8 @@ bool encode_rows(whisper_context & ctx, const std::vector<int> & rows, const std
     b.t_encode_us += time_us() - t0;
     return true;
 }
+
+namespace {
 
 // ---------------------------------------------------------------------------------------------- batched greedy step
 // step records are already in b.step_host[0..nb); results land in b.sample_host[0..nb)

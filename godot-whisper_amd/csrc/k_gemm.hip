@@ -321,11 +321,22 @@ void dispatch(const GemmArgs & a, hipStream_t st) {
 
 } // namespace
 
+static thread_local GemmLog * tl_gemm_log = nullptr;
+void gemm_log_install(GemmLog * log) { tl_gemm_log = log; }
+
 void gemm(int epi, const GemmArgs & a_in, hipStream_t st) {
     static const bool no_glds = getenv("WMI_GEMM_NO_GLDS") != nullptr;       // debug / A-B: register-staged loop for every tile size
     static const bool guard_all = getenv("WMI_GEMM_GUARD_ALL") != nullptr;   // debug / A-B: bounds-checked epilogue for every tile
     static const bool narrow = getenv("WMI_GEMM_NARROW_STORES") != nullptr;  // debug / A-B: 8-byte epilogue stores
     GemmArgs a = a_in; a.no_glds = (no_glds ? 1 : 0) | (guard_all ? 2 : 0) | (narrow ? 4 : 0);
+    if (GemmLog * lg = tl_gemm_log) {
+        const size_t wgs = (size_t) ((a.M + 63) / 64) * (size_t) ((a.N + 31) / 32);     // the smallest tile any dispatch below uses is 64 x 32
+        if (!a.probe && lg->used + wgs * 5 <= lg->cap_words) {
+            a.probe = lg->buf + lg->used;
+            lg->entries.push_back(GemmLogEntry{epi, a.M, a.N, a.K, lg->used, (int) wgs});
+            lg->used += wgs * 5;
+        }
+    }
     // The big grids (lock-step encoder: M = chunks x 1500) whose output is wide enough for several 192 x 256 tiles per CU go to the
     // persistent ping-pong kernel (k_gemm8.hip): mlp.0 (N = 4 S) and the cross K / V of all decoder layers (N = 2 L S).  Measured at
     // M = 12 000 (profiles/r04a_gemm8_lab_*): mlp.0 41 -> 35.7 us, cross K/V 132 -> 105 us, every output element identical.  The N = S

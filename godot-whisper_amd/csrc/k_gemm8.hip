@@ -296,7 +296,7 @@ void launch8(const GemmArgs & a, hipStream_t st) {
     const size_t smem = (size_t) NSA * BM * 128 + (size_t) NSW * 256 * 128;
     static std::atomic<uint64_t> lds_ok{0};
     allow_full_lds((const void *) k_gemm8<BM, EPI, NSA, NSW, SWAPPED, KS>, lds_ok);
-    static const int n_cu = [] { int dev = 0, n = 256; (void) hipGetDevice(&dev); (void) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 8 ? n & ~7 : 8; }();
+    const int n_cu = cu_count_x8();
     const int tiles = ntm * ntn;
     const int grid = tiles < n_cu ? (tiles + 7) & ~7 : n_cu;
     hipLaunchKernelGGL((k_gemm8<BM, EPI, NSA, NSW, SWAPPED, KS>), dim3(grid), dim3(512), smem, st, a);
@@ -543,7 +543,7 @@ void launch8l(const GemmArgs & a, hipStream_t st) {
     const size_t smem = (size_t) NSA * BM * 128 + (size_t) NSW * 256 * 128;
     static std::atomic<uint64_t> lds_ok{0};
     allow_full_lds((const void *) k_gemm8l<BM, EPI, NSA, NSW, KS>, lds_ok);
-    static const int n_cu = [] { int dev = 0, n = 256; (void) hipGetDevice(&dev); (void) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 8 ? n & ~7 : 8; }();
+    const int n_cu = cu_count_x8();
     const int tiles = ntm * ntn;
     const int grid = tiles < n_cu ? (tiles + 7) & ~7 : n_cu;
     hipLaunchKernelGGL((k_gemm8l<BM, EPI, NSA, NSW, KS>), dim3(grid), dim3(768), smem, st, a);

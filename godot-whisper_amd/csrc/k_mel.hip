@@ -673,7 +673,7 @@ void vad_window(const float * x, int n, int n_last, float alpha, bool filter, fl
 __global__ void k_touch(int * p, int nblk) { if (threadIdx.x == 0 && blockIdx.x == 0) p[0] += 1; }
 void touch(int * p, int blocks, hipStream_t st) { hipLaunchKernelGGL(k_touch, dim3(blocks), dim3(256), 0, st, p, blocks); }
 
-static Stamp g_stamp{nullptr, 0};
+static thread_local Stamp g_stamp{nullptr, 0};       // per host thread: see kernels.h
 void  stamp_enable(unsigned long long * base) { g_stamp.base = base; g_stamp.slot = 0; }
 Stamp stamp_next() { if (!g_stamp.base) return Stamp{nullptr, 0}; return Stamp{g_stamp.base, g_stamp.slot++}; }
 int   stamp_count() { return g_stamp.slot; }

@@ -39,11 +39,29 @@ __device__ __forceinline__ __half f2h(float x) { return __float2half_rn(pin_f32(
 __host__ __device__ __forceinline__ int vt_pos(int t) { return (t & ~12) | ((t & 4) << 1) | ((t & 8) >> 1); }
 #endif
 
+// Compute units of the CURRENT device, rounded down to a multiple of the 8 XCDs (persistent grids: one workgroup per CU).  One slot per
+// device ordinal — a process may hold contexts on several GPUs (wmi_pool_*), and a count cached from the first device a kernel saw
+// would size the grids of all the others.
+inline int cu_count_x8() {
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    std::atomic<int> & c = cache[dev & 63];
+    int n = c.load(std::memory_order_relaxed);
+    if (n > 0) return n;
+    n = 256;
+    (void) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    n = n > 8 ? n & ~7 : 8;
+    c.store(n, std::memory_order_relaxed);
+    return n;
+}
+
 // ---------------------------------------------------------------- in-kernel time stamps (probe: wmi_step_stamps)
 // Body / boundary split of a dependent chain of launches: when stamping is on, lane 0 of every wavefront of a stamped launch
 // writes (s_memrealtime at its first instruction, s_memrealtime behind its last store) to
 // base[(slot * STAMP_WAVES + wave index) * 4] (+ two optional mid points); the host takes min start / max end per launch.  Off (base == null) costs one
-// scalar compare per kernel.  The launchers draw their slot from stamp_next() in launch order (probe runs are single-threaded).
+// scalar compare per kernel.  The launchers draw their slot from stamp_next() in launch order; the switch is THREAD-LOCAL: only launches
+// enqueued by the thread that called stamp_enable() are stamped (pool workers and replica contexts launching beside a probe see "off").
 constexpr int STAMP_WAVES = 4096;                       // wavefront records per launch
 struct Stamp { unsigned long long * base; int slot; };
 void  stamp_enable(unsigned long long * base);          // null = off; resets the slot counter
@@ -144,6 +162,12 @@ struct GemmArgs {
     unsigned long long * probe;     // probe (wmi_bench_kernel 7): per workgroup {entry, first tile landed, K loop done, epilogue done, SE/CU id}
 };
 void gemm(int epi, const GemmArgs & a, hipStream_t st);
+// Probe (wmi_encoder_gemm_stamps): while a log is installed on the calling THREAD, every gemm() launch that has no probe of its own gets a
+// slice of `buf` as GemmArgs::probe (5 words per workgroup: entry ... done, wall-clock ticks) and an entry here — the in-situ duration of
+// each GEMM of an encoder pass is then max(done) - min(entry) over its workgroups, with the cache state the pass itself leaves.
+struct GemmLogEntry { int epi, M, N, K; size_t off; int cap; };
+struct GemmLog { unsigned long long * buf = nullptr; size_t cap_words = 0, used = 0; std::vector<GemmLogEntry> entries; };
+void gemm_log_install(GemmLog * log);       // null = off
 // k_gemm8.hip: the eight-wavefront ping-pong form for the big grids (M = chunks x 1500): BM x 256 tiles, bm in {96, 128, 160, 192, 256},
 // swapped = transposed accumulator fragments (row-major f16 / f32 epilogues), ks = k extent of a slot.  Bit-identical to gemm().
 // false = not served (N % 256, K % 64, epilogue): the caller keeps gemm().

@@ -348,6 +348,8 @@ void destroy_state(State * st);
 bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, bool samples_on_device, bool sync = true);
 bool set_mel(whisper_context & ctx, const float * data, int n_len, int n_mel);
 bool encode(whisper_context & ctx, int mel_offset);
+// lock-step chunks (batch.cpp): rows[r] = lane whose mel feeds chunk row r, seek[r] = its mel frame offset
+bool encode_rows(whisper_context & ctx, const std::vector<int> & rows, const std::vector<int> & seek, int audio_ctx);
 bool decode(whisper_context & ctx, const Batch & batch);
 // block-quantised models (device_q.cpp): the layer loops of encode() / decode() with the quantised kernels
 template <typename BUFS> inline k::Q8Rows q8_rows(const BUFS & d, int K) {

@@ -250,6 +250,14 @@ WHISPER_API double wmi_bench_kernel(struct whisper_context * ctx, int which, int
  * Returns the number of launches written (<= cap), -1 when no greedy step has run on this context (or the model is quantised). */
 WHISPER_API int wmi_step_stamps(struct whisper_context * ctx, double * out, int cap, int chained);
 
+/* Probe: in-situ duration of every f16 encoder GEMM (conv front-end as implicit GEMMs, q|k|v, out, mlp.0, mlp.2, cross K/V) of ONE encoder
+ * pass, from wall-clock stamps the kernels' workgroups take themselves (first workgroup entered -> last workgroup done, stores drained):
+ * the cache state is the pass's own, not a back-to-back loop's.  chunks = 1: the context's last mel spectrogram (after whisper_full /
+ * whisper_pcm_to_mel); chunks > 1: the rows of the last wmi_full_batch call.  out[6 i + 0..5] = {epilogue id, M, N, K, microseconds,
+ * workgroups}; returns the number of launches written (<= cap), -1 when there is nothing to replay or the model is block-quantised.
+ * bench.py builds SURVEY section 8(d)'s "MFMA utilisation on encoder GEMMs" from it (sum of 2 M N K / sum of microseconds). */
+WHISPER_API int wmi_encoder_gemm_stamps(struct whisper_context * ctx, int chunks, double * out, int cap);
+
 /* Host arithmetic self-test (no device needed): the window sums of the token timestamps are the reference's left-to-right f32 sums
  * (W/whisper.cpp:6506-6515), evaluated in blocks as integer additions wherever that is exact (csrc/full.cpp: seq_sum_f32).
  * out_blocked = that routine's result for x[0..n), out_plain = the plain loop's; they must have the same bits.  Returns 0. */
