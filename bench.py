@@ -93,6 +93,20 @@ def main():
     model_bytes = synth.make_model(args.shape, seed=1234) if (rank == 0 or world == 1) else None
     ctx, t_bcast = shard.load_replicated(lib, model_bytes, rank, world, dist, local_rank, dev)
     assert ctx, "model load failed"
+    arena_bytes = int(lib.wmi_weights_bytes(ctx, 0))
+    # what the collective layer actually saw: ranks, and the device each rank computes on (ordinal + PCI bus id) — at N > 1 the ranks
+    # must sit on DISTINCT devices unless this is the declared one-GPU rehearsal
+    ranks_seen = dist.get_world_size() if world > 1 else 1
+    my_dev = {"rank": rank, "ordinal": int(torch.cuda.current_device()), "name": torch.cuda.get_device_name(dev),
+              "pci_bus_id": getattr(torch.cuda.get_device_properties(dev), "pci_bus_id", None)}
+    if world > 1:
+        devs = [None] * world
+        dist.all_gather_object(devs, my_dev)
+        ids = [(d["ordinal"], d["pci_bus_id"]) for d in devs]
+        assert ranks_seen == world, f"backend reports {ranks_seen} ranks, launcher {world}"
+        assert rehearsal or len(set(ids)) == world, f"ranks share devices without WMI_BENCH_REHEARSAL=1: {devs}"
+    else:
+        devs = [my_dev]
 
     # ---- inputs: a few distinct seeded chunks per rank, already in HBM
     n_distinct = 8
@@ -251,6 +265,9 @@ def main():
             "sample_ms_per_step": round((t6[5] / 1e3) / args.steps, 4),
             "comm_backend": comm_backend,
             "weight_bcast_ms": round(1e3 * t_bcast, 3),
+            "weight_bcast_gb_per_s": (round(arena_bytes / t_bcast / 1e9, 1) if (world > 1 and t_bcast > 0) else None),
+            "weight_arena_mb": round(arena_bytes / 1e6, 1),
+            "ranks_seen": int(ranks_seen), "rank_devices": devs,
             "weight_bcast": ("none (one rank: the file is parsed in place)" if world == 1 else
                              f"one {comm_backend} broadcast of the packed device arena (no re-parse on the other ranks)"),
         }

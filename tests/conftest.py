@@ -52,3 +52,21 @@ def checker_lib():
         return lib
     assert port.available(), "no checker available: build oracle/libwhisper_port.so (python __graft_entry__.py build)"
     return None
+
+
+def pytest_terminal_summary(terminalreporter, exitstatus, config):
+    """The margin of every floating-point parity bound this run held (tests/stage_compare.py: hold): worst measured value as a
+    fraction of its bound — a regression that stays inside a bound still shows here."""
+    import json
+    import os
+    import stage_compare as sc
+    if not sc.MARGINS:
+        return
+    tr = terminalreporter
+    tr.write_sep("-", "parity margins: worst measured / bound per kind (1.0 = at the bound)")
+    for kind, m in sorted(sc.MARGINS.items()):
+        tr.write_line(f"{m['worst_ratio']:6.3f}  {kind}: measured {m['measured']:.3e} of {m['limit']:.3e} over {m['n']} checks")
+    out = os.environ.get("WMI_MARGINS_OUT")
+    if out:
+        with open(out, "w") as f:
+            json.dump(sc.MARGINS, f, indent=1, sort_keys=True)

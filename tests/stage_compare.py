@@ -21,6 +21,27 @@ def err_stats(a: np.ndarray, b: np.ndarray) -> dict:
             "ref_rms": scale, "argmax": int(d.argmax())}
 
 
+# Worst measured value per kind of floating-point bound, as a fraction of the bound it was held to: printed at the end of a pytest run
+# (tests/conftest.py) so that the log of a GPU run shows the MARGIN of every parity statement, not only that it held.
+MARGINS: dict = {}
+
+
+def hold(kind: str, measured: float, limit: float, what=None):
+    """assert measured <= limit, and remember the largest measured / limit seen for `kind`."""
+    assert measured <= limit, (kind, what, measured, limit)     # (negative controls fail here: only bounds that HELD are recorded)
+    m = MARGINS.setdefault(kind, {"worst_ratio": 0.0, "measured": 0.0, "limit": limit, "n": 0, "where": None})
+    m["n"] += 1
+    r = measured / limit if limit > 0 else float("inf")
+    if r > m["worst_ratio"]:
+        m.update(worst_ratio=r, measured=measured, limit=limit, where=str(what)[:80] if what is not None else None)
+
+
+def hold_tensor(k: str, st: dict, tol, what=None, abs_mul: float = 1.0):
+    """tol = (absolute, rms-relative) bound of an encoder-side tensor; st = err_stats()."""
+    hold(f"{k} rms-rel", st["rms_rel"], tol[1], (what, st))
+    hold(f"{k} max |d|" + (f" (x{abs_mul:g} deep model)" if abs_mul != 1.0 else ""), st["max_abs"], abs_mul * tol[0], (what, st))
+
+
 class RefSide:
     """Drives oracle/_ref/libwhisper_ref.so and returns tensors in the PRODUCT's layouts."""
 

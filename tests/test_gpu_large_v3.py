@@ -84,13 +84,13 @@ def test_large_v3_full_depth_f16(product_lib, checker_lib):
     chk.n_threads = _threads()
     try:
         mel_r, _ = chk.mel(pcm); mel_p, _ = prod.mel(pcm)
-        assert np.abs(mel_p - mel_r).max() <= tp.TOL["mel"][0]
+        sc.hold("log-mel max |d|", float(np.abs(mel_p - mel_r).max()), tp.TOL["mel"][0])
         er = chk.encode(0, 0); ep = prod.encode(0, 0)
         stats = {k: sc.err_stats(ep[k], er[k]) for k in er}
         print("large-v3 f16 encoder:", {k: (round(v["rms_rel"], 6), round(v["max_abs"], 5)) for k, v in stats.items()})
         for k, st in stats.items():
             # 32 layers: the absolute bound of the 6-layer models is doubled (residual stream rms grows with depth), rms-rel stays
-            assert st["rms_rel"] <= tp.TOL[k][1] and st["max_abs"] <= 2 * tp.TOL[k][0], (k, st)
+            sc.hold_tensor(k, st, tp.TOL[k], "large-v3 f16", abs_mul=2.0)
         prompt = tp.sot_prompt(chk, prod)
         lr = chk.decode(prompt, 0); lp = prod.decode(prompt, 0)
         ls = [sc.err_stats(lp, lr)]
@@ -103,7 +103,7 @@ def test_large_v3_full_depth_f16(product_lib, checker_lib):
                 assert int(np.argmax(lp)) == int(np.argmax(lr)), i
         print("large-v3 f16 logits:", [(round(s["rms_rel"], 6), round(s["max_abs"], 5)) for s in ls])
         for s in ls:
-            assert s["rms_rel"] <= tp.LOGIT_RMS and s["max_abs"] <= 2 * tp.LOGIT_ABS, s
+            sc.hold("logits rms-rel", s["rms_rel"], tp.LOGIT_RMS, ("large-v3 f16", s)); sc.hold("logits max |d| (x2 deep model)", s["max_abs"], 2 * tp.LOGIT_ABS, ("large-v3 f16", s))
     finally:
         prod.close(); chk.close()
 
@@ -294,8 +294,10 @@ def _assert_forced_rows_within_yardstick(got, ref, pert, what):
         worst["ratio_rms"] = max(worst["ratio_rms"], e["rms_rel"] / max(n["rms_rel"], 1e-12))
         worst["ratio_max"] = max(worst["ratio_max"], e["max_abs"] / max(n["max_abs"], 1e-12))
         worst["rms"] = max(worst["rms"], e["rms_rel"])
-        assert e["rms_rel"] <= max(tp.LOGIT_RMS, 2.0 * n["rms_rel"]) and e["rms_rel"] <= tp.Q_CAP["logit_rms"], (what, hist, e, n)
-        assert e["max_abs"] <= max(tp.LOGIT_ABS, 3.0 * n["max_abs"]), (what, hist, e, n)
+        sc.hold("large-v3 q5_1 beam tree: logits rms-rel vs max(f16 bound, 2 x reference self-noise at the node)", e["rms_rel"],
+                min(max(tp.LOGIT_RMS, 2.0 * n["rms_rel"]), tp.Q_CAP["logit_rms"]), (what, hist, e, n))
+        sc.hold("large-v3 q5_1 beam tree: logits max |d| vs max(f16 bound, 3 x reference self-noise at the node)", e["max_abs"],
+                max(tp.LOGIT_ABS, 3.0 * n["max_abs"]), (what, hist, e, n))
     return worst
 
 
