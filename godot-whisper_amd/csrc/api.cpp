@@ -10,6 +10,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstring>
+#include <mutex>
 #include <exception>
 #include <fstream>
 
@@ -19,6 +20,9 @@ namespace {
 void default_log(ggml_log_level, const char * text, void *) { fputs(text, stderr); fflush(stderr); }
 ggml_log_callback g_log_cb = default_log;
 void * g_log_ud = nullptr;
+// one callback invocation at a time: replica contexts and pool workers log from library-created threads, a host's callback (Godot's
+// print, src/register_types.cpp:34-58) was written for one caller.  Recursive: a callback that logs does not deadlock itself.
+std::recursive_mutex g_log_mu;
 }
 
 void log_msg(ggml_log_level lvl, const char * fmt, ...) {
@@ -27,6 +31,7 @@ void log_msg(ggml_log_level lvl, const char * fmt, ...) {
     va_copy(ap2, ap);
     char buf[1024];
     const int len = vsnprintf(buf, sizeof(buf), fmt, ap);
+    std::lock_guard<std::recursive_mutex> lk(g_log_mu);
     if (len < (int) sizeof(buf)) g_log_cb(lvl, buf, g_log_ud);
     else { std::vector<char> big(len + 1); vsnprintf(big.data(), big.size(), fmt, ap2); g_log_cb(lvl, big.data(), g_log_ud); }
     va_end(ap2);
@@ -161,7 +166,10 @@ const char * whisper_full_get_token_text(struct whisper_context * ctx, int i, in
 }
 whisper_token_data whisper_full_get_token_data(struct whisper_context * ctx, int i, int j) { return ctx->state->result_all[i].tokens[j]; }
 
-void whisper_log_set(ggml_log_callback cb, void * user_data) { g_log_cb = cb ? cb : default_log; g_log_ud = user_data; }
+void whisper_log_set(ggml_log_callback cb, void * user_data) {
+    std::lock_guard<std::recursive_mutex> lk(g_log_mu);
+    g_log_cb = cb ? cb : default_log; g_log_ud = user_data;
+}
 
 // ------------------------------------------------------------------ rest of the whisper.h subset
 struct whisper_context_params whisper_context_default_params(void) { struct whisper_context_params p = { true }; return p; }
@@ -533,6 +541,16 @@ int wmi_get_tensor(struct whisper_context * ctx, const char * name, float * dst,
     const int S = hp.n_audio_state, T = st.enc_n_ctx > 0 ? st.enc_n_ctx : hp.n_audio_ctx, Lt = hp.n_text_layer;
     const void * src = nullptr; size_t count = 0; bool is_half = false;
     const std::string nm(name);
+    if (nm == "energy") {                                    // the |x| envelope of the last transcription with token timestamps (k_signal_energy)
+        if (!signal_energy_wait(st)) return -1;
+        const int cnt = st.energy_n;
+        if (!dst) return cnt;
+        if (n > cnt) n = cnt;
+        if (n <= 0) return 0;
+        if (st.energy) { memcpy(dst, st.energy, (size_t) n * 4); return n; }            // pinned host image
+        if (!d.energy || !HIP_OK(hipMemcpy(dst, d.energy, (size_t) n * 4, hipMemcpyDeviceToHost))) return -1;
+        return n;
+    }
     if (nm == "mel")            { src = d.mel; count = (size_t) st.mel.n_len * st.mel.n_mel; }
     else if (nm == "embd_conv") { src = d.embd_conv; count = (size_t) T * S; }
     else if (nm == "embd_enc")  { src = d.enc_out; count = (size_t) T * S; }
@@ -602,13 +620,14 @@ int wmi_batch_chunk_mode(struct whisper_context * ctx, int chunk) {
 }
 
 int wmi_set_batch_replicas(struct whisper_context * ctx, int n) {
-    if (!ctx) return -1;
+    if (!ctx) return -2;                                    // (-1 is a valid answer: "the previous setting was the default")
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);
     try {
         if (!ctx->batch) ctx->batch = new BatchWork();
-    } catch (const std::exception &) { return -1; }
+    } catch (const std::exception &) { return -2; }
     const int prev = ctx->batch->replicas_wanted;
     ctx->batch->replicas_wanted = n < 0 ? -1 : (n > 15 ? 15 : n);
+    if (n >= 0) trim_replicas(*ctx, ctx->batch->replicas_wanted);      // fewer wanted: their states and streams are released now
     // the replicas are made now rather than inside the first call that wants them: state allocation (~0.6 GB each for large-v3) stays out
     // of that call, and their hardware queues exist before the context's other streams do (see init_state: the order matters)
     if (n > 0 && compute_ready(*ctx, __func__)) {

@@ -491,6 +491,14 @@ static void free_replica(whisper_context * r) {
     delete r;
 }
 
+// Surplus replicas are released when fewer are wanted (each holds a whole State — ~0.6 GB for large-v3 — and its stream goes back to the
+// process-wide pool of own-queue streams): a caller that lowers wmi_set_batch_replicas gets the memory back without whisper_free.
+void trim_replicas(whisper_context & ctx, int keep) {
+    if (!ctx.batch) return;
+    auto & reps = ctx.batch->replicas;
+    while ((int) reps.size() > std::max(keep, 0)) { free_replica(reps.back()); reps.pop_back(); }
+}
+
 int ensure_replicas(whisper_context & ctx, int n) {
     if (!ctx.batch) ctx.batch = new BatchWork();
     while ((int) ctx.batch->replicas.size() < n) {
@@ -594,8 +602,8 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
                 }
             } catch (const std::exception & e) {
                 WMI_ERR("wmi_full_batch: worker %d: %s\n", w, e.what());
-                rets[w] = -9;
-            } catch (...) { rets[w] = -9; }
+                rets[w] = -10;
+            } catch (...) { rets[w] = -10; }
         };
         {
             std::vector<std::thread> th;
@@ -657,6 +665,7 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
             State & ls = *b.lanes[r];
             StateSwap sw(ctx, &ls);
             ls.result_all.clear();
+            ls.ts_failed = false;
             ls.prompt_past = prompt_user;                     // every chunk is an independent transcription (no_context semantics)
             ls.exp_n_audio_ctx = params.audio_ctx;
             if (v.is_multilingual()) ls.lang_id = lang_id(params.language);
@@ -859,7 +868,8 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
                     for (int ri : emit) emit_row(ri);
                 }
                 for (State * ls : held) ls->ts_hold = false;
-                if (!held.empty()) flush_token_timestamps_of(ctx, held);
+                if (!held.empty() && !flush_token_timestamps_of(ctx, held)) { WMI_ERR("%s: failed to refine the token timestamps on the device\n", __func__); return -9; }
+                for (int ri : emit) if (b.lanes[rows[ri].lane]->ts_failed) { WMI_ERR("%s: failed to refine the token timestamps on the device\n", __func__); return -9; }
                 b.t_emit_us += time_us() - te0;
             }
         }

@@ -72,6 +72,7 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
     const Vocab & v = ctx.model.vocab;
     const HParams & hp = ctx.model.hp;
     st.result_all.clear();
+    st.ts_failed = false;
     // the envelope kernel reads the caller's samples on a side stream: never return while it is in flight
     struct EnvelopeGuard { State & st; ~EnvelopeGuard() { (void) signal_energy_wait(st); } } envelope_guard{st};
 
@@ -457,6 +458,7 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
             struct Em { int64_t & acc; int64_t t0; ~Em() { acc += time_us() - t0; } } em_timer{T_emit, tem0};
             const Decoder & best = st.decoders[best_decoder_id];
             emit_window(ctx, st, params, seek, prompt, prompt_init.size(), best);
+            if (st.ts_failed) { WMI_ERR("%s: failed to refine the token timestamps on the device\n", __func__); return -9; }
             seek += best.seek_delta;
         }
     }
@@ -478,7 +480,7 @@ void emit_window(whisper_context & ctx, State & st, const whisper_full_params & 
     // (nothing between the segments reads the refined times: no callback, no max_len re-wrap)
     st.ts_defer = params.token_timestamps && params.max_len <= 0 && !params.new_segment_callback && !params.print_realtime;
     st.ts_pending.clear();
-    struct Flush { whisper_context & c; State & s; ~Flush() { flush_token_timestamps(c, s); s.ts_defer = false; } } flush_guard{ctx, st};
+    struct Flush { whisper_context & c; State & s; ~Flush() { (void) flush_token_timestamps(c, s); s.ts_defer = false; } } flush_guard{ctx, st};
     if (!toks.empty() && ctx.model.n_loaded > 0) {
         int i0 = 0;
         int64_t t0 = seek + 2 * (toks.front().tid - v.beg);
@@ -634,22 +636,28 @@ void ts_apply(const std::vector<k::TsTok> & in, const std::vector<TsRef> & ref, 
 }
 
 // the pending segments of ONE state, or (lock-step calls) of all chunks at once: one launch, one synchronisation
-void flush_token_timestamps(whisper_context & ctx, State & st) {
-    if (st.ts_pending.empty() || st.ts_hold) return;
+bool flush_token_timestamps(whisper_context & ctx, State & st) {
+    if (st.ts_pending.empty() || st.ts_hold) return true;
     std::vector<State *> one{ &st };
-    flush_token_timestamps_of(ctx, one);
+    return flush_token_timestamps_of(ctx, one);
 }
-void flush_token_timestamps_of(whisper_context & ctx, const std::vector<State *> & states) {
+bool flush_token_timestamps_of(whisper_context & ctx, const std::vector<State *> & states) {
     std::vector<k::TsTok> in; std::vector<TsRef> ref;
     State * first = nullptr;
-    for (State * s : states) if (s && !s->ts_pending.empty()) { if (!first) first = s; ts_collect(ctx, *s, in, ref); }
-    if (!first || in.empty()) return;
+    std::vector<State *> involved;
+    for (State * s : states) if (s && !s->ts_pending.empty()) { if (!first) first = s; involved.push_back(s); ts_collect(ctx, *s, in, ref); }
+    if (!first || in.empty()) return true;
     std::vector<k::TsOut> res(in.size());
     for (size_t q0 = 0; q0 < in.size(); q0 += 448) {            // (the pinned block holds 448 records)
         const int cnt = (int) std::min<size_t>(448, in.size() - q0);
-        if (!ts_refine_device(*first, in.data() + q0, cnt, res.data() + q0)) { WMI_ERR("%s: timestamp refinement on the device failed\n", __func__); return; }
+        if (!ts_refine_device(*first, in.data() + q0, cnt, res.data() + q0)) {
+            WMI_ERR("%s: timestamp refinement on the device failed\n", __func__);
+            for (State * s : involved) s->ts_failed = true;      // reported by whisper_full / wmi_full_batch as -9
+            return false;
+        }
     }
     ts_apply(in, ref, res);
+    return true;
 }
 
 void token_level_timestamps(whisper_context & ctx, State & st, int i_segment, float thold_pt, float thold_ptsum) {
@@ -715,7 +723,7 @@ void token_level_timestamps(whisper_context & ctx, State & st, int i_segment, fl
     if (st.energy_on_device) {                               // something reads the refined times right away (max_len re-wrap, a callback): now
         st.ts_pending.assign(1, i_segment);
         std::vector<State *> one{ &st };
-        flush_token_timestamps_of(ctx, one);
+        (void) flush_token_timestamps_of(ctx, one);          // failure: st.ts_failed, reported by the caller of the window
         return;
     }
     const float * en = st.energy;                    // pinned host memory the GPU wrote (device.cpp: signal_energy_device)

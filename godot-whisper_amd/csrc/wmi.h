@@ -261,6 +261,7 @@ struct State {
     const float * energy = nullptr; int energy_n = 0;   // |x| envelope of the last PCM (view of dev.energy_host)
     const float * energy_bmin = nullptr, * energy_bmax = nullptr;   // its per-256-sample block extrema
     bool energy_on_device = false;
+    bool ts_failed = false;                             // the device-side refinement of token times failed: the call returns -9 instead of unrefined times
     bool ts_hold = false;                               // lock-step: emit_window leaves the pending list to the caller (flush_token_timestamps_of)
     bool ts_defer = false; std::vector<int> ts_pending;     // emit_window: segments whose envelope-side refinement runs as ONE device call at the end of the window                      // energy == nullptr: the envelope lives in dev.energy, use ts_refine_device()
     int32_t exp_n_audio_ctx = 0;
@@ -389,8 +390,10 @@ bool signal_energy_device(whisper_context & ctx, int hw, bool sync = true, int v
 // window sums and walks instead of reading it (15 MB of PCIe writes per 8-chunk call, ~0.3 ms of whatever runs beside them, are not made)
 bool ts_refine_device(State & st, const k::TsTok * in, int n, k::TsOut * out);
 struct TsRef { State * st; int seg, j; };
-void flush_token_timestamps(whisper_context & ctx, State & st);      // full.cpp: the pending segments' envelope-side refinement, one device call
-void flush_token_timestamps_of(whisper_context & ctx, const std::vector<State *> & states);    // ... of several states (lock-step chunks) in ONE device call
+// false = the device call failed: every state involved is marked ts_failed (the envelope lives only in HBM, there is no host form to fall
+// back to) and the transcription call reports it as -9 — never silently unrefined t0 / t1
+bool flush_token_timestamps(whisper_context & ctx, State & st);      // full.cpp: the pending segments' envelope-side refinement, one device call
+bool flush_token_timestamps_of(whisper_context & ctx, const std::vector<State *> & states);    // ... of several states (lock-step chunks) in ONE device call
 bool signal_energy_flush(State & st);             // via_dma 2: a THIN copy kernel moves the envelope to the pinned image (lock-step calls: beside the decode steps)
 bool signal_energy_wait(State & st);
 
@@ -409,6 +412,7 @@ int  full(whisper_context & ctx, whisper_full_params params, const float * sampl
 int  full_batch(whisper_context & ctx, whisper_full_params params, const float * const * pcm, const int * n_samples, int n_chunks, bool on_device);
 void free_batch(whisper_context & ctx);
 int  ensure_replicas(whisper_context & ctx, int n);     // create up to n replica contexts now; returns how many exist (<= n)
+void trim_replicas(whisper_context & ctx, int keep);         // release the replicas beyond `keep` (states, streams back to the pool)
 // segment emission of one decoded window: updates prompt_past and appends to state.result_all (W/whisper.cpp:5682-5796)
 void emit_window(whisper_context & ctx, State & st, const whisper_full_params & params, int seek, const std::vector<int32_t> & prompt,
                  size_t n_prompt_init, const Decoder & best);

@@ -107,7 +107,8 @@ WHISPER_API const char * whisper_print_system_info(void);
 /* ---- [host] one transcription (W/whisper.h:532, :537-541) ---- */
 WHISPER_API struct whisper_full_params whisper_full_default_params(enum whisper_sampling_strategy strategy);
 /* 0 ok; -1 speed_up unsupported; -2 mel; -3 language detect; -4 too many decoders; -5 audio_ctx too large;
- * -6 encode; -7 prompt decode; -8 decode (W/whisper.cpp:4976-5561).  Not re-entrant per context. */
+ * -6 encode; -7 prompt decode; -8 decode (W/whisper.cpp:4976-5561); -9 (this backend only) the device-side refinement of token
+ * timestamps failed — lock-step calls keep the |x| envelope in HBM, so there is no host form to fall back to.  Not re-entrant per context. */
 WHISPER_API int whisper_full(struct whisper_context * ctx, struct whisper_full_params params, const float * samples, int n_samples);
 
 /* ---- [host] result walk (W/whisper.h:564, :585-601) ---- */

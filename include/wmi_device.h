@@ -141,7 +141,10 @@ WHISPER_API int wmi_batch_chunk_mode(struct whisper_context * ctx, int chunk);
  * `ctx`, ~0.15 GB of state each for base.en, ~0.6 GB for large-v3) work beside `ctx`, chunk c on worker c mod (1 + n).
  * replaces: the worker threads of whisper_full_parallel (W/whisper.cpp:5837-5913: one shared model, one whisper_state per worker).
  * Results do not depend on n (every chunk is whisper_full on a fresh state).  n = 0: one chunk at a time; n < 0: the default (3, or
- * WMI_BATCH_REPLICAS).  Not used when params carry user callbacks or print_realtime.  Returns the previous setting. */
+ * WMI_BATCH_REPLICAS).  Not used when params carry user callbacks or print_realtime.  Lowering n releases the surplus replicas at once
+ * (their state memory and streams).  With n > 0 whisper_log_set's callback and the print_progress lines can be invoked from the
+ * library's worker threads (one call at a time: the library serialises them).  Returns the previous setting (-1 = default), -2 for a
+ * null context. */
 WHISPER_API int wmi_set_batch_replicas(struct whisper_context * ctx, int n);
 
 /* Wall-clock buckets of the last wmi_full_batch call, microseconds: mel + envelope, encoder, decoder steps,

@@ -268,3 +268,45 @@ def test_token_timestamp_sums_and_walks_on_the_device_equal_the_sequential_loops
         assert sums[t].tobytes() == np.float32(want_sum).tobytes(), (kind, t, a, b, sums[t], want_sum)
         assert th[t].tobytes() == np.float32(want_th).tobytes() or (np.isnan(th[t]) and np.isnan(want_th)), (kind, t, th[t], want_th)
         assert walks[t].tolist() == want_walks, (kind, t, a, b, walks[t].tolist(), want_walks)
+
+
+# ------------------------------------------------------------------------------------------------ the |x| envelope itself
+def _envelope_reference(x, hw=32):
+    """get_signal_energy (W/whisper.cpp:6350-6366) step by step: `sum += fabs(signal[i + j])` with a float sum and the double fabs is
+    (float) ((double) sum + |x|) per in-range j in order; then sum / (2 hw + 1) as a float division."""
+    n = x.size
+    ax = np.abs(x.astype(np.float64))
+    acc = np.zeros(n, np.float32)
+    idx = np.arange(n)
+    for j in range(-hw, hw + 1):
+        k = idx + j
+        ok = (k >= 0) & (k < n)
+        step = (acc.astype(np.float64) + ax[np.clip(k, 0, n - 1)]).astype(np.float32)
+        acc = np.where(ok, step, acc)
+    return (acc / np.float32(2 * hw + 1)).astype(np.float32)
+
+
+@pytest.mark.parametrize("kind", ["denormal", "mixed", "speech"])
+def test_envelope_of_denormal_samples(product_lib, node, kind):
+    """csrc/k_mel.hip k_signal_energy runs the reference's 65-step chain as plain f32 additions — equal to its double-add-then-float only
+    while the device keeps f32 denormals (Makefile: -fno-gpu-flush-denormals-to-zero).  Samples whose partial sums are denormal, cross
+    into the normal range, or sit beside ordinary speech-sized values: every envelope value must have the reference's bits."""
+    rng = np.random.default_rng({"denormal": 11, "mixed": 12, "speech": 13}[kind])
+    n = 16000 * 3
+    if kind == "denormal":                       # |x| in the f32 denormal range: 65 of them sum to at most ~6e-39 < FLT_MIN
+        x = (rng.integers(1, 60000, n).astype(np.float64) * 1.4e-45).astype(np.float32) * rng.choice([-1.0, 1.0], n).astype(np.float32)
+    elif kind == "mixed":                        # denormals, values around FLT_MIN, zeros and ordinary samples in runs
+        x = (rng.integers(0, 1 << 23, n).astype(np.float64) * 1.4e-45).astype(np.float32)
+        x[n // 3: n // 3 + 4000] = (rng.standard_normal(4000) * 1.2e-38).astype(np.float32)
+        x[n // 2: n // 2 + 4000] = 0.0
+        x[2 * n // 3: 2 * n // 3 + 6000] = (0.1 * rng.standard_normal(6000)).astype(np.float32)
+    else:
+        x = synth.make_pcm(3.0, seed=99)[:n].astype(np.float32)
+    assert np.any((np.abs(x) > 0) & (np.abs(x) < 1.17549435e-38)) or kind == "speech"
+    p = node.full_params("", 0)                  # host parameter set: token_timestamps on -> the envelope kernel runs
+    assert p.token_timestamps
+    assert product_lib.whisper_full(node.ctx, p, x.ctypes.data_as(C.POINTER(C.c_float)), int(x.size)) == 0
+    got = np.zeros(n, np.float32)
+    assert product_lib.wmi_get_tensor(node.ctx, b"energy", got.ctypes.data_as(C.POINTER(C.c_float)), n) == n
+    want = _envelope_reference(x)
+    assert got.tobytes() == want.tobytes(), (kind, int(np.argmax(got.view(np.uint32) != want.view(np.uint32))))
