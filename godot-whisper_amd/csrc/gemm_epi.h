@@ -390,4 +390,77 @@ __device__ __forceinline__ void epilogue_cols_wide(const GemmArgs & a, floatx4 (
     }
 }
 
+// ---- the f16 results of epilogue_cols_wide LEFT IN REGISTERS (k_gemm8's deferred stores).  out[i][0] / out[i][1] are the two 16-byte pieces
+// a lane stores for fragment row i — rows mb + i*16 + (frow & 7) and + 8 —, ptr the address of out[0][0]'s destination, ldd the row stride
+// of the destination in elements: piece (i, h) belongs at ptr + (i*16 + h*8) * ldd.  Same expressions, same lane exchanges as the storing
+// form above: the bytes that leave later are the bytes it would have stored.  Interior tiles only (no bounds checks), FN = 4.
+template <int EPI, int FM, int FN>
+__device__ __forceinline__ void pack_cols_wide(const GemmArgs & a, floatx4 (&acc)[FM][FN], const int mb, const int nb, const int n0, const int lane,
+                                               uint4 (&out)[FM][2], __half * & ptr, int & ldd_out) {
+    static_assert(FN == 4, "pack_cols_wide: wave tiles of four fragment columns");
+    static_assert(EPI == EPI_F16_BIAS || EPI == EPI_F16_BIAS_GELU || EPI == EPI_Q_SCALED || EPI == EPI_CROSS_KV || EPI == EPI_QKV_ENC, "epilogue");
+    const int frow = lane & 15, fq = lane >> 4;
+    const bool lo = frow < 8;
+    const int r8 = frow & 7, hb = frow >> 3;
+    float bias[FN][4];
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.bias) b4 = *(const float4 *) (a.bias + nb + j * 16 + fq * 4);
+        bias[j][0] = b4.x; bias[j][1] = b4.y; bias[j][2] = b4.z; bias[j][3] = b4.w;
+    }
+    __half * dst; int ldd; int c0; float scale = 1.0f; bool use_bias = true;
+    if constexpr (EPI == EPI_QKV_ENC) {
+        const int seg = __builtin_amdgcn_readfirstlane(nb / a.S);
+        c0 = nb - seg * a.S;
+        dst = seg == 0 ? (__half *) a.C : (__half *) a.aux; ldd = seg == 0 ? a.ldc : a.ldaux;
+    } else if constexpr (EPI == EPI_CROSS_KV) {
+        const int il = __builtin_amdgcn_readfirstlane(nb / (2 * a.S)), c = nb - il * 2 * a.S;
+        const bool isk = c < a.S;
+        dst = (isk ? (__half *) a.C : (__half *) a.aux) + il * a.layer_stride; ldd = isk ? a.ldc : a.ldaux; c0 = isk ? c : c - a.S;
+        scale = isk ? a.scale : 1.0f; use_bias = !isk;
+    } else {
+        dst = (__half *) a.C; ldd = a.ldc; c0 = nb;
+        if constexpr (EPI == EPI_Q_SCALED) scale = a.scale;
+    }
+    const int cb = ((fq & 1) << 4) | ((fq >> 1) << 3);
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+        uint4 blk[2];
+#pragma unroll
+        for (int j = 0; j < FN; j += 2) {
+            uint32_t w[2][2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const floatx4 v = acc[i][j + jj];
+                half4 h;
+                if constexpr (EPI == EPI_F16_BIAS_GELU) {
+                    const float2v x0 = {v[0] + bias[j + jj][0], v[1] + bias[j + jj][1]}, x1 = {v[2] + bias[j + jj][2], v[3] + bias[j + jj][3]};
+                    const half2v g0 = gelu16_pair(x0), g1 = gelu16_pair(x1);
+                    h[0] = g0[0]; h[1] = g0[1]; h[2] = g1[0]; h[3] = g1[1];
+                } else if constexpr (EPI == EPI_CROSS_KV) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[r] = (_Float16) pin_f32(use_bias ? v[r] + bias[j + jj][r] : v[r] * scale);
+                } else if constexpr (EPI == EPI_Q_SCALED) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[r] = (_Float16) pin_f32((v[r] + bias[j + jj][r]) * scale);
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[r] = (_Float16) pin_f32(v[r] + bias[j + jj][r]);
+                }
+                const uint2 u = *(const uint2 *) &h;
+                w[jj][0] = u.x; w[jj][1] = u.y;
+            }
+            const auto s0 = __builtin_amdgcn_permlane16_swap(w[0][0], w[1][0], false, false);
+            const auto s1 = __builtin_amdgcn_permlane16_swap(w[0][1], w[1][1], false, false);
+            blk[j / 2] = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        }
+        uint4 P = blk[0], Q = blk[1];
+        trade_rows8(P, Q, lo);
+        out[i][0] = P; out[i][1] = Q;
+    }
+    ptr = dst + (size_t) (mb + r8) * ldd + (c0 + hb * 32 + cb);
+    ldd_out = ldd;
+}
+
 }}} // namespace wmi::k::gemm_detail

@@ -49,7 +49,7 @@ __device__ __forceinline__ uint32_t lds_off8(int row, int chunk) {     // byte o
 //          of its LOAD slot (the stage was freed by the barrier in front of it: two slots of flight), group 1 requests W of step t + 2
 //          behind its reads (four slots)
 //   2 / 2  BM = 256: group 0 requests both images of step t + 1 at the start of its LOAD slot
-template <int BM, int EPI, int NSA, int NSW, bool SWAPPED, int KS>
+template <int BM, int EPI, int NSA, int NSW, bool SWAPPED, int KS, bool DEFER = false>
 __global__ __launch_bounds__(512) void k_gemm8(const GemmArgs a) {
     constexpr int BN = 256, FM = BM / 32, FN = 4;
     constexpr int SZA = BM * 128, SZW = BN * 128;          // bytes of one stage of each ring
@@ -102,12 +102,11 @@ __global__ __launch_bounds__(512) void k_gemm8(const GemmArgs a) {
     const int total = n_my * nk;                           // K steps of this workgroup, over all of its tiles
     const uint32_t lds0 = lds_addr(smem);
     const int frow = lane & 15, fq = lane >> 4;
-    // fragment addresses inside a stage for k-step 0; k-step q flips bit 2 of the chunk index: chunk = (4 q + fq) ^ (row & 7)
-    uint32_t offA[FM], offB[FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i) offA[i] = lds_off8(grp * (BM / 2) + i * 16 + frow, fq);
-#pragma unroll
-    for (int j = 0; j < FN; ++j) offB[j] = RING_W + lds_off8(wn * 64 + j * 16 + frow, fq);
+    // fragment addresses inside a stage for k-step 0; k-step q flips bit 2 of the chunk index: chunk = (4 q + fq) ^ (row & 7).  Fragment
+    // row i / column j is 16 rows = 2 KiB further on and leaves row & 7 alone: ONE address register per operand, the rest is the
+    // ds_read's immediate offset (ten registers less than an address per fragment: the deferred stores need them)
+    const uint32_t offA0 = lds_off8(grp * (BM / 2) + frow, fq);
+    const uint32_t offB0 = RING_W + lds_off8(wn * 64 + frow, fq);
 
     auto body = [&](auto grp_tag) {
         constexpr int G = decltype(grp_tag)::value;
@@ -123,14 +122,14 @@ __global__ __launch_bounds__(512) void k_gemm8(const GemmArgs a) {
         const int prow = lane >> 3;
         struct Stream { int i = 0, k = 0, n = 0; const __half * base = nullptr; };
         Stream sa, sw;
-        uint32_t vA[PA > 0 ? PA : 1], vW[PW > 0 ? PW : 1];
+        // One byte offset per operand: piece p of a wave's run is 8 rows further down the same (swizzled) 16-byte column — + p * 16 ld
+        // bytes, formed in front of each request (glds_run_affine).  A rows past the bottom edge of the matrix read the last valid row.
+        uint32_t vA0 = 0, vAclamp = 0, vW0 = 0;
         const int pa0 = DEEP ? (G ? 4 * PA0 + wn * PA1 : wn * PA0) : wn * PA;     // this wave's first piece of each image
         const int pw0 = DEEP ? wave * PW : wn * PW;
-#pragma unroll
-        for (int p = 0; p < PW; ++p) {                    // W rows never leave the matrix (N is a multiple of 256): offsets fixed for the launch
-            const int lrow = (pw0 + p) * 8 + prow, pch = (lane & 7) ^ (lrow & 7);
-            vW[p] = (uint32_t) (lrow * a.ldw + pch * 8) * 2u;
-        }
+        const int pchunk = (lane & 7) ^ (prow & 7);          // (piece rows are multiples of 8: row & 7 = prow)
+        if constexpr (PW > 0) vW0 = (uint32_t) ((pw0 * 8 + prow) * a.ldw + pchunk * 8) * 2u;     // W rows never leave the matrix (N is a multiple of 256)
+        bool a_edge = false;
         auto adv = [&](Stream & t) { ++t.n; if (++t.k == nk) { t.k = 0; ++t.i; } };
         auto request_a = [&]() {
             if constexpr (PA > 0) {
@@ -138,21 +137,21 @@ __global__ __launch_bounds__(512) void k_gemm8(const GemmArgs a) {
                     int m0, n0; tile_origin(sa.i, m0, n0);
                     sa.base = a.A + (size_t) m0 * a.lda;
                     const int rmax = a.M - 1 - m0;
-#pragma unroll
-                    for (int p = 0; p < PA; ++p) {
-                        int lrow = (pa0 + p) * 8 + prow; const int pch = (lane & 7) ^ (lrow & 7);
-                        if (lrow > rmax) lrow = rmax;
-                        vA[p] = (uint32_t) (lrow * a.lda + pch * 8) * 2u;
-                    }
+                    a_edge = rmax < BM - 1;                    // (workgroup-uniform: the tile hangs over the bottom edge)
+                    int lrow = pa0 * 8 + prow; if (lrow > rmax) lrow = rmax;
+                    vA0 = (uint32_t) (lrow * a.lda + pchunk * 8) * 2u;
+                    vAclamp = (uint32_t) (rmax * a.lda + pchunk * 8) * 2u;
                 }
-                glds_run<PA>(vA, sa.base + sa.k * 64, lds0 + (uint32_t) (sa.n % NSA) * SZA + (uint32_t) pa0 * 1024u);
+                const uint32_t dstA = lds0 + (uint32_t) (sa.n % NSA) * SZA + (uint32_t) pa0 * 1024u;
+                if (a_edge) glds_run_affine<PA, true>(vA0, (uint32_t) a.lda * 16u, vAclamp, sa.base + sa.k * 64, dstA);
+                else        glds_run_affine<PA, false>(vA0, (uint32_t) a.lda * 16u, 0u, sa.base + sa.k * 64, dstA);
             }
             adv(sa);
         };
         auto request_w = [&]() {
             if constexpr (PW > 0) {
                 if (sw.k == 0) { int m0, n0; tile_origin(sw.i, m0, n0); sw.base = a.W + (size_t) n0 * a.ldw; }
-                glds_run<PW>(vW, sw.base + sw.k * 64, lds0 + RING_W + (uint32_t) (sw.n % NSW) * SZW + (uint32_t) pw0 * 1024u);
+                glds_run_affine<PW, false>(vW0, (uint32_t) a.ldw * 16u, 0u, sw.base + sw.k * 64, lds0 + RING_W + (uint32_t) (sw.n % NSW) * SZW + (uint32_t) pw0 * 1024u);
             }
             adv(sw);
         };
@@ -186,8 +185,24 @@ __global__ __launch_bounds__(512) void k_gemm8(const GemmArgs a) {
 #define G8_STAMP(i) do { } while (0)
 #endif
         int gs = 0;
-        for (int ti = 0; ti < n_my; ++ti) {
-            for (int kt = 0; kt < nk; ++kt, ++gs) {
+        // DEFER: the f16 results of a tile stay in registers (pend) and leave two 16-byte stores at a time during the first FM K steps of
+        // the workgroup's NEXT tile, behind the group's own vmcnt wait of that step (a store also counts in vmcnt: issued there, it has a whole
+        // K step to retire before the next counted wait sees it — the waits stay safe either way, outstanding loads <= outstanding
+        // operations and the DMA loads retire in order, but a store that is still in flight makes them wait longer than they must).
+        // Why: every workgroup reaches its epilogue at the same time and the chip takes ~7-8 TB/s of stores whatever they are aimed at
+        // (24.6 MB per round of mlp.0 x 8: 2.9 us with every matrix pipe idle); spread over the next tile's K loop the same bytes are free.
+        uint4 pend[DEFER ? FM : 1][2]; __half * pend_ptr = nullptr; int pend_ld = 0; bool have_pend = false;
+        auto store_pend = [&](auto u_tag) {
+            constexpr int U = decltype(u_tag)::value;
+            if constexpr (DEFER && U >= 0 && U < FM) {
+                if (have_pend) {
+                    *(uint4 *) (pend_ptr + (size_t) (U * 16) * pend_ld)     = pend[U][0];
+                    *(uint4 *) (pend_ptr + (size_t) (U * 16 + 8) * pend_ld) = pend[U][1];
+                }
+            }
+        };
+        auto kstep = [&](auto u_tag) {
+            {
                 const unsigned char * stA = smem + (size_t) (gs % NSA) * SZA;
                 const unsigned char * stW = smem + (size_t) (gs % NSW) * SZW;
 #pragma unroll
@@ -200,9 +215,9 @@ __global__ __launch_bounds__(512) void k_gemm8(const GemmArgs a) {
                         for (int q = 0; q < NKK; ++q) {
                             const uint32_t kx = (uint32_t) ((sl * NKK + q) << 6);
 #pragma unroll
-                            for (int j = 0; j < FN; ++j) fb[q][j] = *(const half8 *) (stW + (offB[j] ^ kx));
+                            for (int j = 0; j < FN; ++j) fb[q][j] = *(const half8 *) (stW + (offB0 ^ kx) + j * 2048);
 #pragma unroll
-                            for (int i = 0; i < FM; ++i) fa[q][i] = *(const half8 *) (stA + (offA[i] ^ kx));
+                            for (int i = 0; i < FM; ++i) fa[q][i] = *(const half8 *) (stA + (offA0 ^ kx) + i * 2048);
                         }
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -215,7 +230,7 @@ __global__ __launch_bounds__(512) void k_gemm8(const GemmArgs a) {
                     }
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                     G8_STAMP(0);
-                    if constexpr (G == 1) { if (sl == 64 / KS - 1 && gs + 1 < total) wait_step(gs + 1); }
+                    if constexpr (G == 1) { if (sl == 64 / KS - 1 && gs + 1 < total) wait_step(gs + 1); if (sl == 64 / KS - 1) store_pend(u_tag); }
                     G8_STAMP(3);
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
@@ -235,7 +250,7 @@ __global__ __launch_bounds__(512) void k_gemm8(const GemmArgs a) {
                             }
                     __builtin_amdgcn_s_setprio(0);
                     G8_STAMP(2);
-                    if constexpr (G == 0) { if (sl == 64 / KS - 1 && gs + 1 < total) wait_step(gs + 1); }
+                    if constexpr (G == 0) { if (sl == 64 / KS - 1 && gs + 1 < total) wait_step(gs + 1); if (sl == 64 / KS - 1) store_pend(u_tag); }
                     G8_STAMP(3);
                     __builtin_amdgcn_sched_barrier(0);
                     __builtin_amdgcn_s_barrier();
@@ -243,6 +258,23 @@ __global__ __launch_bounds__(512) void k_gemm8(const GemmArgs a) {
                     G8_STAMP(4);
                 }
             }
+        };
+        using NoStore = std::integral_constant<int, -1>;
+        for (int ti = 0; ti < n_my; ++ti) {
+            int kt = 0;
+            if constexpr (DEFER) {
+                // the first FM K steps of a tile carry the previous tile's stores: written out, the piece index is a compile-time constant
+#define G8_STEP(U) if constexpr (U < FM) { if (kt < nk) { kstep(std::integral_constant<int, U>{}); ++kt; ++gs; } }
+                G8_STEP(0) G8_STEP(1) G8_STEP(2) G8_STEP(3) G8_STEP(4) G8_STEP(5) G8_STEP(6) G8_STEP(7)
+#undef G8_STEP
+                if (have_pend && nk < FM) {                 // (a K loop shorter than the tile has fragment rows: the rest leaves now)
+#define G8_REST(U) if constexpr (U < FM) { if (nk <= U) store_pend(std::integral_constant<int, U>{}); }
+                    G8_REST(0) G8_REST(1) G8_REST(2) G8_REST(3) G8_REST(4) G8_REST(5) G8_REST(6) G8_REST(7)
+#undef G8_REST
+                }
+                have_pend = false;
+            }
+            for (; kt < nk; ++kt, ++gs) kstep(NoStore{});
             // ---- epilogue of tile ti (gemm_epi.h); the requests for the next tile's first steps are in flight.
             // Both groups run it in the SAME slot (group 0 sits out group 1's last MFMA slot, group 1 takes its extra barrier behind the
             // epilogue): one slot behind each other, each group's epilogue had the partner waiting at the next barrier for all of it.
@@ -259,7 +291,13 @@ __global__ __launch_bounds__(512) void k_gemm8(const GemmArgs a) {
                     for (int j = 0; j < FN; ++j) asm volatile("" :: "v"(acc[i][j]));
             } else
             if constexpr (SWAPPED) {
-                if (lab & 1024) { if (interior) epilogue_cols<EPI, FM, FN, false>(a, acc, mb, nb, n0, lane); else epilogue_cols<EPI, FM, FN, true>(a, acc, mb, nb, n0, lane); }
+                bool packed = false;
+                if constexpr (DEFER) {
+                    // every tile but the workgroup's last, and no tile at the bottom edge of the matrix (those store at once, bounds-checked)
+                    if (interior && ti + 1 < n_my) { pack_cols_wide<EPI, FM, FN>(a, acc, mb, nb, n0, lane, pend, pend_ptr, pend_ld); have_pend = true; packed = true; }
+                }
+                if (packed) { }
+                else if (lab & 1024) { if (interior) epilogue_cols<EPI, FM, FN, false>(a, acc, mb, nb, n0, lane); else epilogue_cols<EPI, FM, FN, true>(a, acc, mb, nb, n0, lane); }
                 else            { if (interior) epilogue_cols_wide<EPI, FM, FN, false>(a, acc, mb, nb, n0, lane); else epilogue_cols_wide<EPI, FM, FN, true>(a, acc, mb, nb, n0, lane); }
             }
             else                   { if (interior) epilogue_rows<EPI, FM, FN, false>(a, acc, mb, nb, lane);     else epilogue_rows<EPI, FM, FN, true>(a, acc, mb, nb, lane); }
@@ -290,265 +328,21 @@ __global__ __launch_bounds__(512) void k_gemm8(const GemmArgs a) {
     }
 }
 
-template <int BM, int EPI, int NSA, int NSW, bool SWAPPED, int KS>
+template <int BM, int EPI, int NSA, int NSW, bool SWAPPED, int KS, bool DEFER = false>
 void launch8(const GemmArgs & a, hipStream_t st) {
     const int ntm = (a.M + BM - 1) / BM, ntn = a.N / 256;
     const size_t smem = (size_t) NSA * BM * 128 + (size_t) NSW * 256 * 128;
     static std::atomic<uint64_t> lds_ok{0};
-    allow_full_lds((const void *) k_gemm8<BM, EPI, NSA, NSW, SWAPPED, KS>, lds_ok);
+    allow_full_lds((const void *) k_gemm8<BM, EPI, NSA, NSW, SWAPPED, KS, DEFER>, lds_ok);
     const int n_cu = cu_count_x8();
     const int tiles = ntm * ntn;
-    const int grid = tiles < n_cu ? (tiles + 7) & ~7 : n_cu;
-    hipLaunchKernelGGL((k_gemm8<BM, EPI, NSA, NSW, SWAPPED, KS>), dim3(grid), dim3(512), smem, st, a);
-}
-
+    int grid = tiles < n_cu ? (tiles + 7) & ~7 : n_cu;
 #ifdef WMI_G8_LAB
-// ---------------------------------------------------------------------------------------------------------------------------------
-// (lab only — measured, NOT kept: profiles/r04a_gemm8_lab_loader_waves_not_kept.txt.  mlp.0 at M = 12 000: 36.7 us on 128 x 256 tiles with
-// 32-deep slots / 38.2 us on 96 x 256 with 64-deep slots against 35.6 us for k_gemm8 on 192 x 256; cross K/V 108 against 104 us.  Twelve
-// wavefronts leave 168 VGPRs each — the 192-row tile spills — and a barrier among twelve waves every 450 cycles costs what the freed
-// LOAD slots gain: the skeleton alone (no DMA, reads or MFMA) is 10.7 us of the 36.  Two of the variants also showed a few thousand
-// differing bytes on the cross K/V shape: an unresolved hazard between the loaders' run-ahead and a tile boundary.)
-// k_gemm8l: the same ping-pong, with the DMA taken off the MFMA wavefronts.  Slot accounting of k_gemm8 (profiles/r04a_gemm8_lab_slots_and_
-// ablations.txt): a LOAD slot is 1000-1220 cycles — ~300 of fragment reads and 110 cycles PER DMA INSTRUCTION (the CU's vector memory path
-// takes 1 KiB per ~27 cycles, ~38 B/clk, and holds the issuing wave meanwhile) — against 875 cycles of MFMA slot: the K step is paced by
-// the DMA issue of the waves that should be feeding the matrix pipe.  Here four more wavefronts (8..11, one per SIMD) do nothing but issue
-// the tile requests, a few per slot, and meet the others at every barrier; the eight MFMA wavefronts read fragments and multiply.  Three
-// wavefronts per SIMD leave 168 VGPRs each: 128 x 256 tiles with 64-deep slots, or 192 x 256 with 32-deep ones.
-//
-//   loader schedule, K step t (slots numbered by group 0): first the image that runs one step ahead (two-deep ring: its stage was freed by
-//   the barrier that ended step t - 1), then the two-steps-ahead image; before the barrier that ends step t the loader waits until only the
-//   two-steps-ahead requests of this step are outstanding — everything step t + 1 reads has then landed.
-template <int BM, int EPI, int NSA, int NSW, int KS>
-__global__ __launch_bounds__(768) void k_gemm8l(const GemmArgs a) {
-    constexpr int BN = 256, FM = BM / 32, FN = 4;
-    constexpr int SZA = BM * 128, SZW = BN * 128, RING_W = NSA * SZA;
-    constexpr int NA = BM / 8, NW = BN / 8;
-    constexpr int PA = NA / 4, PW = NW / 4;                 // pieces per loader wavefront and step
-    constexpr int NSL = 2 * (64 / KS);                      // slots (= barriers) per K step
-    constexpr int NKK = KS / 32;
-    static_assert(BM % 32 == 0 && NA % 4 == 0 && (NSA == 2 || NSA == 3) && (NSW == 2 || NSW == 3), "tile / rings");
-    static_assert(KS == 64 ? (PA == 1 || PA == 2 || PA == 3 || PA == 4 || PA == 6 || PA == 8) : (PA % 2 == 0 && PA / 2 <= 4), "loader chunking");
-    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef WMI_G8_LAB
-    const int lab = a.no_glds;
-#else
-    constexpr int lab = 0;
+    if (a.no_glds & 4096) grid = 64;                        // (lab) a quarter of the CUs: is the epilogue's store rate a chip-wide limit?
 #endif
-    const unsigned long long pt0 = a.probe ? wall_clock64() : 0ull;
-    unsigned long long pt1 = 0ull, pt2 = 0ull, pte = 0ull;
-
-    const int ntm = (a.M + BM - 1) / BM, ntn = a.N / BN, ntiles = ntm * ntn;
-    const int nx = (int) gridDim.x >> 3;
-    const int xcd = (int) blockIdx.x & 7, jx = (int) blockIdx.x >> 3;
-    const int per = (ntiles + 7) >> 3;
-    const int run = ntiles - xcd * per < per ? ntiles - xcd * per : per;
-    const int n_my = run > jx ? (run - jx + nx - 1) / nx : 0;
-    constexpr int GN = 8;
-    auto tile_origin = [&](int i, int & m0, int & n0) {
-        const int idx = xcd * per + jx + i * nx;
-        const int ng = idx / (ntm * GN), rem = idx - ng * (ntm * GN);
-        const int gcur = ntn - ng * GN < GN ? ntn - ng * GN : GN;
-        m0 = (rem / gcur) * BM; n0 = (ng * GN + rem % gcur) * BN;
-    };
-    const int nk = a.K / 64;
-    const int total = n_my * nk;
-    const uint32_t lds0 = lds_addr(smem);
-
-    if (wave >= 8) {
-        // ------------------------------------------------------------------------------------------------ loader wavefronts
-        const int ld = wave - 8, prow = lane >> 3;
-        struct Stream { int i = 0, k = 0, n = 0; const __half * base = nullptr; };
-        Stream sa, sw;
-        uint32_t vA[PA], vW[PW];
-        const int pa0 = ld * PA, pw0 = ld * PW;
-#pragma unroll
-        for (int p = 0; p < PW; ++p) {
-            const int lrow = (pw0 + p) * 8 + prow, pch = (lane & 7) ^ (lrow & 7);
-            vW[p] = (uint32_t) (lrow * a.ldw + pch * 8) * 2u;
-        }
-        auto adv = [&](Stream & t) { ++t.n; if (++t.k == nk) { t.k = 0; ++t.i; } };
-        auto prep_a = [&]() {
-            if (sa.k == 0) {
-                int m0, n0; tile_origin(sa.i, m0, n0);
-                sa.base = a.A + (size_t) m0 * a.lda;
-                const int rmax = a.M - 1 - m0;
-#pragma unroll
-                for (int p = 0; p < PA; ++p) {
-                    int lrow = (pa0 + p) * 8 + prow; const int pch = (lane & 7) ^ (lrow & 7);
-                    if (lrow > rmax) lrow = rmax;
-                    vA[p] = (uint32_t) (lrow * a.lda + pch * 8) * 2u;
-                }
-            }
-        };
-        auto prep_w = [&]() { if (sw.k == 0) { int m0, n0; tile_origin(sw.i, m0, n0); sw.base = a.W + (size_t) n0 * a.ldw; } };
-        // part h of H of this step's requests for an image (H = 1: the whole image in one slot; H = 2: half per slot)
-        auto req_a = [&](auto h_tag, auto H_tag) {
-            constexpr int h = decltype(h_tag)::value, Hn = decltype(H_tag)::value, N = PA / Hn;
-            if (h == 0) prep_a();
-            uint32_t v[N];
-#pragma unroll
-            for (int p = 0; p < N; ++p) v[p] = vA[h * N + p];
-            glds_run<N>(v, sa.base + sa.k * 64, lds0 + (uint32_t) (sa.n % NSA) * SZA + (uint32_t) (pa0 + h * N) * 1024u);
-            if (h == Hn - 1) adv(sa);
-        };
-        auto req_w = [&](auto h_tag, auto H_tag) {
-            constexpr int h = decltype(h_tag)::value, Hn = decltype(H_tag)::value, N = PW / Hn;
-            if (h == 0) prep_w();
-            uint32_t v[N];
-#pragma unroll
-            for (int p = 0; p < N; ++p) v[p] = vW[h * N + p];
-            glds_run<N>(v, sw.base + sw.k * 64, lds0 + RING_W + (uint32_t) (sw.n % NSW) * SZW + (uint32_t) (pw0 + h * N) * 1024u);
-            if (h == Hn - 1) adv(sw);
-        };
-        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
-        // everything step gs reads has landed when only this loader's two-steps-ahead requests issued behind it are outstanding
-        auto wait_step = [&](int gs) {
-            const bool a_late = NSA == 3 && sa.n > gs + 1, w_late = NSW == 3 && sw.n > gs + 1;
-            if (a_late && w_late) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PA + PW) : "memory");
-            else if (w_late)      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PW) : "memory");
-            else if (a_late)      asm volatile("s_waitcnt vmcnt(%0)" :: "n"(PA) : "memory");
-            else                  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        };
-        // prologue (one-step-ahead image first: wait_step counts on that order)
-        if constexpr (NSA == 2) { if (sa.n < total) req_a(I0{}, I1{}); }
-        if constexpr (NSW == 2) { if (sw.n < total) req_w(I0{}, I1{}); }
-        if constexpr (NSA == 3) { for (int s0 = 0; s0 < 2; ++s0) if (sa.n < total) req_a(I0{}, I1{}); }
-        if constexpr (NSW == 3) { for (int s0 = 0; s0 < 2; ++s0) if (sw.n < total) req_w(I0{}, I1{}); }
-        // (three-deep images issued step 0 and step 1 back to back: step 1's pieces are the "late" ones of the first wait)
-        if (total > 0) wait_step(0);
-        __builtin_amdgcn_s_barrier();                                   // B0
-        int gs = 0;
-        for (int ti = 0; ti < n_my; ++ti) {
-            for (int kt = 0; kt < nk; ++kt, ++gs) {
-                // requests of this step: image(s) one step ahead in the first slot(s), two steps ahead behind them
-                const bool more_a = sa.n < total && !(lab & 8), more_w = sw.n < total && !(lab & 8);
-                if constexpr (NSL == 2) {
-                    if constexpr (NSA == 2) { if (more_a) req_a(I0{}, I1{}); if constexpr (NSW == 2) { if (more_w) req_w(I0{}, I1{}); } }
-                    else { if (more_a) req_a(I0{}, I1{}); }
-                    __builtin_amdgcn_s_barrier();
-                    if constexpr (!(NSA == 2 && NSW == 2)) { if (more_w) req_w(I0{}, I1{}); }
-                    if (gs + 1 < total) wait_step(gs + 1);
-                    __builtin_amdgcn_s_barrier();
-                } else {
-                    if (more_a) req_a(I0{}, I2{});
-                    __builtin_amdgcn_s_barrier();
-                    if (more_a) req_a(I1{}, I2{});
-                    __builtin_amdgcn_s_barrier();
-                    if (more_w) req_w(I0{}, I2{});
-                    __builtin_amdgcn_s_barrier();
-                    if (more_w) req_w(I1{}, I2{});
-                    if (gs + 1 < total) wait_step(gs + 1);
-                    __builtin_amdgcn_s_barrier();
-                }
-            }
-            __builtin_amdgcn_s_barrier();                               // the tile's epilogue slot
-        }
-        __builtin_amdgcn_s_barrier();                                   // group 1's lag
-        return;
-    }
-
-    // ------------------------------------------------------------------------------------------------ MFMA wavefronts
-    const int grp = wave >> 2, wn = wave & 3;
-    floatx4 acc[FM][FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
-#pragma unroll
-        for (int j = 0; j < FN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-    const int frow = lane & 15, fq = lane >> 4;
-    uint32_t offA[FM], offB[FN];
-#pragma unroll
-    for (int i = 0; i < FM; ++i) offA[i] = lds_off8(grp * (BM / 2) + i * 16 + frow, fq);
-#pragma unroll
-    for (int j = 0; j < FN; ++j) offB[j] = RING_W + lds_off8(wn * 64 + j * 16 + frow, fq);
-
-    auto body = [&](auto grp_tag) {
-        constexpr int G = decltype(grp_tag)::value;
-        __builtin_amdgcn_s_barrier();                                   // B0: the loaders' first step has landed
-        if (a.probe) pt1 = wall_clock64();
-        if constexpr (G == 1) __builtin_amdgcn_s_barrier();            // group 1 runs one slot behind
-        int gs = 0;
-        for (int ti = 0; ti < n_my; ++ti) {
-            for (int kt = 0; kt < nk; ++kt, ++gs) {
-                const unsigned char * stA = smem + (size_t) (gs % NSA) * SZA;
-                const unsigned char * stW = smem + (size_t) (gs % NSW) * SZW;
-#pragma unroll
-                for (int sl = 0; sl < 64 / KS; ++sl) {
-                    half8 fa[NKK][FM], fb[NKK][FN];
-                    if (!(lab & 32) || gs == 0) {
-#pragma unroll
-                        for (int q = 0; q < NKK; ++q) {
-                            const uint32_t kx = (uint32_t) ((sl * NKK + q) << 6);
-#pragma unroll
-                            for (int j = 0; j < FN; ++j) fb[q][j] = *(const half8 *) (stW + (offB[j] ^ kx));
-#pragma unroll
-                            for (int i = 0; i < FM; ++i) fa[q][i] = *(const half8 *) (stA + (offA[i] ^ kx));
-                        }
-                    }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                    __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_barrier();
-                    __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_setprio(1);
-                    if (!(lab & 16))
-#pragma unroll
-                    for (int q = 0; q < NKK; ++q)
-#pragma unroll
-                        for (int i = 0; i < FM; ++i)
-#pragma unroll
-                            for (int j = 0; j < FN; ++j)
-                                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fb[q][j], fa[q][i], acc[i][j], 0, 0, 0);
-                    __builtin_amdgcn_s_setprio(0);
-                    __builtin_amdgcn_sched_barrier(0);
-                    __builtin_amdgcn_s_barrier();
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            if constexpr (G == 0) __builtin_amdgcn_s_barrier();        // both groups run the epilogue in the same slot (see k_gemm8)
-            if (a.probe && ti == 0) pt2 = wall_clock64();
-            int m0, n0; tile_origin(ti, m0, n0);
-            const int mb = m0 + grp * (BM / 2), nb = n0 + wn * 64;
-            const bool interior = m0 + BM <= a.M;
-            if (lab & 4) {
-#pragma unroll
-                for (int i = 0; i < FM; ++i)
-#pragma unroll
-                    for (int j = 0; j < FN; ++j) asm volatile("" :: "v"(acc[i][j]));
-            } else {
-                if (interior) epilogue_cols_wide<EPI, FM, FN, false>(a, acc, mb, nb, n0, lane); else epilogue_cols_wide<EPI, FM, FN, true>(a, acc, mb, nb, n0, lane);
-            }
-#pragma unroll
-            for (int i = 0; i < FM; ++i)
-#pragma unroll
-                for (int j = 0; j < FN; ++j) acc[i][j] = floatx4{0.f, 0.f, 0.f, 0.f};
-            if (a.probe && ti == 0) pte = wall_clock64();
-            if constexpr (G == 1) __builtin_amdgcn_s_barrier();
-        }
-        if constexpr (G == 0) __builtin_amdgcn_s_barrier();
-    };
-    if (grp == 0) body(std::integral_constant<int, 0>{}); else body(std::integral_constant<int, 1>{});
-    if (a.probe && tid == 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        unsigned long long * o = a.probe + (size_t) blockIdx.x * 5;
-        o[0] = pt0; o[1] = pt1; o[2] = pt2; o[3] = wall_clock64(); o[4] = pte;
-    }
+    hipLaunchKernelGGL((k_gemm8<BM, EPI, NSA, NSW, SWAPPED, KS, DEFER>), dim3(grid), dim3(512), smem, st, a);
 }
 
-template <int BM, int EPI, int NSA, int NSW, int KS>
-void launch8l(const GemmArgs & a, hipStream_t st) {
-    const int ntm = (a.M + BM - 1) / BM, ntn = a.N / 256;
-    const size_t smem = (size_t) NSA * BM * 128 + (size_t) NSW * 256 * 128;
-    static std::atomic<uint64_t> lds_ok{0};
-    allow_full_lds((const void *) k_gemm8l<BM, EPI, NSA, NSW, KS>, lds_ok);
-    const int n_cu = cu_count_x8();
-    const int tiles = ntm * ntn;
-    const int grid = tiles < n_cu ? (tiles + 7) & ~7 : n_cu;
-    hipLaunchKernelGGL((k_gemm8l<BM, EPI, NSA, NSW, KS>), dim3(grid), dim3(768), smem, st, a);
-}
-#endif  // WMI_G8_LAB
 
 } // namespace
 
@@ -558,20 +352,19 @@ void launch8l(const GemmArgs & a, hipStream_t st) {
 bool gemm8(int epi, int bm, bool swapped, const GemmArgs & a, hipStream_t st, int ks) {
     if ((a.N % 256) != 0 || (a.K % 64) != 0 || a.M < 1) return false;
 #ifdef WMI_G8_LAB
-    if (ks == 164 || ks == 132) {                          // (lab) the loader-wave kernel: 64- / 32-deep slots
+    if (ks == 264 || ks == 232) {                          // (lab) deferred stores: the f16 row-major epilogues, transposed fragments
         if (!swapped) return false;
-#define WMI_G8L(E)                                                                                      \
+#define WMI_G8D(E)                                                                                      \
     case E:                                                                                             \
-        if (ks == 164) { if (bm == 128) launch8l<128, E, 3, 3, 64>(a, st); else if (bm == 96) launch8l<96, E, 3, 3, 64>(a, st); else return false; }    \
-        else { if (bm == 192) launch8l<192, E, 2, 3, 32>(a, st); else if (bm == 128) launch8l<128, E, 3, 3, 32>(a, st); else if (bm == 256) launch8l<256, E, 2, 2, 32>(a, st); else return false; } \
+        if (ks == 264) { if (bm == 192) launch8<192, E, 2, 3, true, 64, true>(a, st); else if (bm == 128) launch8<128, E, 3, 3, true, 64, true>(a, st); else if (bm == 160) launch8<160, E, 3, 3, true, 64, true>(a, st); else return false; } \
+        else           { if (bm == 192) launch8<192, E, 2, 3, true, 32, true>(a, st); else if (bm == 256) launch8<256, E, 2, 2, true, 32, true>(a, st); else return false; } \
         return true;
         switch (epi) {
-            WMI_G8L(EPI_F16_BIAS_GELU)
-            WMI_G8L(EPI_F32_BIAS_RESID)
-            WMI_G8L(EPI_CROSS_KV)
+            WMI_G8D(EPI_F16_BIAS_GELU)
+            WMI_G8D(EPI_CROSS_KV)
             default: return false;
         }
-#undef WMI_G8L
+#undef WMI_G8D
     }
     if (ks != 32 && ks != 64) return false;
 #define WMI_G8B(E, SW, KSV)                                                                             \

@@ -105,6 +105,45 @@ __device__ __forceinline__ void glds_run(const uint32_t (&v)[N], const void * sb
 #undef WMI_GL_
 #undef WMI_GL_HEAD
 #undef WMI_GL_TAIL
+
+// The same run with ONE offset register: piece p reads at v0 + p * stride (8 rows further down the same columns), clamped to vclamp
+// (CLAMP: the lane's offset in the last valid row — the bottom edge of a matrix whose row count is not a multiple of the tile).  The
+// piece offsets are formed in a scratch register right in front of each request (v_add_u32 [+ v_min_u32]): two or three VGPRs per
+// operand instead of one per piece — k_gemm8's deferred stores need the registers.  N in 1..8.
+#define WMI_GLA_(CL) "v_add_u32 %[t], %[v0], %[acc]\n\t" CL "global_load_lds_dwordx4 %[t], %[b]\n\ts_add_u32 m0, m0, 0x400\n\ts_add_u32 %[acc], %[acc], %[st]\n\t"
+#define WMI_GLA_CL "v_min_u32 %[t], %[t], %[vc]\n\t"
+#define WMI_GLA_REP1(CL) WMI_GLA_(CL)
+#define WMI_GLA_REP2(CL) WMI_GLA_(CL) WMI_GLA_(CL)
+#define WMI_GLA_REP3(CL) WMI_GLA_REP2(CL) WMI_GLA_(CL)
+#define WMI_GLA_REP4(CL) WMI_GLA_REP2(CL) WMI_GLA_REP2(CL)
+#define WMI_GLA_REP5(CL) WMI_GLA_REP4(CL) WMI_GLA_(CL)
+#define WMI_GLA_REP6(CL) WMI_GLA_REP4(CL) WMI_GLA_REP2(CL)
+#define WMI_GLA_REP7(CL) WMI_GLA_REP4(CL) WMI_GLA_REP3(CL)
+#define WMI_GLA_REP8(CL) WMI_GLA_REP4(CL) WMI_GLA_REP4(CL)
+#define WMI_GLA_HEAD "s_mov_b32 %[k], m0\n\ts_mov_b32 m0, %[d]\n\ts_mov_b32 %[acc], 0\n\t"
+#define WMI_GLA_TAIL "s_mov_b32 m0, %[k]"
+#define WMI_GLA_CASE(NN)                                                                                                            \
+    if constexpr (N == NN) {                                                                                                          \
+        if constexpr (CLAMP) asm volatile(WMI_GLA_HEAD WMI_GLA_REP##NN(WMI_GLA_CL) WMI_GLA_TAIL : [k] "=&s"(keep), [acc] "=&s"(acc), [t] "=&v"(t)   \
+                                          : [v0] "v"(v0), [vc] "v"(vclamp), [st] "s"(st), [d] "s"(d), [b] "s"(b) : "memory", "scc");  \
+        else                 asm volatile(WMI_GLA_HEAD WMI_GLA_REP##NN("") WMI_GLA_TAIL : [k] "=&s"(keep), [acc] "=&s"(acc), [t] "=&v"(t)           \
+                                          : [v0] "v"(v0), [st] "s"(st), [d] "s"(d), [b] "s"(b) : "memory", "scc");                    \
+    }
+template <int N, bool CLAMP>
+__device__ __forceinline__ void glds_run_affine(uint32_t v0, uint32_t stride, uint32_t vclamp, const void * sbase, uint32_t lds_dst) {
+    static_assert(N >= 1 && N <= 8, "glds_run_affine: piece count");
+    uint32_t keep, acc, t;
+    const uint32_t d = __builtin_amdgcn_readfirstlane(lds_dst), st = __builtin_amdgcn_readfirstlane(stride);
+    const uint64_t b64 = (uint64_t) (uintptr_t) sbase;
+    const uint64_t b = ((uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (b64 >> 32)) << 32) | (uint32_t) __builtin_amdgcn_readfirstlane((int) (uint32_t) b64);
+    WMI_GLA_CASE(1) WMI_GLA_CASE(2) WMI_GLA_CASE(3) WMI_GLA_CASE(4) WMI_GLA_CASE(5) WMI_GLA_CASE(6) WMI_GLA_CASE(7) WMI_GLA_CASE(8)
+    (void) vclamp;
+}
+#undef WMI_GLA_CASE
+#undef WMI_GLA_
+#undef WMI_GLA_CL
+#undef WMI_GLA_HEAD
+#undef WMI_GLA_TAIL
 __device__ __forceinline__ uint32_t lds_addr(const void * p) { return (uint32_t) (uintptr_t) (__attribute__((address_space(3))) const void *) p; }
 
 // xor_lane with the mask as a value: inside a fully unrolled `for (o = 32; o > 0; o >>= 1)` the switch folds to the one DPP form

@@ -71,7 +71,7 @@ int main(int argc, char ** argv) {
         printf("%-26s M=%5d N=%5d K=%5d | shipping k_gemm %8.2f us %7.1f TF/s\n", s.what, s.M, s.N, s.K, t0, flop / t0 / 1e6);
         std::vector<unsigned char> c0(csz), x0(csz), c1(csz), x1(csz);
         CK(hipMemcpy(c0.data(), dC0, csz, hipMemcpyDeviceToHost)); CK(hipMemcpy(x0.data(), dX0, csz, hipMemcpyDeviceToHost));
-        for (int bm : {96, 128, 160, 192, 256}) for (int ks : {64, 32, 164, 132}) for (int sw = 1; sw >= 1; --sw) {
+        for (int bm : {96, 128, 160, 192, 256}) for (int ks : {64, 32, 264, 232}) for (int sw = 1; sw >= 1; --sw) {   // 2xx: deferred stores
             if (getenv("LAB_BM") && atoi(getenv("LAB_BM")) != bm) continue;
             if (getenv("LAB_KS") && atoi(getenv("LAB_KS")) != ks) continue;
             CK(hipMemset(dC1, 0, csz)); CK(hipMemset(dX1, 0, csz));
@@ -112,6 +112,14 @@ int main(int argc, char ** argv) {
                     for (int g = 0; g < 2; ++g)
                         printf("        slots, group %d (cycles per K step and wave): LOAD work %.0f, barrier behind LOAD %.0f, MFMA work %.0f, vmcnt wait %.0f, barrier behind MFMA %.0f\n", g,
                                sum[g][0] / (cap * 4) / nsteps, sum[g][1] / (cap * 4) / nsteps, sum[g][2] / (cap * 4) / nsteps, sum[g][3] / (cap * 4) / nsteps, sum[g][4] / (cap * 4) / nsteps);
+                }
+                {   // a quarter of the CUs (64 workgroups walking the whole tile list): per-tile epilogue time when few CUs store at once
+                    unsigned long long * dq; CK(hipMalloc(&dq, (size_t) 64 * 5 * 8)); CK(hipMemset(dq, 0, (size_t) 64 * 5 * 8));
+                    GemmArgs aq = a1; aq.probe = dq; aq.no_glds = 4096;
+                    gemm8(s.epi, bm, sw != 0, aq, st, ks); CK(hipStreamSynchronize(st));
+                    std::vector<unsigned long long> hq((size_t) 64 * 5); CK(hipMemcpy(hq.data(), dq, hq.size() * 8, hipMemcpyDeviceToHost)); (void) hipFree(dq);
+                    double l = 0, e = 0; for (int i = 0; i < 64; ++i) { l += hq[i * 5 + 2] - hq[i * 5 + 1]; e += hq[i * 5 + 4] - hq[i * 5 + 2]; }
+                    printf("        64 workgroups only: first tile's K loop %.2f us, its epilogue %.2f us\n", l / 64 * 0.01, e / 64 * 0.01);
                 }
                 for (int flags : {4, 4 | 8, 4 | 16, 4 | 8 | 16, 4 | 8 | 32, 4 | 8 | 16 | 32}) {
                     GemmArgs af = a1; af.no_glds = flags;

@@ -8,10 +8,13 @@ the committed goldens that the reference itself produced.
 Tolerances (floating point; the reference is an f16-operand / f32-accumulate machine, SURVEY App. B — every
 rounding point is reproduced, what differs is f32 summation order inside dot products, which flips a small
 fraction of f16 roundings):
-    log-mel                      |d| <= 2e-6                       (same FFT decomposition and tables)
-    encoder tensors / cross K,V  rms(d)/rms(ref) <= 2e-3 ; |d| <= 2e-2
-    logits                       rms(d)/rms(ref) <= 2e-3 ; |d| <= 6e-2   (logit rms ~ 6)
+    log-mel                      |d| <= 5e-7                       (same FFT decomposition and tables)
+    encoder tensors / cross K,V  rms(d)/rms(ref) <= 1e-3 ; |d| <= 8e-3
+    logits                       rms(d)/rms(ref) <= 1e-3 ; |d| <= 3e-2   (logit rms ~ 6)
     token probabilities          |dp| <= 1e-2
+(round 5: held to ~2x what a full GPU run measures — mel 1.2e-7, tensors 5.7e-4 / 3.9e-3, logits 5.7e-4 / 1.55e-2,
+profiles/r05a_parity_margins.json; every run prints the margins, tests/conftest.py — the round-4 bounds were 3-5x looser and a
+3x regression would have passed)
     token ids, timestamps, text  identical on every greedy case below
 """
 import ctypes as C
@@ -28,8 +31,9 @@ from oracle import port, reflib
 pytestmark = pytest.mark.gpu
 
 G = np.load(gu.GOLDEN / "hotpath.npz")
-TOL = {"mel": (2e-6, 1.0), "embd_conv": (2e-2, 2e-3), "embd_enc": (2e-2, 2e-3), "cross_k": (2e-2, 2e-3), "cross_v": (2e-2, 2e-3)}
-LOGIT_ABS, LOGIT_RMS = 6e-2, 2e-3
+TOL = {"mel": (5e-7, 1.0), "embd_conv": (8e-3, 1e-3), "embd_enc": (8e-3, 1e-3), "cross_k": (8e-3, 1e-3), "cross_v": (8e-3, 1e-3)}
+LOGIT_ABS, LOGIT_RMS = 3e-2, 1e-3
+P_LOGIT_ABS = 6e-2              # the logit error the token-probability bound of the streaming replay is derived from (unchanged)
 
 
 def make_checker(model, ref_lib_or_none):
@@ -69,17 +73,17 @@ def test_stages_against_checker(product_lib, checker_lib, name):
             sc.hold_tensor(k, st, TOL[k])
             # and the reference's golden sample of the same tensor
             g = G[f"{name}/{k}/sample"]
-            assert np.abs(ep[k].ravel()[::997] - g).max() <= TOL[k][0], k
+            sc.hold(f"{k} max |d| vs the reference's golden sample", float(np.abs(ep[k].ravel()[::997] - g).max()), TOL[k][0], name)
         prompt = sot_prompt(chk, prod)
         lr = chk.decode(prompt, 0); lp = prod.decode(prompt, 0)
         assert_logits(lp, lr, "prompt")
-        assert np.abs(lp[::101] - G[f"{name}/logits_prompt/sample"]).max() <= LOGIT_ABS
+        sc.hold("logits max |d| vs the reference's golden sample", float(np.abs(lp[::101] - G[f"{name}/logits_prompt/sample"]).max()), LOGIT_ABS, name)
         for i, tok in enumerate(G[f"{name}/fed_tokens"]):
             lr = chk.decode([int(tok)], len(prompt) + i); lp = prod.decode([int(tok)], len(prompt) + i)
             assert_logits(lp, lr, f"step{i}")
         many = prompt + [int(x) for x in (np.arange(11) * 997 + 1000)]          # > 8 rows: MFMA GEMM path of the decoder
         assert_logits(prod.decode(many, 0), chk.decode(many, 0), "batch12")
-        assert np.abs(prod.decode(many, 0)[::101] - G[f"{name}/logits_batch/sample"]).max() <= LOGIT_ABS
+        sc.hold("logits max |d| vs the reference's golden sample", float(np.abs(prod.decode(many, 0)[::101] - G[f"{name}/logits_batch/sample"]).max()), LOGIT_ABS, name)
     finally:
         prod.close(); chk.close()
 
@@ -222,7 +226,7 @@ def test_base_en_full_size_against_checker(product_lib, checker_lib):
         b = prod.decode(prompt + [1000, 2000], 0).copy()
         assert np.array_equal(a, b)
         prod.decode(prompt, 0); prod.decode([1000], len(prompt)); c = prod.decode([2000], len(prompt) + 1)
-        assert np.abs(a - c).max() <= LOGIT_ABS
+        sc.hold("logits max |d|, 3-row batch vs three one-row steps (product vs product)", float(np.abs(a - c).max()), P_LOGIT_ABS)
     finally:
         prod.close(); chk.close()
 
@@ -951,9 +955,9 @@ def test_ten_minute_stream_small_shape(product_lib, checker_lib):
                 n_full += 1
             if first:
                 # p = soft-max probability of the picked token: a logit difference d moves it by p (1 - p) d, i.e. by up to 0.25 x the logit
-                # bound (LOGIT_ABS = 6e-2, + 20 % for the log-sum-exp) where the distribution is flat (p ~ 0.3-0.5 on these weights); 1e-2 holds where p > 0.9
+                # bound (P_LOGIT_ABS = 6e-2, + 20 % for the log-sum-exp) where the distribution is flat (p ~ 0.3-0.5 on these weights); 1e-2 holds where p > 0.9
                 dp = np.abs(g[:first, 2] - w[:first, 2]); worst_p = max(worst_p, float(dp.max()))
-                assert np.all(dp <= np.maximum(1e-2, 1.2 * LOGIT_ABS * w[:first, 2] * (1 - w[:first, 2]) + 2e-3)), (n_cmp, dp, w[:first, 2])
+                assert np.all(dp <= np.maximum(1e-2, 1.2 * P_LOGIT_ABS * w[:first, 2] * (1 - w[:first, 2]) + 2e-3)), (n_cmp, dp, w[:first, 2])
                 assert np.array_equal(g[:first, 6], w[:first, 6])                 # token start times of the common prefix
             n_tok += first
             n_cmp += 1
