@@ -122,7 +122,11 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
     // 43.7 us) and the residual epilogues (44.6 / 43.2 on 128 x 128 tiles, 23.9 / 21.6 on 64 x 64): those keep the first orientation
     // on the big grids.  Workgroup-uniform, both epilogues are compiled.
     const bool big = a.M >= 4096;
-    const bool swap = SWAP && !(EPI == EPI_QKV_ENC && (n0 >= 2 * a.S || big)) && !(EPI == EPI_F32_BIAS_RESID && big);
+    // (round 5, with the full-line stores of epilogue_cols_wide: the q and k thirds in the transposed form on the big grids measure the
+    //  same as the first orientation — 41.3-41.8 against 40.9-41.2 us, profiles/r05b_gemm_lab_qkv.txt: the V^T third's scattered 8-byte
+    //  stores are what the q|k|v epilogue costs over a plain one (34.5 us) — so the round-3 choice stays; a.no_glds bit 8 =
+    //  WMI_GEMM_QKV_SWAP is the A/B knob)
+    const bool swap = SWAP && !(EPI == EPI_QKV_ENC && (n0 >= 2 * a.S || (big && !(a.no_glds & 8)))) && !(EPI == EPI_F32_BIAS_RESID && big);
     auto compute = [&](int buf, auto sw_tag) {
         constexpr bool SWF = decltype(sw_tag)::value;
 #pragma unroll
@@ -328,7 +332,8 @@ void gemm(int epi, const GemmArgs & a_in, hipStream_t st) {
     static const bool no_glds = getenv("WMI_GEMM_NO_GLDS") != nullptr;       // debug / A-B: register-staged loop for every tile size
     static const bool guard_all = getenv("WMI_GEMM_GUARD_ALL") != nullptr;   // debug / A-B: bounds-checked epilogue for every tile
     static const bool narrow = getenv("WMI_GEMM_NARROW_STORES") != nullptr;  // debug / A-B: 8-byte epilogue stores
-    GemmArgs a = a_in; a.no_glds = (no_glds ? 1 : 0) | (guard_all ? 2 : 0) | (narrow ? 4 : 0);
+    static const bool qkv_swap = getenv("WMI_GEMM_QKV_SWAP") != nullptr;    // debug / A-B: q and k thirds of the big q|k|v grids in the transposed orientation
+    GemmArgs a = a_in; a.no_glds = (no_glds ? 1 : 0) | (guard_all ? 2 : 0) | (narrow ? 4 : 0) | (qkv_swap ? 8 : 0);
     if (GemmLog * lg = tl_gemm_log) {
         const size_t wgs = (size_t) ((a.M + 63) / 64) * (size_t) ((a.N + 31) / 32);     // the smallest tile any dispatch below uses is 64 x 32
         if (!a.probe && lg->used + wgs * 5 <= lg->cap_words) {
@@ -346,6 +351,14 @@ void gemm(int epi, const GemmArgs & a_in, hipStream_t st) {
         (epi != EPI_CROSS_KV || (a.S % 64) == 0)) {
         const long t192 = (long) ((a.M + 191) / 192) * (a.N / 256);
         if (t192 >= 384) { GemmArgs b = a; b.no_glds = 0; if (gemm8(epi, 192, true, b, st)) return; }
+    }
+    // (q|k|v stays below: on 288-row tiles — 42 x 6 = 252, ONE round at M = 12 000 — the persistent kernel measures 41.1 us against 41.0 us
+    //  here, in situ 37.5 against 37.4: the V^T third's epilogue decides, not the tiling; WMI_GEMM8_QKV=1 routes it there for A/B)
+    static const bool g8_qkv = getenv("WMI_GEMM8_QKV") != nullptr;
+    if (g8_qkv && g8 && !no_glds && epi == EPI_QKV_ENC && a.M >= 4096 && (a.N % 256) == 0 && (a.K % 64) == 0 && a.S > 0 && (a.S % 128) == 0 && a.N == 3 * a.S) {
+        const long t288 = (long) ((a.M + 287) / 288) * (a.N / 256);
+        const int n_cu = cu_count_x8();
+        if (t288 <= n_cu && t288 * 5 >= (long) n_cu * 4) { GemmArgs b = a; b.no_glds = 0; if (gemm8(epi, 288, true, b, st, 32)) return; }
     }
     switch (epi) {
         case EPI_F16_BIAS:       dispatch<EPI_F16_BIAS>(a, st); break;

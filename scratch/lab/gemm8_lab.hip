@@ -25,6 +25,7 @@ int main(int argc, char ** argv) {
         { 1500, 2048,  512, EPI_F16_BIAS_GELU,  "mlp.0 x1 (GELU)"},
         {24000, 2048,  512, EPI_F16_BIAS_GELU,  "mlp.0 x16 (GELU)"},
         {12000, 2048,  512, EPI_F16_BIAS,       "mlp.0-shaped x8, f16 + bias only"},
+        {12000, 1536,  512, EPI_QKV_ENC,        "q|k|v^T x8 (the encoder's own epilogue)"},
     };
     const int only = argc > 1 ? atoi(argv[1]) : -1;
     hipStream_t st; CK(hipStreamCreate(&st));
@@ -48,6 +49,10 @@ int main(int argc, char ** argv) {
         auto args = [&](unsigned char * C, unsigned char * X) {
             GemmArgs a{}; a.A = dA; a.lda = s.K; a.W = dW; a.ldw = s.K; a.M = s.M; a.N = s.N; a.K = s.K; a.bias = db; a.C = C; a.ldc = s.N;
             if (s.epi == EPI_F32_BIAS_RESID) { a.resid = dR; a.ldr = s.N; }
+            if (s.epi == EPI_QKV_ENC) {            // q -> C, k -> X, V^T [chunk][S][Tpad] -> X + 16 MiB (all f16)
+                a.S = 512; a.ldc = 512; a.aux = X; a.ldaux = 512; a.aux2 = X + (16u << 20); a.ldaux2 = 1504; a.rows_per_chunk = 1500;
+                a.chunk_stride_aux2 = (int64_t) 512 * 1504;
+            }
             if (s.epi == EPI_CROSS_KV) {           // columns [layer][K: S | V: S], outputs [layer][M][S] each
                 a.S = 512; a.scale = 0.35355339f; a.aux = X; a.ldc = 512; a.ldaux = 512; a.layer_stride = (size_t) s.M * 512;
             }
@@ -71,11 +76,18 @@ int main(int argc, char ** argv) {
         printf("%-26s M=%5d N=%5d K=%5d | shipping k_gemm %8.2f us %7.1f TF/s\n", s.what, s.M, s.N, s.K, t0, flop / t0 / 1e6);
         std::vector<unsigned char> c0(csz), x0(csz), c1(csz), x1(csz);
         CK(hipMemcpy(c0.data(), dC0, csz, hipMemcpyDeviceToHost)); CK(hipMemcpy(x0.data(), dX0, csz, hipMemcpyDeviceToHost));
-        for (int bm : {96, 128, 160, 192, 256}) for (int ks : {64, 32, 264, 232}) for (int sw = 1; sw >= 1; --sw) {   // 2xx: deferred stores
+        for (int bm : {96, 128, 160, 192, 256, 288}) for (int ks : {64, 32}) for (int sw = 1; sw >= 1; --sw) {   // 2xx: deferred stores
+            if (getenv("LAB_SET")) {                      // "bm:ks,bm:ks,..."
+                char key[32]; snprintf(key, sizeof(key), "%d:%d", bm, ks);
+                const char * set = getenv("LAB_SET"); const char * f = strstr(set, key);
+                bool hit = false;
+                while (f) { const char e = f[strlen(key)]; if ((f == set || f[-1] == ',') && (e == 0 || e == ',')) { hit = true; break; } f = strstr(f + 1, key); }
+                if (!hit) continue;
+            }
             if (getenv("LAB_BM") && atoi(getenv("LAB_BM")) != bm) continue;
             if (getenv("LAB_KS") && atoi(getenv("LAB_KS")) != ks) continue;
             CK(hipMemset(dC1, 0, csz)); CK(hipMemset(dX1, 0, csz));
-            const GemmArgs a1 = args(dC1, dX1);
+            GemmArgs a1 = args(dC1, dX1); if (getenv("LAB_FLAGS")) a1.no_glds = atoi(getenv("LAB_FLAGS"));
             if (!gemm8(s.epi, bm, sw != 0, a1, st, ks)) { printf("    gemm8 bm=%3d ks=%d: not served\n", bm, ks); continue; }
             CK(hipStreamSynchronize(st)); CK(hipGetLastError());
             CK(hipMemcpy(c1.data(), dC1, csz, hipMemcpyDeviceToHost)); CK(hipMemcpy(x1.data(), dX1, csz, hipMemcpyDeviceToHost));
