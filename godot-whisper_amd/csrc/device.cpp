@@ -892,7 +892,7 @@ int step_stamps(whisper_context & ctx, double * out, int cap, bool chained) {
     const int Tc = st.enc_n_ctx > 0 ? st.enc_n_ctx : ctx.model.hp.n_audio_ctx;
     hipStream_t s = d.stream;
     const bool long_kv = ((const k::DecStep *) d.step_host)->n_kv > 64;
-    constexpr int MAXL = 256;
+    constexpr int MAXL = 512;
     const size_t bytes = (size_t) MAXL * k::STAMP_WAVES * 4 * sizeof(unsigned long long);
     unsigned long long * buf = nullptr;
     if (!HIP_OK(hipMalloc((void **) &buf, bytes))) return -1;

@@ -19,6 +19,7 @@
 
 namespace wmi {
 
+
 namespace {
 
 // activation source of a projection
@@ -234,6 +235,16 @@ void enqueue_greedy_step_q(whisper_context & ctx, int Tc) {
         if (resid && !co && !src.x16) pend = nullptr;                        // the self-attention's out projection writes the row whole again
         if (src.x16 && epi == k::EPI_F32_BIAS_RESID && fc2_ksplit(g, d.xattn)) pend = d.xattn;      // mlp.2
         k::qrows(g, src.ln_g ? nullptr : src.x32, W, s);
+#ifdef WMI_QROWS_PROBE
+        // (probe build, WMI_Q_DOUBLE=1) the same launch once more on the NEXT layer's matrix of the same kind: cold weights, warm
+        // instruction cache — what of a launch's body is instruction fetch?  (results are garbage: timing only)
+        static const bool dbl = getenv("WMI_Q_DOUBLE") != nullptr;
+        if (dbl && &W >= (const k::QMat *) &w.dec[0] && &W < (const k::QMat *) &w.dec[Lt - 1]) {
+            const k::QMat & W2 = *(const k::QMat *) ((const char *) &W + sizeof(DecLayerW));
+            k::GemvArgs g2 = g; g2.pf_ptr = nullptr;
+            k::qrows(g2, src.ln_g ? nullptr : src.x32, W2, s);
+        }
+#endif
     };
     for (int il = 0; il < Lt; ++il) {
         const DecLayerW & l = w.dec[il];

@@ -598,6 +598,14 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && NR4 == 1) ? 4 : 1) void k_qrow
     constexpr int CH = CHX ? CHX : NW == 16 ? 5 : NW == 8 ? 3 : 5;      // weight tiles in flight per wavefront (K = 5120 / 1280: everything at once; CHX: a K part of 40 tiles on 16 wavefronts)
     constexpr int NT = NW * 64;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    // The arguments on the path to the first vector loads, in one batch of scalar loads (kernels.h: WMI_ARG_NOW).  In-kernel stamps
+    // (profiles/r05c_large_v3_q5_1_kqrows_preamble.txt) had found the prologue reached 1.7 us after the wavefront's start — behind six
+    // DEPENDENT kernarg round trips, a vmcnt(0) on residual + pending partial and four integer divisions — and the activation row
+    // arriving at +2.4..3.0 us of a 5.8 us launch.
+    WMI_ARG_NOW(a.x32); WMI_ARG_NOW(a.ln_g); WMI_ARG_NOW(a.ln_b); WMI_ARG_NOW(a.a16); WMI_ARG_NOW(a.n); WMI_ARG_NOW(a.K); WMI_ARG_NOW(a.N);
+    WMI_ARG_NOW(a.bias); WMI_ARG_NOW(a.epi); WMI_ARG_NOW(a.resid); WMI_ARG_NOW(a.ldr); WMI_ARG_NOW(a.rows); WMI_ARG_NOW(a.row_off);
+    WMI_ARG_NOW(a.comb_o); WMI_ARG_NOW(a.comb_l); WMI_ARG_NOW(a.comb_ns); WMI_ARG_NOW(a.comb_m); WMI_ARG_NOW(a.lanes); WMI_ARG_NOW(a.step_stride);
+    WMI_ARG_NOW(a.pf_ptr); WMI_ARG_NOW(a.stamps); WMI_ARG_NOW(gridDim.x); WMI_ARG_NOW(a.ksplit); WMI_ARG_NOW(a.pend); WMI_ARG_NOW(a32); WMI_ARG_NOW(Wt);
     const unsigned long long ts0 = stamp_t0(a.stamps);     // probe (wmi_step_stamps): entry, activation rows quantised, tiles multiplied, end
     unsigned long long tm1 = 0, tm2 = 0;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -618,8 +626,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && NR4 == 1) ? 4 : 1) void k_qrow
     // vmcnt queue: +1 us per launch instead of -1.)
     const int nmain = a.pf_ptr ? (int) gridDim.x - PF_WG : (int) gridDim.x;
     // K split over workgroups (GemvArgs::ksplit): workgroup = (row group, K part); tiles [tp0, tp0 + npq) of every row group
-    const int ks = a.ksplit > 1 ? a.ksplit : 1, kq = ks > 1 ? (int) blockIdx.x % ks : 0;
-    const int npq = np / ks, tp0 = kq * npq, rstride = nmain / ks;
+    // (ksplit is a power of two: shifts, not divisions — every instruction in front of the first activation load is latency the whole
+    //  chain pays)
+    const int ks = a.ksplit > 1 ? a.ksplit : 1, ksh = 31 - __builtin_clz((unsigned) ks), kq = (int) blockIdx.x & (ks - 1);
+    const int npq = np >> ksh, tp0 = kq * npq, rstride = nmain >> ksh;
     if ((int) blockIdx.x >= nmain) {
         // every line of this workgroup's share is requested before the first one is waited for: as `acc ^= load` in a loop hipcc waited
         // vmcnt(0) per iteration (ISA dump), i.e. one HBM round trip per line and thread — the five groups per workgroup of an N = 4 S
@@ -634,7 +644,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && NR4 == 1) ? 4 : 1) void k_qrow
         asm volatile("s_waitcnt vmcnt(0)" : "+v"(junk) :: "memory");
         return;
     }
-    int rg = (int) blockIdx.x / ks;
+    int rg = (int) blockIdx.x >> ksh;
     const int rg_first = rg;
 
     // ---- epilogue operands of this workgroup's first row group (bias, residual, cache slot): they depend on nothing this launch
@@ -647,9 +657,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && NR4 == 1) ? 4 : 1) void k_qrow
             if (a.bias) bias_pre = a.bias[nf];
             if (a.epi == EPI_F32_BIAS_RESID) {
                 // (straight-line: the pending partial is read from a valid address either way and selected afterwards)
-                const float rv = a.resid[(size_t) r * a.ldr + nf];
-                const float pv = (a.pend ? a.pend : a.resid)[(size_t) r * a.ldr + nf];
-                resid_pre = a.pend ? rv + pv : rv;
+                // (the sum with a pending K-split partial is a vmcnt(0) right here — a memory round trip in front of the tile loads: only
+                //  the one launch per layer that has a partial pending takes that branch; as "load both, select" every residual launch paid it)
+                if (a.pend) resid_pre = a.resid[(size_t) r * a.ldr + nf] + a.pend[(size_t) r * a.ldr + nf];
+                else        resid_pre = a.resid[(size_t) r * a.ldr + nf];
             }
             if (a.row_off) ro_pre = a.lanes ? a.row_off[r * a.step_stride] : *a.row_off;
         }
@@ -749,7 +760,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && NR4 == 1) ? 4 : 1) void k_qrow
             }
         } else                                               // few rows: a (row, slice) task per wavefront, the row's statistics recomputed by each
         for (int task = wave; task < n * nsl; task += NW) {
-            const int r = task / nsl, sl = task - r * nsl;
+#ifdef WMI_QROWS_PROBE
+            if (a.stamps && !tm1) tm1 = wall_clock64();          // (probe build) mark 1 = the prologue's code has been reached
+#endif
+            const int r = n == 1 ? 0 : task / nsl, sl = task - r * nsl;
             const int src = a.rows ? a.rows[r] : r;
             const float * xr = a.x32 + (size_t) src * K;
             float4 v[MAXV];
@@ -773,6 +787,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && NR4 == 1) ? 4 : 1) void k_qrow
                 else v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             }
             _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) sum += WMI_SHX(sum, o);
+#ifdef WMI_QROWS_PROBE
+            if (a.stamps && !tm2) { asm volatile("" :: "v"(sum)); tm2 = wall_clock64(); }      // (probe build) mark 2 = the row has arrived
+#endif
             const float mean = sum / (float) K;
             float sqs = 0.0f;
 #pragma unroll
@@ -800,9 +817,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && NR4 == 1) ? 4 : 1) void k_qrow
         }
     } else {
         // blocks quantise independently: (row, 256-column slice) pairs spread over all wavefronts
-        const int nsl = ((K + 255) >> 8) / ks, sl0 = kq * nsl;      // (a K part quantises its own slices only)
+        const int nsl = ((K + 255) >> 8) >> ksh, sl0 = kq * nsl;      // (a K part quantises its own slices only)
         for (int sl = wave; sl < n * nsl; sl += NW) {
-            const int r = sl / nsl, c = (sl0 + sl - r * nsl) * 256 + lane * 4, cc = c < K ? c : 0;
+            const int r = n == 1 ? 0 : sl / nsl, c = (sl0 + sl - r * nsl) * 256 + lane * 4, cc = c < K ? c : 0;
             const int src = a.rows ? a.rows[r] : r;
             float4 v;
             if constexpr (SRC == 0) v = *(const float4 *) (a32 + (size_t) src * K + cc);
@@ -854,7 +871,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && NR4 == 1) ? 4 : 1) void k_qrow
     // scale slots of absent rows: finite zeros (they are multiplied, never stored)
     if (n < R8) for (int e = tid; e < nb * R8; e += NT) { if ((e % R8) >= n) { sd[e] = 0.0f; ss[e] = 0.0f; } }
     __syncthreads();
+#ifndef WMI_QROWS_PROBE
     if (a.stamps) tm1 = wall_clock64();
+#endif
 
     const int arow = (lane & 31) < n ? (lane & 31) : 0;     // activation row this lane feeds the MFMA with
     const int fk = lane >> 5;

@@ -56,6 +56,15 @@ inline int cu_count_x8() {
     return n;
 }
 
+// Kernel arguments, all requested at the kernel's first instructions.  hipcc places the s_load of a by-value argument struct's field in
+// the basic block that first uses it: a kernel with early branches (probe switch, helper workgroups, optional operands) walks through
+// half a dozen DEPENDENT scalar-load round trips to the kernarg segment (~0.25-0.3 us each, cold in the scalar cache at every launch)
+// before its first vector load goes out — 1.7 us of a 5.8 us launch in k_qrows (in-kernel stamps, profiles/r05c_*).  Naming a field as an
+// asm input makes it live here, so the loads of everything named leave together and one wait covers them.
+#if defined(__HIPCC__)
+#define WMI_ARG_NOW(x) asm volatile("" :: "s"(x))
+#endif
+
 // ---------------------------------------------------------------- in-kernel time stamps (probe: wmi_step_stamps)
 // Body / boundary split of a dependent chain of launches: when stamping is on, lane 0 of every wavefront of a stamped launch
 // writes (s_memrealtime at its first instruction, s_memrealtime behind its last store) to
