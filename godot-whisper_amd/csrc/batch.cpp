@@ -660,6 +660,19 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
         static const bool ts_device = !(getenv("WMI_TS_DEVICE") && atoi(getenv("WMI_TS_DEVICE")) == 0);
         const bool env_interleaved = env_when_ == 0 || env_when_ >= 3;   // each chunk's envelope kernel right behind its mel kernels (3: into HBM, copied out beside the decode steps)
         // ---- per chunk: PCM -> mel, envelope, window bounds (the head of full())
+        // The mel kernels of all chunks, and their envelopes where those stay in HBM, are ONE launch per kernel (device.cpp:
+        // pcm_to_mel_batch): per chunk on its own stream (3 mel launches + envelope + two event operations, 8 + 8 streams) the phase
+        // was ~0.3 ms of host enqueue time per 8-chunk call.  WMI_MEL_PER_CHUNK=1 (A/B): the per-chunk form.
+        static const bool mel_per_chunk = getenv("WMI_MEL_PER_CHUNK") != nullptr;
+        const bool env_batched = params.token_timestamps && ts_device && env_when_ == 0;
+        const bool mel_batched = !mel_per_chunk && ng >= 2 && (env_batched || !params.token_timestamps);
+        if (mel_batched) {
+            const int64_t tm0 = time_us();
+            std::vector<State *> sts(ng);
+            for (int r = 0; r < ng; ++r) sts[r] = b.lanes[r];
+            if (!pcm_to_mel_batch(ctx, sts, pcm + g0, n_samples + g0, on_device, env_batched)) { WMI_ERR("%s: failed to compute log mel spectrogram\n", __func__); return -2; }
+            b.t_mel_us += time_us() - tm0;
+        }
         for (int r = 0; r < ng; ++r) {
             Row & row = rows[r]; row.chunk = g0 + r; row.lane = r;
             State & ls = *b.lanes[r];
@@ -671,12 +684,12 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
             if (v.is_multilingual()) ls.lang_id = lang_id(params.language);
             const int64_t tm0 = time_us();
             // kernels of all chunks are queued back to back; one synchronisation after the loop
-            if (n_samples[row.chunk] > 0) {
+            if (n_samples[row.chunk] > 0 && !mel_batched) {
                 if (!pcm_to_mel(ctx, pcm[row.chunk], n_samples[row.chunk], on_device, false)) { WMI_ERR("%s: failed to compute log mel spectrogram\n", __func__); return -2; }
             }
             if (params.token_timestamps) {
                 ls.t_beg = 0; ls.t_last = 0; ls.tid_last = 0;
-                if (env_interleaved && n_samples[row.chunk] > 0 && !signal_energy_device(ctx, 32, false, (ts_device && env_when_ == 0) ? 3 : env_when_ >= 3 ? 2 : 0)) { WMI_ERR("%s: failed to compute the signal envelope\n", __func__); return -2; }
+                if (!mel_batched && env_interleaved && n_samples[row.chunk] > 0 && !signal_energy_device(ctx, 32, false, (ts_device && env_when_ == 0) ? 3 : env_when_ >= 3 ? 2 : 0)) { WMI_ERR("%s: failed to compute the signal envelope\n", __func__); return -2; }
             }
             b.t_mel_us += time_us() - tm0;
         }
@@ -703,7 +716,7 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
             const int64_t tm0 = time_us();
             for (int r = 0; r < ng; ++r) {                        // the encoder (main stream) waits for every chunk's mel
                 DeviceState & ld = b.lanes[r]->dev;
-                if (!ld.mel_stream || n_samples[g0 + r] <= 0) continue;
+                if (mel_batched || !ld.mel_stream || n_samples[g0 + r] <= 0) continue;      // (batched: the kernels are on the main stream already)
                 if (!HIP_OK(hipEventRecord(ld.mel_ev, ld.mel_stream)) || !HIP_OK(hipStreamWaitEvent(primary->dev.stream, ld.mel_ev, 0))) return -2;
             }
             if (!HIP_OK(hipStreamSynchronize(primary->dev.stream))) return -2;

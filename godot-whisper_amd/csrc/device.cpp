@@ -164,6 +164,7 @@ void destroy_state(State * st) {
     dfree(st->kv_self.k); dfree(st->kv_self.v); dfree(d.kvc_k); dfree(d.kvc_v);
     if (d.copy_stream) { (void) hipStreamSynchronize(d.copy_stream); (void) hipStreamDestroy(d.copy_stream); }
     if (d.energy_ev) (void) hipEventDestroy(d.energy_ev);
+    if (d.mel_ev) { (void) hipEventDestroy(d.mel_ev); d.mel_ev = nullptr; }       // (the state of a lock-step call's primary: pcm_to_mel_batch)
     dfree(d.energy); if (d.energy_host) (void) hipHostFree(d.energy_host);
     if (d.ts_host) (void) hipHostFree(d.ts_host);
     dfree(d.pcm); dfree(d.mel); dfree(d.mel_max); dfree(d.mel_t); dfree(d.conv1); dfree(d.x); dfree(d.embd_conv);
@@ -222,18 +223,88 @@ bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, boo
     return true;
 }
 
+static bool ensure_copy_stream(DeviceState & d) {
+    if (d.copy_stream) return true;
+    // lowest priority: the envelope is needed at emission time only, whatever shares the chip with it goes first
+    int prio_lo = 0, prio_hi = 0;
+    (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (!HIP_OK(hipStreamCreateWithPriority(&d.copy_stream, hipStreamNonBlocking, prio_lo))) HIP_TRY(hipStreamCreateWithFlags(&d.copy_stream, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&d.energy_ev, hipEventDisableTiming));
+    return true;
+}
+static hipStream_t envelope_stream(const DeviceState & d) { return d.energy_wait_stream ? d.energy_wait_stream : d.copy_stream; }
+
+bool pcm_to_mel_batch(whisper_context & ctx, const std::vector<State *> & states, const float * const * pcm, const int * n_samples,
+                      bool samples_on_device, bool envelopes) {
+    if (!compute_ready(ctx, __func__)) return false;
+    DeviceState & pd = ctx.state->dev;                      // the calling state: its stream carries the launches
+    hipStream_t s = pd.stream;
+    const int n_mel = ctx.model.n_filt_mel;
+    const int64_t t0 = time_us();
+    k::MelBatch mb{}; int nb = 0; std::vector<State *> in;
+    if (envelopes && !ensure_copy_stream(pd)) return false;
+    for (size_t r = 0; r < states.size(); ++r) {
+        const int n = n_samples[r];
+        if (n <= 0) continue;
+        if (nb >= 16) return false;
+        State & st = *states[r]; DeviceState & d = st.dev;
+        const int64_t n_pad = (int64_t) n + 480000 + 400;   // Appendix G, as pcm_to_mel
+        const int n_len = (int) ((n_pad - 400) / 160);
+        if (!ensure_mel_capacity(d, (size_t) n_pad + (size_t) n, (size_t) n_mel * n_len)) return false;
+        const float * src = pcm[r];
+        if (!samples_on_device) {
+            float * stage = d.pcm + n_pad;
+            HIP_TRY(hipMemcpyAsync(stage, pcm[r], (size_t) n * 4, hipMemcpyHostToDevice, s));
+            src = stage;
+        }
+        d.last_pcm = src; d.last_pcm_n = n;
+        st.mel.n_len = n_len; st.mel.n_len_org = 1 + (n + 200 - 400) / 160; st.mel.n_mel = n_mel;
+        mb.pcm[nb] = src; mb.pad[nb] = d.pcm; mb.mel[nb] = d.mel; mb.gmax[nb] = (int *) d.mel_max; mb.n[nb] = n;
+        if (envelopes) {
+            // the previous call's envelope of this state may still be in flight on whichever stream wrote it
+            if (d.energy_pending && envelope_stream(d)) { HIP_TRY(hipStreamSynchronize(envelope_stream(d))); d.energy_pending = false; }
+            const size_t nblk = (size_t) n / 256 + 2;
+            if ((size_t) n > d.energy_cap) {                // (energy_cap = capacity of the pinned image AND layout stride of the device image: kept in step with signal_energy_device)
+                st.energy = nullptr; st.energy_n = 0; st.energy_bmin = st.energy_bmax = nullptr;
+                if (d.energy_host) (void) hipHostFree(d.energy_host);
+                d.energy_host = nullptr; d.energy_cap = 0;
+                if (!HIP_OK(hipHostMalloc((void **) &d.energy_host, ((size_t) n + 2 * ((size_t) n / 256 + 2)) * 4, hipHostMallocDefault))) return false;
+                d.energy_cap = (size_t) n;
+            }
+            const size_t need = d.energy_cap + 2 * nblk;
+            if (d.energy_dev_cap < need) { dfree(d.energy); d.energy_dev_cap = 0; if (!dalloc(d.energy, need)) return false; d.energy_dev_cap = need; }
+            mb.energy[nb] = d.energy; mb.bmin[nb] = d.energy + d.energy_cap; mb.bmax[nb] = d.energy + d.energy_cap + nblk;
+        }
+        in.push_back(&st); ++nb;
+    }
+    if (nb == 0) return true;
+    if (envelopes) {
+        // the envelope kernel runs on the side stream BESIDE the mel kernels (both only read the samples) and the main stream takes it back
+        // before the encoder: left to run into the encoder, its 15 000 workgroups took CUs from the persistent GEMMs (8 chunks: encoder
+        // 1.47 -> 1.55 ms, measured)
+        if (!pd.mel_ev) HIP_TRY(hipEventCreateWithFlags(&pd.mel_ev, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(pd.energy_ev, s));           // behind the staging of the samples
+        HIP_TRY(hipStreamWaitEvent(pd.copy_stream, pd.energy_ev, 0));
+        k::signal_energy_batch(mb, nb, 32, pd.copy_stream);
+        HIP_TRY(hipEventRecord(pd.mel_ev, pd.copy_stream));
+        for (State * st : in) {
+            DeviceState & d = st->dev;
+            d.energy_device_only = true; d.energy_unflushed = false; d.energy_pending = true; d.energy_wait_stream = pd.copy_stream;
+        }
+    }
+    k::mel_batch(mb, nb, n_mel, ctx.w.mel_filters, ctx.w.mel_ranges, ctx.w.mel_taps, s);
+    if (envelopes) HIP_TRY(hipStreamWaitEvent(s, pd.mel_ev, 0));
+    ctx.state->t_mel_us += time_us() - t0;
+    return hipGetLastError() == hipSuccess;
+}
+
 bool signal_energy_device(whisper_context & ctx, int hw, bool sync, int via_dma) {
     State & st = *ctx.state; DeviceState & d = st.dev;
     const int n = d.last_pcm_n;
     if (!d.last_pcm || n <= 0) return false;
-    if (!d.copy_stream) {
-        // lowest priority: the envelope is needed at emission time only, whatever shares the chip with it goes first
-        int prio_lo = 0, prio_hi = 0;
-        (void) hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
-        if (!HIP_OK(hipStreamCreateWithPriority(&d.copy_stream, hipStreamNonBlocking, prio_lo))) HIP_TRY(hipStreamCreateWithFlags(&d.copy_stream, hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&d.energy_ev, hipEventDisableTiming));
-    }
-    if (d.energy_pending) { HIP_TRY(hipStreamSynchronize(d.copy_stream)); d.energy_pending = false; }   // previous envelope still being written
+    if (!ensure_copy_stream(d)) return false;
+    if (d.energy_pending) { HIP_TRY(hipStreamSynchronize(envelope_stream(d))); d.energy_pending = false; }   // previous envelope still being written
+    d.energy_wait_stream = nullptr;
     d.energy_device_only = false;
     if ((size_t) n > d.energy_cap) {
         st.energy = nullptr; st.energy_n = 0; st.energy_bmin = st.energy_bmax = nullptr;
@@ -290,14 +361,15 @@ bool ts_refine_device(State & st, const k::TsTok * in, int n, k::TsOut * out) {
     DeviceState & d = st.dev;
     constexpr int CAP = 448;
     if (n <= 0) return true;
-    if (n > CAP || !d.energy || !d.copy_stream) return false;
+    hipStream_t es = envelope_stream(d);
+    if (n > CAP || !d.energy || !es) return false;
     if (!d.ts_host && !HIP_OK(hipHostMalloc(&d.ts_host, CAP * (sizeof(k::TsTok) + sizeof(k::TsOut)), hipHostMallocDefault))) return false;
     k::TsTok * hin = (k::TsTok *) d.ts_host; k::TsOut * hout = (k::TsOut *) (hin + CAP);
     memcpy(hin, in, (size_t) n * sizeof(k::TsTok));
     const size_t nb = (size_t) d.last_pcm_n / 256 + 2;
     // the kernel reads its records from, and writes its results to, the pinned block; on the envelope's own stream (behind the envelope kernel)
-    k::ts_refine(d.energy, d.energy + d.energy_cap, d.energy + d.energy_cap + nb, d.last_pcm_n, hin, hout, n, d.copy_stream);
-    HIP_TRY(hipStreamSynchronize(d.copy_stream));
+    k::ts_refine(d.energy, d.energy + d.energy_cap, d.energy + d.energy_cap + nb, d.last_pcm_n, hin, hout, n, es);
+    HIP_TRY(hipStreamSynchronize(es));
     memcpy(out, hout, (size_t) n * sizeof(k::TsOut));
     return true;
 }
@@ -306,7 +378,7 @@ bool signal_energy_wait(State & st) {
     DeviceState & d = st.dev;
     if (!d.energy_pending) return true;
     if (d.energy_device_only) {
-        HIP_TRY(hipStreamSynchronize(d.copy_stream));
+        HIP_TRY(hipStreamSynchronize(envelope_stream(d)));
         st.energy = nullptr; st.energy_bmin = st.energy_bmax = nullptr; st.energy_n = d.last_pcm_n; st.energy_on_device = true;
         d.energy_pending = false;
         return true;

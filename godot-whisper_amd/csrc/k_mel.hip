@@ -38,7 +38,7 @@ void upload_tables() {
 __device__ inline int enc_ordered(float f) { int i = __float_as_int(f); return i >= 0 ? i : i ^ 0x7FFFFFFF; }
 __device__ inline float dec_ordered(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
 
-__global__ void k_mel_pad(const float * __restrict__ pcm, int n, float * __restrict__ out, int total, int * __restrict__ gmax) {
+__device__ __forceinline__ void mel_pad_body(const float * __restrict__ pcm, int n, float * __restrict__ out, int total, int * __restrict__ gmax) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0 && gmax) *gmax = INT_MIN;     // running maximum of the frame kernel that follows on the stream (was a launch of its own)
     if (i >= total) return;
@@ -51,6 +51,11 @@ __global__ void k_mel_pad(const float * __restrict__ pcm, int n, float * __restr
     }
     out[i] = v;
 }
+__global__ void k_mel_pad(const float * __restrict__ pcm, int n, float * __restrict__ out, int total, int * __restrict__ gmax) { mel_pad_body(pcm, n, out, total, gmax); }
+// Lock-step chunks: the same kernels with the chunk on grid.y — one launch per kernel for all chunks of a call instead of one per chunk
+// (8 chunks: 8 x (3 mel launches + envelope + 2 event operations) on 8 + 8 streams were ~0.3 ms of HOST time in front of the encoder).
+// The body of every kernel is the single-chunk kernel's: per chunk the arithmetic and its order are unchanged.
+__global__ void k_mel_pad_b(const MelBatch b) { const int c = blockIdx.y; mel_pad_body(b.pcm[c], b.n[c], b.pad[c], b.n[c] + 480400, b.gmax[c]); }
 
 // butterfly stage: for g groups, combine E = src[(g)*half ...], O = src[(g + ngroups)*half ...]
 // into dst[g*N + k], dst[g*N + k + half].  Arrays are stored as [leaf][k] complex (re, im interleaved, read and
@@ -77,15 +82,16 @@ __device__ inline void butterfly_stage(const float * src, float * dst, int ngrou
 }
 
 // frames past the audio: log10(1e-10)  (W/whisper.cpp:2784-2789) — one thread per element, no FFT workgroups
-__global__ void k_mel_tail(float * __restrict__ mel, int n_len, int n_mel, int n_fft_frames, int * __restrict__ gmax) {
+__device__ __forceinline__ void mel_tail_body(float * __restrict__ mel, int n_len, int n_mel, int n_fft_frames, int * __restrict__ gmax) {
     const int w = n_len - n_fft_frames;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < w * n_mel) { const int j = i / w, f = n_fft_frames + (i - j * w); mel[(size_t) j * n_len + f] = -10.0f; }
     if (i == 0 && w > 0) atomicMax(gmax, enc_ordered(-10.0f));
 }
+__global__ void k_mel_tail(float * __restrict__ mel, int n_len, int n_mel, int n_fft_frames, int * __restrict__ gmax) { mel_tail_body(mel, n_len, n_mel, n_fft_frames, gmax); }
 
 constexpr int MEL_NT = 256;            // threads per frame (4 wavefronts: 1.6 leaf-DFT outputs per thread)
-__global__ __launch_bounds__(MEL_NT) void k_mel_frames(const float * __restrict__ pad, int n_valid, int n_fft_frames,
+__device__ __forceinline__ void mel_frames_body(const float * __restrict__ pad, int n_valid, int n_fft_frames,
                                                     int n_len, int n_mel, const float * __restrict__ filters,
                                                     const int32_t * __restrict__ ranges, const float * __restrict__ taps,
                                                     float * __restrict__ mel, int * __restrict__ gmax) {
@@ -218,8 +224,27 @@ __global__ __launch_bounds__(MEL_NT) void k_mel_frames(const float * __restrict_
         }
     }
 }
+__global__ __launch_bounds__(MEL_NT) void k_mel_frames(const float * __restrict__ pad, int n_valid, int n_fft_frames,
+                                                    int n_len, int n_mel, const float * __restrict__ filters,
+                                                    const int32_t * __restrict__ ranges, const float * __restrict__ taps,
+                                                    float * __restrict__ mel, int * __restrict__ gmax) {
+    mel_frames_body(pad, n_valid, n_fft_frames, n_len, n_mel, filters, ranges, taps, mel, gmax);
+}
+// (Appendix G's sizes of a chunk of n samples: padded image n + 480 400, n_len = (n + 480 000) / 160 frames of which the first
+//  min((n + 200) / 160 + 1, n_len) hold audio)
+__device__ __forceinline__ int mel_n_len(int n) { return (int) (((long long) n + 480000) / 160); }
+__device__ __forceinline__ int mel_n_fft(int n) { const int a = (n + 200) / 160 + 1, l = mel_n_len(n); return a < l ? a : l; }
+__global__ __launch_bounds__(MEL_NT) void k_mel_frames_b(const MelBatch b, int n_mel, const float * __restrict__ filters,
+                                                      const int32_t * __restrict__ ranges, const float * __restrict__ taps) {
+    const int c = blockIdx.y, n = b.n[c];
+    mel_frames_body(b.pad[c], n + 200, mel_n_fft(n), mel_n_len(n), n_mel, filters, ranges, taps, b.mel[c], b.gmax[c]);
+}
+__global__ void k_mel_tail_b(const MelBatch b, int n_mel) {
+    const int c = blockIdx.y, n = b.n[c];
+    mel_tail_body(b.mel[c], mel_n_len(n), n_mel, mel_n_fft(n), b.gmax[c]);
+}
 
-__global__ void k_mel_normalize(float * __restrict__ mel, int n, const int * __restrict__ gmax) {
+__device__ __forceinline__ void mel_normalize_body(float * __restrict__ mel, int n, const int * __restrict__ gmax) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const double mmax = (double) dec_ordered(*gmax) - 8.0;       // W/whisper.cpp:2855-2871
@@ -227,6 +252,8 @@ __global__ void k_mel_normalize(float * __restrict__ mel, int n, const int * __r
     if ((double) v < mmax) v = (float) mmax;
     mel[i] = (float) (((double) v + 4.0) / 4.0);
 }
+__global__ void k_mel_normalize(float * __restrict__ mel, int n, const int * __restrict__ gmax) { mel_normalize_body(mel, n, gmax); }
+__global__ void k_mel_normalize_b(const MelBatch b, int n_mel) { const int c = blockIdx.y; mel_normalize_body(b.mel[c], n_mel * mel_n_len(b.n[c]), b.gmax[c]); }
 
 __global__ void k_mel_slice(const float * __restrict__ mel, int n_len, int n_mel, int offset, int n_frames,
                             __half * __restrict__ out, int ld, int rows_total) {
@@ -282,7 +309,7 @@ __global__ void k_fill_zero_strided(uint32_t * p, size_t words, size_t stride_wo
 // heuristics walk outwards from a token "while the envelope stays above / below a threshold" (W/whisper.cpp:6500-6590),
 // on stationary audio across the whole signal for every token; with the block extrema the host skips 256 samples per
 // comparison and stops on exactly the same sample.
-__global__ __launch_bounds__(256) void k_signal_energy(const float * __restrict__ x, int n, int hw, float * __restrict__ out,
+__device__ __forceinline__ void signal_energy_body(const float * __restrict__ x, int n, int hw, float * __restrict__ out,
                                                        float * __restrict__ bmin, float * __restrict__ bmax) {
     __shared__ float s_min[4], s_max[4];
     // block-stride loop: the grid may be thinner than one workgroup per 256 samples (WMI_ENVELOPE_GRID, A/B: the kernel is bound by its
@@ -328,6 +355,12 @@ __global__ __launch_bounds__(256) void k_signal_energy(const float * __restrict_
         bmax[blk] = fmaxf(fmaxf(s_max[0], s_max[1]), fmaxf(s_max[2], s_max[3]));
     }
     }
+}
+__global__ __launch_bounds__(256) void k_signal_energy(const float * __restrict__ x, int n, int hw, float * __restrict__ out,
+                                                       float * __restrict__ bmin, float * __restrict__ bmax) { signal_energy_body(x, n, hw, out, bmin, bmax); }
+__global__ __launch_bounds__(256) void k_signal_energy_b(const MelBatch b, int hw) {
+    const int c = blockIdx.y;
+    signal_energy_body(b.pcm[c], b.n[c], hw, b.energy[c], b.bmin[c], b.bmax[c]);
 }
 
 // ---------------------------------------------------------------- host-adjacent DSP
@@ -434,6 +467,32 @@ void mel_frames(const float * pcm_pad, int n_valid, int n_fft_frames, int n_len,
                            filters, ranges, taps, mel, gmax);
     const int tail = (n_len - n_fft_frames) * n_mel;
     if (tail > 0) hipLaunchKernelGGL(k_mel_tail, dim3((tail + 255) / 256), dim3(256), 0, st, mel, n_len, n_mel, n_fft_frames, gmax);
+}
+
+// lock-step chunks: pad + frames (+ tail) + normalise of nb chunks, one launch each (grid.y = chunk; grid.x = the largest chunk's extent,
+// the others' surplus workgroups return at once)
+void mel_batch(const MelBatch & b, int nb, int n_mel, const float * filters, const int32_t * ranges, const float * taps, hipStream_t st) {
+    {
+        int dev = 0; (void) hipGetDevice(&dev);
+        const uint64_t bit = 1ull << (dev & 63);
+        if (!(g_tables_mask.load(std::memory_order_acquire) & bit)) { upload_tables(); g_tables_mask.fetch_or(bit, std::memory_order_release); }
+    }
+    int n_max = 0, n_min = INT_MAX;
+    for (int c = 0; c < nb; ++c) { n_max = std::max(n_max, b.n[c]); n_min = std::min(n_min, b.n[c]); }
+    auto n_len = [](int n) { return (int) (((long long) n + 480000) / 160); };
+    auto n_fft = [&](int n) { return std::min((n + 200) / 160 + 1, n_len(n)); };
+    hipLaunchKernelGGL(k_mel_pad_b, dim3((n_max + 480400 + 255) / 256, nb), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(k_mel_frames_b, dim3(n_fft(n_max), nb), dim3(MEL_NT), 0, st, b, n_mel, filters, ranges, taps);
+    int tail_max = 0;
+    for (int c = 0; c < nb; ++c) tail_max = std::max(tail_max, (n_len(b.n[c]) - n_fft(b.n[c])) * n_mel);
+    if (tail_max > 0) hipLaunchKernelGGL(k_mel_tail_b, dim3((tail_max + 255) / 256, nb), dim3(256), 0, st, b, n_mel);
+    hipLaunchKernelGGL(k_mel_normalize_b, dim3((n_mel * n_len(n_max) + 255) / 256, nb), dim3(256), 0, st, b, n_mel);
+}
+// ... and their |x| envelopes (b.energy / bmin / bmax)
+void signal_energy_batch(const MelBatch & b, int nb, int hw, hipStream_t st) {
+    int n_max = 0;
+    for (int c = 0; c < nb; ++c) n_max = std::max(n_max, b.n[c]);
+    if (n_max > 0) hipLaunchKernelGGL(k_signal_energy_b, dim3((n_max + 255) / 256, nb), dim3(256), 0, st, b, hw);
 }
 
 void mel_normalize(float * mel, int n, const int * gmax, hipStream_t st) {

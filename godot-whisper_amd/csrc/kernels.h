@@ -94,6 +94,11 @@ void mel_pad(const float * pcm, int n_samples, float * pcm_pad, int n_pad_total,
 void mel_frames(const float * pcm_pad, int n_valid, int n_fft_frames, int n_len, int n_mel,
                 const float * filters, const int32_t * ranges, const float * taps, float * mel, int * gmax, hipStream_t st);
 void mel_normalize(float * mel, int n, const int * gmax, hipStream_t st);
+// lock-step chunks (batch.cpp): the mel kernels and the envelope kernel of up to 16 chunks in ONE launch each — per chunk the samples
+// (device), the padded image, the mel image, the running-maximum word and the envelope with its block extrema
+struct MelBatch { const float * pcm[16]; float * pad[16]; float * mel[16]; int * gmax[16]; float * energy[16]; float * bmin[16]; float * bmax[16]; int n[16]; };
+void mel_batch(const MelBatch & b, int nb, int n_mel, const float * filters, const int32_t * ranges, const float * taps, hipStream_t st);
+void signal_energy_batch(const MelBatch & b, int nb, int hw, hipStream_t st);
 // token-major f16 slice for the conv front-end: out[r][c], r in [0, rows_total), row r holds frame
 // (offset + r - 1); rows outside [1, n_frames] and frames >= n_len are zero.
 // lock-step chunks: the slices of up to 16 chunks in one launch (chunk c -> rows c * rows_total ..), and the guard rows between stacked chunks

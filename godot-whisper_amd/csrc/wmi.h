@@ -190,6 +190,7 @@ struct DeviceState {
     float * energy_host = nullptr;                            // pinned mirror
     size_t  energy_dev_cap = 0;                               // floats allocated at `energy` (envelope + block extrema; the copy-engine form)
     hipStream_t copy_stream = nullptr; hipEvent_t energy_ev = nullptr;   // envelope D2H overlaps the encoder
+    hipStream_t energy_wait_stream = nullptr;                 // lock-step calls: the stream of the batched envelope launch that wrote this state's envelope (not owned)
     hipStream_t mel_stream = nullptr;  hipEvent_t mel_ev = nullptr;      // lock-step chunks: the mel kernels of the chunks overlap
     bool    energy_pending = false;                            // copy in flight: signal_energy_wait() before reading state.energy
     bool    energy_device_only = false;                        // the envelope stays in HBM: the timestamp walks run there too (ts_refine_device), nothing crosses PCIe
@@ -347,6 +348,11 @@ void destroy_state(State * st);
 
 // hot path (device)
 bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, bool samples_on_device, bool sync = true);
+// lock-step chunks: log-mel of several states' chunks by ONE launch per kernel on the context's stream (k::mel_batch), and — with
+// `envelopes` — their |x| envelopes into HBM by one more (the device-resident form the token timestamps of a lock-step call read).
+// Entries with n_samples <= 0 are skipped.  Per chunk the kernels' arithmetic is pcm_to_mel's / signal_energy_device's.
+bool pcm_to_mel_batch(whisper_context & ctx, const std::vector<State *> & states, const float * const * pcm, const int * n_samples,
+                      bool samples_on_device, bool envelopes);
 bool set_mel(whisper_context & ctx, const float * data, int n_len, int n_mel);
 bool encode(whisper_context & ctx, int mel_offset);
 // lock-step chunks (batch.cpp): rows[r] = lane whose mel feeds chunk row r, seek[r] = its mel frame offset
