@@ -483,6 +483,8 @@ bool encode(whisper_context & ctx, int mel_offset) {
     return true;
 }
 
+static int stamps_reduce(whisper_context & ctx, const unsigned long long * buf, int n, double * out, int cap);
+
 // ------------------------------------------------------------------------------------------------ decoder
 bool decode(whisper_context & ctx, const Batch & batch) {
     if (!compute_ready(ctx, __func__)) return false;
@@ -514,13 +516,48 @@ bool decode(whisper_context & ctx, const Batch & batch) {
     }
     // (the device block has the pinned block's layout for THIS n: tokens | positions | rows | mask, packed)
     d.d_pos = d.d_tokens + n; d.d_rows = d.d_pos + n; d.d_mask = (float *) (d.d_rows + n);
+    // WMI_DECODE_TRACE=1 (debug): GPU time between the first and the last command of the call (events) beside the host's wall time
+    static const bool trace = getenv("WMI_DECODE_TRACE") != nullptr;
+    static hipEvent_t tr0 = nullptr, tr1 = nullptr;
+    if (trace) { if (!tr0) { (void) hipEventCreate(&tr0); (void) hipEventCreate(&tr1); } (void) hipEventRecord(tr0, s); }
     HIP_TRY(hipMemcpyAsync(d.d_tokens, p_tok, ((size_t) 3 * n + (size_t) n * n_kv) * 4, hipMemcpyHostToDevice, s));
 
     if (ctx.model.quantised) {
-        if (!decode_layers_q(ctx, n, n_kv, kv_head, Tc, rows)) return false;
+        // WMI_DECODE_STAMPS=k (debug): in-kernel stamps of the k-th several-row call's launches (start, body, the kernels' two mid marks)
+        static const int stamp_call = getenv("WMI_DECODE_STAMPS") ? atoi(getenv("WMI_DECODE_STAMPS")) : -1;
+        static int n_multi = 0;
+        unsigned long long * sbuf = nullptr; constexpr int SMAXL = 512;
+        if (stamp_call >= 0 && n > 1 && n_multi++ == stamp_call) {
+            const size_t bytes = (size_t) SMAXL * k::STAMP_WAVES * 4 * sizeof(unsigned long long);
+            if (HIP_OK(hipMalloc((void **) &sbuf, bytes))) { (void) hipMemsetAsync(sbuf, 0, bytes, s); k::stamp_enable(sbuf); }
+        }
+        const bool layers_ok = decode_layers_q(ctx, n, n_kv, kv_head, Tc, rows);
+        if (sbuf) {
+            const int nl = std::min(k::stamp_count(), SMAXL);
+            k::stamp_enable(nullptr);
+            (void) hipStreamSynchronize(s);
+            std::vector<double> o((size_t) 6 * nl);
+            const int got = stamps_reduce(ctx, sbuf, nl, o.data(), nl);
+            for (int i = 0; i < got; ++i)
+                if (o[6 * i + 3] > 0)
+                    fprintf(stderr, "[wmi] stamps n=%d launch %3d: start %8.2f  last-start +%5.2f  body %5.2f  waves %4d  mark1 +%6.2f  mark2 +%6.2f  gap-before %5.2f\n", n, i,
+                            o[6 * i], o[6 * i + 1] - o[6 * i], o[6 * i + 2] - o[6 * i], (int) o[6 * i + 3], o[6 * i + 4] > 0 ? o[6 * i + 4] - o[6 * i] : -1.0,
+                            o[6 * i + 5] > 0 ? o[6 * i + 5] - o[6 * i] : -1.0, i ? o[6 * i] - o[6 * (i - 1) + 2] : 0.0);
+            (void) hipFree(sbuf);
+        }
+        if (!layers_ok) return false;
+        const int64_t t_enq = time_us();
+        if (trace) (void) hipEventRecord(tr1, s);
         HIP_TRY(hipStreamSynchronize(s));
         if (!HIP_OK(hipGetLastError())) return false;
         const int64_t dtq = time_us() - t0;
+        if (trace) {
+            static int64_t t_prev_end = 0;
+            float ms = 0.f; (void) hipEventElapsedTime(&ms, tr0, tr1);
+            fprintf(stderr, "[wmi] decode n=%d n_kv=%d: wall %.0f us (enqueue done at %.0f) | first-to-last command on the GPU %.0f us | since the previous call returned %.0f us\n",
+                    n, n_kv, (double) dtq, (double) (t_enq - t0), ms * 1e3, t_prev_end ? (double) (t0 - t_prev_end) : 0.0);
+            t_prev_end = time_us();
+        }
         if (n == 1)      { st.t_decode_us += dtq; st.n_decode++; }
         else if (n < 16) { st.t_batchd_us += dtq; st.n_batchd += n; }
         else             { st.t_prompt_us += dtq; st.n_prompt += n; }
@@ -951,39 +988,10 @@ double bench_greedy_step_chain(whisper_context & ctx, int iters) {
     return (double) ms * 1000.0 / (iters * (pexec ? reps : 1));
 }
 
-// probe: body / boundary split of the greedy step's dependent launches from in-kernel time stamps (kernels.h: Stamp).  The step is
-// captured with stamping on, replayed a few times, and the LAST replay's records are reduced per launch:
-// out[6 i + 0..5] = first wavefront start, last wavefront start, last wavefront end (microseconds from the step's first start),
-// number of wavefront records, and two optional mid points (k_gemv1: activation row ready, first row tile reduced; -1 if absent).  Returns the number of launches (<= cap), -1 when there is no step to replay.
-int step_stamps(whisper_context & ctx, double * out, int cap, bool chained) {
-    State & st = *ctx.state; DeviceState & d = st.dev;
-    if (!d.step_dev || cap <= 0) return -1;
-    if (ctx.model.quantised) chained = false;               // (the block-quantised step has one form)
-    // the chained replays advance the device-side record (cache head / n_kv + 1 per replay: four below): refuse near the end of the cache
-    if (chained && (int) ((const k::DecStep *) d.step_host)->kv_head + 6 >= (int) st.kv_self.size) return -1;
-    const int Tc = st.enc_n_ctx > 0 ? st.enc_n_ctx : ctx.model.hp.n_audio_ctx;
-    hipStream_t s = d.stream;
-    const bool long_kv = ((const k::DecStep *) d.step_host)->n_kv > 64;
-    constexpr int MAXL = 512;
-    const size_t bytes = (size_t) MAXL * k::STAMP_WAVES * 4 * sizeof(unsigned long long);
-    unsigned long long * buf = nullptr;
-    if (!HIP_OK(hipMalloc((void **) &buf, bytes))) return -1;
-    (void) hipMemsetAsync(buf, 0, bytes, s);
-    d.chain_valid = false;
-    enqueue_greedy_step(ctx, Tc, long_kv, false);           // leaves a valid device-side record for the chained form
-    (void) hipStreamSynchronize(s);
-    hipGraph_t g = nullptr; hipGraphExec_t ex = nullptr; int n = 0;
-    k::stamp_enable(buf);
-    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-        enqueue_greedy_step(ctx, Tc, long_kv, chained);
-        n = k::stamp_count();
-        if (hipStreamEndCapture(s, &g) != hipSuccess || !g || hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) ex = nullptr;
-    }
-    k::stamp_enable(nullptr);
+// reduces the stamp records of n launches (kernels.h: Stamp) to out[6 i + 0..5] — see step_stamps
+static int stamps_reduce(whisper_context & ctx, const unsigned long long * buf, int n, double * out, int cap) {
     int ret = -1;
-    if (ex && n > 0 && n <= MAXL) {
-        for (int i = 0; i < 3; ++i) (void) hipGraphLaunch(ex, s);
-        (void) hipStreamSynchronize(s);
+    {
         std::vector<unsigned long long> h((size_t) n * k::STAMP_WAVES * 4);
         if (HIP_OK(hipMemcpy(h.data(), buf, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost))) {
             int khz = 100000; (void) hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, ctx.device);
@@ -1017,6 +1025,44 @@ int step_stamps(whisper_context & ctx, double * out, int cap, bool chained) {
                 }
             }
         }
+        }
+    return ret;
+}
+
+// probe: body / boundary split of the greedy step's dependent launches from in-kernel time stamps (kernels.h: Stamp).  The step is
+// captured with stamping on, replayed a few times, and the LAST replay's records are reduced per launch:
+// out[6 i + 0..5] = first wavefront start, last wavefront start, last wavefront end (microseconds from the step's first start),
+// number of wavefront records, and two optional mid points (k_gemv1: activation row ready, first row tile reduced; -1 if absent).  Returns the number of launches (<= cap), -1 when there is no step to replay.
+int step_stamps(whisper_context & ctx, double * out, int cap, bool chained) {
+    State & st = *ctx.state; DeviceState & d = st.dev;
+    if (!d.step_dev || cap <= 0) return -1;
+    if (ctx.model.quantised) chained = false;               // (the block-quantised step has one form)
+    // the chained replays advance the device-side record (cache head / n_kv + 1 per replay: four below): refuse near the end of the cache
+    if (chained && (int) ((const k::DecStep *) d.step_host)->kv_head + 6 >= (int) st.kv_self.size) return -1;
+    const int Tc = st.enc_n_ctx > 0 ? st.enc_n_ctx : ctx.model.hp.n_audio_ctx;
+    hipStream_t s = d.stream;
+    const bool long_kv = ((const k::DecStep *) d.step_host)->n_kv > 64;
+    constexpr int MAXL = 512;
+    const size_t bytes = (size_t) MAXL * k::STAMP_WAVES * 4 * sizeof(unsigned long long);
+    unsigned long long * buf = nullptr;
+    if (!HIP_OK(hipMalloc((void **) &buf, bytes))) return -1;
+    (void) hipMemsetAsync(buf, 0, bytes, s);
+    d.chain_valid = false;
+    enqueue_greedy_step(ctx, Tc, long_kv, false);           // leaves a valid device-side record for the chained form
+    (void) hipStreamSynchronize(s);
+    hipGraph_t g = nullptr; hipGraphExec_t ex = nullptr; int n = 0;
+    k::stamp_enable(buf);
+    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        enqueue_greedy_step(ctx, Tc, long_kv, chained);
+        n = k::stamp_count();
+        if (hipStreamEndCapture(s, &g) != hipSuccess || !g || hipGraphInstantiate(&ex, g, nullptr, nullptr, 0) != hipSuccess) ex = nullptr;
+    }
+    k::stamp_enable(nullptr);
+    int ret = -1;
+    if (ex && n > 0 && n <= MAXL) {
+        for (int i = 0; i < 3; ++i) (void) hipGraphLaunch(ex, s);
+        (void) hipStreamSynchronize(s);
+        ret = stamps_reduce(ctx, buf, n, out, cap);
     }
     if (ex) (void) hipGraphExecDestroy(ex);
     if (g) (void) hipGraphDestroy(g);

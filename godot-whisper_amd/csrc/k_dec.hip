@@ -1548,26 +1548,22 @@ __global__ __launch_bounds__(256) void k_rows_mfma(const GemvArgs a) {
         auto copy_rows = [&](auto cp_tag) {
             constexpr int CP = decltype(cp_tag)::value;
             for (int e0 = 0; e0 < total; e0 += 256 * CP) {
-                uint4 tmp[CP];
-                int src[CP];
+                // (as HIP's uint4 struct the array was left in SCRATCH memory — 144 bytes per lane in every k_rows_mfma instantiation, round 5)
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                u32x4 tmp[CP];
+                int src[CP], cc[CP], dst[CP];                // dst: LDS offset in halves, -1 = no piece
 #pragma unroll
                 for (int q = 0; q < CP; ++q) {
                     const int e = e0 + tid + 256 * q, ec = e < total ? e : 0;
                     const int r = ec / cpr;
+                    cc[q] = ec - r * cpr; dst[q] = e < total ? r * lda + cc[q] * 8 : -1;
                     src[q] = a.rows ? a.rows[r] : r;
                 }
 #pragma unroll
-                for (int q = 0; q < CP; ++q) {
-                    const int e = e0 + tid + 256 * q, ec = e < total ? e : 0;
-                    const int r = ec / cpr, c = ec - r * cpr;
-                    tmp[q] = ((const uint4 *) (a.a16 + (size_t) src[q] * K))[c];
-                }
+                for (int q = 0; q < CP; ++q) tmp[q] = ((const u32x4 *) (a.a16 + (size_t) src[q] * K))[cc[q]];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int q = 0; q < CP; ++q) {
-                    const int e = e0 + tid + 256 * q;
-                    if (e < total) { const int r = e / cpr, c = e - r * cpr; ((uint4 *) (act + r * lda))[c] = tmp[q]; }
-                }
+                for (int q = 0; q < CP; ++q) if (dst[q] >= 0) *(u32x4 *) (act + dst[q]) = tmp[q];
             }
         };
         if (total <= 512) copy_rows(std::integral_constant<int, 2>{});

@@ -19,6 +19,7 @@ print("model", shape, qt, len(m) / 1e6, "MB in", round(time.time() - t0, 1), "s"
 node = host.SpeechToText(lib); node.set_language_model(m); node.language = "en"
 pcm = synth.make_pcm(30.0, seed=7)
 cases = (("greedy mt16", 0, 1, 16), ("beam5 mt16", 1, 5, 16), ("greedy mt0", 0, 1, 0), ("beam5 mt0", 1, 5, 0))[: int(os.environ.get("ONLY", "4"))]
+if os.environ.get("CASE"): cases = [c for c in cases if c[0].startswith(os.environ["CASE"])]
 for name, strat, bs, mt in cases:
     p = lib.whisper_full_default_params(strat)
     q = node.full_params("", 0)
