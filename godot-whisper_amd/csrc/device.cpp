@@ -123,6 +123,12 @@ bool init_state(whisper_context & ctx, bool replica_state, hipStream_t adopt) {
             && dalloc(d.xattn, k::attn_cross_scratch_floats((int) n, (int) H, (int) T));
     d.pinned_bytes = std::max<size_t>((size_t) d.logits_rows_cap * hp.n_vocab * 4, n * n_self * 4 + 3 * n * 4 + 4096);
     ok = ok && HIP_OK(hipHostMalloc(&d.pinned, d.pinned_bytes, hipHostMallocDefault));
+    // the in-launch hand-off of the one-row step's MLP (k::mlp_pair): 2 S granules + the launch counter, zeroed once (tag 0 = never valid)
+    {
+        unsigned char * hand = nullptr;
+        ok = ok && dalloc(hand, (size_t) 16 * S + 64);
+        if (ok) { d.mlp_hand = hand; d.mlp_arrive = (unsigned long long *) (hand + (size_t) 16 * S); k::fill_zero(hand, (size_t) 16 * S + 64, d.stream); }
+    }
     if (!ok) { WMI_ERR("%s: device allocation failed\n", __func__); return false; }
     // buffers that are read before being fully written must hold finite values
     k::fill_zero(d.vt, S * d.Tpad * sizeof(__half), d.stream);
@@ -171,6 +177,7 @@ void destroy_state(State * st) {
     dfree(d.xn); dfree(d.q); dfree(d.k); dfree(d.vt); dfree(d.att); dfree(d.h); dfree(d.rowmax); dfree(d.enc_out);
     dfree(d.enc_out_h); dfree(d.d_tokens); d.d_pos = nullptr; d.d_mask = nullptr; d.d_rows = nullptr; dfree(d.dx); dfree(d.dxn);
     dfree(d.dq); dfree(d.datt); dfree(d.dh); dfree(d.logits); dfree(d.xattn); dfree(d.ban_dev);
+    if (d.mlp_hand) { (void) hipFree(d.mlp_hand); d.mlp_hand = nullptr; d.mlp_arrive = nullptr; }
     dfree(d.aq); dfree(d.ads); dfree(d.aq16); dfree(d.wq16); dfree(d.att32); dfree(d.datt32);
     for (auto & sg : d.step_graphs) { if (sg.exec) (void) hipGraphExecDestroy(sg.exec); if (sg.graph) (void) hipGraphDestroy(sg.graph); sg = DeviceState::StepGraph{}; }
     if (d.step_dev) (void) hipFree(d.step_dev);
@@ -820,6 +827,17 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = fa
             g.C = d.dx; g.ldc = S; g.resid = d.dx; g.ldr = S; g.S = S;
             if (M & 16) k::gemv(g, s);
         }
+        // both MLP projections as ONE launch with an in-launch hand-off of the hidden row (k::mlp_pair; WMI_NO_MLP_PAIR=1: two launches)
+        const bool no_pair = getenv("WMI_NO_MLP_PAIR") != nullptr;                     // (read per enqueue: the step probe A/Bs both forms inside one process)
+        bool paired = false;
+        if ((M & 32) && (M & 64) && !no_pair && d.mlp_hand && (Lt & 1) == 0) {      // (the launches' parity must alternate across steps too)
+            k::MlpPairArgs p{};
+            p.x = d.dx; p.ln_g = l.ln3_g; p.ln_b = l.ln3_b; p.eps = hp.eps; p.S = S; p.W1 = l.w_fc1; p.b1 = l.b_fc1; p.W2 = l.w_fc2; p.b2 = l.b_fc2;
+            p.epoch = (uint32_t *) d.mlp_arrive; p.par = il & 1; p.hand = d.mlp_hand;
+            if (chained && il == Lt - 1) { p.step_copy_src = d.step_host; p.step_copy_dst = d.step_dev; }
+            paired = k::mlp_pair(p, d.dx, s);
+        }
+        if (paired) continue;
         if (M & 32) gv(k::EPI_F16_BIAS_GELU, l.ln3_g, l.ln3_b, nullptr, S, 4 * S, l.w_fc1, l.b_fc1, d.dh, 4 * S, nullptr, nullptr, nullptr, 0.f, nullptr);
         if ((M & 64) && chained && il == Lt - 1) {             // + the workgroup that mirrors the host's step record (filter flags, seq)
             k::GemvArgs g{};

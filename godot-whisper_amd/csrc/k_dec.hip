@@ -1772,6 +1772,141 @@ int gemv_fused_parts(const GemvArgs & a) {
     const int blocks = (a.N + 31) / 32;
     return std::min(blocks, logits_blocks_cap());
 }
+// ------------------------------------------------------------------------------------------------ one MLP, one launch
+// Phase 1 = k_gemv1<4, 1, false, 1, EPI_F16_BIAS_GELU> (LayerNorm in every wavefront, four weight rows per wavefront, the same halving
+// reduction), phase 2 = the mlp.2 projection with ONE row per wavefront (4 S rows of phase 1 on S wavefronts -> S rows of phase 2 on the same
+// S wavefronts).  Per output the operations and their order are the two-launch form's (k_gemv1: fmaf chain over (chunk, element), 64-lane
+// sum with the xor order 32, 16, .., 1 — addition commutes, so halving and plain butterflies give the same bits), so the step stays
+// bit-identical to the other forms (tests/test_gpu_variants.py).
+//
+// The hand-off (scratch/lab/persist_chain.hip measured it: 1.8 us per dependent 512 x 512 phase inside one launch against 2.8 us per launch
+// of a captured chain): a hidden value pair leaves its producer as ONE 8-byte store {f16 pair, tag} that bypasses the caches (sc1); a
+// consumer workgroup sweeps the 2 S granules once — two 16-byte sc0 sc1 loads per thread — until every tag is this launch's, stages the
+// payloads in LDS, one barrier.  No flag, no fence: a granule is valid exactly when its tag matches; the tag counts this kernel's launches
+// (see `epoch` in the kernel).  Measured and dropped: tags from a device-scope counter — bumped when a workgroup leaves it kept the launch
+// open ~1.2 us past its last store; as a ticket per wavefront at the start, 512 same-address atomics took ~6 us and the row's loads
+// retire behind them.
+// All workgroups are resident at once (S / 4 <= 128 workgroups on 256 CUs): the spin cannot starve a producer.
+template <int NCH2>
+__global__ __launch_bounds__(256) void k_mlp_pair(const MlpPairArgs a, float * __restrict__ xio, int G, const Stamp sp) {
+    __shared__ __attribute__((aligned(16))) uint32_t hrow[NCH2 * 256];       // the hidden row as f16 pairs
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const unsigned long long ts0 = stamp_t0(sp.base);
+    if ((int) blockIdx.x == G) {                            // chained greedy steps: the host's step record -> device (see k_gemv1)
+        if (tid < (int) (sizeof(DecStep) / 4)) ((int32_t *) a.step_copy_dst)[tid] = ((const volatile int32_t *) a.step_copy_src)[tid];
+        return;
+    }
+    const int S = a.S, K2 = 4 * S;
+    const int gw = blockIdx.x * 4 + wave;                   // phase 1: rows 4 gw .. + 4 of W1; phase 2: row gw of W2
+    // this launch's tag: epoch[par] + 1, where `par` alternates from one launch of this kernel to the next (a.par: the layer's parity) and
+    // THIS launch leaves epoch[par ^ 1] = tag for the next one.  No workgroup of a launch reads the word the launch writes, so a workgroup that
+    // starts late sees the same value as the first one; nothing is ever reset, stale granules carry smaller tags.
+    const uint32_t tag = a.epoch[a.par] + 1u;
+    if (blockIdx.x == 0 && tid == 0) a.epoch[a.par ^ 1] = tag;
+    constexpr int RIF = 4, LPR = 16;
+    const int wrow = lane / LPR; const bool writer = (lane % LPR) == 0;
+    // ---- phase 1 loads: the row first (L2), gain / bias, then the weight rows of both phases (HBM / Infinity Cache)
+    float xv[1][8], gv[1][8], bv[1][8], av1[1][8];
+    ln_row_load<1>(xio, S, lane, xv);
+    ln_row_load<1>(a.ln_g, S, lane, gv);
+    ln_row_load<1>(a.ln_b, S, lane, bv);
+    __builtin_amdgcn_sched_barrier(0);
+    uint4 w1[RIF], w2[NCH2];
+    const int c1 = lane * 8 < S ? lane * 8 : 0;
+#pragma unroll
+    for (int u = 0; u < RIF; ++u) w1[u] = *(const uint4 *) (a.W1 + (size_t) (gw * RIF + u) * S + c1);
+    const float bias1 = a.b1 ? a.b1[gw * RIF + wrow] : 0.0f;
+#pragma unroll
+    for (int t = 0; t < NCH2; ++t) { const int c = lane * 8 + 512 * t; w2[t] = *(const uint4 *) (a.W2 + (size_t) gw * K2 + (c < K2 ? c : 0)); }
+    const float bias2 = a.b2 ? a.b2[gw] : 0.0f;
+    const float resid2 = xio[gw];
+    __builtin_amdgcn_sched_barrier(0);
+    ln_row_mask<1>(xv, S, lane); ln_row_mask<1>(gv, S, lane); ln_row_mask<1>(bv, S, lane);
+    ln_row_compute<1>(xv, gv, bv, S, a.eps, lane, av1);
+    const unsigned long long tm1 = stamp_t0(sp.base);
+    {
+        float acc[RIF];
+#pragma unroll
+        for (int u = 0; u < RIF; ++u) {
+            acc[u] = 0.0f;
+            const __half2 * h = (const __half2 *) &w1[u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float2 f = __half22float2(h[e]);
+                acc[u] = fmaf(f.x, av1[0][2 * e], acc[u]);
+                acc[u] = fmaf(f.y, av1[0][2 * e + 1], acc[u]);
+            }
+        }
+        float v;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const bool hi = lane & 32; const float keep = hi ? acc[u + 2] : acc[u], send = hi ? acc[u] : acc[u + 2]; acc[u] = keep + WMI_SHX(send, 32); }
+        { const bool hi = lane & 16; const float keep = hi ? acc[1] : acc[0], send = hi ? acc[0] : acc[1]; v = keep + WMI_SHX(send, 16); }
+        v += WMI_SHX(v, 8); v += WMI_SHX(v, 4); v += WMI_SHX(v, 2); v += WMI_SHX(v, 1);
+        // lanes 0 / 16 / 32 / 48 hold rows 4 gw + 0 / 1 / 2 / 3: pairs (0, 1) and (2, 3) leave as one granule each
+        const __half hv = f2h(gelu16(v + bias1));
+        const uint32_t mine = (uint32_t) __half_as_ushort(hv);
+        const uint32_t other = (uint32_t) WMI_SHX((int) mine, 16);
+        if (writer && !(wrow & 1)) {
+            const unsigned long long g = ((unsigned long long) tag << 32) | (unsigned long long) (mine | (other << 16));
+            __hip_atomic_store((unsigned long long *) a.hand + (gw * 2 + (wrow >> 1)), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (a.h_out && writer) a.h_out[gw * RIF + wrow] = hv;
+        // ---- the sweep: thread t takes granules 2 t, 2 t + 1 of every 512-granule block (NCH2 / 2 blocks... 2 S granules in all)
+        constexpr int NB = NCH2 / 2 + (NCH2 & 1);           // 16-byte loads per thread: ceil(2 S / 512) with 2 S <= 256 NCH2
+        const int ngran = 2 * S;
+        static_assert(NB == 2, "two 16-byte loads per thread");
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const int g0 = tid * 2, g1 = 512 + tid * 2;
+        const unsigned long long * src0 = (const unsigned long long *) a.hand + (g0 < ngran ? g0 : 0);      // (small models: fewer granules than threads)
+        const unsigned long long * src1 = (const unsigned long long *) a.hand + (g1 < ngran ? g1 : 0);
+        // (two sweeps in flight, alternating, so that a sweep that leaves just before the granules land does not cost a whole round trip:
+        //  measured slower — the hand-off 2.15 -> 2.6 us, the step +6 us: the polling traffic of 128 workgroups doubles)
+        for (uint32_t spins = 0; spins < (1u << 20); ++spins) {      // (bounded: ~1 s — a launch that could not make progress must not hang the queue; the step's results are then wrong and say so downstream)
+            u32x4 q0, q1;                                    // both requests in flight, one wait
+            asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                         : "=&v"(q0), "=&v"(q1) : "v"(src0), "v"(src1) : "memory");
+            bool ok = true;
+            if (g0 < ngran) { ok = q0[1] == tag && q0[3] == tag; hrow[g0] = q0[0]; hrow[g0 + 1] = q0[2]; }
+            if (g1 < ngran) { ok = ok && q1[1] == tag && q1[3] == tag; hrow[g1] = q1[0]; hrow[g1 + 1] = q1[2]; }
+            if (__all(ok)) break;
+        }
+        __syncthreads();
+    }
+    const unsigned long long tm2 = stamp_t0(sp.base);
+    // ---- phase 2: row gw of W2 against the hidden row
+    {
+        float acc = 0.0f;
+#pragma unroll
+        for (int t = 0; t < NCH2; ++t) {
+            const int c = lane * 8 + 512 * t;
+            uint4 u4 = *(const uint4 *) (hrow + ((c < K2 ? c : 0) >> 1));
+            if (c >= K2) u4 = make_uint4(0u, 0u, 0u, 0u);
+            const __half2 * hh = (const __half2 *) &u4; const __half2 * wh = (const __half2 *) &w2[t];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float2 f = __half22float2(wh[e]), x2 = __half22float2(hh[e]);
+                acc = fmaf(f.x, x2.x, acc);
+                acc = fmaf(f.y, x2.y, acc);
+            }
+        }
+        float v = acc;
+        v += WMI_SHX(v, 32); v += WMI_SHX(v, 16); v += WMI_SHX(v, 8); v += WMI_SHX(v, 4); v += WMI_SHX(v, 2); v += WMI_SHX(v, 1);
+        if (lane == 0) xio[gw] = (v + bias2) + resid2;
+    }
+    stamp_end(sp.base, sp.slot, gw, ts0, tm1, tm2);
+}
+
+bool mlp_pair(const MlpPairArgs & a, float * x_inout, hipStream_t st) {
+    const int S = a.S;
+    if (S > 512 || (S % 64) != 0 || 4 * S > 2048 || !a.epoch || !a.hand) return false;
+    const int G = S / 4;                                    // 4 S rows of W1, 16 per workgroup
+    const int blocks = G + (a.step_copy_src ? 1 : 0);
+    const Stamp sp = stamp_next();
+    if (4 * S <= 1536) hipLaunchKernelGGL(k_mlp_pair<3>, dim3(blocks), dim3(256), 0, st, a, x_inout, G, sp);
+    else               hipLaunchKernelGGL(k_mlp_pair<4>, dim3(blocks), dim3(256), 0, st, a, x_inout, G, sp);
+    return true;
+}
+
 void gemv(const GemvArgs & a, hipStream_t st) {
     const Stamp sp = stamp_next();
     if (sp.base) { GemvArgs b = a; b.stamps = sp.base; b.stamp_slot = sp.slot; gemv_(b, st); return; }

@@ -296,6 +296,20 @@ void attn_cross_combine(const float * part_o, const float * part_l, const float 
                         float * out32 = nullptr);
 enum { EPI_LOGITS = 100 };                    // C f32 [n][N] = acc
 void gemv(const GemvArgs & a, hipStream_t st);
+
+// One decoder MLP of the one-row step as ONE launch: x += W2 . gelu(W1 . LN(x) + b1) + b2 (k_mlp_pair, k_dec.hip).  The hidden row goes
+// from the workgroups that produce it to every workgroup of the same launch through data-tagged 8-byte granules ({two f16, tag}, written
+// and read past the caches): no launch boundary between the two projections.  `hand` holds 2 S granules (16 S bytes, zeroed once),
+// `epoch` two 32-bit words (zeroed once; the launches' tags, see the kernel).  false = shape not covered
+// (S > 512, 4 S > 2048): run the two projections as two launches.
+struct MlpPairArgs {
+    const float * x; const float * ln_g, * ln_b; float eps; int S;
+    const __half * W1; const float * b1; const __half * W2; const float * b2;
+    uint32_t * epoch; int par; void * hand;                    // epoch[2] (zeroed once), par = 0 / 1 alternating from launch to launch
+    const void * step_copy_src; void * step_copy_dst;          // chained greedy steps: see GemvArgs::step_copy_src
+    __half * h_out;                                            // optional plain copy of the hidden row (tests / debugging)
+};
+bool mlp_pair(const MlpPairArgs & a, float * x_inout, hipStream_t st);
 void set_attn_one_group(bool on);              // encoder attention: never split the keys over two wave groups (bit-identical for any batch)
 bool rows_valu_enabled();
 void set_rows_valu(bool on);                  // lock-step rows: true = VALU kernel (bit-identical to the one-row path), false = MFMA

@@ -234,6 +234,8 @@ struct DeviceState {
     //   long    f16 models: (row, head)-parallel self-attention + plain out projection instead of the fused prologue (device.cpp)
     //   chained no embedding launch — the previous step's pick kernel left the token, the position, the cache head and the next
     //           activation row on the device; valid while the host feeds exactly that token at that position
+    // one-row step, one MLP per launch (k::mlp_pair): the hidden row's granules and the launch counter the tags are derived from
+    void * mlp_hand = nullptr; unsigned long long * mlp_arrive = nullptr;
     struct StepGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int T = -1; int seen = 0; };
     StepGraph step_graphs[4];
     bool chain_valid = false; int32_t chain_token = 0, chain_pos = 0, chain_head = 0;

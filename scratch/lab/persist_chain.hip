@@ -92,6 +92,54 @@ __global__ __launch_bounds__(256) void k_persist(const __half * __restrict__ W, 
     }
 }
 
+// (c) as (b), but the row is gathered ONCE per workgroup: wavefront w sweeps a quarter of the granules (two per lane, one 16-byte sc1 load),
+// stages the values in LDS, one barrier, every wavefront reads its x from LDS — the price list's "one sweep per CU" form (4x fewer polling
+// loads than (b), where each of the four wavefronts swept the whole row)
+template <int RPW>
+__global__ __launch_bounds__(256) void k_persist_lds(const __half * __restrict__ W, size_t w_stride, int n_w, Gran * __restrict__ ring, int P,
+                                                     int stride_blocks, int * __restrict__ err) {
+    if (blockIdx.x % stride_blocks != 0) return;
+    __shared__ float xs[2][S];
+    const int tid = threadIdx.x, lane = tid & 63, gw = (blockIdx.x / stride_blocks) * 4 + (tid >> 6);
+    const int r0 = gw * RPW;
+    uint4 w[RPW];
+#pragma unroll
+    for (int u = 0; u < RPW; ++u) w[u] = *(const uint4 *) (W + (size_t) (r0 + u) * S + lane * 8);
+    for (int p = 0; p < P; ++p) {
+        const Gran * src = ring + (size_t) (p % 3) * S;
+        float * xb = xs[p & 1];
+        unsigned spins = 0;
+        for (;;) {
+            uint4 g;
+            asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(g) : "v"(src + tid * 2) : "memory");
+            const bool ok = g.y == (unsigned) p && g.w == (unsigned) p;
+            if (ok) { xb[tid * 2] = __uint_as_float(g.x); xb[tid * 2 + 1] = __uint_as_float(g.z); }
+            if (__all(ok)) break;
+            if (++spins > 4000000u) { if (lane == 0) atomicExch(err, p + 1); return; }
+        }
+        __syncthreads();
+        float xv[8];
+        const float4 a = *(const float4 *) (xb + lane * 8), b = *(const float4 *) (xb + lane * 8 + 4);
+        xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w; xv[4] = b.x; xv[5] = b.y; xv[6] = b.z; xv[7] = b.w;
+        float res[RPW];
+#pragma unroll
+        for (int u = 0; u < RPW; ++u) res[u] = wave_sum(dot8(w[u], xv));
+        if (p + 1 < P) {
+            const __half * Wn = W + (size_t) ((p + 1) % n_w) * w_stride;
+#pragma unroll
+            for (int u = 0; u < RPW; ++u) w[u] = *(const uint4 *) (Wn + (size_t) (r0 + u) * S + lane * 8);
+        }
+        Gran * dst = ring + (size_t) ((p + 1) % 3) * S;
+        if (lane < RPW) {
+            float mine = res[0];
+#pragma unroll
+            for (int u = 1; u < RPW; ++u) if (lane == u) mine = res[u];
+            const unsigned long long g = ((unsigned long long) (unsigned) (p + 1) << 32) | __float_as_uint(mine);
+            __hip_atomic_store((unsigned long long *) (dst + r0 + lane), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+
 int main() {
     const int P = 42 * 8, n_w = 14;
     std::vector<__half> hW((size_t) n_w * S * S);
@@ -134,6 +182,24 @@ int main() {
             printf("persistent %-11s: %.2f us per phase, max |diff| vs launches %.3g, err %d\n", what, ms * 1000 / P, md, herr);
         }
     };
+    // the launch chain again as a captured graph (what the product replays)
+    {
+        hipGraph_t g; hipGraphExec_t ex;
+        CK(hipMemcpy(xa, x0.data(), S * 4, hipMemcpyHostToDevice));
+        CK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        float * a = xa, * b = xb;
+        for (int p = 0; p < P; ++p) { hipLaunchKernelGGL(k_phase<4>, dim3(S / 16), dim3(256), 0, st, W + (size_t) (p % n_w) * S * S, a, b, S); std::swap(a, b); }
+        CK(hipStreamEndCapture(st, &g)); CK(hipGraphInstantiate(&ex, g, nullptr, nullptr, 0));
+        for (int rep = 0; rep < 3; ++rep) {
+            CK(hipMemcpy(xa, x0.data(), S * 4, hipMemcpyHostToDevice));
+            CK(hipEventRecord(e0, st)); CK(hipGraphLaunch(ex, st)); CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            printf("launch chain (graph)  : %.2f us per phase\n", ms * 1000 / P);
+        }
+    }
+    run(k_persist_lds<4>, 32, 256, 8, "LDS G=32 1XCD");
+    run(k_persist_lds<4>, 32, 32, 1, "LDS G=32 sprd");
+    run(k_persist_lds<2>, 64, 256, 4, "LDS G=64");
     run(k_persist<4>, 32, 256, 8, "G=32 (1 XCD)");
     run(k_persist<4>, 32, 32, 1, "G=32 spread");
     run(k_persist<2>, 64, 256, 4, "G=64 (2 XCD)");

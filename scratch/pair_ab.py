@@ -1,0 +1,21 @@
+"""Scratch: the one-row step chain on the GPU (wmi_bench_kernel 20) with the MLP as one launch vs two, alternating inside ONE process."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry
+entry.load_package()
+from godot_whisper_amd import host, runtime, synth
+lib = runtime.require_gpu(); runtime.silence_logs(lib)
+libc = C.CDLL(None)
+for shape in ("base.en", "tiny.en"):
+    node = host.SpeechToText(lib); node.set_language_model(synth.make_model(shape, seed=1234))
+    pcm = synth.make_pcm(30.0, seed=1234)
+    for _ in range(6): node.transcribe(pcm, "", 0)
+    libc.setenv(b"WMI_STEP_MASK", b"0x1ff", 1)
+    res = {"pair": [], "two": []}
+    for rep in range(6):
+        libc.unsetenv(b"WMI_NO_MLP_PAIR"); res["pair"].append(lib.wmi_bench_kernel(node.ctx, 20, 300))
+        libc.setenv(b"WMI_NO_MLP_PAIR", b"1", 1); res["two"].append(lib.wmi_bench_kernel(node.ctx, 20, 300))
+    libc.unsetenv(b"WMI_NO_MLP_PAIR")
+    print(shape, "step chain us | one launch per MLP:", " ".join("%.2f" % v for v in res["pair"]), "| two launches:", " ".join("%.2f" % v for v in res["two"]), flush=True)
+    node.close()

@@ -52,7 +52,7 @@ def default_run():
     return _run({})
 
 
-@pytest.mark.parametrize("knob", ["WMI_NO_CHAIN", "WMI_NO_GRAPH"])
+@pytest.mark.parametrize("knob", ["WMI_NO_CHAIN", "WMI_NO_GRAPH", "WMI_NO_MLP_PAIR"])      # (the last: both MLP projections as one launch with an in-launch hand-off vs two launches)
 def test_step_forms_are_bit_identical(default_run, knob):
     other = _run({knob: "1"})
     for shape, runs in default_run.items():
