@@ -1787,8 +1787,8 @@ int gemv_fused_parts(const GemvArgs & a) {
 // open ~1.2 us past its last store; as a ticket per wavefront at the start, 512 same-address atomics took ~6 us and the row's loads
 // retire behind them.
 // All workgroups are resident at once (S / 4 <= 128 workgroups on 256 CUs): the spin cannot starve a producer.
-template <int NCH2>
-__global__ __launch_bounds__(256) void k_mlp_pair(const MlpPairArgs a, float * __restrict__ xio, int G, const Stamp sp) {
+template <int NCH2, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_mlp_pair(const MlpPairArgs a, float * __restrict__ xio, int G, const Stamp sp) {
     __shared__ __attribute__((aligned(16))) uint32_t hrow[NCH2 * 256];       // the hidden row as f16 pairs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const unsigned long long ts0 = stamp_t0(sp.base);
@@ -1797,7 +1797,8 @@ __global__ __launch_bounds__(256) void k_mlp_pair(const MlpPairArgs a, float * _
         return;
     }
     const int S = a.S, K2 = 4 * S;
-    const int gw = blockIdx.x * 4 + wave;                   // phase 1: rows 4 gw .. + 4 of W1; phase 2: row gw of W2
+    constexpr int NT = 64 * WPB;
+    const int gw = blockIdx.x * WPB + wave;                 // phase 1: rows 4 gw .. + 4 of W1; phase 2: row gw of W2
     // this launch's tag: epoch[par] + 1, where `par` alternates from one launch of this kernel to the next (a.par: the layer's parity) and
     // THIS launch leaves epoch[par ^ 1] = tag for the next one.  No workgroup of a launch reads the word the launch writes, so a workgroup that
     // starts late sees the same value as the first one; nothing is ever reset, stale granules carry smaller tags.
@@ -1851,23 +1852,25 @@ __global__ __launch_bounds__(256) void k_mlp_pair(const MlpPairArgs a, float * _
             __hip_atomic_store((unsigned long long *) a.hand + (gw * 2 + (wrow >> 1)), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (a.h_out && writer) a.h_out[gw * RIF + wrow] = hv;
-        // ---- the sweep: thread t takes granules 2 t, 2 t + 1 of every 512-granule block (NCH2 / 2 blocks... 2 S granules in all)
-        constexpr int NB = NCH2 / 2 + (NCH2 & 1);           // 16-byte loads per thread: ceil(2 S / 512) with 2 S <= 256 NCH2
-        const int ngran = 2 * S;
-        static_assert(NB == 2, "two 16-byte loads per thread");
+        // ---- the sweep: thread t takes granules 2 t, 2 t + 1 of every block of 2 NT granules (one 16-byte load each; 2 S granules in all)
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        const int g0 = tid * 2, g1 = 512 + tid * 2;
+        const int ngran = 2 * S;
+        const int g0 = tid * 2, g1 = 2 * NT + tid * 2;
         const unsigned long long * src0 = (const unsigned long long *) a.hand + (g0 < ngran ? g0 : 0);      // (small models: fewer granules than threads)
         const unsigned long long * src1 = (const unsigned long long *) a.hand + (g1 < ngran ? g1 : 0);
+        const bool second = 2 * NT < ngran;                  // wave-uniform: 4-wavefront workgroups at S = 512
         // (two sweeps in flight, alternating, so that a sweep that leaves just before the granules land does not cost a whole round trip:
         //  measured slower — the hand-off 2.15 -> 2.6 us, the step +6 us: the polling traffic of 128 workgroups doubles)
         for (uint32_t spins = 0; spins < (1u << 20); ++spins) {      // (bounded: ~1 s — a launch that could not make progress must not hang the queue; the step's results are then wrong and say so downstream)
-            u32x4 q0, q1;                                    // both requests in flight, one wait
-            asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
-                         : "=&v"(q0), "=&v"(q1) : "v"(src0), "v"(src1) : "memory");
+            u32x4 q0, q1 = {0u, 0u, 0u, 0u};                 // both requests in flight, one wait
+            if (second)
+                asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                             : "=&v"(q0), "=&v"(q1) : "v"(src0), "v"(src1) : "memory");
+            else
+                asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q0) : "v"(src0) : "memory");
             bool ok = true;
             if (g0 < ngran) { ok = q0[1] == tag && q0[3] == tag; hrow[g0] = q0[0]; hrow[g0 + 1] = q0[2]; }
-            if (g1 < ngran) { ok = ok && q1[1] == tag && q1[3] == tag; hrow[g1] = q1[0]; hrow[g1 + 1] = q1[2]; }
+            if (second && g1 < ngran) { ok = ok && q1[1] == tag && q1[3] == tag; hrow[g1] = q1[0]; hrow[g1 + 1] = q1[2]; }
             if (__all(ok)) break;
         }
         __syncthreads();
@@ -1899,11 +1902,20 @@ __global__ __launch_bounds__(256) void k_mlp_pair(const MlpPairArgs a, float * _
 bool mlp_pair(const MlpPairArgs & a, float * x_inout, hipStream_t st) {
     const int S = a.S;
     if (S > 512 || (S % 64) != 0 || 4 * S > 2048 || !a.epoch || !a.hand) return false;
-    const int G = S / 4;                                    // 4 S rows of W1, 16 per workgroup
+    // 4 S rows of W1, four per wavefront, 4-wavefront workgroups.  (WMI_PAIR_WPB=8: eight — half as many sweeping workgroups, one 16-byte
+    // load per thread and sweep instead of two: measured SLOWER, step chain 157.5 against 155.4 us; two launches 158.9, same process)
+    const int wpb = getenv("WMI_PAIR_WPB") ? atoi(getenv("WMI_PAIR_WPB")) : 4;          // (read per enqueue: A/B inside one process)
+    const bool w8 = wpb == 8 && (S % 8) == 0;
+    const int G = S / (w8 ? 8 : 4);
     const int blocks = G + (a.step_copy_src ? 1 : 0);
     const Stamp sp = stamp_next();
-    if (4 * S <= 1536) hipLaunchKernelGGL(k_mlp_pair<3>, dim3(blocks), dim3(256), 0, st, a, x_inout, G, sp);
-    else               hipLaunchKernelGGL(k_mlp_pair<4>, dim3(blocks), dim3(256), 0, st, a, x_inout, G, sp);
+    if (w8) {
+        if (4 * S <= 1536) hipLaunchKernelGGL((k_mlp_pair<3, 8>), dim3(blocks), dim3(512), 0, st, a, x_inout, G, sp);
+        else               hipLaunchKernelGGL((k_mlp_pair<4, 8>), dim3(blocks), dim3(512), 0, st, a, x_inout, G, sp);
+    } else {
+        if (4 * S <= 1536) hipLaunchKernelGGL((k_mlp_pair<3, 4>), dim3(blocks), dim3(256), 0, st, a, x_inout, G, sp);
+        else               hipLaunchKernelGGL((k_mlp_pair<4, 4>), dim3(blocks), dim3(256), 0, st, a, x_inout, G, sp);
+    }
     return true;
 }
 

@@ -12,10 +12,11 @@ for shape in ("base.en", "tiny.en"):
     pcm = synth.make_pcm(30.0, seed=1234)
     for _ in range(6): node.transcribe(pcm, "", 0)
     libc.setenv(b"WMI_STEP_MASK", b"0x1ff", 1)
-    res = {"pair": [], "two": []}
-    for rep in range(6):
-        libc.unsetenv(b"WMI_NO_MLP_PAIR"); res["pair"].append(lib.wmi_bench_kernel(node.ctx, 20, 300))
+    res = {"pair8": [], "pair4": [], "two": []}
+    for rep in range(5):
+        libc.unsetenv(b"WMI_NO_MLP_PAIR"); libc.unsetenv(b"WMI_PAIR_WPB"); res["pair8"].append(lib.wmi_bench_kernel(node.ctx, 20, 300))
+        libc.setenv(b"WMI_PAIR_WPB", b"4", 1); res["pair4"].append(lib.wmi_bench_kernel(node.ctx, 20, 300)); libc.unsetenv(b"WMI_PAIR_WPB")
         libc.setenv(b"WMI_NO_MLP_PAIR", b"1", 1); res["two"].append(lib.wmi_bench_kernel(node.ctx, 20, 300))
     libc.unsetenv(b"WMI_NO_MLP_PAIR")
-    print(shape, "step chain us | one launch per MLP:", " ".join("%.2f" % v for v in res["pair"]), "| two launches:", " ".join("%.2f" % v for v in res["two"]), flush=True)
+    print(shape, "step chain us | one launch per MLP, 8-wavefront workgroups:", " ".join("%.2f" % v for v in res["pair8"]), "| 4-wavefront:", " ".join("%.2f" % v for v in res["pair4"]), "| two launches:", " ".join("%.2f" % v for v in res["two"]), flush=True)
     node.close()
