@@ -321,19 +321,19 @@ __device__ __forceinline__ bool self_attn_wave(const __half * __restrict__ sq, c
 __device__ __forceinline__ void self_attn_row(const __half * __restrict__ sq, const __half * __restrict__ sk,
                                               const __half * __restrict__ sv, int n_kv, int K, int cap,
                                               float * sc, float * qf, __half * out, const uint4 (&kpre)[8], bool use_pre) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, NTH = (int) blockDim.x;      // (256 or 512 threads)
     const int H = K / 64;
     {   // q -> f32 in LDS.  All loads of a thread first: as a plain strided loop hipcc emitted one load + vmcnt(0) per
         // element for short trip counts (K = 512: two dependent round trips before the first score)
         constexpr int QU = 5;                           // K <= 1280
         __half qv[QU];
 #pragma unroll
-        for (int u = 0; u < QU; ++u) { const int c = tid + u * 256; qv[u] = sq[c < K ? c : 0]; }
+        for (int u = 0; u < QU; ++u) { const int c = tid + u * NTH; qv[u] = sq[c < K ? c : 0]; }
 #pragma unroll
-        for (int u = 0; u < QU; ++u) { const int c = tid + u * 256; if (c < K) qf[c] = __half2float(qv[u]); }
+        for (int u = 0; u < QU; ++u) { const int c = tid + u * NTH; if (c < K) qf[c] = __half2float(qv[u]); }
     }
     __syncthreads();
-    for (int p = tid; p < H * n_kv; p += 256) {
+    for (int p = tid; p < H * n_kv; p += NTH) {
         const int j = p / H, h = p - j * H;
         const uint4 * kp = (const uint4 *) (sk + (size_t) j * K + h * 64);
         float dot = 0.0f;
@@ -351,7 +351,7 @@ __device__ __forceinline__ void self_attn_row(const __half * __restrict__ sq, co
         sc[(size_t) h * cap + j] = dot;
     }
     __syncthreads();
-    for (int h = wave; h < H; h += 4) {                 // soft-max of one head per wavefront
+    for (int h = wave; h < H; h += (NTH >> 6)) {                 // soft-max of one head per wavefront
         float * row = sc + (size_t) h * cap;
         float m = -INFINITY;
         for (int j = lane; j < n_kv; j += 64) m = fmaxf(m, row[j]);
@@ -363,7 +363,7 @@ __device__ __forceinline__ void self_attn_row(const __half * __restrict__ sq, co
         for (int j = lane; j < n_kv; j += 64) row[j] = round_f16(row[j] * inv);
     }
     __syncthreads();
-    for (int c = tid; c < K; c += 256) {
+    for (int c = tid; c < K; c += NTH) {
         const float * row = sc + (size_t) (c >> 6) * cap;
         const __half * vp = sv + c;
         float acc = 0.0f;
@@ -1000,7 +1000,7 @@ __global__ __launch_bounds__(64 * WPB) void k_gemv1(const GemvArgs a_in) {
                 if (wave < H) {
                     int hs[HPW];
 #pragma unroll
-                    for (int u = 0; u < HPW; ++u) hs[u] = wave + 4 * u;
+                    for (int u = 0; u < HPW; ++u) hs[u] = wave + WPB * u;
                     done = self_attn_wave<HPW>(a.sa_q, a.sa_k, a.sa_v, a.sa_nkv, K, a.sa_cap, hs, H, lane, act, nullptr, sc + wave * 64 * HPW, al);
                 }
             } else {
@@ -1227,7 +1227,7 @@ __global__ __launch_bounds__(64 * WPB) void k_gemv1(const GemvArgs a_in) {
 
 template <int RIF, int NCH, bool NT = false, int PRO = -1, int EPI = -1, int HPW = 0, int WPB = 4, bool FS = false>
 void launch_gemv1(const GemvArgs & a, hipStream_t st, int max_blocks = 512) {
-    static_assert(WPB == 4 || PRO == 0, "one-wavefront workgroups: plain f16 rows only");
+    static_assert(WPB == 4 || PRO == 0 || (PRO == 2 && WPB == 8), "one-wavefront workgroups: plain f16 rows only; eight wavefronts: the self-attention prologue");
     size_t smem = 0;
     if (a.sa_q)        smem = ((((size_t) a.K * sizeof(__half)) + 15) & ~(size_t) 15) + (sa_score_floats(a.K, a.sa_cap) + a.K) * sizeof(float);
     else if (a.comb_o) smem = (size_t) a.K * sizeof(__half);
@@ -1270,6 +1270,10 @@ static bool launch_gemv1_special(const GemvArgs & a, int nch, hipStream_t st) {
         // self-attention + out projection: (row chunks, heads per wavefront) — tiny 1/2, base 1/2, small 2/3, medium 2/4, large 3/5
         const int hpw = (a.K / 64 + 3) / 4;
         if (nch == 1 && hpw == 1) { launch_gemv1<4, 1, false, 2, EPI_F32_BIAS_RESID, 1>(a, st); return true; }
+        // eight heads (base): eight wavefronts with ONE head each and two weight rows per wavefront — the attention is a dependent chain of
+        // ~1000 VALU instructions per head pair, i.e. most of this launch's body (row ready at +2.6 .. 2.9 us of 3.2); WMI_SA_WPB=4: the round-3 form
+        const int sa_wpb = getenv("WMI_SA_WPB") ? atoi(getenv("WMI_SA_WPB")) : 8;        // (read per enqueue: A/B inside one process)
+        if (nch == 1 && hpw == 2 && sa_wpb == 8 && a.K == 512 && !a.lanes) { launch_gemv1<2, 1, false, 2, EPI_F32_BIAS_RESID, 1, 8>(a, st); return true; }
         if (nch == 1 && hpw == 2) { launch_gemv1<4, 1, false, 2, EPI_F32_BIAS_RESID, 2>(a, st); return true; }
         if (nch == 2 && hpw == 3) { launch_gemv1<4, 2, false, 2, EPI_F32_BIAS_RESID, 3>(a, st); return true; }
         if (nch == 2 && hpw == 4) { launch_gemv1<4, 2, false, 2, EPI_F32_BIAS_RESID, 4>(a, st); return true; }

@@ -12,6 +12,11 @@ for shape in ("base.en", "tiny.en"):
     pcm = synth.make_pcm(30.0, seed=1234)
     for _ in range(6): node.transcribe(pcm, "", 0)
     libc.setenv(b"WMI_STEP_MASK", b"0x1ff", 1)
+    res = {"sa8": [], "sa4": []}
+    for rep in range(5):
+        libc.unsetenv(b"WMI_SA_WPB"); res["sa8"].append(lib.wmi_bench_kernel(node.ctx, 20, 300))
+        libc.setenv(b"WMI_SA_WPB", b"4", 1); res["sa4"].append(lib.wmi_bench_kernel(node.ctx, 20, 300)); libc.unsetenv(b"WMI_SA_WPB")
+    print(shape, "step chain us | self-attention + out on 8 wavefronts (one head each):", " ".join("%.2f" % v for v in res["sa8"]), "| 4 wavefronts:", " ".join("%.2f" % v for v in res["sa4"]), flush=True)
     res = {"pair8": [], "pair4": [], "two": []}
     for rep in range(5):
         libc.unsetenv(b"WMI_NO_MLP_PAIR"); libc.unsetenv(b"WMI_PAIR_WPB"); res["pair8"].append(lib.wmi_bench_kernel(node.ctx, 20, 300))

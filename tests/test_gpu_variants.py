@@ -52,9 +52,11 @@ def default_run():
     return _run({})
 
 
-@pytest.mark.parametrize("knob", ["WMI_NO_CHAIN", "WMI_NO_GRAPH", "WMI_NO_MLP_PAIR"])      # (the last: both MLP projections as one launch with an in-launch hand-off vs two launches)
+# WMI_NO_MLP_PAIR: both MLP projections as one launch with an in-launch hand-off vs two launches; WMI_SA_WPB=4: the self-attention + out
+# projection with two heads per wavefront on four wavefronts vs one head on each of eight
+@pytest.mark.parametrize("knob", ["WMI_NO_CHAIN", "WMI_NO_GRAPH", "WMI_NO_MLP_PAIR", "WMI_SA_WPB=4"])
 def test_step_forms_are_bit_identical(default_run, knob):
-    other = _run({knob: "1"})
+    other = _run({knob.split("=")[0]: knob.split("=")[1] if "=" in knob else "1"})
     for shape, runs in default_run.items():
         assert len(runs[0]) > 0, shape
         for a, b in zip(runs, other[shape]):
