@@ -319,7 +319,7 @@ def main():
             # launch under ~4 us; profiles/r03*_step_chains*.txt.)
             kinds = [   # (name, launches per step, algorithmic bytes per launch, key in profiles/*_pmc_summary.json)
                 ("k_gemv1<4,1,false,1,EPI_QKV_DEC> LN + q|k|v projection", Lt, 3 * S2, "k_gemv1<4, 1, false, 1, 5"),
-                ("k_gemv1<4,1,false,2,EPI_F32_BIAS_RESID,2> self-attention over the KV cache + out projection", Lt, S2 + 2 * nkv * hp_S * 2, "k_gemv1<4, 1, false, 2, 2"),
+                ("k_gemv1<2,1,false,2,EPI_F32_BIAS_RESID,1,8> self-attention over the KV cache (one head per wavefront, eight wavefronts) + out projection", Lt, S2 + 2 * nkv * hp_S * 2, "k_gemv1<2, 1, false, 2, 2"),
                 ("k_xattn_fused<1,true>: LN + cross query, scores, soft-max numerators and P.V over the cross K/V (one launch)", Lt, S2 + 2 * T * hp_S * 2, "k_xattn_fused<1, true>"),
                 ("k_gemv1<4,1,false,3,EPI_F32_BIAS_RESID> cross-attention combine + out projection", Lt, S2, "k_gemv1<4, 1, false, 3, 2"),
                 ("k_gemv1<4,1,false,1,EPI_F16_BIAS_GELU> LN + mlp.0", Lt, 4 * S2, "k_gemv1<4, 1, false, 1, 1"),

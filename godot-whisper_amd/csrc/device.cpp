@@ -47,16 +47,28 @@ static bool make_own_queue_stream(int device, hipStream_t * out) {
 // chains run beside each other depends on WHEN their hardware queues were created relative to the process's other queues — the queues a
 // process makes first behave, queues made after several contexts have come and gone did not (bench.py: 40 ms per chunk against 18).  So
 // the streams are made once, as early as a context exists, never destroyed, and handed from context to context.
+// The pool is capped (WMI_OWN_QUEUE_CAP, default 16 per device = four contexts with their three spare queues each): a process that keeps
+// more contexts than that alive gets ordinary non-blocking streams for the rest — hardware queues are a finite resource the embedding
+// application shares.  These streams are created with the default flags: like every blocking stream they synchronise with the
+// legacy NULL stream; an embedder that works on the NULL stream (torch's default stream is one) serialises with a context's launches —
+// use a non-blocking stream on the application's side, or WMI_POOLED_MAIN_STREAM=1 for a non-blocking context stream.
 static std::mutex g_oq_mu;
 static std::map<int, std::vector<hipStream_t>> g_oq_pool;
+static std::map<int, int> g_oq_made;
 hipStream_t own_queue_stream_get(int device) {
+    static const int cap = getenv("WMI_OWN_QUEUE_CAP") ? std::max(0, atoi(getenv("WMI_OWN_QUEUE_CAP"))) : 16;
     {
         std::lock_guard<std::mutex> lk(g_oq_mu);
         auto & v = g_oq_pool[device];
         if (!v.empty()) { hipStream_t s = v.back(); v.pop_back(); return s; }
+        if (g_oq_made[device] >= cap) return nullptr;
+        g_oq_made[device] += 1;
     }
     hipStream_t s = nullptr;
-    return make_own_queue_stream(device, &s) ? s : nullptr;
+    if (make_own_queue_stream(device, &s)) return s;
+    std::lock_guard<std::mutex> lk(g_oq_mu);
+    g_oq_made[device] -= 1;
+    return nullptr;
 }
 void own_queue_stream_put(int device, hipStream_t s) {
     if (!s) return;

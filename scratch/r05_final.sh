@@ -1,10 +1,12 @@
 #!/bin/bash
 # end-of-round evidence: default bench, 8-chunk bench, rocprof summaries (one chunk + 8 chunks), 2-rank rehearsal
 TAG=${1:-r05e}
-python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; tail -c 300 gpurun_out/${TAG}_bench.err
-python bench.py --chunks 8 --no-config4 --no-cpu-baseline > gpurun_out/${TAG}_bench_chunks8.json 2> gpurun_out/${TAG}_bench_chunks8.err
+# (the profiles first: bench.py takes `traffic` from the committed PMC summaries)
 bash profiles/collect.sh ${TAG} > gpurun_out/${TAG}_collect.log 2>&1
 bash profiles/collect.sh ${TAG}8 --chunks 8 > gpurun_out/${TAG}8_collect.log 2>&1
+cp gpurun_out/prof_${TAG}/${TAG}_* gpurun_out/prof_${TAG}8/${TAG}8_* profiles/ 2>/dev/null
+python bench.py > gpurun_out/${TAG}_bench.json 2> gpurun_out/${TAG}_bench.err; tail -c 300 gpurun_out/${TAG}_bench.err
+python bench.py --chunks 8 --no-config4 --no-cpu-baseline > gpurun_out/${TAG}_bench_chunks8.json 2> gpurun_out/${TAG}_bench_chunks8.err
 WMI_BENCH_REHEARSAL=1 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 20 --warmup 3 --no-config4 --no-cpu-baseline > gpurun_out/${TAG}_rehearsal_2ranks_1gpu_gloo.log 2>&1
 tail -c 600 gpurun_out/${TAG}_rehearsal_2ranks_1gpu_gloo.log
 python - <<PY
