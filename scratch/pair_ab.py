@@ -12,6 +12,11 @@ for shape in ("base.en", "tiny.en"):
     pcm = synth.make_pcm(30.0, seed=1234)
     for _ in range(6): node.transcribe(pcm, "", 0)
     libc.setenv(b"WMI_STEP_MASK", b"0x1ff", 1)
+    res = {"x8": [], "x4": []}
+    for rep in range(5):
+        libc.unsetenv(b"WMI_XATTN_WPB"); res["x8"].append(lib.wmi_bench_kernel(node.ctx, 20, 300))
+        libc.setenv(b"WMI_XATTN_WPB", b"4", 1); res["x4"].append(lib.wmi_bench_kernel(node.ctx, 20, 300)); libc.unsetenv(b"WMI_XATTN_WPB")
+    print(shape, "step chain us | cross-attention, two slices per 8-wavefront workgroup:", " ".join("%.2f" % v for v in res["x8"]), "| one slice per workgroup:", " ".join("%.2f" % v for v in res["x4"]), flush=True)
     res = {"sa8": [], "sa4": []}
     for rep in range(5):
         libc.unsetenv(b"WMI_SA_WPB"); res["sa8"].append(lib.wmi_bench_kernel(node.ctx, 20, 300))
