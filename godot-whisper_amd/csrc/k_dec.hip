@@ -1791,7 +1791,8 @@ int gemv_fused_parts(const GemvArgs & a) {
 // open ~1.2 us past its last store; as a ticket per wavefront at the start, 512 same-address atomics took ~6 us and the row's loads
 // retire behind them.
 // All workgroups are resident at once (S / 4 <= 128 workgroups on 256 CUs): the spin cannot starve a producer.
-template <int NCH2, int WPB>
+// NCH1 / NCH2: 512-column chunks of a row of W1 (S columns) / of W2 (4 S columns): (1, 3) tiny, (1, 4) base, (2, 6) small, (2, 8) medium, (3, 10) large
+template <int NCH1, int NCH2, int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_mlp_pair(const MlpPairArgs a, float * __restrict__ xio, int G, const Stamp sp) {
     __shared__ __attribute__((aligned(16))) uint32_t hrow[NCH2 * 256];       // the hidden row as f16 pairs
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1811,37 +1812,43 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_pair(const MlpPairArgs a, floa
     constexpr int RIF = 4, LPR = 16;
     const int wrow = lane / LPR; const bool writer = (lane % LPR) == 0;
     // ---- phase 1 loads: the row first (L2), gain / bias, then the weight rows of both phases (HBM / Infinity Cache)
-    float xv[1][8], gv[1][8], bv[1][8], av1[1][8];
-    ln_row_load<1>(xio, S, lane, xv);
-    ln_row_load<1>(a.ln_g, S, lane, gv);
-    ln_row_load<1>(a.ln_b, S, lane, bv);
+    float xv[NCH1][8], gv[NCH1][8], bv[NCH1][8], av1[NCH1][8];
+    ln_row_load<NCH1>(xio, S, lane, xv);
+    ln_row_load<NCH1>(a.ln_g, S, lane, gv);
+    ln_row_load<NCH1>(a.ln_b, S, lane, bv);
     __builtin_amdgcn_sched_barrier(0);
-    uint4 w1[RIF], w2[NCH2];
-    const int c1 = lane * 8 < S ? lane * 8 : 0;
+    uint4 w1[NCH1][RIF], w2[NCH2];
 #pragma unroll
-    for (int u = 0; u < RIF; ++u) w1[u] = *(const uint4 *) (a.W1 + (size_t) (gw * RIF + u) * S + c1);
+    for (int t = 0; t < NCH1; ++t) {
+        const int c = lane * 8 + 512 * t, c1 = c < S ? c : 0;    // (columns past S: the activation there is exactly 0)
+#pragma unroll
+        for (int u = 0; u < RIF; ++u) w1[t][u] = *(const uint4 *) (a.W1 + (size_t) (gw * RIF + u) * S + c1);
+    }
     const float bias1 = a.b1 ? a.b1[gw * RIF + wrow] : 0.0f;
 #pragma unroll
     for (int t = 0; t < NCH2; ++t) { const int c = lane * 8 + 512 * t; w2[t] = *(const uint4 *) (a.W2 + (size_t) gw * K2 + (c < K2 ? c : 0)); }
     const float bias2 = a.b2 ? a.b2[gw] : 0.0f;
     const float resid2 = xio[gw];
     __builtin_amdgcn_sched_barrier(0);
-    ln_row_mask<1>(xv, S, lane); ln_row_mask<1>(gv, S, lane); ln_row_mask<1>(bv, S, lane);
-    ln_row_compute<1>(xv, gv, bv, S, a.eps, lane, av1);
+    ln_row_mask<NCH1>(xv, S, lane); ln_row_mask<NCH1>(gv, S, lane); ln_row_mask<NCH1>(bv, S, lane);
+    ln_row_compute<NCH1>(xv, gv, bv, S, a.eps, lane, av1);
     const unsigned long long tm1 = stamp_t0(sp.base);
     {
         float acc[RIF];
 #pragma unroll
-        for (int u = 0; u < RIF; ++u) {
-            acc[u] = 0.0f;
-            const __half2 * h = (const __half2 *) &w1[u];
+        for (int u = 0; u < RIF; ++u) acc[u] = 0.0f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float2 f = __half22float2(h[e]);
-                acc[u] = fmaf(f.x, av1[0][2 * e], acc[u]);
-                acc[u] = fmaf(f.y, av1[0][2 * e + 1], acc[u]);
+        for (int t = 0; t < NCH1; ++t)                        // (k_gemv1's order: chunk, then row, then element)
+#pragma unroll
+            for (int u = 0; u < RIF; ++u) {
+                const __half2 * h = (const __half2 *) &w1[t][u];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float2 f = __half22float2(h[e]);
+                    acc[u] = fmaf(f.x, av1[t][2 * e], acc[u]);
+                    acc[u] = fmaf(f.y, av1[t][2 * e + 1], acc[u]);
+                }
             }
-        }
         float v;
 #pragma unroll
         for (int u = 0; u < 2; ++u) { const bool hi = lane & 32; const float keep = hi ? acc[u + 2] : acc[u], send = hi ? acc[u] : acc[u + 2]; acc[u] = keep + WMI_SHX(send, 32); }
@@ -1858,23 +1865,29 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_pair(const MlpPairArgs a, floa
         if (a.h_out && writer) a.h_out[gw * RIF + wrow] = hv;
         // ---- the sweep: thread t takes granules 2 t, 2 t + 1 of every block of 2 NT granules (one 16-byte load each; 2 S granules in all)
         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        constexpr int NL = WPB == 8 ? NCH1 : 2 * NCH1;       // 16-byte loads per thread and sweep (2 S <= 1024 NCH1 granules, 2 NT per block)
         const int ngran = 2 * S;
-        const int g0 = tid * 2, g1 = 2 * NT + tid * 2;
-        const unsigned long long * src0 = (const unsigned long long *) a.hand + (g0 < ngran ? g0 : 0);      // (small models: fewer granules than threads)
-        const unsigned long long * src1 = (const unsigned long long *) a.hand + (g1 < ngran ? g1 : 0);
-        const bool second = 2 * NT < ngran;                  // wave-uniform: 4-wavefront workgroups at S = 512
+        const unsigned long long * src[NL];
+#pragma unroll
+        for (int b2 = 0; b2 < NL; ++b2) { const int g = b2 * 2 * NT + tid * 2; src[b2] = (const unsigned long long *) a.hand + (g < ngran ? g : 0); }      // (fewer granules than slots: re-read granule 0)
         // (two sweeps in flight, alternating, so that a sweep that leaves just before the granules land does not cost a whole round trip:
         //  measured slower — the hand-off 2.15 -> 2.6 us, the step +6 us: the polling traffic of 128 workgroups doubles)
         for (uint32_t spins = 0; spins < (1u << 20); ++spins) {      // (bounded: ~1 s — a launch that could not make progress must not hang the queue; the step's results are then wrong and say so downstream)
-            u32x4 q0, q1 = {0u, 0u, 0u, 0u};                 // both requests in flight, one wait
-            if (second)
-                asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
-                             : "=&v"(q0), "=&v"(q1) : "v"(src0), "v"(src1) : "memory");
-            else
-                asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q0) : "v"(src0) : "memory");
+            u32x4 q[NL];                                     // all requests in flight, one wait (the wait names the registers: nothing reads them before it)
+#pragma unroll
+            for (int b2 = 0; b2 < NL; ++b2) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(q[b2]) : "v"(src[b2]) : "memory");
+            if constexpr (NL == 1)      asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]) :: "memory");
+            else if constexpr (NL == 2) asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]) :: "memory");
+            else if constexpr (NL == 3) asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]) :: "memory");
+            else if constexpr (NL == 4) asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]) :: "memory");
+            else                        asm volatile("s_waitcnt vmcnt(0)" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]), "+v"(q[4]), "+v"(q[NL - 1]) :: "memory");
+            static_assert(NL <= 6, "sweep width");
             bool ok = true;
-            if (g0 < ngran) { ok = q0[1] == tag && q0[3] == tag; hrow[g0] = q0[0]; hrow[g0 + 1] = q0[2]; }
-            if (second && g1 < ngran) { ok = ok && q1[1] == tag && q1[3] == tag; hrow[g1] = q1[0]; hrow[g1 + 1] = q1[2]; }
+#pragma unroll
+            for (int b2 = 0; b2 < NL; ++b2) {
+                const int g = b2 * 2 * NT + tid * 2;
+                if (g < ngran) { ok = ok && q[b2][1] == tag && q[b2][3] == tag; hrow[g] = q[b2][0]; hrow[g + 1] = q[b2][2]; }
+            }
             if (__all(ok)) break;
         }
         __syncthreads();
@@ -1905,21 +1918,31 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_pair(const MlpPairArgs a, floa
 
 bool mlp_pair(const MlpPairArgs & a, float * x_inout, hipStream_t st) {
     const int S = a.S;
-    if (S > 512 || (S % 64) != 0 || 4 * S > 2048 || !a.epoch || !a.hand) return false;
+    // measured, step chain on the GPU with the MLP as one launch / two launches (scratch/pair_ab.py, one process): tiny.en 111.7 / 115.5 us,
+    // base.en 155.4 / 158.9, small 384.8 / 406.5 (-5.3 %), medium 873.8 / 890.3, large-v3 (f16) 1563 / 1541 — at S = 1280 the two 13 MB
+    // matrices are a bandwidth matter and one row per wavefront streams them worse than the two-launch tiling: two launches there
+    if (S > 1024 || (S % 64) != 0 || !a.epoch || !a.hand) return false;
     // 4 S rows of W1, four per wavefront, 4-wavefront workgroups.  (WMI_PAIR_WPB=8: eight — half as many sweeping workgroups, one 16-byte
     // load per thread and sweep instead of two: measured SLOWER, step chain 157.5 against 155.4 us; two launches 158.9, same process)
     const int wpb = getenv("WMI_PAIR_WPB") ? atoi(getenv("WMI_PAIR_WPB")) : 4;          // (read per enqueue: A/B inside one process)
-    const bool w8 = wpb == 8 && (S % 8) == 0;
+    const bool w8 = wpb == 8 && (S % 8) == 0 && S <= 512;
     const int G = S / (w8 ? 8 : 4);
     const int blocks = G + (a.step_copy_src ? 1 : 0);
-    const Stamp sp = stamp_next();
-    if (w8) {
-        if (4 * S <= 1536) hipLaunchKernelGGL((k_mlp_pair<3, 8>), dim3(blocks), dim3(512), 0, st, a, x_inout, G, sp);
-        else               hipLaunchKernelGGL((k_mlp_pair<4, 8>), dim3(blocks), dim3(512), 0, st, a, x_inout, G, sp);
-    } else {
-        if (4 * S <= 1536) hipLaunchKernelGGL((k_mlp_pair<3, 4>), dim3(blocks), dim3(256), 0, st, a, x_inout, G, sp);
-        else               hipLaunchKernelGGL((k_mlp_pair<4, 4>), dim3(blocks), dim3(256), 0, st, a, x_inout, G, sp);
-    }
+    const int nch2 = (4 * S + 511) / 512;
+    // every workgroup of the launch must be resident at once (they wait for each other): checked once per instantiation against the
+    // occupancy the runtime reports — a shape that would not fit runs as two launches
+#define WMI_PAIR(N1, N2, W) do { \
+        static const int fit = [] { int nb = 0, dev = 0, ncu = 0; \
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *) k_mlp_pair<N1, N2, W>, 64 * W, 0) != hipSuccess) return 0; \
+            (void) hipGetDevice(&dev); (void) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); return nb * ncu; }(); \
+        if (blocks > fit) return false; \
+        const Stamp sp = stamp_next(); \
+        hipLaunchKernelGGL((k_mlp_pair<N1, N2, W>), dim3(blocks), dim3(64 * W), 0, st, a, x_inout, G, sp); } while (0)
+    if (w8) { if (nch2 <= 3) WMI_PAIR(1, 3, 8); else WMI_PAIR(1, 4, 8); }
+    else if (S <= 512)  { if (nch2 <= 3) WMI_PAIR(1, 3, 4); else WMI_PAIR(1, 4, 4); }
+    else if (S <= 768)  WMI_PAIR(2, 6, 4);
+    else                WMI_PAIR(2, 8, 4);
+#undef WMI_PAIR
     return true;
 }
 

@@ -300,8 +300,8 @@ void gemv(const GemvArgs & a, hipStream_t st);
 // One decoder MLP of the one-row step as ONE launch: x += W2 . gelu(W1 . LN(x) + b1) + b2 (k_mlp_pair, k_dec.hip).  The hidden row goes
 // from the workgroups that produce it to every workgroup of the same launch through data-tagged 8-byte granules ({two f16, tag}, written
 // and read past the caches): no launch boundary between the two projections.  `hand` holds 2 S granules (16 S bytes, zeroed once),
-// `epoch` two 32-bit words (zeroed once; the launches' tags, see the kernel).  false = shape not covered
-// (S > 512, 4 S > 2048): run the two projections as two launches.
+// `epoch` two 32-bit words (zeroed once; the launches' tags, see the kernel).  false = shape not covered (S > 1024: measured slower at S = 1280; or the launch's workgroups
+// would not all be resident at once): run the two projections as two launches.
 struct MlpPairArgs {
     const float * x; const float * ln_g, * ln_b; float eps; int S;
     const __half * W1; const float * b1; const __half * W2; const float * b2;

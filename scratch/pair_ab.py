@@ -7,7 +7,7 @@ entry.load_package()
 from godot_whisper_amd import host, runtime, synth
 lib = runtime.require_gpu(); runtime.silence_logs(lib)
 libc = C.CDLL(None)
-for shape in ("base.en", "tiny.en"):
+for shape in os.environ.get("SHAPES", "base.en,tiny.en").split(","):
     node = host.SpeechToText(lib); node.set_language_model(synth.make_model(shape, seed=1234))
     pcm = synth.make_pcm(30.0, seed=1234)
     for _ in range(6): node.transcribe(pcm, "", 0)

@@ -25,7 +25,9 @@ entry.load_package()
 from godot_whisper_amd import host, runtime, synth
 lib = runtime.require_gpu(); runtime.silence_logs(lib)
 out = {}
-for shape, secs, mt in (("base.en", 30.0, 16), ("micro.en", 41.0, 0), ("micro", 30.0, 0)):
+# base.en capped and uncapped (self cache beyond 64 cells: the step's long-cache forms), tiny.en (S = 384: the ragged shapes of the fused MLP launch),
+# the micro models (odd layer count: two-launch MLP; two windows)
+for shape, secs, mt in (("base.en", 30.0, 16), ("base.en", 30.0, 0), ("tiny.en", 30.0, 16), ("micro.en", 41.0, 0), ("micro", 30.0, 0)):
     node = host.SpeechToText(lib); node.set_language_model(synth.make_model(shape, seed=4242))
     if shape == "micro": node.language = "de"
     res = []
@@ -33,7 +35,7 @@ for shape, secs, mt in (("base.en", 30.0, 16), ("micro.en", 41.0, 0), ("micro", 
         p = node.full_params("", 0); p.max_tokens = mt; p.temperature_inc = 0.0
         r = node.transcribe(synth.make_pcm(secs, seed=900 + rep % 2), params=p)
         res.append([[int(t["id"]), int(t["tid"]), float(t["p"]), float(t["plog"]), int(t["t0"]), int(t["t1"])] for t in r[1:]])
-    out[shape] = res
+    out["%s/%d" % (shape, mt)] = res
     node.close()
 print("RESULT" + json.dumps(out))
 """.replace("ROOT_PLACEHOLDER", repr(ROOT))
