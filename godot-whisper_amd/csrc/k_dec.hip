@@ -1266,6 +1266,14 @@ static bool launch_gemv1_special(const GemvArgs & a, int nch, hipStream_t st) {
         if (pro == 1 && a.epi == EPI_QKV_DEC)        { launch_gemv1<4, 1, false, 1, EPI_QKV_DEC>(a, st); return true; }
         if (pro == 1 && a.epi == EPI_F16_BIAS_GELU)  { launch_gemv1<4, 1, false, 1, EPI_F16_BIAS_GELU>(a, st); return true; }
     }
+    // the wider f16 models (small / medium: two chunks of 512 columns, large: three) — round 5: the same lean instantiations as base.en's
+    // (WMI_GEMV1_WIDE_GENERIC=1: the run-time-dispatch kernel, as before)
+    const bool wide_generic = getenv("WMI_GEMV1_WIDE_GENERIC") != nullptr;        // (read per enqueue: A/B inside one process)
+    if (!wide_generic && !a.lanes && (nch == 2 || nch == 3)) {
+        if (pro == 1 && a.epi == EPI_QKV_DEC)       { if (nch == 2) launch_gemv1<4, 2, false, 1, EPI_QKV_DEC>(a, st); else launch_gemv1<4, 3, false, 1, EPI_QKV_DEC>(a, st); return true; }
+        if (pro == 1 && a.epi == EPI_F16_BIAS_GELU) { if (nch == 2) launch_gemv1<4, 2, false, 1, EPI_F16_BIAS_GELU>(a, st); else launch_gemv1<4, 3, false, 1, EPI_F16_BIAS_GELU>(a, st); return true; }
+        if (pro == 3 && a.epi == EPI_F32_BIAS_RESID) { if (nch == 2) launch_gemv1<4, 2, false, 3, EPI_F32_BIAS_RESID>(a, st); else launch_gemv1<4, 3, false, 3, EPI_F32_BIAS_RESID>(a, st); return true; }
+    }
     if (pro == 2 && a.epi == EPI_F32_BIAS_RESID && (a.K % 64) == 0) {
         // self-attention + out projection: (row chunks, heads per wavefront) — tiny 1/2, base 1/2, small 2/3, medium 2/4, large 3/5
         const int hpw = (a.K / 64 + 3) / 4;

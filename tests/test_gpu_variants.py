@@ -27,9 +27,9 @@ lib = runtime.require_gpu(); runtime.silence_logs(lib)
 out = {}
 # base.en capped and uncapped (self cache beyond 64 cells: the step's long-cache forms), tiny.en (S = 384: the ragged shapes of the fused MLP launch),
 # the micro models (odd layer count: two-launch MLP; two windows)
-for shape, secs, mt in (("base.en", 30.0, 16), ("base.en", 30.0, 0), ("tiny.en", 30.0, 16), ("micro.en", 41.0, 0), ("micro", 30.0, 0)):
+for shape, secs, mt in (("base.en", 30.0, 16), ("base.en", 30.0, 0), ("tiny.en", 30.0, 16), ("small", 30.0, 16), ("micro.en", 41.0, 0), ("micro", 30.0, 0)):
     node = host.SpeechToText(lib); node.set_language_model(synth.make_model(shape, seed=4242))
-    if shape == "micro": node.language = "de"
+    if shape in ("micro", "small"): node.language = "de"
     res = []
     for rep in range(6):                               # enough steps for the graphs to be captured (> 64 per form) and replayed
         p = node.full_params("", 0); p.max_tokens = mt; p.temperature_inc = 0.0
@@ -55,8 +55,9 @@ def default_run():
 
 
 # WMI_NO_MLP_PAIR: both MLP projections as one launch with an in-launch hand-off vs two launches; WMI_SA_WPB=4: the self-attention + out
-# projection with two heads per wavefront on four wavefronts vs one head on each of eight
-@pytest.mark.parametrize("knob", ["WMI_NO_CHAIN", "WMI_NO_GRAPH", "WMI_NO_MLP_PAIR", "WMI_SA_WPB=4"])
+# projection with two heads per wavefront on four wavefronts vs one head on each of eight; WMI_GEMV1_WIDE_GENERIC: the wider models' projections
+# through the run-time-dispatch kernel vs their lean instantiations
+@pytest.mark.parametrize("knob", ["WMI_NO_CHAIN", "WMI_NO_GRAPH", "WMI_NO_MLP_PAIR", "WMI_SA_WPB=4", "WMI_GEMV1_WIDE_GENERIC"])
 def test_step_forms_are_bit_identical(default_run, knob):
     other = _run({knob.split("=")[0]: knob.split("=")[1] if "=" in knob else "1"})
     for shape, runs in default_run.items():
