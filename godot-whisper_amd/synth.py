@@ -43,6 +43,8 @@ SHAPES = {
     # large-v3's widths (1280 state, 20 heads, 128 mel bins, 51866 tokens / 100 languages) on 2 + 3 layers: exercises
     # every kernel at the widest shape of BASELINE configs[4] at a size the CPU checker finishes in seconds
     "v3-slice": (51866, 1500, 1280, 20, 2, 448, 1280, 20, 3, 128),
+    # medium's widths (1024 state, 16 heads) on 2 + 4 layers: the widest shape the one-launch MLP of the one-row step covers (an even layer count)
+    "medium-slice": (51865, 1500, 1024, 16, 2, 448, 1024, 16, 4, 80),
 }
 
 

@@ -27,9 +27,11 @@ lib = runtime.require_gpu(); runtime.silence_logs(lib)
 out = {}
 # base.en capped and uncapped (self cache beyond 64 cells: the step's long-cache forms), tiny.en (S = 384: the ragged shapes of the fused MLP launch),
 # the micro models (odd layer count: two-launch MLP; two windows)
-for shape, secs, mt in (("base.en", 30.0, 16), ("base.en", 30.0, 0), ("tiny.en", 30.0, 16), ("small", 30.0, 16), ("micro.en", 41.0, 0), ("micro", 30.0, 0)):
+# medium-slice / v3-slice: medium's and large-v3's widths on a few layers (two and three 512-column chunks per row: the wider models' instantiations)
+for shape, secs, mt in (("base.en", 30.0, 16), ("base.en", 30.0, 0), ("tiny.en", 30.0, 16), ("small", 30.0, 16), ("medium-slice", 30.0, 16), ("v3-slice", 30.0, 16),
+                        ("micro.en", 41.0, 0), ("micro", 30.0, 0)):
     node = host.SpeechToText(lib); node.set_language_model(synth.make_model(shape, seed=4242))
-    if shape in ("micro", "small"): node.language = "de"
+    if not shape.endswith(".en"): node.language = "de"
     res = []
     for rep in range(6):                               # enough steps for the graphs to be captured (> 64 per form) and replayed
         p = node.full_params("", 0); p.max_tokens = mt; p.temperature_inc = 0.0
