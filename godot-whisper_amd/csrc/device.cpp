@@ -782,7 +782,12 @@ static unsigned g_step_mask = ~0u;
 // chained: the step starts from what the previous step's pick kernel prepared on the device (token, position, cache head, activation
 // row): no embedding launch; the host's record (filter flags, sequence number) reaches the device through the extra workgroup of
 // the last mlp.2 launch.
-static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = false, bool chained = false) {
+static std::atomic<int> g_busy_transcriptions{0};
+BusyScope::BusyScope() { g_busy_transcriptions.fetch_add(1, std::memory_order_relaxed); }
+BusyScope::~BusyScope() { g_busy_transcriptions.fetch_sub(1, std::memory_order_relaxed); }
+int busy_transcriptions() { return g_busy_transcriptions.load(std::memory_order_relaxed); }
+
+static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = false, bool chained = false, bool solo = true) {
     if (ctx.model.quantised) { enqueue_greedy_step_q(ctx, Tc); return; }
     State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
     KVCache & kv = st.kv_self;
@@ -842,7 +847,7 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = fa
         // both MLP projections as ONE launch with an in-launch hand-off of the hidden row (k::mlp_pair; WMI_NO_MLP_PAIR=1: two launches)
         const bool no_pair = getenv("WMI_NO_MLP_PAIR") != nullptr;                     // (read per enqueue: the step probe A/Bs both forms inside one process)
         bool paired = false;
-        if ((M & 32) && (M & 64) && !no_pair && d.mlp_hand && (Lt & 1) == 0) {      // (the launches' parity must alternate across steps too)
+        if ((M & 32) && (M & 64) && !no_pair && solo && d.mlp_hand && (Lt & 1) == 0) {      // (the launches' parity must alternate across steps too)
             k::MlpPairArgs p{};
             p.x = d.dx; p.ln_g = l.ln3_g; p.ln_b = l.ln3_b; p.eps = hp.eps; p.S = S; p.W1 = l.w_fc1; p.b1 = l.b_fc1; p.W2 = l.w_fc2; p.b2 = l.b_fc2;
             p.epoch = (uint32_t *) d.mlp_arrive; p.par = il & 1; p.hand = d.mlp_hand;
@@ -914,7 +919,10 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
     const bool chained = !no_chain && !ctx.model.quantised && d.chain_valid && token == d.chain_token && pos == d.chain_pos &&
                          (int) kv.head == d.chain_head;
     d.chain_valid = false;
-    DeviceState::StepGraph & sg = d.step_graphs[(long_kv ? 1 : 0) | (chained ? 2 : 0)];
+    // alone on the GPU as far as this process knows: the forms with kernels that wait inside a launch (k::mlp_pair); otherwise the plain chain
+    // (both are bit-identical, so a transcription may change form from one step to the next)
+    const bool solo = busy_transcriptions() <= 1;
+    DeviceState::StepGraph & sg = d.step_graphs[(long_kv ? 1 : 0) | (chained ? 2 : 0) | (solo ? 0 : 4)];
     hipGraph_t & graph = sg.graph; hipGraphExec_t & exec = sg.exec; int & graph_T = sg.T;
     if (use_graph && exec && graph_T != Tc) {                           // encoder length changed: the captured step is stale
         (void) hipGraphExecDestroy(exec); (void) hipGraphDestroy(graph);
@@ -935,11 +943,11 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
         // (not for the chained form: a step's pick kernel advances the device-side record, so the step must not run twice — and its
         // kernels are the plain form's, which has run many times by now)
         if (!chained) {
-            enqueue_greedy_step(ctx, Tc, long_kv, false);
+            enqueue_greedy_step(ctx, Tc, long_kv, false, solo);
             HIP_TRY(hipStreamSynchronize(s));
         }
         if (HIP_OK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal))) {
-            enqueue_greedy_step(ctx, Tc, long_kv, chained);
+            enqueue_greedy_step(ctx, Tc, long_kv, chained, solo);
             hipGraph_t g = nullptr;
             const bool ended = HIP_OK(hipStreamEndCapture(s, &g));
             if (ended && g && HIP_OK(hipGraphInstantiate(&exec, g, nullptr, nullptr, 0))) {
@@ -958,7 +966,7 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
     if (use_graph && exec) {
         HIP_TRY(hipGraphLaunch(exec, s));
     } else {
-        enqueue_greedy_step(ctx, Tc, long_kv, chained);
+        enqueue_greedy_step(ctx, Tc, long_kv, chained, solo);
     }
     const k::SampleOut * r = (const k::SampleOut *) d.sample_host;
     if (!wait_for_sample(r, d.step_seq, s)) return false;

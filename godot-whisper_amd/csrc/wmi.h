@@ -237,7 +237,7 @@ struct DeviceState {
     // one-row step, one MLP per launch (k::mlp_pair): the hidden row's granules and the launch counter the tags are derived from
     void * mlp_hand = nullptr; unsigned long long * mlp_arrive = nullptr;
     struct StepGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int T = -1; int seen = 0; };
-    StepGraph step_graphs[4];
+    StepGraph step_graphs[8];                               // + 4: the forms without kernels that wait inside a launch (several transcriptions in flight)
     bool chain_valid = false; int32_t chain_token = 0, chain_pos = 0, chain_head = 0;
     int32_t step_seq = 0;                                             // sequence number of the last greedy step launched
     // device-side draws (beam search, t > 0): decode() leaves the logits rows in d.logits, sample_rows_device() draws from them
@@ -391,6 +391,11 @@ void pool_run(int n_tasks, const std::function<void(int)> & fn);
 double bench_greedy_step_chain(whisper_context & ctx, int iters);
 double bench_rows_step_chain(whisper_context & ctx, int nb, int iters);
 int    step_stamps(whisper_context & ctx, double * out, int cap, bool chained);
+// transcriptions in flight in this process (full()): kernels whose workgroups wait for each other INSIDE a launch (k::mlp_pair) are only
+// used while there is one — beside other contexts' launch chains their workgroups become resident at different times and the early ones
+// spin (measured: six contexts at once 7.4 ms per transcription against 4.5 with the two-launch form, profiles/r05g_*)
+struct BusyScope { BusyScope(); ~BusyScope(); };
+int busy_transcriptions();
 // |x| envelope of the last PCM on the GPU; the D2H copy runs on a side stream while the encoder works.
 // sync = false: state.energy is valid only after signal_energy_wait()
 bool signal_energy_device(whisper_context & ctx, int hw, bool sync = true, int via_dma = 0);   // via_dma 1: kernel -> device buffer -> hipMemcpyAsync; 2: kernel -> device buffer now, signal_energy_flush() later
