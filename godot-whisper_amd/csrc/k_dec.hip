@@ -1798,7 +1798,9 @@ int gemv_fused_parts(const GemvArgs & a) {
 // (see `epoch` in the kernel).  Measured and dropped: tags from a device-scope counter — bumped when a workgroup leaves it kept the launch
 // open ~1.2 us past its last store; as a ticket per wavefront at the start, 512 same-address atomics took ~6 us and the row's loads
 // retire behind them.
-// All workgroups are resident at once (S / 4 <= 128 workgroups on 256 CUs): the spin cannot starve a producer.
+// All workgroups are resident at once (checked against the runtime's occupancy in mlp_pair()): the spin cannot starve a producer.  The caller
+// uses this kernel only while its transcription is alone in the process (device.cpp: BusyScope): beside other contexts' launches the
+// workgroups start at different times and the early ones poll (profiles/r05g_* §9).
 // NCH1 / NCH2: 512-column chunks of a row of W1 (S columns) / of W2 (4 S columns): (1, 3) tiny, (1, 4) base, (2, 6) small, (2, 8) medium, (3, 10) large
 template <int NCH1, int NCH2, int WPB>
 __global__ __launch_bounds__(64 * WPB) void k_mlp_pair(const MlpPairArgs a, float * __restrict__ xio, int G, const Stamp sp) {
