@@ -782,10 +782,10 @@ static unsigned g_step_mask = ~0u;
 // chained: the step starts from what the previous step's pick kernel prepared on the device (token, position, cache head, activation
 // row): no embedding launch; the host's record (filter flags, sequence number) reaches the device through the extra workgroup of
 // the last mlp.2 launch.
-static std::atomic<int> g_busy_transcriptions{0};
-BusyScope::BusyScope() { g_busy_transcriptions.fetch_add(1, std::memory_order_relaxed); }
-BusyScope::~BusyScope() { g_busy_transcriptions.fetch_sub(1, std::memory_order_relaxed); }
-int busy_transcriptions() { return g_busy_transcriptions.load(std::memory_order_relaxed); }
+static std::atomic<int> g_busy_transcriptions[64];
+BusyScope::BusyScope(int device) : dev(device & 63) { g_busy_transcriptions[dev].fetch_add(1, std::memory_order_relaxed); }
+BusyScope::~BusyScope() { g_busy_transcriptions[dev].fetch_sub(1, std::memory_order_relaxed); }
+int busy_transcriptions(int device) { return g_busy_transcriptions[device & 63].load(std::memory_order_relaxed); }
 
 static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = false, bool chained = false, bool solo = true) {
     if (ctx.model.quantised) { enqueue_greedy_step_q(ctx, Tc); return; }
@@ -921,7 +921,7 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
     d.chain_valid = false;
     // alone on the GPU as far as this process knows: the forms with kernels that wait inside a launch (k::mlp_pair); otherwise the plain chain
     // (both are bit-identical, so a transcription may change form from one step to the next)
-    const bool solo = busy_transcriptions() <= 1;
+    const bool solo = busy_transcriptions(ctx.device) <= 1;
     DeviceState::StepGraph & sg = d.step_graphs[(long_kv ? 1 : 0) | (chained ? 2 : 0) | (solo ? 0 : 4)];
     hipGraph_t & graph = sg.graph; hipGraphExec_t & exec = sg.exec; int & graph_T = sg.T;
     if (use_graph && exec && graph_T != Tc) {                           // encoder length changed: the captured step is stale

@@ -61,7 +61,7 @@ void emit_segment(whisper_context & ctx, State & st, const whisper_full_params &
 } // namespace
 
 int full(whisper_context & ctx, whisper_full_params params, const float * samples, const float * d_samples, int n_samples) {
-    BusyScope busy;                                         // (see wmi.h: kernels that wait inside a launch are used by a lone transcription only)
+    BusyScope busy(ctx.device);                                      // (see wmi.h: kernels that wait inside a launch are used by a lone transcription only)
     State & st = *ctx.state;
     static const bool dbg_t = getenv("WMI_DEBUG_TIMING") != nullptr;
     const int64_t T0 = time_us(); int64_t T_mel = 0, T_energy = 0, T_emit = 0;

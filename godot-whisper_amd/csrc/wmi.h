@@ -391,11 +391,11 @@ void pool_run(int n_tasks, const std::function<void(int)> & fn);
 double bench_greedy_step_chain(whisper_context & ctx, int iters);
 double bench_rows_step_chain(whisper_context & ctx, int nb, int iters);
 int    step_stamps(whisper_context & ctx, double * out, int cap, bool chained);
-// transcriptions in flight in this process (full()): kernels whose workgroups wait for each other INSIDE a launch (k::mlp_pair) are only
+// transcriptions in flight in this process on one device (full()): kernels whose workgroups wait for each other INSIDE a launch (k::mlp_pair) are only
 // used while there is one — beside other contexts' launch chains their workgroups become resident at different times and the early ones
 // spin (measured: six contexts at once 7.4 ms per transcription against 4.5 with the two-launch form, profiles/r05g_*)
-struct BusyScope { BusyScope(); ~BusyScope(); };
-int busy_transcriptions();
+struct BusyScope { int dev; explicit BusyScope(int device); ~BusyScope(); };      // (counted per device: an in-process pool runs one context per GPU)
+int busy_transcriptions(int device);
 // |x| envelope of the last PCM on the GPU; the D2H copy runs on a side stream while the encoder works.
 // sync = false: state.energy is valid only after signal_energy_wait()
 bool signal_energy_device(whisper_context & ctx, int hw, bool sync = true, int via_dma = 0);   // via_dma 1: kernel -> device buffer -> hipMemcpyAsync; 2: kernel -> device buffer now, signal_energy_flush() later
