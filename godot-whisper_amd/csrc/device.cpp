@@ -12,6 +12,7 @@
 
 #include "wmi.h"
 #include <atomic>
+#include <thread>
 #include <map>
 #include <mutex>
 #include "kernels.h"
@@ -787,6 +788,24 @@ BusyScope::BusyScope(int device) : dev(device & 63) { g_busy_transcriptions[dev]
 BusyScope::~BusyScope() { g_busy_transcriptions[dev].fetch_sub(1, std::memory_order_relaxed); }
 int busy_transcriptions(int device) { return g_busy_transcriptions[device & 63].load(std::memory_order_relaxed); }
 
+// per-device turn for a greedy step (see decode_greedy_step).  A plain mutex, not a fair ticket: whoever gets the device next is as good as
+// anyone for throughput, and a fair ticket's next holder may be a descheduled thread (six contexts on the ticket: 10.5 ms per transcription
+// against 4.9 without any turn-taking; 2 - 3 contexts: 4.6 against 10 - 12).  A short spin first: the holder is ~150 us from releasing.
+namespace {
+std::mutex g_step_turn[64];
+struct StepTicket {
+    std::mutex * mu = nullptr;
+    StepTicket(int device, bool take) {
+        if (!take) return;
+        std::mutex & m = g_step_turn[device & 63];
+        for (int it = 0; it < 2000; ++it) { if (m.try_lock()) { mu = &m; return; } __builtin_ia32_pause(); }
+        m.lock(); mu = &m;
+    }
+    void release() { if (mu) { mu->unlock(); mu = nullptr; } }
+    ~StepTicket() { release(); }
+};
+}
+
 static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = false, bool chained = false, bool solo = true) {
     if (ctx.model.quantised) { enqueue_greedy_step_q(ctx, Tc); return; }
     State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
@@ -963,6 +982,13 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
         } else d.step_capture_failed = true;
     }
     hs->seq = ++d.step_seq;
+    // Several greedy transcriptions at once on one device: their dependent launch chains do not overlap usefully — a step leaves no idle GPU
+    // time to fill, and interleaved chains stretch every launch boundary (two contexts: 9.3 ms per transcription against 3.5 alone,
+    // profiles/r05g_* §9).  A step therefore owns the device from its launch to its sample whenever another transcription is in flight: a
+    // turn per device (a mutex), held ~150 us; alone, nothing is taken.  (WMI_NO_STEP_TICKET=1: off.  The general decode() path — beam search,
+    // t > 0 — has host work between its steps and gains from running side by side: replica contexts, no ticket.)
+    static const bool no_ticket = getenv("WMI_NO_STEP_TICKET") != nullptr;
+    StepTicket ticket(ctx.device, !no_ticket && !solo);
     if (use_graph && exec) {
         HIP_TRY(hipGraphLaunch(exec, s));
     } else {
@@ -970,6 +996,7 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
     }
     const k::SampleOut * r = (const k::SampleOut *) d.sample_host;
     if (!wait_for_sample(r, d.step_seq, s)) return false;
+    ticket.release();
     // what the pick kernel has left on the device for the next step
     d.chain_valid = !ctx.model.quantised && pos + 1 < hp.n_text_ctx && hp.n_text_state <= 1536;      // (k_filter_pick prepares rows of <= 3 x 512 columns)
     d.chain_token = r->id; d.chain_pos = pos + 1; d.chain_head = (int32_t) kv.head + 1;
