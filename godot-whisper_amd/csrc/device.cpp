@@ -183,6 +183,7 @@ void destroy_state(State * st) {
     dfree(st->kv_self.k); dfree(st->kv_self.v); dfree(d.kvc_k); dfree(d.kvc_v);
     if (d.copy_stream) { (void) hipStreamSynchronize(d.copy_stream); (void) hipStreamDestroy(d.copy_stream); }
     if (d.energy_ev) (void) hipEventDestroy(d.energy_ev);
+    for (hipEvent_t & e : d.ph_ev) { if (e) (void) hipEventDestroy(e); e = nullptr; }
     if (d.mel_ev) { (void) hipEventDestroy(d.mel_ev); d.mel_ev = nullptr; }       // (the state of a lock-step call's primary: pcm_to_mel_batch)
     dfree(d.energy); if (d.energy_host) (void) hipHostFree(d.energy_host);
     if (d.ts_host) (void) hipHostFree(d.ts_host);
@@ -214,7 +215,21 @@ static bool ensure_mel_capacity(DeviceState & d, size_t n_pad, size_t n_mel_elem
     return true;
 }
 
-bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, bool samples_on_device, bool sync) {
+static bool phase_events(DeviceState & d) {
+    for (hipEvent_t & e : d.ph_ev) if (!e && !HIP_OK(hipEventCreate(&e))) return false;
+    return true;
+}
+int64_t phase_settle(State & st, bool wait) {
+    DeviceState & d = st.dev;
+    if (!d.ph_mel && !d.ph_enc) return 0;
+    if (wait) (void) hipStreamSynchronize(d.stream);
+    float ms = 0.0f; double gpu_us = 0.0;
+    if (d.ph_mel) { if (hipEventSynchronize(d.ph_ev[1]) == hipSuccess && hipEventElapsedTime(&ms, d.ph_ev[0], d.ph_ev[1]) == hipSuccess) { st.t_mel_us += (int64_t) (ms * 1e3); gpu_us += ms * 1e3; } d.ph_mel = false; }
+    if (d.ph_enc) { if (hipEventSynchronize(d.ph_ev[3]) == hipSuccess && hipEventElapsedTime(&ms, d.ph_ev[2], d.ph_ev[3]) == hipSuccess) { st.t_encode_us += (int64_t) (ms * 1e3); gpu_us += ms * 1e3; } d.ph_enc = false; }
+    return d.ph_host0 + (int64_t) gpu_us;
+}
+
+bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, bool samples_on_device, bool sync, bool defer) {
     if (!compute_ready(ctx, __func__)) return false;
     State & st = *ctx.state; DeviceState & d = st.dev;
     const int64_t t0 = time_us();
@@ -227,6 +242,8 @@ bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, boo
     const int n_valid = n_samples + 200;
     const int n_fft_frames = std::min(n_valid / 160 + 1, n_len);
     if (!ensure_mel_capacity(d, (size_t) n_pad + (size_t) n_samples, (size_t) n_mel * n_len)) return false;
+    defer = defer && ms == d.stream && phase_events(d);
+    if (defer) { (void) phase_settle(st, true); HIP_TRY(hipEventRecord(d.ph_ev[0], ms)); }
     const float * src = samples;
     if (!samples_on_device) {                      // stage the borrowed host PCM behind the padded image
         float * stage = d.pcm + n_pad;
@@ -237,8 +254,9 @@ bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, boo
     k::mel_pad(src, n_samples, d.pcm, (int) n_pad, ms, (int *) d.mel_max);
     k::mel_frames(d.pcm, n_valid, n_fft_frames, n_len, n_mel, ctx.w.mel_filters, ctx.w.mel_ranges, ctx.w.mel_taps, d.mel, (int *) d.mel_max, ms);
     k::mel_normalize(d.mel, n_mel * n_len, (const int *) d.mel_max, ms);
-    if (sync) HIP_TRY(hipStreamSynchronize(ms));          // lock-step chunks: one sync for all chunks (batch.cpp)
     st.mel.n_len = n_len; st.mel.n_len_org = n_len_org; st.mel.n_mel = n_mel;
+    if (defer) { HIP_TRY(hipEventRecord(d.ph_ev[1], ms)); d.ph_mel = true; d.ph_host0 = t0; return true; }
+    if (sync) HIP_TRY(hipStreamSynchronize(ms));          // lock-step chunks: one sync for all chunks (batch.cpp)
     st.t_mel_us += time_us() - t0;
     return true;
 }
@@ -423,11 +441,17 @@ bool set_mel(whisper_context & ctx, const float * data, int n_len, int n_mel) {
 }
 
 // ------------------------------------------------------------------------------------------------ encoder
-bool encode(whisper_context & ctx, int mel_offset) {
+bool encode(whisper_context & ctx, int mel_offset, bool defer) {
     if (!compute_ready(ctx, __func__)) return false;
     State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
     const int64_t t0 = time_us();
     d.chain_valid = false;
+    defer = defer && !ctx.model.quantised && phase_events(d);
+    if (defer) {
+        if (d.ph_enc) (void) phase_settle(st, true);        // (an encoder pass whose decoder never ran)
+        HIP_TRY(hipEventRecord(d.ph_ev[2], d.stream));
+        if (!d.ph_mel) d.ph_host0 = t0;
+    }
     const int T = st.exp_n_audio_ctx > 0 ? st.exp_n_audio_ctx : hp.n_audio_ctx;
     const int S = hp.n_audio_state, H = hp.n_audio_head, La = hp.n_audio_layer, Lt = hp.n_text_layer, nm = hp.n_mels;
     hipStream_t s = d.stream;
@@ -495,11 +519,20 @@ bool encode(whisper_context & ctx, int mel_offset) {
         k::gemm(k::EPI_CROSS_KV, a, s);
     }
     }
+    st.enc_n_ctx = T;
+    st.n_encode++;
+    if (defer) {                                            // no host wait: the caller's next launches queue up behind the encoder
+        HIP_TRY(hipEventRecord(d.ph_ev[3], s)); d.ph_enc = true;
+        return HIP_OK(hipGetLastError());
+    }
     HIP_TRY(hipStreamSynchronize(s));
     if (!HIP_OK(hipGetLastError())) return false;
-    st.enc_n_ctx = T;
-    st.t_encode_us += time_us() - t0;
-    st.n_encode++;
+    {
+        int64_t dt = time_us() - t0;
+        const int64_t done = phase_settle(st, false);       // a deferred log-mel in front of this pass: its GPU time is not the encoder's
+        if (done > t0) dt = std::max<int64_t>(0, dt - (done - t0));
+        st.t_encode_us += dt;
+    }
     return true;
 }
 
@@ -570,7 +603,8 @@ bool decode(whisper_context & ctx, const Batch & batch) {
         if (trace) (void) hipEventRecord(tr1, s);
         HIP_TRY(hipStreamSynchronize(s));
         if (!HIP_OK(hipGetLastError())) return false;
-        const int64_t dtq = time_us() - t0;
+        int64_t dtq = time_us() - t0;
+        { const int64_t done = phase_settle(st, false); if (done > t0) dtq = std::max<int64_t>(0, dtq - (done - t0)); }
         if (trace) {
             static int64_t t_prev_end = 0;
             float ms = 0.f; (void) hipEventElapsedTime(&ms, tr0, tr1);
@@ -649,7 +683,8 @@ bool decode(whisper_context & ctx, const Batch & batch) {
     HIP_TRY(hipStreamSynchronize(s));
     if (!HIP_OK(hipGetLastError())) return false;
 
-    const int64_t dt = time_us() - t0;                            // timing buckets, W/whisper.cpp:2583-2592
+    int64_t dt = time_us() - t0;                                  // timing buckets, W/whisper.cpp:2583-2592
+    { const int64_t done = phase_settle(st, false); if (done > t0) dt = std::max<int64_t>(0, dt - (done - t0)); }      // (the part of this call spent waiting for a deferred log-mel / encoder)
     if (n == 1)      { st.t_decode_us += dt; st.n_decode++; }
     else if (n < 16) { st.t_batchd_us += dt; st.n_batchd += n; }
     else             { st.t_prompt_us += dt; st.n_prompt += n; }
@@ -1003,7 +1038,12 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
     if (getenv("WMI_DEBUG_SYNC")) fprintf(stderr, "[wmi] step token=%d pos=%d n_kv=%d head=%d flags=%d floor=%d init=%d -> id=%d tid=%d p=%g plog=%g pt=%g ptsum=%g\n",
         token, pos, hs->n_kv, hs->kv_head, hs->flags, hs->ts_floor_end, hs->ts_initial_start, r->id, r->tid, r->p, r->plog, r->pt, r->ptsum);
     out = whisper_token_data{ r->id, r->tid, r->p, r->plog, r->pt, r->ptsum, -1, -1, 0.0f };
-    st.t_decode_us += time_us() - t0; st.n_decode++; st.n_sample++;
+    {
+        int64_t dt = time_us() - t0;
+        const int64_t done = phase_settle(st, false);       // the stream is idle: the step's sample has arrived
+        if (done > t0) dt = std::max<int64_t>(0, dt - (done - t0));
+        st.t_decode_us += dt; st.n_decode++; st.n_sample++;
+    }
     return true;
 }
 

@@ -76,10 +76,13 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
     st.ts_failed = false;
     // the envelope kernel reads the caller's samples on a side stream: never return while it is in flight
     struct EnvelopeGuard { State & st; ~EnvelopeGuard() { (void) signal_energy_wait(st); } } envelope_guard{st};
+    static const bool defer_phases = getenv("WMI_PHASE_SYNC") == nullptr;
+    struct PhaseGuard { State & st; ~PhaseGuard() { (void) phase_settle(st, true); } } phase_guard{st};      // (a call that ends before any decode step)
 
     if (n_samples > 0) {
         if (params.speed_up) { WMI_ERR("%s: failed to compute log mel spectrogram\n", __func__); return -1; }
-        const bool ok_mel = d_samples ? pcm_to_mel(ctx, d_samples, n_samples, true) : pcm_to_mel(ctx, samples, n_samples, false);
+        // (no host wait behind the log-mel and the encoder: the next phase's launches queue up behind them; WMI_PHASE_SYNC=1: wait as before)
+        const bool ok_mel = d_samples ? pcm_to_mel(ctx, d_samples, n_samples, true, true, defer_phases) : pcm_to_mel(ctx, samples, n_samples, false, true, defer_phases);
         if (!ok_mel) { WMI_ERR("%s: failed to compute log mel spectrogram\n", __func__); return -2; }
         T_mel = time_us() - T0;
     }
@@ -175,7 +178,7 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
             WMI_ERR("%s: encoder_begin_callback returned false - aborting\n", __func__);
             break;
         }
-        if (!encode(ctx, seek) || (params.abort_callback && params.abort_callback(params.abort_callback_user_data))) {
+        if (!encode(ctx, seek, defer_phases) || (params.abort_callback && params.abort_callback(params.abort_callback_user_data))) {
             WMI_ERR("%s: failed to encode\n", __func__);
             return -6;
         }

@@ -190,6 +190,9 @@ struct DeviceState {
     float * energy_host = nullptr;                            // pinned mirror
     size_t  energy_dev_cap = 0;                               // floats allocated at `energy` (envelope + block extrema; the copy-engine form)
     hipStream_t copy_stream = nullptr; hipEvent_t energy_ev = nullptr;   // envelope D2H overlaps the encoder
+    // full(): the log-mel and the encoder are enqueued without a host wait behind them (the decoder's first step goes out while they
+    // run); their timers are settled from these events at the next point where the stream is known to be idle (phase_settle)
+    hipEvent_t ph_ev[4] = {nullptr, nullptr, nullptr, nullptr}; bool ph_mel = false, ph_enc = false; int64_t ph_host0 = 0;
     hipStream_t energy_wait_stream = nullptr;                 // lock-step calls: the stream of the batched envelope launch that wrote this state's envelope (not owned)
     hipStream_t mel_stream = nullptr;  hipEvent_t mel_ev = nullptr;      // lock-step chunks: the mel kernels of the chunks overlap
     bool    energy_pending = false;                            // copy in flight: signal_energy_wait() before reading state.energy
@@ -349,14 +352,18 @@ State * create_state(whisper_context & ctx);      // a further state for the sam
 void destroy_state(State * st);
 
 // hot path (device)
-bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, bool samples_on_device, bool sync = true);
+// defer (full()): no host wait behind the launches, the time goes to t_mel_us / t_encode_us when the events are settled
+bool pcm_to_mel(whisper_context & ctx, const float * samples, int n_samples, bool samples_on_device, bool sync = true, bool defer = false);
+// the GPU time of the deferred phases into the state's timers; returns the host time (time_us) at which they were complete on the GPU as far
+// as the events tell (0: nothing was pending).  wait: synchronise the stream first (else the caller knows it is idle)
+int64_t phase_settle(State & st, bool wait);
 // lock-step chunks: log-mel of several states' chunks by ONE launch per kernel on the context's stream (k::mel_batch), and — with
 // `envelopes` — their |x| envelopes into HBM by one more (the device-resident form the token timestamps of a lock-step call read).
 // Entries with n_samples <= 0 are skipped.  Per chunk the kernels' arithmetic is pcm_to_mel's / signal_energy_device's.
 bool pcm_to_mel_batch(whisper_context & ctx, const std::vector<State *> & states, const float * const * pcm, const int * n_samples,
                       bool samples_on_device, bool envelopes);
 bool set_mel(whisper_context & ctx, const float * data, int n_len, int n_mel);
-bool encode(whisper_context & ctx, int mel_offset);
+bool encode(whisper_context & ctx, int mel_offset, bool defer = false);
 // lock-step chunks (batch.cpp): rows[r] = lane whose mel feeds chunk row r, seek[r] = its mel frame offset
 bool encode_rows(whisper_context & ctx, const std::vector<int> & rows, const std::vector<int> & seek, int audio_ctx);
 bool decode(whisper_context & ctx, const Batch & batch);
