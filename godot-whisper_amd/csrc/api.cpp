@@ -827,10 +827,22 @@ int wmi_step_stamps(struct whisper_context * ctx, double * out, int cap, int cha
     try { return step_stamps(*ctx, out, cap, chained != 0); } catch (...) { return -1; }
 }
 
+void wmi_reload_knobs(void) { k::reload_knobs(); }
+
+int wmi_pair_status(struct whisper_context * ctx, int32_t * out3, int rearm) {
+    if (!ctx || !ctx->state) return -1;
+    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    DeviceState & d = ctx->state->dev;
+    if (out3) { out3[0] = d.pair_fallbacks; out3[1] = d.pair_slow_events; out3[2] = (d.pair_off ? 1 : 0) | (d.pair_backoff > 0 ? 2 : 0); }
+    if (rearm) { d.pair_off = false; d.pair_backoff = 0; }
+    return 0;
+}
+
 double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters) {
     if (!ctx || !ctx->state || iters < 1) return -1.0;
     std::lock_guard<std::recursive_mutex> lk(ctx->mu);      // the probes replay the context's kernels on its buffers: not beside a transcription
     (void) hipSetDevice(ctx->device);
+    if (which >= 20) k::reload_knobs();                     // (lab scripts flip the step's switches between probe calls of one process)
     State & st = *ctx->state; DeviceState & d = st.dev; const HParams & hp = ctx->model.hp; const Weights & w = ctx->w;
     const int S = hp.n_audio_state, T = hp.n_audio_ctx, H = hp.n_audio_head;
     hipStream_t s = d.stream;

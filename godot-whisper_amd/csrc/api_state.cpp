@@ -21,8 +21,8 @@ namespace {
 inline State * S(struct whisper_state * s) { return reinterpret_cast<State *>(s); }
 
 struct StateScope {
-    whisper_context * ctx; State * saved; std::unique_lock<std::recursive_mutex> lk;
-    StateScope(whisper_context * c, struct whisper_state * s) : ctx(c), lk(c->mu) {
+    whisper_context * ctx; State * saved; std::unique_lock<std::recursive_mutex> lk; BusyScope busy;      // (counted once the lock is held: a waiting caller is not on the GPU)
+    StateScope(whisper_context * c, struct whisper_state * s) : ctx(c), lk(c->mu), busy(c->device) {
         saved = c->state; c->state = S(s);
         if (!c->host_only) (void) hipSetDevice(c->device);
     }

@@ -535,6 +535,7 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
                bool on_device) {
     if (!compute_ready(ctx, __func__)) return -2;
     if (n_chunks <= 0) return 0;
+    BusyScope busy(ctx.device);                                    // (a lock-step call owns the GPU as much as a transcription does: wmi.h)
     const Vocab & v = ctx.model.vocab;
     const HParams & hp = ctx.model.hp;
     State * primary = ctx.state;

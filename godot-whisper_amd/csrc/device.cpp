@@ -736,19 +736,22 @@ bool upload_static_ban(whisper_context & ctx, const whisper_full_params & params
 // into pinned host memory behind its result (k_filter_pick); the host spins on it (~1 us instead of the 10-20 us of an
 // interrupt-driven hipStreamSynchronize, paid once per token).  Bounded: after ~2 s it falls back to a real
 // synchronisation and reports what the stream says.
-bool wait_for_sample(const k::SampleOut * r, int32_t want, hipStream_t s) {
+bool wait_for_sample(const k::SampleOut * r, int32_t want, hipStream_t s, int32_t * status) {
     // both halves of the record are written by one 16-byte store each and carry the step's number: a half whose tag matches
-    // is complete (x86 loads are not reordered with each other: tag first, then the fields)
+    // is complete (x86 loads are not reordered with each other: tag first, then the fields).  The tags' upper bits are the status of the
+    // step's in-launch hand-offs (k::SAMPLE_TAG_*), handed back through `status`.
     const volatile int32_t * t0 = &r->seq0, * t1 = &r->seq;
+    want &= k::SAMPLE_SEQ_MASK;
+    auto both = [&]() { const int32_t a = *t0, b = *t1; if ((a & k::SAMPLE_SEQ_MASK) != want || a != b) return false; if (status) *status = a & ~k::SAMPLE_SEQ_MASK; return true; };
     static const bool no_spin = getenv("WMI_NO_SPIN") != nullptr;          // debug / A-B
     if (!no_spin) {
         const int64_t tb = time_us();
         for (uint32_t it = 1;; ++it) {
-            if (*t0 == want && *t1 == want) {
+            if (both()) {
                 // the device writes each 16-byte half with one store that carries the tag; the caller reads the fields behind this
                 // return — re-read the tags behind a compiler barrier so that "tag, fields, tag" brackets what the caller copies
                 asm volatile("" ::: "memory");
-                if (*t0 == want && *t1 == want) return true;
+                if (both()) return true;
             }
             __builtin_ia32_pause();
             if ((it & 0xFFFF) == 0 && time_us() - tb > 2000000) break;
@@ -756,7 +759,7 @@ bool wait_for_sample(const k::SampleOut * r, int32_t want, hipStream_t s) {
     }
     if (!HIP_OK(hipStreamSynchronize(s))) return false;
     asm volatile("" ::: "memory");
-    return *t0 == want && *t1 == want;
+    return both();
 }
 
 // Draws on the device ("argmax / top-k on GPU so only ~k numbers cross PCIe per step").  The logits rows of the
@@ -819,8 +822,9 @@ static unsigned g_step_mask = ~0u;
 // row): no embedding launch; the host's record (filter flags, sequence number) reaches the device through the extra workgroup of
 // the last mlp.2 launch.
 static std::atomic<int> g_busy_transcriptions[64];
-BusyScope::BusyScope(int device) : dev(device & 63) { g_busy_transcriptions[dev].fetch_add(1, std::memory_order_relaxed); }
-BusyScope::~BusyScope() { g_busy_transcriptions[dev].fetch_sub(1, std::memory_order_relaxed); }
+static thread_local int t_busy_depth = 0;                 // a thread is counted once however its entry points nest (wmi_full_batch -> full(), *_with_state -> full())
+BusyScope::BusyScope(int device) : dev(device & 63), counted(t_busy_depth++ == 0) { if (counted) g_busy_transcriptions[dev].fetch_add(1, std::memory_order_relaxed); }
+BusyScope::~BusyScope() { --t_busy_depth; if (counted) g_busy_transcriptions[dev].fetch_sub(1, std::memory_order_relaxed); }
 int busy_transcriptions(int device) { return g_busy_transcriptions[device & 63].load(std::memory_order_relaxed); }
 
 // per-device turn for a greedy step (see decode_greedy_step).  A plain mutex, not a fair ticket: whoever gets the device next is as good as
@@ -841,6 +845,7 @@ struct StepTicket {
 };
 }
 
+constexpr int PAIR_FAULT_WORD = 4;           // d.mlp_arrive as 32-bit words: [0], [1] the launches' tags, [4] the hand-offs' status (k::MlpPairArgs::fault)
 static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = false, bool chained = false, bool solo = true) {
     if (ctx.model.quantised) { enqueue_greedy_step_q(ctx, Tc); return; }
     State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
@@ -867,6 +872,10 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = fa
         g.scale = scale; g.S = S; g.rows = nullptr; g.row_off = row_off;
         k::gemv(g, s);
     };
+    // the MLP form is decided once for the whole step: the paired launches' tags alternate between two words from launch to launch (an even
+    // number of layers keeps that up across steps), so either every layer pairs or none does
+    const k::Knobs & kn = k::knobs();
+    const bool paired = (M & 32) && (M & 64) && !kn.no_mlp_pair && solo && d.mlp_hand && (Lt & 1) == 0 && k::mlp_pair_usable(S, chained);
     for (int il = 0; il < Lt; ++il) {
         const DecLayerW & l = w.dec[il];
         __half * ck = kv.k + ((size_t) il * n_ctx) * S, * cv = kv.v + ((size_t) il * n_ctx) * S;
@@ -899,16 +908,15 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = fa
             if (M & 16) k::gemv(g, s);
         }
         // both MLP projections as ONE launch with an in-launch hand-off of the hidden row (k::mlp_pair; WMI_NO_MLP_PAIR=1: two launches)
-        const bool no_pair = getenv("WMI_NO_MLP_PAIR") != nullptr;                     // (read per enqueue: the step probe A/Bs both forms inside one process)
-        bool paired = false;
-        if ((M & 32) && (M & 64) && !no_pair && solo && d.mlp_hand && (Lt & 1) == 0) {      // (the launches' parity must alternate across steps too)
+        if (paired) {
             k::MlpPairArgs p{};
             p.x = d.dx; p.ln_g = l.ln3_g; p.ln_b = l.ln3_b; p.eps = hp.eps; p.S = S; p.W1 = l.w_fc1; p.b1 = l.b_fc1; p.W2 = l.w_fc2; p.b2 = l.b_fc2;
-            p.epoch = (uint32_t *) d.mlp_arrive; p.par = il & 1; p.hand = d.mlp_hand;
+            p.epoch = (uint32_t *) d.mlp_arrive; p.par = il & 1; p.hand = d.mlp_hand; p.fault = (uint32_t *) d.mlp_arrive + PAIR_FAULT_WORD;
+            p.spin_cap = kn.pair_spin_cap; p.withhold = kn.pair_withhold;
             if (chained && il == Lt - 1) { p.step_copy_src = d.step_host; p.step_copy_dst = d.step_dev; }
-            paired = k::mlp_pair(p, d.dx, s);
+            k::mlp_pair(p, d.dx, s);
+            continue;
         }
-        if (paired) continue;
         if (M & 32) gv(k::EPI_F16_BIAS_GELU, l.ln3_g, l.ln3_b, nullptr, S, 4 * S, l.w_fc1, l.b_fc1, d.dh, 4 * S, nullptr, nullptr, nullptr, 0.f, nullptr);
         if ((M & 64) && chained && il == Lt - 1) {             // + the workgroup that mirrors the host's step record (filter flags, seq)
             k::GemvArgs g{};
@@ -933,7 +941,7 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = fa
         chk("logits", Lt);
     }
     // the pick also prepares the next step on the device (token = pick, position / cache head + 1, x = te[pick] + pe[pos + 1])
-    const k::ChainNext cn{ (k::DecStep *) d.step_dev, w.d_te, w.d_pe, d.dx, S, hp.n_text_ctx };
+    const k::ChainNext cn{ (k::DecStep *) d.step_dev, w.d_te, w.d_pe, d.dx, S, hp.n_text_ctx, paired ? (const uint32_t *) d.mlp_arrive + PAIR_FAULT_WORD : nullptr };
     if (M & 256) k::filter_argmax(d.logits, d.ban_dev, stp, (k::SampleOut *) d.sample_dev, d.filter_scratch, s, (k::SampleOut *) d.sample_host, 1, &cn, fused_parts); chk("filter", Lt);
 }
 
@@ -975,7 +983,10 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
     d.chain_valid = false;
     // alone on the GPU as far as this process knows: the forms with kernels that wait inside a launch (k::mlp_pair); otherwise the plain chain
     // (both are bit-identical, so a transcription may change form from one step to the next)
-    const bool solo = busy_transcriptions(ctx.device) <= 1;
+    // d.pair_off: the in-launch hand-off has timed out once on this state (never again), or has been slow (not for a while: another PROCESS'
+    // work on the device is invisible to the count above — the kernel's own poll count is what tells)
+    if (d.pair_backoff > 0) --d.pair_backoff;
+    const bool solo = busy_transcriptions(ctx.device) <= 1 && !d.pair_off && d.pair_backoff == 0;
     DeviceState::StepGraph & sg = d.step_graphs[(long_kv ? 1 : 0) | (chained ? 2 : 0) | (solo ? 0 : 4)];
     hipGraph_t & graph = sg.graph; hipGraphExec_t & exec = sg.exec; int & graph_T = sg.T;
     if (use_graph && exec && graph_T != Tc) {                           // encoder length changed: the captured step is stale
@@ -1016,7 +1027,7 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
             }
         } else d.step_capture_failed = true;
     }
-    hs->seq = ++d.step_seq;
+    hs->seq = d.step_seq = (d.step_seq + 1) & k::SAMPLE_SEQ_MASK;
     // Several greedy transcriptions at once on one device: their dependent launch chains do not overlap usefully — a step leaves no idle GPU
     // time to fill, and interleaved chains stretch every launch boundary (two contexts: 9.3 ms per transcription against 3.5 alone,
     // profiles/r05g_* §9).  A step therefore owns the device from its launch to its sample whenever another transcription is in flight: a
@@ -1030,12 +1041,31 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
         enqueue_greedy_step(ctx, Tc, long_kv, chained, solo);
     }
     const k::SampleOut * r = (const k::SampleOut *) d.sample_host;
-    if (!wait_for_sample(r, d.step_seq, s)) return false;
+    int32_t status = 0;
+    if (!wait_for_sample(r, d.step_seq, s, &status)) return false;
+    if (status & k::SAMPLE_TAG_SLOW) {
+        // correct, but the launch's workgroups waited for each other for long: the device is shared with work this process does not
+        // count (another process, the embedder's own kernels) — two launches for the next steps, then try again
+        d.pair_backoff = 512; ++d.pair_slow_events;
+        (void) hipMemsetAsync((uint32_t *) d.mlp_arrive + PAIR_FAULT_WORD, 0, sizeof(uint32_t), s);
+    }
+    if (status & k::SAMPLE_TAG_FAULT) {
+        // a hand-off inside a k_mlp_pair launch did not complete (or its tags were out of step): this step's rows are not to be trusted.
+        // The step is run again from the host's record in the two-launch form — embedding launch, every cache cell and the device-side
+        // record rewritten — and the state keeps that form from here on.  (W/whisper.cpp:2517-2595: a decode either succeeds or reports.)
+        if (!d.pair_off) WMI_WARN("%s: in-launch hand-off of the MLP failed (status %#x) - step re-run, staying on the two-launch form\n", __func__, (unsigned) status);
+        d.pair_off = true; ++d.pair_fallbacks;
+        if (!HIP_OK(hipMemsetAsync((uint32_t *) d.mlp_arrive + PAIR_FAULT_WORD, 0, sizeof(uint32_t), s))) return false;
+        hs->seq = d.step_seq = (d.step_seq + 1) & k::SAMPLE_SEQ_MASK;
+        enqueue_greedy_step(ctx, Tc, long_kv, false, false);
+        status = 0;
+        if (!wait_for_sample(r, d.step_seq, s, &status) || (status & k::SAMPLE_TAG_FAULT)) { WMI_ERR("%s: the step's re-run failed\n", __func__); return false; }
+    }
     ticket.release();
     // what the pick kernel has left on the device for the next step
     d.chain_valid = !ctx.model.quantised && pos + 1 < hp.n_text_ctx && hp.n_text_state <= 1536;      // (k_filter_pick prepares rows of <= 3 x 512 columns)
     d.chain_token = r->id; d.chain_pos = pos + 1; d.chain_head = (int32_t) kv.head + 1;
-    if (getenv("WMI_DEBUG_SYNC")) fprintf(stderr, "[wmi] step token=%d pos=%d n_kv=%d head=%d flags=%d floor=%d init=%d -> id=%d tid=%d p=%g plog=%g pt=%g ptsum=%g\n",
+    if (k::knobs().debug_sync) fprintf(stderr, "[wmi] step token=%d pos=%d n_kv=%d head=%d flags=%d floor=%d init=%d -> id=%d tid=%d p=%g plog=%g pt=%g ptsum=%g\n",
         token, pos, hs->n_kv, hs->kv_head, hs->flags, hs->ts_floor_end, hs->ts_initial_start, r->id, r->tid, r->p, r->plog, r->pt, r->ptsum);
     out = whisper_token_data{ r->id, r->tid, r->p, r->plog, r->pt, r->ptsum, -1, -1, 0.0f };
     {

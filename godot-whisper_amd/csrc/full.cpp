@@ -221,7 +221,7 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
             // Beam search and t > 0 (whisper_sample_token_topk / whisper_sample_token(best = false)): the filters, the soft-max and the
             // CDF search of the draws run on the device as well (device.cpp: sample_rows_device) — the decoders' mt19937 generators stay
             // here and supply the uniform numbers.  User callbacks and grammars need the host arrays and keep the host path.
-            const bool no_dev_draw = getenv("WMI_HOST_DRAWS") != nullptr;             // debug / A-B and the tests (read per window)
+            const bool no_dev_draw = k::knobs().host_draws;                           // debug / A-B and the tests (wmi_reload_knobs after a change)
             const bool dev_draw = !fast && !no_dev_draw && fast_path_enabled() && (beam || t_cur > 0.0f) && n_cur <= MAX_DECODERS &&
                                   !params.logits_filter_callback && !params.grammar_rules && params.n_grammar_rules == 0 &&
                                   ctx.model.n_loaded > 0 && upload_static_ban(ctx, params);

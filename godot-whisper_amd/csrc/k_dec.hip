@@ -1268,7 +1268,7 @@ static bool launch_gemv1_special(const GemvArgs & a, int nch, hipStream_t st) {
     }
     // the wider f16 models (small / medium: two chunks of 512 columns, large: three) — round 5: the same lean instantiations as base.en's
     // (WMI_GEMV1_WIDE_GENERIC=1: the run-time-dispatch kernel, as before)
-    const bool wide_generic = getenv("WMI_GEMV1_WIDE_GENERIC") != nullptr;        // (read per enqueue: A/B inside one process)
+    const bool wide_generic = knobs().gemv1_wide_generic;
     if (!wide_generic && !a.lanes && (nch == 2 || nch == 3)) {
         if (pro == 1 && a.epi == EPI_QKV_DEC)       { if (nch == 2) launch_gemv1<4, 2, false, 1, EPI_QKV_DEC>(a, st); else launch_gemv1<4, 3, false, 1, EPI_QKV_DEC>(a, st); return true; }
         if (pro == 1 && a.epi == EPI_F16_BIAS_GELU) { if (nch == 2) launch_gemv1<4, 2, false, 1, EPI_F16_BIAS_GELU>(a, st); else launch_gemv1<4, 3, false, 1, EPI_F16_BIAS_GELU>(a, st); return true; }
@@ -1280,7 +1280,7 @@ static bool launch_gemv1_special(const GemvArgs & a, int nch, hipStream_t st) {
         if (nch == 1 && hpw == 1) { launch_gemv1<4, 1, false, 2, EPI_F32_BIAS_RESID, 1>(a, st); return true; }
         // eight heads (base): eight wavefronts with ONE head each and two weight rows per wavefront — the attention is a dependent chain of
         // ~1000 VALU instructions per head pair, i.e. most of this launch's body (row ready at +2.6 .. 2.9 us of 3.2); WMI_SA_WPB=4: the round-3 form
-        const int sa_wpb = getenv("WMI_SA_WPB") ? atoi(getenv("WMI_SA_WPB")) : 8;        // (read per enqueue: A/B inside one process)
+        const int sa_wpb = knobs().sa_wpb;
         if (nch == 1 && hpw == 2 && sa_wpb == 8 && a.K == 512 && !a.lanes) { launch_gemv1<2, 1, false, 2, EPI_F32_BIAS_RESID, 1, 8>(a, st); return true; }
         if (nch == 1 && hpw == 2) { launch_gemv1<4, 1, false, 2, EPI_F32_BIAS_RESID, 2>(a, st); return true; }
         if (nch == 2 && hpw == 3) { launch_gemv1<4, 2, false, 2, EPI_F32_BIAS_RESID, 3>(a, st); return true; }
@@ -1818,7 +1818,12 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_pair(const MlpPairArgs a, floa
     // THIS launch leaves epoch[par ^ 1] = tag for the next one.  No workgroup of a launch reads the word the launch writes, so a workgroup that
     // starts late sees the same value as the first one; nothing is ever reset, stale granules carry smaller tags.
     const uint32_t tag = a.epoch[a.par] + 1u;
-    if (blockIdx.x == 0 && tid == 0) a.epoch[a.par ^ 1] = tag;
+    if (blockIdx.x == 0 && tid == 0) {
+        // the other word holds tag - 2 (or 0 before the first launch) when the launches alternated; tag or more means this parity ran twice in
+        // a row — stale granules would pass the tag test below: say so (the step is run again by the host in the two-launch form)
+        if (a.epoch[a.par ^ 1] >= tag) __hip_atomic_fetch_or(a.fault, PAIR_FAULT_PARITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.epoch[a.par ^ 1] = tag;
+    }
     constexpr int RIF = 4, LPR = 16;
     const int wrow = lane / LPR; const bool writer = (lane % LPR) == 0;
     // ---- phase 1 loads: the row first (L2), gain / bias, then the weight rows of both phases (HBM / Infinity Cache)
@@ -1868,7 +1873,8 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_pair(const MlpPairArgs a, floa
         const __half hv = f2h(gelu16(v + bias1));
         const uint32_t mine = (uint32_t) __half_as_ushort(hv);
         const uint32_t other = (uint32_t) WMI_SHX((int) mine, 16);
-        if (writer && !(wrow & 1)) {
+        if (a.withhold < 0 && gw == -a.withhold - 1) for (int i = 0; i < 60; ++i) __builtin_amdgcn_s_sleep(127);      // tests: one late producer (~0.2 ms)
+        if (writer && !(wrow & 1) && gw + 1 != a.withhold) {
             const unsigned long long g = ((unsigned long long) tag << 32) | (unsigned long long) (mine | (other << 16));
             __hip_atomic_store((unsigned long long *) a.hand + (gw * 2 + (wrow >> 1)), g, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -1882,7 +1888,12 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_pair(const MlpPairArgs a, floa
         for (int b2 = 0; b2 < NL; ++b2) { const int g = b2 * 2 * NT + tid * 2; src[b2] = (const unsigned long long *) a.hand + (g < ngran ? g : 0); }      // (fewer granules than slots: re-read granule 0)
         // (two sweeps in flight, alternating, so that a sweep that leaves just before the granules land does not cost a whole round trip:
         //  measured slower — the hand-off 2.15 -> 2.6 us, the step +6 us: the polling traffic of 128 workgroups doubles)
-        for (uint32_t spins = 0; spins < (1u << 20); ++spins) {      // (bounded: ~1 s — a launch that could not make progress must not hang the queue; the step's results are then wrong and say so downstream)
+        // bounded (~1 s): a launch that cannot make progress must not hang the queue.  A consumer that gives up computes its rows from stale
+        // granules — and sets PAIR_FAULT_TIMEOUT in the step's status word, which the pick kernel hands to the host in the result's tags: the host
+        // runs the step again in the two-launch form (device.cpp: decode_greedy_step).  A sweep that needed many polls only sets PAIR_SLOW.
+        const uint32_t spin_cap = a.spin_cap ? a.spin_cap : (1u << 20);
+        uint32_t spins = 0; bool landed = false;
+        for (; spins < spin_cap; ++spins) {
             u32x4 q[NL];                                     // all requests in flight, one wait (the wait names the registers: nothing reads them before it)
 #pragma unroll
             for (int b2 = 0; b2 < NL; ++b2) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(q[b2]) : "v"(src[b2]) : "memory");
@@ -1898,8 +1909,10 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_pair(const MlpPairArgs a, floa
                 const int g = b2 * 2 * NT + tid * 2;
                 if (g < ngran) { ok = ok && q[b2][1] == tag && q[b2][3] == tag; hrow[g] = q[b2][0]; hrow[g + 1] = q[b2][2]; }
             }
-            if (__all(ok)) break;
+            if (__all(ok)) { landed = true; break; }
         }
+        if (lane == 0 && (!landed || spins > PAIR_SLOW_POLLS))      // (rare: nothing on the ordinary path but the two compares)
+            __hip_atomic_fetch_or(a.fault, landed ? PAIR_SLOW : PAIR_FAULT_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __syncthreads();
     }
     const unsigned long long tm2 = stamp_t0(sp.base);
@@ -1926,35 +1939,88 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_pair(const MlpPairArgs a, floa
     stamp_end(sp.base, sp.slot, gw, ts0, tm1, tm2);
 }
 
-bool mlp_pair(const MlpPairArgs & a, float * x_inout, hipStream_t st) {
-    const int S = a.S;
+// -- the A/B switches of the launch paths: one read of the environment per process (an embedding application may call setenv on its own threads)
+static Knobs read_knobs() {
+    Knobs kn{};
+    kn.no_mlp_pair = getenv("WMI_NO_MLP_PAIR") != nullptr;
+    kn.pair_wpb = getenv("WMI_PAIR_WPB") ? atoi(getenv("WMI_PAIR_WPB")) : 4;
+    kn.sa_wpb = getenv("WMI_SA_WPB") ? atoi(getenv("WMI_SA_WPB")) : 8;
+    kn.gemv1_wide_generic = getenv("WMI_GEMV1_WIDE_GENERIC") != nullptr;
+    kn.host_draws = getenv("WMI_HOST_DRAWS") != nullptr;
+    kn.debug_sync = getenv("WMI_DEBUG_SYNC") != nullptr;
+    kn.pair_withhold = getenv("WMI_PAIR_WITHHOLD") ? atoi(getenv("WMI_PAIR_WITHHOLD")) : 0;        // tests: see MlpPairArgs::withhold
+    kn.pair_spin_cap = getenv("WMI_PAIR_SPIN_CAP") ? (uint32_t) strtoul(getenv("WMI_PAIR_SPIN_CAP"), nullptr, 0) : 0u;
+    return kn;
+}
+static std::atomic<const Knobs *> g_knobs{nullptr};
+const Knobs & knobs() {
+    const Knobs * kn = g_knobs.load(std::memory_order_acquire);
+    if (kn) return *kn;
+    const Knobs * fresh = new Knobs(read_knobs());
+    const Knobs * expect = nullptr;
+    if (g_knobs.compare_exchange_strong(expect, fresh, std::memory_order_acq_rel)) return *fresh;
+    delete fresh;
+    return *expect;
+}
+void reload_knobs() { g_knobs.store(new Knobs(read_knobs()), std::memory_order_release); }      // (the old block is left in place: a reader may still hold it)
+
+// (S, 8-wavefront workgroups?) -> instantiation; the two functions below walk the same table
+#define WMI_PAIR_TABLE(S, w8, nch2, X) do { \
+        if (w8)             { if ((nch2) <= 3) X(1, 3, 8); else X(1, 4, 8); } \
+        else if ((S) <= 512) { if ((nch2) <= 3) X(1, 3, 4); else X(1, 4, 4); } \
+        else if ((S) <= 768) X(2, 6, 4); \
+        else                X(2, 8, 4); } while (0)
+
+template <int N1, int N2, int W>
+static int pair_fit() {
+    // workgroups of this instantiation that are resident at once, per device ordinal (an in-process pool holds a context per GPU, and a
+    // partitioned device has fewer CUs than the first one seen)
+    static std::atomic<int> cache[64];
+    int dev = 0;
+    (void) hipGetDevice(&dev);
+    std::atomic<int> & c = cache[dev & 63];
+    int fit = c.load(std::memory_order_relaxed);
+    if (fit > 0) return fit;
+    int nb = 0, ncu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *) k_mlp_pair<N1, N2, W>, 64 * W, 0) != hipSuccess) return 0;
+    (void) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+    // (the occupancy query over-reports by one workgroup per CU for SGPR-heavy kernels on this stack: one CU's worth of margin; the
+    //  launches here are at most S / 4 + 1 = 257 workgroups against thousands)
+    fit = nb > 1 ? (nb - 1) * ncu : nb * ncu;
+    c.store(fit, std::memory_order_relaxed);
+    return fit;
+}
+
+bool mlp_pair_usable(int S, bool with_mirror) {
     // measured, step chain on the GPU with the MLP as one launch / two launches (scratch/pair_ab.py, one process): tiny.en 111.7 / 115.5 us,
     // base.en 155.4 / 158.9, small 384.8 / 406.5 (-5.3 %), medium 873.8 / 890.3, large-v3 (f16) 1563 / 1541 — at S = 1280 the two 13 MB
     // matrices are a bandwidth matter and one row per wavefront streams them worse than the two-launch tiling: two launches there
-    if (S > 1024 || (S % 64) != 0 || !a.epoch || !a.hand) return false;
+    if (S > 1024 || (S % 64) != 0) return false;
+    const int wpb = knobs().pair_wpb;
+    const bool w8 = wpb == 8 && (S % 8) == 0 && S <= 512;
+    const int blocks = S / (w8 ? 8 : 4) + (with_mirror ? 1 : 0);
+    const int nch2 = (4 * S + 511) / 512;
+    int fit = 0;
+#define WMI_PAIR_FIT(N1, N2, W) fit = pair_fit<N1, N2, W>()
+    WMI_PAIR_TABLE(S, w8, nch2, WMI_PAIR_FIT);
+#undef WMI_PAIR_FIT
+    return blocks <= fit;
+}
+
+void mlp_pair(const MlpPairArgs & a, float * x_inout, hipStream_t st) {
+    const int S = a.S;
     // 4 S rows of W1, four per wavefront, 4-wavefront workgroups.  (WMI_PAIR_WPB=8: eight — half as many sweeping workgroups, one 16-byte
     // load per thread and sweep instead of two: measured SLOWER, step chain 157.5 against 155.4 us; two launches 158.9, same process)
-    const int wpb = getenv("WMI_PAIR_WPB") ? atoi(getenv("WMI_PAIR_WPB")) : 4;          // (read per enqueue: A/B inside one process)
-    const bool w8 = wpb == 8 && (S % 8) == 0 && S <= 512;
+    const bool w8 = knobs().pair_wpb == 8 && (S % 8) == 0 && S <= 512;
     const int G = S / (w8 ? 8 : 4);
     const int blocks = G + (a.step_copy_src ? 1 : 0);
     const int nch2 = (4 * S + 511) / 512;
-    // every workgroup of the launch must be resident at once (they wait for each other): checked once per instantiation against the
-    // occupancy the runtime reports — a shape that would not fit runs as two launches
-#define WMI_PAIR(N1, N2, W) do { \
-        static const int fit = [] { int nb = 0, dev = 0, ncu = 0; \
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *) k_mlp_pair<N1, N2, W>, 64 * W, 0) != hipSuccess) return 0; \
-            (void) hipGetDevice(&dev); (void) hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev); return nb * ncu; }(); \
-        if (blocks > fit) return false; \
-        const Stamp sp = stamp_next(); \
-        hipLaunchKernelGGL((k_mlp_pair<N1, N2, W>), dim3(blocks), dim3(64 * W), 0, st, a, x_inout, G, sp); } while (0)
-    if (w8) { if (nch2 <= 3) WMI_PAIR(1, 3, 8); else WMI_PAIR(1, 4, 8); }
-    else if (S <= 512)  { if (nch2 <= 3) WMI_PAIR(1, 3, 4); else WMI_PAIR(1, 4, 4); }
-    else if (S <= 768)  WMI_PAIR(2, 6, 4);
-    else                WMI_PAIR(2, 8, 4);
-#undef WMI_PAIR
-    return true;
+    const Stamp sp = stamp_next();
+#define WMI_PAIR_GO(N1, N2, W) hipLaunchKernelGGL((k_mlp_pair<N1, N2, W>), dim3(blocks), dim3(64 * W), 0, st, a, x_inout, G, sp)
+    WMI_PAIR_TABLE(S, w8, nch2, WMI_PAIR_GO);
+#undef WMI_PAIR_GO
 }
+#undef WMI_PAIR_TABLE
 
 void gemv(const GemvArgs & a, hipStream_t st) {
     const Stamp sp = stamp_next();

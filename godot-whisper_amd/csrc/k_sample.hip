@@ -122,7 +122,12 @@ __global__ __launch_bounds__(64) void k_filter_pick(const Partial * __restrict__
     // the step record and the partials are requested together (field by field at their first use, the record cost three more
     // dependent round trips on this one-wavefront kernel)
     const int4 st0 = *(const int4 *) stp;                  // token, pos, n_kv, kv_head
-    const int beg = stp->beg, seqv = stp->seq;
+    const int beg = stp->beg;
+    // status of the step's in-launch hand-offs (k_mlp_pair) rides in the tags the host polls: an unconditional load (of a zero pad word when
+    // there is no such word) requested with the record
+    const uint32_t * const fault_p = chain.fault ? chain.fault : (const uint32_t *) &stp->pad[0];
+    const uint32_t fault = *(const volatile uint32_t *) fault_p;
+    const int seqv = (stp->seq & SAMPLE_SEQ_MASK) | ((fault & (PAIR_FAULT_TIMEOUT | PAIR_FAULT_PARITY)) ? SAMPLE_TAG_FAULT : 0) | ((fault & PAIR_SLOW) ? SAMPLE_TAG_SLOW : 0);
     Partial pq[PPL];                                     // partials lane, lane + 64, ... (all requested before the first use)
 #pragma unroll
     for (int q = 0; q < PPL; ++q) { const int idx = lane + 64 * q; pq[q] = part[idx < nparts ? idx : 0]; }
@@ -320,7 +325,7 @@ void filter_argmax(const float * logits, const uint8_t * static_ban, const DecSt
     if (!fused) hipLaunchKernelGGL(k_filter_stats, dim3(NB, n_rows), dim3(NT), 0, st, logits, static_ban, step, part, stamp_next());
     ChainNext cn{};                                         // one row: the greedy step of device.cpp; rows: the lock-step step of batch.cpp
     if (chain) cn = *chain;
-    if (cn.step_rw && cn.S > 1536) cn = ChainNext{};          // (no such model: the row registers cover 3 chunks; the host then embeds)
+    if (cn.step_rw && cn.S > 1536) { const uint32_t * f = cn.fault; cn = ChainNext{}; cn.fault = f; }          // (no such model: the row registers cover 3 chunks; the host then embeds)
     const int xu = cn.step_rw ? (cn.S + 511) / 512 : 1;
     const int np = fused ? fused_parts : NB;
     constexpr int PF = FS_MAX_PARTS / 64;

@@ -306,10 +306,26 @@ struct MlpPairArgs {
     const float * x; const float * ln_g, * ln_b; float eps; int S;
     const __half * W1; const float * b1; const __half * W2; const float * b2;
     uint32_t * epoch; int par; void * hand;                    // epoch[2] (zeroed once), par = 0 / 1 alternating from launch to launch
+    // sticky status word of the hand-off (zeroed once, cleared by the host after it has acted): PAIR_FAULT_TIMEOUT a consumer gave up waiting
+    // (its rows of this launch are garbage), PAIR_FAULT_PARITY two launches in a row with the same `par` (stale granules pass the tag test),
+    // PAIR_SLOW a sweep needed more than PAIR_SLOW_POLLS polls (correct, but something else owns the GPU: the two-launch form is the faster one).
+    // The step's pick kernel reports the word in the sequence tags of SampleOut (ChainNext::fault), the host re-runs / switches form.
+    uint32_t * fault; uint32_t spin_cap;                       // spin_cap: polls before a consumer gives up (0 = 1 << 20, about a second)
+    int withhold;                                              // tests: wavefront `withhold - 1` never publishes its granules; < 0: wavefront `-withhold - 1` publishes ~0.2 ms late (0 = off)
     const void * step_copy_src; void * step_copy_dst;          // chained greedy steps: see GemvArgs::step_copy_src
     __half * h_out;                                            // optional plain copy of the hidden row (tests / debugging)
 };
-bool mlp_pair(const MlpPairArgs & a, float * x_inout, hipStream_t st);
+enum : uint32_t { PAIR_FAULT_TIMEOUT = 1u, PAIR_FAULT_PARITY = 2u, PAIR_SLOW = 4u };
+constexpr uint32_t PAIR_SLOW_POLLS = 64;
+// decided ONCE per step for all its layers (the launches' parity must alternate: a layer that alone fell back to two launches would break
+// it): shape covered, and the widest launch of the step (+ 1 workgroup with the step-record mirror) resident at once on the CURRENT device
+bool mlp_pair_usable(int S, bool with_mirror);
+void mlp_pair(const MlpPairArgs & a, float * x_inout, hipStream_t st);
+// A/B switches of the launch paths that are read from the environment: once per process (reload_knobs(): lab scripts that flip them between
+// probe calls of one process, exported as wmi_reload_knobs — not while a transcription runs on another thread)
+struct Knobs { bool no_mlp_pair; int pair_wpb; int sa_wpb; bool gemv1_wide_generic; bool host_draws; bool debug_sync; int pair_withhold; uint32_t pair_spin_cap; };
+const Knobs & knobs();
+void reload_knobs();
 void set_attn_one_group(bool on);              // encoder attention: never split the keys over two wave groups (bit-identical for any batch)
 bool rows_valu_enabled();
 void set_rows_valu(bool on);                  // lock-step rows: true = VALU kernel (bit-identical to the one-row path), false = MFMA
@@ -337,7 +353,10 @@ struct alignas(16) SampleOut { int32_t id, tid; float p; int32_t seq0; float plo
 // n_rows > 1: lock-step chunks — logits [n_rows][n_vocab], step[n_rows], out[n_rows]
 // chain (one row): the pick kernel also prepares the NEXT greedy step on the device — token = the pick, pos / n_kv / kv_head + 1 in
 // *step_rw, and the next activation row x = te[pick] + pe[pos + 1] — so that the next step needs no embedding launch
-struct ChainNext { DecStep * step_rw; const __half * te; const float * pe; float * x; int S; int n_pos; };
+struct ChainNext { DecStep * step_rw; const __half * te; const float * pe; float * x; int S; int n_pos;
+                   const uint32_t * fault; };             // MlpPairArgs::fault of the step's launches (nullptr: none): reported in the tags, see SAMPLE_TAG_*
+// SampleOut::seq0 / seq = the step's sequence number (SAMPLE_SEQ_MASK bits) | status of the step's in-launch hand-offs
+constexpr int32_t SAMPLE_SEQ_MASK = 0x0FFFFFFF, SAMPLE_TAG_FAULT = 0x40000000, SAMPLE_TAG_SLOW = 0x20000000;
 // fused_parts > 0 (one row): scratch already holds that many partials (GemvArgs::fs_part): only the pick kernel runs
 void filter_argmax(const float * logits, const uint8_t * static_ban, const DecStep * step, SampleOut * out, void * scratch, hipStream_t st,
                    SampleOut * out_host = nullptr, int n_rows = 1, const ChainNext * chain = nullptr, int fused_parts = 0);

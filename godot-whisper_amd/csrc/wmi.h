@@ -239,6 +239,8 @@ struct DeviceState {
     //           activation row on the device; valid while the host feeds exactly that token at that position
     // one-row step, one MLP per launch (k::mlp_pair): the hidden row's granules and the launch counter the tags are derived from
     void * mlp_hand = nullptr; unsigned long long * mlp_arrive = nullptr;
+    bool pair_off = false; int pair_backoff = 0;                      // the hand-off failed once (two launches from then on) / was slow (two launches for that many steps)
+    int  pair_fallbacks = 0, pair_slow_events = 0;                    // steps re-run in the two-launch form / slow hand-offs seen (wmi_pair_status)
     struct StepGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int T = -1; int seen = 0; };
     StepGraph step_graphs[8];                               // + 4: the forms without kernels that wait inside a launch (several transcriptions in flight)
     bool chain_valid = false; int32_t chain_token = 0, chain_pos = 0, chain_head = 0;
@@ -391,17 +393,19 @@ bool upload_static_ban(whisper_context & ctx, const whisper_full_params & params
 // u [n_rows][k] uniform numbers in [0, 1) from the decoders' generators.  out [n_rows][k].
 bool sample_rows_device(whisper_context & ctx, const StepFilter * f, const int * rows, int n_rows, float temperature, int k,
                         const double * u, int tid_default, whisper_token_data * out);
-bool wait_for_sample(const k::SampleOut * r, int32_t want, hipStream_t s);   // spin on a pinned, self-tagged result record (device.cpp)
+bool wait_for_sample(const k::SampleOut * r, int32_t want, hipStream_t s, int32_t * status = nullptr);   // spin on a pinned, self-tagged result record (device.cpp)
 bool fast_path_enabled();
 // host worker pool (pool.cpp): fn(0..n_tasks-1) on a few persistent threads + the caller; nested calls run inline
 void pool_run(int n_tasks, const std::function<void(int)> & fn);
 double bench_greedy_step_chain(whisper_context & ctx, int iters);
 double bench_rows_step_chain(whisper_context & ctx, int nb, int iters);
 int    step_stamps(whisper_context & ctx, double * out, int cap, bool chained);
-// transcriptions in flight in this process on one device (full()): kernels whose workgroups wait for each other INSIDE a launch (k::mlp_pair) are only
-// used while there is one — beside other contexts' launch chains their workgroups become resident at different times and the early ones
-// spin (measured: six contexts at once 7.4 ms per transcription against 4.5 with the two-launch form, profiles/r05g_*)
-struct BusyScope { int dev; explicit BusyScope(int device); ~BusyScope(); };      // (counted per device: an in-process pool runs one context per GPU)
+// device calls in flight in this process on one device (full(), wmi_full_batch, every *_with_state entry point — a thread counts once however
+// they nest): kernels whose workgroups wait for each other INSIDE a launch (k::mlp_pair) are only used while there is one — beside other
+// contexts' launch chains their workgroups become resident at different times and the early ones spin (measured: six contexts at once 7.4 ms
+// per transcription against 4.5 with the two-launch form, profiles/r05g_*).  Work this count cannot see (another process, the embedder's own
+// kernels) is caught by the kernel itself: a slow hand-off is reported and the step changes form (DeviceState::pair_backoff).
+struct BusyScope { int dev; bool counted; explicit BusyScope(int device); ~BusyScope(); };      // (counted per device: an in-process pool runs one context per GPU)
 int busy_transcriptions(int device);
 // |x| envelope of the last PCM on the GPU; the D2H copy runs on a side stream while the encoder works.
 // sync = false: state.energy is valid only after signal_energy_wait()

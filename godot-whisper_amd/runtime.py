@@ -43,6 +43,8 @@ DEVICE_API = [
                                     C.POINTER(abi.whisper_token_data)]),
     ("wmi_selftest_proj", C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     ("wmi_bench_kernel", C.c_double, [C.c_void_p, C.c_int, C.c_int]),
+    ("wmi_reload_knobs", None, []),
+    ("wmi_pair_status", C.c_int, [C.c_void_p, C.POINTER(C.c_int32), C.c_int]),
     ("wmi_step_stamps", C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.c_int, C.c_int]),
     ("wmi_encoder_gemm_stamps", C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_double), C.c_int]),
     ("wmi_pool_init", C.c_void_p, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.c_int]),

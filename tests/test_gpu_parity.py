@@ -1091,6 +1091,7 @@ def test_device_draws_equal_host_draws(product_lib, variant, shape):
             os.environ["WMI_HOST_DRAWS"] = "1"
         else:
             os.environ.pop("WMI_HOST_DRAWS", None)
+        product_lib.wmi_reload_knobs()                      # (the switches are read once per process)
         node = host.SpeechToText(product_lib); node.set_language_model(model)
         if shape == "micro":
             node.language = "fr"
@@ -1112,6 +1113,7 @@ def test_device_draws_equal_host_draws(product_lib, variant, shape):
         finally:
             node.close()
     os.environ.pop("WMI_HOST_DRAWS", None)
+    product_lib.wmi_reload_knobs()
     g, w = res["device"], res["host"]
     assert len(w) >= 4
     assert g.shape == w.shape and np.array_equal(g[:, [0, 1, 6, 7]], w[:, [0, 1, 6, 7]]), (g[:, 0], w[:, 0])

@@ -68,6 +68,69 @@ def test_step_forms_are_bit_identical(default_run, knob):
             assert a == b, (knob, shape)                # ids, tids, probabilities (exact f32 values) and token times
 
 
+# ------------------------------------------------------------------------------------------------ the one-launch MLP must not fail silently
+_PAIR_SCRIPT = r"""
+import ctypes as C, json, sys
+sys.path.insert(0, ROOT_PLACEHOLDER)
+import __graft_entry__ as entry
+entry.load_package()
+from godot_whisper_amd import host, runtime, synth
+lib = runtime.require_gpu(); runtime.silence_logs(lib)
+out = {}
+for shape, secs, mt in (("base.en", 30.0, 16), ("tiny.en", 30.0, 16), ("small", 30.0, 16)):
+    node = host.SpeechToText(lib); node.set_language_model(synth.make_model(shape, seed=4242))
+    if not shape.endswith(".en"): node.language = "de"
+    res = []; status = []
+    for rep in range(6):
+        p = node.full_params("", 0); p.max_tokens = mt; p.temperature_inc = 0.0
+        r = node.transcribe(synth.make_pcm(secs, seed=900 + rep % 2), params=p)
+        res.append([[int(t["id"]), int(t["tid"]), float(t["p"]), float(t["plog"]), int(t["t0"]), int(t["t1"])] for t in r[1:]])
+        st = (C.c_int32 * 3)()
+        assert lib.wmi_pair_status(node.ctx, st, 1 if rep % 2 == 0 else 0) == 0      # re-armed after every other transcription: eager and replayed steps both meet the fault
+        status.append(list(st))
+    out["%s/%d" % (shape, mt)] = res; out["status:%s/%d" % (shape, mt)] = status
+    node.close()
+print("RESULT" + json.dumps(out))
+""".replace("ROOT_PLACEHOLDER", repr(ROOT))
+
+
+def _run_pair(env_extra):
+    env = dict(os.environ); env.update(env_extra)
+    r = subprocess.run([sys.executable, "-c", _PAIR_SCRIPT], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1]
+    return json.loads(line[len("RESULT"):]), r.stderr
+
+
+def test_a_failed_hand_off_inside_the_mlp_launch_is_reported_and_the_step_rerun(default_run):
+    """k_mlp_pair's workgroups hand the hidden row to each other inside the launch; a consumer that gives up waiting computes from stale
+    granules.  WMI_PAIR_WITHHOLD=6: wavefront 5 of every paired launch never publishes its granules (WMI_PAIR_SPIN_CAP: give up after 3000
+    polls instead of a second).  The kernel must say so, the host must run the step again in the two-launch form, and the token stream
+    must be the ordinary one, bit for bit (W/whisper.cpp:2517-2595: a decode either succeeds or reports)."""
+    got, err = _run_pair({"WMI_PAIR_WITHHOLD": "6", "WMI_PAIR_SPIN_CAP": "3000"})
+    for key, runs in got.items():
+        if key.startswith("status:"):
+            fallbacks = [s[0] for s in runs]
+            assert fallbacks[0] >= 1 and fallbacks[-1] >= 3, (key, runs)            # one per armed transcription
+            assert all(s[2] & 1 for s in runs), (key, runs)                        # ... and the one-launch form stays off behind each
+            continue
+        for a, b in zip(default_run[key], runs):
+            assert a == b, key
+
+
+def test_a_slow_hand_off_switches_the_step_to_two_launches(default_run):
+    """WMI_PAIR_WITHHOLD=-6: wavefront 5 publishes ~0.2 ms late — what a device shared with work this process cannot see looks like from
+    inside the launch.  Results are the ordinary ones; the kernel reports the slow sweep and the state takes the two-launch form for a while."""
+    got, err = _run_pair({"WMI_PAIR_WITHHOLD": "-6"})
+    for key, runs in got.items():
+        if key.startswith("status:"):
+            assert runs[0][0] == 0 and runs[-1][0] == 0, (key, runs)               # nothing re-run
+            assert runs[0][1] >= 1 and (runs[0][2] & 2), (key, runs)               # slow seen, backing off
+            continue
+        for a, b in zip(default_run[key], runs):
+            assert a == b, key
+
+
 def test_two_pass_cross_attention_agrees_within_the_margin(default_run):
     other = _run({"WMI_XATTN_TWO_PASS": "1"})
     for shape, runs in default_run.items():
