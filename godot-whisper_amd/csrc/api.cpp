@@ -888,7 +888,7 @@ double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters) {
             } break;
             case 5: {                                  // encoder attention of all lock-step chunks
                 const BatchWork & b = *ctx->batch;
-                k::attn_encoder(b.q, b.k, b.vt, T, b.Tpad, S, H, 0.125f, b.att, s, b.B);
+                k::attn_encoder(b.q, b.k, b.vt, T, b.Tpad, S, H, 0.125f, b.att, s, b.B, nullptr, b.qk_rows);
             } break;
             default: break;
         }

@@ -90,8 +90,10 @@ bool ensure_batch(whisper_context & ctx, int B) {
     w.Tpad = (int) ((T + 63) / 64 * 64);
     w.mel_rows = 2 * T + 8;
     const size_t nb = (size_t) B;
+    // LN1's output and q / k keep every chunk on a 16-row boundary (encode_rows: the q|k|v GEMM's V^T epilogue): T rounded up to 16 rows per chunk
+    const size_t TP = (T + 15) & ~(size_t) 15;
     bool ok = dalloc(w.mel_t, nb * w.mel_rows * hp.n_mels + 1024) && dalloc(w.conv1, nb * (2 * T + 8) * S + 4 * S)
-           && dalloc(w.x, nb * T * S) && dalloc(w.xn, nb * T * S) && dalloc(w.q, nb * T * S) && dalloc(w.k, nb * T * S)
+           && dalloc(w.x, nb * T * S) && dalloc(w.xn, nb * TP * S) && dalloc(w.q, nb * TP * S) && dalloc(w.k, nb * TP * S)
            && dalloc(w.att, nb * T * S) && dalloc(w.vt, nb * S * w.Tpad) && dalloc(w.h, nb * T * 4 * S) && dalloc(w.enc_out_h, nb * T * S)
            && dalloc(w.kvc_k, Lt * nb * T * S) && dalloc(w.kvc_v, Lt * nb * T * S)
            && dalloc(w.self_k, nb * Lt * n_ctx * S) && dalloc(w.self_v, nb * Lt * n_ctx * S)
@@ -111,6 +113,7 @@ bool ensure_batch(whisper_context & ctx, int B) {
     memset(w.sample_host, 0, nb * sizeof(k::SampleOut));
     w.step_seq = 0;
     k::fill_zero(w.vt, nb * S * w.Tpad * sizeof(__half), s);
+    k::fill_zero(w.xn, nb * TP * S * sizeof(__half), s);            // (the chunks' padding rows are GEMM operands: finite)
     k::fill_zero(w.conv1, (nb * (2 * T + 8) * S + 4 * S) * sizeof(__half), s);
     k::fill_zero(w.mel_t, (nb * w.mel_rows * hp.n_mels + 1024) * sizeof(__half), s);
     k::fill_zero(w.self_k, nb * Lt * n_ctx * S * sizeof(__half), s);
@@ -205,17 +208,26 @@ bool encode_rows(whisper_context & ctx, const std::vector<int> & rows, const std
         return true;
     }
     const float kq_scale = 1.0f / sqrtf((float) S / H);
+    // Rows per chunk of LN1's output, q and k: T rounded up to 16 (1500 -> 1504), so that every 16-row MFMA fragment of the q|k|v GEMM lies
+    // inside one chunk at a 16-step offset — its V^T third then leaves in whole 128-byte lines (gemm_epi.h: epilogue_vt_wide) instead of 32-byte
+    // pieces (what the launch cost over a plain epilogue: 41 against 29.5 us at 8 chunks).  The padding rows are zero in xn (never written),
+    // finite junk in q / k / V^T (never read as queries or keys: the attention stops at T).  WMI_ENC_NO_ROWPAD=1: off (A/B).
+    static const bool no_rowpad = getenv("WMI_ENC_NO_ROWPAD") != nullptr;
+    const int TP = (nb >= 2 && !no_rowpad && (T & 15) != 0 && ((T + 15) & ~15) <= b.Tpad) ? (T + 15) & ~15 : T;
+    const int MP = nb * TP;
+    b.qk_rows = TP;
     for (int il = 0; il < La; ++il) {
         const EncLayerW & l = w.enc[il];
-        k::layernorm(b.x, M, S, l.ln1_g, l.ln1_b, hp.eps, b.xn, nullptr, s);
+        if (TP != T) k::layernorm(b.x, M, S, l.ln1_g, l.ln1_b, hp.eps, b.xn, nullptr, s, T, TP);
+        else         k::layernorm(b.x, M, S, l.ln1_g, l.ln1_b, hp.eps, b.xn, nullptr, s);
         {
             k::GemmArgs a{};
-            a.A = b.xn; a.lda = S; a.W = l.w_qkv; a.ldw = S; a.M = M; a.N = 3 * S; a.K = S; a.bias = l.b_qkv;
+            a.A = b.xn; a.lda = S; a.W = l.w_qkv; a.ldw = S; a.M = MP; a.N = 3 * S; a.K = S; a.bias = l.b_qkv;
             a.C = b.q; a.ldc = S; a.aux = b.k; a.ldaux = S; a.aux2 = b.vt; a.ldaux2 = b.Tpad; a.S = S;
-            a.rows_per_chunk = T; a.chunk_stride_aux2 = (int64_t) S * b.Tpad;
+            a.rows_per_chunk = TP; a.chunk_stride_aux2 = (int64_t) S * b.Tpad;
             k::gemm(k::EPI_QKV_ENC, a, s);
         }
-        k::attn_encoder(b.q, b.k, b.vt, T, b.Tpad, S, H, kq_scale, b.att, s, nb);
+        k::attn_encoder(b.q, b.k, b.vt, T, b.Tpad, S, H, kq_scale, b.att, s, nb, nullptr, TP);
         {
             k::GemmArgs a{};
             a.A = b.att; a.lda = S; a.W = l.w_o; a.ldw = S; a.M = M; a.N = S; a.K = S; a.bias = l.b_o;

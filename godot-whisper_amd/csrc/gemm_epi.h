@@ -70,8 +70,15 @@ __device__ __forceinline__ Conv2Row conv2_row(const GemmArgs & a, int m) {
 // Interior tiles take the instantiation without bounds checks: a per-element `if (m < M)` makes every store its own basic block, and
 // hipcc then waits vmcnt(0) before each one (vmcnt also counts stores on gfx9-family parts), i.e. the 64 stores of a lane complete one
 // after the other (profiles/: -10..30 % kernel time on the M = 12 000 GEMMs).
+template <int FM, int FN, bool GUARD>
+__device__ __forceinline__ void epilogue_vt_wide(const GemmArgs & a, floatx4 (&acc)[FM][FN], const int mb, const int nb, const int lane);
+__device__ __forceinline__ bool vt_wide_ok(const GemmArgs & a);
 template <int EPI, int FM, int FN, bool GUARD>
 __device__ __forceinline__ void epilogue_rows(const GemmArgs & a, floatx4 (&acc)[FM][FN], const int mb, const int nb, const int lane) {
+    if constexpr (EPI == EPI_QKV_ENC) {
+        // the V^T third (a wave tile never straddles the thirds: 64 | S) with whole-line stores where the chunks' 16-step blocks line up
+        if (__builtin_amdgcn_readfirstlane(nb) >= 2 * a.S && vt_wide_ok(a)) { epilogue_vt_wide<FM, FN, GUARD>(a, acc, mb, nb, lane); return; }
+    }
     const int frow = lane & 15, fq = lane >> 4;
     float biasv[FN];
 #pragma unroll
@@ -277,6 +284,84 @@ __device__ __forceinline__ void trade_rows8(uint4 & P, uint4 & Q, const bool lo)
     uint4 t = lo ? Q : P;
     t = ror8_u4(t);
     if (lo) Q = t; else P = t;
+}
+
+// ---- the V^T third of the encoder's q|k|v in the first orientation, with WHOLE-LINE stores.  A lane of fragment (i, j) holds time steps
+// t = tb + 4 fq + r of column c = frow (tb = the fragment's 16-step block), i.e. the 8-byte piece at V^T position tb + 4 fq' of row c, where
+// fq' = fq with its two bits swapped (vt_pos): lanes fq = 0 / 2 hold the adjacent pieces 0 / 1 of the block, lanes 1 / 3 the pieces 2 / 3.
+// Plain form: 64 lanes x 8 B = 16 rows x 32 B per wave instruction, and the epilogue of a big tile is bound by that request count (what the
+// q|k|v launch cost over a plain epilogue at M = 12 000: 41 us against 29.5, profiles/r05b_*).  Here:
+//   pair  (fragments i, i + 1):  v_permlane32_swap per dword — lanes 0-31 end up with BOTH pieces of their half of block i, lanes 32-63
+//         with both pieces of their half of block i + 1: 16 B per lane, 16 rows x 64 B per instruction, half the instructions;
+//   quad  (fragments i .. i + 3): two pairs, then the lane halves frow < 8 / >= 8 trade one 16-byte register through DPP row_ror:8
+//         (trade_rows8): an instruction covers 8 rows x 128 B.
+// Pure data movement: every stored value is the plain form's.  Needs 16-step blocks that do not straddle chunks (rows per chunk a
+// multiple of 16, or one chunk) — the caller checks; a block that lies beyond M or beyond the row's Tpad is not stored, rows t >= T of a
+// block that straddles the end of a chunk's valid steps land in the row's padding (finite values: clamped A rows; never read as keys).
+struct VtDest { __half * p; bool ok; };
+template <bool GUARD>
+__device__ __forceinline__ VtDest vt_block_dest(const GemmArgs & a, const int m_blk, const int c, const int pos8) {
+    const int rpc = a.rows_per_chunk > 0 ? a.rows_per_chunk : a.M;
+    const int cb = m_blk / rpc, tb = m_blk - cb * rpc;
+    VtDest d;
+    d.ok = (!GUARD || m_blk < a.M) && tb + 16 <= a.ldaux2;
+    d.p = (__half *) a.aux2 + (size_t) cb * a.chunk_stride_aux2 + (size_t) c * a.ldaux2 + tb + pos8;
+    return d;
+}
+template <int FM, int FN, bool GUARD>
+__device__ __forceinline__ void epilogue_vt_wide(const GemmArgs & a, floatx4 (&acc)[FM][FN], const int mb, const int nb, const int lane) {
+    const int frow = lane & 15, fq = lane >> 4;
+    const bool lo = frow < 8;
+    const int pos8 = (fq & 1) << 3, up = fq >> 1;            // after a pair swap: this lane's 8 steps inside its block, and which block of the pair
+    auto pack = [&](const floatx4 & v, const float bias, uint32_t (&w)[2]) {
+        half4 h;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) h[r] = (_Float16) pin_f32(v[r] + bias);
+        const uint2 u = *(const uint2 *) &h;
+        w[0] = u.x; w[1] = u.y;
+    };
+    auto pair16 = [&](const floatx4 & v0, const floatx4 & v1, const float bias) -> uint4 {
+        uint32_t w0[2], w1[2];
+        pack(v0, bias, w0); pack(v1, bias, w1);
+        const auto s0 = __builtin_amdgcn_permlane32_swap(w0[0], w1[0], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(w0[1], w1[1], false, false);
+        return make_uint4(s0[0], s1[0], s0[1], s1[1]);       // [first piece | second piece] of block i (lanes 0-31) / i + 1 (lanes 32-63)
+    };
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+        const int n = nb + j * 16 + frow;                    // (N is a multiple of 16 on every caller: no column guard)
+        const int c = n - 2 * a.S;
+        const float bias = a.bias ? a.bias[n] : 0.0f;
+        int i = 0;
+#pragma unroll
+        for (; i + 3 < FM; i += 4) {
+            uint4 P = pair16(acc[i][j], acc[i + 1][j], bias), Q = pair16(acc[i + 2][j], acc[i + 3][j], bias);
+            trade_rows8(P, Q, lo);
+            // lanes frow < 8 now hold blocks i / i + 1 of columns (frow & 7) [P] and (frow & 7) + 8 [Q], lanes frow >= 8 blocks i + 2 / i + 3
+            const int blk = mb + (i + (lo ? 0 : 2) + up) * 16, cc = c - frow + (frow & 7);
+            const VtDest d0 = vt_block_dest<GUARD>(a, blk, cc, pos8), d1 = vt_block_dest<GUARD>(a, blk, cc + 8, pos8);
+            if (d0.ok) *(uint4 *) d0.p = P;
+            if (d1.ok) *(uint4 *) d1.p = Q;
+        }
+#pragma unroll
+        for (; i + 1 < FM; i += 2) {
+            const uint4 P = pair16(acc[i][j], acc[i + 1][j], bias);
+            const VtDest d = vt_block_dest<GUARD>(a, mb + (i + up) * 16, c, pos8);
+            if (d.ok) *(uint4 *) d.p = P;
+        }
+#pragma unroll
+        for (; i < FM; ++i) {                                // a last single fragment row: the 8-byte form
+            uint32_t w[2];
+            pack(acc[i][j], bias, w);
+            const VtDest d = vt_block_dest<GUARD>(a, mb + i * 16, c, 0);
+            if (d.ok) *(uint2 *) (d.p + ((fq & 1) << 3) + ((fq >> 1) << 2)) = make_uint2(w[0], w[1]);
+        }
+    }
+}
+// wave-uniform: may the V^T third of this launch take the whole-line form?
+__device__ __forceinline__ bool vt_wide_ok(const GemmArgs & a) {
+    const int rpc = a.rows_per_chunk > 0 ? a.rows_per_chunk : a.M;
+    return !(a.no_glds & 16) && (rpc >= a.M || (rpc & 15) == 0) && (a.ldaux2 & 7) == 0 && (a.chunk_stride_aux2 & 7) == 0;
 }
 
 template <int EPI, int FM, int FN, bool GUARD>

@@ -45,7 +45,7 @@ __device__ __forceinline__ uint32_t lds_off(int row, int chunk) { return (uint32
 template <int NW, int KS>
 __global__ __launch_bounds__(NW * 64 * KS) void k_attn_enc(const __half * __restrict__ q, const __half * __restrict__ k,
                                                   const __half * __restrict__ vt, int T, int Tpad, int S, float scale,
-                                                  __half * __restrict__ out, float * __restrict__ out32) {
+                                                  __half * __restrict__ out, float * __restrict__ out32, int qk_rows) {
     __shared__ __attribute__((aligned(16))) unsigned char sK_[KS][64 * 128];
     __shared__ __attribute__((aligned(16))) unsigned char sV_[KS][64 * 128];
     const int half = KS == 1 ? 0 : (int) (threadIdx.x / (NW * 64));       // key half of this wavefront group
@@ -56,7 +56,7 @@ __global__ __launch_bounds__(NW * 64 * KS) void k_attn_enc(const __half * __rest
     const int q0 = blockIdx.x * (NW * 16) + wave * 16;
     {   // chunk (lane of a batched encode): activations are [B][T][S], V^T is [B][S][Tpad]
         const size_t zb = blockIdx.z;
-        q += zb * (size_t) T * S; k += zb * (size_t) T * S; vt += zb * (size_t) S * Tpad;
+        q += zb * (size_t) qk_rows * S; k += zb * (size_t) qk_rows * S; vt += zb * (size_t) S * Tpad;
         if (out32) out32 += zb * (size_t) T * S; else out += zb * (size_t) T * S;
     }
 
@@ -953,22 +953,23 @@ static bool g_attn_one_group = false;
 void set_attn_one_group(bool on) { if (on != g_attn_one_group) bump_mode_epoch(); g_attn_one_group = on; }
 
 void attn_encoder(const __half * q, const __half * k, const __half * vt, int T, int Tpad, int S, int H, float scale,
-                  __half * out, hipStream_t st, int B, float * out32) {
+                  __half * out, hipStream_t st, int B, float * out32, int qk_chunk_rows) {
+    const int qk_rows = qk_chunk_rows > 0 ? qk_chunk_rows : T;
     // WMI_ATTN_FORM: 2 (default) = 32-row wavefronts, one sweep with a running maximum; 1 = the same kernel with the exact row
     // maximum found in a first sweep (the reference's soft-max argument); 0 = the round-1/2 kernel (16-row wavefronts, two sweeps)
     static const int form = getenv("WMI_ATTN_FORM") ? atoi(getenv("WMI_ATTN_FORM")) : 2;
     static const int ksplit = getenv("WMI_ATTN_KSPLIT") ? atoi(getenv("WMI_ATTN_KSPLIT")) : -1;      // A/B knob; default: by grid size
     if (form >= 1 && scale == 0.125f && (Tpad % 64) == 0) {
         const bool split = ksplit >= 0 ? ksplit > 1 : (((T + 127) / 128) * H * B < 512 && T >= 512 && !g_attn_one_group);
-        attn_encoder2(q, k, vt, T, Tpad, S, H, out, st, B, out32, form == 2, split);
+        attn_encoder2(q, k, vt, T, Tpad, S, H, out, st, B, out32, form == 2, split, qk_rows);
         return;
     }
     static const int nw = getenv("WMI_ATTN_NW") ? atoi(getenv("WMI_ATTN_NW")) : 4;      // wavefronts per workgroup (A/B knob)
     const int nblk = ((T + 63) / 64) * H * B;
     const bool ks2 = ksplit >= 0 ? ksplit == 2 : (nblk <= 512 && T >= 256 && !g_attn_one_group);
-    if (nw == 4 && ks2) hipLaunchKernelGGL((k_attn_enc<4, 2>), dim3((T + 63) / 64, H, B), dim3(512), 0, st, q, k, vt, T, Tpad, S, scale, out, out32);
-    else if (nw == 4)   hipLaunchKernelGGL((k_attn_enc<4, 1>), dim3((T + 63) / 64, H, B), dim3(256), 0, st, q, k, vt, T, Tpad, S, scale, out, out32);
-    else                hipLaunchKernelGGL((k_attn_enc<2, 1>), dim3((T + 31) / 32, H, B), dim3(128), 0, st, q, k, vt, T, Tpad, S, scale, out, out32);
+    if (nw == 4 && ks2) hipLaunchKernelGGL((k_attn_enc<4, 2>), dim3((T + 63) / 64, H, B), dim3(512), 0, st, q, k, vt, T, Tpad, S, scale, out, out32, qk_rows);
+    else if (nw == 4)   hipLaunchKernelGGL((k_attn_enc<4, 1>), dim3((T + 63) / 64, H, B), dim3(256), 0, st, q, k, vt, T, Tpad, S, scale, out, out32, qk_rows);
+    else                hipLaunchKernelGGL((k_attn_enc<2, 1>), dim3((T + 31) / 32, H, B), dim3(128), 0, st, q, k, vt, T, Tpad, S, scale, out, out32, qk_rows);
 }
 
 void attn_decoder(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int n_kv,

@@ -46,7 +46,7 @@ __device__ __forceinline__ float max3(float a, float b, float c) { float d; asm(
 template <int QW, int KS, bool ONE, int NST, bool WIDE_OUT = true>
 __global__ __launch_bounds__(QW * KS * 64) void k_attn_enc2(const __half * __restrict__ q, const __half * __restrict__ k,
                                                             const __half * __restrict__ vt, int T, int Tpad, int S,
-                                                            __half * __restrict__ out, float * __restrict__ out32, int xcd_order) {
+                                                            __half * __restrict__ out, float * __restrict__ out32, int xcd_order, int qk_rows) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     typedef float floatx16 __attribute__((ext_vector_type(16)));
     typedef float float2v __attribute__((ext_vector_type(2)));
@@ -77,7 +77,7 @@ __global__ __launch_bounds__(QW * KS * 64) void k_attn_enc2(const __half * __res
     const int q0 = bx * (QW * 32) + qw * 32;
     {
         const size_t zb = bz;
-        q += zb * (size_t) T * S; k += zb * (size_t) T * S; vt += zb * (size_t) S * Tpad;
+        q += zb * (size_t) qk_rows * S; k += zb * (size_t) qk_rows * S; vt += zb * (size_t) S * Tpad;
         if (out32) out32 += zb * (size_t) T * S; else out += zb * (size_t) T * S;
     }
     unsigned char * const ring = smem + grp * (NST * STAGE);
@@ -355,7 +355,7 @@ __global__ __launch_bounds__(QW * KS * 64) void k_attn_enc2(const __half * __res
 
 template <int QW, int KS, bool ONE, int NST>
 void launch_attn_enc2(const __half * q, const __half * k, const __half * vt, int T, int Tpad, int S, int H, __half * out,
-                      hipStream_t st, int B, float * out32) {
+                      hipStream_t st, int B, float * out32, int qk_rows) {
     static std::atomic<uint64_t> lds_ok{0};
     constexpr size_t ring = (size_t) KS * NST * 16384;
     constexpr size_t extra = (!ONE && KS > 1) ? (size_t) KS * QW * 32 * 4 : 0;
@@ -371,7 +371,7 @@ void launch_attn_enc2(const __half * q, const __half * k, const __half * vt, int
         static_assert(smem0 <= 160 * 1024, "LDS");
         if (smem0 > 48 * 1024) allow_full_lds((const void *) k_attn_enc2<QW, KS, ONE, NST, false>, lds_ok);
         hipLaunchKernelGGL((k_attn_enc2<QW, KS, ONE, NST, false>), dim3((T + QW * 32 - 1) / (QW * 32), H, B), dim3(QW * KS * 64), smem0, st,
-                           q, k, vt, T, Tpad, S, out, out32, xcd_order);
+                           q, k, vt, T, Tpad, S, out, out32, xcd_order, qk_rows);
         return;
     }
     constexpr size_t smem = KS == 1 ? (smem0 > (size_t) QW * 4096 ? smem0 : (size_t) QW * 4096) : smem0 + (size_t) QW * 4096;      // the query wavefronts' output images: inside the ring (one key group) or behind it
@@ -379,21 +379,22 @@ void launch_attn_enc2(const __half * q, const __half * k, const __half * vt, int
     static std::atomic<uint64_t> lds_ok_w{0};
     if (smem > 48 * 1024) allow_full_lds((const void *) k_attn_enc2<QW, KS, ONE, NST, true>, lds_ok_w);
     hipLaunchKernelGGL((k_attn_enc2<QW, KS, ONE, NST, true>), dim3((T + QW * 32 - 1) / (QW * 32), H, B), dim3(QW * KS * 64), smem, st,
-                       q, k, vt, T, Tpad, S, out, out32, xcd_order);
+                       q, k, vt, T, Tpad, S, out, out32, xcd_order, qk_rows);
 }
 
 }  // namespace
 
 
 void attn_encoder2(const __half * q, const __half * k, const __half * vt, int T, int Tpad, int S, int H, __half * out, hipStream_t st,
-                   int B, float * out32, bool one_sweep, bool split) {
+                   int B, float * out32, bool one_sweep, bool split, int qk_chunk_rows) {
+    const int qk_rows = qk_chunk_rows > 0 ? qk_chunk_rows : T;
     // one key group wherever the result must not depend on how many chunks share the launch (lock-step "exact" mode) and
     // wherever the grid fills the chip by itself; four key groups of two wavefronts for one or two chunks
     // WMI_ATTN_CFG = <wavefronts per key group><key groups><ring depth>, e.g. 242 (A/B knob; the defaults are the measured best)
     static const int cfg_env = getenv("WMI_ATTN_CFG") ? atoi(getenv("WMI_ATTN_CFG")) : 0;
     const int cfg = cfg_env ? cfg_env : (split ? 242 : 412);
-#define WMI_ATTN_CASE(C, QW, KS, NST) case C: if (one_sweep) launch_attn_enc2<QW, KS, true, NST>(q, k, vt, T, Tpad, S, H, out, st, B, out32); \
-                                              else           launch_attn_enc2<QW, KS, false, NST>(q, k, vt, T, Tpad, S, H, out, st, B, out32); break;
+#define WMI_ATTN_CASE(C, QW, KS, NST) case C: if (one_sweep) launch_attn_enc2<QW, KS, true, NST>(q, k, vt, T, Tpad, S, H, out, st, B, out32, qk_rows); \
+                                              else           launch_attn_enc2<QW, KS, false, NST>(q, k, vt, T, Tpad, S, H, out, st, B, out32, qk_rows); break;
     switch (cfg) {
         WMI_ATTN_CASE(242, 2, 4, 2)
         WMI_ATTN_CASE(223, 2, 2, 3)

@@ -333,7 +333,8 @@ void gemm(int epi, const GemmArgs & a_in, hipStream_t st) {
     static const bool guard_all = getenv("WMI_GEMM_GUARD_ALL") != nullptr;   // debug / A-B: bounds-checked epilogue for every tile
     static const bool narrow = getenv("WMI_GEMM_NARROW_STORES") != nullptr;  // debug / A-B: 8-byte epilogue stores
     static const bool qkv_swap = getenv("WMI_GEMM_QKV_SWAP") != nullptr;    // debug / A-B: q and k thirds of the big q|k|v grids in the transposed orientation
-    GemmArgs a = a_in; a.no_glds = (no_glds ? 1 : 0) | (guard_all ? 2 : 0) | (narrow ? 4 : 0) | (qkv_swap ? 8 : 0);
+    static const bool vt_narrow = getenv("WMI_GEMM_VT_NARROW") != nullptr;  // debug / A-B: the V^T third of the encoder's q|k|v as 8-byte stores
+    GemmArgs a = a_in; a.no_glds = (no_glds ? 1 : 0) | (guard_all ? 2 : 0) | (narrow ? 4 : 0) | (qkv_swap ? 8 : 0) | (vt_narrow ? 16 : 0);
     if (GemmLog * lg = tl_gemm_log) {
         const size_t wgs = (size_t) ((a.M + 63) / 64) * (size_t) ((a.N + 31) / 32);     // the smallest tile any dispatch below uses is 64 x 32
         if (!a.probe && lg->used + wgs * 5 <= lg->cap_words) {
@@ -350,15 +351,17 @@ void gemm(int epi, const GemmArgs & a_in, hipStream_t st) {
     if (g8 && !no_glds && (epi == EPI_F16_BIAS_GELU || epi == EPI_CROSS_KV) && a.M >= 4096 && a.N >= 1024 && (a.N % 256) == 0 && (a.K % 64) == 0 &&
         (epi != EPI_CROSS_KV || (a.S % 64) == 0)) {
         const long t192 = (long) ((a.M + 191) / 192) * (a.N / 256);
-        if (t192 >= 384) { GemmArgs b = a; b.no_glds = 0; if (gemm8(epi, 192, true, b, st)) return; }
+        if (t192 >= 384) { GemmArgs b = a; b.no_glds = a.no_glds & 16; if (gemm8(epi, 192, true, b, st)) return; }
     }
     // (q|k|v stays below: on 288-row tiles — 42 x 6 = 252, ONE round at M = 12 000 — the persistent kernel measures 41.1 us against 41.0 us
     //  here, in situ 37.5 against 37.4: the V^T third's epilogue decides, not the tiling; WMI_GEMM8_QKV=1 routes it there for A/B)
-    static const bool g8_qkv = getenv("WMI_GEMM8_QKV") != nullptr;
+    // (round 6: with the V^T third leaving in whole lines — gemm_epi.h: epilogue_vt_wide, chunks on 16-row boundaries — the tiling decides again:
+    //  288-row tiles in whole rounds of the persistent kernel; WMI_GEMM8_QKV=0: off)
+    static const bool g8_qkv = getenv("WMI_GEMM8_QKV") ? atoi(getenv("WMI_GEMM8_QKV")) != 0 : true;
     if (g8_qkv && g8 && !no_glds && epi == EPI_QKV_ENC && a.M >= 4096 && (a.N % 256) == 0 && (a.K % 64) == 0 && a.S > 0 && (a.S % 128) == 0 && a.N == 3 * a.S) {
         const long t288 = (long) ((a.M + 287) / 288) * (a.N / 256);
-        const int n_cu = cu_count_x8();
-        if (t288 <= n_cu && t288 * 5 >= (long) n_cu * 4) { GemmArgs b = a; b.no_glds = 0; if (gemm8(epi, 288, true, b, st, 32)) return; }
+        const long n_cu = cu_count_x8(), rounds = (t288 + n_cu - 1) / n_cu;
+        if (t288 * 5 >= rounds * n_cu * 4) { GemmArgs b = a; b.no_glds = a.no_glds & 16; if (gemm8(epi, 288, true, b, st, 32)) return; }
     }
     switch (epi) {
         case EPI_F16_BIAS:       dispatch<EPI_F16_BIAS>(a, st); break;

@@ -15,11 +15,14 @@ namespace {
 template <int MAXV>   // MAXV = ceil(S / 256) float4 groups per lane
 __global__ __launch_bounds__(256) void k_layernorm(const float * __restrict__ x, int rows, int S,
                                                    const float * __restrict__ g, const float * __restrict__ b, float eps,
-                                                   __half * __restrict__ out16, float * __restrict__ out32) {
+                                                   __half * __restrict__ out16, float * __restrict__ out32, int rpc_in, int rpc_out) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const float * xr = x + (size_t) row * S;
+    // lock-step chunks: input rows chunk * rpc_in + t, output rows chunk * rpc_out + t (the q|k|v GEMM wants every chunk to start on a
+    // 16-row boundary, see batch.cpp); rpc_in = 0: the same row
+    const int orow = rpc_in > 0 ? (row / rpc_in) * rpc_out + row % rpc_in : row;
     // all loads of the row (x, gain, bias) first, from clamped columns: with the load inside the summation loop hipcc waited
     // for every 16 bytes before requesting the next (MAXV + 2 MAXV dependent round trips per row)
     float4 v[MAXV], gg[MAXV], bb[MAXV];
@@ -57,11 +60,11 @@ __global__ __launch_bounds__(256) void k_layernorm(const float * __restrict__ x,
             y.y = __fadd_rn(__fmul_rn(v[i].y * scale, gg[i].y), bb[i].y);
             y.z = __fadd_rn(__fmul_rn(v[i].z * scale, gg[i].z), bb[i].z);
             y.w = __fadd_rn(__fmul_rn(v[i].w * scale, gg[i].w), bb[i].w);
-            if (out32) *(float4 *) (out32 + (size_t) row * S + c) = y;
+            if (out32) *(float4 *) (out32 + (size_t) orow * S + c) = y;
             if (out16) {
                 __half2 h01 = __floats2half2_rn(pin_f32(y.x), pin_f32(y.y)), h23 = __floats2half2_rn(pin_f32(y.z), pin_f32(y.w));
                 uint2 pk; pk.x = *(uint32_t *) &h01; pk.y = *(uint32_t *) &h23;
-                *(uint2 *) (out16 + (size_t) row * S + c) = pk;
+                *(uint2 *) (out16 + (size_t) orow * S + c) = pk;
             }
         }
     }
@@ -70,13 +73,13 @@ __global__ __launch_bounds__(256) void k_layernorm(const float * __restrict__ x,
 } // namespace
 
 void layernorm(const float * x, int rows, int S, const float * g, const float * b, float eps,
-               __half * out16, float * out32, hipStream_t st) {
+               __half * out16, float * out32, hipStream_t st, int rows_per_chunk_in, int rows_per_chunk_out) {
     if (rows <= 0) return;
     const dim3 grid((rows + 3) / 4), block(256);
     const int nv = (S + 255) / 256;
-    if (nv <= 2)      hipLaunchKernelGGL((k_layernorm<2>), grid, block, 0, st, x, rows, S, g, b, eps, out16, out32);
-    else if (nv <= 4) hipLaunchKernelGGL((k_layernorm<4>), grid, block, 0, st, x, rows, S, g, b, eps, out16, out32);
-    else              hipLaunchKernelGGL((k_layernorm<8>), grid, block, 0, st, x, rows, S, g, b, eps, out16, out32);
+    if (nv <= 2)      hipLaunchKernelGGL((k_layernorm<2>), grid, block, 0, st, x, rows, S, g, b, eps, out16, out32, rows_per_chunk_in, rows_per_chunk_out);
+    else if (nv <= 4) hipLaunchKernelGGL((k_layernorm<4>), grid, block, 0, st, x, rows, S, g, b, eps, out16, out32, rows_per_chunk_in, rows_per_chunk_out);
+    else              hipLaunchKernelGGL((k_layernorm<8>), grid, block, 0, st, x, rows, S, g, b, eps, out16, out32, rows_per_chunk_in, rows_per_chunk_out);
 }
 
 }} // namespace wmi::k

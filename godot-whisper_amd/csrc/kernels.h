@@ -190,7 +190,7 @@ bool gemm8(int epi, int bm, bool swapped, const GemmArgs & a, hipStream_t st, in
 // ---------------------------------------------------------------- LayerNorm (k_norm.hip)
 // y = (x - mean) / sqrt(var + eps) * g + b ; one wave per row. out16 and/or out32 may be null.
 void layernorm(const float * x, int rows, int S, const float * g, const float * b, float eps,
-               __half * out16, float * out32, hipStream_t st);
+               __half * out16, float * out32, hipStream_t st, int rows_per_chunk_in = 0, int rows_per_chunk_out = 0);      // > 0: output row = chunk * out + t for input row chunk * in + t
 
 // ---------------------------------------------------------------- attention (k_attn.hip)
 // encoder: q,k [T][S] f16 ; vt [S][Tpad] f16 ; out [T][S] f16 ; scale applied to q.k before softmax
@@ -199,9 +199,10 @@ void layernorm(const float * x, int rows, int S, const float * g, const float * 
 // f32 tensor directly, as the reference does); same for the decoder kernels below
 // second form (k_attn_enc.hip): 32-row wavefronts; one_sweep = running maximum, else exact maximum first; split = four key groups
 void attn_encoder2(const __half * q, const __half * k, const __half * vt, int T, int Tpad, int S, int H, __half * out, hipStream_t st,
-                   int B, float * out32, bool one_sweep, bool split);
+                   int B, float * out32, bool one_sweep, bool split, int qk_chunk_rows = 0);
 void attn_encoder(const __half * q, const __half * k, const __half * vt, int T, int Tpad, int S, int H,
-                  float scale, __half * out, hipStream_t st, int B = 1, float * out32 = nullptr);
+                  float scale, __half * out, hipStream_t st, int B = 1, float * out32 = nullptr,
+                  int qk_chunk_rows = 0);     // rows between the chunks of q and k (0 = T; lock-step chunks start on 16-row boundaries, batch.cpp)
 // decoder: one (token, head) per workgroup.  kc/vc: [n_kv][S] caches (this layer), mask: [n][ld_mask] or null
 void attn_decoder(const __half * q, int n, int S, int H, const __half * kc, const __half * vc, int n_kv,
                   const float * mask, int ld_mask, __half * out, hipStream_t st,

@@ -282,7 +282,7 @@ struct State {
 // Activations carry a chunk dimension (encoder GEMMs see M = B * T rows), every chunk has its own self / cross cache.
 struct BatchWork {
     int B = 0;                                               // chunk slots allocated (<= 8: rows of the decode GEMV)
-    int Tpad = 0;
+    int Tpad = 0; int qk_rows = 0;                            // qk_rows: rows between the chunks of xn (LN1 output) / q / k in the last encode_rows (T, or T rounded up to 16)
     size_t mel_rows = 0;                                      // rows of one chunk's token-major mel image
     __half * mel_t = nullptr, * conv1 = nullptr;              // [B][mel_rows][n_mel], [B][2T+4][S]
     float  * x = nullptr;                                     // [B*T][S] f32 residual stream
