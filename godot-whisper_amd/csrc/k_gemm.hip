@@ -299,7 +299,11 @@ void dispatch(const GemmArgs & a, hipStream_t st) {
         // Round quantisation on the big grids: two workgroups per CU = 512 resident tiles; q|k|v at M = 12 000 is 1 128 tiles of 128 rows
         // (2.2 rounds: the third runs 20 % full), the N = S projections 376 (one round, 73 % full).  Tiles of 96 rows make that 1 500 and
         // 500: whole rounds.  Taken when they fill the rounds better by more than their ~5 % lower operand reuse costs.
-        if constexpr (EPI == EPI_QKV_ENC || EPI == EPI_F32_BIAS_RESID) {
+        // (round 6: the conv front-end's big grids on 96-row tiles too — conv2 x8 is 376 tiles of 128 rows = 0.73 of the 512 resident slots, 504 of 96
+        //  rows fill them: 38.5 -> 33.4 us, conv1 18.6 -> 17.6; WMI_GEMM_CONV96=0: off)
+        static const bool conv96 = getenv("WMI_GEMM_CONV96") ? atoi(getenv("WMI_GEMM_CONV96")) != 0 : true;
+        if constexpr (EPI == EPI_QKV_ENC || EPI == EPI_F32_BIAS_RESID || EPI == EPI_CONV2 || EPI == EPI_F16_BIAS_GELU) {
+            if (!conv96 && (EPI == EPI_CONV2 || EPI == EPI_F16_BIAS_GELU)) { launch<128, 128, EPI>(a, st); return; }
             static const bool no96 = getenv("WMI_GEMM_NO_96") != nullptr;          // A/B knob
             const long t96 = (long) ((a.M + 95) / 96) * ((a.N + 127) / 128);
             auto fill = [](long t) { return (double) t / (double) (((t + 511) / 512) * 512); };
@@ -351,6 +355,9 @@ void gemm(int epi, const GemmArgs & a_in, hipStream_t st) {
     if (g8 && !no_glds && (epi == EPI_F16_BIAS_GELU || epi == EPI_CROSS_KV) && a.M >= 4096 && a.N >= 1024 && (a.N % 256) == 0 && (a.K % 64) == 0 &&
         (epi != EPI_CROSS_KV || (a.S % 64) == 0)) {
         const long t192 = (long) ((a.M + 191) / 192) * (a.N / 256);
+        static const int bm_cross = getenv("WMI_GEMM8_CROSS_BM") ? atoi(getenv("WMI_GEMM8_CROSS_BM")) : 192;      // A/B knobs
+        static const int bm_mlp0 = getenv("WMI_GEMM8_MLP0_BM") ? atoi(getenv("WMI_GEMM8_MLP0_BM")) : 192;
+        if ((epi == EPI_CROSS_KV ? bm_cross : bm_mlp0) == 288) { GemmArgs b = a; b.no_glds = a.no_glds & 16; if (gemm8(epi, 288, true, b, st, 32)) return; }
         if (t192 >= 384) { GemmArgs b = a; b.no_glds = a.no_glds & 16; if (gemm8(epi, 192, true, b, st)) return; }
     }
     // (q|k|v stays below: on 288-row tiles — 42 x 6 = 252, ONE round at M = 12 000 — the persistent kernel measures 41.1 us against 41.0 us

@@ -363,6 +363,8 @@ bool gemm8(int epi, int bm, bool swapped, const GemmArgs & a, hipStream_t st, in
     if (!swapped) return false;
     // q|k|v of the lock-step encoder: 288-row tiles on 32-deep slots (42 x 6 = 252 tiles at M = 12 000: one round), orientation per column tile
     if (epi == EPI_QKV_ENC && bm == 288 && ks == 32) { launch8<288, EPI_QKV_ENC, 2, 2, true, 32>(a, st); return true; }
+    if (epi == EPI_CROSS_KV && bm == 288 && ks == 32) { launch8<288, EPI_CROSS_KV, 2, 2, true, 32>(a, st); return true; }
+    if (epi == EPI_F16_BIAS_GELU && bm == 288 && ks == 32) { launch8<288, EPI_F16_BIAS_GELU, 2, 2, true, 32>(a, st); return true; }
     if (ks != 64) return false;
 #define WMI_G8(E)                                                                                       \
     case E:                                                                                             \
