@@ -355,9 +355,7 @@ void gemm(int epi, const GemmArgs & a_in, hipStream_t st) {
     if (g8 && !no_glds && (epi == EPI_F16_BIAS_GELU || epi == EPI_CROSS_KV) && a.M >= 4096 && a.N >= 1024 && (a.N % 256) == 0 && (a.K % 64) == 0 &&
         (epi != EPI_CROSS_KV || (a.S % 64) == 0)) {
         const long t192 = (long) ((a.M + 191) / 192) * (a.N / 256);
-        static const int bm_cross = getenv("WMI_GEMM8_CROSS_BM") ? atoi(getenv("WMI_GEMM8_CROSS_BM")) : 192;      // A/B knobs
-        static const int bm_mlp0 = getenv("WMI_GEMM8_MLP0_BM") ? atoi(getenv("WMI_GEMM8_MLP0_BM")) : 192;
-        if ((epi == EPI_CROSS_KV ? bm_cross : bm_mlp0) == 288) { GemmArgs b = a; b.no_glds = a.no_glds & 16; if (gemm8(epi, 288, true, b, st, 32)) return; }
+        // (round 6: 288-row tiles for these two measured slower — cross K/V 90.4 against 85.0 us, mlp.0 43.5 against 32.7: profiles/r06c_*)
         if (t192 >= 384) { GemmArgs b = a; b.no_glds = a.no_glds & 16; if (gemm8(epi, 192, true, b, st)) return; }
     }
     // (q|k|v stays below: on 288-row tiles — 42 x 6 = 252, ONE round at M = 12 000 — the persistent kernel measures 41.1 us against 41.0 us
