@@ -126,7 +126,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
     //  same as the first orientation — 41.3-41.8 against 40.9-41.2 us, profiles/r05b_gemm_lab_qkv.txt: the V^T third's scattered 8-byte
     //  stores are what the q|k|v epilogue costs over a plain one (34.5 us) — so the round-3 choice stays; a.no_glds bit 8 =
     //  WMI_GEMM_QKV_SWAP is the A/B knob)
-    const bool swap = SWAP && !(EPI == EPI_QKV_ENC && (n0 >= 2 * a.S || (big && !(a.no_glds & 8)))) && !(EPI == EPI_F32_BIAS_RESID && big);
+    const bool swap = SWAP && !(EPI == EPI_QKV_ENC && (n0 >= 2 * a.S || (big && !(a.no_glds & 8)))) && !(EPI == EPI_F32_BIAS_RESID && big && !(a.no_glds & 32));
     auto compute = [&](int buf, auto sw_tag) {
         constexpr bool SWF = decltype(sw_tag)::value;
 #pragma unroll
@@ -294,6 +294,22 @@ void dispatch(const GemmArgs & a, hipStream_t st) {
             if (tall == 3) { launch_n<256, 256, EPI, 2, 8>(a, st); return; }
         }
     }
+    // Round 6: the N = S projections of the big grids (out, mlp.2 at M = chunks x 1500) on 192 x 128 tiles, ONE workgroup of eight wavefronts per CU
+    // on a three-deep ring: 252 tiles at 8 chunks = one round, 76.8 flop per operand byte against 54.9 for two co-resident 96 x 128 workgroups.
+    // Measured at 8 chunks (profiles/r06e_*): mlp.2 40.3 -> 34.2 us, out 15.5 -> 13.8; 16 chunks mlp.2 75.6 -> 72.2; 4 chunks mlp.2 34.3 -> 28.2 but
+    // out 9.2 -> 10.6 (128 tiles: half the chip) — so the short-K projection takes it only with >= 200 tiles.  Ring depth: two 40.0, three 35.8, four
+    // (all 160 KB of LDS) 33.4 - 34.8 us for mlp.2; four wavefronts 42.1; the conv front-end on this tile 33.3 - 33.9 against 33.4 - 34.7 us (stays).
+    //   WMI_GEMM_NS192: 0 = off   1 = eight wavefronts, three-deep   2 = two-deep   3 = four wavefronts   4 = four-deep (default)
+    static const int ns192 = getenv("WMI_GEMM_NS192") ? atoi(getenv("WMI_GEMM_NS192")) : 4;
+    if constexpr (EPI == EPI_F32_BIAS_RESID) {
+        const long t192 = (long) ((a.M + 191) / 192) * (a.N / 128);
+        if (ns192 && a.M >= 4096 && a.N <= 1024 && (a.N % 128) == 0 && (a.K % BK) == 0 && !(a.no_glds & 1) && (a.K >= 1024 || t192 >= 200)) {
+            if (ns192 == 1) { launch_n<192, 128, EPI, 3, 8>(a, st); return; }
+            if (ns192 == 2) { launch_n<192, 128, EPI, 2, 8>(a, st); return; }
+            if (ns192 == 3) { launch_n<192, 128, EPI, 3, 4>(a, st); return; }
+            if (ns192 == 4) { launch_n<192, 128, EPI, 4, 8>(a, st); return; }
+        }
+    }
     static const long t128_min = getenv("WMI_GEMM_T128") ? atol(getenv("WMI_GEMM_T128")) : 320;        // A/B knob; 376 tiles (out projection at M = 12 000): 18.6 us against 23.0 us as 1 504 tiles of 64 x 64
     if (t128 >= t128_min || (t128 >= 256 && a.K >= 1024)) {
         // Round quantisation on the big grids: two workgroups per CU = 512 resident tiles; q|k|v at M = 12 000 is 1 128 tiles of 128 rows
@@ -337,8 +353,9 @@ void gemm(int epi, const GemmArgs & a_in, hipStream_t st) {
     static const bool guard_all = getenv("WMI_GEMM_GUARD_ALL") != nullptr;   // debug / A-B: bounds-checked epilogue for every tile
     static const bool narrow = getenv("WMI_GEMM_NARROW_STORES") != nullptr;  // debug / A-B: 8-byte epilogue stores
     static const bool qkv_swap = getenv("WMI_GEMM_QKV_SWAP") != nullptr;    // debug / A-B: q and k thirds of the big q|k|v grids in the transposed orientation
+    static const bool resid_swap = getenv("WMI_GEMM_RESID_SWAP") != nullptr;   // debug / A-B: the residual epilogues of the big grids in the transposed orientation (16-byte f32 stores)
     static const bool vt_narrow = getenv("WMI_GEMM_VT_NARROW") != nullptr;  // debug / A-B: the V^T third of the encoder's q|k|v as 8-byte stores
-    GemmArgs a = a_in; a.no_glds = (no_glds ? 1 : 0) | (guard_all ? 2 : 0) | (narrow ? 4 : 0) | (qkv_swap ? 8 : 0) | (vt_narrow ? 16 : 0);
+    GemmArgs a = a_in; a.no_glds = (no_glds ? 1 : 0) | (guard_all ? 2 : 0) | (narrow ? 4 : 0) | (qkv_swap ? 8 : 0) | (vt_narrow ? 16 : 0) | (resid_swap ? 32 : 0);
     if (GemmLog * lg = tl_gemm_log) {
         const size_t wgs = (size_t) ((a.M + 63) / 64) * (size_t) ((a.N + 31) / 32);     // the smallest tile any dispatch below uses is 64 x 32
         if (!a.probe && lg->used + wgs * 5 <= lg->cap_words) {
