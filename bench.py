@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--shape", default=SHAPE)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--stream-seconds", type=float, default=30.0,
+    ap.add_argument("--stream-seconds", type=float, default=600.0,
                     help="secondary figure: BASELINE configs[2] — CaptureStreamToText over this many seconds of synthetic microphone "
                          "audio with the `small` multilingual shape (every 0.3 s the grown buffer is transcribed again, ragged audio_ctx)")
     ap.add_argument("--no-config4", action="store_true", help="skip the BASELINE configs[4] figure (large-v3 q5_1, beam 5: ~1 min of model synthesis)")

@@ -152,7 +152,13 @@ struct whisper_full_params whisper_full_default_params(enum whisper_sampling_str
 }
 
 // the context's own state is one more whisper_state (api_state.cpp), as in the reference (W/whisper.cpp:5809-5815)
-static inline struct whisper_state * own_state(struct whisper_context * ctx) { return ctx ? reinterpret_cast<struct whisper_state *>(ctx->state) : nullptr; }
+// An entry point that works on the CONTEXT (lock-step work set, DSP scratch, probes) and, through it, on the context's own state: the context's
+// lock, then that state's (the order every path takes them in; a *_with_state call holds a state's lock only and never asks for the context's)
+struct CtxScope {
+    std::unique_lock<std::recursive_mutex> lk, lks;
+    explicit CtxScope(struct whisper_context * c) : lk(c->mu) { if (State * st = c->state.own) lks = std::unique_lock<std::recursive_mutex>(st->mu); }
+};
+static inline struct whisper_state * own_state(struct whisper_context * ctx) { return ctx ? reinterpret_cast<struct whisper_state *>(ctx->state.get()) : nullptr; }
 
 int whisper_full(struct whisper_context * ctx, struct whisper_full_params params, const float * samples, int n_samples) {
     return whisper_full_with_state(ctx, own_state(ctx), params, samples, n_samples);
@@ -352,7 +358,7 @@ static float * dsp_scratch(whisper_context * ctx, size_t bytes) {
 
 int wmi_downmix_stereo(struct whisper_context * ctx, const float * frames, int n_frames, int on_device, float * mono_out) {
     if (!ctx || !ctx->state || ctx->host_only || !frames || !mono_out || n_frames < 0) return -1;
-    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    CtxScope lk(ctx);
     if (!HIP_OK(hipSetDevice(ctx->device))) return -2;
     hipStream_t s = ctx->state->dev.stream;
     if (n_frames == 0) return 0;
@@ -368,7 +374,7 @@ int wmi_resample(struct whisper_context * ctx, const float * src, int n_frames, 
                  float * dst, int dst_capacity) {
     if (!ctx || !ctx->state || ctx->host_only || !src || !dst || n_frames < 0 || src_rate <= 0 || dst_rate <= 0 || dst_capacity < 0 ||
         converter < 0 || converter > 2) return -1;
-    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    CtxScope lk(ctx);
     if (!HIP_OK(hipSetDevice(ctx->device))) return -2;
     hipStream_t s = ctx->state->dev.stream;
     if (src_rate == dst_rate) {                                                                    // src/speech_to_text.cpp:38-42
@@ -420,7 +426,7 @@ int wmi_resample(struct whisper_context * ctx, const float * src, int n_frames, 
 
 int wmi_selftest_ts_refine(struct whisper_context * ctx, const float * envelope, int n, const int * s0s1, int n_tok, float * sums, float * thold, int * walks) {
     if (!ctx || !envelope || n <= 0 || !s0s1 || n_tok <= 0 || n_tok > 4096 || !sums || !thold || !walks) return -1;
-    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    CtxScope lk(ctx);
     if (!compute_ready(*ctx, __func__)) return -2;
     try {
         (void) hipSetDevice(ctx->device);
@@ -483,7 +489,7 @@ int wmi_vad(struct whisper_context * ctx, const float * pcm, int n_samples, int 
     if (!ctx || !ctx->state || ctx->host_only || !pcm || n_samples < 0) return -1;
     const int n_win = WHISPER_SAMPLE_RATE * 3, n_last = (WHISPER_SAMPLE_RATE * 500) / 1000;      // src/speech_to_text.cpp:381-386
     if (n_samples < n_win) return 0;                                                              // not enough accumulated audio
-    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    CtxScope lk(ctx);
     if (!HIP_OK(hipSetDevice(ctx->device))) return -2;
     hipStream_t s = ctx->state->dev.stream;
     // alpha exactly as the host computes it (:54-56): Math_PI is a double constant, rc is rounded to float
@@ -507,7 +513,7 @@ int wmi_vad(struct whisper_context * ctx, const float * pcm, int n_samples, int 
 }
 
 int wmi_pcm_to_mel_device(struct whisper_context * ctx, const float * d_samples, int n_samples) {
-    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    CtxScope lk(ctx);
     (void) hipSetDevice(ctx->device);
     return pcm_to_mel(*ctx, d_samples, n_samples, true) ? 0 : -1;
 }
@@ -515,27 +521,27 @@ int wmi_pcm_to_mel_device(struct whisper_context * ctx, const float * d_samples,
 int wmi_full_device_pcm(struct whisper_context * ctx, struct whisper_full_params params, const float * d_samples, int n_samples,
                         const float * h_samples) {
     if (!ctx || !ctx->state) return -1;
-    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    CtxScope lk(ctx);
     (void) hipSetDevice(ctx->device);
     return full(*ctx, params, h_samples, d_samples, n_samples);
 }
 
 int wmi_set_audio_ctx(struct whisper_context * ctx, int n_audio_ctx) {
-    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    CtxScope lk(ctx);
     if (n_audio_ctx < 0 || n_audio_ctx > ctx->model.hp.n_audio_ctx) return -5;
     ctx->state->exp_n_audio_ctx = n_audio_ctx;
     return 0;
 }
 
 int wmi_mel_dims(struct whisper_context * ctx, int * n_len, int * n_len_org, int * n_mel) {
-    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    CtxScope lk(ctx);
     const Mel & m = ctx->state->mel;
     if (n_len) *n_len = m.n_len; if (n_len_org) *n_len_org = m.n_len_org; if (n_mel) *n_mel = m.n_mel;
     return m.n_len * m.n_mel;
 }
 
 int wmi_get_tensor(struct whisper_context * ctx, const char * name, float * dst, int n) {
-    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    CtxScope lk(ctx);
     (void) hipSetDevice(ctx->device);
     State & st = *ctx->state; DeviceState & d = st.dev; const HParams & hp = ctx->model.hp;
     const int S = hp.n_audio_state, T = st.enc_n_ctx > 0 ? st.enc_n_ctx : hp.n_audio_ctx, Lt = hp.n_text_layer;
@@ -578,7 +584,7 @@ int wmi_get_tensor(struct whisper_context * ctx, const char * name, float * dst,
 }
 
 void wmi_get_timings(struct whisper_context * ctx, int64_t * t6, int32_t * n5) {
-    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    CtxScope lk(ctx);
     const State & s = *ctx->state;
     t6[0] = s.t_mel_us; t6[1] = s.t_encode_us; t6[2] = s.t_decode_us; t6[3] = s.t_batchd_us; t6[4] = s.t_prompt_us; t6[5] = s.t_sample_us;
     n5[0] = s.n_encode; n5[1] = s.n_decode; n5[2] = s.n_batchd; n5[3] = s.n_prompt; n5[4] = s.n_sample;
@@ -587,7 +593,7 @@ void wmi_get_timings(struct whisper_context * ctx, int64_t * t6, int32_t * n5) {
 int wmi_full_batch(struct whisper_context * ctx, struct whisper_full_params params, const float * const * pcm, const int * n_samples,
                    int n_chunks, int pcm_on_device) {
     if (!ctx || !ctx->state || !pcm || !n_samples || n_chunks < 0) return -1;
-    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    CtxScope lk(ctx);
     (void) hipSetDevice(ctx->device);
     params.no_context = true;                 // chunks are independent transcriptions
     return full_batch(*ctx, params, pcm, n_samples, n_chunks, pcm_on_device != 0);
@@ -597,7 +603,7 @@ void wmi_set_lockstep_exact(int on) { k::set_rows_valu(on != 0); k::set_attn_one
 
 int wmi_batch_select(struct whisper_context * ctx, int chunk) {
     if (!ctx) return -1;
-    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    CtxScope lk(ctx);
     if (!ctx->state || !ctx->batch || chunk < 0 || chunk >= (int) ctx->batch->results.size()) return -1;
     ctx->state->result_all = ctx->batch->results[chunk];
     return (int) ctx->state->result_all.size();
@@ -606,7 +612,7 @@ int wmi_batch_select(struct whisper_context * ctx, int chunk) {
 void wmi_get_batch_timings(struct whisper_context * ctx, int64_t * t4, int32_t * n_steps) {
     t4[0] = t4[1] = t4[2] = t4[3] = 0; *n_steps = 0;
     if (!ctx) return;
-    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    CtxScope lk(ctx);
     if (!ctx->batch) return;
     const BatchWork & b = *ctx->batch;
     t4[0] = b.t_mel_us; t4[1] = b.t_encode_us; t4[2] = b.t_decode_us; t4[3] = b.t_emit_us; *n_steps = b.n_steps;
@@ -614,14 +620,14 @@ void wmi_get_batch_timings(struct whisper_context * ctx, int64_t * t4, int32_t *
 
 int wmi_batch_chunk_mode(struct whisper_context * ctx, int chunk) {
     if (!ctx) return -1;
-    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    CtxScope lk(ctx);
     if (!ctx->batch || chunk < 0 || chunk >= (int) ctx->batch->redo.size()) return -1;
     return ctx->batch->redo[chunk];
 }
 
 int wmi_set_batch_replicas(struct whisper_context * ctx, int n) {
     if (!ctx) return -2;                                    // (-1 is a valid answer: "the previous setting was the default")
-    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    CtxScope lk(ctx);
     try {
         if (!ctx->batch) ctx->batch = new BatchWork();
     } catch (const std::exception &) { return -2; }
@@ -822,7 +828,7 @@ int wmi_selftest_seqsum(const float * x, int n, float * out_blocked, float * out
 
 int wmi_step_stamps(struct whisper_context * ctx, double * out, int cap, int chained) {
     if (!ctx || !ctx->state || !out) return -1;
-    std::lock_guard<std::recursive_mutex> lk(ctx->mu);      // the probe replays the context's step: not beside a transcription
+    CtxScope lk(ctx);      // the probe replays the context's step: not beside a transcription
     (void) hipSetDevice(ctx->device);
     try { return step_stamps(*ctx, out, cap, chained != 0); } catch (...) { return -1; }
 }
@@ -831,7 +837,7 @@ void wmi_reload_knobs(void) { k::reload_knobs(); }
 
 int wmi_pair_status(struct whisper_context * ctx, int32_t * out3, int rearm) {
     if (!ctx || !ctx->state) return -1;
-    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    CtxScope lk(ctx);
     DeviceState & d = ctx->state->dev;
     if (out3) { out3[0] = d.pair_fallbacks; out3[1] = d.pair_slow_events; out3[2] = (d.pair_off ? 1 : 0) | (d.pair_backoff > 0 ? 2 : 0); }
     if (rearm) { d.pair_off = false; d.pair_backoff = 0; }
@@ -840,7 +846,7 @@ int wmi_pair_status(struct whisper_context * ctx, int32_t * out3, int rearm) {
 
 double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters) {
     if (!ctx || !ctx->state || iters < 1) return -1.0;
-    std::lock_guard<std::recursive_mutex> lk(ctx->mu);      // the probes replay the context's kernels on its buffers: not beside a transcription
+    CtxScope lk(ctx);      // the probes replay the context's kernels on its buffers: not beside a transcription
     (void) hipSetDevice(ctx->device);
     if (which >= 20) k::reload_knobs();                     // (lab scripts flip the step's switches between probe calls of one process)
     State & st = *ctx->state; DeviceState & d = st.dev; const HParams & hp = ctx->model.hp; const Weights & w = ctx->w;
@@ -1000,7 +1006,7 @@ double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters) {
 // workgroups that reported}.  Returns the number of launches written, -1 when there is nothing to replay.
 int wmi_encoder_gemm_stamps(struct whisper_context * ctx, int chunks, double * out, int cap) {
     if (!ctx || !ctx->state || !out || cap < 1 || ctx->model.quantised) return -1;
-    std::lock_guard<std::recursive_mutex> lk(ctx->mu);
+    CtxScope lk(ctx);
     (void) hipSetDevice(ctx->device);
     State & st = *ctx->state; DeviceState & d = st.dev;
     std::vector<int> rows, seek;

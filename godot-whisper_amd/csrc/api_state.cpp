@@ -5,8 +5,9 @@
 // A whisper_state is this backend's wmi::State: its own KV caches, encoder/decoder activation arenas, HIP stream and
 // captured decode graph on the context's GPU — the same ownership split as the reference (W/whisper.cpp:3001-3120:
 // weights belong to the context, everything mutable to the state).  The compute code reaches its working set through
-// ctx.state, so a *_with_state call installs the caller's state for its duration under the context's lock: calls on
-// one context serialise (one GPU stream per state executes them in order anyway); different contexts are independent.
+// ctx.state, which resolves per THREAD: a *_with_state call installs the caller's state for the calling thread and holds
+// that state's lock.  Calls on one state serialise; calls on different states of one context run concurrently, each on its
+// state's own stream (round 6; before, they took turns on the context's lock).
 
 #include "wmi.h"
 #include "kernels.h"
@@ -20,13 +21,13 @@ namespace {
 
 inline State * S(struct whisper_state * s) { return reinterpret_cast<State *>(s); }
 
+// A *_with_state call: the caller's state is what ctx.state means on THIS thread for the duration of the call (wmi.h: StateSlot), under
+// the STATE's lock — calls on one state serialise, calls on different states of one context run side by side (W/whisper.cpp:5837-5858).
 struct StateScope {
-    whisper_context * ctx; State * saved; std::unique_lock<std::recursive_mutex> lk; BusyScope busy;      // (counted once the lock is held: a waiting caller is not on the GPU)
-    StateScope(whisper_context * c, struct whisper_state * s) : ctx(c), lk(c->mu), busy(c->device) {
-        saved = c->state; c->state = S(s);
+    std::unique_lock<std::recursive_mutex> lk; StateInstall inst; BusyScope busy;      // (counted once the lock is held: a waiting caller is not on the GPU)
+    StateScope(whisper_context * c, struct whisper_state * s) : lk(S(s)->mu), inst(c->state, S(s)), busy(c->device) {
         if (!c->host_only) (void) hipSetDevice(c->device);
     }
-    ~StateScope() { ctx->state = saved; }
 };
 
 bool read_file(const char * path, std::vector<char> & buf) {
@@ -123,7 +124,7 @@ int whisper_pcm_to_mel_phase_vocoder_with_state(struct whisper_context *, struct
     return -1;
 }
 int whisper_pcm_to_mel_phase_vocoder(struct whisper_context * ctx, const float * samples, int n_samples, int n_threads) {
-    return whisper_pcm_to_mel_phase_vocoder_with_state(ctx, ctx ? reinterpret_cast<struct whisper_state *>(ctx->state) : nullptr, samples, n_samples, n_threads);
+    return whisper_pcm_to_mel_phase_vocoder_with_state(ctx, ctx ? reinterpret_cast<struct whisper_state *>(ctx->state.get()) : nullptr, samples, n_samples, n_threads);
 }
 int whisper_set_mel_with_state(struct whisper_context * ctx, struct whisper_state * state, const float * data, int n_len, int n_mel) {
     if (!ctx || !state) return -1;
@@ -179,7 +180,7 @@ int whisper_full_parallel(struct whisper_context * ctx, struct whisper_full_para
     {
         auto cur = params;
         cur.print_realtime = false;
-        ret = whisper_full_with_state(ctx, reinterpret_cast<struct whisper_state *>(ctx->state), cur, samples, offset_samples + per);
+        ret = whisper_full_with_state(ctx, reinterpret_cast<struct whisper_state *>(ctx->state.get()), cur, samples, offset_samples + per);
     }
     for (int i = 0; i < n_processors - 1; ++i) {
         const int start = offset_samples + (i + 1) * per;
@@ -202,7 +203,7 @@ int whisper_full_parallel(struct whisper_context * ctx, struct whisper_full_para
             if (!main.result_all.empty()) seg.t0 = std::max(seg.t0, main.result_all.back().t1);
             main.result_all.push_back(std::move(seg));
             if (params.new_segment_callback)
-                params.new_segment_callback(ctx, reinterpret_cast<struct whisper_state *>(ctx->state), 1, params.new_segment_callback_user_data);
+                params.new_segment_callback(ctx, reinterpret_cast<struct whisper_state *>(ctx->state.get()), 1, params.new_segment_callback_user_data);
         }
         main.t_mel_us += si.t_mel_us; main.t_sample_us += si.t_sample_us; main.t_encode_us += si.t_encode_us;
         main.t_decode_us += si.t_decode_us; main.t_batchd_us += si.t_batchd_us; main.t_prompt_us += si.t_prompt_us;

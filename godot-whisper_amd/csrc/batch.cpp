@@ -33,10 +33,9 @@ template <typename T> bool dalloc(T *& p, size_t n_elems) {
 }
 template <typename T> void dfree(T *& p) { if (p) (void) hipFree(p); p = nullptr; }
 
-struct StateSwap {                          // run per-chunk host logic (mel, envelope, emission) against a lane's state
-    whisper_context & ctx; State * saved;
-    StateSwap(whisper_context & c, State * lane) : ctx(c), saved(c.state) { c.state = lane; }
-    ~StateSwap() { ctx.state = saved; }
+struct StateSwap {                          // run per-chunk host logic (mel, envelope, emission) against a lane's state (this thread only: wmi.h StateSlot)
+    StateInstall inst;
+    StateSwap(whisper_context & c, State * lane) : inst(c.state, lane) {}
 };
 
 State * new_lane_state(whisper_context & ctx) {

@@ -78,10 +78,25 @@ void own_queue_stream_put(int device, hipStream_t s) {
     g_oq_pool[device].push_back(s);
 }
 
+// ---- which state ctx.state is, per thread (wmi.h: StateSlot)
+static thread_local StateInstall * t_state_install = nullptr;
+State * StateSlot::get() const {
+    for (const StateInstall * p = t_state_install; p; p = p->prev) if (p->slot == this) return p->st;
+    return own;
+}
+StateInstall::StateInstall(const StateSlot & sl, State * s) : slot(&sl), st(s), prev(t_state_install) { t_state_install = this; }
+StateInstall::~StateInstall() { t_state_install = prev; }
+StateInstall * state_installs_top() { return t_state_install; }
+void state_installs_set(StateInstall * top) { t_state_install = top; }
+
+static bool init_state_into(whisper_context & ctx, State * st, bool replica_state, hipStream_t adopt);
 bool init_state(whisper_context & ctx, bool replica_state, hipStream_t adopt) {
-    const HParams & hp = ctx.model.hp;
     State * st = new State();
-    ctx.state = st;
+    ctx.state = st;                                          // the context's own state (free_state releases it, also after a failure here)
+    return init_state_into(ctx, st, replica_state, adopt);
+}
+static bool init_state_into(whisper_context & ctx, State * st, bool replica_state, hipStream_t adopt) {
+    const HParams & hp = ctx.model.hp;
     st->device = ctx.device;
     DeviceState & d = st->dev;
     if (!HIP_OK(hipSetDevice(ctx.device))) return false;
@@ -162,12 +177,11 @@ bool init_state(whisper_context & ctx, bool replica_state, hipStream_t adopt) {
 }
 
 State * create_state(whisper_context & ctx) {
-    State * saved = ctx.state;
-    ctx.state = nullptr;
-    State * st = nullptr;
-    if (init_state(ctx, true)) st = ctx.state; else free_state(ctx);        // (a further state: the context's spare streams exist already)
-    ctx.state = saved;
-    return st;
+    // a further state for the same weights (whisper_init_state).  The context's own state is not touched: another thread may be computing on it.
+    State * st = new State();
+    if (init_state_into(ctx, st, true, nullptr)) return st;                // (the context's spare streams exist already)
+    destroy_state(st);
+    return nullptr;
 }
 
 void free_state(whisper_context & ctx) {
@@ -571,14 +585,14 @@ bool decode(whisper_context & ctx, const Batch & batch) {
     d.d_pos = d.d_tokens + n; d.d_rows = d.d_pos + n; d.d_mask = (float *) (d.d_rows + n);
     // WMI_DECODE_TRACE=1 (debug): GPU time between the first and the last command of the call (events) beside the host's wall time
     static const bool trace = getenv("WMI_DECODE_TRACE") != nullptr;
-    static hipEvent_t tr0 = nullptr, tr1 = nullptr;
+    static thread_local hipEvent_t tr0 = nullptr, tr1 = nullptr;      // (probe state per thread: states of one context decode concurrently)
     if (trace) { if (!tr0) { (void) hipEventCreate(&tr0); (void) hipEventCreate(&tr1); } (void) hipEventRecord(tr0, s); }
     HIP_TRY(hipMemcpyAsync(d.d_tokens, p_tok, ((size_t) 3 * n + (size_t) n * n_kv) * 4, hipMemcpyHostToDevice, s));
 
     if (ctx.model.quantised) {
         // WMI_DECODE_STAMPS=k (debug): in-kernel stamps of the k-th several-row call's launches (start, body, the kernels' two mid marks)
         static const int stamp_call = getenv("WMI_DECODE_STAMPS") ? atoi(getenv("WMI_DECODE_STAMPS")) : -1;
-        static int n_multi = 0;
+        static thread_local int n_multi = 0;
         unsigned long long * sbuf = nullptr; constexpr int SMAXL = 512;
         if (stamp_call >= 0 && n > 1 && n_multi++ == stamp_call) {
             const size_t bytes = (size_t) SMAXL * k::STAMP_WAVES * 4 * sizeof(unsigned long long);
@@ -606,7 +620,7 @@ bool decode(whisper_context & ctx, const Batch & batch) {
         int64_t dtq = time_us() - t0;
         { const int64_t done = phase_settle(st, false); if (done > t0) dtq = std::max<int64_t>(0, dtq - (done - t0)); }
         if (trace) {
-            static int64_t t_prev_end = 0;
+            static thread_local int64_t t_prev_end = 0;
             float ms = 0.f; (void) hipEventElapsedTime(&ms, tr0, tr1);
             fprintf(stderr, "[wmi] decode n=%d n_kv=%d: wall %.0f us (enqueue done at %.0f) | first-to-last command on the GPU %.0f us | since the previous call returned %.0f us\n",
                     n, n_kv, (double) dtq, (double) (t_enq - t0), ms * 1e3, t_prev_end ? (double) (t0 - t_prev_end) : 0.0);
@@ -827,20 +841,35 @@ BusyScope::BusyScope(int device) : dev(device & 63), counted(t_busy_depth++ == 0
 BusyScope::~BusyScope() { --t_busy_depth; if (counted) g_busy_transcriptions[dev].fetch_sub(1, std::memory_order_relaxed); }
 int busy_transcriptions(int device) { return g_busy_transcriptions[device & 63].load(std::memory_order_relaxed); }
 
-// per-device turn for a greedy step (see decode_greedy_step).  A plain mutex, not a fair ticket: whoever gets the device next is as good as
-// anyone for throughput, and a fair ticket's next holder may be a descheduled thread (six contexts on the ticket: 10.5 ms per transcription
-// against 4.9 without any turn-taking; 2 - 3 contexts: 4.6 against 10 - 12).  A short spin first: the holder is ~150 us from releasing.
+// per-device turns for greedy steps (see decode_greedy_step): at most `cap` steps of different states / contexts in flight on a device.
+// Round 5 took ONE turn per device (a mutex): several contexts' dependent launch chains, interleaved freely, stretched every launch boundary
+// (six contexts 7.4 ms per transcription).  Round 6 measured how many chains the device carries well — N threads on N states of one context,
+// base.en, ms per transcription (scratch/r06_conc_time.py, profiles/r06f_*):
+//     N                        1      2      3      4      6      8
+//     one turn (round 5)      3.23   2.98   3.11   2.98   3.09   3.20      the chains simply alternate: nothing gained by the threads
+//     two turns               3.24   2.00   1.96   2.46   1.88   2.26
+//     three turns             3.23   2.01   1.59   4.52   2.23   3.76
+//     no turns                3.24   1.91   1.58   5.96   4.11   4.28
+// Three chains side by side are the best the device does, but a fourth anywhere (another thread's encoder counts) breaks it — the runtime
+// multiplexes streams onto few hardware queues (DESIGN hazard 21) — so two turns: 1.3 - 1.7 x one transcription at a time, for every N.
+// WMI_STEP_SLOTS = 1 is round 5's form.  Not a fair queue: whoever gets a free turn next is as good as anyone for throughput, and a fair
+// ticket's next holder may be a descheduled thread.
 namespace {
-std::mutex g_step_turn[64];
+struct StepSlots { std::atomic<int> used{0}; };
+StepSlots g_step_slots[64];
 struct StepTicket {
-    std::mutex * mu = nullptr;
+    StepSlots * sl = nullptr;
     StepTicket(int device, bool take) {
         if (!take) return;
-        std::mutex & m = g_step_turn[device & 63];
-        for (int it = 0; it < 2000; ++it) { if (m.try_lock()) { mu = &m; return; } __builtin_ia32_pause(); }
-        m.lock(); mu = &m;
+        static const int cap = getenv("WMI_STEP_SLOTS") ? std::max(1, atoi(getenv("WMI_STEP_SLOTS"))) : 2;
+        StepSlots & s = g_step_slots[device & 63];
+        for (uint32_t it = 0;; ++it) {
+            int u = s.used.load(std::memory_order_relaxed);
+            if (u < cap && s.used.compare_exchange_weak(u, u + 1, std::memory_order_acquire)) { sl = &s; return; }
+            if ((it & 1023) == 1023) std::this_thread::yield(); else __builtin_ia32_pause();      // (a holder is ~150 us from releasing)
+        }
     }
-    void release() { if (mu) { mu->unlock(); mu = nullptr; } }
+    void release() { if (sl) { sl->used.fetch_sub(1, std::memory_order_release); sl = nullptr; } }
     ~StepTicket() { release(); }
 };
 }
@@ -1028,11 +1057,10 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
         } else d.step_capture_failed = true;
     }
     hs->seq = d.step_seq = (d.step_seq + 1) & k::SAMPLE_SEQ_MASK;
-    // Several greedy transcriptions at once on one device: their dependent launch chains do not overlap usefully — a step leaves no idle GPU
-    // time to fill, and interleaved chains stretch every launch boundary (two contexts: 9.3 ms per transcription against 3.5 alone,
-    // profiles/r05g_* §9).  A step therefore owns the device from its launch to its sample whenever another transcription is in flight: a
-    // turn per device (a mutex), held ~150 us; alone, nothing is taken.  (WMI_NO_STEP_TICKET=1: off.  The general decode() path — beam search,
-    // t > 0 — has host work between its steps and gains from running side by side: replica contexts, no ticket.)
+    // Several greedy transcriptions at once on one device (states of one context, replica contexts, an in-process pool): two or three dependent
+    // launch chains overlap well, more of them stretch every launch boundary.  A step therefore takes one of the device's (two) turns from its
+    // launch to its sample whenever another device call is in flight; alone, nothing is taken (StepTicket above has the measurements).
+    // (WMI_NO_STEP_TICKET=1: off.  The general decode() path — beam search, t > 0 — has host work between its steps: no ticket.)
     static const bool no_ticket = getenv("WMI_NO_STEP_TICKET") != nullptr;
     StepTicket ticket(ctx.device, !no_ticket && !solo);
     if (use_graph && exec) {

@@ -170,11 +170,11 @@ int full(whisper_context & ctx, whisper_full_params params, const float * sample
 
     while (true) {
         if (params.progress_callback)
-            params.progress_callback(&ctx, (whisper_state *) ctx.state, (100 * (seek - seek_start)) / (seek_end - seek_start),
+            params.progress_callback(&ctx, (whisper_state *) ctx.state.get(), (100 * (seek - seek_start)) / (seek_end - seek_start),
                                      params.progress_callback_user_data);
         if (seek + 100 >= seek_end) break;
         if (params.encoder_begin_callback &&
-            !params.encoder_begin_callback(&ctx, (whisper_state *) ctx.state, params.encoder_begin_callback_user_data)) {
+            !params.encoder_begin_callback(&ctx, (whisper_state *) ctx.state.get(), params.encoder_begin_callback_user_data)) {
             WMI_ERR("%s: encoder_begin_callback returned false - aborting\n", __func__);
             break;
         }

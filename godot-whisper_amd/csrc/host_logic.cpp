@@ -199,7 +199,7 @@ void process_logits(whisper_context & ctx, Decoder & dec, const whisper_full_par
     for (int i = 0; i < lang_count(); ++i) ban(v.sot + 1 + i);       // always all 100 ids
 
     if (params.logits_filter_callback)
-        params.logits_filter_callback(&ctx, (whisper_state *) ctx.state, hist.data(), (int) hist.size(), logits.data(),
+        params.logits_filter_callback(&ctx, (whisper_state *) ctx.state.get(), hist.data(), (int) hist.size(), logits.data(),
                                       params.logits_filter_callback_user_data);
 
     if (params.suppress_non_speech_tokens) {

@@ -22,6 +22,7 @@ struct Pool {
     uint64_t gen = 0;                          // generation of the current job (guarded by m)
     bool stop = false;
     const std::function<void(int)> * fn = nullptr;
+    StateInstall * installs = nullptr;         // the job's caller's view of ctx.state (wmi.h: StateSlot), taken on by the workers for the job
     int n = 0;
     std::atomic<uint64_t> next{0};             // (generation << 32) | next task index: a worker of an older job can never claim
     std::atomic<int> done{0};
@@ -47,15 +48,17 @@ struct Pool {
     void work() {
         uint64_t seen = 0;
         for (;;) {
-            const std::function<void(int)> * f; int cnt; uint64_t g;
+            const std::function<void(int)> * f; int cnt; uint64_t g; StateInstall * inst;
             {
                 std::unique_lock<std::mutex> lk(m);
                 cv.wait(lk, [&] { return stop || gen != seen; });
                 if (stop) return;
-                seen = g = gen; f = fn; cnt = n;
+                seen = g = gen; f = fn; cnt = n; inst = installs;
             }
             t_in_task_set(true);
+            state_installs_set(inst);
             drain(g, f, cnt);
+            state_installs_set(nullptr);
             t_in_task_set(false);
         }
     }
@@ -86,7 +89,7 @@ void pool_run(int n_tasks, const std::function<void(int)> & fn) {
     uint64_t g;
     {
         std::lock_guard<std::mutex> lk(p->m);
-        g = ++p->gen; p->fn = &fn; p->n = n_tasks;
+        g = ++p->gen; p->fn = &fn; p->n = n_tasks; p->installs = state_installs_top();
         p->done.store(0, std::memory_order_relaxed);
         p->next.store((g & 0xffffffffu) << 32, std::memory_order_release);
     }

@@ -254,6 +254,10 @@ struct DeviceState {
 };
 
 struct State {
+    // every entry point that computes on this state holds this for the duration of the call (api_state.cpp: StateScope): calls on ONE
+    // state serialise, calls on different states of one context run concurrently on their own streams (the reference's
+    // whisper_full_parallel runs whisper_full_with_state on its states from parallel threads: W/whisper.cpp:5837-5858)
+    std::recursive_mutex mu;
     int     device = 0;                           // HIP device of the arenas below
     int64_t t_sample_us = 0, t_encode_us = 0, t_decode_us = 0, t_batchd_us = 0, t_prompt_us = 0, t_mel_us = 0;
     int32_t n_sample = 0, n_encode = 0, n_decode = 0, n_batchd = 0, n_prompt = 0, n_fail_p = 0, n_fail_h = 0;
@@ -314,12 +318,37 @@ struct BatchWork {
 
 } // namespace wmi
 
+namespace wmi {
+// The context's `state` member.  The compute code reaches its working set through ctx.state; which state that is depends on the CALLING
+// THREAD: a *_with_state entry point (or a lock-step lane, batch.cpp) installs the caller's state for the thread (StateInstall), every
+// other thread keeps seeing its own installation or, with none, the context's own state.  Nothing is swapped inside the context, so two
+// threads can compute on two states of one context at the same time.
+struct StateSlot {
+    State * own = nullptr;                       // the state made with the context (whisper_init_from_*), null for the *_no_state constructors
+    State * get() const;
+    operator State * () const { return get(); }
+    State * operator->() const { return get(); }
+    State & operator*() const { return *get(); }
+    StateSlot & operator=(State * s) { own = s; return *this; }
+};
+struct StateInstall {                            // RAII: `st` is what `slot` resolves to on this thread until destruction (nests)
+    const StateSlot * slot; State * st; StateInstall * prev;
+    StateInstall(const StateSlot & sl, State * s);
+    ~StateInstall();
+    StateInstall(const StateInstall &) = delete; StateInstall & operator=(const StateInstall &) = delete;
+};
+// the calling thread's installations, to hand them to a helper thread for the duration of a job (pool.cpp: the tasks of pool_run see
+// ctx.state as their caller does; the chain lives on the caller's stack, which outlives the job)
+StateInstall * state_installs_top();
+void state_installs_set(StateInstall * top);
+}
+
 struct whisper_context {
     int64_t t_load_us = 0, t_start_us = 0;
     whisper_context_params params{};
     wmi::ModelFile model;
     wmi::Weights   w;
-    wmi::State *   state = nullptr;
+    wmi::StateSlot state;
     int            device = 0;
     bool           host_only = false;   // vocabulary + host logic only (tests); every compute call fails loudly
     // loaded from a payload-less header image (wmi_init_from_header): the arena is allocated, zeroed and laid out but its bytes
@@ -332,8 +361,8 @@ struct whisper_context {
     float * d_sinc[3] = {nullptr, nullptr, nullptr};   // resampler coefficient tables on the device, by converter (wmi_resample)
     float * vad_res = nullptr;          // pinned host memory the VAD kernel writes {decision, energy_all, energy_last} into (wmi_vad)
     float * dsp_scratch = nullptr; size_t dsp_scratch_bytes = 0;   // grow-only device staging of the host-pointer forms of wmi_vad / wmi_downmix_stereo / wmi_resample
-    // the compute code reaches its working set through ctx.state: the *_with_state entry points install the caller's
-    // state for the duration of the call under this lock (calls on one context serialise; the GPU runs them in order anyway)
+    // guards what belongs to the CONTEXT: the lock-step work set (wmi_full_batch), the DSP scratch, state creation, the probes.  Compute
+    // on a state takes the state's own lock (wmi::State::mu), not this one.
     std::recursive_mutex mu;
 };
 

@@ -98,6 +98,76 @@ def test_caller_owned_states_are_independent_working_sets(product_lib):
     node.close()
 
 
+@pytest.mark.parametrize("strategy", ["greedy", "beam3"])
+def test_states_of_one_context_compute_concurrently(product_lib, strategy):
+    """whisper_full_with_state from parallel threads on different states of ONE context — what the reference's whisper_full_parallel does
+    with its states (W/whisper.cpp:5837-5858).  Every result equals the one a state with the same call history gives when the calls
+    take turns (a state carries its decoders' mt19937 generators from call to call, so beam search depends on the history — as in the
+    reference), and the calls really run side by side: the two threads finish well before the sum of their calls' solo durations
+    (before round 6 every *_with_state call took the context's one lock and the threads took turns)."""
+    import os, threading, time
+    lib = product_lib
+    model = synth.make_model("base.en", seed=4242)
+    pcms = [synth.make_pcm(30.0, seed=900 + i) for i in range(4)]
+    node = host.SpeechToText(lib); node.set_language_model(model); ctx = node.ctx
+    if strategy == "greedy":
+        p = _params(lib)
+    else:
+        p = lib.whisper_full_default_params(abi.WHISPER_SAMPLING_BEAM_SEARCH)
+        p.language = b"en"; p.temperature_inc = 0.0; p.print_progress = False; p.token_timestamps = True; p.beam_search.beam_size = 3
+    p.max_tokens = 24
+    reps = 6
+    order = [list(range(len(pcms))), list(range(len(pcms)))[::-1]]      # the two threads are never on the same audio at the same time
+    # taking turns: two states, thread t's call sequence on state t, one call after the other
+    alone = [lib.whisper_init_state(ctx) for _ in range(2)]
+    assert all(alone)
+    want = [[] for _ in alone]; solo = 0.0
+    for t, st in enumerate(alone):
+        for rep in range(2 + reps):
+            for i in order[t]:
+                t0 = time.perf_counter()
+                assert lib.whisper_full_with_state(ctx, st, p, _fp(pcms[i]), pcms[i].size) == 0
+                if rep >= 2:
+                    solo += time.perf_counter() - t0               # the timed calls of the side-by-side run below, alone
+                else:
+                    want[t].append(_state_segments(lib, ctx, st))
+    assert want[0][0] and want[0][0] != want[0][1]
+    # side by side: two fresh states, the same call sequences from two threads
+    states = [lib.whisper_init_state(ctx) for _ in range(2)]
+    assert all(states)
+    got = [[] for _ in states]; errs = []
+    def work(t, n_reps, check):
+        try:
+            for rep in range(n_reps):
+                for i in order[t]:
+                    rc = lib.whisper_full_with_state(ctx, states[t], p, _fp(pcms[i]), pcms[i].size)
+                    if check:
+                        got[t].append((rc, _state_segments(lib, ctx, states[t])))
+                    elif rc != 0:
+                        errs.append(rc)
+        except Exception as e:                                    # pragma: no cover
+            errs.append(e)
+    def run(n_reps, check):
+        th = [threading.Thread(target=work, args=(t, n_reps, check)) for t in range(len(states))]
+        t0 = time.perf_counter()
+        for x in th: x.start()
+        for x in th: x.join()
+        return time.perf_counter() - t0
+    run(2, True)                                                  # checked pass: every result read back between the calls
+    assert not errs, errs
+    for t in range(len(states)):
+        assert len(got[t]) == len(want[t])
+        for c, ((rc, segs), w) in enumerate(zip(got[t], want[t])):
+            assert rc == 0 and segs == w, (strategy, t, c)
+    wall = run(reps, False)                                       # timed pass: the calls only
+    assert not errs, errs
+    print(f"{strategy}: two threads x {reps * len(pcms)} calls: {wall * 1e3:.1f} ms side by side, {solo * 1e3:.1f} ms as the sum of the calls alone ({solo / wall:.2f} x)")
+    assert wall < float(os.environ.get("WMI_TEST_CONC_BOUND", "0.8")) * solo, (wall, solo)
+    for st in states + alone:
+        lib.whisper_free_state(st)
+    node.close()
+
+
 def test_no_state_and_loader_constructors(product_lib):
     """whisper_init_*_no_state leaves the context without a working set (whisper_full refuses), whisper_init_state supplies
     one; the loader-callback constructor reads the same image through read/eof/close (W/whisper.cpp:3178-3338)."""
