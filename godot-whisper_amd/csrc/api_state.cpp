@@ -14,6 +14,7 @@
 
 #include <cstring>
 #include <fstream>
+#include <thread>
 
 using namespace wmi;
 
@@ -159,8 +160,8 @@ int whisper_full_with_state(struct whisper_context * ctx, struct whisper_state *
 }
 
 // W/whisper.cpp:5817-5924.  The split, the per-piece parameters, the time offsets, the no-overlap clamp, the callback
-// replay and the timing bookkeeping are the reference's; the pieces run one after the other on their own states
-// instead of on host threads (one GPU: concurrency comes from wmi_full_batch, which takes independent chunks).
+// replay, the timing bookkeeping AND the threads are the reference's: pieces 1.. run on host threads of their own, each on
+// its own state (own stream), piece 0 on the caller's thread.
 int whisper_full_parallel(struct whisper_context * ctx, struct whisper_full_params params, const float * samples, int n_samples, int n_processors) {
     if (n_processors == 1) return whisper_full(ctx, params, samples, n_samples);
     if (!ctx || !ctx->state || n_processors < 1) return -1;
@@ -176,21 +177,28 @@ int whisper_full_parallel(struct whisper_context * ctx, struct whisper_full_para
         if (!st) { for (auto * s : states) whisper_free_state(s); return -1; }
         states.push_back(st);
     }
+    // the pieces 1.. on threads of their own, piece 0 on this one (W/whisper.cpp:5837-5858): every piece computes on its own state, under that
+    // state's lock, on that state's stream (round 6; before, the pieces took turns)
     int ret;
     {
+        std::vector<std::thread> workers;
+        struct Joiner { std::vector<std::thread> & t; ~Joiner() { for (auto & x : t) if (x.joinable()) x.join(); } } joiner{workers};
+        static const bool serial = getenv("WMI_PARALLEL_SERIAL") != nullptr;      // debug / A-B: one piece after the other
+        for (int i = 0; i < n_processors - 1; ++i) {
+            const int start = offset_samples + (i + 1) * per;
+            const int n_cur = (i == n_processors - 2) ? n_samples - start : per;
+            auto cur = params;
+            cur.offset_ms = 0;
+            cur.print_progress = false; cur.print_realtime = false;
+            cur.new_segment_callback = nullptr; cur.new_segment_callback_user_data = nullptr;
+            cur.progress_callback = nullptr;    cur.progress_callback_user_data = nullptr;
+            struct whisper_state * st = states[i];
+            auto piece = [ctx, st, cur, samples, start, n_cur]() { (void) whisper_full_with_state(ctx, st, cur, samples + start, n_cur); };   // the reference drops the workers' return codes too
+            if (serial) piece(); else workers.emplace_back(piece);
+        }
         auto cur = params;
         cur.print_realtime = false;
         ret = whisper_full_with_state(ctx, reinterpret_cast<struct whisper_state *>(ctx->state.get()), cur, samples, offset_samples + per);
-    }
-    for (int i = 0; i < n_processors - 1; ++i) {
-        const int start = offset_samples + (i + 1) * per;
-        const int n_cur = (i == n_processors - 2) ? n_samples - start : per;
-        auto cur = params;
-        cur.offset_ms = 0;
-        cur.print_progress = false; cur.print_realtime = false;
-        cur.new_segment_callback = nullptr; cur.new_segment_callback_user_data = nullptr;
-        cur.progress_callback = nullptr;    cur.progress_callback_user_data = nullptr;
-        (void) whisper_full_with_state(ctx, states[i], cur, samples + start, n_cur);       // the reference drops the workers' return codes too
     }
 
     const int64_t offset_t = (int64_t) (params.offset_ms / 10.0);
