@@ -450,6 +450,11 @@ def main():
             tb16 = (time.perf_counter() - tb0) / reps16
             out["batch16"] = {"workload": "16 x 30 s chunks per call in lock-step, same params", "value": round(nb16 * CHUNK_S / tb16, 1),
                               "unit": "x realtime", "ms_per_call": round(tb16 * 1e3, 3)}
+            try:
+                u16 = encoder_gemm_utilisation(lib, ctx, 16, 2030.0)
+                if u16: out["encoder_gemm_mfma_utilisation_batch16"] = u16
+            except Exception as e:  # pragma: no cover
+                out["encoder_gemm_mfma_utilisation_batch16_error"] = repr(e)
         # ---- CPU baseline on this box's host cores (bounded sample), rank 0 / N=1 only
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(model_bytes, pcm_host[0])
@@ -691,7 +696,8 @@ def encoder_gemm_utilisation(lib, ctx, chunks: int, measured_peak_tflops: float 
     """`MFMA utilisation` on the encoder GEMMs = (conv + projection + MLP + cross K/V FLOP) / (time in those kernels x
     peak).  Times are IN SITU: one encoder pass with a probe slice on every gemm() launch (wmi_encoder_gemm_stamps: first workgroup
     entered -> last workgroup done, taken by the kernels themselves), not back-to-back loops of one warm shape.  FLOP = 2 M N K of each
-    launch as launched (the stacked-chunk conv launches include their guard rows: < 0.4 %)."""
+    launch as launched (the stacked-chunk conv launches include their guard rows: < 0.4 %), except q|k|v of lock-step chunks, whose
+    launch covers 1504 rows per chunk (every chunk on a 16-row boundary): the 1500 real rows are counted."""
     cap = 128
     buf = (C.c_double * (6 * cap))()
     n = lib.wmi_encoder_gemm_stamps(ctx, chunks, buf, cap)
@@ -708,6 +714,8 @@ def encoder_gemm_utilisation(lib, ctx, chunks: int, measured_peak_tflops: float 
         epi, M, N, K = int(epi), int(M), int(N), int(K)
         if us <= 0:
             continue
+        if epi == 4 and chunks > 1:
+            M = min(M, chunks * 1500)                   # q|k|v of lock-step chunks is launched over 1504 rows per chunk (16-row boundaries): count the 1500
         seen_conv2 = seen_conv2 or epi == 3
         if epi == 1:
             key = (1, "mlp0") if seen_conv2 else (1, "conv1")
