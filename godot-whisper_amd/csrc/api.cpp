@@ -341,7 +341,7 @@ size_t wmi_model_header(const void * model, size_t model_size, void * out, size_
 void * wmi_arena_ptr(struct whisper_context * ctx) { return ctx ? ctx->w.arena : nullptr; }
 size_t wmi_weights_bytes(struct whisper_context * ctx, int which) {
     if (!ctx) return 0;
-    return which == 0 ? ctx->w.arena_bytes : which == 1 ? ctx->w.matrix_bytes : which == 2 ? (size_t) ctx->w.qtype : 0;
+    return which == 0 ? ctx->w.arena_bytes : which == 1 ? ctx->w.matrix_bytes : which == 2 ? (size_t) ctx->w.qtype : which == 3 ? k::qweights_f16_cached_bytes() : 0;
 }
 
 // grow-only device staging for the host-pointer forms (a hipMalloc / hipFree pair per call costs more than the kernels: the VAD call

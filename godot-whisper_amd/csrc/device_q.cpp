@@ -60,7 +60,8 @@ bool encode_layers_q_on(whisper_context & ctx, const EncBufsQ & e, hipStream_t s
     const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
     const int S = hp.n_audio_state, H = hp.n_audio_head, La = hp.n_audio_layer, Lt = hp.n_text_layer;
     const int T = e.T, M = e.nb * e.T;
-    const k::Q8Rows A = e.A, A4 = e.A4;
+    k::Q8Rows A = e.A, A4 = e.A4;
+    A.w_resident_ok = A4.w_resident_ok = true;              // the encoder's matrices: resident f16 images beside the blocks (k_quant.hip)
     const int qt = w.qtype;
     const float kq_scale = 1.0f / sqrtf((float) S / H);
     for (int il = 0; il < La; ++il) {

@@ -24,6 +24,8 @@
 //   k_qembed    token embedding gather with dequantisation
 
 #include "kernels.h"
+#include <map>
+#include <mutex>
 #include "wave_ops.h"
 
 #include <algorithm>
@@ -1137,6 +1139,51 @@ template <int QT> static void qdequant_launch(const uint8_t * Wt, int64_t row0, 
 
 } // namespace
 
+// ---- resident f16 images of the matrices that the f16 form multiplies with (round 6, OPT-IN: WMI_QENC_F16_CACHE=1).  The scratch image above
+// is rewritten for every projection of every encode (large-v3 q5_1: 1.26 GB of f16(d q + m) written and re-read per 30 s chunk); with the
+// images kept beside the blocks (large-v3: + 1.7 GB of HBM for the encoder's matrices and the cross K | V projections; the decoder's
+// matrices — the bytes a token streams — stay quantised only) that pass disappears.  Measured on large-v3 q5_1: encoder 6.70 -> 6.51 ms
+// (the pass was already fused into the row quantiser's launch and mostly hidden behind it) — 0.5 % of a chunk for 1.7 GB, so the default
+// stays "quantised blocks only".  The image is the one k_qdequant writes: the products are the same bits with and without it.
+namespace {
+struct F16Image { __half * p = nullptr; size_t bytes = 0; };
+std::mutex g_f16img_mu;
+std::map<const void *, F16Image> g_f16img;               // key: first tile of the cached row range (device address: unique per arena)
+std::atomic<size_t> g_f16img_bytes{0};
+}
+size_t qweights_f16_cached_bytes() { return g_f16img_bytes.load(std::memory_order_relaxed); }
+void qweights_f16_release(const void * lo, const void * hi) {
+    std::lock_guard<std::mutex> lk(g_f16img_mu);
+    for (auto it = g_f16img.begin(); it != g_f16img.end();) {
+        if (it->first >= lo && it->first < hi) { (void) hipFree(it->second.p); g_f16img_bytes.fetch_sub(it->second.bytes, std::memory_order_relaxed); it = g_f16img.erase(it); }
+        else ++it;
+    }
+}
+// rows [row0, row0 + rows) of W as a resident f16 image [rows][K]; nullptr: not cached (switched off, no memory to spare, allocation failed)
+static const __half * qweights_f16_get(QMat W, int64_t row0, int64_t rows, int K, hipStream_t st) {
+    static const int mode = getenv("WMI_QENC_F16_CACHE") ? atoi(getenv("WMI_QENC_F16_CACHE")) : 0;
+    if (mode == 0 || !W.tiles || (row0 % 32) != 0) return nullptr;
+    const size_t tile_b = (size_t) q_tile_bytes(W.qtype);
+    const void * key = W.tiles + (size_t) (row0 / 32) * (size_t) (K / 64) * tile_b;
+    std::lock_guard<std::mutex> lk(g_f16img_mu);
+    auto it = g_f16img.find(key);
+    if (it != g_f16img.end()) return it->second.bytes == (size_t) rows * K * sizeof(__half) ? it->second.p : nullptr;
+    const size_t bytes = (size_t) rows * K * sizeof(__half);
+    { size_t fr = 0, tot = 0; if (hipMemGetInfo(&fr, &tot) != hipSuccess || fr < bytes + ((size_t) 16 << 30)) return nullptr; }      // (never the last 16 GB)
+    F16Image img;
+    if (hipMalloc((void **) &img.p, bytes) != hipSuccess) { (void) hipGetLastError(); return nullptr; }
+    img.bytes = bytes;
+    qdequant(W, row0, rows, K, img.p, st);
+    (void) hipStreamSynchronize(st);                      // (once per matrix: other states' streams may use the image from here on)
+    g_f16img[key] = img; g_f16img_bytes.fetch_add(bytes, std::memory_order_relaxed);
+    return img.p;
+}
+bool qweights_f16_resident(const QMat & W) {
+    if (!W.tiles) return false;
+    std::lock_guard<std::mutex> lk(g_f16img_mu);
+    return g_f16img.find((const void *) W.tiles) != g_f16img.end();
+}
+
 static int qgemm_f16_rows() {
     // f16 form (see k_qdequant) from WMI_QGEMM_F16_ROWS activation rows on (0 = never: the block-dot kernel for every M)
     static const int v = getenv("WMI_QGEMM_F16_ROWS") ? atoi(getenv("WMI_QGEMM_F16_ROWS")) : 256;
@@ -1162,7 +1209,9 @@ bool quantize_rows(const float * x32, const __half * x16, int M, int K, const fl
                    int qtype, Q8Rows out, float * out32, __half * out16, hipStream_t st, const QMat * W_next, int N_next) {
     if (M <= 0) return false;
     static const bool fuse = getenv("WMI_QGEMM_NO_FUSED_DEQ") == nullptr;    // A/B knob
-    if (fuse && W_next && W_next->tiles && W_next->qtype == qtype && out.deq && out.wdeq && qgemm_f16_rows() > 0 && M >= qgemm_f16_rows() &&
+    // (a projection whose matrix may be a resident f16 image gets it from qgemm — made on first use — not from this launch)
+    static const bool resident_off = !(getenv("WMI_QENC_F16_CACHE") && atoi(getenv("WMI_QENC_F16_CACHE")) != 0);
+    if (fuse && W_next && (resident_off || !out.w_resident_ok) && W_next->tiles && W_next->qtype == qtype && out.deq && out.wdeq && qgemm_f16_rows() > 0 && M >= qgemm_f16_rows() &&
         (K % 64) == 0 && (N_next % 32) == 0 && (size_t) N_next * K <= out.wdeq_elems) {
         // the projection that follows takes the f16 form: its weight image is written by this launch (qgemm is told through Q8Rows::wdeq_ready)
         switch (qtype) {
@@ -1204,6 +1253,10 @@ void qgemm(int epi, const GemmArgs & a, Q8Rows A, QMat W, hipStream_t st) {
     if (f16_rows > 0 && a.M >= f16_rows && A.deq && A.wdeq && (a.K % 64) == 0 && (a.N % 32) == 0) {
         const int64_t cap = (int64_t) (A.wdeq_elems / (size_t) a.K) / 32 * 32;               // weight rows the image holds
         GemmArgs g = a; g.A = A.deq; g.lda = a.K; g.W = A.wdeq; g.ldw = a.K;
+        if (!(A.wdeq_ready && A.wdeq_of == (const void *) W.tiles)) {
+            // the whole matrix as a resident image (made on first use; see qweights_f16_get): no dequantisation pass, no layer groups
+            if (A.w_resident_ok) if (const __half * img = qweights_f16_get(W, 0, a.N, a.K, st)) { g.W = img; gemm(epi, g, st); return; }
+        }
         if (epi == EPI_CROSS_KV && cap >= 2 * a.S) {
             // the decoder layers' K | V projections, as many layers at a time as the image holds
             const int layers = a.N / (2 * a.S), per = (int) std::min<int64_t>(layers, cap / (2 * a.S));

@@ -404,7 +404,8 @@ struct QMat { const uint8_t * tiles = nullptr; int qtype = QT_NONE; };
 // dequantised weight matrix (or a group of cross K | V layers) [rows][K] f16
 // wdeq_ready: the image already holds the matrix the next qgemm multiplies with (written by quantize_rows' fused launch)
 struct Q8Rows { int8_t * qs; float * d; float * s; int ldm; __half * deq = nullptr; __half * wdeq = nullptr; size_t wdeq_elems = 0; bool wdeq_ready = false;
-                const void * wdeq_of = nullptr; };     // wdeq_of: the matrix (QMat::tiles) whose f16 image wdeq holds when wdeq_ready — qgemm checks it
+                const void * wdeq_of = nullptr;        // wdeq_of: the matrix (QMat::tiles) whose f16 image wdeq holds when wdeq_ready — qgemm checks it
+                bool w_resident_ok = false; };         // the caller's matrices may be kept as resident f16 images (the encoder's: k_quant.hip qweights_f16_get)
 // rows -> q8.  Exactly one source: x32 (+ optional LayerNorm gain/bias: y = LN(x) * g + b in f32, the reference quantises that
 // f32 tensor) or x16 (an f16 tensor, e.g. the GELU output, widened exactly).  out32 / out16: optional copy of the LN result.
 // W_next / N_next (optional): the [N_next][K] matrix of the projection these rows feed.  When that projection will take the f16 form
@@ -415,6 +416,10 @@ bool quantize_rows(const float * x32, const __half * x16, int M, int K, const fl
 // C[M][N] = A_q8[M][K] . W_q[N][K]^T with the GEMM's epilogues (Epi above; GemmArgs fields A / W / lda / ldw unused).
 // N % 128 == 0, K % 64 == 0.
 void qgemm(int epi, const GemmArgs & a, Q8Rows A, QMat W, hipStream_t st);
+// resident f16 images of the matrices the f16 form multiplies with (k_quant.hip: qweights_f16_get): bytes held by the process, and the
+// release of every image whose matrix lies in the arena [lo, hi) (free_weights)
+size_t qweights_f16_cached_bytes();
+void   qweights_f16_release(const void * lo, const void * hi);
 // rows [row0, row0 + rows) of a quantised matrix (row0 % 32 == 0) as f16(d * q + m) [rows][K]
 void qdequant(QMat W, int64_t row0, int64_t rows, int K, __half * out, hipStream_t st);
 

@@ -572,6 +572,7 @@ bool upload_weights(const ModelFile & mf, const uint8_t * host_buf, Weights & w,
 }
 
 void free_weights(Weights & w) {
+    if (w.arena && !w.arena_borrowed) k::qweights_f16_release(w.arena, (const char *) w.arena + w.arena_bytes);      // the f16 images of its matrices
     if (w.arena && !w.arena_borrowed) (void) hipFree(w.arena);
     w.arena = nullptr; w.arena_bytes = 0; w.arena_borrowed = false;
 }

@@ -53,7 +53,8 @@ WHISPER_API struct whisper_context * wmi_init_host_only(const void * buffer, siz
  * (a context that "loads fine" and transcribes from an unfilled arena must not exist).
  * wmi_model_header returns the image size (call with out == NULL to size the buffer), 0 for an invalid model.
  * wmi_weights_bytes: which = 0 the whole arena, 1 the matrices only (what a decoded token streams; quantised models: their
- * blocks), 2 the ggml type of the quantised matrices (0: f16). */
+ * blocks), 2 the ggml type of the quantised matrices (0: f16), 3 the bytes of resident f16 images of quantised ENCODER matrices held by
+ * the process (opt-in, WMI_QENC_F16_CACHE=1: written on first use beside the blocks; 0 by default — the weights are held quantised only). */
 WHISPER_API size_t wmi_model_header(const void * model, size_t model_size, void * out, size_t cap);
 WHISPER_API void * wmi_arena_ptr(struct whisper_context * ctx);
 WHISPER_API struct whisper_context * wmi_init_from_header(const void * header, size_t header_size, int device);
