@@ -450,8 +450,14 @@ def main():
             tb16 = (time.perf_counter() - tb0) / reps16
             out["batch16"] = {"workload": "16 x 30 s chunks per call in lock-step, same params", "value": round(nb16 * CHUNK_S / tb16, 1),
                               "unit": "x realtime", "ms_per_call": round(tb16 * 1e3, 3)}
+            out["batch16"]["groups"] = "two lock-step groups of 8 side by side (replica context; wmi_set_lockstep_groups default from 16 chunks on)"
             try:
+                lib.wmi_set_lockstep_groups(ctx, 1)             # the probe replays ONE 16-row encoder pass on this context's work set
+                for _ in range(3):
+                    tg0 = time.perf_counter(); assert lib.wmi_full_batch(ctx, params, ptrs16, lens16, nb16, 1) == 0; tg1 = time.perf_counter() - tg0
+                out["batch16"]["ms_per_call_one_group"] = round(tg1 * 1e3, 3)
                 u16 = encoder_gemm_utilisation(lib, ctx, 16, 2030.0)
+                lib.wmi_set_lockstep_groups(ctx, 0)
                 if u16: out["encoder_gemm_mfma_utilisation_batch16"] = u16
             except Exception as e:  # pragma: no cover
                 out["encoder_gemm_mfma_utilisation_batch16_error"] = repr(e)

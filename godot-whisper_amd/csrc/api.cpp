@@ -625,6 +625,15 @@ int wmi_batch_chunk_mode(struct whisper_context * ctx, int chunk) {
     return ctx->batch->redo[chunk];
 }
 
+int wmi_set_lockstep_groups(struct whisper_context * ctx, int n) {
+    if (!ctx) return -2;
+    CtxScope lk(ctx);
+    try { if (!ctx->batch) ctx->batch = new BatchWork(); } catch (const std::exception &) { return -2; }
+    const int prev = ctx->batch->groups_wanted;
+    ctx->batch->groups_wanted = n < 0 ? 0 : (n > 4 ? 4 : n);
+    return prev;
+}
+
 int wmi_set_batch_replicas(struct whisper_context * ctx, int n) {
     if (!ctx) return -2;                                    // (-1 is a valid answer: "the previous setting was the default")
     CtxScope lk(ctx);

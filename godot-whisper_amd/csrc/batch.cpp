@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <thread>
+#include <mutex>
 
 namespace wmi {
 
@@ -630,6 +631,63 @@ int full_batch(whisper_context & ctx, whisper_full_params params, const float * 
         WMI_ERR("%s: audio_ctx is larger than the maximum allowed (%d > %d)\n", __func__, params.audio_ctx, hp.n_audio_ctx);
         return -5;
     }
+    // ---- lock-step GROUPS side by side (round 6).  The chunks are dealt to `groups` contiguous ranges, each a lock-step call of its own — range
+    // 0 on this context, the others on replica contexts (own state, stream and work set, the weights borrowed) on host threads of their own.
+    // A chunk's result does not depend on which chunks share its launches (per-row arithmetic; the encoder attention's key split follows the
+    // grid size: bits can differ between groupings in the default mode as they do between chunk counts, never in the exact mode).
+    // Measured, base.en, ms per call with host PCM (scratch/r06_groups_time.py, profiles/r06k_*): one-row transcriptions gain 1.7 x from a second
+    // chain, lock-step rows do not — their launches are 4 - 16 x wider and two 4-row chains take as long per step (207 us) as one 8-row chain
+    // (212): 8 chunks 5.80 - 5.85 (one group) / 5.82 - 5.90 (two) / 6.21 (three); 16 chunks 9.07 - 9.14 / 8.32 - 8.34 / 8.86 — what two groups
+    // of eight win is the width limit of the rows kernels.  Default: two groups from 16 chunks on (WMI_LOCKSTEP_GROUPS / wmi_set_lockstep_groups
+    // set the count for every call of >= 4 chunks; 1 = one chain).
+    static thread_local bool t_in_group = false;
+    if (!t_in_group) {
+        static const int groups_env = getenv("WMI_LOCKSTEP_GROUPS") ? atoi(getenv("WMI_LOCKSTEP_GROUPS")) : 0;
+        int G = ctx.batch->groups_wanted > 0 ? ctx.batch->groups_wanted : groups_env > 0 ? groups_env : (n_chunks >= 16 ? 2 : 1);
+        G = std::max(1, std::min(G, n_chunks / 2));
+        if (G > 1) G = ensure_replicas(ctx, G - 1) + 1;                    // (out of memory: fewer groups)
+        if (G > 1) {
+            std::vector<std::vector<Segment>> all(n_chunks);
+            std::vector<int> all_redo(n_chunks, 0), rets(G, 0), c0(G + 1, 0);
+            for (int g = 0; g < G; ++g) c0[g + 1] = c0[g] + n_chunks / G + (g < n_chunks % G ? 1 : 0);
+            int64_t tm[4] = {0, 0, 0, 0}; int steps = 0, chained = 0;
+            std::mutex merge_mu;
+            auto work = [&](int g) {
+                try {
+                    whisper_context & wc = g == 0 ? ctx : *ctx.batch->replicas[g - 1];
+                    (void) hipSetDevice(ctx.device);
+                    if (g > 0 && wc.batch) wc.batch->groups_wanted = 1;
+                    t_in_group = true;
+                    struct Off { ~Off() { t_in_group = false; } } off;
+                    const int cnt = c0[g + 1] - c0[g];
+                    const int rc = full_batch(wc, params, pcm + c0[g], n_samples + c0[g], cnt, on_device);
+                    rets[g] = rc;
+                    if (rc != 0 || !wc.batch) return;
+                    std::lock_guard<std::mutex> lk(merge_mu);
+                    for (int i = 0; i < cnt; ++i) { all[c0[g] + i] = std::move(wc.batch->results[i]); all_redo[c0[g] + i] = wc.batch->redo[i]; }
+                    tm[0] = std::max(tm[0], wc.batch->t_mel_us); tm[1] = std::max(tm[1], wc.batch->t_encode_us);
+                    tm[2] = std::max(tm[2], wc.batch->t_decode_us); tm[3] = std::max(tm[3], wc.batch->t_emit_us);
+                    steps = std::max(steps, wc.batch->n_steps); chained = std::max(chained, wc.batch->n_chained);
+                } catch (const std::exception & e) {
+                    WMI_ERR("wmi_full_batch: lock-step group %d: %s\n", g, e.what());
+                    rets[g] = -10;
+                } catch (...) { rets[g] = -10; }
+            };
+            {
+                std::vector<std::thread> th;
+                struct Joiner { std::vector<std::thread> & t; ~Joiner() { for (auto & x : t) if (x.joinable()) x.join(); } } joiner{th};
+                for (int g = 1; g < G; ++g) th.emplace_back(work, g);
+                work(0);
+            }
+            for (int g = 0; g < G; ++g) if (rets[g] != 0) return rets[g];
+            BatchWork & bw = *ctx.batch;
+            bw.results = std::move(all); bw.redo = std::move(all_redo);
+            bw.t_mel_us = tm[0]; bw.t_encode_us = tm[1]; bw.t_decode_us = tm[2]; bw.t_emit_us = tm[3]; bw.n_steps = steps; bw.n_chained = chained;
+            bw.groups_last = G;
+            return 0;
+        }
+    }
+    ctx.batch->groups_last = 1;
     const int max_lanes = k::rows_valu_enabled() ? 8 : MAX_LANES;
     if (!ensure_batch(ctx, std::min(n_chunks, max_lanes))) return -2;
     BatchWork & b = *ctx.batch;

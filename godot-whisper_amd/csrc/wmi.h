@@ -313,6 +313,7 @@ struct BatchWork {
     // chunks that cannot advance in lock-step (beam search, t > 0, quantised beams ...) run through the general driver on replica
     // contexts: own state and stream, the weight arena borrowed from this context — see full_batch
     std::vector<whisper_context *> replicas; int replicas_wanted = -1;      // -1: default (WMI_BATCH_REPLICAS, 3)
+    int groups_wanted = 0, groups_last = 1;                  // lock-step groups side by side (0: default = WMI_LOCKSTEP_GROUPS, 2); how many the last call used
     int64_t t_mel_us = 0, t_encode_us = 0, t_decode_us = 0, t_emit_us = 0; int n_steps = 0, n_chained = 0;
 };
 

@@ -28,6 +28,7 @@ DEVICE_API = [
     ("wmi_batch_select", C.c_int, [C.c_void_p, C.c_int]),
     ("wmi_batch_chunk_mode", C.c_int, [C.c_void_p, C.c_int]),
     ("wmi_set_batch_replicas", C.c_int, [C.c_void_p, C.c_int]),
+    ("wmi_set_lockstep_groups", C.c_int, [C.c_void_p, C.c_int]),
     ("wmi_selftest_pool", C.c_int64, [C.c_int, C.c_int]),
     ("wmi_selftest_seqsum", C.c_int, [C.POINTER(C.c_float), C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     ("wmi_get_batch_timings", None, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),

@@ -137,6 +137,15 @@ WHISPER_API void wmi_set_lockstep_exact(int on);
 WHISPER_API int wmi_batch_select(struct whisper_context * ctx, int chunk);
 /* 0: chunk `chunk` was decoded in lock-step; 1: it was run alone (fallback, see above); -1: bad index. */
 WHISPER_API int wmi_batch_chunk_mode(struct whisper_context * ctx, int chunk);
+/* Lock-step calls in GROUPS side by side: wmi_full_batch deals its lock-step chunks to `n` contiguous ranges, each a lock-step call of its
+ * own — range 0 on this context, the others on replica contexts (own state, stream and work set; the weights are borrowed) on host threads
+ * of their own.
+ * n = 0: the default (two groups from 16 chunks on — measured: 16 chunks 9.1 -> 8.3 ms per call, 8 chunks level; WMI_LOCKSTEP_GROUPS
+ * overrides), 1: one chain.  A chunk's result does not depend on the grouping in the
+ * exact mode (wmi_set_lockstep_exact); in the default mode the usual last-bit differences between chunk counts apply.
+ * Returns the previous setting, -2 for a null context. */
+WHISPER_API int wmi_set_lockstep_groups(struct whisper_context * ctx, int n);
+
 /* Chunks that cannot advance in lock-step (beam search, temperature > 0, quantised beams ...) are run through the whisper_full
  * driver, up to 1 + n of them at a time: n replica contexts (own whisper_state and stream, the weight arena shared read-only with
  * `ctx`, ~0.15 GB of state each for base.en, ~0.6 GB for large-v3) work beside `ctx`, chunk c on worker c mod (1 + n).
