@@ -470,6 +470,30 @@ def test_lockstep_chunks_equal_one_at_a_time(product_lib, lockstep_mode, shape, 
         node.close()
 
 
+def test_lockstep_groups_side_by_side_equal_one_group(product_lib, lockstep_mode):
+    """wmi_set_lockstep_groups: the chunks of one wmi_full_batch call as two or three lock-step calls side by side (range 0 on the context,
+    the others on replica contexts, host threads of their own) give every chunk the transcription the one-group call gives it — bit for
+    bit in the exact mode, and (the encoder attention's key split follows the grid size) margin-aware in the default mode."""
+    model = synth.make_model("micro.en", seed=2024)
+    secs = [30.0, 11.0, 4.0, 47.0, 30.0, 22.5, 30.0, 8.0, 30.0, 15.0]
+    pcms = [synth.make_pcm(s, seed=300 + i, gate=(i % 3 == 1)) for i, s in enumerate(secs)]
+    node = host.SpeechToText(product_lib); node.set_language_model(model)
+    try:
+        p = node.full_params("", 0); p.temperature_inc = 0.0
+        assert product_lib.wmi_set_lockstep_groups(node.ctx, 1) >= 0
+        want = node.transcribe_batch(pcms, params=p)
+        assert node.last_ret == 0 and list(node.last_modes) == [0] * len(pcms)
+        for groups in (2, 3):
+            product_lib.wmi_set_lockstep_groups(node.ctx, groups)
+            got = node.transcribe_batch(pcms, params=p)
+            assert node.last_ret == 0 and len(got) == len(pcms) and list(node.last_modes) == [0] * len(pcms)
+            for c, (g, w) in enumerate(zip(got, want)):
+                _assert_same_transcription(g, w, ("groups", groups, c), lockstep_mode == "exact")
+    finally:
+        product_lib.wmi_set_lockstep_groups(node.ctx, 0)
+        node.close()
+
+
 @pytest.mark.parametrize("qtype", ["q5_1", "q8_0", "q4_0"])
 def test_lockstep_chunks_of_quantised_models_equal_one_at_a_time(product_lib, lockstep_mode, qtype):
     """Block-quantised weights in lock-step: the chunks are rows of the same q8 x block-quantised kernels (per-row arithmetic does
