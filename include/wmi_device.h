@@ -179,7 +179,14 @@ WHISPER_API int wmi_get_tensor(struct whisper_context * ctx, const char * name, 
 WHISPER_API int wmi_mel_dims(struct whisper_context * ctx, int * n_len, int * n_len_org, int * n_mel);
 
 /* Stage timers in microseconds, the reference's counters (W/whisper.cpp:770-783):
- * t[0..5] = mel, encode, decode, batchd, prompt, sample ; n[0..4] = n_encode, n_decode, n_batchd, n_prompt, n_sample */
+ * t[0..5] = mel, encode, decode, batchd, prompt, sample ; n[0..4] = n_encode, n_decode, n_batchd, n_prompt, n_sample
+ * What a timer measures: whisper_full on an f16 model does not wait behind the log-mel and the encoder (the decoder's launches queue up
+ * behind them on the stream); their timers are then the GPU time of each phase, taken from stream events when the first decode step's
+ * sample arrives, and the decode timer is the host's wall time minus what spilled over from those phases.  Every other path (the stage
+ * calls whisper_pcm_to_mel / whisper_encode / whisper_decode, block-quantised models, lock-step calls, WMI_PHASE_SYNC=1) waits behind each
+ * phase and records host wall time.  A consequence for errors: a device fault inside the deferred encoder surfaces at the first decode
+ * step's wait, i.e. as whisper_full's "failed to decode" (-7 / -8) rather than "failed to encode" (-6); a faulted device fails every later
+ * call either way. */
 WHISPER_API void wmi_get_timings(struct whisper_context * ctx, int64_t * t6, int32_t * n5);
 
 /* The context's HIP stream (as void*), so a caller can order its own work / events against the hot path. */
