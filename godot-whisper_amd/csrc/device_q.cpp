@@ -167,16 +167,21 @@ bool decode_layers_q(whisper_context & ctx, int n, int n_kv, int kv_head, int Tc
         proj(k::EPI_F32_BIAS_RESID, att, S, S, l.q_o, l.b_o, d.dx, S, d.dx, nullptr, 0, nullptr, 0, 0.f);
         Src ln2; ln2.x32 = d.dx; ln2.ln_g = l.ln2_g; ln2.ln_b = l.ln2_b;
         next(l.q_co, S, S);
-        proj(k::EPI_Q_SCALED, ln2, S, S, l.q_cq, l.b_cq, d.dq, S, nullptr, nullptr, 0, nullptr, 0, kq_scale);
         if (rows_fit(n, S)) {                     // the out projection combines the key-slice partials in its prologue (one launch fewer)
             const float * po = nullptr, * pl = nullptr, * pm = nullptr; int ns = 0;
-            k::attn_cross_split_partials(d.dq, n, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, &po, &pl, &pm, &ns, s);
+            // the cross query inside the attention launch (one launch fewer again), else as its own launch
+            if (!k::qattn_cross_qsplit_partials(d.dx, l.ln2_g, l.ln2_b, hp.eps, l.q_cq, l.b_cq, kq_scale, n, S, H, d.kvc_k + (size_t) il * Tc * S,
+                                                d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, &po, &pl, &pm, &ns, s, 0, pfW ? *pfW : k::QMat{}, pfN, pfK)) {
+                proj(k::EPI_Q_SCALED, ln2, S, S, l.q_cq, l.b_cq, d.dq, S, nullptr, nullptr, 0, nullptr, 0, kq_scale);
+                k::attn_cross_split_partials(d.dq, n, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, &po, &pl, &pm, &ns, s);
+            }
             k::GemvArgs g{};
             g.eps = hp.eps; g.n = n; g.K = S; g.N = S; g.bias = l.b_co; g.epi = k::EPI_F32_BIAS_RESID; g.C = d.dx; g.ldc = S; g.resid = d.dx; g.ldr = S;
             g.S = S; g.comb_o = po; g.comb_l = pl; g.comb_m = pm; g.comb_ns = ns;
             next(l.q_fc1, 4 * S, S); set_pf(g);
             k::qrows(g, nullptr, l.q_co, s);
         } else {
+        proj(k::EPI_Q_SCALED, ln2, S, S, l.q_cq, l.b_cq, d.dq, S, nullptr, nullptr, 0, nullptr, 0, kq_scale);
         k::attn_cross_split(d.dq, n, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, nullptr, s, 0, d.datt32);
         proj(k::EPI_F32_BIAS_RESID, att, S, S, l.q_co, l.b_co, d.dx, S, d.dx, nullptr, 0, nullptr, 0, 0.f);
         }
@@ -206,9 +211,10 @@ bool decode_layers_q(whisper_context & ctx, int n, int n_kv, int kv_head, int Tc
 }
 
 // One greedy decode step of a block-quantised model as a fixed launch sequence (graph-replayable: every per-step quantity
-// is read from DecStep on the device, device.cpp: decode_greedy_step): 9 launches per layer —
-//   q|k|v (LayerNorm + q8 in the prologue) -> self-attention (f32 out) -> out projection -> cross query ->
-//   cross scores -> cross P.V -> cross out projection (combines the key slices in its prologue) -> mlp.0 -> mlp.2
+// is read from DecStep on the device, device.cpp: decode_greedy_step): 7 launches per layer —
+//   q|k|v (LayerNorm + q8 in the prologue) -> self-attention (f32 out) -> out projection -> cross-attention of the key slices with the
+//   LayerNorm + cross query inside (k_xattn_fused_q; WMI_Q_XATTN_TWO_LAUNCHES: the query as its own launch) -> cross out projection
+//   (combines the key slices in its prologue) -> mlp.0 -> mlp.2
 void enqueue_greedy_step_q(whisper_context & ctx, int Tc) {
     State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
     KVCache & kv = st.kv_self;
@@ -259,9 +265,13 @@ void enqueue_greedy_step_q(whisper_context & ctx, int Tc) {
         rows(k::EPI_F32_BIAS_RESID, att, S, S, l.q_o, l.b_o, d.dx, S, d.dx, nullptr, nullptr, 0.f, nullptr);
         Src ln2; ln2.x32 = d.dx; ln2.ln_g = l.ln2_g; ln2.ln_b = l.ln2_b;
         next(l.q_co, S, S);
-        rows(k::EPI_Q_SCALED, ln2, S, S, l.q_cq, l.b_cq, d.dq, S, nullptr, nullptr, nullptr, kq_scale, nullptr);
         const float * po = nullptr, * pl = nullptr, * pm = nullptr; int ns = 0;
-        k::attn_cross_split_partials(d.dq, 1, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, &po, &pl, &pm, &ns, s);
+        if (k::qattn_cross_qsplit_partials(d.dx, l.ln2_g, l.ln2_b, hp.eps, l.q_cq, l.b_cq, kq_scale, 1, S, H, d.kvc_k + (size_t) il * Tc * S,
+                                           d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, &po, &pl, &pm, &ns, s, 0, pfW ? *pfW : k::QMat{}, pfN, pfK)) pfW = nullptr;
+        else {
+            rows(k::EPI_Q_SCALED, ln2, S, S, l.q_cq, l.b_cq, d.dq, S, nullptr, nullptr, nullptr, kq_scale, nullptr);
+            k::attn_cross_split_partials(d.dq, 1, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, &po, &pl, &pm, &ns, s);
+        }
         next(l.q_fc1, 4 * S, S);
         rows(k::EPI_F32_BIAS_RESID, Src{}, S, S, l.q_co, l.b_co, d.dx, S, d.dx, nullptr, nullptr, 0.f, nullptr, po, pl, ns, pm);
         Src ln3; ln3.x32 = d.dx; ln3.ln_g = l.ln3_g; ln3.ln_b = l.ln3_b;
@@ -320,10 +330,15 @@ void enqueue_rows_step_q(whisper_context & ctx, int nb) {
         k::qrows(rows(k::EPI_F32_BIAS_RESID, att, S, S, l.q_o, l.b_o, b.dx, S, b.dx, nullptr, nullptr, 0.f, nullptr), att.x32, l.q_o, s);
         Src ln2; ln2.x32 = b.dx; ln2.ln_g = l.ln2_g; ln2.ln_b = l.ln2_b;
         next(l.q_co, S, S);
-        k::qrows(rows(k::EPI_Q_SCALED, ln2, S, S, l.q_cq, l.b_cq, b.dq, S, nullptr, nullptr, nullptr, kq_scale, nullptr), nullptr, l.q_cq, s);
         const float * po = nullptr, * pl = nullptr, * pm = nullptr; int ns = 0;
-        k::attn_cross_split_partials(b.dq, nb, S, H, b.kvc_k + (size_t) il * cross_layer, b.kvc_v + (size_t) il * cross_layer, Tc,
-                                     b.xattn, &po, &pl, &pm, &ns, s, (int64_t) Tc * S);
+        if (k::qattn_cross_qsplit_partials(b.dx, l.ln2_g, l.ln2_b, hp.eps, l.q_cq, l.b_cq, kq_scale, nb, S, H, b.kvc_k + (size_t) il * cross_layer,
+                                           b.kvc_v + (size_t) il * cross_layer, Tc, b.xattn, &po, &pl, &pm, &ns, s, (int64_t) Tc * S,
+                                           pfW ? *pfW : k::QMat{}, pfN, pfK)) pfW = nullptr;
+        else {
+            k::qrows(rows(k::EPI_Q_SCALED, ln2, S, S, l.q_cq, l.b_cq, b.dq, S, nullptr, nullptr, nullptr, kq_scale, nullptr), nullptr, l.q_cq, s);
+            k::attn_cross_split_partials(b.dq, nb, S, H, b.kvc_k + (size_t) il * cross_layer, b.kvc_v + (size_t) il * cross_layer, Tc,
+                                         b.xattn, &po, &pl, &pm, &ns, s, (int64_t) Tc * S);
+        }
         {
             next(l.q_fc1, 4 * S, S);
             k::GemvArgs g = rows(k::EPI_F32_BIAS_RESID, Src{}, S, S, l.q_co, l.b_co, b.dx, S, b.dx, nullptr, nullptr, 0.f, nullptr);

@@ -915,6 +915,12 @@ void attn_cross_combine(const float * part_o, const float * part_l, const float 
     hipLaunchKernelGGL(k_xattn_combine, dim3(H, n), dim3(64), 0, st, part_o, part_l, part_m, ns, S, out, out32);
 }
 
+XattnPlan attn_cross_plan(int n, int H, int T, float * scratch) {
+    const XLayout L = xattn_layout(n, H, T, scratch);
+    XattnPlan P; P.ns = L.ns; P.ks = L.ks; P.pmax = L.pmax; P.part_l = L.part_l; P.part_o = L.part_o; P.fused = L.fused; P.head_major = xattn_head_major();
+    return P;
+}
+
 void attn_cross_partials_layout(int n, int H, int T, float * scratch, const float ** po, const float ** pl, const float ** pm, int * pns) {
     const XLayout L = xattn_layout(n, H, T, scratch);
     *po = L.part_o; *pl = L.part_l; *pm = L.fused ? L.pmax : nullptr; *pns = L.ns;

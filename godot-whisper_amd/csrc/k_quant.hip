@@ -27,6 +27,7 @@
 #include <map>
 #include <mutex>
 #include "wave_ops.h"
+#include "xattn_tail.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -974,6 +975,217 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 && NR4 == 1) ? 4 : 1) void k_qrow
     stamp_end(a.stamps, a.stamp_slot, (int) blockIdx.x * NW + wave, ts0, tm1, tm2);
 }
 
+// ------------------------------------------------------------------------------------------------ cross-attention, query projected inside
+// One launch for "LayerNorm + cross query" and "scores, soft-max numerators, P.V of a key slice" of a block-quantised model (the f16 models'
+// k_xattn_fused<NC, true>, k_attn.hip): a (row, head, slice) workgroup projects ITS head's 64 query values — two row groups of W_cq — and
+// goes on with its key slice (xattn_tail.h).  The eight slices of a head repeat the projection: 8 x the head's 50 KB of tiles from L2 /
+// Infinity Cache against one launch (body + boundary, 6.4 us of the ~49 us decoder layer of large-v3 q5_1) less: ~3 us per layer net
+// (the step 1 540 -> 1 450 us, base.en q4_0 240 -> 222, medium q4_1 1 055 -> 965).
+// Per query value the operations and their order are k_qrows': LayerNorm and q8 blocks per 256-column slice (the "few rows" form), tile
+// pairs w, w + NV, ... on wavefront w in order, partial sums of the NV wavefronts added in their order — NV is the wavefront count
+// qrows_nw() picks for this K (4 up to 8 tile pairs, else 8).  The key-slice part runs on wavefronts 0..3 (its sums are laid out for
+// four); with NV = 8 the other four only keep the barriers company.  Same bits as the two-launch form (tests/test_gpu_variants.py),
+// whose switch is WMI_Q_XATTN_TWO_LAUNCHES.
+// pf_ptr: the next weight-streaming launch's matrix (see k_qrows): a dword per 128-byte line, requested behind everything this workgroup
+// needs; group g goes to the workgroups with linear id = g (mod pf_groups): a multiple of 8 groups keeps the XCD of the launch that
+// streams the group.
+template <int QT, int NV>
+__global__ __launch_bounds__(64 * NV) void k_xattn_fused_q(const float * __restrict__ x32, const float * __restrict__ ln_g, const float * __restrict__ ln_b,
+                                                           float eps, const uint8_t * __restrict__ Wt, const float * __restrict__ bq, float qscale, int S,
+                                                           const __half * __restrict__ kc, const __half * __restrict__ vc, int T, int ks, int ns,
+                                                           float * __restrict__ pmax, float * __restrict__ part_o, float * __restrict__ part_l,
+                                                           int64_t kv_row_stride, int head_major,
+                                                           const uint8_t * __restrict__ pf_ptr, uint32_t pf_groups, uint32_t pf_group_bytes, const Stamp sp) {
+    constexpr int QW = Geo<QT>::QW, HW = Geo<QT>::HW;
+    constexpr bool HAS_M = Geo<QT>::M, F16D = Geo<QT>::F16D;
+    constexpr int CHV = NV == 4 ? 2 : 3;                    // tile pairs per wavefront and row group (<= 8, resp. <= 24 pairs per row)
+    constexpr int MAXV = 6;                                 // K <= 1536
+    constexpr uint32_t NT = 64 * NV;
+    __shared__ __attribute__((aligned(16))) int8_t sq[1536 + 16];
+    __shared__ float sd[48], ss[48];
+    __shared__ float redq[NV][2][32];
+    __shared__ float qs[64];
+    __shared__ float red[4], lred[4];
+    __shared__ float ored[4][64];
+    // every argument in one batch of scalar loads (kernels.h: WMI_ARG_NOW): taken where they are first used, the row's loads left behind five
+    // dependent round trips to the kernarg segment — rows quantised 0.35 us later
+    {
+        const unsigned gx = gridDim.x, gy = gridDim.y;
+        asm volatile("" :: "s"(x32), "s"(ln_g), "s"(ln_b), "s"(eps), "s"(Wt), "s"(bq), "s"(qscale), "s"(S), "s"(kc), "s"(vc), "s"(T), "s"(ks), "s"(ns),
+                     "s"(pmax), "s"(part_o), "s"(part_l), "s"(kv_row_stride), "s"(head_major), "s"(pf_ptr), "s"(pf_groups), "s"(pf_group_bytes),
+                     "s"(sp.base), "s"(sp.slot), "s"(gx), "s"(gy));
+    }
+    const unsigned long long ts0 = stamp_t0(sp.base);
+    unsigned long long tm1 = 0, tm2 = 0;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // (uniform: the tile and key addresses below are scalar base + lane offset)
+    const int slice = head_major ? blockIdx.y : blockIdx.x, head = head_major ? blockIdx.x : blockIdx.y, i = blockIdx.z;
+    const int H = head_major ? gridDim.x : gridDim.y;
+    const size_t row = (size_t) i * H + head;
+    kc += (int64_t) i * kv_row_stride; vc += (int64_t) i * kv_row_stride;
+    const int K = S, np = K >> 6, nsl = (K + 255) >> 8;
+    const bool tail_wave = wave < 4;                         // wave-uniform
+    const XaKeys keys = xa_keys(slice, ks, T, S, head, wave & 3, lane);
+
+    // ---- loads, in the order they are needed (vmcnt retires in order): the residual row (the previous launch wrote it), gain / bias of
+    // this wavefront's slice, the weight tiles; K, V and the next launch's lines follow behind the quantiser
+    const float * xr = x32 + (size_t) i * K;
+    float4 v[MAXV];
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) { const int c = (u * 64 + lane) * 4; v[u] = *(const float4 *) (xr + (c < K ? c : 0)); }
+    const int cs = (wave * 64 + lane) * 4, ccs = cs < K ? cs : 0;       // this wavefront's slice (wave < nsl), this lane's four columns
+    const float4 gg = *(const float4 *) (ln_g + ccs), bb = *(const float4 *) (ln_b + ccs);
+    __builtin_amdgcn_sched_barrier(0);
+    const float bias = (bq && tid < 64) ? bq[head * 64 + tid] : 0.0f;      // (cold: first in the queue)
+    __builtin_amdgcn_sched_barrier(0);
+    uint32_t wq[2][CHV][QW], wh[2][CHV][HW];
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+        for (int u = 0; u < CHV; ++u) {
+            int tp = wave + NV * u; if (tp > np - 1) tp = np - 1;
+            const uint8_t * t = Wt + ((size_t) (2 * head + g2) * np + tp) * tile_bytes<QT>();       // uniform
+            const uint32_t l16 = (uint32_t) lane * 16u, l32 = (uint32_t) lane * 32u, l8 = (uint32_t) lane * 8u, l4 = (uint32_t) lane * 4u;
+            uint32_t (&q)[QW] = wq[g2][u]; uint32_t (&h)[HW] = wh[g2][u];
+            if constexpr (QW == 4) { const uint4 a4 = *(const uint4 *) (t + l16); q[0] = a4.x; q[1] = a4.y; q[2] = a4.z; q[3] = a4.w; }
+            else { const uint4 a4 = *(const uint4 *) (t + l32), b4 = *(const uint4 *) (t + 16 + l32);
+                   q[0] = a4.x; q[1] = a4.y; q[2] = a4.z; q[3] = a4.w; q[4] = b4.x; q[5] = b4.y; q[6] = b4.z; q[7] = b4.w; }
+            if constexpr (HW == 2) { const uint2 h2 = *(const uint2 *) (t + 64 * QW * 4 + l8); h[0] = h2.x; h[1] = h2.y; }
+            else h[0] = *(const uint32_t *) (t + 64 * QW * 4 + l4);
+        }
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- LayerNorm statistics of the row (every wavefront), this wavefront's slice as q8 blocks in LDS (k_qrows, SRC = 1, few rows)
+    float sum = 0.0f;
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) {
+        const int c = (u * 64 + lane) * 4;
+        if (c < K) sum += (v[u].x + v[u].y) + (v[u].z + v[u].w);
+        else v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) sum += WMI_SHX(sum, o);
+    const float mean = sum / (float) K;
+    float sqs = 0.0f;
+#pragma unroll
+    for (int u = 0; u < MAXV; ++u) {
+        const int c = (u * 64 + lane) * 4;
+        if (c < K) {
+            v[u].x -= mean; v[u].y -= mean; v[u].z -= mean; v[u].w -= mean;
+            sqs += (v[u].x * v[u].x + v[u].y * v[u].y) + (v[u].z * v[u].z + v[u].w * v[u].w);
+        }
+    }
+    _Pragma("unroll") for (int o = 32; o > 0; o >>= 1) sqs += WMI_SHX(sqs, o);
+    const float scale = 1.0f / sqrtf(sqs / (float) K + eps);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wave < nsl) {                                        // wave-uniform
+        float4 y = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int w = 0; w < MAXV; ++w) if (w == wave) y = v[w];
+        y.x = __fadd_rn(__fmul_rn(y.x * scale, gg.x), bb.x); y.y = __fadd_rn(__fmul_rn(y.y * scale, gg.y), bb.y);
+        y.z = __fadd_rn(__fmul_rn(y.z * scale, gg.z), bb.z); y.w = __fadd_rn(__fmul_rn(y.w * scale, gg.w), bb.w);
+        if (cs >= K) y = make_float4(0.f, 0.f, 0.f, 0.f);
+        float d, sv;
+        const uint32_t q = quant4<F16D>(y.x, y.y, y.z, y.w, d, sv);
+        if (cs < K) {
+            *(uint32_t *) (sq + cs) = q;
+            if ((lane & 7) == 0) { sd[cs >> 5] = d; ss[cs >> 5] = sv; }
+        }
+    }
+    // K, V (wavefronts 0..3) and the next launch's lines go out behind the quantiser.  Measured on large-v3 q5_1 (in-kernel stamps, step
+    // chain): requested at the top 1 439 - 1 459 us per step, behind the LayerNorm statistics 1 447 - 1 465, here 1 454 (two launches:
+    // 1 535 - 1 545) — the rows are quantised at + 3.8 .. 4.7 us of the launch in every order (k_qrows: + 2.9), the query is ready at
+    // + 5.6 .. 6.2, the launch ends at + 7.4 .. 8.0.  All of them UNCONDITIONAL plain loads (the wavefronts without a key slice, the threads
+    // without a line to prefetch read byte 0): behind loads in a branch hipcc cannot count what is in flight and waits for everything (ISA
+    // dump: vmcnt(0) in front of the quantiser), loads issued from inline assembly are invisible to its count (every later wait one load
+    // too strict), volatile ones drain the queue.
+    __builtin_amdgcn_sched_barrier(0);
+    uint4 kk[XA_KPASS], vv[XA_KPASS];
+#pragma unroll
+    for (int p = 0; p < XA_KPASS; ++p) kk[p] = *(const uint4 *) ((const char *) kc + (tail_wave ? keys.off[p] : 0u));
+#pragma unroll
+    for (int p = 0; p < XA_KPASS; ++p) vv[p] = *(const uint4 *) ((const char *) vc + (tail_wave ? keys.off[p] : 0u));
+    uint32_t junk0, junk1;
+    {
+        const uint32_t lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z), nwg = gridDim.x * gridDim.y * gridDim.z;
+        const uint32_t pg = pf_ptr ? pf_groups : 1u, pb = pf_ptr ? pf_group_bytes : 0u;
+        const uint32_t g = lin % pg, share = lin / pg, nshare = (nwg + pg - 1) / pg;
+        const uint8_t * gp = (pf_ptr ? pf_ptr : Wt) + (size_t) g * pb;
+        const uint32_t off0 = (share * NT + (uint32_t) tid) * 128u, off1 = off0 + nshare * NT * 128u;      // at most two lines per thread
+        junk0 = __builtin_nontemporal_load((const uint32_t *) (gp + (off0 < pb ? off0 : 0u)));
+        junk1 = __builtin_nontemporal_load((const uint32_t *) (gp + (off1 < pb ? off1 : 0u)));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __syncthreads();
+    if (sp.base) tm1 = wall_clock64();
+
+    // ---- the block dots of this head's two row groups (k_qrows' tile phase, one activation row)
+    const int fk = lane >> 5;
+    const int8_t * afrag = sq + fk * 16;
+#pragma unroll
+    for (int g2 = 0; g2 < 2; ++g2) {
+        float out = 0.0f;
+#pragma unroll
+        for (int u = 0; u < CHV; ++u) {
+            const int tp = wave + NV * u;
+            if (tp < np) {                                   // wave-uniform
+                uint32_t lo[4], hi[4]; float d, m;
+                unpack<QT>(wq[g2][u], wh[g2][u], lo, hi, d, m);
+                float d0 = d, d1 = d, m0 = m, m1 = m;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const auto r2 = __builtin_amdgcn_permlane32_swap(lo[e], hi[e], false, false);
+                    lo[e] = r2[0]; hi[e] = r2[1];
+                }
+                { const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(d0), __float_as_uint(d1), false, false); d0 = __uint_as_float(r2[0]); d1 = __uint_as_float(r2[1]); }
+                if (HAS_M) { const auto r2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(m0), __float_as_uint(m1), false, false); m0 = __uint_as_float(r2[0]); m1 = __uint_as_float(r2[1]); }
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int b = 2 * tp + h;
+                    const intx4 fa = *(const intx4 *) (afrag + b * 32);
+                    intx4 fb; if (h == 0) { fb[0] = lo[0]; fb[1] = lo[1]; fb[2] = lo[2]; fb[3] = lo[3]; } else { fb[0] = hi[0]; fb[1] = hi[1]; fb[2] = hi[2]; fb[3] = hi[3]; }
+                    intx16 z;
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) z[e] = 0;
+                    const intx16 ia = __builtin_amdgcn_mfma_i32_32x32x32_i8(fa, fb, z, 0, 0, 0);
+                    const float dwv = h == 0 ? d0 : d1, mwv = h == 0 ? m0 : m1;
+                    out = fmaf((float) ia[0], sd[b] * dwv, out);
+                    if (HAS_M) out = fmaf(mwv, ss[b], out);
+                }
+            }
+        }
+        if (lane < 32) redq[wave][g2][lane] = out;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int g2 = tid >> 5, nl = tid & 31;
+        float a = redq[0][g2][nl];
+#pragma unroll
+        for (int w = 1; w < NV; ++w) a += redq[w][g2][nl];
+        qs[tid] = xa_round_f16((a + bias) * qscale);
+    }
+    __syncthreads();
+    if (sp.base) tm2 = wall_clock64();
+    if (tail_wave) xa_slice_tail(qs, kk, vv, keys.ok, red, lred, ored, row, ns, slice, pmax, part_o, part_l);
+    else { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); }      // (the tail's two barriers; these wavefronts touch nothing it shares)
+    asm volatile("" :: "v"(junk0), "v"(junk1));              // (the prefetched dwords are "used" here: their wait sits at the end)
+    stamp_end(sp.base, sp.slot, (((int) blockIdx.z * (int) gridDim.y + (int) blockIdx.y) * (int) gridDim.x + (int) blockIdx.x) * NV + wave, ts0, tm1, tm2);
+}
+
+template <int QT, int NV>
+static void launch_xattn_fused_q(const XattnPlan & P, const float * x32, const float * ln_g, const float * ln_b, float eps, const uint8_t * Wt,
+                                 const float * bq, float qscale, int n, int S, int H, const __half * kc, const __half * vc, int T, hipStream_t st,
+                                 int64_t kv_row_stride, const uint8_t * pf_ptr, uint32_t pf_groups, uint32_t pf_group_bytes) {
+    const dim3 grid = P.head_major ? dim3(H, P.ns, n) : dim3(P.ns, H, n);
+    hipLaunchKernelGGL((k_xattn_fused_q<QT, NV>), grid, dim3(64 * NV), 0, st, x32, ln_g, ln_b, eps, Wt, bq, qscale, S, kc, vc, T, P.ks, P.ns,
+                       P.pmax, P.part_o, P.part_l, kv_row_stride, P.head_major ? 1 : 0, pf_ptr, pf_groups, pf_group_bytes, stamp_next());
+}
+template <int QT>
+static void xattn_fused_q_nv(const XattnPlan & P, const float * x32, const float * ln_g, const float * ln_b, float eps, const uint8_t * Wt,
+                             const float * bq, float qscale, int n, int S, int H, const __half * kc, const __half * vc, int T, hipStream_t st,
+                             int64_t kv_row_stride, const uint8_t * pf_ptr, uint32_t pf_groups, uint32_t pf_group_bytes) {
+    if (S / 64 <= 8) launch_xattn_fused_q<QT, 4>(P, x32, ln_g, ln_b, eps, Wt, bq, qscale, n, S, H, kc, vc, T, st, kv_row_stride, pf_ptr, pf_groups, pf_group_bytes);
+    else             launch_xattn_fused_q<QT, 8>(P, x32, ln_g, ln_b, eps, Wt, bq, qscale, n, S, H, kc, vc, T, st, kv_row_stride, pf_ptr, pf_groups, pf_group_bytes);
+}
+
 template <int QT, int NR4, int SRC, int NW, int CHX = 0>
 void launch_qrows(const GemvArgs & a, const float * a32, const uint8_t * Wt, hipStream_t st) {
     const int nb = a.K / 32, R8 = NR4 * 8;
@@ -1303,6 +1515,29 @@ void qrows(const GemvArgs & a_in, const float * a32, QMat W, hipStream_t st) {
         case QT_Q8_0: qrows_t<QT_Q8_0>(a, a32, W.tiles, st); break;
         default: break;
     }
+}
+
+bool qattn_cross_qsplit_partials(const float * x32, const float * ln_g, const float * ln_b, float eps, QMat Wcq, const float * bq, float qscale,
+                                 int n, int S, int H, const __half * kc, const __half * vc, int T, float * scratch,
+                                 const float ** po, const float ** pl, const float ** pm, int * pns, hipStream_t st, int64_t kv_row_stride,
+                                 QMat pfW, int pfN, int pfK) {
+    static const bool off = getenv("WMI_Q_XATTN_TWO_LAUNCHES") != nullptr;          // A/B knob: cross query as its own k_qrows launch
+    const XattnPlan P = attn_cross_plan(n, H, T, scratch);
+    if (off || !P.fused || !Wcq.tiles || !ln_g || S != H * 64 || S > 1536 || (S % 64) != 0 || S / 64 > 24) return false;
+    const uint8_t * pf_ptr = nullptr; uint32_t pf_groups = 0, pf_group_bytes = 0;
+    if (pfW.tiles && pfN > 0 && pfN <= 8192) {
+        pf_ptr = pfW.tiles; pf_groups = (uint32_t) ((pfN + 31) / 32); pf_group_bytes = (uint32_t) ((size_t) (pfK / 64) * q_tile_bytes(pfW.qtype));
+    }
+    switch (Wcq.qtype) {
+        case QT_Q4_0: xattn_fused_q_nv<QT_Q4_0>(P, x32, ln_g, ln_b, eps, Wcq.tiles, bq, qscale, n, S, H, kc, vc, T, st, kv_row_stride, pf_ptr, pf_groups, pf_group_bytes); break;
+        case QT_Q4_1: xattn_fused_q_nv<QT_Q4_1>(P, x32, ln_g, ln_b, eps, Wcq.tiles, bq, qscale, n, S, H, kc, vc, T, st, kv_row_stride, pf_ptr, pf_groups, pf_group_bytes); break;
+        case QT_Q5_0: xattn_fused_q_nv<QT_Q5_0>(P, x32, ln_g, ln_b, eps, Wcq.tiles, bq, qscale, n, S, H, kc, vc, T, st, kv_row_stride, pf_ptr, pf_groups, pf_group_bytes); break;
+        case QT_Q5_1: xattn_fused_q_nv<QT_Q5_1>(P, x32, ln_g, ln_b, eps, Wcq.tiles, bq, qscale, n, S, H, kc, vc, T, st, kv_row_stride, pf_ptr, pf_groups, pf_group_bytes); break;
+        case QT_Q8_0: xattn_fused_q_nv<QT_Q8_0>(P, x32, ln_g, ln_b, eps, Wcq.tiles, bq, qscale, n, S, H, kc, vc, T, st, kv_row_stride, pf_ptr, pf_groups, pf_group_bytes); break;
+        default: return false;
+    }
+    *po = P.part_o; *pl = P.part_l; *pm = P.pmax; *pns = P.ns;
+    return true;
 }
 
 template <int QT> static void qembed_launch(const int32_t * tokens, const int32_t * pos, const DecStep * hs, DecStep * ds, int n, int S,

@@ -220,6 +220,10 @@ void attn_cross_split_partials(const __half * q, int n, int S, int H, const __ha
 // consumer rescales by (one-launch form, k_xattn_fused) — pass it on as GemvArgs::comb_m / to attn_cross_combine
 // the same with the query projection folded into the score kernel: q = (W_cq . LN(x32) + b_cq) * qscale is recomputed per
 // (slice, head) workgroup (bit-identical to gemv + EPI_Q_SCALED); saves one launch per decoder layer
+// where the one-launch form of the cross-attention puts a step's partials, and its grid: for the form whose query projection is a
+// block-quantised matrix (k_quant.hip: qattn_cross_qsplit_partials).  fused = false: the key slices are too long for one launch
+struct XattnPlan { int ns, ks; float * pmax, * part_l, * part_o; bool fused, head_major; };
+XattnPlan attn_cross_plan(int n, int H, int T, float * scratch);
 void attn_cross_qsplit_partials(const float * x32, const float * ln_g, const float * ln_b, float eps, const __half * wq,
                                 const float * bq, float qscale, int n, int S, int H, const __half * kc, const __half * vc, int T,
                                 float * scratch, const float ** part_o, const float ** part_l, const float ** part_m, int * ns, hipStream_t st,
@@ -428,6 +432,13 @@ void qdequant(QMat W, int64_t row0, int64_t rows, int K, __half * out, hipStream
 // the fused attention prologues (sa_*, comb_*) are not available here.
 void qrows(const GemvArgs & a, const float * a32, QMat W, hipStream_t st);
 bool qrows_ksplit_ok(const GemvArgs & a, int parts);        // may this launch split K over `parts` workgroups per row group (GemvArgs::ksplit)?
+// the cross-attention of <= 32 rows of a block-quantised model with the query projection inside (LayerNorm(x32) . W_cq, scaled, f16) — one
+// launch instead of qrows(EPI_Q_SCALED) + attn_cross_split_partials, the same bits; partials as attn_cross_split_partials.  pfW / pfN / pfK:
+// the next weight-streaming launch's matrix (prefetched).  false: not available for this shape (nothing launched; take the two launches)
+bool qattn_cross_qsplit_partials(const float * x32, const float * ln_g, const float * ln_b, float eps, QMat Wcq, const float * bq, float qscale,
+                                 int n, int S, int H, const __half * kc, const __half * vc, int T, float * scratch,
+                                 const float ** po, const float ** pl, const float ** pm, int * pns, hipStream_t st, int64_t kv_row_stride,
+                                 QMat pfW, int pfN, int pfK);
 
 // token embedding gather from a quantised matrix: x[i] = dequant(te[token[i]]) + pe[pos[i]]   (W/ggml.c get_rows, dequantize_row_*)
 void qdec_embed(const int32_t * tokens, const int32_t * pos, int n, int S, QMat te, const float * pe, float * x, hipStream_t st);

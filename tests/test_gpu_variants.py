@@ -381,3 +381,57 @@ def test_quantised_mlp2_k_split_agrees_with_the_undivided_form(tmp_path, qtype):
     for name in ("split", "whole"):
         assert len(outs[name]["greedy"]) >= 8
         assert outs[name]["lockstep"] == outs[name]["alone"], name
+
+# ------------------------------------------------------------------------------------------------ block-quantised models: the cross query inside the attention launch
+# k_xattn_fused_q (k_quant.hip) projects the head's query in the cross-attention launch with k_qrows' operations in k_qrows' order;
+# WMI_Q_XATTN_TWO_LAUNCHES=1 keeps the query as its own launch.  One row (greedy), several rows (beam search, prompt) and lock-step
+# chunks go through it; every block kind has its own instantiation, and S <= 512 / S > 512 differ in the wavefront count.
+_Q_SCRIPT = r"""
+import json, sys
+sys.path.insert(0, ROOT_PLACEHOLDER)
+import __graft_entry__ as entry
+entry.load_package()
+from godot_whisper_amd import host, runtime, synth
+lib = runtime.require_gpu(); runtime.silence_logs(lib)
+out = {}
+for shape, qt in (("base.en", "q5_1"), ("tiny.en", "q4_0"), ("small", "q8_0"), ("tiny.en", "q5_0"), ("v3-slice", "q4_1")):
+    node = host.SpeechToText(lib); node.set_language_model(synth.quantize_model(synth.make_model(shape, seed=4242), qt))
+    node.language = "en" if shape.endswith(".en") or shape.startswith("v3") else "de"
+    res = {}
+    pcm = synth.make_pcm(30.0, seed=901)
+    for name, strat, bs, mt, prompt in (("greedy", 0, 1, 16, ""), ("beam3", 1, 3, 10, ""), ("prompted", 0, 1, 8, "and so my fellow")):
+        p = lib.whisper_full_default_params(strat); q = node.full_params(prompt, 0)
+        for f in ("language", "audio_ctx", "split_on_word", "token_timestamps", "suppress_non_speech_tokens", "single_segment", "entropy_thold", "initial_prompt"):
+            setattr(p, f, getattr(q, f))
+        p.max_tokens = mt; p.temperature_inc = 0.0
+        if strat == 1: p.beam_search.beam_size = bs
+        rr = []
+        for rep in range(3):
+            r = node.transcribe(pcm, params=p)
+            rr.append([[int(t["id"]), int(t["tid"]), float(t["p"]), float(t["plog"]), int(t["t0"]), int(t["t1"])] for t in r[1:]])
+        res[name] = rr
+    pcms = [synth.make_pcm(30.0, seed=950 + i) for i in range(3)]
+    p = node.full_params("", 0); p.temperature_inc = 0.0
+    r = node.transcribe_batch(pcms, params=p)
+    res["lockstep3"] = [[[int(t["id"]), float(t["p"]), float(t["plog"])] for t in one[1:]] for one in r]
+    out[shape + ":" + qt] = res
+    node.close()
+print("RESULT" + json.dumps(out))
+""".replace("ROOT_PLACEHOLDER", repr(ROOT))
+
+
+def _run_q(env_extra):
+    env = dict(os.environ); env.update(env_extra)
+    r = subprocess.run([sys.executable, "-c", _Q_SCRIPT], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1]
+    return json.loads(line[len("RESULT"):])
+
+
+def test_quantised_cross_query_inside_the_attention_launch_is_bit_identical():
+    one, two = _run_q({}), _run_q({"WMI_Q_XATTN_TWO_LAUNCHES": "1"})
+    assert set(one) == set(two) and len(one) == 5
+    for model, forms in one.items():
+        for form, runs in forms.items():
+            assert len(runs[0]) > 0, (model, form)
+            assert runs == two[model][form], (model, form)      # ids, probabilities (exact f32 values), token times
