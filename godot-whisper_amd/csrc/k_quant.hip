@@ -1522,6 +1522,11 @@ bool qattn_cross_qsplit_partials(const float * x32, const float * ln_g, const fl
                                  const float ** po, const float ** pl, const float ** pm, int * pns, hipStream_t st, int64_t kv_row_stride,
                                  QMat pfW, int pfN, int pfK) {
     static const bool off = getenv("WMI_Q_XATTN_TWO_LAUNCHES") != nullptr;          // A/B knob: cross query as its own k_qrows launch
+    // One row only (the greedy step): every (row, head, slice) workgroup unpacks the head's tiles for ITS row, where the k_qrows launch
+    // unpacks a tile once for up to eight rows — large-v3 q5_1, beam 5: 44.3 -> 49.3 ms per chunk, 8 lock-step chunks 78.5 -> 87.4 ms per
+    // call with every row count through this launch (greedy chunk 35.3 -> 33.9).  WMI_Q_XATTN_ROWS raises the limit (A/B).
+    static const int max_rows = getenv("WMI_Q_XATTN_ROWS") ? atoi(getenv("WMI_Q_XATTN_ROWS")) : 1;
+    if (n > max_rows) return false;
     const XattnPlan P = attn_cross_plan(n, H, T, scratch);
     if (off || !P.fused || !Wcq.tiles || !ln_g || S != H * 64 || S > 1536 || (S % 64) != 0 || S / 64 > 24) return false;
     const uint8_t * pf_ptr = nullptr; uint32_t pf_groups = 0, pf_group_bytes = 0;

@@ -432,7 +432,7 @@ void qdequant(QMat W, int64_t row0, int64_t rows, int K, __half * out, hipStream
 // the fused attention prologues (sa_*, comb_*) are not available here.
 void qrows(const GemvArgs & a, const float * a32, QMat W, hipStream_t st);
 bool qrows_ksplit_ok(const GemvArgs & a, int parts);        // may this launch split K over `parts` workgroups per row group (GemvArgs::ksplit)?
-// the cross-attention of <= 32 rows of a block-quantised model with the query projection inside (LayerNorm(x32) . W_cq, scaled, f16) — one
+// the cross-attention of a row of a block-quantised model (more rows: WMI_Q_XATTN_ROWS, slower) with the query projection inside (LayerNorm(x32) . W_cq, scaled, f16) — one
 // launch instead of qrows(EPI_Q_SCALED) + attn_cross_split_partials, the same bits; partials as attn_cross_split_partials.  pfW / pfN / pfK:
 // the next weight-streaming launch's matrix (prefetched).  false: not available for this shape (nothing launched; take the two launches)
 bool qattn_cross_qsplit_partials(const float * x32, const float * ln_g, const float * ln_b, float eps, QMat Wcq, const float * bq, float qscale,

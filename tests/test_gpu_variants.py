@@ -384,8 +384,8 @@ def test_quantised_mlp2_k_split_agrees_with_the_undivided_form(tmp_path, qtype):
 
 # ------------------------------------------------------------------------------------------------ block-quantised models: the cross query inside the attention launch
 # k_xattn_fused_q (k_quant.hip) projects the head's query in the cross-attention launch with k_qrows' operations in k_qrows' order;
-# WMI_Q_XATTN_TWO_LAUNCHES=1 keeps the query as its own launch.  One row (greedy), several rows (beam search, prompt) and lock-step
-# chunks go through it; every block kind has its own instantiation, and S <= 512 / S > 512 differ in the wavefront count.
+# WMI_Q_XATTN_TWO_LAUNCHES=1 keeps the query as its own launch.  One row (greedy) by default, several rows (beam search, prompt) and
+# lock-step chunks with WMI_Q_XATTN_ROWS; every block kind has its own instantiation, and S <= 512 / S > 512 differ in the wavefront count.
 _Q_SCRIPT = r"""
 import json, sys
 sys.path.insert(0, ROOT_PLACEHOLDER)
@@ -429,7 +429,8 @@ def _run_q(env_extra):
 
 
 def test_quantised_cross_query_inside_the_attention_launch_is_bit_identical():
-    one, two = _run_q({}), _run_q({"WMI_Q_XATTN_TWO_LAUNCHES": "1"})
+    # (WMI_Q_XATTN_ROWS=32: beams, prompt rows and lock-step chunks through the launch as well — by default only the one-row greedy step is)
+    one, two = _run_q({"WMI_Q_XATTN_ROWS": "32"}), _run_q({"WMI_Q_XATTN_TWO_LAUNCHES": "1"})
     assert set(one) == set(two) and len(one) == 5
     for model, forms in one.items():
         for form, runs in forms.items():
