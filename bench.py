@@ -739,7 +739,9 @@ def encoder_gemm_utilisation(lib, ctx, chunks: int, measured_peak_tflops: float 
     for key in order:
         e = shapes[key]
         tf = e["gflop_sum"] / (e["us_sum"] * 1e-6) / 1e3
-        kern = "k_gemm8 (persistent 8-wave ping-pong)" if (e["workgroups"] <= 256 and e["M"] >= 4096) else "k_gemm"
+        # (the persistent kernel always launches one workgroup per CU; a smaller grid at M >= 4096 is k_gemm's 192 x 128 tiling of the N = S projections)
+        kern = ("k_gemm8 (persistent 8-wave ping-pong)" if (e["workgroups"] == 256 and e["M"] >= 4096) else
+                "k_gemm<192,128> (one 8-wave workgroup per CU, four-deep ring)" if (e["workgroups"] < 256 and e["M"] >= 4096 and e["N"] <= 1024) else "k_gemm")
         per.append({"shape": e["shape"], "M": e["M"], "N": e["N"], "K": e["K"], "launches": e["launches"], "avg_us": round(e["us_sum"] / e["launches"], 2),
                     "tflops": round(tf, 1), "frac": round(tf / 2500.0, 4), "share_of_gemm_time": round(e["us_sum"] / tot_us, 3),
                     "kernel": kern, "workgroups": e["workgroups"]})
