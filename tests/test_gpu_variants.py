@@ -414,6 +414,12 @@ for shape, qt in (("base.en", "q5_1"), ("tiny.en", "q4_0"), ("small", "q8_0"), (
     p = node.full_params("", 0); p.temperature_inc = 0.0
     r = node.transcribe_batch(pcms, params=p)
     res["lockstep3"] = [[[int(t["id"]), float(t["p"]), float(t["plog"])] for t in one[1:]] for one in r]
+    ragged = []                                        # audio_ctx that leaves one key slice, a slice boundary + 1, a ragged last slice
+    for actx in (100, 193, 777):
+        p = node.full_params("", actx); p.temperature_inc = 0.0; p.max_tokens = 10
+        r = node.transcribe(synth.make_pcm(actx / 50.0, seed=actx), params=p)
+        ragged.append([[int(t["id"]), float(t["p"]), float(t["plog"])] for t in r[1:]])
+    res["ragged_audio_ctx"] = ragged
     out[shape + ":" + qt] = res
     node.close()
 print("RESULT" + json.dumps(out))
