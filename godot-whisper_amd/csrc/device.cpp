@@ -154,8 +154,9 @@ static bool init_state_into(whisper_context & ctx, State * st, bool replica_stat
     // the in-launch hand-off of the one-row step's MLP (k::mlp_pair): 2 S granules + the launch counter, zeroed once (tag 0 = never valid)
     {
         unsigned char * hand = nullptr;
-        ok = ok && dalloc(hand, (size_t) 16 * S + 64);
-        if (ok) { d.mlp_hand = hand; d.mlp_arrive = (unsigned long long *) (hand + (size_t) 16 * S); k::fill_zero(hand, (size_t) 16 * S + 64, d.stream); }
+        // (+ 2 S granules behind the words for the one-launch front of a layer, k::front: 3 S / 2 of q|k|v, S / 2 of the attention row)
+        ok = ok && dalloc(hand, (size_t) 32 * S + 64);
+        if (ok) { d.mlp_hand = hand; d.mlp_arrive = (unsigned long long *) (hand + (size_t) 16 * S); k::fill_zero(hand, (size_t) 32 * S + 64, d.stream); }
     }
     if (!ok) { WMI_ERR("%s: device allocation failed\n", __func__); return false; }
     // buffers that are read before being fully written must hold finite values
@@ -874,7 +875,7 @@ struct StepTicket {
 };
 }
 
-constexpr int PAIR_FAULT_WORD = 4;           // d.mlp_arrive as 32-bit words: [0], [1] the launches' tags, [4] the hand-offs' status (k::MlpPairArgs::fault)
+constexpr int PAIR_FAULT_WORD = 4;           // d.mlp_arrive as 32-bit words: [0], [1] the MLP launches' tags, [2], [3] the front launches', [4] the hand-offs' status (k::MlpPairArgs::fault)
 static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = false, bool chained = false, bool solo = true) {
     if (ctx.model.quantised) { enqueue_greedy_step_q(ctx, Tc); return; }
     State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
@@ -905,9 +906,21 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = fa
     // number of layers keeps that up across steps), so either every layer pairs or none does
     const k::Knobs & kn = k::knobs();
     const bool paired = (M & 32) && (M & 64) && !kn.no_mlp_pair && solo && d.mlp_hand && (Lt & 1) == 0 && k::mlp_pair_usable(S, chained);
+    // the same decision for the front of the layers (k::front): short caches only; its status goes through the MLP pair's word, so it
+    // runs where that pair does (the pick kernel reports the word, a fault re-runs the step without either)
+    const bool fronted = paired && !long_kv && (M & 2) && (M & 4) && !kn.no_front && k::front_usable(S);
     for (int il = 0; il < Lt; ++il) {
         const DecLayerW & l = w.dec[il];
         __half * ck = kv.k + ((size_t) il * n_ctx) * S, * cv = kv.v + ((size_t) il * n_ctx) * S;
+        if (fronted) {     // LN + q|k|v, the self-attention (once per head) and the out projection as ONE launch with two hand-offs (k::front)
+            k::FrontArgs f{};
+            f.x = d.dx; f.xout = d.dx; f.ln_g = l.ln1_g; f.ln_b = l.ln1_b; f.eps = hp.eps; f.S = S; f.Wqkv = l.w_qkv; f.bqkv = l.b_qkv; f.scale = kq_scale;
+            f.q16 = d.dq; f.ck = ck; f.cv = cv; f.kv_head = &stp->kv_head; f.n_kv = &stp->n_kv; f.cap = hp.n_text_ctx; f.Wo = l.w_o; f.bo = l.b_o;
+            f.gq = (unsigned long long *) ((unsigned char *) d.mlp_hand + (size_t) 16 * S + 64); f.ga = f.gq + 3 * S / 2;
+            f.epoch = (uint32_t *) d.mlp_arrive + 2; f.par = il & 1; f.fault = (uint32_t *) d.mlp_arrive + PAIR_FAULT_WORD;
+            f.spin_cap = kn.pair_spin_cap; f.withhold = kn.front_withhold;
+            k::front(f, s); chk("front", il);
+        } else {
         if (M & 2) gv(k::EPI_QKV_DEC, l.ln1_g, l.ln1_b, nullptr, S, 3 * S, l.w_qkv, l.b_qkv, d.dq, S, nullptr, ck, cv, kq_scale, &stp->kv_head); chk("qkv", il);
         if ((M & 4) && long_kv) {
             k::self_attn_rows(d.dq, 1, S, ck, cv, 0, &stp->n_kv, 0, hp.n_text_ctx, d.datt, s, nullptr, true);
@@ -919,6 +932,7 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = fa
             g.n = 1; g.K = S; g.N = S; g.W = l.w_o; g.bias = l.b_o; g.epi = k::EPI_F32_BIAS_RESID;
             g.C = d.dx; g.ldc = S; g.resid = d.dx; g.ldr = S; g.S = S;
             k::gemv(g, s); chk("self-attn+out", il);
+        }
         }
         {   // LN2 + cross query folded into the score kernel; partials combined inside the out-projection's prologue
             static const bool unfused_q = getenv("WMI_XATTN_UNFUSED_Q") != nullptr;          // debug / A-B

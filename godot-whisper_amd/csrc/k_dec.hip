@@ -1817,13 +1817,7 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_pair(const MlpPairArgs a, floa
     // this launch's tag: epoch[par] + 1, where `par` alternates from one launch of this kernel to the next (a.par: the layer's parity) and
     // THIS launch leaves epoch[par ^ 1] = tag for the next one.  No workgroup of a launch reads the word the launch writes, so a workgroup that
     // starts late sees the same value as the first one; nothing is ever reset, stale granules carry smaller tags.
-    const uint32_t tag = a.epoch[a.par] + 1u;
-    if (blockIdx.x == 0 && tid == 0) {
-        // the other word holds tag - 2 (or 0 before the first launch) when the launches alternated; tag or more means this parity ran twice in
-        // a row — stale granules would pass the tag test below: say so (the step is run again by the host in the two-launch form)
-        if (a.epoch[a.par ^ 1] >= tag) __hip_atomic_fetch_or(a.fault, PAIR_FAULT_PARITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        a.epoch[a.par ^ 1] = tag;
-    }
+    // (the two words are requested behind the weight rows and looked at where the granules are built: see tag_v below)
     constexpr int RIF = 4, LPR = 16;
     const int wrow = lane / LPR; const bool writer = (lane % LPR) == 0;
     // ---- phase 1 loads: the row first (L2), gain / bias, then the weight rows of both phases (HBM / Infinity Cache)
@@ -1844,6 +1838,10 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_pair(const MlpPairArgs a, floa
     for (int t = 0; t < NCH2; ++t) { const int c = lane * 8 + 512 * t; w2[t] = *(const uint4 *) (a.W2 + (size_t) gw * K2 + (c < K2 ? c : 0)); }
     const float bias2 = a.b2 ? a.b2[gw] : 0.0f;
     const float resid2 = xio[gw];
+    // the tag words LAST and through a lane offset the compiler cannot fold: as a uniform load at the kernel's top the tag was
+    // load -> vmcnt(0) -> readfirstlane, a memory round trip in front of the row's loads (round 6, found in k_front: LayerNorm + 0.2 - 0.9 us)
+    int zl = 0; asm volatile("" : "+v"(zl));
+    const uint32_t tag_v = a.epoch[a.par + zl] + 1u, other_v = a.epoch[(a.par ^ 1) + zl];
     __builtin_amdgcn_sched_barrier(0);
     ln_row_mask<NCH1>(xv, S, lane); ln_row_mask<NCH1>(gv, S, lane); ln_row_mask<NCH1>(bv, S, lane);
     ln_row_compute<NCH1>(xv, gv, bv, S, a.eps, lane, av1);
@@ -1870,6 +1868,13 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_pair(const MlpPairArgs a, floa
         { const bool hi = lane & 16; const float keep = hi ? acc[1] : acc[0], send = hi ? acc[0] : acc[1]; v = keep + WMI_SHX(send, 16); }
         v += WMI_SHX(v, 8); v += WMI_SHX(v, 4); v += WMI_SHX(v, 2); v += WMI_SHX(v, 1);
         // lanes 0 / 16 / 32 / 48 hold rows 4 gw + 0 / 1 / 2 / 3: pairs (0, 1) and (2, 3) leave as one granule each
+        const uint32_t tag = __builtin_amdgcn_readfirstlane(tag_v);
+        if (blockIdx.x == 0 && tid == 0) {
+            // the other word holds tag - 2 (or 0 before the first launch) when the launches alternated; tag or more means this parity ran twice in
+            // a row — stale granules would pass the tag test below: say so (the step is run again by the host in the two-launch form)
+            if (other_v >= tag) __hip_atomic_fetch_or(a.fault, PAIR_FAULT_PARITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.epoch[a.par ^ 1] = tag;
+        }
         const __half hv = f2h(gelu16(v + bias1));
         const uint32_t mine = (uint32_t) __half_as_ushort(hv);
         const uint32_t other = (uint32_t) WMI_SHX((int) mine, 16);
@@ -1939,6 +1944,212 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_pair(const MlpPairArgs a, floa
     stamp_end(sp.base, sp.slot, gw, ts0, tm1, tm2);
 }
 
+// ------------------------------------------------------------------------------------------------ the front of a decoder layer, one launch
+// LayerNorm + q|k|v, the self-attention over the cache and the out projection + residual of the one-row step as ONE launch with two
+// hand-offs (profiles/r06o_*: the lab measured 6.7 - 6.9 us per layer against 8.1 - 8.3 for the two launches below it replaces):
+//   phase 1 = k_gemv1<4, 1, false, 1, EPI_QKV_DEC> (3 S rows on 3 S / 32 workgroups of eight wavefronts, four rows per wavefront): q to
+//             a.q16, k / v into the cache at the step's slot — and every f16 pair as a granule {pair, tag} (k_mlp_pair's form);
+//   phase 2 = ONE wavefront per head (wavefront 0 of workgroup h) gathers its head's q, k, v (96 granules), attends over the cache with
+//             the new key's k / v taken from the granules (self_attn_body: the routine of the out projection's prologue) and publishes the
+//             head's 64 values (32 granules) — once, where the two-launch form recomputes the attention in each of its 32 workgroups;
+//   phase 3 = k_gemv1<2, 1, false, 2, EPI_F32_BIAS_RESID, 1, 8>'s projection on S / 16 of the workgroups: the attention row swept once
+//             per workgroup (S / 2 granules), weights / bias / residual requested at the start of the launch.
+// Per value the operations and their order are the two launches': bit-identical (tests/test_gpu_variants.py).  Caches of <= 64 cells
+// (the caller keeps the two launches beyond), S <= 512, one head per 64 columns.  Tags, bounded spins and the status word: k_mlp_pair's
+// (MlpPairArgs); the phase-3 store overwrites x only after every phase-1 wavefront has consumed it (it cannot gather its row before).
+__global__ __launch_bounds__(512) void k_front(const FrontArgs a, const Stamp sp) {
+    __shared__ __attribute__((aligned(16))) __half act[512];          // the attention row (phase 3)
+    __shared__ __attribute__((aligned(16))) __half hq[3 * 64];        // q, k, v of this workgroup's head (phase 2)
+    __shared__ __attribute__((aligned(16))) __half hatt[64];
+    __shared__ __attribute__((aligned(16))) float wscr[64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wg = blockIdx.x;
+    const unsigned long long ts0 = stamp_t0(sp.base);
+    const int S = a.S, K = S, H = S >> 6, N1 = 3 * S;
+    const int gw = wg * 8 + wave;
+    const bool head_wave = wg < H && wave == 0, p3 = wg < (S >> 4);
+    constexpr int LPR1 = 16, LPR3 = 32;
+    const int wrow1 = lane / LPR1, wrow3 = lane / LPR3;
+    int zl = 0; asm volatile("" : "+v"(zl));
+
+    // ---- every load of the launch that depends on nothing it computes, in one straight line (no load in a branch: DESIGN hazards 23, 35):
+    // the row, gain, bias; phase 1's weight rows and epilogue operands; phase 3's; the cached keys / values of phase 2 (the wavefronts
+    // without a head read key 0 of head 0)
+    float xv[1][8], gv[1][8], bv[1][8], av[1][8];
+    ln_row_load<1>(a.x, K, lane, xv);
+    ln_row_load<1>(a.ln_g, K, lane, gv);
+    ln_row_load<1>(a.ln_b, K, lane, bv);
+    __builtin_amdgcn_sched_barrier(0);
+    const int c8 = lane * 8, cc = c8 < K ? c8 : 0;
+    uint4 w1[4], w3[2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { int o = gw * 4 + u; if (o > N1 - 1) o = N1 - 1; w1[u] = *(const uint4 *) (a.Wqkv + (size_t) o * K + cc); }
+    float bias1, bias3, resid3; int ro_pre, nkv_pre;
+    {
+        int n = gw * 4 + wrow1; if (n > N1 - 1) n = N1 - 1;
+        bias1 = *(a.bqkv ? a.bqkv + n : (const float *) a.Wqkv);
+        ro_pre = a.kv_head[zl]; nkv_pre = a.n_kv[zl];
+    }
+    const int orow = (p3 ? gw : 0) * 2;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) w3[u] = *(const uint4 *) (a.Wo + (size_t) (orow + u) * K + cc);
+    bias3 = *(a.bo ? a.bo + orow + wrow3 : (const float *) a.Wo);
+    resid3 = a.x[orow + wrow3];
+    const int g = lane >> 3, o8 = lane & 7;
+    const int hh = head_wave ? wg : 0;
+    uint4 kv[1][8], vv[1][8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {                            // keys [0, 32) (self_attn_wave's first batch)
+        const int j = head_wave ? 8 * t + g : 0, jc = j < a.cap ? j : 0;
+        kv[0][t] = *(const uint4 *) (a.ck + (size_t) jc * K + hh * 64 + o8 * 8);
+        vv[0][t] = *(const uint4 *) (a.cv + (size_t) jc * K + hh * 64 + o8 * 8);
+    }
+    // the launch's tag (k_mlp_pair's scheme: epoch[par] + 1, this launch leaves it in epoch[par ^ 1]) — requested LAST and through a lane
+    // offset the compiler cannot fold: as a uniform load at the kernel's top it was load -> vmcnt(0) -> readfirstlane, a memory round trip
+    // in front of the row's loads (LayerNorm done at + 2.4 us instead of + 1.5)
+    const uint32_t tag_v = a.epoch[a.par + zl] + 1u, other_v = a.epoch[(a.par ^ 1) + zl];
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- phase 1
+    ln_row_mask<1>(xv, K, lane); ln_row_mask<1>(gv, K, lane); ln_row_mask<1>(bv, K, lane);
+    ln_row_compute<1>(xv, gv, bv, K, a.eps, lane, av);
+    const unsigned long long tm1 = stamp_t0(sp.base);
+    uint32_t tag;
+    {
+        float acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[u] = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const __half2 * h = (const __half2 *) &w1[u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float2 f = __half22float2(h[e]);
+                acc[u] = fmaf(f.x, av[0][2 * e], acc[u]);
+                acc[u] = fmaf(f.y, av[0][2 * e + 1], acc[u]);
+            }
+        }
+        float v;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const bool hi = lane & 32; const float keep = hi ? acc[u + 2] : acc[u], send = hi ? acc[u] : acc[u + 2]; acc[u] = keep + WMI_SHX(send, 32); }
+        { const bool hi = lane & 16; const float keep = hi ? acc[1] : acc[0], send = hi ? acc[0] : acc[1]; v = keep + WMI_SHX(send, 16); }
+        v += WMI_SHX(v, 8); v += WMI_SHX(v, 4); v += WMI_SHX(v, 2); v += WMI_SHX(v, 1);
+        // lanes 0 / 16 / 32 / 48 hold rows 4 gw + 0 .. 3
+        tag = __builtin_amdgcn_readfirstlane(tag_v);
+        if (wg == 0 && tid == 0) {
+            if (other_v >= tag) __hip_atomic_fetch_or(a.fault, PAIR_FAULT_PARITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.epoch[a.par ^ 1] = tag;
+        }
+        const int o0 = gw * 4, n = o0 + wrow1;
+        const int seg = __builtin_amdgcn_readfirstlane(o0 / S);
+        const int c = n - seg * S;
+        const float bias = a.bqkv ? bias1 : 0.0f;
+        const float val = seg == 0 ? (v + bias) * a.scale : seg == 1 ? v * a.scale : v + bias;
+        const __half hv = f2h(val);
+        const bool writer = (lane % LPR1) == 0 && n < N1;
+        if (writer) {
+            __half * dst = seg == 0 ? a.q16 : seg == 1 ? a.ck + (size_t) ro_pre * K : a.cv + (size_t) ro_pre * K;
+            dst[c] = hv;
+        }
+        const uint32_t mine = (uint32_t) __half_as_ushort(hv);
+        const uint32_t other = (uint32_t) WMI_SHX((int) mine, 16);
+        if (writer && !(wrow1 & 1) && gw + 1 != a.withhold) {
+            const unsigned long long gr = ((unsigned long long) tag << 32) | (unsigned long long) (mine | (other << 16));
+            __hip_atomic_store(a.gq + (gw * 2 + (wrow1 >> 1)), gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    const uint32_t spin_cap = a.spin_cap ? a.spin_cap : (1u << 20);
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    unsigned long long tm2 = 0;
+    // ---- phase 2: this workgroup's head, on wavefront 0
+    if (head_wave) {
+        const int h = wg;
+        // q_h: granules 32 h .. + 32 of segment 0, k_h / v_h: the same of segments 1 / 2 (S / 2 granules each); lane l < 48 takes two
+        const int part = lane >> 4;
+        const unsigned long long * src = a.gq + (lane < 48 ? part * (S >> 1) + 32 * h + (lane & 15) * 2 : 32 * h);
+        uint32_t spins = 0; bool landed = false; u32x4 q;
+        for (; spins < spin_cap; ++spins) {
+            asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q) : "v"(src) : "memory");
+            const bool ok = lane >= 48 || (q[1] == tag && q[3] == tag);
+            if (__all(ok)) { landed = true; break; }
+        }
+        if (lane == 0 && (!landed || spins > PAIR_SLOW_POLLS))
+            __hip_atomic_fetch_or(a.fault, landed ? PAIR_SLOW : PAIR_FAULT_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < 48) *(uint2 *) (hq + part * 64 + (lane & 15) * 4) = make_uint2(q[0], q[2]);
+        const int n_kv = __builtin_amdgcn_readfirstlane(nkv_pre), slot = __builtin_amdgcn_readfirstlane(ro_pre);
+        uint4 qv[1];
+        qv[0] = *(const uint4 *) (hq + o8 * 8);
+        const uint4 knew = *(const uint4 *) (hq + 64 + o8 * 8), vnew = *(const uint4 *) (hq + 128 + o8 * 8);
+        const int hs[1] = { h };
+        if (n_kv > 32) {
+#pragma unroll
+            for (int t = 4; t < 8; ++t) {
+                const int j = 8 * t + g, jc = j < n_kv ? j : 0;
+                kv[0][t] = *(const uint4 *) (a.ck + (size_t) jc * K + h * 64 + o8 * 8);
+                vv[0][t] = *(const uint4 *) (a.cv + (size_t) jc * K + h * 64 + o8 * 8);
+            }
+#pragma unroll
+            for (int t = 0; t < 8; ++t) if (8 * t + g == slot) { kv[0][t] = knew; vv[0][t] = vnew; }
+            self_attn_body<1, 8>(qv, kv, vv, n_kv, hs, H, lane, hatt - h * 64, nullptr, wscr);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) if (8 * t + g == slot) { kv[0][t] = knew; vv[0][t] = vnew; }
+#pragma unroll
+            for (int t = 4; t < 8; ++t) { kv[0][t] = make_uint4(0u, 0u, 0u, 0u); vv[0][t] = kv[0][t]; }
+            self_attn_body<1, 4>(qv, kv, vv, n_kv, hs, H, lane, hatt - h * 64, nullptr, wscr);
+        }
+        if (lane < 32) {
+            const uint32_t pr = *(const uint32_t *) (hatt + 2 * lane);
+            const unsigned long long gr = ((unsigned long long) tag << 32) | (unsigned long long) pr;
+            __hip_atomic_store(a.ga + (h * 32 + lane), gr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        tm2 = stamp_t0(sp.base);
+    }
+    // ---- phase 3: the attention row, swept once per workgroup; two rows per wavefront
+    if (p3) {
+        if (tid < (S >> 2)) {
+            const unsigned long long * src = a.ga + tid * 2;
+            uint32_t spins = 0; bool landed = false; u32x4 q;
+            for (; spins < spin_cap; ++spins) {
+                asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q) : "v"(src) : "memory");
+                const bool ok = q[1] == tag && q[3] == tag;
+                if (__all(ok)) { landed = true; break; }
+            }
+            if (lane == 0 && (!landed || spins > PAIR_SLOW_POLLS))
+                __hip_atomic_fetch_or(a.fault, landed ? PAIR_SLOW : PAIR_FAULT_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *(uint2 *) (act + tid * 4) = make_uint2(q[0], q[2]);
+        }
+        __syncthreads();
+        uint4 u4 = *(const uint4 *) (act + cc);
+        if (c8 >= K) u4 = make_uint4(0u, 0u, 0u, 0u);
+        float a3[8];
+        {
+            const __half2 * h = (const __half2 *) &u4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float2 f = __half22float2(h[e]); a3[2 * e] = f.x; a3[2 * e + 1] = f.y; }
+        }
+        float acc[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            acc[u] = 0.0f;
+            const __half2 * h = (const __half2 *) &w3[u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float2 f = __half22float2(h[e]);
+                acc[u] = fmaf(f.x, a3[2 * e], acc[u]);
+                acc[u] = fmaf(f.y, a3[2 * e + 1], acc[u]);
+            }
+        }
+        float v;
+        { const bool hi = lane & 32; const float keep = hi ? acc[1] : acc[0], send = hi ? acc[0] : acc[1]; v = keep + WMI_SHX(send, 32); }
+        v += WMI_SHX(v, 16); v += WMI_SHX(v, 8); v += WMI_SHX(v, 4); v += WMI_SHX(v, 2); v += WMI_SHX(v, 1);
+        if ((lane % LPR3) == 0) {
+            const float bias = a.bo ? bias3 : 0.0f;
+            a.xout[orow + wrow3] = (v + bias) + resid3;
+        }
+    }
+    stamp_end(sp.base, sp.slot, gw, ts0, tm1, tm2);
+}
+
 // -- the A/B switches of the launch paths: one read of the environment per process (an embedding application may call setenv on its own threads)
 static Knobs read_knobs() {
     Knobs kn{};
@@ -1950,6 +2161,8 @@ static Knobs read_knobs() {
     kn.debug_sync = getenv("WMI_DEBUG_SYNC") != nullptr;
     kn.pair_withhold = getenv("WMI_PAIR_WITHHOLD") ? atoi(getenv("WMI_PAIR_WITHHOLD")) : 0;        // tests: see MlpPairArgs::withhold
     kn.pair_spin_cap = getenv("WMI_PAIR_SPIN_CAP") ? (uint32_t) strtoul(getenv("WMI_PAIR_SPIN_CAP"), nullptr, 0) : 0u;
+    kn.no_front = getenv("WMI_NO_FRONT") != nullptr;           // LN + q|k|v, self-attention + out as two launches (k_front off)
+    kn.front_withhold = getenv("WMI_FRONT_WITHHOLD") ? atoi(getenv("WMI_FRONT_WITHHOLD")) : 0;      // tests: see FrontArgs::withhold
     return kn;
 }
 static std::atomic<const Knobs *> g_knobs{nullptr};
@@ -2021,6 +2234,25 @@ void mlp_pair(const MlpPairArgs & a, float * x_inout, hipStream_t st) {
 #undef WMI_PAIR_GO
 }
 #undef WMI_PAIR_TABLE
+
+bool front_usable(int S) {
+    // one 512-column chunk per row, one head per 64 columns, every workgroup of the launch resident at once (they wait for each other)
+    if (S > 512 || (S % 64) != 0 || S < 128) return false;
+    static std::atomic<int> cache[64];
+    int dev = 0; (void) hipGetDevice(&dev);
+    int v = cache[dev & 63].load(std::memory_order_relaxed);
+    if (v == 0) {
+        int cus = 0, nb = 0;
+        (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *) k_front, 512, 0) != hipSuccess) nb = 0;
+        v = 1 + std::max(0, (cus - 1) * std::min(nb, 1));       // one workgroup per CU is all this launch counts on, one CU left to others
+        cache[dev & 63].store(v, std::memory_order_relaxed);
+    }
+    return 3 * S / 32 <= v - 1;
+}
+void front(const FrontArgs & a, hipStream_t st) {
+    hipLaunchKernelGGL(k_front, dim3(3 * a.S / 32), dim3(512), 0, st, a, stamp_next());
+}
 
 void gemv(const GemvArgs & a, hipStream_t st) {
     const Stamp sp = stamp_next();

@@ -326,9 +326,21 @@ constexpr uint32_t PAIR_SLOW_POLLS = 64;
 // it): shape covered, and the widest launch of the step (+ 1 workgroup with the step-record mirror) resident at once on the CURRENT device
 bool mlp_pair_usable(int S, bool with_mirror);
 void mlp_pair(const MlpPairArgs & a, float * x_inout, hipStream_t st);
+// The front of a decoder layer of the one-row step as one launch (k_dec.hip: k_front): LayerNorm + q|k|v with EPI_QKV_DEC's stores, the
+// self-attention over a cache of <= 64 cells computed once per head, the out projection + residual (in place: xout = x).  gq: 3 S / 2
+// granules, ga: S / 2 granules (8 bytes each, zeroed once); epoch / par / fault / spin_cap / withhold as in MlpPairArgs (own epoch words).
+struct FrontArgs {
+    const float * x; float * xout; const float * ln_g, * ln_b; float eps; int S;
+    const __half * Wqkv; const float * bqkv; float scale; __half * q16; __half * ck, * cv;       // ck / cv: the layer's self cache [cell][S]
+    const int32_t * kv_head, * n_kv; int cap;                                                    // the step record's cache head / key count; cells in the cache
+    const __half * Wo; const float * bo;
+    unsigned long long * gq, * ga; uint32_t * epoch; int par; uint32_t * fault; uint32_t spin_cap; int withhold;
+};
+bool front_usable(int S);
+void front(const FrontArgs & a, hipStream_t st);
 // A/B switches of the launch paths that are read from the environment: once per process (reload_knobs(): lab scripts that flip them between
 // probe calls of one process, exported as wmi_reload_knobs — not while a transcription runs on another thread)
-struct Knobs { bool no_mlp_pair; int pair_wpb; int sa_wpb; bool gemv1_wide_generic; bool host_draws; bool debug_sync; int pair_withhold; uint32_t pair_spin_cap; };
+struct Knobs { bool no_mlp_pair; int pair_wpb; int sa_wpb; bool gemv1_wide_generic; bool host_draws; bool debug_sync; int pair_withhold; uint32_t pair_spin_cap; bool no_front; int front_withhold; };
 const Knobs & knobs();
 void reload_knobs();
 void set_attn_one_group(bool on);              // encoder attention: never split the keys over two wave groups (bit-identical for any batch)
