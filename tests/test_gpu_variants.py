@@ -119,6 +119,24 @@ def test_a_failed_hand_off_inside_the_mlp_launch_is_reported_and_the_step_rerun(
             assert a == b, key
 
 
+def test_a_failed_hand_off_inside_the_front_launch_is_reported_and_the_step_rerun(default_run):
+    """k_front (LN + q|k|v, self-attention, out projection as one launch) has two hand-offs of the same kind.  WMI_FRONT_WITHHOLD=6:
+    wavefront 5 of its phase 1 never publishes (rows 20..23 of q: head 0 waits in vain, and with it every consumer of the attention
+    row).  The status word is the MLP pair's: reported by the pick kernel, the step re-run in the two-launch forms, the stream unchanged."""
+    got, err = _run_pair({"WMI_FRONT_WITHHOLD": "6", "WMI_PAIR_SPIN_CAP": "3000"})
+    for key, runs in got.items():
+        if key.startswith("status:"):
+            fallbacks = [s[0] for s in runs]
+            if key.startswith("status:small"):                                     # S = 768: the launch is not used (one 512-column chunk per row)
+                assert fallbacks[-1] == 0, (key, runs)
+                continue
+            assert fallbacks[0] >= 1 and fallbacks[-1] >= 3, (key, runs)
+            assert all(s[2] & 1 for s in runs), (key, runs)
+            continue
+        for a, b in zip(default_run[key], runs):
+            assert a == b, key
+
+
 def test_a_slow_hand_off_switches_the_step_to_two_launches(default_run):
     """WMI_PAIR_WITHHOLD=-6: wavefront 5 publishes ~0.2 ms late — what a device shared with work this process cannot see looks like from
     inside the launch.  Results are the ordinary ones; the kernel reports the slow sweep and the state takes the two-launch form for a while."""
