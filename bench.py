@@ -334,8 +334,12 @@ def main():
             sbuf = (C.c_double * (6 * cap))()
             nst = lib.wmi_step_stamps(ctx, sbuf, cap, 1)
             rows = [(sbuf[6 * i], sbuf[6 * i + 2]) for i in range(max(nst, 0)) if sbuf[6 * i + 3] > 0]
+            pair_kind = ("k_mlp_pair<4>: LN + mlp.0 + GELU, in-launch hand-off of the hidden row (tagged 8-byte granules), mlp.2 + residual", Lt, 8 * S2, "k_mlp_pair")
             if len(rows) in (5 * Lt + 2, 5 * Lt + 3):        # both MLP projections in ONE launch (k_mlp_pair, round 5): five launches per layer
-                kinds = kinds[:4] + [("k_mlp_pair<4>: LN + mlp.0 + GELU, in-launch hand-off of the hidden row (tagged 8-byte granules), mlp.2 + residual", Lt, 8 * S2, "k_mlp_pair")]
+                kinds = kinds[:4] + [pair_kind]
+            elif len(rows) in (4 * Lt + 2, 4 * Lt + 3):      # + the front of the layer in ONE launch (k_front, round 6): four launches per layer
+                kinds = [("k_front: LN + q|k|v (cache write), self-attention once per head, out projection + residual; two in-launch hand-offs (tagged 8-byte granules)",
+                          Lt, 4 * S2 + 2 * nkv * hp_S * 2, "k_front")] + kinds[2:4] + [pair_kind]
             per_layer = len(kinds)
             tail = tail_fused if len(rows) == per_layer * Lt + 2 else tail_plain
             assert len(rows) == per_layer * Lt + len(tail), ("unexpected launch count of the chained step", len(rows))
