@@ -340,6 +340,11 @@ def main():
             elif len(rows) in (4 * Lt + 2, 4 * Lt + 3):      # + the front of the layer in ONE launch (k_front, round 6): four launches per layer
                 kinds = [("k_front: LN + q|k|v (cache write), self-attention once per head, out projection + residual; two in-launch hand-offs (tagged 8-byte granules)",
                           Lt, 4 * S2 + 2 * nkv * hp_S * 2, "k_front")] + kinds[2:4] + [pair_kind]
+            elif len(rows) in (3 * Lt + 2, 3 * Lt + 3):      # + the back of the cross-attention in ONE launch (k_xback, round 6): three launches per layer
+                kinds = [("k_front: LN + q|k|v (cache write), self-attention once per head, out projection + residual; two in-launch hand-offs (tagged 8-byte granules)",
+                          Lt, 4 * S2 + 2 * nkv * hp_S * 2, "k_front"),
+                         ("k_xback: LN + cross query + key slices over the cross K/V, combine once per head, out projection + residual; two in-launch hand-offs",
+                          Lt, 2 * S2 + 2 * T * hp_S * 2, "k_xback"), pair_kind]
             per_layer = len(kinds)
             tail = tail_fused if len(rows) == per_layer * Lt + 2 else tail_plain
             assert len(rows) == per_layer * Lt + len(tail), ("unexpected launch count of the chained step", len(rows))

@@ -155,8 +155,9 @@ static bool init_state_into(whisper_context & ctx, State * st, bool replica_stat
     {
         unsigned char * hand = nullptr;
         // (+ 2 S granules behind the words for the one-launch front of a layer, k::front: 3 S / 2 of q|k|v, S / 2 of the attention row)
-        ok = ok && dalloc(hand, (size_t) 32 * S + 64);
-        if (ok) { d.mlp_hand = hand; d.mlp_arrive = (unsigned long long *) (hand + (size_t) 16 * S); k::fill_zero(hand, (size_t) 32 * S + 64, d.stream); }
+        // (+ 40 KB behind those for the one-launch back of the cross-attention, k::xback: 8 heads x 8 slices x 66 granules of partials, S / 2 of the row)
+        ok = ok && dalloc(hand, (size_t) 32 * S + 64 + 40960);
+        if (ok) { d.mlp_hand = hand; d.mlp_arrive = (unsigned long long *) (hand + (size_t) 16 * S); k::fill_zero(hand, (size_t) 32 * S + 64 + 40960, d.stream); }
     }
     if (!ok) { WMI_ERR("%s: device allocation failed\n", __func__); return false; }
     // buffers that are read before being fully written must hold finite values
@@ -875,7 +876,7 @@ struct StepTicket {
 };
 }
 
-constexpr int PAIR_FAULT_WORD = 4;           // d.mlp_arrive as 32-bit words: [0], [1] the MLP launches' tags, [2], [3] the front launches', [4] the hand-offs' status (k::MlpPairArgs::fault)
+constexpr int PAIR_FAULT_WORD = 4;           // d.mlp_arrive as 32-bit words: [0], [1] the MLP launches' tags, [2], [3] the front launches', [6], [7] the cross-attention back's, [4] the hand-offs' status (k::MlpPairArgs::fault)
 static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = false, bool chained = false, bool solo = true) {
     if (ctx.model.quantised) { enqueue_greedy_step_q(ctx, Tc); return; }
     State & st = *ctx.state; DeviceState & d = st.dev; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
@@ -909,6 +910,7 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = fa
     // the same decision for the front of the layers (k::front): short caches only; its status goes through the MLP pair's word, so it
     // runs where that pair does (the pick kernel reports the word, a fault re-runs the step without either)
     const bool fronted = paired && !long_kv && (M & 2) && (M & 4) && !kn.no_front && k::front_usable(S);
+    const bool backed = paired && (M & 8) && (M & 16) && !kn.no_xback && k::xback_usable(S, H, Tc);
     for (int il = 0; il < Lt; ++il) {
         const DecLayerW & l = w.dec[il];
         __half * ck = kv.k + ((size_t) il * n_ctx) * S, * cv = kv.v + ((size_t) il * n_ctx) * S;
@@ -938,6 +940,16 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = fa
             static const bool unfused_q = getenv("WMI_XATTN_UNFUSED_Q") != nullptr;          // debug / A-B
             const float * po = nullptr, * pl = nullptr, * pm = nullptr; int ns = 0;
             if (!(M & 8)) { k::attn_cross_partials_layout(1, H, Tc, d.xattn, &po, &pl, &pm, &ns); }
+            else if (backed) {   // LN + cross query + key slices, the combine (once per head) and the out projection as ONE launch (k::xback)
+                k::XbackArgs xb{};
+                xb.x = d.dx; xb.xout = d.dx; xb.ln_g = l.ln2_g; xb.ln_b = l.ln2_b; xb.eps = hp.eps; xb.S = S; xb.wq = l.w_cq; xb.bq = l.b_cq; xb.qscale = kq_scale;
+                xb.kc = d.kvc_k + (size_t) il * Tc * S; xb.vc = d.kvc_v + (size_t) il * Tc * S; xb.T = Tc; xb.Wo = l.w_co; xb.bo = l.b_co;
+                xb.gp = (unsigned long long *) ((unsigned char *) d.mlp_hand + (size_t) 32 * S + 64); xb.ga = xb.gp + 8 * 8 * 66;
+                xb.epoch = (uint32_t *) d.mlp_arrive + 6; xb.par = il & 1; xb.fault = (uint32_t *) d.mlp_arrive + PAIR_FAULT_WORD;
+                xb.spin_cap = kn.pair_spin_cap; xb.withhold = kn.xback_withhold;
+                k::xback(xb, H, d.xattn, s); chk("cross-attn + out", il);
+                goto mlp;
+            }
             else if (unfused_q || S > 1536) {                  // the fused kernel keeps a whole row per wavefront in registers: S <= 1536
                 gv(k::EPI_Q_SCALED, l.ln2_g, l.ln2_b, nullptr, S, S, l.w_cq, l.b_cq, d.dq, S, nullptr, nullptr, nullptr, kq_scale, nullptr);
                 k::attn_cross_split_partials(d.dq, 1, S, H, d.kvc_k + (size_t) il * Tc * S, d.kvc_v + (size_t) il * Tc * S, Tc, d.xattn, &po, &pl, &pm, &ns, s);
@@ -950,6 +962,7 @@ static void enqueue_greedy_step(whisper_context & ctx, int Tc, bool long_kv = fa
             g.C = d.dx; g.ldc = S; g.resid = d.dx; g.ldr = S; g.S = S;
             if (M & 16) k::gemv(g, s);
         }
+        mlp:
         // both MLP projections as ONE launch with an in-launch hand-off of the hidden row (k::mlp_pair; WMI_NO_MLP_PAIR=1: two launches)
         if (paired) {
             k::MlpPairArgs p{};

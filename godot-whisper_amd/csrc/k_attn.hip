@@ -18,6 +18,7 @@
 
 #include "kernels.h"
 #include "wave_ops.h"
+#include "xattn_tail.h"
 #include <cstdlib>
 #include <atomic>
 
@@ -827,6 +828,225 @@ __global__ __launch_bounds__(256) void k_xattn_fused(const float * __restrict__ 
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------ the back of the cross-attention, one launch
+// LN + cross query + key slices (k_xattn_fused<1, true>), the combine of a head's slices and the out projection + residual
+// (k_gemv1<4, 1, false, 3, EPI_F32_BIAS_RESID>) of the one-row step as ONE launch with two few-reader hand-offs (k_front's pattern,
+// profiles/r06o_*): a (head, slice) workgroup publishes its partial (m, l, o[64]) as 66 granules {f32, tag}; wavefront 0 of the head's
+// slice-0 workgroup gathers the head's ns partials, combines them ONCE (the two-launch form combines in each of its 32 workgroups) and
+// publishes the head's 64 values as 32 granules {f16 pair, tag}; the first S / 16 workgroups sweep the S / 2 granules of the row and
+// take four rows of the projection per wavefront (weights requested at the start).  Per value the operations and their order are the two
+// launches'.  4 <= ns <= 8 key slices, S <= 512.  Tags, spins, status word: MlpPairArgs.  The partials still go to part_o / part_l / pmax.
+__global__ __launch_bounds__(256) void k_xback(const XbackArgs a, const Stamp sp) {
+    __shared__ float qs[64];
+    __shared__ float red[4], lred[4];
+    __shared__ float ored[4][64];
+    __shared__ __attribute__((aligned(16))) __half act[512];
+    __shared__ __attribute__((aligned(16))) __half hatt[64];
+    const unsigned long long ts0 = stamp_t0(sp.base);
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int head = blockIdx.x, slice = blockIdx.y, H = gridDim.x, ns = a.ns, S = a.S, K = S;
+    const int lin = head + H * slice;
+    const bool p3 = lin < (S >> 4), comb_wave = slice == 0 && wave == 0;
+    const XaKeys keys = xa_keys(slice, a.ks, a.T, S, head, wave, lane);
+    int zl = 0; asm volatile("" : "+v"(zl));
+
+    // ---- every load that depends on nothing this launch computes, in one straight line: the row, gain / bias, the 16 query-weight rows of
+    // this wavefront, K, V; the projection's four weight rows, bias, residual; the launch tag last (DESIGN hazards 23, 35, 36)
+    const bool on = lane * 8 < S; const int c0 = on ? lane * 8 : 0;
+    float xv[8], gv[8], bv[8];
+    {
+        const float * xr = a.x + c0;
+        const float4 x0 = *(const float4 *) xr, x1 = *(const float4 *) (xr + 4);
+        xv[0] = x0.x; xv[1] = x0.y; xv[2] = x0.z; xv[3] = x0.w; xv[4] = x1.x; xv[5] = x1.y; xv[6] = x1.z; xv[7] = x1.w;
+        const float4 g0 = *(const float4 *) (a.ln_g + c0), g1 = *(const float4 *) (a.ln_g + c0 + 4);
+        const float4 b0 = *(const float4 *) (a.ln_b + c0), b1 = *(const float4 *) (a.ln_b + c0 + 4);
+        gv[0] = g0.x; gv[1] = g0.y; gv[2] = g0.z; gv[3] = g0.w; gv[4] = g1.x; gv[5] = g1.y; gv[6] = g1.z; gv[7] = g1.w;
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    uint4 w[16];
+    const __half * wrow0 = a.wq + (size_t) (head * 64 + wave * 16) * S;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) w[u] = *(const uint4 *) (wrow0 + (size_t) u * S + c0);
+    const float bias_raw = *(a.bq ? a.bq + head * 64 + wave * 16 + ((lane >> 2) & 15) : (const float *) a.wq);
+    uint4 kk[XA_KPASS], vv[XA_KPASS];
+#pragma unroll
+    for (int p = 0; p < XA_KPASS; ++p) kk[p] = *(const uint4 *) ((const char *) a.kc + keys.off[p]);
+#pragma unroll
+    for (int p = 0; p < XA_KPASS; ++p) vv[p] = *(const uint4 *) ((const char *) a.vc + keys.off[p]);
+    const int gw3 = (p3 ? lin : 0) * 4 + wave, wrow3 = lane >> 4;
+    uint4 w3[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w3[u] = *(const uint4 *) (a.Wo + (size_t) (gw3 * 4 + u) * K + c0);
+    const float bias3 = *(a.bo ? a.bo + gw3 * 4 + wrow3 : (const float *) a.Wo);
+    const float resid3 = a.x[gw3 * 4 + wrow3];
+    const uint32_t tag_v = a.epoch[a.par + zl] + 1u, other_v = a.epoch[(a.par ^ 1) + zl];
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- LayerNorm + this head's query (k_xattn_fused<1, true>)
+    if (!on) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { xv[e] = 0.0f; gv[e] = 0.0f; bv[e] = 0.0f; }
+    }
+    float sum = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum += xv[e];
+    _Pragma("unroll") for (int x = 32; x > 0; x >>= 1) sum += WMI_SHX(sum, x);
+    const float mean = sum / (float) S;
+    float sq = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { if (on) { xv[e] -= mean; sq += xv[e] * xv[e]; } }
+    _Pragma("unroll") for (int x = 32; x > 0; x >>= 1) sq += WMI_SHX(sq, x);
+    const float scl = 1.0f / sqrtf(sq / (float) S + a.eps);
+    float av[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) av[e] = round_f16(__fadd_rn(__fmul_rn(xv[e] * scl, gv[e]), bv[e]));
+    __builtin_amdgcn_sched_barrier(0);
+    if (!on) {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) w[u] = make_uint4(0u, 0u, 0u, 0u);
+    }
+    {
+        float acc[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            float q = 0.0f;
+            const __half2 * wh = (const __half2 *) &w[u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float2 f = __half22float2(wh[e]);
+                q = fmaf(f.x, av[2 * e], q);
+                q = fmaf(f.y, av[2 * e + 1], q);
+            }
+            acc[u] = q;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { const bool hi = lane & 32; const float keep = hi ? acc[u + 8] : acc[u], send = hi ? acc[u] : acc[u + 8]; acc[u] = keep + WMI_SHX(send, 32); }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const bool hi = lane & 16; const float keep = hi ? acc[u + 4] : acc[u], send = hi ? acc[u] : acc[u + 4]; acc[u] = keep + WMI_SHX(send, 16); }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const bool hi = lane & 8; const float keep = hi ? acc[u + 2] : acc[u], send = hi ? acc[u] : acc[u + 2]; acc[u] = keep + WMI_SHX(send, 8); }
+        { const bool hi = lane & 4; const float keep = hi ? acc[1] : acc[0], send = hi ? acc[0] : acc[1]; acc[0] = keep + WMI_SHX(send, 4); }
+        acc[0] += WMI_SHX(acc[0], 2);
+        acc[0] += WMI_SHX(acc[0], 1);
+        const float bias = a.bq ? bias_raw : 0.0f;
+        if ((lane & 3) == 0) qs[wave * 16 + ((lane >> 2) & 15)] = round_f16((acc[0] + bias) * a.qscale);
+    }
+    __syncthreads();
+    const unsigned long long tm1 = stamp_t0(sp.base);
+    // ---- this workgroup's key slice (xattn_tail.h), its partial to memory as before and as 66 granules {f32, tag}
+    xa_slice_tail(qs, kk, vv, keys.ok, red, lred, ored, (size_t) head, ns, slice, a.pmax, a.part_o, a.part_l);
+    const uint32_t tag = __builtin_amdgcn_readfirstlane(tag_v);
+    if (lin == 0 && tid == 0) {
+        if (other_v >= tag) __hip_atomic_fetch_or(a.fault, PAIR_FAULT_PARITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        a.epoch[a.par ^ 1] = tag;
+    }
+    {
+        unsigned long long * gp = a.gp + (size_t) (head * ns + slice) * 66;
+        if (tid < 64 && lin + 1 != a.withhold) {
+            const float po = (ored[0][tid] + ored[1][tid]) + (ored[2][tid] + ored[3][tid]);
+            __hip_atomic_store(gp + tid, ((unsigned long long) tag << 32) | (unsigned long long) __float_as_uint(po), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid == 64) {
+            const float pl = (lred[0] + lred[1]) + (lred[2] + lred[3]);
+            __hip_atomic_store(gp + 64, ((unsigned long long) tag << 32) | (unsigned long long) __float_as_uint(pl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid == 65) {
+            const float pm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            __hip_atomic_store(gp + 65, ((unsigned long long) tag << 32) | (unsigned long long) __float_as_uint(pm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+    const uint32_t spin_cap = a.spin_cap ? a.spin_cap : (1u << 20);
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    unsigned long long tm2 = 0;
+    // ---- the head's slices combined once (k_gemv1's combine prologue: maximum of the slice maxima, w = exp(m_s - M), o and l (double) in slice order)
+    if (comb_wave) {
+        const unsigned long long * hp = a.gp + (size_t) head * ns * 66;
+        uint32_t spins = 0; bool landed = false;
+        u32x2 po[8]; u32x4 lm[8];
+        for (; spins < spin_cap; ++spins) {
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) {
+                const int sc = s2 < ns ? s2 : 0;
+                asm volatile("global_load_dwordx2 %0, %1, off sc0 sc1" : "=&v"(po[s2]) : "v"(hp + sc * 66 + lane) : "memory");
+                asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1" : "=&v"(lm[s2]) : "v"(hp + sc * 66 + 64) : "memory");
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(po[0]), "+v"(po[1]), "+v"(po[2]), "+v"(po[3]), "+v"(po[4]), "+v"(po[5]), "+v"(po[6]), "+v"(po[7]) :: "memory");
+            asm volatile("" : "+v"(lm[0]), "+v"(lm[1]), "+v"(lm[2]), "+v"(lm[3]), "+v"(lm[4]), "+v"(lm[5]), "+v"(lm[6]), "+v"(lm[7]));
+            bool ok = true;
+#pragma unroll
+            for (int s2 = 0; s2 < 8; ++s2) ok = ok && po[s2][1] == tag && lm[s2][1] == tag && lm[s2][3] == tag;
+            if (__all(ok)) { landed = true; break; }
+        }
+        if (lane == 0 && (!landed || spins > PAIR_SLOW_POLLS))
+            __hip_atomic_fetch_or(a.fault, landed ? PAIR_SLOW : PAIR_FAULT_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        float o = 0.0f, M = -INFINITY; double l = 0.0;
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) if (s2 < ns) M = fmaxf(M, __uint_as_float(lm[s2][2]));
+#pragma unroll
+        for (int s2 = 0; s2 < 8; ++s2) {
+            if (s2 < ns) {
+                const float pm = __uint_as_float(lm[s2][2]);
+                const float wgt = pm > -INFINITY ? __expf(pm - M) : 0.0f;
+                o += __uint_as_float(po[s2][0]) * wgt; l += (double) __uint_as_float(lm[s2][0]) * (double) wgt;
+            }
+        }
+        const __half hv = f2h(o * (float) (1.0 / l));
+        const uint32_t mine = (uint32_t) __half_as_ushort(hv), other = (uint32_t) WMI_SHX((int) mine, 1);
+        if (!(lane & 1))
+            __hip_atomic_store(a.ga + (head * 32 + (lane >> 1)), ((unsigned long long) tag << 32) | (unsigned long long) (mine | (other << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        (void) hatt;
+        tm2 = stamp_t0(sp.base);
+    }
+    // ---- the out projection + residual on the first S / 16 workgroups: the row swept once per workgroup, four rows per wavefront
+    if (p3) {
+        if (tid < (S >> 2)) {
+            const unsigned long long * src = a.ga + tid * 2;
+            uint32_t spins = 0; bool landed = false; u32x4 q;
+            for (; spins < spin_cap; ++spins) {
+                asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(q) : "v"(src) : "memory");
+                const bool ok = q[1] == tag && q[3] == tag;
+                if (__all(ok)) { landed = true; break; }
+            }
+            if (lane == 0 && (!landed || spins > PAIR_SLOW_POLLS))
+                __hip_atomic_fetch_or(a.fault, landed ? PAIR_SLOW : PAIR_FAULT_TIMEOUT, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            *(uint2 *) (act + tid * 4) = make_uint2(q[0], q[2]);
+        }
+        __syncthreads();
+        uint4 u4 = *(const uint4 *) (act + c0);
+        if (!on) u4 = make_uint4(0u, 0u, 0u, 0u);
+        float a3[8];
+        {
+            const __half2 * h = (const __half2 *) &u4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float2 f = __half22float2(h[e]); a3[2 * e] = f.x; a3[2 * e + 1] = f.y; }
+        }
+        float acc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            acc[u] = 0.0f;
+            const __half2 * h = (const __half2 *) &w3[u];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float2 f = __half22float2(h[e]);
+                acc[u] = fmaf(f.x, a3[2 * e], acc[u]);
+                acc[u] = fmaf(f.y, a3[2 * e + 1], acc[u]);
+            }
+        }
+        float v;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) { const bool hi = lane & 32; const float keep = hi ? acc[u + 2] : acc[u], send = hi ? acc[u] : acc[u + 2]; acc[u] = keep + WMI_SHX(send, 32); }
+        { const bool hi = lane & 16; const float keep = hi ? acc[1] : acc[0], send = hi ? acc[0] : acc[1]; v = keep + WMI_SHX(send, 16); }
+        v += WMI_SHX(v, 8); v += WMI_SHX(v, 4); v += WMI_SHX(v, 2); v += WMI_SHX(v, 1);
+        if ((lane & 15) == 0) {
+            const float bias = a.bo ? bias3 : 0.0f;
+            a.xout[gw3 * 4 + wrow3] = (v + bias) + resid3;
+        }
+    }
+    stamp_end(sp.base, sp.slot, lin * 4 + wave, ts0, tm1, tm2);
+}
+
 // weight of slice s2 when partials are relative to their own slice maximum (part_m != null), else 1
 __device__ __forceinline__ float slice_weight(const float * part_m, size_t base, int ns, int s2, float M) {
     (void) ns;
@@ -948,6 +1168,22 @@ void attn_cross_qsplit_partials(const float * x32, const float * ln_g, const flo
     const size_t smem = (((size_t) L.ks + 3) & ~(size_t) 3) * 4 + 4 * 64 * 4;
     if (!(g_xattn_probe_skip & 2))
     hipLaunchKernelGGL(k_xattn_pv, dim3(L.ns, H, n), dim3(256), smem, st, vc, S, T, L.ks, L.ns, L.sc, L.ld_sc, L.pmax, L.part_o, L.part_l, kv_row_stride);
+}
+
+bool xback_usable(int S, int H, int T) {
+    if (S > 512 || (S % 64) != 0 || H * 64 != S) return false;
+    const XLayout L = xattn_layout(1, H, T, nullptr);
+    if (!L.fused || L.ns < 4 || L.ns > 8 || !xattn_head_major()) return false;
+    static std::atomic<int> cus_cache[64];
+    int dev = 0; (void) hipGetDevice(&dev);
+    int cus = cus_cache[dev & 63].load(std::memory_order_relaxed);
+    if (cus == 0) { (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); cus_cache[dev & 63].store(cus, std::memory_order_relaxed); }
+    return H * L.ns <= cus - 1;                             // every workgroup resident at once (they wait for each other), one CU left to others
+}
+void xback(XbackArgs a, int H, float * scratch, hipStream_t st) {
+    const XLayout L = xattn_layout(1, H, a.T, scratch);
+    a.ks = L.ks; a.ns = L.ns; a.pmax = L.pmax; a.part_o = L.part_o; a.part_l = L.part_l;
+    hipLaunchKernelGGL(k_xback, dim3(H, L.ns, 1), dim3(256), 0, st, a, stamp_next());
 }
 
 size_t attn_cross_scratch_floats(int n, int H, int T) {

@@ -2163,6 +2163,8 @@ static Knobs read_knobs() {
     kn.pair_spin_cap = getenv("WMI_PAIR_SPIN_CAP") ? (uint32_t) strtoul(getenv("WMI_PAIR_SPIN_CAP"), nullptr, 0) : 0u;
     kn.no_front = getenv("WMI_NO_FRONT") != nullptr;           // LN + q|k|v, self-attention + out as two launches (k_front off)
     kn.front_withhold = getenv("WMI_FRONT_WITHHOLD") ? atoi(getenv("WMI_FRONT_WITHHOLD")) : 0;      // tests: see FrontArgs::withhold
+    kn.no_xback = getenv("WMI_NO_XBACK") != nullptr;           // cross-attention, combine + out projection as two launches (k_xback off)
+    kn.xback_withhold = getenv("WMI_XBACK_WITHHOLD") ? atoi(getenv("WMI_XBACK_WITHHOLD")) : 0;      // tests: see XbackArgs::withhold
     return kn;
 }
 static std::atomic<const Knobs *> g_knobs{nullptr};

@@ -336,11 +336,24 @@ struct FrontArgs {
     const __half * Wo; const float * bo;
     unsigned long long * gq, * ga; uint32_t * epoch; int par; uint32_t * fault; uint32_t spin_cap; int withhold;
 };
+// The back of the cross-attention of the one-row step as one launch (k_attn.hip: k_xback): LN + cross query + key slices, the combine of a
+// head's slices (once per head) and the out projection + residual (in place: xout = x).  gp: H * ns * 66 granules of partials, ga: S / 2
+// granules of the attention row (8 bytes each, zeroed once); epoch / par / fault / spin_cap / withhold as in MlpPairArgs (own epoch words).
+// ks / ns / pmax / part_o / part_l are filled in by xback() from the cross-attention's scratch layout.
+struct XbackArgs {
+    const float * x; float * xout; const float * ln_g, * ln_b; float eps; int S;
+    const __half * wq; const float * bq; float qscale; const __half * kc, * vc; int T, ks, ns;
+    float * pmax, * part_o, * part_l;
+    const __half * Wo; const float * bo;
+    unsigned long long * gp, * ga; uint32_t * epoch; int par; uint32_t * fault; uint32_t spin_cap; int withhold;
+};
+bool xback_usable(int S, int H, int T);
+void xback(XbackArgs a, int H, float * scratch, hipStream_t st);
 bool front_usable(int S);
 void front(const FrontArgs & a, hipStream_t st);
 // A/B switches of the launch paths that are read from the environment: once per process (reload_knobs(): lab scripts that flip them between
 // probe calls of one process, exported as wmi_reload_knobs — not while a transcription runs on another thread)
-struct Knobs { bool no_mlp_pair; int pair_wpb; int sa_wpb; bool gemv1_wide_generic; bool host_draws; bool debug_sync; int pair_withhold; uint32_t pair_spin_cap; bool no_front; int front_withhold; };
+struct Knobs { bool no_mlp_pair; int pair_wpb; int sa_wpb; bool gemv1_wide_generic; bool host_draws; bool debug_sync; int pair_withhold; uint32_t pair_spin_cap; bool no_front; int front_withhold; bool no_xback; int xback_withhold; };
 const Knobs & knobs();
 void reload_knobs();
 void set_attn_one_group(bool on);              // encoder attention: never split the keys over two wave groups (bit-identical for any batch)

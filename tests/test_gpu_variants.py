@@ -57,10 +57,10 @@ def default_run():
 
 
 # WMI_NO_MLP_PAIR: both MLP projections as one launch with an in-launch hand-off vs two launches; WMI_NO_FRONT: LN + q|k|v, the
-# self-attention and the out projection as one launch with two hand-offs (k_front) vs two launches; WMI_SA_WPB=4: the self-attention + out
+# self-attention and the out projection as one launch with two hand-offs (k_front) vs two launches; WMI_NO_XBACK: the cross-attention's key slices, the combine and the out projection as one launch (k_xback) vs two; WMI_SA_WPB=4: the self-attention + out
 # projection with two heads per wavefront on four wavefronts vs one head on each of eight; WMI_GEMV1_WIDE_GENERIC: the wider models' projections
 # through the run-time-dispatch kernel vs their lean instantiations
-@pytest.mark.parametrize("knob", ["WMI_NO_CHAIN", "WMI_NO_GRAPH", "WMI_NO_MLP_PAIR", "WMI_NO_FRONT", "WMI_SA_WPB=4", "WMI_GEMV1_WIDE_GENERIC"])
+@pytest.mark.parametrize("knob", ["WMI_NO_CHAIN", "WMI_NO_GRAPH", "WMI_NO_MLP_PAIR", "WMI_NO_FRONT", "WMI_NO_XBACK", "WMI_SA_WPB=4", "WMI_GEMV1_WIDE_GENERIC"])
 def test_step_forms_are_bit_identical(default_run, knob):
     other = _run({knob.split("=")[0]: knob.split("=")[1] if "=" in knob else "1"})
     for shape, runs in default_run.items():
@@ -128,6 +128,23 @@ def test_a_failed_hand_off_inside_the_front_launch_is_reported_and_the_step_reru
         if key.startswith("status:"):
             fallbacks = [s[0] for s in runs]
             if key.startswith("status:small"):                                     # S = 768: the launch is not used (one 512-column chunk per row)
+                assert fallbacks[-1] == 0, (key, runs)
+                continue
+            assert fallbacks[0] >= 1 and fallbacks[-1] >= 3, (key, runs)
+            assert all(s[2] & 1 for s in runs), (key, runs)
+            continue
+        for a, b in zip(default_run[key], runs):
+            assert a == b, key
+
+
+def test_a_failed_hand_off_inside_the_cross_attention_launch_is_reported_and_the_step_rerun(default_run):
+    """k_xback (cross-attention key slices, combine, out projection as one launch): WMI_XBACK_WITHHOLD=3 — workgroup 2 never publishes its
+    partial's values; its head's combiner gives up, so does every consumer of the row.  Reported, re-run, stream unchanged."""
+    got, err = _run_pair({"WMI_XBACK_WITHHOLD": "3", "WMI_PAIR_SPIN_CAP": "3000"})
+    for key, runs in got.items():
+        if key.startswith("status:"):
+            fallbacks = [s[0] for s in runs]
+            if key.startswith("status:small"):                                     # S = 768: the launch is not used
                 assert fallbacks[-1] == 0, (key, runs)
                 continue
             assert fallbacks[0] >= 1 and fallbacks[-1] >= 3, (key, runs)
