@@ -262,11 +262,11 @@ WHISPER_API int wmi_selftest_quant(int device, int qtype, int mode, const void *
 WHISPER_API double wmi_bench_kernel(struct whisper_context * ctx, int which, int iters);
 
 /* The A/B switches that the launch paths read from the environment (WMI_NO_MLP_PAIR, WMI_PAIR_WPB, WMI_SA_WPB, WMI_GEMV1_WIDE_GENERIC,
- * WMI_HOST_DRAWS, WMI_DEBUG_SYNC, WMI_PAIR_WITHHOLD, WMI_PAIR_SPIN_CAP, WMI_NO_FRONT, WMI_FRONT_WITHHOLD) are read ONCE per process; a lab script that flips them between
+ * WMI_HOST_DRAWS, WMI_DEBUG_SYNC, WMI_PAIR_WITHHOLD, WMI_PAIR_SPIN_CAP, WMI_NO_FRONT, WMI_FRONT_WITHHOLD, WMI_NO_XBACK, WMI_XBACK_WITHHOLD) are read ONCE per process; a lab script that flips them between
  * probe calls of one process calls this afterwards.  Not while a transcription runs on another thread. */
 WHISPER_API void wmi_reload_knobs(void);
 
-/* Status of the one-launch forms of the greedy step (k_mlp_pair, k_front: their workgroups hand rows to each other INSIDE the launch; one status word).  A
+/* Status of the one-launch forms of the greedy step (k_mlp_pair, k_front, k_xback: their workgroups hand rows to each other INSIDE the launch; one status word).  A
  * hand-off that does not complete is reported by the kernel, the step is run again in the two-launch form and the state keeps that form;
  * a slow hand-off (the device is shared with work this process does not count) switches to two launches for the next 512 steps.
  * out3 = { steps re-run, slow hand-offs seen, bit 0: the one-launch form is off for good, bit 1: off for now }.  rearm != 0 allows the
