@@ -1955,10 +1955,11 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_pair(const MlpPairArgs a, floa
 //   phase 3 = k_gemv1<2, 1, false, 2, EPI_F32_BIAS_RESID, 1, 8>'s projection on S / 16 of the workgroups: the attention row swept once
 //             per workgroup (S / 2 granules), weights / bias / residual requested at the start of the launch.
 // Per value the operations and their order are the two launches': bit-identical (tests/test_gpu_variants.py).  Caches of <= 64 cells
-// (the caller keeps the two launches beyond), S <= 512, one head per 64 columns.  Tags, bounded spins and the status word: k_mlp_pair's
+// (the caller keeps the two launches beyond), S <= 1024 (NCH chunks of 512 columns per row), one head per 64 columns.  Tags, bounded spins and the status word: k_mlp_pair's
 // (MlpPairArgs); the phase-3 store overwrites x only after every phase-1 wavefront has consumed it (it cannot gather its row before).
+template <int NCH>
 __global__ __launch_bounds__(512) void k_front(const FrontArgs a, const Stamp sp) {
-    __shared__ __attribute__((aligned(16))) __half act[512];          // the attention row (phase 3)
+    __shared__ __attribute__((aligned(16))) __half act[512 * NCH];          // the attention row (phase 3)
     __shared__ __attribute__((aligned(16))) __half hq[3 * 64];        // q, k, v of this workgroup's head (phase 2)
     __shared__ __attribute__((aligned(16))) __half hatt[64];
     __shared__ __attribute__((aligned(16))) float wscr[64];
@@ -1974,15 +1975,18 @@ __global__ __launch_bounds__(512) void k_front(const FrontArgs a, const Stamp sp
     // ---- every load of the launch that depends on nothing it computes, in one straight line (no load in a branch: DESIGN hazards 23, 35):
     // the row, gain, bias; phase 1's weight rows and epilogue operands; phase 3's; the cached keys / values of phase 2 (the wavefronts
     // without a head read key 0 of head 0)
-    float xv[1][8], gv[1][8], bv[1][8], av[1][8];
-    ln_row_load<1>(a.x, K, lane, xv);
-    ln_row_load<1>(a.ln_g, K, lane, gv);
-    ln_row_load<1>(a.ln_b, K, lane, bv);
+    float xv[NCH][8], gv[NCH][8], bv[NCH][8], av[NCH][8];
+    ln_row_load<NCH>(a.x, K, lane, xv);
+    ln_row_load<NCH>(a.ln_g, K, lane, gv);
+    ln_row_load<NCH>(a.ln_b, K, lane, bv);
     __builtin_amdgcn_sched_barrier(0);
-    const int c8 = lane * 8, cc = c8 < K ? c8 : 0;
-    uint4 w1[4], w3[2];
+    uint4 w1[NCH][4], w3[NCH][2];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) { int o = gw * 4 + u; if (o > N1 - 1) o = N1 - 1; w1[u] = *(const uint4 *) (a.Wqkv + (size_t) o * K + cc); }
+    for (int t = 0; t < NCH; ++t) {
+        const int c = lane * 8 + 512 * t, cc = c < K ? c : 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { int o = gw * 4 + u; if (o > N1 - 1) o = N1 - 1; w1[t][u] = *(const uint4 *) (a.Wqkv + (size_t) o * K + cc); }
+    }
     float bias1, bias3, resid3; int ro_pre, nkv_pre;
     {
         int n = gw * 4 + wrow1; if (n > N1 - 1) n = N1 - 1;
@@ -1991,7 +1995,11 @@ __global__ __launch_bounds__(512) void k_front(const FrontArgs a, const Stamp sp
     }
     const int orow = (p3 ? gw : 0) * 2;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) w3[u] = *(const uint4 *) (a.Wo + (size_t) (orow + u) * K + cc);
+    for (int t = 0; t < NCH; ++t) {
+        const int c = lane * 8 + 512 * t, cc = c < K ? c : 0;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) w3[t][u] = *(const uint4 *) (a.Wo + (size_t) (orow + u) * K + cc);
+    }
     bias3 = *(a.bo ? a.bo + orow + wrow3 : (const float *) a.Wo);
     resid3 = a.x[orow + wrow3];
     const int g = lane >> 3, o8 = lane & 7;
@@ -2010,8 +2018,8 @@ __global__ __launch_bounds__(512) void k_front(const FrontArgs a, const Stamp sp
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- phase 1
-    ln_row_mask<1>(xv, K, lane); ln_row_mask<1>(gv, K, lane); ln_row_mask<1>(bv, K, lane);
-    ln_row_compute<1>(xv, gv, bv, K, a.eps, lane, av);
+    ln_row_mask<NCH>(xv, K, lane); ln_row_mask<NCH>(gv, K, lane); ln_row_mask<NCH>(bv, K, lane);
+    ln_row_compute<NCH>(xv, gv, bv, K, a.eps, lane, av);
     const unsigned long long tm1 = stamp_t0(sp.base);
     uint32_t tag;
     {
@@ -2019,15 +2027,17 @@ __global__ __launch_bounds__(512) void k_front(const FrontArgs a, const Stamp sp
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc[u] = 0.0f;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const __half2 * h = (const __half2 *) &w1[u];
+        for (int t = 0; t < NCH; ++t)                          // (k_gemv1's order: chunk, then row, then element)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float2 f = __half22float2(h[e]);
-                acc[u] = fmaf(f.x, av[0][2 * e], acc[u]);
-                acc[u] = fmaf(f.y, av[0][2 * e + 1], acc[u]);
+            for (int u = 0; u < 4; ++u) {
+                const __half2 * h = (const __half2 *) &w1[t][u];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float2 f = __half22float2(h[e]);
+                    acc[u] = fmaf(f.x, av[t][2 * e], acc[u]);
+                    acc[u] = fmaf(f.y, av[t][2 * e + 1], acc[u]);
+                }
             }
-        }
         float v;
 #pragma unroll
         for (int u = 0; u < 2; ++u) { const bool hi = lane & 32; const float keep = hi ? acc[u + 2] : acc[u], send = hi ? acc[u] : acc[u + 2]; acc[u] = keep + WMI_SHX(send, 32); }
@@ -2119,26 +2129,31 @@ __global__ __launch_bounds__(512) void k_front(const FrontArgs a, const Stamp sp
             *(uint2 *) (act + tid * 4) = make_uint2(q[0], q[2]);
         }
         __syncthreads();
-        uint4 u4 = *(const uint4 *) (act + cc);
-        if (c8 >= K) u4 = make_uint4(0u, 0u, 0u, 0u);
-        float a3[8];
-        {
+        float a3[NCH][8];
+#pragma unroll
+        for (int t = 0; t < NCH; ++t) {
+            const int c = lane * 8 + 512 * t;
+            uint4 u4 = *(const uint4 *) (act + (c < K ? c : 0));
+            if (c >= K) u4 = make_uint4(0u, 0u, 0u, 0u);
             const __half2 * h = (const __half2 *) &u4;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { const float2 f = __half22float2(h[e]); a3[2 * e] = f.x; a3[2 * e + 1] = f.y; }
+            for (int e = 0; e < 4; ++e) { const float2 f = __half22float2(h[e]); a3[t][2 * e] = f.x; a3[t][2 * e + 1] = f.y; }
         }
         float acc[2];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            acc[u] = 0.0f;
-            const __half2 * h = (const __half2 *) &w3[u];
+        for (int u = 0; u < 2; ++u) acc[u] = 0.0f;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float2 f = __half22float2(h[e]);
-                acc[u] = fmaf(f.x, a3[2 * e], acc[u]);
-                acc[u] = fmaf(f.y, a3[2 * e + 1], acc[u]);
+        for (int t = 0; t < NCH; ++t)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const __half2 * h = (const __half2 *) &w3[t][u];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float2 f = __half22float2(h[e]);
+                    acc[u] = fmaf(f.x, a3[t][2 * e], acc[u]);
+                    acc[u] = fmaf(f.y, a3[t][2 * e + 1], acc[u]);
+                }
             }
-        }
         float v;
         { const bool hi = lane & 32; const float keep = hi ? acc[1] : acc[0], send = hi ? acc[0] : acc[1]; v = keep + WMI_SHX(send, 32); }
         v += WMI_SHX(v, 16); v += WMI_SHX(v, 8); v += WMI_SHX(v, 4); v += WMI_SHX(v, 2); v += WMI_SHX(v, 1);
@@ -2239,21 +2254,22 @@ void mlp_pair(const MlpPairArgs & a, float * x_inout, hipStream_t st) {
 
 bool front_usable(int S) {
     // one 512-column chunk per row, one head per 64 columns, every workgroup of the launch resident at once (they wait for each other)
-    if (S > 512 || (S % 64) != 0 || S < 128) return false;
+    if (S > 1024 || (S % 64) != 0 || S < 128) return false;
     static std::atomic<int> cache[64];
     int dev = 0; (void) hipGetDevice(&dev);
     int v = cache[dev & 63].load(std::memory_order_relaxed);
     if (v == 0) {
         int cus = 0, nb = 0;
         (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *) k_front, 512, 0) != hipSuccess) nb = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *) k_front<2>, 512, 0) != hipSuccess) nb = 0;
         v = 1 + std::max(0, (cus - 1) * std::min(nb, 1));       // one workgroup per CU is all this launch counts on, one CU left to others
         cache[dev & 63].store(v, std::memory_order_relaxed);
     }
     return 3 * S / 32 <= v - 1;
 }
 void front(const FrontArgs & a, hipStream_t st) {
-    hipLaunchKernelGGL(k_front, dim3(3 * a.S / 32), dim3(512), 0, st, a, stamp_next());
+    if (a.S <= 512) hipLaunchKernelGGL(k_front<1>, dim3(3 * a.S / 32), dim3(512), 0, st, a, stamp_next());
+    else            hipLaunchKernelGGL(k_front<2>, dim3(3 * a.S / 32), dim3(512), 0, st, a, stamp_next());
 }
 
 void gemv(const GemvArgs & a, hipStream_t st) {
