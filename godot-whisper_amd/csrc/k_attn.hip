@@ -841,7 +841,6 @@ __global__ __launch_bounds__(256) void k_xback(const XbackArgs a, const Stamp sp
     __shared__ float red[4], lred[4];
     __shared__ float ored[4][64];
     __shared__ __attribute__((aligned(16))) __half act[512];
-    __shared__ __attribute__((aligned(16))) __half hatt[64];
     const unsigned long long ts0 = stamp_t0(sp.base);
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int head = blockIdx.x, slice = blockIdx.y, H = gridDim.x, ns = a.ns, S = a.S, K = S;
@@ -996,7 +995,6 @@ __global__ __launch_bounds__(256) void k_xback(const XbackArgs a, const Stamp sp
         const uint32_t mine = (uint32_t) __half_as_ushort(hv), other = (uint32_t) WMI_SHX((int) mine, 1);
         if (!(lane & 1))
             __hip_atomic_store(a.ga + (head * 32 + (lane >> 1)), ((unsigned long long) tag << 32) | (unsigned long long) (mine | (other << 16)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        (void) hatt;
         tm2 = stamp_t0(sp.base);
     }
     // ---- the out projection + residual on the first S / 16 workgroups: the row swept once per workgroup, four rows per wavefront
