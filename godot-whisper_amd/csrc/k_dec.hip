@@ -1972,9 +1972,24 @@ __global__ __launch_bounds__(512) void k_front(const FrontArgs a, const Stamp sp
     const int wrow1 = lane / LPR1, wrow3 = lane / LPR3;
     int zl = 0; asm volatile("" : "+v"(zl));
 
-    // ---- every load of the launch that depends on nothing it computes, in one straight line (no load in a branch: DESIGN hazards 23, 35):
-    // the row, gain, bias; phase 1's weight rows and epilogue operands; phase 3's; the cached keys / values of phase 2 (the wavefronts
-    // without a head read key 0 of head 0)
+    // ---- every load of the launch that depends on nothing it computes, at the top (DESIGN hazards 23, 35): the head wavefronts' cached
+    // keys / values, then in one straight line the row, gain, bias; phase 1's weight rows and epilogue operands; phase 3's; the tag words
+    // (the head wavefronts' cached keys / values FIRST and in a branch: a conditional load is harmless to hipcc's wait counts only in front
+    //  of — older than — the loads that are waited for early (hazard 23); as unconditional dummy loads on all 384 wavefronts they stood in
+    //  the CUs' address pipes in front of the late wavefronts' rows: LayerNorm done 0.3 - 0.5 us later)
+    const int g = lane >> 3, o8 = lane & 7;
+    uint4 kv[1][8], vv[1][8];
+    if (head_wave) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {                        // keys [0, 32) (self_attn_wave's first batch)
+            const int j = 8 * t + g, jc = j < a.cap ? j : 0;
+            kv[0][t] = *(const uint4 *) (a.ck + (size_t) jc * K + wg * 64 + o8 * 8);
+            vv[0][t] = *(const uint4 *) (a.cv + (size_t) jc * K + wg * 64 + o8 * 8);
+        }
+    } else {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) { kv[0][t] = make_uint4(0u, 0u, 0u, 0u); vv[0][t] = kv[0][t]; }
+    }
     float xv[NCH][8], gv[NCH][8], bv[NCH][8], av[NCH][8];
     ln_row_load<NCH>(a.x, K, lane, xv);
     ln_row_load<NCH>(a.ln_g, K, lane, gv);
@@ -2002,15 +2017,6 @@ __global__ __launch_bounds__(512) void k_front(const FrontArgs a, const Stamp sp
     }
     bias3 = *(a.bo ? a.bo + orow + wrow3 : (const float *) a.Wo);
     resid3 = a.x[orow + wrow3];
-    const int g = lane >> 3, o8 = lane & 7;
-    const int hh = head_wave ? wg : 0;
-    uint4 kv[1][8], vv[1][8];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {                            // keys [0, 32) (self_attn_wave's first batch)
-        const int j = head_wave ? 8 * t + g : 0, jc = j < a.cap ? j : 0;
-        kv[0][t] = *(const uint4 *) (a.ck + (size_t) jc * K + hh * 64 + o8 * 8);
-        vv[0][t] = *(const uint4 *) (a.cv + (size_t) jc * K + hh * 64 + o8 * 8);
-    }
     // the launch's tag (k_mlp_pair's scheme: epoch[par] + 1, this launch leaves it in epoch[par ^ 1]) — requested LAST and through a lane
     // offset the compiler cannot fold: as a uniform load at the kernel's top it was load -> vmcnt(0) -> readfirstlane, a memory round trip
     // in front of the row's loads (LayerNorm done at + 2.4 us instead of + 1.5)
