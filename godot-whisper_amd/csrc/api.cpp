@@ -850,6 +850,11 @@ int wmi_pair_status(struct whisper_context * ctx, int32_t * out3, int rearm) {
     DeviceState & d = ctx->state->dev;
     if (out3) { out3[0] = d.pair_fallbacks; out3[1] = d.pair_slow_events; out3[2] = (d.pair_off ? 1 : 0) | (d.pair_backoff > 0 ? 2 : 0); }
     if (rearm) { d.pair_off = false; d.pair_backoff = 0; }
+    if (ctx->batch) {                                        // + the lock-step rows' one-launch front (k_front with the row on grid.y): bit 2 = off
+        BatchWork & b = *ctx->batch;
+        if (out3) { out3[0] += b.front_fallbacks; out3[2] |= b.front_off ? 4 : 0; }
+        if (rearm) { b.front_off = false; b.front_backoff = 0; }
+    }
     return 0;
 }
 

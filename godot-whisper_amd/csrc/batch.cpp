@@ -78,6 +78,7 @@ bool ensure_batch(whisper_context & ctx, int B) {
         rg = BatchWork::RowsGraph{};
     }
     w.chain_valid = false;
+    if (w.front_hand) (void) hipFree(w.front_hand);
     if (w.step_dev) (void) hipFree(w.step_dev);
     if (w.sample_dev) (void) hipFree(w.sample_dev);
     if (w.filter_scratch) (void) hipFree(w.filter_scratch);
@@ -104,6 +105,10 @@ bool ensure_batch(whisper_context & ctx, int B) {
         ok = ok && dalloc(w.aq, nb * T * 4 * S) && dalloc(w.ads, 2 * nb * T * (4 * S / 32)) && dalloc(w.att32, nb * T * S) && dalloc(w.datt32, nb * S);
         w.wq16_elems = 8 * S * S;
         ok = ok && dalloc(w.aq16, nb * T * 4 * S) && dalloc(w.wq16, w.wq16_elems);
+    }
+    if (ok && !ctx.model.quantised && S <= 1024) {
+        const size_t bytes = nb * 16 * S + 64;
+        if (HIP_OK(hipMalloc(&w.front_hand, bytes))) k::fill_zero(w.front_hand, bytes, ctx.state->dev.stream); else w.front_hand = nullptr;
     }
     ok = ok && HIP_OK(hipMalloc(&w.step_dev, nb * sizeof(k::DecStep))) && HIP_OK(hipMalloc(&w.sample_dev, nb * sizeof(k::SampleOut)))
             && HIP_OK(hipMalloc(&w.filter_scratch, k::filter_scratch_bytes(B)))
@@ -273,7 +278,19 @@ static unsigned g_rows_mask = ~0u;
 
 // chained: the step starts from what the previous step's pick kernel left on the device (see BatchWork::chain_*): no embedding
 // launch; the rest of the host's step records reaches the filters through extra workgroups of the last layer's self-attention launch
-static void enqueue_rows_step(whisper_context & ctx, int nb, bool chained = false) {
+// may this step run the front of its layers (LN + q|k|v, self-attention, out projection) as one launch per layer (k::front, rows on grid.y)?
+// Every row's cache <= 64 cells, an even layer count (the launches' tags alternate), no other transcription on the device (the launch's
+// workgroups wait for each other: all of them must be resident), no hand-off failure so far, not backing off after a slow one.
+static bool rows_fronted(whisper_context & ctx, int nb) {
+    BatchWork & b = *ctx.batch; const HParams & hp = ctx.model.hp;
+    if (ctx.model.quantised || !b.front_hand || b.front_off || b.front_backoff > 0 || (hp.n_text_layer & 1) || k::knobs().no_front) return false;
+    if (busy_transcriptions(ctx.device) > 1 || !k::front_usable(hp.n_text_state, nb)) return false;
+    const k::DecStep * hs = (const k::DecStep *) b.step_host;
+    for (int r = 0; r < nb; ++r) if (hs[r].n_kv > 64) return false;
+    return true;
+}
+
+static void enqueue_rows_step(whisper_context & ctx, int nb, bool chained = false, int fronted_in = -1) {
     if (ctx.model.quantised) { enqueue_rows_step_q(ctx, nb); return; }
     BatchWork & b = *ctx.batch; const Weights & w = ctx.w; const HParams & hp = ctx.model.hp;
     const unsigned M = g_rows_mask;
@@ -295,6 +312,9 @@ static void enqueue_rows_step(whisper_context & ctx, int nb, bool chained = fals
         glog.x32 = b.dx; glog.ln_g = w.d_ln_g; glog.ln_b = w.d_ln_b;
     }
     const bool mirror_in_logits = chained && (M & 512) && k::gemv_rows_carries_mirror(glog);
+    // the front of the layers as one launch per layer (rows_fronted; the caller decides when its graphs depend on it) — not when the
+    // step-record mirror has to ride in the last layer's self-attention launch, not for a probe of single kernel kinds
+    const bool fronted = (fronted_in < 0 ? rows_fronted(ctx, nb) : fronted_in != 0) && (M & 2) && (M & 4) && (M & 8) && (!chained || mirror_in_logits);
     if ((M & 1) && !chained) k::dec_embed_step((const k::DecStep *) b.step_host, (k::DecStep *) b.step_dev, S, w.d_te, w.d_pe, b.dx, s, nb);
     auto base = [&](int K, int N, const __half * W, const float * bias, int epi, void * C, int ldc) {
         k::GemvArgs g{};
@@ -305,6 +325,16 @@ static void enqueue_rows_step(whisper_context & ctx, int nb, bool chained = fals
     for (int il = 0; il < Lt; ++il) {
         const DecLayerW & l = w.dec[il];
         __half * ck = b.self_k + (size_t) il * n_ctx * S, * cv = b.self_v + (size_t) il * n_ctx * S;     // chunk 0; + r * cache_stride
+        if (fronted) {   // LN1 + q|k|v, the self-attention (once per head) and the out projection of every row as ONE launch (k::front, rows on grid.y)
+            k::FrontArgs f{};
+            f.x = b.dx; f.xout = b.dx; f.ln_g = l.ln1_g; f.ln_b = l.ln1_b; f.eps = hp.eps; f.S = S; f.Wqkv = l.w_qkv; f.bqkv = l.b_qkv; f.scale = kq_scale;
+            f.q16 = b.dq; f.ck = ck; f.cv = cv; f.kv_head = &stp->kv_head; f.n_kv = &stp->n_kv; f.cap = n_ctx; f.Wo = l.w_o; f.bo = l.b_o;
+            f.gq = (unsigned long long *) b.front_hand; f.ga = f.gq + 3 * S / 2;
+            uint32_t * words = (uint32_t *) ((unsigned char *) b.front_hand + (size_t) b.B * 16 * S);
+            f.epoch = words; f.par = il & 1; f.fault = words + 4; f.spin_cap = k::knobs().pair_spin_cap; f.withhold = k::knobs().front_withhold;
+            f.cache_row_stride = cache_stride; f.step_stride = step_stride; f.rows = nb;
+            k::front(f, s);
+        } else {
         {   // LN1 + q | k -> cache | v -> cache
             k::GemvArgs g = base(S, 3 * S, l.w_qkv, l.b_qkv, k::EPI_QKV_DEC, b.dq, S);
             g.x32 = b.dx; g.ln_g = l.ln1_g; g.ln_b = l.ln1_b; g.aux = ck; g.ldaux = S; g.aux2 = cv; g.ldaux2 = S; g.scale = kq_scale;
@@ -327,6 +357,7 @@ static void enqueue_rows_step(whisper_context & ctx, int nb, bool chained = fals
                 g.a16 = b.datt;
                 if (M & 8) k::gemv(g, s);
             }
+        }
         }
         {   // LN2 + cross query (folded into the score kernel) + cross-attention partials over each row's own chunk
             const float * po = nullptr, * pl = nullptr, * pm = nullptr; int ns = 0;
@@ -363,7 +394,8 @@ static void enqueue_rows_step(whisper_context & ctx, int nb, bool chained = fals
         if (M & 512) k::gemv(g, s);
     }
     // the picks also prepare the next step on the device (row r: token = pick, position / cache head + 1, x[r] = te[pick] + pe[pos + 1])
-    const k::ChainNext cn{ (k::DecStep *) b.step_dev, w.d_te, w.d_pe, b.dx, S, n_ctx };
+    const k::ChainNext cn{ (k::DecStep *) b.step_dev, w.d_te, w.d_pe, b.dx, S, n_ctx,
+                           fronted ? (const uint32_t *) ((const unsigned char *) b.front_hand + (size_t) b.B * 16 * S) + 4 : nullptr };
     if (M & 1024) k::filter_argmax(b.logits, ctx.state->dev.ban_dev, stp, (k::SampleOut *) b.sample_dev, b.filter_scratch, s,
                                    (k::SampleOut *) b.sample_host, nb, S <= 1536 ? &cn : nullptr);
 }
@@ -384,7 +416,9 @@ bool decode_rows_step(whisper_context & ctx, int nb) {
             chained = b.chain_row_ok[r] && hs[r].token == b.chain_token[r] && hs[r].pos == b.chain_pos[r] && hs[r].kv_head == b.chain_pos[r] &&
                       hs[r].n_kv == b.chain_pos[r] + 1;
         b.chain_valid = false; b.n_chained += chained ? 1 : 0;
-        BatchWork::RowsGraph & rg = b.rows_graph[chained ? 1 : 0];
+        if (b.front_backoff > 0) --b.front_backoff;
+        const bool fronted = rows_fronted(ctx, nb);
+        BatchWork::RowsGraph & rg = b.rows_graph[(chained ? 1 : 0) | (fronted ? 2 : 0)];
         // the key includes the epoch of the run-time kernel switches (wmi_set_lockstep_exact: VALU rows / one-group attention):
         // a step captured under the other mode would keep replaying that mode's kernels
         const int epoch = k::mode_epoch();
@@ -394,11 +428,11 @@ bool decode_rows_step(whisper_context & ctx, int nb) {
             rg = BatchWork::RowsGraph{}; rg.nb = nb; rg.T = b.enc_T; rg.rows = b.enc_rows; rg.epoch = epoch;
         }
         ++rg.seen;                                                // (counted over both forms: the embedding form runs once per window)
-        const BatchWork::RowsGraph & og = b.rows_graph[chained ? 0 : 1];
+        const BatchWork::RowsGraph & og = b.rows_graph[(chained ? 0 : 1) | (fronted ? 2 : 0)];
         const int seen_other = (og.nb == nb && og.T == b.enc_T && og.rows == b.enc_rows && og.epoch == epoch) ? og.seen : 0;
         if (use_graph && !rg.exec && !rg.failed && rg.seen + seen_other > 24) {
             if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                enqueue_rows_step(ctx, nb, chained);
+                enqueue_rows_step(ctx, nb, chained, fronted ? 1 : 0);
                 hipGraph_t g = nullptr;
                 if (hipStreamEndCapture(s, &g) == hipSuccess && g && hipGraphInstantiate(&rg.exec, g, nullptr, nullptr, 0) == hipSuccess) rg.graph = g;
                 else {
@@ -411,12 +445,28 @@ bool decode_rows_step(whisper_context & ctx, int nb) {
             } else rg.failed = true;
         }
         if (use_graph && rg.exec) HIP_TRY(hipGraphLaunch(rg.exec, s));
-        else enqueue_rows_step(ctx, nb, chained);
+        else enqueue_rows_step(ctx, nb, chained, fronted ? 1 : 0);
     }
     {   // every row's result carries the step's sequence number (set by the caller in the step records)
         const k::DecStep * hs = (const k::DecStep *) b.step_host;
         const k::SampleOut * so = (const k::SampleOut *) b.sample_host;
-        for (int r = 0; r < nb; ++r) if (!wait_for_sample(&so[r], hs[r].seq, s)) return false;
+        int32_t status_all = 0;
+        for (int r = 0; r < nb; ++r) { int32_t st1 = 0; if (!wait_for_sample(&so[r], hs[r].seq, s, &st1)) return false; status_all |= st1; }
+        if (status_all & (k::SAMPLE_TAG_FAULT | k::SAMPLE_TAG_SLOW)) {
+            uint32_t * word = (uint32_t *) ((unsigned char *) b.front_hand + (size_t) b.B * 16 * ctx.model.hp.n_text_state) + 4;
+            HIP_TRY(hipMemsetAsync(word, 0, sizeof(uint32_t), s));
+            if (status_all & k::SAMPLE_TAG_FAULT) {
+                // a hand-off inside a k_front launch did not complete: this step's rows are not to be trusted.  The step is run again from the
+                // host's records in the two-launch form (embedding launch: every cache cell and device-side record rewritten), which the batch keeps
+                if (!b.front_off) WMI_WARN("%s: in-launch hand-off of a layer's front failed (status %#x) - step re-run, staying on the two-launch form\n", __func__, (unsigned) status_all);
+                b.front_off = true; ++b.front_fallbacks;
+                ++b.step_seq;
+                k::DecStep * hw = (k::DecStep *) b.step_host;
+                for (int r = 0; r < nb; ++r) hw[r].seq = b.step_seq;
+                enqueue_rows_step(ctx, nb, false, 0);
+                for (int r = 0; r < nb; ++r) { int32_t st1 = 0; if (!wait_for_sample(&so[r], hs[r].seq, s, &st1) || (st1 & k::SAMPLE_TAG_FAULT)) { WMI_ERR("%s: the step's re-run failed\n", __func__); return false; } }
+            } else b.front_backoff = 512;                        // a slow sweep: something else owns part of the device — two launches for a while
+        }
         // what the pick kernel has left on the device for the next step (k_filter_pick prepares rows of <= 3 x 512 columns)
         const HParams & hp = ctx.model.hp;
         b.chain_valid = !ctx.model.quantised && hp.n_text_state <= 1536 && nb <= 16; b.chain_nb = nb;
@@ -532,6 +582,7 @@ void free_batch(whisper_context & ctx) {
         if (rg.graph) (void) hipGraphDestroy(rg.graph);
         rg = BatchWork::RowsGraph{};
     }
+    if (w.front_hand) (void) hipFree(w.front_hand);
     if (w.step_dev) (void) hipFree(w.step_dev);
     if (w.sample_dev) (void) hipFree(w.sample_dev);
     if (w.filter_scratch) (void) hipFree(w.filter_scratch);

@@ -1958,7 +1958,16 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_pair(const MlpPairArgs a, floa
 // (the caller keeps the two launches beyond), S <= 1024 (NCH chunks of 512 columns per row), one head per 64 columns.  Tags, bounded spins and the status word: k_mlp_pair's
 // (MlpPairArgs); the phase-3 store overwrites x only after every phase-1 wavefront has consumed it (it cannot gather its row before).
 template <int NCH>
-__global__ __launch_bounds__(512) void k_front(const FrontArgs a, const Stamp sp) {
+__global__ __launch_bounds__(512) void k_front(const FrontArgs a_in, const Stamp sp) {
+    // lock-step rows: row y is a one-row problem of its own (k_gemv1's convention): shift the per-row operands, everything below is the one-row kernel
+    FrontArgs a = a_in;
+    {
+        const int y = blockIdx.y;
+        a.x += (size_t) y * a.S; a.xout += (size_t) y * a.S; a.q16 += (size_t) y * a.S;
+        a.ck += (int64_t) y * a.cache_row_stride; a.cv += (int64_t) y * a.cache_row_stride;
+        a.kv_head += (size_t) y * a.step_stride; a.n_kv += (size_t) y * a.step_stride;
+        a.gq += (size_t) y * 2 * a.S; a.ga += (size_t) y * 2 * a.S;
+    }
     __shared__ __attribute__((aligned(16))) __half act[512 * NCH];          // the attention row (phase 3)
     __shared__ __attribute__((aligned(16))) __half hq[3 * 64];        // q, k, v of this workgroup's head (phase 2)
     __shared__ __attribute__((aligned(16))) __half hatt[64];
@@ -2051,7 +2060,7 @@ __global__ __launch_bounds__(512) void k_front(const FrontArgs a, const Stamp sp
         v += WMI_SHX(v, 8); v += WMI_SHX(v, 4); v += WMI_SHX(v, 2); v += WMI_SHX(v, 1);
         // lanes 0 / 16 / 32 / 48 hold rows 4 gw + 0 .. 3
         tag = __builtin_amdgcn_readfirstlane(tag_v);
-        if (wg == 0 && tid == 0) {
+        if (wg == 0 && blockIdx.y == 0 && tid == 0) {
             if (other_v >= tag) __hip_atomic_fetch_or(a.fault, PAIR_FAULT_PARITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             a.epoch[a.par ^ 1] = tag;
         }
@@ -2168,7 +2177,7 @@ __global__ __launch_bounds__(512) void k_front(const FrontArgs a, const Stamp sp
             a.xout[orow + wrow3] = (v + bias) + resid3;
         }
     }
-    stamp_end(sp.base, sp.slot, gw, ts0, tm1, tm2);
+    stamp_end(sp.base, sp.slot, (int) blockIdx.y * (int) gridDim.x * 8 + gw, ts0, tm1, tm2);
 }
 
 // -- the A/B switches of the launch paths: one read of the environment per process (an embedding application may call setenv on its own threads)
@@ -2258,24 +2267,27 @@ void mlp_pair(const MlpPairArgs & a, float * x_inout, hipStream_t st) {
 }
 #undef WMI_PAIR_TABLE
 
-bool front_usable(int S) {
-    // one 512-column chunk per row, one head per 64 columns, every workgroup of the launch resident at once (they wait for each other)
+bool front_usable(int S, int rows) {
+    // <= two 512-column chunks per row, one head per 64 columns, every workgroup of the launch resident at once (they wait for each other)
     if (S > 1024 || (S % 64) != 0 || S < 128) return false;
-    static std::atomic<int> cache[64];
+    static std::atomic<int> cache[64][2];
     int dev = 0; (void) hipGetDevice(&dev);
-    int v = cache[dev & 63].load(std::memory_order_relaxed);
+    const int wide = S > 512 ? 1 : 0;
+    int v = cache[dev & 63][wide].load(std::memory_order_relaxed);
     if (v == 0) {
         int cus = 0, nb = 0;
         (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *) k_front<2>, 512, 0) != hipSuccess) nb = 0;
-        v = 1 + std::max(0, (cus - 1) * std::min(nb, 1));       // one workgroup per CU is all this launch counts on, one CU left to others
-        cache[dev & 63].store(v, std::memory_order_relaxed);
+        const void * fn = wide ? (const void *) k_front<2> : (const void *) k_front<1>;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 512, 0) != hipSuccess) nb = 0;
+        v = 1 + std::max(0, (cus - 1) * std::min(nb, 2));       // workgroups resident at once, one CU left to others (two per CU at most counted)
+        cache[dev & 63][wide].store(v, std::memory_order_relaxed);
     }
-    return 3 * S / 32 <= v - 1;
+    return (3 * S / 32) * std::max(rows, 1) <= v - 1;
 }
 void front(const FrontArgs & a, hipStream_t st) {
-    if (a.S <= 512) hipLaunchKernelGGL(k_front<1>, dim3(3 * a.S / 32), dim3(512), 0, st, a, stamp_next());
-    else            hipLaunchKernelGGL(k_front<2>, dim3(3 * a.S / 32), dim3(512), 0, st, a, stamp_next());
+    const dim3 grid(3 * a.S / 32, a.rows > 1 ? a.rows : 1);
+    if (a.S <= 512) hipLaunchKernelGGL(k_front<1>, grid, dim3(512), 0, st, a, stamp_next());
+    else            hipLaunchKernelGGL(k_front<2>, grid, dim3(512), 0, st, a, stamp_next());
 }
 
 void gemv(const GemvArgs & a, hipStream_t st) {

@@ -335,6 +335,9 @@ struct FrontArgs {
     const int32_t * kv_head, * n_kv; int cap;                                                    // the step record's cache head / key count; cells in the cache
     const __half * Wo; const float * bo;
     unsigned long long * gq, * ga; uint32_t * epoch; int par; uint32_t * fault; uint32_t spin_cap; int withhold;
+    // lock-step rows (grid.y = row): row y has its own activation row (x + y S), q16 row, self cache (+ y cache_row_stride), step record
+    // (+ y step_stride words) and granules (+ y 2 S); rows = 0 / 1: one row
+    int64_t cache_row_stride; int step_stride; int rows;
 };
 // The back of the cross-attention of the one-row step as one launch (k_attn.hip: k_xback): LN + cross query + key slices, the combine of a
 // head's slices (once per head) and the out projection + residual (in place: xout = x).  gp: H * ns * 66 granules of partials, ga: S / 2
@@ -349,7 +352,7 @@ struct XbackArgs {
 };
 bool xback_usable(int S, int H, int T);
 void xback(XbackArgs a, int H, float * scratch, hipStream_t st);
-bool front_usable(int S);
+bool front_usable(int S, int rows = 1);
 void front(const FrontArgs & a, hipStream_t st);
 // A/B switches of the launch paths that are read from the environment: once per process (reload_knobs(): lab scripts that flip them between
 // probe calls of one process, exported as wmi_reload_knobs — not while a transcription runs on another thread)

@@ -298,11 +298,14 @@ struct BatchWork {
     int8_t * aq = nullptr; float * ads = nullptr; int aq_rows = 0; float * att32 = nullptr, * datt32 = nullptr;
     __half * aq16 = nullptr, * wq16 = nullptr; size_t wq16_elems = 0;  // as DeviceState's
     void   * step_dev = nullptr, * step_host = nullptr, * sample_dev = nullptr, * sample_host = nullptr, * filter_scratch = nullptr;
+    // granules of the one-launch front of a layer for lock-step rows (k::front, rows on grid.y): [B][2 S] granules, then 16 words
+    // ([0], [1] the launches' tags, [4] the hand-offs' status); front_off: a hand-off failed once, the two launches from then on
+    void   * front_hand = nullptr; bool front_off = false; int front_fallbacks = 0, front_backoff = 0;
     int      enc_rows = 0, enc_T = 0;                         // chunk rows / encoder length of the last batched encode
     int32_t  step_seq = 0;                                    // sequence number of the last lock-step decode step
     // the lock-step step as a captured graph, keyed by what its launches depend on (rows, encoder length, chunk rows of the cross
     // cache); eager until the same key has been decoded for a while (capture + instantiate cost more than a window's steps)
-    struct RowsGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int nb = -1, T = -1, rows = -1, epoch = -1, seen = 0; bool failed = false; } rows_graph[2];   // [chained]
+    struct RowsGraph { hipGraph_t graph = nullptr; hipGraphExec_t exec = nullptr; int nb = -1, T = -1, rows = -1, epoch = -1, seen = 0; bool failed = false; } rows_graph[4];   // [chained + 2 * fronted (the front of the layers as one launch, k::front)]
     // chained steps: the pick kernel of a step leaves every row's next token, position and cache head in step_dev and the next
     // activation row in dx (as the one-row greedy step does, DeviceState::chain_*); a step whose host records say the same for
     // every row starts without the embedding launch (which reads the records over PCIe in front of everything else)

@@ -269,8 +269,9 @@ WHISPER_API void wmi_reload_knobs(void);
 /* Status of the one-launch forms of the greedy step (k_mlp_pair, k_front, k_xback: their workgroups hand rows to each other INSIDE the launch; one status word).  A
  * hand-off that does not complete is reported by the kernel, the step is run again in the two-launch form and the state keeps that form;
  * a slow hand-off (the device is shared with work this process does not count) switches to two launches for the next 512 steps.
- * out3 = { steps re-run, slow hand-offs seen, bit 0: the one-launch form is off for good, bit 1: off for now }.  rearm != 0 allows the
- * one-launch form again (tests).  Returns 0, -1 without a context / state.  Reference behaviour matched: a decode either succeeds or
+ * out3 = { steps re-run, slow hand-offs seen, bit 0: the one-launch form is off for good, bit 1: off for now, bit 2: the lock-step rows'
+ * one-launch front (k_front with the row on grid.y, wmi_full_batch) is off; its re-run steps are counted in out3[0] }.  rearm != 0 allows the
+ * one-launch forms again (tests).  Returns 0, -1 without a context / state.  Reference behaviour matched: a decode either succeeds or
  * reports, W/whisper.cpp:2517-2595. */
 WHISPER_API int wmi_pair_status(struct whisper_context * ctx, int32_t * out3, int rearm);
 

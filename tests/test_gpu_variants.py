@@ -288,6 +288,9 @@ for shape in ("base.en", "micro"):
         res = node.transcribe_batch(pcms, params=p)
         runs.append([[[int(t["id"]), int(t["tid"]), float(t["p"]), float(t["plog"]), int(t["t0"]), int(t["t1"])] for t in r[1:]] for r in res])
     out[shape] = runs
+    import ctypes as C
+    st = (C.c_int32 * 3)(); lib.wmi_pair_status(node.ctx, st, 0)
+    out["_status:" + shape] = list(st)
     node.close()
 print("RESULT" + json.dumps(out))
 """.replace("ROOT_PLACEHOLDER", repr(ROOT))
@@ -305,8 +308,31 @@ def test_chained_lockstep_steps_are_bit_identical():
         return json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1][len("RESULT"):])
     a, b = run({}), run({"WMI_NO_CHAIN": "1"})
     for shape in a:
+        if shape.startswith("_"): continue
         assert sum(len(c) > 0 for c in a[shape][0]) >= 6, shape
         assert a[shape] == b[shape], shape
+
+
+def test_lockstep_front_of_the_layers_as_one_launch_is_bit_identical_and_reports_a_failed_hand_off():
+    """Lock-step rows run the front of every decoder layer (LN + q|k|v, self-attention, out projection) as ONE launch with the row on
+    grid.y (k_front) while every row's cache holds <= 64 cells; WMI_NO_FRONT=1 keeps the launches apart.  Same bits.  With a granule
+    withheld (WMI_FRONT_WITHHOLD) the hand-off's failure is reported through the pick kernel's tags, the step re-run in the two-launch
+    form and the results are still the same (micro: long windows, caches pass 64 cells mid-call: both forms within one call)."""
+    def run(env_extra):
+        env = dict(os.environ); env.update(env_extra)
+        r = subprocess.run([sys.executable, "-c", _RAGGED_BATCH_SCRIPT], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        return json.loads([l for l in r.stdout.splitlines() if l.startswith("RESULT")][-1][len("RESULT"):]), r.stderr
+    (a, _), (b, _), (c, err) = run({}), run({"WMI_NO_FRONT": "1"}), run({"WMI_FRONT_WITHHOLD": "6", "WMI_PAIR_SPIN_CAP": "3000"})
+    for shape in a:
+        if shape.startswith("_"):
+            assert a[shape][0] == 0 and b[shape][0] == 0, (shape, a[shape], b[shape])       # nothing re-run
+            if shape == "_status:base.en":                                                 # (micro has an odd layer count: never fronted)
+                assert c[shape][0] >= 1 and (c[shape][2] & 4), (shape, c[shape])             # the failed hand-off was seen, the form is off
+            continue
+        assert sum(len(x) > 0 for x in a[shape][0]) >= 6, shape
+        assert a[shape] == b[shape], shape
+        assert a[shape] == c[shape], shape
 
 
 # ------------------------------------------------------------------------------------------------ quantised projections: the two forms
