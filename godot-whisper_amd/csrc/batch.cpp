@@ -107,7 +107,7 @@ bool ensure_batch(whisper_context & ctx, int B) {
         ok = ok && dalloc(w.aq16, nb * T * 4 * S) && dalloc(w.wq16, w.wq16_elems);
     }
     if (ok && !ctx.model.quantised && S <= 1024) {
-        const size_t bytes = nb * 16 * S + 64;
+        const size_t bytes = nb * 16 * S + 64 + nb * (size_t) k::XBACK_ROW_GRANULES * 8;      // + the rows' cross-attention back (k::xback)
         if (HIP_OK(hipMalloc(&w.front_hand, bytes))) k::fill_zero(w.front_hand, bytes, ctx.state->dev.stream); else w.front_hand = nullptr;
     }
     ok = ok && HIP_OK(hipMalloc(&w.step_dev, nb * sizeof(k::DecStep))) && HIP_OK(hipMalloc(&w.sample_dev, nb * sizeof(k::SampleOut)))
@@ -315,6 +315,8 @@ static void enqueue_rows_step(whisper_context & ctx, int nb, bool chained = fals
     // the front of the layers as one launch per layer (rows_fronted; the caller decides when its graphs depend on it) — not when the
     // step-record mirror has to ride in the last layer's self-attention launch, not for a probe of single kernel kinds
     const bool fronted = (fronted_in < 0 ? rows_fronted(ctx, nb) : fronted_in != 0) && (M & 2) && (M & 4) && (M & 8) && (!chained || mirror_in_logits);
+    // ... and the back of the cross-attention the same way where its launch fits (k::xback_usable: 4 - 8 key slices, S <= 512, residency)
+    const bool backed = fronted && (M & 16) && (M & 64) && !k::knobs().no_xback && k::xback_usable(S, H, Tc, nb);
     if ((M & 1) && !chained) k::dec_embed_step((const k::DecStep *) b.step_host, (k::DecStep *) b.step_dev, S, w.d_te, w.d_pe, b.dx, s, nb);
     auto base = [&](int K, int N, const __half * W, const float * bias, int epi, void * C, int ldc) {
         k::GemvArgs g{};
@@ -368,6 +370,17 @@ static void enqueue_rows_step(whisper_context & ctx, int nb, bool chained = fals
                 k::gemv(g, s);
                 k::attn_cross_split_partials(b.dq, nb, S, H, b.kvc_k + (size_t) il * cross_layer, b.kvc_v + (size_t) il * cross_layer, Tc,
                                              b.xattn, &po, &pl, &pm, &ns, s, (int64_t) Tc * S);
+            } else if (backed) {   // LN2 + cross query + key slices, the combine (once per head) and the out projection of every row as ONE launch (k::xback, rows on grid.z)
+                k::XbackArgs xb{};
+                xb.x = b.dx; xb.xout = b.dx; xb.ln_g = l.ln2_g; xb.ln_b = l.ln2_b; xb.eps = hp.eps; xb.S = S; xb.wq = l.w_cq; xb.bq = l.b_cq; xb.qscale = kq_scale;
+                xb.kc = b.kvc_k + (size_t) il * cross_layer; xb.vc = b.kvc_v + (size_t) il * cross_layer; xb.T = Tc; xb.Wo = l.w_co; xb.bo = l.b_co;
+                unsigned char * base = (unsigned char *) b.front_hand + (size_t) b.B * 16 * S;
+                xb.gp = (unsigned long long *) (base + 64); xb.ga = xb.gp + 8 * 8 * 66;
+                xb.epoch = (uint32_t *) base + 6; xb.par = il & 1; xb.fault = (uint32_t *) base + 4;
+                xb.spin_cap = k::knobs().pair_spin_cap; xb.withhold = k::knobs().xback_withhold;
+                xb.kv_row_stride = (int64_t) Tc * S; xb.rows = nb;
+                k::xback(xb, H, b.xattn, s);
+                goto mlp_rows;
             } else
             k::attn_cross_qsplit_partials(b.dx, l.ln2_g, l.ln2_b, hp.eps, l.w_cq, l.b_cq, kq_scale, nb, S, H,
                                           b.kvc_k + (size_t) il * cross_layer, b.kvc_v + (size_t) il * cross_layer, Tc,
@@ -377,6 +390,7 @@ static void enqueue_rows_step(whisper_context & ctx, int nb, bool chained = fals
             g.comb_o = po; g.comb_l = pl; g.comb_m = pm; g.comb_ns = ns; g.resid = b.dx;
             if (M & 64) k::gemv(g, s);
         }
+        mlp_rows:
         {
             k::GemvArgs g = base(S, 4 * S, l.w_fc1, l.b_fc1, k::EPI_F16_BIAS_GELU, b.dh, 4 * S);
             g.x32 = b.dx; g.ln_g = l.ln3_g; g.ln_b = l.ln3_b;

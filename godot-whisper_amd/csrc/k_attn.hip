@@ -836,7 +836,15 @@ __global__ __launch_bounds__(256) void k_xattn_fused(const float * __restrict__ 
 // publishes the head's 64 values as 32 granules {f16 pair, tag}; the first S / 16 workgroups sweep the S / 2 granules of the row and
 // take four rows of the projection per wavefront (weights requested at the start).  Per value the operations and their order are the two
 // launches'.  4 <= ns <= 8 key slices, S <= 512.  Tags, spins, status word: MlpPairArgs.  The partials still go to part_o / part_l / pmax.
-__global__ __launch_bounds__(256) void k_xback(const XbackArgs a, const Stamp sp) {
+__global__ __launch_bounds__(256) void k_xback(const XbackArgs a_in, const Stamp sp) {
+    // lock-step rows: row z is a one-row problem of its own: shift the per-row operands, everything below is the one-row kernel
+    XbackArgs a = a_in;
+    {
+        const int z = blockIdx.z;
+        a.x += (size_t) z * a.S; a.xout += (size_t) z * a.S;
+        a.kc += (int64_t) z * a.kv_row_stride; a.vc += (int64_t) z * a.kv_row_stride;
+        a.gp += (size_t) z * XBACK_ROW_GRANULES; a.ga += (size_t) z * XBACK_ROW_GRANULES;
+    }
     __shared__ float qs[64];
     __shared__ float red[4], lred[4];
     __shared__ float ored[4][64];
@@ -874,11 +882,6 @@ __global__ __launch_bounds__(256) void k_xback(const XbackArgs a, const Stamp sp
 #pragma unroll
     for (int p = 0; p < XA_KPASS; ++p) vv[p] = *(const uint4 *) ((const char *) a.vc + keys.off[p]);
     const int gw3 = (p3 ? lin : 0) * 4 + wave, wrow3 = lane >> 4;
-    uint4 w3[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) w3[u] = *(const uint4 *) (a.Wo + (size_t) (gw3 * 4 + u) * K + c0);
-    const float bias3 = *(a.bo ? a.bo + gw3 * 4 + wrow3 : (const float *) a.Wo);
-    const float resid3 = a.x[gw3 * 4 + wrow3];
     const uint32_t tag_v = a.epoch[a.par + zl] + 1u, other_v = a.epoch[(a.par ^ 1) + zl];
     __builtin_amdgcn_sched_barrier(0);
 
@@ -931,12 +934,20 @@ __global__ __launch_bounds__(256) void k_xback(const XbackArgs a, const Stamp sp
         const float bias = a.bq ? bias_raw : 0.0f;
         if ((lane & 3) == 0) qs[wave * 16 + ((lane >> 2) & 15)] = round_f16((acc[0] + bias) * a.qscale);
     }
+    // the projection's weight rows, bias and residual go out here, where the query's 16 weight rows have left their registers (3 us before
+    // their use; 168 registers = three wavefronts per SIMD: lock-step rows need 64 x rows workgroups resident at once).  The residual is
+    // read before this workgroup has published anything: no projection of this launch can have overwritten x yet
+    uint4 w3[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) w3[u] = *(const uint4 *) (a.Wo + (size_t) (gw3 * 4 + u) * K + c0);
+    const float bias3 = *(a.bo ? a.bo + gw3 * 4 + wrow3 : (const float *) a.Wo);
+    const float resid3 = a.x[gw3 * 4 + wrow3];
     __syncthreads();
     const unsigned long long tm1 = stamp_t0(sp.base);
     // ---- this workgroup's key slice (xattn_tail.h), its partial to memory as before and as 66 granules {f32, tag}
-    xa_slice_tail(qs, kk, vv, keys.ok, red, lred, ored, (size_t) head, ns, slice, a.pmax, a.part_o, a.part_l);
+    xa_slice_tail(qs, kk, vv, keys.ok, red, lred, ored, (size_t) blockIdx.z * H + head, ns, slice, a.pmax, a.part_o, a.part_l);
     const uint32_t tag = __builtin_amdgcn_readfirstlane(tag_v);
-    if (lin == 0 && tid == 0) {
+    if (lin == 0 && blockIdx.z == 0 && tid == 0) {
         if (other_v >= tag) __hip_atomic_fetch_or(a.fault, PAIR_FAULT_PARITY, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         a.epoch[a.par ^ 1] = tag;
     }
@@ -1042,7 +1053,7 @@ __global__ __launch_bounds__(256) void k_xback(const XbackArgs a, const Stamp sp
             a.xout[gw3 * 4 + wrow3] = (v + bias) + resid3;
         }
     }
-    stamp_end(sp.base, sp.slot, lin * 4 + wave, ts0, tm1, tm2);
+    stamp_end(sp.base, sp.slot, ((int) blockIdx.z * (int) gridDim.x * (int) gridDim.y + lin) * 4 + wave, ts0, tm1, tm2);
 }
 
 // weight of slice s2 when partials are relative to their own slice maximum (part_m != null), else 1
@@ -1168,20 +1179,27 @@ void attn_cross_qsplit_partials(const float * x32, const float * ln_g, const flo
     hipLaunchKernelGGL(k_xattn_pv, dim3(L.ns, H, n), dim3(256), smem, st, vc, S, T, L.ks, L.ns, L.sc, L.ld_sc, L.pmax, L.part_o, L.part_l, kv_row_stride);
 }
 
-bool xback_usable(int S, int H, int T) {
+bool xback_usable(int S, int H, int T, int rows) {
     if (S > 512 || (S % 64) != 0 || H * 64 != S) return false;
     const XLayout L = xattn_layout(1, H, T, nullptr);
     if (!L.fused || L.ns < 4 || L.ns > 8 || !xattn_head_major()) return false;
-    static std::atomic<int> cus_cache[64];
+    static std::atomic<int> cache[64];
     int dev = 0; (void) hipGetDevice(&dev);
-    int cus = cus_cache[dev & 63].load(std::memory_order_relaxed);
-    if (cus == 0) { (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); cus_cache[dev & 63].store(cus, std::memory_order_relaxed); }
-    return H * L.ns <= cus - 1;                             // every workgroup resident at once (they wait for each other), one CU left to others
+    int v = cache[dev & 63].load(std::memory_order_relaxed);
+    if (v == 0) {
+        int cus = 0, nb = 0;
+        (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, (const void *) k_xback, 256, 0) != hipSuccess) nb = 0;
+        v = 1 + std::max(0, (cus - 1) * std::min(nb, 3));       // workgroups resident at once (they wait for each other), one CU left to others
+        cache[dev & 63].store(v, std::memory_order_relaxed);
+    }
+    return H * L.ns * std::max(rows, 1) <= v - 1;
 }
 void xback(XbackArgs a, int H, float * scratch, hipStream_t st) {
-    const XLayout L = xattn_layout(1, H, a.T, scratch);
+    const int n = a.rows > 1 ? a.rows : 1;
+    const XLayout L = xattn_layout(n, H, a.T, scratch);
     a.ks = L.ks; a.ns = L.ns; a.pmax = L.pmax; a.part_o = L.part_o; a.part_l = L.part_l;
-    hipLaunchKernelGGL(k_xback, dim3(H, L.ns, 1), dim3(256), 0, st, a, stamp_next());
+    hipLaunchKernelGGL(k_xback, dim3(H, L.ns, n), dim3(256), 0, st, a, stamp_next());
 }
 
 size_t attn_cross_scratch_floats(int n, int H, int T) {

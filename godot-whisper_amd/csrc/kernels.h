@@ -349,8 +349,12 @@ struct XbackArgs {
     float * pmax, * part_o, * part_l;
     const __half * Wo; const float * bo;
     unsigned long long * gp, * ga; uint32_t * epoch; int par; uint32_t * fault; uint32_t spin_cap; int withhold;
+    // lock-step rows (grid.z = row): row z has its own activation row (x + z S), cross cache (+ z kv_row_stride) and granules
+    // (+ z XBACK_ROW_GRANULES); rows = 0 / 1: one row
+    int64_t kv_row_stride; int rows;
 };
-bool xback_usable(int S, int H, int T);
+constexpr int XBACK_ROW_GRANULES = 8 * 8 * 66 + 256;        // a row's partials (<= 8 heads x 8 slices x 66) + its attention row (S / 2 <= 256)
+bool xback_usable(int S, int H, int T, int rows = 1);
 void xback(XbackArgs a, int H, float * scratch, hipStream_t st);
 bool front_usable(int S, int rows = 1);
 void front(const FrontArgs & a, hipStream_t st);
