@@ -856,18 +856,27 @@ int busy_transcriptions(int device) { return g_busy_transcriptions[device & 63].
 // multiplexes streams onto few hardware queues (DESIGN hazard 21) — so two turns: 1.3 - 1.7 x one transcription at a time, for every N.
 // WMI_STEP_SLOTS = 1 is round 5's form.  Not a fair queue: whoever gets a free turn next is as good as anyone for throughput, and a fair
 // ticket's next holder may be a descheduled thread.
+// The second turn is for steps of the SAME context only (states of one context share one copy of the weights): with separate contexts side
+// by side two turns are worse than one — 3 contexts x 150 transcriptions 8.2 - 8.4 ms per transcription against 3.8 with one turn
+// (scratch/stress_pair.py) — while N states of one context gain from the second (table above).
 namespace {
-struct StepSlots { std::atomic<int> used{0}; };
+struct StepSlots { std::atomic<int> used{0}; std::atomic<const void *> owner{nullptr}; };
 StepSlots g_step_slots[64];
 struct StepTicket {
     StepSlots * sl = nullptr;
-    StepTicket(int device, bool take) {
+    StepTicket(int device, bool take, const void * ctx) {
         if (!take) return;
         static const int cap = getenv("WMI_STEP_SLOTS") ? std::max(1, atoi(getenv("WMI_STEP_SLOTS"))) : 2;
         StepSlots & s = g_step_slots[device & 63];
         for (uint32_t it = 0;; ++it) {
-            int u = s.used.load(std::memory_order_relaxed);
-            if (u < cap && s.used.compare_exchange_weak(u, u + 1, std::memory_order_acquire)) { sl = &s; return; }
+            int u = s.used.load(std::memory_order_acquire);
+            if (u == 0) {
+                if (s.used.compare_exchange_weak(u, 1, std::memory_order_acquire)) { s.owner.store(ctx, std::memory_order_release); sl = &s; return; }
+            } else if (u < cap && s.owner.load(std::memory_order_acquire) == ctx) {
+                // (the owner word is written just behind the 0 -> 1 transition: a step that reads the previous owner in that window runs beside
+                //  another context's step once — slower, not wrong)
+                if (s.used.compare_exchange_weak(u, u + 1, std::memory_order_acquire)) { sl = &s; return; }
+            }
             if ((it & 1023) == 1023) std::this_thread::yield(); else __builtin_ia32_pause();      // (a holder is ~150 us from releasing)
         }
     }
@@ -1089,7 +1098,7 @@ bool decode_greedy_step(whisper_context & ctx, int32_t token, int32_t pos, const
     // launch to its sample whenever another device call is in flight; alone, nothing is taken (StepTicket above has the measurements).
     // (WMI_NO_STEP_TICKET=1: off.  The general decode() path — beam search, t > 0 — has host work between its steps: no ticket.)
     static const bool no_ticket = getenv("WMI_NO_STEP_TICKET") != nullptr;
-    StepTicket ticket(ctx.device, !no_ticket && !solo);
+    StepTicket ticket(ctx.device, !no_ticket && !solo, &ctx);
     if (use_graph && exec) {
         HIP_TRY(hipGraphLaunch(exec, s));
     } else {
