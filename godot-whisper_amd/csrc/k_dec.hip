@@ -1957,8 +1957,10 @@ __global__ __launch_bounds__(64 * WPB) void k_mlp_pair(const MlpPairArgs a, floa
 // Per value the operations and their order are the two launches': bit-identical (tests/test_gpu_variants.py).  Caches of <= 64 cells
 // (the caller keeps the two launches beyond), S <= 1024 (NCH chunks of 512 columns per row), one head per 64 columns.  Tags, bounded spins and the status word: k_mlp_pair's
 // (MlpPairArgs); the phase-3 store overwrites x only after every phase-1 wavefront has consumed it (it cannot gather its row before).
-template <int NCH>
-__global__ __launch_bounds__(512) void k_front(const FrontArgs a_in, const Stamp sp) {
+// WPB wavefronts per workgroup: 8 (3 S / 32 workgroups, phase 3 with two rows per wavefront) or 4 (3 S / 16 workgroups, four rows per
+// wavefront: k_gemv1<4, ...>'s halving sum, the same bits) — S / 16 workgroups sweep the attention row either way
+template <int NCH, int WPB>
+__global__ __launch_bounds__(64 * WPB) void k_front(const FrontArgs a_in, const Stamp sp) {
     // lock-step rows: row y is a one-row problem of its own (k_gemv1's convention): shift the per-row operands, everything below is the one-row kernel
     FrontArgs a = a_in;
     {
@@ -1975,9 +1977,10 @@ __global__ __launch_bounds__(512) void k_front(const FrontArgs a_in, const Stamp
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), wg = blockIdx.x;
     const unsigned long long ts0 = stamp_t0(sp.base);
     const int S = a.S, K = S, H = S >> 6, N1 = 3 * S;
-    const int gw = wg * 8 + wave;
+    const int gw = wg * WPB + wave;
+    constexpr int R3 = WPB == 8 ? 2 : 4;                    // rows of the out projection per wavefront
     const bool head_wave = wg < H && wave == 0, p3 = wg < (S >> 4);
-    constexpr int LPR1 = 16, LPR3 = 32;
+    constexpr int LPR1 = 16, LPR3 = 64 / R3;
     const int wrow1 = lane / LPR1, wrow3 = lane / LPR3;
     int zl = 0; asm volatile("" : "+v"(zl));
 
@@ -2004,7 +2007,7 @@ __global__ __launch_bounds__(512) void k_front(const FrontArgs a_in, const Stamp
     ln_row_load<NCH>(a.ln_g, K, lane, gv);
     ln_row_load<NCH>(a.ln_b, K, lane, bv);
     __builtin_amdgcn_sched_barrier(0);
-    uint4 w1[NCH][4], w3[NCH][2];
+    uint4 w1[NCH][4], w3[NCH][R3];
 #pragma unroll
     for (int t = 0; t < NCH; ++t) {
         const int c = lane * 8 + 512 * t, cc = c < K ? c : 0;
@@ -2017,12 +2020,12 @@ __global__ __launch_bounds__(512) void k_front(const FrontArgs a_in, const Stamp
         bias1 = *(a.bqkv ? a.bqkv + n : (const float *) a.Wqkv);
         ro_pre = a.kv_head[zl]; nkv_pre = a.n_kv[zl];
     }
-    const int orow = (p3 ? gw : 0) * 2;
+    const int orow = (p3 ? gw : 0) * R3;
 #pragma unroll
     for (int t = 0; t < NCH; ++t) {
         const int c = lane * 8 + 512 * t, cc = c < K ? c : 0;
 #pragma unroll
-        for (int u = 0; u < 2; ++u) w3[t][u] = *(const uint4 *) (a.Wo + (size_t) (orow + u) * K + cc);
+        for (int u = 0; u < R3; ++u) w3[t][u] = *(const uint4 *) (a.Wo + (size_t) (orow + u) * K + cc);
     }
     bias3 = *(a.bo ? a.bo + orow + wrow3 : (const float *) a.Wo);
     resid3 = a.x[orow + wrow3];
@@ -2154,13 +2157,13 @@ __global__ __launch_bounds__(512) void k_front(const FrontArgs a_in, const Stamp
 #pragma unroll
             for (int e = 0; e < 4; ++e) { const float2 f = __half22float2(h[e]); a3[t][2 * e] = f.x; a3[t][2 * e + 1] = f.y; }
         }
-        float acc[2];
+        float acc[R3];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) acc[u] = 0.0f;
+        for (int u = 0; u < R3; ++u) acc[u] = 0.0f;
 #pragma unroll
         for (int t = 0; t < NCH; ++t)
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
+            for (int u = 0; u < R3; ++u) {
                 const __half2 * h = (const __half2 *) &w3[t][u];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -2170,14 +2173,21 @@ __global__ __launch_bounds__(512) void k_front(const FrontArgs a_in, const Stamp
                 }
             }
         float v;
-        { const bool hi = lane & 32; const float keep = hi ? acc[1] : acc[0], send = hi ? acc[0] : acc[1]; v = keep + WMI_SHX(send, 32); }
-        v += WMI_SHX(v, 16); v += WMI_SHX(v, 8); v += WMI_SHX(v, 4); v += WMI_SHX(v, 2); v += WMI_SHX(v, 1);
+        if constexpr (R3 == 2) {
+            { const bool hi = lane & 32; const float keep = hi ? acc[1] : acc[0], send = hi ? acc[0] : acc[1]; v = keep + WMI_SHX(send, 32); }
+            v += WMI_SHX(v, 16); v += WMI_SHX(v, 8); v += WMI_SHX(v, 4); v += WMI_SHX(v, 2); v += WMI_SHX(v, 1);
+        } else {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) { const bool hi = lane & 32; const float keep = hi ? acc[u + 2] : acc[u], send = hi ? acc[u] : acc[u + 2]; acc[u] = keep + WMI_SHX(send, 32); }
+            { const bool hi = lane & 16; const float keep = hi ? acc[1] : acc[0], send = hi ? acc[0] : acc[1]; v = keep + WMI_SHX(send, 16); }
+            v += WMI_SHX(v, 8); v += WMI_SHX(v, 4); v += WMI_SHX(v, 2); v += WMI_SHX(v, 1);
+        }
         if ((lane % LPR3) == 0) {
             const float bias = a.bo ? bias3 : 0.0f;
             a.xout[orow + wrow3] = (v + bias) + resid3;
         }
     }
-    stamp_end(sp.base, sp.slot, (int) blockIdx.y * (int) gridDim.x * 8 + gw, ts0, tm1, tm2);
+    stamp_end(sp.base, sp.slot, (int) blockIdx.y * (int) gridDim.x * WPB + gw, ts0, tm1, tm2);
 }
 
 // -- the A/B switches of the launch paths: one read of the environment per process (an embedding application may call setenv on its own threads)
@@ -2193,6 +2203,7 @@ static Knobs read_knobs() {
     kn.pair_spin_cap = getenv("WMI_PAIR_SPIN_CAP") ? (uint32_t) strtoul(getenv("WMI_PAIR_SPIN_CAP"), nullptr, 0) : 0u;
     kn.no_front = getenv("WMI_NO_FRONT") != nullptr;           // LN + q|k|v, self-attention + out as two launches (k_front off)
     kn.front_withhold = getenv("WMI_FRONT_WITHHOLD") ? atoi(getenv("WMI_FRONT_WITHHOLD")) : 0;      // tests: see FrontArgs::withhold
+    kn.front_wpb = getenv("WMI_FRONT_WPB") ? atoi(getenv("WMI_FRONT_WPB")) : 4;      // wavefronts per workgroup of the one-row k_front (8: A/B)
     kn.no_xback = getenv("WMI_NO_XBACK") != nullptr;           // cross-attention, combine + out projection as two launches (k_xback off)
     kn.xback_withhold = getenv("WMI_XBACK_WITHHOLD") ? atoi(getenv("WMI_XBACK_WITHHOLD")) : 0;      // tests: see XbackArgs::withhold
     return kn;
@@ -2267,27 +2278,37 @@ void mlp_pair(const MlpPairArgs & a, float * x_inout, hipStream_t st) {
 }
 #undef WMI_PAIR_TABLE
 
+// wavefronts per workgroup: four for one row (eight-wavefront workgroups get going ~0.7 us later: LayerNorm done + 2.1 - 2.3 us against
+// + 1.9 - 2.0, decode 141.2 -> 137.5 us per token), eight for lock-step rows (half as many workgroups to keep resident; measured with eight)
+static int front_wpb(int rows) { return rows > 1 ? 8 : (knobs().front_wpb == 8 ? 8 : 4); }
 bool front_usable(int S, int rows) {
     // <= two 512-column chunks per row, one head per 64 columns, every workgroup of the launch resident at once (they wait for each other)
     if (S > 1024 || (S % 64) != 0 || S < 128) return false;
-    static std::atomic<int> cache[64][2];
+    static std::atomic<int> cache[64][2][2];
     int dev = 0; (void) hipGetDevice(&dev);
-    const int wide = S > 512 ? 1 : 0;
-    int v = cache[dev & 63][wide].load(std::memory_order_relaxed);
+    const int wide = S > 512 ? 1 : 0, wpb = front_wpb(rows), w8 = wpb == 8 ? 1 : 0;
+    int v = cache[dev & 63][wide][w8].load(std::memory_order_relaxed);
     if (v == 0) {
         int cus = 0, nb = 0;
         (void) hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-        const void * fn = wide ? (const void *) k_front<2> : (const void *) k_front<1>;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 512, 0) != hipSuccess) nb = 0;
+        const void * fn = wpb == 4 ? (wide ? (const void *) k_front<2, 4> : (const void *) k_front<1, 4>) : (wide ? (const void *) k_front<2, 8> : (const void *) k_front<1, 8>);
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 64 * wpb, 0) != hipSuccess) nb = 0;
         v = 1 + std::max(0, (cus - 1) * std::min(nb, 2));       // workgroups resident at once, one CU left to others (two per CU at most counted)
-        cache[dev & 63][wide].store(v, std::memory_order_relaxed);
+        cache[dev & 63][wide][w8].store(v, std::memory_order_relaxed);
     }
-    return (3 * S / 32) * std::max(rows, 1) <= v - 1;
+    return (3 * S / (wpb == 4 ? 16 : 32)) * std::max(rows, 1) <= v - 1;
 }
 void front(const FrontArgs & a, hipStream_t st) {
-    const dim3 grid(3 * a.S / 32, a.rows > 1 ? a.rows : 1);
-    if (a.S <= 512) hipLaunchKernelGGL(k_front<1>, grid, dim3(512), 0, st, a, stamp_next());
-    else            hipLaunchKernelGGL(k_front<2>, grid, dim3(512), 0, st, a, stamp_next());
+    const int rows = a.rows > 1 ? a.rows : 1;
+    if (front_wpb(rows) == 4) {
+        const dim3 grid(3 * a.S / 16, rows);
+        if (a.S <= 512) hipLaunchKernelGGL((k_front<1, 4>), grid, dim3(256), 0, st, a, stamp_next());
+        else            hipLaunchKernelGGL((k_front<2, 4>), grid, dim3(256), 0, st, a, stamp_next());
+    } else {
+        const dim3 grid(3 * a.S / 32, rows);
+        if (a.S <= 512) hipLaunchKernelGGL((k_front<1, 8>), grid, dim3(512), 0, st, a, stamp_next());
+        else            hipLaunchKernelGGL((k_front<2, 8>), grid, dim3(512), 0, st, a, stamp_next());
+    }
 }
 
 void gemv(const GemvArgs & a, hipStream_t st) {

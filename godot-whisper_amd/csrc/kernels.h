@@ -360,7 +360,7 @@ bool front_usable(int S, int rows = 1);
 void front(const FrontArgs & a, hipStream_t st);
 // A/B switches of the launch paths that are read from the environment: once per process (reload_knobs(): lab scripts that flip them between
 // probe calls of one process, exported as wmi_reload_knobs — not while a transcription runs on another thread)
-struct Knobs { bool no_mlp_pair; int pair_wpb; int sa_wpb; bool gemv1_wide_generic; bool host_draws; bool debug_sync; int pair_withhold; uint32_t pair_spin_cap; bool no_front; int front_withhold; bool no_xback; int xback_withhold; };
+struct Knobs { bool no_mlp_pair; int pair_wpb; int sa_wpb; bool gemv1_wide_generic; bool host_draws; bool debug_sync; int pair_withhold; uint32_t pair_spin_cap; bool no_front; int front_withhold; bool no_xback; int xback_withhold; int front_wpb; };
 const Knobs & knobs();
 void reload_knobs();
 void set_attn_one_group(bool on);              // encoder attention: never split the keys over two wave groups (bit-identical for any batch)

@@ -60,7 +60,7 @@ def default_run():
 # self-attention and the out projection as one launch with two hand-offs (k_front) vs two launches; WMI_NO_XBACK: the cross-attention's key slices, the combine and the out projection as one launch (k_xback) vs two; WMI_SA_WPB=4: the self-attention + out
 # projection with two heads per wavefront on four wavefronts vs one head on each of eight; WMI_GEMV1_WIDE_GENERIC: the wider models' projections
 # through the run-time-dispatch kernel vs their lean instantiations
-@pytest.mark.parametrize("knob", ["WMI_NO_CHAIN", "WMI_NO_GRAPH", "WMI_NO_MLP_PAIR", "WMI_NO_FRONT", "WMI_NO_XBACK", "WMI_SA_WPB=4", "WMI_GEMV1_WIDE_GENERIC"])
+@pytest.mark.parametrize("knob", ["WMI_NO_CHAIN", "WMI_NO_GRAPH", "WMI_NO_MLP_PAIR", "WMI_NO_FRONT", "WMI_FRONT_WPB=8", "WMI_NO_XBACK", "WMI_SA_WPB=4", "WMI_GEMV1_WIDE_GENERIC"])
 def test_step_forms_are_bit_identical(default_run, knob):
     other = _run({knob.split("=")[0]: knob.split("=")[1] if "=" in knob else "1"})
     for shape, runs in default_run.items():
